@@ -1,0 +1,100 @@
+/*
+ * kmers_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C, step-for-step restatement of the k-mer iteration hot path of
+ * BioJulia/Kmers.jl v1.2.0 (pure Julia; cannot run in this image: no julia).
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference checkout).  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library; the product library
+ * (kmers.jl_amd/csrc) never links or calls it.
+ *
+ * Parity pin: checked against every absolute known-answer vector the
+ * reference's own tests/docstrings hold for this path (tests/golden/kats.json,
+ * groups G1..G12 of SURVEY.md section 8c).  One fact is pinned only structurally
+ * (no absolute KAT in the reference): the LongSequence word order of the
+ * absent third-party dependency BioSequences.jl (compat ~3.4.1/3.5,
+ * BioSymbols 5.1.3): symbol i (1-based) occupies bits [((i-1)*bps) mod 64, +bps)
+ * of data[((i-1)*bps) div 64] -- evidenced by src/construction.jl:213-219 and
+ * :289-324.  The reference itself cannot be built here (oracle/_ref absent:
+ * Julia source, no toolchain).
+ */
+#ifndef KMERS_ORACLE_H
+#define KMERS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_N 8 /* words per kmer supported by the oracle (K <= 256 2-bit) */
+
+#define ORC_OK 0
+#define ORC_E_ENCODE 1 /* BioSequences.EncodeError: src/construction.jl:108-110 */
+#define ORC_E_BADARG 2
+
+typedef struct {
+    uint64_t n_out;   /* elements yielded before iteration stopped or threw */
+    int32_t status;   /* ORC_OK / ORC_E_ENCODE / ORC_E_BADARG */
+    uint32_t err_enc; /* raw source encoding of the offending symbol */
+    uint64_t err_pos; /* 1-based index of the offending symbol */
+} orc_result;
+
+/* ---- geometry: src/kmer.jl:97-152, :603-605 ---- */
+int orc_n_coding_elements(int K, int bps);
+int orc_bits_unused(int K, int bps);
+int orc_elements_in_head(int K, int bps);
+uint64_t orc_get_mask(int K, int bps);
+
+/* ---- tuple shifts: src/tuple_bitflipping.jl:3-50 ---- */
+uint64_t orc_leftshift_carry(uint64_t *x, int N, int64_t nbits, uint64_t carry);
+uint64_t orc_rightshift_carry(uint64_t *x, int N, int64_t nbits, uint64_t carry);
+
+/* ---- single-kmer primitives (kmer = N words, head word first) ---- */
+void orc_shift_encoding(uint64_t *kmer, int K, int bps, uint64_t enc);       /* src/construction_utils.jl:129-134 */
+void orc_shift_first_encoding(uint64_t *kmer, int K, int bps, uint64_t enc); /* src/kmer.jl:511-518 */
+int orc_unsafe_extract(const uint64_t *seq, int src_bps, int dst_bps, int K, uint64_t from,
+                       uint64_t *out, orc_result *res); /* src/construction_utils.jl:27-69 */
+int orc_unsafe_shift_from(const uint64_t *seq, int src_bps, int dst_bps, int K, uint64_t from,
+                          int S, uint64_t *kmer, orc_result *res); /* src/construction_utils.jl:175-218 */
+void orc_reverse(const uint64_t *in, int K, int bps, uint64_t *out);            /* src/transformations.jl:1-10 */
+void orc_complement(const uint64_t *in, int K, int bps, uint64_t *out);         /* src/transformations.jl:14-25 */
+void orc_reverse_complement(const uint64_t *in, int K, int bps, uint64_t *out); /* src/transformations.jl:32-34 */
+void orc_canonical_kmer(const uint64_t *in, int K, int bps, uint64_t *out);     /* src/transformations.jl:36-39 */
+int orc_iscanonical(const uint64_t *in, int K, int bps);                        /* src/transformations.jl:41 */
+int orc_cmp(const uint64_t *x, const uint64_t *y, int N);                       /* src/kmer.jl:176-178 */
+uint64_t orc_fx_hash(const uint64_t *kmer, int N, uint64_t h);                  /* src/kmer.jl:255-261 */
+int orc_as_integer(const uint64_t *kmer, int K, int bps, uint64_t *hi, uint64_t *lo);   /* src/kmer.jl:305-326 */
+int orc_from_integer(uint64_t hi, uint64_t lo, int K, int bps, uint64_t *out);          /* src/kmer.jl:361-384 */
+int orc_kmer_from_longseq(const uint64_t *seq, uint64_t len, int K, int bps, uint64_t *out); /* src/construction.jl:213-219 */
+void orc_longseq_from_kmer(const uint64_t *kmer, int K, int bps, uint64_t *data);            /* src/construction.jl:289-324 */
+
+/* ---- iterators (bulk form: run the reference's iterate() loop to the end) ----
+ * seq = LongSequence.data (little-endian symbol packing), len = symbols.
+ * Outputs are arrays of Kmer structs (N words each, head first), nullable.
+ * On EncodeError: res->n_out elements were yielded before the throw.       */
+int orc_fw_kmers(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, int K,
+                 uint64_t *out, orc_result *res); /* src/iterators/FwKmers.jl:57-115 */
+int orc_fwrv(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, int K,
+             uint64_t *out_fw, uint64_t *out_rv, orc_result *res); /* src/iterators/CanonicalKmers.jl:54-144 */
+int orc_canonical(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, int K,
+                  uint64_t *out_kmers, uint64_t *out_hashes, uint64_t seed,
+                  orc_result *res); /* src/iterators/CanonicalKmers.jl:220-225 (+ src/kmer.jl:255-261) */
+int orc_unambiguous(const uint64_t *seq, uint64_t len, int src_bps, int K,
+                    uint64_t *out_kmers, int64_t *out_starts, orc_result *res); /* src/iterators/UnambiguousKmers.jl:59-148 */
+int orc_spaced(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, int K, int J,
+               uint64_t *out, orc_result *res); /* src/iterators/SpacedKmers.jl:83-139 */
+
+/* XOR-reduce consumer of test/benchmark.jl:9-15 over CanonicalKmers / FwKmers */
+uint64_t orc_reduce_xor_canonical(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, int K,
+                                  orc_result *res);
+
+/* ---- synthetic input (the build's own generator) ---- */
+uint64_t orc_synth_rand64(uint64_t seed, uint64_t idx);
+void orc_synth_words(uint64_t seed, uint64_t first_word, uint64_t n_words, int bps,
+                     uint32_t ambig_per_65536, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
