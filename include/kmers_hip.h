@@ -1,0 +1,162 @@
+/*
+ * kmers_hip.h -- C ABI of libkmers_hip.so, the MI355X (gfx950) implementation of the
+ * k-mer iteration hot path of BioJulia/Kmers.jl v1.2.0.
+ *
+ * The reference has no FFI: its boundary is Julia's iteration protocol over
+ * `FwKmers` / `FwRvIterator` / `CanonicalKmers` / `UnambiguousKmers` / `SpacedKmers`
+ * plus `fx_hash`, `canonical`, `reverse_complement`.  Each entry point below is the
+ * bulk form ("run iterate() to the end and collect") of one of those, with plain
+ * pointers and sizes only; the Julia `@ccall` shim that binds them is shown in
+ * INTEGRATION.md and julia/KmersHIP.jl.  file:line citations are relative to the
+ * reference checkout.
+ *
+ * Data formats (bit-identical to the reference):
+ *   input  = LongSequence.data :: Vector{UInt64}, symbol i (1-based) at bits
+ *            [((i-1)*bps) mod 64, +bps) of word ((i-1)*bps) div 64   (bps = 2 or 4)
+ *   output = Vector{Kmer{A,K,N}} memory: N = cld(K*bps_dst, 64) UInt64 per element,
+ *            data[1] first, first symbol in the most significant used bits, unused
+ *            bits = top bits of data[1] = 0                        (src/kmer.jl:32-44)
+ *
+ * Errors never cross the ABI as exceptions: every call returns a status and fills
+ * a kmers_result.  KMERS_E_ENCODE carries what the Julia shim needs to
+ * `throw(BioSequences.EncodeError(A(), reinterpret(DNA, enc)))` exactly like
+ * src/construction.jl:108-110: the 1-based position of the FIRST offending symbol
+ * in sequence order and its raw 4-bit encoding.  On E_ENCODE the output buffers
+ * are unspecified (the bulk form cannot "yield some, then throw").
+ *
+ * There is NO CPU fallback in this library: without a usable HIP device every
+ * compute entry point returns KMERS_E_HIP.
+ */
+#ifndef KMERS_HIP_H
+#define KMERS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMERS_ABI_VERSION 1
+
+/* status codes */
+#define KMERS_OK 0
+#define KMERS_E_ENCODE 1      /* BioSequences.EncodeError (src/construction.jl:108-110) */
+#define KMERS_E_BADARG 2      /* error("K must be at least 1") etc. (FwKmers.jl:31-35, SpacedKmers.jl:26-32) */
+#define KMERS_E_HIP 3         /* HIP runtime failure / no device */
+#define KMERS_E_NOMEM 4
+#define KMERS_E_UNSUPPORTED 5 /* geometry outside what the kernels cover (see kmers_supported) */
+#define KMERS_E_CAPACITY 6    /* kmers_unambiguous: output capacity too small (res->n_out = needed) */
+
+/* flags */
+#define KMERS_MEM_HOST 0x0   /* sequence/output pointers are host memory (staged through HBM) */
+#define KMERS_MEM_DEVICE 0x1 /* sequence/output pointers are device (HBM) memory              */
+#define KMERS_ASYNC 0x2      /* device memory only: enqueue and return; collect status with kmers_sync */
+
+typedef struct kmers_ctx kmers_ctx; /* one per host thread / HIP stream; not thread-safe */
+
+typedef struct {
+    int32_t status;   /* KMERS_OK or KMERS_E_* */
+    uint32_t err_enc; /* E_ENCODE: raw source encoding of the offending symbol */
+    uint64_t err_pos; /* E_ENCODE: 1-based index (index_origin added) of the offending symbol */
+    uint64_t n_out;   /* elements written */
+} kmers_result;
+
+/* A borrowed view of a LongSequence (never mutated, never retained past the call:
+ * FwKmers.jl:28-30).  first_base lets a LongSubSeq or a halo shard start inside
+ * words[0]; index_origin is added to every reported 1-based position (shards of one
+ * long sequence report global positions). */
+typedef struct {
+    const uint64_t *words; /* LongSequence.data */
+    uint64_t n_bases;      /* LongSequence.len */
+    uint64_t first_base;   /* 0-based symbol offset of the view inside words[] */
+    uint64_t index_origin; /* 0 for a whole sequence */
+    int32_t src_bits;      /* 2 (DNA/RNAAlphabet{2}) or 4 (DNA/RNAAlphabet{4}) */
+    int32_t reserved;
+} kmers_seq;
+
+/* ---- library / context ------------------------------------------------------- */
+int kmers_abi_version(void);
+/* hip_stream: NULL -> the context creates and owns a stream; else a hipStream_t to borrow */
+int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out);
+void kmers_ctx_destroy(kmers_ctx *ctx);
+void *kmers_ctx_stream(kmers_ctx *ctx);
+const char *kmers_last_error(kmers_ctx *ctx);
+/* wait for KMERS_ASYNC work; reports the first EncodeError seen since the last sync */
+int kmers_sync(kmers_ctx *ctx, kmers_result *res);
+
+/* launch tunables (bench / tuning; 0 restores the default) */
+#define KMERS_PARAM_TILE_KMERS 1 /* kmers per workgroup tile (multiple of 512) */
+#define KMERS_PARAM_MAX_GRID 2   /* cap on workgroups per launch (persistent grid-stride above it) */
+int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
+
+/* device memory for hosts without their own HIP binding */
+int kmers_dev_alloc(kmers_ctx *ctx, size_t bytes, void **out);
+int kmers_dev_free(kmers_ctx *ctx, void *p);
+int kmers_memcpy_h2d(kmers_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- geometry (src/kmer.jl:117-137; iterator length()) ----------------------- */
+int kmers_words_per_kmer(int k, int dst_bits);                      /* n_coding_elements, kmer.jl:123-125 */
+uint64_t kmers_count(uint64_t n_bases, int k, int stride);          /* FwKmers.jl:40-43; SpacedKmers.jl:38-42 */
+int kmers_supported(int src_bits, int dst_bits, int k, int stride); /* 1 if the kernels cover it */
+
+/* ---- iterators --------------------------------------------------------------- */
+/* FwKmers{A,K}(seq) collected (FwKmers.jl:57-115); with out_rc != NULL also
+ * reverse_complement of every element = the (fw, rv) pairs of FwRvIterator
+ * (CanonicalKmers.jl:54-144) as two arrays.  n = kmers_count(n_bases, k, 1). */
+int kmers_fw(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t *out_fw,
+             uint64_t *out_rc, int flags, kmers_result *res);
+
+/* CanonicalKmers{A,K}(seq) collected (CanonicalKmers.jl:199-225: fw < rv ? fw : rv);
+ * with out_hashes != NULL also fx_hash(kmer, seed) of every element (kmer.jl:255-261).
+ * Either output may be NULL. */
+int kmers_canonical(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits,
+                    uint64_t *out_kmers, uint64_t *out_hashes, uint64_t seed, int flags,
+                    kmers_result *res);
+
+/* SpacedKmers{A,K,J}(seq) collected (SpacedKmers.jl:83-139), strict semantics: an
+ * ambiguous symbol inside any inspected position is E_ENCODE; with J >= K the gaps
+ * are never inspected (SpacedKmers.jl:133-134). */
+int kmers_spaced(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_bits,
+                 uint64_t *out_kmers, int flags, kmers_result *res);
+
+/* UnambiguousKmers{A,K}(seq) collected (UnambiguousKmers.jl:59-148): every window of
+ * K unambiguous symbols with its 1-based start.  Output count is data dependent
+ * (SizeUnknown, :33): capacity = elements the buffers can hold; res->n_out = count.
+ * stride > 1 keeps only windows whose 0-based start is a multiple of stride (the
+ * "Spaced with ambiguous-base skip" composition of BASELINE.json config 5,
+ * docs/src/faq.md:28-33); stride = 1 is the reference iterator. */
+int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride,
+                      uint64_t *out_kmers, int64_t *out_starts, uint64_t capacity, int flags,
+                      kmers_result *res);
+
+/* Fused consumer of test/benchmark.jl:9-15: XOR of data[1] over all (canonical or
+ * forward) kmers, nothing materialised.  *out_value is host memory. */
+int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, int canonical,
+                     uint64_t *out_value, int flags, kmers_result *res);
+
+/* ---- element-wise operations on arrays of kmers ------------------------------ */
+/* fx_hash(x::Kmer, h::UInt) (kmer.jl:255-261) over n kmers of n_words words each */
+int kmers_fx_hash(kmers_ctx *ctx, const uint64_t *kmers, int n_words, uint64_t n, uint64_t seed,
+                  uint64_t *out_hashes, int flags);
+
+#define KMERS_OP_REVERSE 0     /* transformations.jl:1-10  */
+#define KMERS_OP_COMPLEMENT 1  /* transformations.jl:14-25 */
+#define KMERS_OP_REVCOMP 2     /* transformations.jl:32-34 */
+#define KMERS_OP_CANONICAL 3   /* transformations.jl:36-39 */
+#define KMERS_OP_ISCANONICAL 4 /* transformations.jl:41 ; out = one uint64 0/1 per kmer */
+int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bits, uint64_t n,
+                    uint64_t *out, int flags);
+
+/* ---- synthetic input (bench / tests) -------------------------- */
+/* Fills out_dev (DEVICE memory) with words [first_word, first_word + n_words) of the
+ * seeded uniform A/C/G/T sequence in LongSequence layout; bits = 2 or 4.  With
+ * ambig_per_65536 > 0 (4-bit only) each base becomes N with that probability. */
+int kmers_synth_dna(kmers_ctx *ctx, uint64_t seed, uint64_t first_word, uint64_t n_words, int bits,
+                    uint32_t ambig_per_65536, uint64_t *out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMERS_HIP_H */

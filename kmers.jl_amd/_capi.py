@@ -1,0 +1,85 @@
+"""ctypes binding of include/kmers_hip.h (the C ABI of libkmers_hip.so).
+
+This is the same binding a Julia `@ccall` shim would make.  There is no
+fallback: if the library is missing or no HIP device is usable, loading / context creation
+raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY = range(7)
+MEM_HOST, MEM_DEVICE, ASYNC = 0, 1, 2
+OP_REVERSE, OP_COMPLEMENT, OP_REVCOMP, OP_CANONICAL, OP_ISCANONICAL = range(5)
+PARAM_TILE_KMERS, PARAM_MAX_GRID = 1, 2
+
+STATUS_NAMES = {OK: "KMERS_OK", E_ENCODE: "KMERS_E_ENCODE", E_BADARG: "KMERS_E_BADARG",
+                E_HIP: "KMERS_E_HIP", E_NOMEM: "KMERS_E_NOMEM",
+                E_UNSUPPORTED: "KMERS_E_UNSUPPORTED", E_CAPACITY: "KMERS_E_CAPACITY"}
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("err_enc", C.c_uint32), ("err_pos", C.c_uint64),
+                ("n_out", C.c_uint64)]
+
+
+class Seq(C.Structure):
+    _fields_ = [("words", C.c_void_p), ("n_bases", C.c_uint64), ("first_base", C.c_uint64),
+                ("index_origin", C.c_uint64), ("src_bits", C.c_int32), ("reserved", C.c_int32)]
+
+
+# every symbol include/kmers_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_R = C.POINTER(Result)
+_S = C.POINTER(Seq)
+SYMBOLS = {
+    "kmers_abi_version": (C.c_int, []),
+    "kmers_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "kmers_ctx_destroy": (None, [_P]),
+    "kmers_ctx_stream": (_P, [_P]),
+    "kmers_last_error": (C.c_char_p, [_P]),
+    "kmers_sync": (C.c_int, [_P, _R]),
+    "kmers_ctx_set_param": (C.c_int, [_P, C.c_int, C.c_int64]),
+    "kmers_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "kmers_dev_free": (C.c_int, [_P, _P]),
+    "kmers_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "kmers_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "kmers_words_per_kmer": (C.c_int, [C.c_int, C.c_int]),
+    "kmers_count": (C.c_uint64, [C.c_uint64, C.c_int, C.c_int]),
+    "kmers_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "kmers_fw": (C.c_int, [_P, _S, C.c_int, C.c_int, _P, _P, C.c_int, _R]),
+    "kmers_canonical": (C.c_int, [_P, _S, C.c_int, C.c_int, _P, _P, C.c_uint64, C.c_int, _R]),
+    "kmers_spaced": (C.c_int, [_P, _S, C.c_int, C.c_int, C.c_int, _P, C.c_int, _R]),
+    "kmers_unambiguous": (C.c_int, [_P, _S, C.c_int, C.c_int, _P, _P, C.c_uint64, C.c_int, _R]),
+    "kmers_reduce_xor": (C.c_int, [_P, _S, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int, _R]),
+    "kmers_fx_hash": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int]),
+    "kmers_transform": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_uint64, _P, C.c_int]),
+    "kmers_synth_dna": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _P]),
+}
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """Load libkmers_hip.so (must have been built: `python -m kmers_jl_amd.build` or
+    __graft_entry__.build()).  Raises -- never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the HIP extension has not been built (run __graft_entry__.build()). "
+            "kmers_jl_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,134 @@
+// batch_kernels.hpp -- element-wise kernels over arrays of kmers and the synthetic input
+// generator.  Reference: src/kmer.jl:255-261 (fx_hash), src/transformations.jl:1-41
+// (reverse / complement / reverse_complement / canonical / iscanonical).
+#pragma once
+#include "device_bits.hpp"
+
+namespace kmers {
+
+// ---- fx_hash over n kmers of NW words ----------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(256) void fx_hash_kernel(const uint64_t *__restrict__ kmers, uint64_t n,
+                                                       uint64_t seed, uint64_t *__restrict__ out) {
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t h = seed;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) h = fx_step(h, kmers[i * NW + w]);
+        out[i] = h;
+    }
+}
+
+// generic width (any number of words): used for NW > 4
+__global__ __launch_bounds__(256) void fx_hash_kernel_any(const uint64_t *__restrict__ kmers, int nw, uint64_t n,
+                                                           uint64_t seed, uint64_t *__restrict__ out) {
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t h = seed;
+        for (int w = 0; w < nw; ++w) h = fx_step(h, kmers[i * nw + w]);
+        out[i] = h;
+    }
+}
+
+// ---- whole-kmer transforms ---------------------------------------------------------------
+// reverse the order of the BITS-wide symbols of one word (BioSequences.reversebits)
+template <int BITS>
+__device__ __forceinline__ uint64_t reverse_symbols(uint64_t x) {
+    uint64_t r = __brevll(x);
+    r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+    if constexpr (BITS == 4) r = ((r >> 2) & 0x3333333333333333ull) | ((r & 0x3333333333333333ull) << 2);
+    return r;
+}
+
+// complement_bitpar: 2-bit NOT; 4-bit = bit reversal inside every nibble
+template <int BITS>
+__device__ __forceinline__ uint64_t complement_word(uint64_t x) {
+    if constexpr (BITS == 2) return ~x;
+    x = ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);
+    return ((x & 0xCCCCCCCCCCCCCCCCull) >> 2) | ((x & 0x3333333333333333ull) << 2);
+}
+
+template <int NW, int BITS>
+__device__ __forceinline__ void kmer_complement(uint64_t (&d)[NW], uint64_t mask) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) d[w] = complement_word<BITS>(d[w]);
+    if constexpr (BITS == 2) d[0] &= mask;  // transformations.jl:24 (the 4-bit method needs no mask, :12-13)
+}
+
+// transformations.jl:1-10: reversebits of every word, tuple reversed, right shift by bits_unused
+template <int NW, int BITS>
+__device__ __forceinline__ void kmer_reverse(uint64_t (&d)[NW], uint32_t bu) {
+    uint64_t t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[w] = reverse_symbols<BITS>(d[NW - 1 - w]);
+#pragma unroll
+    for (int w = NW - 1; w >= 0; --w) {
+        uint64_t carry_in = w > 0 ? ((t[w - 1] << 1) << (63u - bu)) : 0ull;  // low bu bits of the word above
+        d[w] = (t[w] >> bu) | carry_in;
+    }
+}
+
+template <int NW, int BITS>
+__global__ __launch_bounds__(256) void transform_kernel(int op, const uint64_t *__restrict__ in, uint64_t n, int k,
+                                                         uint64_t *__restrict__ out) {
+    const uint64_t mask = head_mask(k, BITS);
+    const uint32_t bu = (uint32_t)bits_unused(k, BITS);
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t x[NW], y[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) x[w] = y[w] = in[i * NW + w];
+        if (op == 0) {
+            kmer_reverse<NW, BITS>(y, bu);
+        } else if (op == 1) {
+            kmer_complement<NW, BITS>(y, mask);
+        } else {
+            kmer_complement<NW, BITS>(y, mask);
+            kmer_reverse<NW, BITS>(y, bu);  // reverse_complement = reverse(complement(x)), :32-34
+        }
+        if (op >= 3) {
+            // lexicographic tuple compare, head first (kmer.jl:176-178)
+            int c = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if (c == 0) c = x[w] < y[w] ? -1 : (x[w] > y[w] ? 1 : 0);
+            if (op == 4) {
+                out[i] = c <= 0 ? 1ull : 0ull;  // iscanonical: x <= rc (:41)
+                continue;
+            }
+            if (c == -1) {  // canonical: ifelse(x < rc, x, rc) (:36-39)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) y[w] = x[w];
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) out[i * NW + w] = y[w];
+    }
+}
+
+// ---- synthetic input (the CPU checker restates the same generator) ------
+__global__ __launch_bounds__(256) void synth_kernel(uint64_t seed, uint64_t first_word, uint64_t n_words, int bits,
+                                                     uint32_t ambig, uint64_t *__restrict__ out) {
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) {
+        uint64_t w = first_word + i;
+        if (bits == 2) {
+            out[i] = synth_rand64(seed, w);
+            continue;
+        }
+        uint64_t r = synth_rand64(seed, w >> 1) >> (32 * (w & 1));
+        uint64_t word = 0;
+        for (int j = 0; j < 16; ++j) {
+            uint64_t nib = 1ull << ((r >> (2 * j)) & 3);
+            if (ambig) {
+                uint64_t b = w * 16 + (uint64_t)j;
+                uint64_t u = (synth_rand64(seed ^ 0xA5A5A5A5A5A5A5A5ull, b >> 2) >> (16 * (b & 3))) & 0xffff;
+                if (u < ambig) nib = 0xF;
+            }
+            word |= nib << (4 * j);
+        }
+        out[i] = word;
+    }
+}
+
+}  // namespace kmers

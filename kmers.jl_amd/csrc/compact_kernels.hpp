@@ -1,0 +1,130 @@
+// compact_kernels.hpp -- UnambiguousKmers (src/iterators/UnambiguousKmers.jl:59-148): every
+// window of K unambiguous symbols together with its 1-based start index.
+//
+// The reference walks the sequence with a `remaining` counter that is reset by every
+// ambiguous symbol (:140-146).  Here a window is emitted iff the K bits of a one-bit-per-
+// symbol ambiguity stream (staged in LDS next to the 2-bit code stream) are all zero, which
+// selects exactly the same windows.  The output count is data dependent, so the work is
+// count -> exclusive scan -> emit, with the order of the reference preserved: each
+// wavefront owns a contiguous quarter of its tile and compacts with ballot + popcount.
+#pragma once
+#include "stream_kernel.hpp"
+
+namespace kmers {
+
+struct CompactArgs {
+    const uint64_t *src;
+    uint64_t first_bit;
+    uint64_t n_cand;          // candidate starts = n_bases - K + 1
+    uint64_t n_tiles;
+    uint32_t *counts;         // [n_tiles * 4] per (tile, wave)
+    const uint64_t *offsets;  // exclusive scan of counts
+    uint64_t *out_kmers;      // nullable
+    long long *out_starts;    // nullable
+    uint64_t index_origin;
+    uint32_t k;
+    uint32_t stride;          // keep windows with (start0 % stride) == 0
+    uint32_t tile_kmers;      // multiple of 256
+};
+
+template <int SRC_BITS, int N, bool EMIT>
+__global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a) {
+    __shared__ uint64_t lds[LDS_QWORDS];
+    __shared__ uint64_t amb[MAX_TILE_BASES / 64 + 8];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t k = a.k;
+    const uint64_t mask = head_mask((int)k, 2);
+    const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+
+    for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const uint64_t m0 = tile * a.tile_kmers;
+        const uint64_t left = a.n_cand - m0;
+        const uint32_t mt = left < a.tile_kmers ? (uint32_t)left : a.tile_kmers;
+        const uint64_t bit0 = a.first_bit + m0 * SRC_BITS;
+        const uint64_t w0 = bit0 >> 6;
+        const uint32_t b0 = (uint32_t)(bit0 & 63u) / SRC_BITS;
+        const uint64_t end_bit = bit0 + ((uint64_t)(mt - 1) + k) * SRC_BITS;
+        const uint32_t nw = (uint32_t)(((end_bit + 63) >> 6) - w0);
+
+        __syncthreads();
+        for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
+            uint64_t x = a.src[w0 + wi];
+            if constexpr (SRC_BITS == 4) {
+                uint64_t bad;
+                uint32_t c = pack_4to2(x, bad);
+                reinterpret_cast<uint32_t *>(lds)[wi] = c;
+                reinterpret_cast<uint16_t *>(amb)[wi] = (uint16_t)bad_bits16(bad);
+            } else {
+                lds[wi] = x;
+                reinterpret_cast<uint32_t *>(amb)[wi] = 0u;  // 32 symbols per 2-bit word, none ambiguous
+            }
+        }
+        __syncthreads();
+
+        const uint32_t per_wave = a.tile_kmers / 4;
+        const uint32_t r_begin = wave * per_wave;
+        const uint32_t r_end = r_begin + per_wave < mt ? r_begin + per_wave : mt;
+        uint64_t pos = 0;
+        if constexpr (EMIT) pos = a.offsets[tile * 4 + wave];
+        uint32_t count = 0;
+        const uint32_t passes = r_end > r_begin ? (r_end - r_begin + 63u) / 64u : 0u;  // wave-uniform
+        for (uint32_t p = 0; p < passes; ++p) {
+            // the whole wave iterates together (ballot needs every lane); lanes past the end are invalid
+            const uint32_t r = r_begin + p * 64u + lane;
+            const bool in = r < r_end;
+            const uint64_t g = m0 + r;
+            bool ok = false;
+            if (in) {
+                uint32_t bit = r + b0;
+                uint64_t A = funnel64(amb[bit >> 6], amb[(bit >> 6) + 1], bit & 63u) & kmask;
+                ok = (A == 0) && (a.stride == 1 || (g % a.stride) == 0);
+            }
+            const uint64_t bal = __ballot(ok);
+            if constexpr (EMIT) {
+                if (ok) {
+                    uint64_t fw[N], rc[N];
+                    window<N>(lds, 2u * (r + b0), k, mask, fw, rc);
+                    uint64_t o = pos + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (a.out_kmers) {
+#pragma unroll
+                        for (int w = 0; w < N; ++w) a.out_kmers[o * N + w] = fw[w];
+                    }
+                    if (a.out_starts) a.out_starts[o] = (long long)(g + 1 + a.index_origin);
+                }
+                pos += __popcll(bal);
+            } else {
+                count += __popcll(bal);
+            }
+        }
+        if constexpr (!EMIT) {
+            if (lane == 0) a.counts[tile * 4 + wave] = count;
+        }
+    }
+}
+
+// Exclusive scan of n 32-bit counts into 64-bit offsets (offsets[n] = total); one workgroup.
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t *__restrict__ counts, uint64_t n,
+                                                            uint64_t *__restrict__ offsets) {
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint64_t chunk = (n + 1023) / 1024;
+    const uint64_t lo = (uint64_t)t * chunk < n ? (uint64_t)t * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+    uint64_t s = 0;
+    for (uint64_t i = lo; i < hi; ++i) s += counts[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan of the partials
+        uint64_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = t ? part[t - 1] : 0;
+    for (uint64_t i = lo; i < hi; ++i) {
+        offsets[i] = run;
+        run += counts[i];
+    }
+    if (t == 1023) offsets[n] = part[1023];
+}
+
+}  // namespace kmers

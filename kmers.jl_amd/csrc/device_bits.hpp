@@ -1,0 +1,82 @@
+// device_bits.hpp -- word-level primitives shared by the gfx950 kernels.
+//
+// Everything here is unsigned 64-bit integer arithmetic (no floating point on this
+// path).  The kernels never roll a kmer symbol by symbol as the reference does
+// (src/iterators/CanonicalKmers.jl:131-144); they cut each window out of a 2-bit
+// little-endian stream staged in LDS and derive both strands from it:
+//   W            = bits [2i, 2i+2K) of the stream (base j of the window at bits 2j)
+//   rc kmer      = ~W & mask                (complement = NOT, order already reversed)
+//   forward kmer = rev2(W) >> (64N - 2K)    (symbol order reversed, big-endian Kmer layout)
+// which is bit-identical to shift_encoding / shift_first_encoding (construction_utils.jl:129-134,
+// kmer.jl:511-518) applied K times, see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kmers {
+
+constexpr uint64_t FX_CONSTANT = 0x517cc1b727220a95ull;  // src/kmer.jl:218
+constexpr uint64_t NO_ERROR_POS = ~0ull;
+
+// ---- geometry (host+device), src/kmer.jl:117-137, :603-605 ------------------------------
+__host__ __device__ inline int n_coding_elements(int k, int bps) { return (k * bps + 63) / 64; }
+__host__ __device__ inline int bits_unused(int k, int bps) {
+    return (64 / bps * n_coding_elements(k, bps) - k) * bps;
+}
+// get_mask: all ones when bits_unused == 0 (Julia's 1 << 64 == 0; in C that shift is UB)
+__host__ __device__ inline uint64_t head_mask(int k, int bps) {
+    int bu = bits_unused(k, bps);
+    return bu == 0 ? ~0ull : ((1ull << (64 - bu)) - 1ull);
+}
+
+// ---- 4-bit one-hot -> 2-bit codes, 16 symbols of one LongDNA{4} word at a time ------------
+// code = trailing_zeros(nibble) (construction_utils.jl:51): bit0 = C|T, bit1 = G|T.
+// `bad` gets a non-zero nibble for every symbol with count_ones != 1 (construction_utils.jl:50).
+__device__ __forceinline__ uint32_t pack_4to2(uint64_t x, uint64_t &bad) {
+    const uint64_t M1 = 0x1111111111111111ull;
+    uint64_t x1 = x >> 1, x2 = x >> 2, x3 = x >> 3;
+    uint64_t pop = (x & M1) + (x1 & M1) + (x2 & M1) + (x3 & M1);
+    bad = pop ^ M1;
+    uint64_t c = ((x1 | x3) & M1) | (((x2 | x3) & M1) << 1);  // 2-bit code in the low bits of each nibble
+    c = (c | (c >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    c = (c | (c >> 4)) & 0x00FF00FF00FF00FFull;
+    c = (c | (c >> 8)) & 0x0000FFFF0000FFFFull;
+    c = (c | (c >> 16));
+    return (uint32_t)c;
+}
+
+// one bit per symbol (bit j set = symbol j of the word is ambiguous) from pack_4to2's `bad`
+__device__ __forceinline__ uint32_t bad_bits16(uint64_t bad) {
+    uint64_t f = (bad | (bad >> 1) | (bad >> 2)) & 0x1111111111111111ull;
+    f = (f | (f >> 3)) & 0x0303030303030303ull;
+    f = (f | (f >> 6)) & 0x000F000F000F000Full;
+    f = (f | (f >> 12)) & 0x000000FF000000FFull;
+    f = (f | (f >> 24));
+    return (uint32_t)f & 0xFFFFu;
+}
+
+// reverse the order of the 32 two-bit symbols of a word (BioSequences.reversebits, bps = 2)
+__device__ __forceinline__ uint64_t rev2(uint64_t x) {
+    uint64_t r = __brevll(x);
+    return ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+}
+
+// 64 stream bits starting at bit s (0..63) of the pair (lo, hi)
+__device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t s) {
+    return (lo >> s) | ((hi << 1) << (63u - s));
+}
+
+// fx_hash step, src/kmer.jl:255-260
+__device__ __forceinline__ uint64_t fx_step(uint64_t h, uint64_t w) {
+    return (((h << 5) | (h >> 59)) ^ w) * FX_CONSTANT;
+}
+
+// SplitMix64 finaliser: the build's synthetic generator
+__host__ __device__ inline uint64_t synth_rand64(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace kmers

@@ -1,0 +1,572 @@
+// kmers_api.hip -- the C ABI of libkmers_hip.so (include/kmers_hip.h): context, argument
+// checking (the reference's constructor errors), host<->HBM staging and kernel launches.
+// There is deliberately no CPU compute path here.
+#include "../../include/kmers_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "batch_kernels.hpp"
+#include "compact_kernels.hpp"
+#include "stream_kernel.hpp"
+
+using namespace kmers;
+
+struct kmers_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    unsigned long long *d_err = nullptr;  // first offending symbol (0-based), ~0 = none
+    uint64_t *d_scratch = nullptr;        // 64 words of device scratch
+    void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_cap[4] = {0, 0, 0, 0};
+    std::string last_error;
+    // what the most recent launch read, for decoding an EncodeError at sync time
+    const uint64_t *err_words = nullptr;  // DEVICE pointer of the staged / resident words
+    uint64_t err_first_bit = 0;
+    uint64_t err_origin = 0;
+    int err_bits = 0;
+    int64_t tile_kmers = 0;  // 0 = default
+    int64_t max_grid = 0;    // 0 = default
+};
+
+namespace {
+
+int fail(kmers_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        ctx->last_error = what;
+        if (e != hipSuccess) {
+            ctx->last_error += ": ";
+            ctx->last_error += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                             \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) return fail(ctx, KMERS_E_HIP, #call, e_); \
+    } while (0)
+
+int ensure_stage(kmers_ctx *ctx, int slot, size_t bytes) {
+    if (bytes <= ctx->stage_cap[slot]) return KMERS_OK;
+    if (ctx->stage[slot]) (void)hipFree(ctx->stage[slot]);
+    ctx->stage[slot] = nullptr;
+    ctx->stage_cap[slot] = 0;
+    size_t cap = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&ctx->stage[slot], cap);
+    if (e != hipSuccess) return fail(ctx, KMERS_E_NOMEM, "hipMalloc(staging)", e);
+    ctx->stage_cap[slot] = cap;
+    return KMERS_OK;
+}
+
+void clear(kmers_result *res) {
+    if (res) std::memset(res, 0, sizeof *res);
+}
+
+// Common argument checks.  K, J errors mirror the constructors (FwKmers.jl:31-35,
+// SpacedKmers.jl:26-32); geometry limits are this library's.
+int check_common(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_bits, int flags) {
+    if (!ctx) return KMERS_E_BADARG;
+    if (!seq) return fail(ctx, KMERS_E_BADARG, "seq is NULL");
+    if (k < 1) return fail(ctx, KMERS_E_BADARG, "K must be at least 1");
+    if (stride < 1) return fail(ctx, KMERS_E_BADARG, "J must be at least 1");
+    if (seq->src_bits != 2 && seq->src_bits != 4) return fail(ctx, KMERS_E_BADARG, "src_bits must be 2 or 4");
+    if (seq->n_bases && !seq->words) return fail(ctx, KMERS_E_BADARG, "seq.words is NULL");
+    if ((flags & KMERS_ASYNC) && !(flags & KMERS_MEM_DEVICE))
+        return fail(ctx, KMERS_E_BADARG, "KMERS_ASYNC requires KMERS_MEM_DEVICE");
+    if (!kmers_supported(seq->src_bits, dst_bits, k, stride))
+        return fail(ctx, KMERS_E_UNSUPPORTED, "unsupported (src_bits, dst_bits, K) geometry");
+    return KMERS_OK;
+}
+
+struct Staged {
+    const uint64_t *d_words = nullptr;  // device pointer whose word 0 holds first_bit
+    uint64_t first_bit = 0;
+};
+
+// Make the sequence words available in HBM.  Host memory: copy the words the view touches.
+int stage_sequence(kmers_ctx *ctx, const kmers_seq *seq, int flags, Staged *out) {
+    uint64_t bit0 = seq->first_base * (uint64_t)seq->src_bits;
+    if (flags & KMERS_MEM_DEVICE) {
+        out->d_words = seq->words;
+        out->first_bit = bit0;
+        return KMERS_OK;
+    }
+    uint64_t w0 = bit0 >> 6;
+    uint64_t w1 = (bit0 + seq->n_bases * (uint64_t)seq->src_bits + 63) >> 6;
+    size_t bytes = (size_t)(w1 - w0) * 8;
+    if (int rc = ensure_stage(ctx, 0, bytes + 8)) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], seq->words + w0, bytes, hipMemcpyHostToDevice, ctx->stream));
+    out->d_words = static_cast<const uint64_t *>(ctx->stage[0]);
+    out->first_bit = bit0 & 63u;
+    return KMERS_OK;
+}
+
+// Wait for the stream and turn the device error slot into a kmers_result.
+int collect(kmers_ctx *ctx, kmers_result *res, uint64_t n_out) {
+    unsigned long long pos = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&pos, ctx->d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (pos == NO_ERROR_POS) {
+        if (res) {
+            res->status = KMERS_OK;
+            res->n_out = n_out;
+        }
+        return KMERS_OK;
+    }
+    // EncodeError: fetch the raw encoding of the offending symbol, re-arm the slot
+    uint64_t bit = ctx->err_first_bit + (uint64_t)pos * (uint64_t)ctx->err_bits;
+    uint64_t word = 0;
+    HIP_TRY(ctx, hipMemcpy(&word, ctx->err_words + (bit >> 6), 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (res) {
+        res->status = KMERS_E_ENCODE;
+        res->err_pos = (uint64_t)pos + 1 + ctx->err_origin;
+        res->err_enc = (uint32_t)((word >> (bit & 63u)) & ((1u << ctx->err_bits) - 1u));
+        res->n_out = 0;
+    }
+    ctx->last_error = "EncodeError: ambiguous symbol cannot be encoded in a 2-bit alphabet";
+    return KMERS_E_ENCODE;
+}
+
+void remember_source(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st) {
+    ctx->err_words = st.d_words;
+    ctx->err_first_bit = st.first_bit;
+    ctx->err_origin = seq->index_origin;
+    ctx->err_bits = seq->src_bits;
+}
+
+template <int MODE>
+int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int n_words, bool vec_ok) {
+    const uint32_t J = a.stride;
+    const bool stride1 = (J == 1) && vec_ok;
+    uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : 4096u;
+    if (J > 1) tile = std::min<uint32_t>(tile, (uint32_t)(MAX_TILE_BASES / J));
+    tile = std::max<uint32_t>(512u, tile & ~511u);
+    if ((uint64_t)(tile - 1) * J + 1 > (uint64_t)MAX_TILE_BASES) return fail(ctx, KMERS_E_UNSUPPORTED, "stride too large for the tile kernel");
+    a.tile_kmers = tile;
+    a.n_tiles = (a.n_kmers + tile - 1) / tile;
+    uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
+    dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap));
+    dim3 block(BLOCK);
+#define LAUNCH(SB, NN, S1) hipLaunchKernelGGL((stream_kernel<SB, NN, MODE, S1>), grid, block, 0, ctx->stream, a)
+    if (src_bits == 4) {
+        if (n_words == 1) { if (stride1) LAUNCH(4, 1, true); else LAUNCH(4, 1, false); }
+        else              { if (stride1) LAUNCH(4, 2, true); else LAUNCH(4, 2, false); }
+    } else {
+        if (n_words == 1) { if (stride1) LAUNCH(2, 1, true); else LAUNCH(2, 1, false); }
+        else              { if (stride1) LAUNCH(2, 2, true); else LAUNCH(2, 2, false); }
+    }
+#undef LAUNCH
+    HIP_TRY(ctx, hipGetLastError());
+    return KMERS_OK;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Shared body of kmers_fw / kmers_canonical / kmers_spaced.
+int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_bits, int mode,
+               uint64_t *out_a, uint64_t *out_b, bool b_is_hash, uint64_t seed, int flags, kmers_result *res) {
+    clear(res);
+    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags)) {
+        if (res) res->status = rc;
+        return rc;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int nw = kmers_words_per_kmer(k, dst_bits);
+    const uint64_t n = kmers_count(seq->n_bases, k, stride);
+    if (n == 0) {  // length(seq) < K: empty iteration, nothing inspected (FwKmers.jl:63)
+        if (res) res->status = KMERS_OK;
+        return KMERS_OK;
+    }
+    Staged st;
+    if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
+    remember_source(ctx, seq, st);
+
+    const bool dev = flags & KMERS_MEM_DEVICE;
+    uint64_t *d_a = out_a, *d_b = out_b;
+    const size_t bytes_a = (size_t)n * nw * 8, bytes_b = (size_t)n * (b_is_hash ? 1 : nw) * 8;
+    if (!dev) {
+        if (out_a) { if (int rc = ensure_stage(ctx, 1, bytes_a)) return rc; d_a = (uint64_t *)ctx->stage[1]; }
+        if (out_b) { if (int rc = ensure_stage(ctx, 2, bytes_b)) return rc; d_b = (uint64_t *)ctx->stage[2]; }
+    }
+    if (nw == 2 && ((d_a && !aligned16(d_a)) || (d_b && !b_is_hash && !aligned16(d_b))))
+        return fail(ctx, KMERS_E_BADARG, "two-word kmer outputs must be 16-byte aligned");
+
+    StreamArgs a{};
+    a.src = st.d_words;
+    a.first_bit = st.first_bit;
+    a.n_bases = seq->n_bases;
+    a.n_kmers = n;
+    a.inspect_end = (n - 1) * (uint64_t)stride + (uint64_t)k;  // end of the last kmer (== n_bases for stride 1)
+    a.out_a = d_a;
+    a.out_b = d_b;
+    a.seed = seed;
+    a.err_slot = ctx->d_err;
+    a.k = (uint32_t)k;
+    a.stride = (uint32_t)stride;
+
+    int rc;
+    if (stride > 32) {
+        // gather path (forward kmers only: kmers_spaced)
+        dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+        if (seq->src_bits == 4) {
+            if (nw == 1) hipLaunchKernelGGL((gather_kernel<4, 1>), grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((gather_kernel<4, 2>), grid, block, 0, ctx->stream, a);
+        } else {
+            if (nw == 1) hipLaunchKernelGGL((gather_kernel<2, 1>), grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((gather_kernel<2, 2>), grid, block, 0, ctx->stream, a);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        rc = KMERS_OK;
+    } else {
+        const bool vec_ok = (!d_a || aligned16(d_a)) && (!d_b || aligned16(d_b));
+        rc = mode == MODE_FW ? launch_stream<MODE_FW>(ctx, a, seq->src_bits, nw, vec_ok)
+                             : launch_stream<MODE_CANON>(ctx, a, seq->src_bits, nw, vec_ok);
+    }
+    if (rc) return rc;
+    if (flags & KMERS_ASYNC) {
+        if (res) { res->status = KMERS_OK; res->n_out = n; }
+        return KMERS_OK;
+    }
+    if (!dev) {
+        if (out_a) HIP_TRY(ctx, hipMemcpyAsync(out_a, d_a, bytes_a, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_b) HIP_TRY(ctx, hipMemcpyAsync(out_b, d_b, bytes_b, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return collect(ctx, res, n);
+}
+
+// UnambiguousKmers: count -> scan -> emit (compact_kernels.hpp)
+int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uint64_t *out_kmers,
+                    int64_t *out_starts, uint64_t capacity, int flags, kmers_result *res) {
+    const int nw = kmers_words_per_kmer(k, 2);
+    const uint64_t n = kmers_count(seq->n_bases, k, 1);
+    if (n == 0) return KMERS_OK;
+    Staged st;
+    if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
+    remember_source(ctx, seq, st);
+    const bool dev = flags & KMERS_MEM_DEVICE;
+
+    CompactArgs a{};
+    a.src = st.d_words;
+    a.first_bit = st.first_bit;
+    a.n_cand = n;
+    a.k = (uint32_t)k;
+    a.stride = (uint32_t)stride;
+    a.index_origin = seq->index_origin;
+    uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : 4096u;
+    tile = std::max<uint32_t>(512u, std::min<uint32_t>(tile, (uint32_t)MAX_TILE_BASES) & ~511u);
+    a.tile_kmers = tile;
+    a.n_tiles = (n + tile - 1) / tile;
+    const uint64_t n_counts = a.n_tiles * 4;
+    // scratch: counts (u32) then offsets (u64, n_counts + 1)
+    size_t counts_bytes = ((size_t)n_counts * 4 + 15) & ~(size_t)15;
+    if (int rc = ensure_stage(ctx, 3, counts_bytes + ((size_t)n_counts + 1) * 8)) return rc;
+    a.counts = static_cast<uint32_t *>(ctx->stage[3]);
+    uint64_t *offsets = reinterpret_cast<uint64_t *>(static_cast<char *>(ctx->stage[3]) + counts_bytes);
+    a.offsets = offsets;
+    uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
+    dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap)), block(BLOCK);
+#define UL(SB, NN, EM) hipLaunchKernelGGL((unambiguous_kernel<SB, NN, EM>), grid, block, 0, ctx->stream, a)
+#define UDISPATCH(EM)                                                         \
+    do {                                                                      \
+        if (seq->src_bits == 4) { if (nw == 1) UL(4, 1, EM); else UL(4, 2, EM); } \
+        else                    { if (nw == 1) UL(2, 1, EM); else UL(2, 2, EM); } \
+    } while (0)
+    UDISPATCH(false);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, a.counts, n_counts, offsets);
+    HIP_TRY(ctx, hipGetLastError());
+    uint64_t total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, offsets + n_counts, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (res) res->n_out = total;
+    if (total > capacity || (!out_kmers && !out_starts)) {
+        // capacity query (both outputs NULL) or buffers too small: report the count only
+        if (total > capacity && (out_kmers || out_starts)) {
+            if (res) res->status = KMERS_E_CAPACITY;
+            return fail(ctx, KMERS_E_CAPACITY, "output capacity too small");
+        }
+        return KMERS_OK;
+    }
+    if (total == 0) return KMERS_OK;
+    uint64_t *d_k = out_kmers;
+    long long *d_s = reinterpret_cast<long long *>(out_starts);
+    const size_t kb = (size_t)total * nw * 8, sb = (size_t)total * 8;
+    if (!dev) {
+        if (out_kmers) { if (int rc = ensure_stage(ctx, 1, kb)) return rc; d_k = (uint64_t *)ctx->stage[1]; }
+        if (out_starts) { if (int rc = ensure_stage(ctx, 2, sb)) return rc; d_s = (long long *)ctx->stage[2]; }
+    }
+    a.out_kmers = d_k;
+    a.out_starts = d_s;
+    UDISPATCH(true);
+#undef UDISPATCH
+#undef UL
+    HIP_TRY(ctx, hipGetLastError());
+    if (!dev) {
+        if (out_kmers) HIP_TRY(ctx, hipMemcpyAsync(out_kmers, d_k, kb, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_starts) HIP_TRY(ctx, hipMemcpyAsync(out_starts, d_s, sb, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KMERS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kmers_abi_version(void) { return KMERS_ABI_VERSION; }
+
+int kmers_words_per_kmer(int k, int dst_bits) {
+    if (k < 0 || (dst_bits != 2 && dst_bits != 4 && dst_bits != 8)) return -1;
+    return n_coding_elements(k, dst_bits);
+}
+
+uint64_t kmers_count(uint64_t n_bases, int k, int stride) {
+    if (k < 1 || stride < 1 || n_bases < (uint64_t)k) return 0;
+    return (n_bases - (uint64_t)k) / (uint64_t)stride + 1;  // SpacedKmers.jl:41; stride 1 == FwKmers.jl:42
+}
+
+int kmers_supported(int src_bits, int dst_bits, int k, int stride) {
+    if (src_bits != 2 && src_bits != 4) return 0;
+    if (dst_bits != 2) return 0;  // 4-bit kmer alphabets: SURVEY.md section 8 row f3 (next)
+    if (k < 1 || k > 64 || stride < 1) return 0;
+    return 1;
+}
+
+int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out) {
+    if (!out) return KMERS_E_BADARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return KMERS_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return KMERS_E_HIP;
+    kmers_ctx *ctx = new (std::nothrow) kmers_ctx();
+    if (!ctx) return KMERS_E_NOMEM;
+    ctx->device = device;
+    if (hip_stream) {
+        ctx->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return KMERS_E_HIP; }
+        ctx->own_stream = true;
+    }
+    if (hipMalloc(&ctx->d_err, 8) != hipSuccess || hipMalloc(&ctx->d_scratch, 64 * 8) != hipSuccess ||
+        hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        kmers_ctx_destroy(ctx);
+        return KMERS_E_HIP;
+    }
+    *out = ctx;
+    return KMERS_OK;
+}
+
+void kmers_ctx_destroy(kmers_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->stage)
+        if (p) (void)hipFree(p);
+    if (ctx->d_err) (void)hipFree(ctx->d_err);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void *kmers_ctx_stream(kmers_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
+const char *kmers_last_error(kmers_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "no context"; }
+
+int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value) {
+    if (!ctx) return KMERS_E_BADARG;
+    if (param == KMERS_PARAM_TILE_KMERS) ctx->tile_kmers = value;
+    else if (param == KMERS_PARAM_MAX_GRID) ctx->max_grid = value;
+    else return fail(ctx, KMERS_E_BADARG, "unknown parameter");
+    return KMERS_OK;
+}
+
+int kmers_sync(kmers_ctx *ctx, kmers_result *res) {
+    if (!ctx) return KMERS_E_BADARG;
+    clear(res);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return collect(ctx, res, 0);
+}
+
+int kmers_dev_alloc(kmers_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return KMERS_E_BADARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+    if (e != hipSuccess) return fail(ctx, KMERS_E_NOMEM, "hipMalloc", e);
+    return KMERS_OK;
+}
+int kmers_dev_free(kmers_ctx *ctx, void *p) {
+    if (!ctx) return KMERS_E_BADARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(p));
+    return KMERS_OK;
+}
+int kmers_memcpy_h2d(kmers_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return KMERS_E_BADARG;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KMERS_OK;
+}
+int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return KMERS_E_BADARG;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KMERS_OK;
+}
+
+int kmers_fw(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t *out_fw, uint64_t *out_rc,
+             int flags, kmers_result *res) {
+    if (ctx && !out_fw && seq && kmers_count(seq->n_bases, k, 1)) return fail(ctx, KMERS_E_BADARG, "out_fw is NULL");
+    return run_stream(ctx, seq, k, 1, dst_bits, MODE_FW, out_fw, out_rc, false, 0, flags, res);
+}
+
+int kmers_canonical(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t *out_kmers,
+                    uint64_t *out_hashes, uint64_t seed, int flags, kmers_result *res) {
+    return run_stream(ctx, seq, k, 1, dst_bits, MODE_CANON, out_kmers, out_hashes, true, seed, flags, res);
+}
+
+int kmers_spaced(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_bits, uint64_t *out_kmers,
+                 int flags, kmers_result *res) {
+    if (ctx && !out_kmers && seq && kmers_count(seq->n_bases, k, stride)) return fail(ctx, KMERS_E_BADARG, "out_kmers is NULL");
+    return run_stream(ctx, seq, k, stride, dst_bits, MODE_FW, out_kmers, nullptr, false, 0, flags, res);
+}
+
+int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, int canonical, uint64_t *out_value,
+                     int flags, kmers_result *res) {
+    clear(res);
+    if (int rc = check_common(ctx, seq, k, 1, dst_bits, flags & ~KMERS_ASYNC)) {
+        if (res) res->status = rc;
+        return rc;
+    }
+    if (!out_value) return fail(ctx, KMERS_E_BADARG, "out_value is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out_value = 0;
+    const uint64_t n = kmers_count(seq->n_bases, k, 1);
+    if (n == 0) return KMERS_OK;
+    Staged st;
+    if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
+    remember_source(ctx, seq, st);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
+    StreamArgs a{};
+    a.src = st.d_words;
+    a.first_bit = st.first_bit;
+    a.n_bases = seq->n_bases;
+    a.n_kmers = n;
+    a.inspect_end = seq->n_bases;
+    a.out_a = ctx->d_scratch;
+    a.err_slot = ctx->d_err;
+    a.k = (uint32_t)k;
+    a.stride = 1;
+    a.xor_canonical = canonical ? 1u : 0u;
+    if (ctx->max_grid <= 0) {
+        // fused consumer: persistent grid, one atomic per wave at the very end
+        int64_t saved = ctx->max_grid;
+        ctx->max_grid = 256 * 8;
+        int rc = launch_stream<MODE_XOR>(ctx, a, seq->src_bits, kmers_words_per_kmer(k, dst_bits), true);
+        ctx->max_grid = saved;
+        if (rc) return rc;
+    } else if (int rc = launch_stream<MODE_XOR>(ctx, a, seq->src_bits, kmers_words_per_kmer(k, dst_bits), true)) {
+        return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(out_value, ctx->d_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
+    return collect(ctx, res, n);
+}
+
+int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uint64_t *out_kmers,
+                      int64_t *out_starts, uint64_t capacity, int flags, kmers_result *res) {
+    clear(res);
+    if (int rc = check_common(ctx, seq, k, stride, 2, flags & ~KMERS_ASYNC)) {
+        if (res) res->status = rc;
+        return rc;
+    }
+    if (flags & KMERS_ASYNC) return fail(ctx, KMERS_E_BADARG, "kmers_unambiguous is synchronous (data-dependent count)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return run_unambiguous(ctx, seq, k, stride, out_kmers, out_starts, capacity, flags, res);
+}
+
+int kmers_fx_hash(kmers_ctx *ctx, const uint64_t *kmers, int n_words, uint64_t n, uint64_t seed, uint64_t *out,
+                  int flags) {
+    if (!ctx) return KMERS_E_BADARG;
+    if (n_words < 0 || (n && (!kmers || !out) && n_words > 0) || (n && !out)) return fail(ctx, KMERS_E_BADARG, "bad fx_hash arguments");
+    if (n == 0) return KMERS_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool dev = flags & KMERS_MEM_DEVICE;
+    const uint64_t *d_in = kmers;
+    uint64_t *d_out = out;
+    size_t in_bytes = (size_t)n * n_words * 8, out_bytes = (size_t)n * 8;
+    if (!dev) {
+        if (int rc = ensure_stage(ctx, 0, in_bytes + 8)) return rc;
+        if (int rc = ensure_stage(ctx, 1, out_bytes)) return rc;
+        if (in_bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], kmers, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_in = (const uint64_t *)ctx->stage[0];
+        d_out = (uint64_t *)ctx->stage[1];
+    }
+    dim3 block(256), grid((unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16));
+    switch (n_words) {
+        case 0: hipLaunchKernelGGL(fx_hash_kernel_any, grid, block, 0, ctx->stream, d_in, 0, n, seed, d_out); break;  // 0-mer: the seed
+        case 1: hipLaunchKernelGGL((fx_hash_kernel<1>), grid, block, 0, ctx->stream, d_in, n, seed, d_out); break;
+        case 2: hipLaunchKernelGGL((fx_hash_kernel<2>), grid, block, 0, ctx->stream, d_in, n, seed, d_out); break;
+        default: hipLaunchKernelGGL(fx_hash_kernel_any, grid, block, 0, ctx->stream, d_in, n_words, n, seed, d_out); break;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (flags & KMERS_ASYNC) return KMERS_OK;
+    if (!dev) HIP_TRY(ctx, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KMERS_OK;
+}
+
+int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bits, uint64_t n, uint64_t *out,
+                    int flags) {
+    if (!ctx) return KMERS_E_BADARG;
+    if (op < 0 || op > 4 || k < 1 || (bits != 2 && bits != 4)) return fail(ctx, KMERS_E_BADARG, "bad transform arguments");
+    const int nw = n_coding_elements(k, bits);
+    if (nw > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_transform supports up to 4 words per kmer");
+    if (n == 0) return KMERS_OK;
+    if (!kmers || !out) return fail(ctx, KMERS_E_BADARG, "NULL kmer array");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool dev = flags & KMERS_MEM_DEVICE;
+    const uint64_t *d_in = kmers;
+    uint64_t *d_out = out;
+    size_t in_bytes = (size_t)n * nw * 8, out_bytes = (size_t)n * (op == KMERS_OP_ISCANONICAL ? 1 : nw) * 8;
+    if (!dev) {
+        if (int rc = ensure_stage(ctx, 0, in_bytes + 8)) return rc;
+        if (int rc = ensure_stage(ctx, 1, out_bytes)) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], kmers, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_in = (const uint64_t *)ctx->stage[0];
+        d_out = (uint64_t *)ctx->stage[1];
+    }
+    dim3 block(256), grid((unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16));
+#define TL(NW_, B_) hipLaunchKernelGGL((transform_kernel<NW_, B_>), grid, block, 0, ctx->stream, op, d_in, n, k, d_out)
+    if (bits == 2) { if (nw == 1) TL(1, 2); else if (nw == 2) TL(2, 2); else if (nw == 3) TL(3, 2); else TL(4, 2); }
+    else           { if (nw == 1) TL(1, 4); else if (nw == 2) TL(2, 4); else if (nw == 3) TL(3, 4); else TL(4, 4); }
+#undef TL
+    HIP_TRY(ctx, hipGetLastError());
+    if (flags & KMERS_ASYNC) return KMERS_OK;
+    if (!dev) HIP_TRY(ctx, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KMERS_OK;
+}
+
+int kmers_synth_dna(kmers_ctx *ctx, uint64_t seed, uint64_t first_word, uint64_t n_words, int bits,
+                    uint32_t ambig_per_65536, uint64_t *out_dev) {
+    if (!ctx) return KMERS_E_BADARG;
+    if ((bits != 2 && bits != 4) || (n_words && !out_dev)) return fail(ctx, KMERS_E_BADARG, "bad synth arguments");
+    if (n_words == 0) return KMERS_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    dim3 block(256), grid((unsigned)std::min<uint64_t>((n_words + 255) / 256, 256 * 32));
+    hipLaunchKernelGGL(synth_kernel, grid, block, 0, ctx->stream, seed, first_word, n_words, bits, ambig_per_65536, out_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KMERS_OK;
+}
+
+}  // extern "C"

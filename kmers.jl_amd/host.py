@@ -1,0 +1,735 @@
+"""Host-side mirror of the reference's iterator / fx_hash / canonical API over the C ABI.
+
+The reference is Julia and no Julia toolchain exists in this image, so the drop-in surface is
+mirrored here in Python with the reference's names and argument meaning:
+
+    Julia                                   here
+    CanonicalDNAMers{31}(seq)               CanonicalDNAMers[31](seq)
+    FwKmers{DNAAlphabet{2}, 21}(seq)        FwKmers[DNAAlphabet[2], 21](seq)
+    SpacedDNAMers{21, 3}(seq)               SpacedDNAMers[21, 3](seq)
+    collect(it), length(it), for x in it    collect(it), len(it), for x in it
+    fx_hash(kmer, h), canonical(kmer), ...  same names
+
+Every computation goes through libkmers_hip.so (kmers_jl_amd._capi); nothing is computed on the
+CPU except packing text into LongSequence words and unpacking kmers back to text.
+(The Julia `@ccall` shim with the same mapping is julia/KmersHIP.jl, see INTEGRATION.md.)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+MASK64 = (1 << 64) - 1
+
+
+# --------------------------------------------------------------------------------------------
+# errors
+class KmersError(RuntimeError):
+    pass
+
+
+class EncodeError(KmersError):
+    """BioSequences.EncodeError (src/construction.jl:108-110)."""
+
+    def __init__(self, alphabet, symbol, position, encoding):
+        self.alphabet, self.symbol, self.position, self.encoding = alphabet, symbol, position, encoding
+        super().__init__(f"cannot encode {symbol} in {alphabet}")
+
+
+class UnsupportedError(KmersError):
+    pass
+
+
+# --------------------------------------------------------------------------------------------
+# alphabets (BioSequences names; only what the hot path needs)
+class _Alphabet:
+    def __init__(self, kind, bits):
+        self.kind, self.bits = kind, bits
+
+    def __repr__(self):
+        return f"{self.kind}Alphabet{{{self.bits}}}"
+
+    def __eq__(self, other):
+        return isinstance(other, _Alphabet) and (self.kind, self.bits) == (other.kind, other.bits)
+
+    def __hash__(self):
+        return hash((self.kind, self.bits))
+
+
+class _AlphabetFamily:
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __getitem__(self, bits):
+        if bits not in (2, 4):
+            raise KmersError("nucleotide alphabets have 2 or 4 bits per symbol")
+        return _Alphabet(self.kind, bits)
+
+
+DNAAlphabet = _AlphabetFamily("DNA")
+RNAAlphabet = _AlphabetFamily("RNA")
+
+_ENC4 = {"-": 0, "A": 1, "C": 2, "M": 3, "G": 4, "R": 5, "S": 6, "V": 7, "T": 8, "W": 9, "Y": 10,
+         "H": 11, "K": 12, "D": 13, "B": 14, "N": 15, "U": 8}
+_ENC2 = {"A": 0, "C": 1, "G": 2, "T": 3, "U": 3}
+
+
+def _decode_table(alphabet):
+    t = "U" if alphabet.kind == "RNA" else "T"
+    if alphabet.bits == 2:
+        return ["A", "C", "G", t]
+    inv = [None] * 16
+    for ch, v in _ENC4.items():
+        if ch not in "TU":
+            inv[v] = ch
+    inv[8] = t
+    return inv
+
+
+# --------------------------------------------------------------------------------------------
+# context
+class Context:
+    """One kmers_ctx (one HIP stream).  `stream` may be a raw hipStream_t handle to borrow."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _capi.load()
+        h = C.c_void_p()
+        rc = self.lib.kmers_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != _capi.OK:
+            raise KmersError(
+                f"kmers_ctx_create(device={device}) failed with {_capi.STATUS_NAMES.get(rc, rc)}: "
+                "no usable MI355X/HIP device (this library has no CPU fallback)")
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.kmers_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return self.lib.kmers_last_error(self.handle).decode()
+
+    def check(self, rc, what):
+        if rc not in (_capi.OK, _capi.E_ENCODE):
+            msg = f"{what}: {_capi.STATUS_NAMES.get(rc, rc)}: {self.last_error()}"
+            if rc == _capi.E_UNSUPPORTED:
+                raise UnsupportedError(msg)
+            raise KmersError(msg)
+        return rc
+
+    def set_param(self, param, value):
+        self.check(self.lib.kmers_ctx_set_param(self.handle, param, value), "kmers_ctx_set_param")
+
+    # device memory
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.lib.kmers_dev_alloc(self.handle, nbytes, C.byref(p)), "kmers_dev_alloc")
+        return p.value
+
+    def free(self, ptr):
+        if ptr and self.handle:
+            self.lib.kmers_dev_free(self.handle, C.c_void_p(ptr))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.lib.kmers_memcpy_h2d(self.handle, C.c_void_p(dptr), arr.ctypes.data_as(C.c_void_p),
+                                             arr.nbytes), "kmers_memcpy_h2d")
+
+    def d2h(self, arr, dptr):
+        self.check(self.lib.kmers_memcpy_d2h(self.handle, arr.ctypes.data_as(C.c_void_p), C.c_void_p(dptr),
+                                             arr.nbytes), "kmers_memcpy_d2h")
+
+    def sync(self):
+        res = _capi.Result()
+        rc = self.lib.kmers_sync(self.handle, C.byref(res))
+        return rc, res
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# --------------------------------------------------------------------------------------------
+# sequences
+class LongSequence:
+    """BioSequences.LongSequence{A}: `.data` = little-endian packed UInt64 words, `.len` symbols."""
+
+    def __init__(self, alphabet, source="", length=None):
+        self.alphabet = alphabet
+        if isinstance(source, (str, bytes)):
+            text = source.decode() if isinstance(source, bytes) else source
+            enc = _ENC2 if alphabet.bits == 2 else _ENC4
+            try:
+                codes = np.fromiter((enc[c] for c in text.upper()), dtype=np.uint64, count=len(text))
+            except KeyError as e:
+                raise EncodeError(alphabet, e.args[0], None, None)
+            self.len = len(text)
+            per = 64 // alphabet.bits
+            nw = (self.len + per - 1) // per
+            pad = np.zeros(nw * per, dtype=np.uint64)
+            pad[:self.len] = codes
+            shifts = (np.arange(per, dtype=np.uint64) * np.uint64(alphabet.bits))
+            self.data = np.bitwise_or.reduce(pad.reshape(nw, per) << shifts, axis=1).astype(np.uint64) \
+                if nw else np.zeros(0, dtype=np.uint64)
+        else:
+            self.data = np.ascontiguousarray(source, dtype=np.uint64)
+            self.len = int(length)
+        self._dev = None  # (ctx, device pointer)
+
+    def __len__(self):
+        return self.len
+
+    def __str__(self):
+        inv = _decode_table(self.alphabet)
+        b = self.alphabet.bits
+        return "".join(inv[(int(self.data[(i * b) >> 6]) >> ((i * b) & 63)) & ((1 << b) - 1)]
+                       for i in range(self.len))
+
+    def __repr__(self):
+        s = str(self) if self.len <= 60 else str(LongSequence(self.alphabet, self.data, 57)) + "..."
+        return f"{self.len}nt {self.alphabet.kind} Sequence:\n{s}"
+
+    def device_words(self, ctx):
+        """HBM-resident copy of `.data` (uploaded once, reused by every iterator pass)."""
+        if self._dev is None or self._dev[0] is not ctx:
+            ptr = ctx.alloc(max(8, self.data.nbytes + 8))
+            if self.data.nbytes:
+                ctx.h2d(ptr, self.data)
+            self._dev = (ctx, ptr)
+        return self._dev[1]
+
+    def __del__(self):
+        try:
+            if self._dev is not None:
+                self._dev[0].free(self._dev[1])
+        except Exception:
+            pass
+
+
+class _LongFamily:
+    def __init__(self, fam):
+        self.fam = fam
+
+    def __getitem__(self, bits):
+        alph = self.fam[bits]
+        return lambda source="", length=None: LongSequence(alph, source, length)
+
+
+LongDNA = _LongFamily(DNAAlphabet)
+LongRNA = _LongFamily(RNAAlphabet)
+
+
+def _as_sequence(s):
+    if isinstance(s, LongSequence):
+        return s
+    raise UnsupportedError(
+        "only LongSequence sources are supported (String / byte sources are SURVEY.md section 8 row f1)")
+
+
+# --------------------------------------------------------------------------------------------
+# kmers
+def n_coding_elements(K, bits):
+    return (K * bits + 63) // 64
+
+
+class Kmer:
+    """Kmer{A,K,N} value (src/kmer.jl:32-44): `.data` = N UInt64, first symbol most significant."""
+    __slots__ = ("alphabet", "K", "data")
+
+    def __init__(self, alphabet, K_or_text, data=None):
+        self.alphabet = alphabet
+        if data is None:
+            text = K_or_text
+            enc = _ENC2 if alphabet.bits == 2 else _ENC4
+            v = 0
+            for ch in text.upper():
+                if ch not in enc:
+                    raise EncodeError(alphabet, ch, None, None)
+                v = (v << alphabet.bits) | enc[ch]
+            self.K = len(text)
+            N = n_coding_elements(self.K, alphabet.bits)
+            self.data = tuple((v >> (64 * (N - 1 - i))) & MASK64 for i in range(N))
+        else:
+            self.K = int(K_or_text)
+            self.data = tuple(int(x) for x in data)
+
+    def __len__(self):
+        return self.K
+
+    def __str__(self):
+        inv = _decode_table(self.alphabet)
+        b = self.alphabet.bits
+        v = 0
+        for w in self.data:
+            v = (v << 64) | w
+        return "".join(inv[(v >> (b * (self.K - 1 - t))) & ((1 << b) - 1)] for t in range(self.K))
+
+    def __repr__(self):
+        return f"{self.alphabet.kind} {self.K}-mer:\n{self}"
+
+    def _key(self):
+        return (self.alphabet.bits, self.K, self.data)
+
+    def __eq__(self, other):
+        return isinstance(other, Kmer) and self._key() == other._key()
+
+    def __hash__(self):
+        return hash(self._key())
+
+    def __lt__(self, other):  # same-K tuple comparison, src/kmer.jl:176-178,200
+        if self.alphabet.bits != other.alphabet.bits or self.K != other.K:
+            raise KmersError("kmers of different type are not ordered here")
+        return self.data < other.data
+
+    def __le__(self, other):
+        return self == other or self < other
+
+
+class _KmerFamily:
+    def __init__(self, alphabet_family):
+        self.fam = alphabet_family
+
+    def __getitem__(self, K):
+        alph = self.fam[2]
+
+        def make(text):
+            k = Kmer(alph, text)
+            if k.K != K:
+                raise KmersError("Length of sequence must be K elements to build Kmer")
+            return k
+        return make
+
+
+DNAKmer = _KmerFamily(DNAAlphabet)
+RNAKmer = _KmerFamily(RNAAlphabet)
+
+
+def mer(text, flag="d"):
+    """`mer"TAG"d` / `mer"UAG"r` literal (src/construction.jl:360-374); 2-bit alphabets."""
+    return Kmer(DNAAlphabet[2] if flag == "d" else RNAAlphabet[2], text)
+
+
+class KmerArray:
+    """Vector{Kmer{A,K,N}}: an (n, N) uint64 array in exactly the reference's memory layout."""
+
+    def __init__(self, alphabet, K, words):
+        self.alphabet, self.K = alphabet, K
+        self.N = n_coding_elements(K, alphabet.bits)
+        self.words = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1, max(1, self.N))
+
+    def __len__(self):
+        return self.words.shape[0]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return KmerArray(self.alphabet, self.K, self.words[i])
+        return Kmer(self.alphabet, self.K, self.words[i])
+
+    def __iter__(self):
+        for row in self.words:
+            yield Kmer(self.alphabet, self.K, row)
+
+    def __eq__(self, other):
+        if isinstance(other, KmerArray):
+            return (self.alphabet.bits, self.K) == (other.alphabet.bits, other.K) and \
+                np.array_equal(self.words, other.words)
+        return list(self) == list(other)
+
+    def tolist(self):
+        return list(self)
+
+
+# --------------------------------------------------------------------------------------------
+# iterators
+def _raise_encode(alphabet, seq, res):
+    sym = _decode_table(seq.alphabet)[res.err_enc] if seq.alphabet.bits == 4 else "?"
+    raise EncodeError(alphabet, sym, int(res.err_pos), int(res.err_enc))
+
+
+class _Parametric(type):
+    """`Iterator[params](seq)` stands for Julia's `Iterator{params}(seq)`."""
+
+    def __getitem__(cls, params):
+        if not isinstance(params, tuple):
+            params = (params,)
+        return lambda seq, ctx=None: cls(*cls._expand(params), seq, ctx=ctx)
+
+
+class AbstractKmerIterator(metaclass=_Parametric):
+    CHUNK = 1 << 20  # kmers per pass of the chunk-buffered `for x in it`
+
+    def __init__(self, alphabet, K, seq, ctx=None, stride=1):
+        if not isinstance(K, int):
+            raise KmersError("K must be an Int")          # FwKmers.jl:32
+        if K < 1:
+            raise KmersError("K must be at least 1")      # FwKmers.jl:33
+        if stride < 1:
+            raise KmersError("J must be at least 1")      # SpacedKmers.jl:30
+        self.alphabet, self.K, self.J = alphabet, K, stride
+        self.seq = _as_sequence(seq)
+        self.ctx = ctx or default_context()
+        self.N = n_coding_elements(K, alphabet.bits)
+        if not self.ctx.lib.kmers_supported(self.seq.alphabet.bits, alphabet.bits, K, stride):
+            raise UnsupportedError(
+                f"Kmer{{{alphabet},{K}}} from {self.seq.alphabet} is outside the kernels' coverage "
+                "(2-bit kmer alphabets, K <= 64)")
+
+    # Base.eltype (src/iterators/common.jl:13-15)
+    @property
+    def eltype(self):
+        return ("Kmer", self.alphabet, self.K, self.N)
+
+    def __len__(self):  # FwKmers.jl:40-43, SpacedKmers.jl:38-42
+        return int(self.ctx.lib.kmers_count(self.seq.len, self.K, self.J))
+
+    def _view(self, first_base, n_bases):
+        return _capi.Seq(self.seq.device_words(self.ctx), n_bases, first_base, first_base,
+                         self.seq.alphabet.bits, 0)
+
+    def _wrap(self, arrays, lo, hi):
+        raise NotImplementedError
+
+    def _run(self, view, n):
+        raise NotImplementedError
+
+    def _range(self, start_kmer, n):
+        """Compute kmers [start_kmer, start_kmer+n) of the iteration -> host arrays."""
+        first = start_kmer * self.J
+        nb = (n - 1) * self.J + self.K
+        return self._run(self._view(first, nb), n)
+
+    def collect(self):
+        n = len(self)
+        out, res = self._range(0, n) if n else (self._empty(), None)
+        if res is not None and res.status == _capi.E_ENCODE:
+            _raise_encode(self.alphabet, self.seq, res)
+        return self._wrap(out)
+
+    def __iter__(self):
+        """Chunk-buffered iteration with the reference's throw point: elements whose windows end
+        before the first ambiguous symbol are yielded, then EncodeError is raised."""
+        total, done = len(self), 0
+        while done < total:
+            n = min(self.CHUNK, total - done)
+            out, res = self._range(done, n)
+            if res.status == _capi.E_ENCODE:
+                bad0 = int(res.err_pos) - 1  # 0-based symbol index
+                good = self._yielded_before(bad0) - done
+                if good > 0:
+                    out, _ = self._range(done, good)
+                    yield from self._elements(self._wrap(out))
+                _raise_encode(self.alphabet, self.seq, res)
+            yield from self._elements(self._wrap(out))
+            done += n
+
+    def _yielded_before(self, bad0):
+        """Number of elements iterate() yields before it touches symbol bad0 (0-based)."""
+        if self.J >= self.K:  # element m touches only [mJ, mJ+K): the bad symbol sits in element bad0 // J
+            return bad0 // self.J
+        if bad0 < self.K:
+            return 0
+        return (bad0 - self.K) // self.J + 1  # rolling: element m needs every symbol below mJ+K
+
+    def _elements(self, wrapped):
+        return iter(wrapped)
+
+    def _host_out(self, n, width):
+        return np.zeros((n, width), dtype=np.uint64)
+
+    def _dev_out(self, n, width):
+        ptr = self.ctx.alloc(max(8, n * width * 8))
+        return ptr
+
+
+def _call_with_device_outputs(it, n, widths, call):
+    """Allocate device outputs, run `call(ptrs)`, copy back; returns (host arrays, Result)."""
+    ctx = it.ctx
+    ptrs = [ctx.alloc(max(8, n * w * 8)) for w in widths]
+    res = _capi.Result()
+    try:
+        rc = call(ptrs, res)
+        ctx.check(rc, type(it).__name__)
+        outs = []
+        for p, w in zip(ptrs, widths):
+            a = np.zeros((n, w), dtype=np.uint64)
+            if rc == _capi.OK and n:
+                ctx.d2h(a, p)
+            outs.append(a)
+    finally:
+        for p in ptrs:
+            ctx.free(p)
+    return outs, res
+
+
+class FwKmers(AbstractKmerIterator):
+    """FwKmers{A,K}(seq) (src/iterators/FwKmers.jl:28-115)."""
+    @staticmethod
+    def _expand(p):
+        return p  # (A, K)
+
+    def _empty(self):
+        return [np.zeros((0, self.N), dtype=np.uint64)]
+
+    def _run(self, view, n):
+        lib, h = self.ctx.lib, self.ctx.handle
+        return _call_with_device_outputs(
+            self, n, [self.N],
+            lambda ptrs, res: lib.kmers_fw(h, C.byref(view), self.K, self.alphabet.bits, ptrs[0], None,
+                                           _capi.MEM_DEVICE, C.byref(res)))
+
+    def _wrap(self, out):
+        return KmerArray(self.alphabet, self.K, out[0])
+
+
+class FwRvIterator(AbstractKmerIterator):
+    """FwRvIterator{A,K}(seq): (forward, reverse_complement) pairs (CanonicalKmers.jl:25-144)."""
+    @staticmethod
+    def _expand(p):
+        return p
+
+    def _empty(self):
+        return [np.zeros((0, self.N), dtype=np.uint64)] * 2
+
+    def _run(self, view, n):
+        lib, h = self.ctx.lib, self.ctx.handle
+        return _call_with_device_outputs(
+            self, n, [self.N, self.N],
+            lambda ptrs, res: lib.kmers_fw(h, C.byref(view), self.K, self.alphabet.bits, ptrs[0], ptrs[1],
+                                           _capi.MEM_DEVICE, C.byref(res)))
+
+    def _wrap(self, out):
+        return (KmerArray(self.alphabet, self.K, out[0]), KmerArray(self.alphabet, self.K, out[1]))
+
+    def _elements(self, wrapped):
+        return zip(iter(wrapped[0]), iter(wrapped[1]))
+
+    def collect(self):
+        fw, rv = super().collect()
+        return list(zip(fw, rv))
+
+
+class CanonicalKmers(AbstractKmerIterator):
+    """CanonicalKmers{A,K}(seq): fw < rv ? fw : rv (CanonicalKmers.jl:199-225)."""
+    @staticmethod
+    def _expand(p):
+        return p
+
+    def _empty(self):
+        return [np.zeros((0, self.N), dtype=np.uint64)]
+
+    def _run(self, view, n):
+        lib, h = self.ctx.lib, self.ctx.handle
+        return _call_with_device_outputs(
+            self, n, [self.N],
+            lambda ptrs, res: lib.kmers_canonical(h, C.byref(view), self.K, self.alphabet.bits, ptrs[0], None, 0,
+                                                  _capi.MEM_DEVICE, C.byref(res)))
+
+    def _wrap(self, out):
+        return KmerArray(self.alphabet, self.K, out[0])
+
+    def collect_with_hashes(self, seed=0):
+        """collect(it) together with fx_hash.(kmers, seed) from the same pass (one fused kernel)."""
+        n = len(self)
+        if n == 0:
+            return KmerArray(self.alphabet, self.K, np.zeros((0, self.N), np.uint64)), np.zeros(0, np.uint64)
+        lib, h = self.ctx.lib, self.ctx.handle
+        view = self._view(0, self.seq.len)
+        out, res = _call_with_device_outputs(
+            self, n, [self.N, 1],
+            lambda ptrs, res: lib.kmers_canonical(h, C.byref(view), self.K, self.alphabet.bits, ptrs[0], ptrs[1],
+                                                  seed, _capi.MEM_DEVICE, C.byref(res)))
+        if res.status == _capi.E_ENCODE:
+            _raise_encode(self.alphabet, self.seq, res)
+        return KmerArray(self.alphabet, self.K, out[0]), out[1].reshape(-1)
+
+
+class SpacedKmers(AbstractKmerIterator):
+    """SpacedKmers{A,K,J}(seq) (src/iterators/SpacedKmers.jl:23-139), strict semantics."""
+
+    def __init__(self, alphabet, K, J, seq, ctx=None):
+        if not isinstance(J, int):
+            raise KmersError("J must be an Int")  # SpacedKmers.jl:29
+        super().__init__(alphabet, K, seq, ctx=ctx, stride=J)
+
+    @staticmethod
+    def _expand(p):
+        return p  # (A, K, J)
+
+    def _empty(self):
+        return [np.zeros((0, self.N), dtype=np.uint64)]
+
+    def _run(self, view, n):
+        lib, h = self.ctx.lib, self.ctx.handle
+        return _call_with_device_outputs(
+            self, n, [self.N],
+            lambda ptrs, res: lib.kmers_spaced(h, C.byref(view), self.K, self.J, self.alphabet.bits, ptrs[0],
+                                               _capi.MEM_DEVICE, C.byref(res)))
+
+    def _wrap(self, out):
+        return KmerArray(self.alphabet, self.K, out[0])
+
+
+class UnambiguousKmers(AbstractKmerIterator):
+    """UnambiguousKmers{A,K}(seq): (kmer, start) of every window without ambiguous symbols
+    (src/iterators/UnambiguousKmers.jl:29-148).  SizeUnknown unless the source is 2-bit (:33-37).
+    `stride` > 1 keeps the windows on the stride lattice (BASELINE.json config 5 skip variant)."""
+
+    def __init__(self, alphabet, K, seq, ctx=None, stride=1):
+        if alphabet.bits != 2:
+            raise KmersError("UnambiguousKmers needs a 2-bit kmer alphabet")  # A <: TwoBit, :29
+        super().__init__(alphabet, K, seq, ctx=ctx, stride=1)
+        self.lattice = stride
+
+    @staticmethod
+    def _expand(p):
+        return p
+
+    def __len__(self):
+        if self.seq.alphabet.bits == 2 and self.lattice == 1:
+            return super().__len__()
+        raise TypeError("UnambiguousKmers over a 4-bit source is SizeUnknown")  # :33
+
+    def collect(self):
+        lib, ctx = self.ctx.lib, self.ctx
+        view = self._view(0, self.seq.len)
+        res = _capi.Result()
+        ctx.check(lib.kmers_unambiguous(ctx.handle, C.byref(view), self.K, self.lattice, None, None, 0,
+                                        _capi.MEM_DEVICE, C.byref(res)), "kmers_unambiguous(count)")
+        n = int(res.n_out)
+        km = np.zeros((n, self.N), dtype=np.uint64)
+        st = np.zeros(n, dtype=np.int64)
+        if n:
+            pk, ps = ctx.alloc(km.nbytes), ctx.alloc(st.nbytes)
+            try:
+                ctx.check(lib.kmers_unambiguous(ctx.handle, C.byref(view), self.K, self.lattice, pk, ps, n,
+                                                _capi.MEM_DEVICE, C.byref(res)), "kmers_unambiguous")
+                ctx.d2h(km, pk)
+                ctx.d2h(st, ps)
+            finally:
+                ctx.free(pk)
+                ctx.free(ps)
+        return list(zip(KmerArray(self.alphabet, self.K, km), st.tolist()))
+
+    def __iter__(self):
+        return iter(self.collect())
+
+
+def _alias(cls, fam):
+    class _A:
+        def __getitem__(self, params):
+            if not isinstance(params, tuple):
+                params = (params,)
+            return lambda seq, ctx=None, **kw: cls(fam[2], *params, seq, ctx=ctx, **kw)
+    return _A()
+
+
+FwDNAMers = _alias(FwKmers, DNAAlphabet)                   # FwKmers.jl:48-49
+FwRNAMers = _alias(FwKmers, RNAAlphabet)                   # FwKmers.jl:51-52
+FwRvDNAIterator = _alias(FwRvIterator, DNAAlphabet)        # CanonicalKmers.jl:35-36
+FwRvRNAIterator = _alias(FwRvIterator, RNAAlphabet)        # CanonicalKmers.jl:38-39
+CanonicalDNAMers = _alias(CanonicalKmers, DNAAlphabet)     # CanonicalKmers.jl:214-215
+CanonicalRNAMers = _alias(CanonicalKmers, RNAAlphabet)     # CanonicalKmers.jl:217-218
+UnambiguousDNAMers = _alias(UnambiguousKmers, DNAAlphabet)  # UnambiguousKmers.jl:53-54
+UnambiguousRNAMers = _alias(UnambiguousKmers, RNAAlphabet)  # UnambiguousKmers.jl:56-57
+SpacedDNAMers = _alias(SpacedKmers, DNAAlphabet)           # SpacedKmers.jl:46-47
+SpacedRNAMers = _alias(SpacedKmers, RNAAlphabet)           # SpacedKmers.jl:49-50
+
+
+def each_codon(seq, ctx=None):
+    """each_codon(s::BioSequence) (SpacedKmers.jl:80-81)."""
+    fam = RNAAlphabet if seq.alphabet.kind == "RNA" else DNAAlphabet
+    return SpacedKmers(fam[2], 3, 3, seq, ctx=ctx)
+
+
+def collect(it):
+    return it.collect()
+
+
+# --------------------------------------------------------------------------------------------
+# element-wise functions (Kmer or KmerArray)
+def _batch(x):
+    if isinstance(x, Kmer):
+        return KmerArray(x.alphabet, x.K, np.array([x.data], dtype=np.uint64).reshape(1, -1)), True
+    return x, False
+
+
+def fx_hash(x, h=0, ctx=None):
+    """fx_hash(x::Kmer, h::UInt) (src/kmer.jl:255-261) for one Kmer or a KmerArray."""
+    ctx = ctx or default_context()
+    arr, single = _batch(x)
+    n = len(arr)
+    out = np.zeros(max(n, 1), dtype=np.uint64)
+    words = arr.words if arr.N else np.zeros(1, dtype=np.uint64)
+    ctx.check(ctx.lib.kmers_fx_hash(ctx.handle, words.ctypes.data_as(C.c_void_p), arr.N, n, h & MASK64,
+                                    out.ctypes.data_as(C.c_void_p), _capi.MEM_HOST), "kmers_fx_hash")
+    return int(out[0]) if single else out[:n]
+
+
+def _transform(op, x, ctx=None):
+    ctx = ctx or default_context()
+    arr, single = _batch(x)
+    n = len(arr)
+    width = 1 if op == _capi.OP_ISCANONICAL else arr.N
+    out = np.zeros((max(n, 1), width), dtype=np.uint64)
+    if n:
+        ctx.check(ctx.lib.kmers_transform(ctx.handle, op, arr.words.ctypes.data_as(C.c_void_p), arr.K,
+                                          arr.alphabet.bits, n, out.ctypes.data_as(C.c_void_p),
+                                          _capi.MEM_HOST), "kmers_transform")
+    if op == _capi.OP_ISCANONICAL:
+        return bool(out[0, 0]) if single else out[:n, 0].astype(bool)
+    res = KmerArray(arr.alphabet, arr.K, out[:n])
+    return res[0] if single else res
+
+
+def reverse(x, ctx=None):
+    return _transform(_capi.OP_REVERSE, x, ctx)             # transformations.jl:1-10
+
+
+def complement(x, ctx=None):
+    return _transform(_capi.OP_COMPLEMENT, x, ctx)          # transformations.jl:14-25
+
+
+def reverse_complement(x, ctx=None):
+    return _transform(_capi.OP_REVCOMP, x, ctx)             # transformations.jl:32-34
+
+
+def canonical(x, ctx=None):
+    return _transform(_capi.OP_CANONICAL, x, ctx)           # transformations.jl:36-39
+
+
+def iscanonical(x, ctx=None):
+    return _transform(_capi.OP_ISCANONICAL, x, ctx)         # transformations.jl:41
+
+
+def as_integer(x):
+    """as_integer(x::Kmer) (src/kmer.jl:305-326): the on-wire integer form (<= 128 bits)."""
+    if x.K * x.alphabet.bits > 128:
+        raise KmersError("Must have at most 128 bits in encoding")
+    v = 0
+    for w in x.data:
+        v = (v << 64) | w
+    return v
+
+
+def from_integer(alphabet, K, u):
+    """from_integer(T, u) (src/kmer.jl:361-384): only the low K*bits bits of u are used."""
+    bits = K * alphabet.bits
+    if bits > 128:
+        raise KmersError("Kmer type must contain at most 128 bits")
+    u &= (1 << bits) - 1 if bits else 0
+    N = n_coding_elements(K, alphabet.bits)
+    return Kmer(alphabet, K, tuple((u >> (64 * (N - 1 - i))) & MASK64 for i in range(N)))

@@ -1,0 +1,346 @@
+"""GPU parity tests proper: HIP kernels through the C ABI (libkmers_hip.so) vs the CPU oracle on
+the same seeded inputs, bit-exact (all arithmetic is unsigned 64-bit integer).  Run with -m gpu."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import naive
+
+pytestmark = pytest.mark.gpu
+
+KS = [1, 2, 5, 16, 21, 31, 32, 33, 47, 63, 64]
+
+
+@pytest.fixture(scope="module")
+def km():
+    import kmers_jl_amd
+    return kmers_jl_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(km):
+    c = km.Context(0)
+    yield c
+    c.close()
+
+
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_seq(km, words, n_bases, bits, first_base=0, origin=0):
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    return km._capi.Seq(words.ctypes.data, n_bases, first_base, origin, bits, 0), words
+
+
+def run_canonical(km, ctx, words, L, bits, K, seed=0, first_base=0, device=False):
+    cap = km._capi
+    N = (2 * K + 63) // 64
+    n = max(0, L - K + 1)
+    kmers = np.zeros((max(n, 1), N), dtype=np.uint64)
+    hashes = np.zeros(max(n, 1), dtype=np.uint64)
+    res = cap.Result()
+    if not device:
+        seq, keep = make_seq(km, words, L, bits, first_base)
+        rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, vp(kmers), vp(hashes), seed, cap.MEM_HOST,
+                                     C.byref(res))
+    else:
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        dw = ctx.alloc(words.nbytes + 8)
+        dk, dh = ctx.alloc(kmers.nbytes), ctx.alloc(hashes.nbytes)
+        ctx.h2d(dw, words)
+        seq = cap.Seq(dw, L, first_base, 0, bits, 0)
+        rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, dk, dh, seed, cap.MEM_DEVICE, C.byref(res))
+        if rc == 0 and n:
+            ctx.d2h(kmers, dk)
+            ctx.d2h(hashes, dh)
+        for p in (dw, dk, dh):
+            ctx.free(p)
+    return rc, kmers[:n], hashes[:n], res
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+@pytest.mark.parametrize("device", [False, True])
+def test_canonical_hash_parity(km, ctx, orc, bits, device):
+    """CanonicalDNAMers{K} + fx_hash vs oracle (CanonicalKmers.jl:131-144,:220-225; kmer.jl:255-261)."""
+    for K in KS:
+        for L in (0, K - 1, K, K + 1, 97, 4096 + K - 1, 4096 + K, 70001):
+            if L < 0:
+                continue
+            seed = (K * 1315423911 + L) & (2**64 - 1)
+            nwords = (L * bits + 63) // 64 + 1
+            words = orc.synth_words(1234 + K, 3, nwords, bits)
+            rc, kmers, hashes, res = run_canonical(km, ctx, words, L, bits, K, seed, device=device)
+            assert rc == 0, (K, L, ctx.last_error())
+            ek, eh, eres = orc.canonical(words, L, bits, 2, K, seed=seed)
+            assert res.n_out == eres.n_out == len(ek)
+            assert np.array_equal(kmers, ek), (K, L)
+            assert np.array_equal(hashes, eh), (K, L)
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+def test_fw_and_revcomp_parity(km, ctx, orc, bits):
+    """FwKmers / FwRvIterator (FwKmers.jl:88-115, CanonicalKmers.jl:94-144) incl. two-word kmers."""
+    cap = km._capi
+    for K in KS:
+        N = (2 * K + 63) // 64
+        for L in (K, K + 7, 5000, 40000):
+            words = orc.synth_words(99 + K, 0, (L * bits + 63) // 64 + 1, bits)
+            n = L - K + 1
+            fw = np.zeros((n, N), dtype=np.uint64)
+            rv = np.zeros((n, N), dtype=np.uint64)
+            res = cap.Result()
+            seq, keep = make_seq(km, words, L, bits)
+            rc = ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, vp(fw), vp(rv), cap.MEM_HOST, C.byref(res))
+            assert rc == 0
+            efw, erv, _ = orc.fwrv(words, L, bits, 2, K)
+            assert np.array_equal(fw, efw), (K, L)
+            assert np.array_equal(rv, erv), (K, L)
+            fw2 = np.zeros((n, N), dtype=np.uint64)
+            rc = ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, vp(fw2), None, cap.MEM_HOST, C.byref(res))
+            assert rc == 0 and np.array_equal(fw2, efw)
+
+
+def test_offset_views(km, ctx, orc):
+    """first_base != 0 (LongSubSeq / halo shards): same result as the oracle on the re-packed view."""
+    cap = km._capi
+    rng = np.random.default_rng(3)
+    text = naive.random_text(rng, 9000)
+    for bits in (2, 4):
+        words = naive.longseq_words(text, bits)
+        for first in (0, 1, 15, 16, 17, 31, 33, 1000, 4097):
+            for K in (3, 31, 33):
+                L = len(text) - first - 5
+                rc, kmers, hashes, res = run_canonical(km, ctx, words, L, bits, K, 7, first_base=first)
+                assert rc == 0
+                sub = naive.longseq_words(text[first:first + L], bits)
+                ek, eh, _ = orc.canonical(sub, L, bits, 2, K, seed=7)
+                assert np.array_equal(kmers, ek), (bits, first, K)
+                assert np.array_equal(hashes, eh)
+
+
+def test_encode_errors_match_oracle(km, ctx, orc):
+    """First offending symbol (position and raw encoding) exactly as the reference would throw
+    (construction.jl:108-110; raise sites FwKmers.jl:112, CanonicalKmers.jl:139)."""
+    cap = km._capi
+    rng = np.random.default_rng(21)
+    for K in (1, 3, 31, 33):
+        for L in (K, 500, 20000):
+            for trial in range(4):
+                text = list(naive.random_text(rng, L))
+                nbad = int(rng.integers(1, 4))
+                for p in rng.integers(0, L, size=nbad):
+                    text[p] = "NMRWSYKVHDB-"[int(rng.integers(0, 12))]
+                text = "".join(text)
+                words = naive.longseq_words(text, 4)
+                rc, _, _, res = run_canonical(km, ctx, words, L, 4, K)
+                _, _, eres = orc.canonical(words, L, 4, 2, K)
+                assert rc == cap.E_ENCODE and eres.status == 1
+                assert (res.err_pos, res.err_enc) == (eres.err_pos, eres.err_enc), (K, L, text[:40])
+                # the context is usable again and clean inputs pass
+                rc, kmers, _, res = run_canonical(km, ctx, naive.longseq_words("ACGT" * 20, 4), 80, 4, min(K, 31))
+                assert rc == 0 and res.status == 0
+    # garbage beyond `len` in the last word is not inspected; L < K inspects nothing (FwKmers.jl:63)
+    words = naive.longseq_words("ACGTACGTAC" + "N" * 6, 4)
+    rc, kmers, _, res = run_canonical(km, ctx, words, 10, 4, 4)
+    assert rc == 0 and len(kmers) == 7
+    rc, kmers, _, res = run_canonical(km, ctx, naive.longseq_words("NN", 4), 2, 4, 3)
+    assert rc == 0 and res.n_out == 0
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+def test_spaced_parity(km, ctx, orc, bits):
+    """SpacedKmers{A,K,J} (SpacedKmers.jl:38-42, :92-139): tile path (J <= 32) and gather path."""
+    cap = km._capi
+    for K, J in [(3, 2), (2, 4), (3, 3), (4, 3), (21, 3), (31, 7), (33, 5), (64, 32), (5, 40), (31, 31), (31, 33),
+                 (63, 100)]:
+        for L in (K - 1, K, K + J, 10 * K + 3 * J + 1, 30011):
+            words = orc.synth_words(5 + J, 1, (L * bits + 63) // 64 + 1, bits)
+            n = 0 if L < K else (L - K) // J + 1
+            N = (2 * K + 63) // 64
+            out = np.zeros((max(n, 1), N), dtype=np.uint64)
+            res = cap.Result()
+            seq, keep = make_seq(km, words, L, bits)
+            rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, 2, vp(out), cap.MEM_HOST, C.byref(res))
+            assert rc == 0, (K, J, L, ctx.last_error())
+            ek, eres = orc.spaced(words, L, bits, 2, K, J)
+            assert res.n_out == n == len(ek)
+            assert np.array_equal(out[:n], ek), (K, J, L)
+
+
+def test_spaced_error_semantics(km, ctx, orc):
+    """J < K: every symbol up to the end of the last kmer is inspected; J >= K: gaps are not
+    (SpacedKmers.jl:133-137; test/runtests.jl:868-869)."""
+    cap = km._capi
+    rng = np.random.default_rng(17)
+    for K, J in [(3, 2), (21, 3), (3, 4), (5, 9), (31, 31), (4, 50)]:
+        for L in (K, K + J, 200, 9000):
+            for p in (0.002, 0.05):
+                text = naive.random_text(rng, L, p_amb=p)
+                words = naive.longseq_words(text, 4)
+                n = 0 if L < K else (L - K) // J + 1
+                out = np.zeros((max(n, 1), 1), dtype=np.uint64)
+                res = cap.Result()
+                seq, keep = make_seq(km, words, L, 4)
+                rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, 2, vp(out), cap.MEM_HOST, C.byref(res))
+                ek, eres = orc.spaced(words, L, 4, 2, K, J)
+                if eres.status == 0:
+                    assert rc == 0 and np.array_equal(out[:n], ek)
+                else:
+                    assert rc == cap.E_ENCODE
+                    assert (res.err_pos, res.err_enc) == (eres.err_pos, eres.err_enc), (K, J, L)
+    # the reference's own case: SpacedDNAMers{3,4}("TAGAWWWW") throws at W (position 5)
+    words = naive.longseq_words("TAGAWWWW", 4)
+    seq, keep = make_seq(km, words, 8, 4)
+    out = np.zeros((2, 1), dtype=np.uint64)
+    res = cap.Result()
+    rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), 3, 4, 2, vp(out), cap.MEM_HOST, C.byref(res))
+    assert rc == cap.E_ENCODE and res.err_pos == 5 and res.err_enc == naive.DNA4["W"]
+
+
+def run_unambiguous(km, ctx, words, L, bits, K, stride=1, origin=0):
+    cap = km._capi
+    res = cap.Result()
+    seq, keep = make_seq(km, words, L, bits, 0, origin)
+    rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, stride, None, None, 0, cap.MEM_HOST, C.byref(res))
+    assert rc == 0
+    n = int(res.n_out)
+    N = (2 * K + 63) // 64
+    kmers = np.zeros((max(n, 1), N), dtype=np.uint64)
+    starts = np.zeros(max(n, 1), dtype=np.int64)
+    rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, stride, vp(kmers), vp(starts), n, cap.MEM_HOST,
+                                   C.byref(res))
+    assert rc == 0 and res.n_out == n
+    return kmers[:n], starts[:n]
+
+
+def test_unambiguous_parity(km, ctx, orc):
+    """UnambiguousKmers (UnambiguousKmers.jl:64-77, :134-148): windows and 1-based starts."""
+    rng = np.random.default_rng(31)
+    for K in (1, 3, 21, 31, 32, 33, 64):
+        for L in (K - 1, K, 300, 5000, 33000):
+            if L < 0:
+                continue
+            for p in (0.0, 0.04, 0.4):
+                text = naive.random_text(rng, L, p_amb=p)
+                words = naive.longseq_words(text, 4)
+                kmers, starts = run_unambiguous(km, ctx, words, L, 4, K)
+                ek, es, _ = orc.unambiguous(words, L, 4, K)
+                assert np.array_equal(kmers, ek), (K, L, p)
+                assert np.array_equal(starts, es), (K, L, p)
+            text = naive.random_text(rng, L)
+            words = naive.longseq_words(text, 2)
+            kmers, starts = run_unambiguous(km, ctx, words, L, 2, K)
+            ek, es, _ = orc.unambiguous(words, L, 2, K)
+            assert np.array_equal(kmers, ek) and np.array_equal(starts, es)
+
+
+def test_spaced_skip_variant(km, ctx, orc):
+    """BASELINE.json config 5 "with ambiguous-base skip" = the elements (kmer, i) of
+    UnambiguousDNAMers{K}(seq) with (i-1) % J == 0 (docs/src/faq.md:28-33)."""
+    rng = np.random.default_rng(37)
+    for K, J in [(21, 3), (5, 2), (31, 7)]:
+        L = 20000
+        text = naive.random_text(rng, L, p_amb=0.04)
+        words = naive.longseq_words(text, 4)
+        kmers, starts = run_unambiguous(km, ctx, words, L, 4, K, stride=J)
+        ek, es, _ = orc.unambiguous(words, L, 4, K)
+        keep = (es - 1) % J == 0
+        assert np.array_equal(kmers, ek[keep]) and np.array_equal(starts, es[keep])
+        # equals strict Spaced output on windows without ambiguity
+        clean = "".join(c if c in "ACGT" else "A" for c in text)
+        exp = [w for w, i in zip(naive.spaced(clean, K, J, 2), range(0, L, J))
+               if naive.is_certain(text[i:i + K])]
+        assert [tuple(int(x) for x in r) for r in kmers] == exp
+
+
+def test_capacity_error(km, ctx):
+    cap = km._capi
+    words = naive.longseq_words("ACGTACGTACGT", 4)
+    seq, keep = make_seq(km, words, 12, 4)
+    kmers = np.zeros((2, 1), dtype=np.uint64)
+    starts = np.zeros(2, dtype=np.int64)
+    res = cap.Result()
+    rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), 3, 1, vp(kmers), vp(starts), 2, cap.MEM_HOST,
+                                   C.byref(res))
+    assert rc == cap.E_CAPACITY and res.n_out == 10
+
+
+def test_reduce_xor(km, ctx, orc):
+    """Fused consumer of test/benchmark.jl:9-15."""
+    cap = km._capi
+    for bits in (2, 4):
+        for K in (7, 31, 33):
+            L = 100003
+            words = orc.synth_words(77, 0, (L * bits + 63) // 64 + 1, bits)
+            seq, keep = make_seq(km, words, L, bits)
+            val = C.c_uint64()
+            res = cap.Result()
+            rc = ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, 2, 1, C.byref(val), cap.MEM_HOST,
+                                          C.byref(res))
+            assert rc == 0
+            exp, _ = orc.reduce_xor_canonical(words, L, bits, 2, K)
+            assert val.value == exp
+            rc = ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, 2, 0, C.byref(val), cap.MEM_HOST,
+                                          C.byref(res))
+            fw, _ = orc.fw_kmers(words, L, bits, 2, K)
+            assert rc == 0 and val.value == int(np.bitwise_xor.reduce(fw[:, 0]))
+
+
+def test_batch_fx_hash_and_transforms(km, ctx, orc):
+    """fx_hash and reverse/complement/reverse_complement/canonical/iscanonical on kmer arrays
+    (kmer.jl:255-261; transformations.jl:1-41)."""
+    cap = km._capi
+    rng = np.random.default_rng(41)
+    for bits in (2, 4):
+        for K in (1, 7, 16, 31, 32, 33, 47, 63, 64, 96, 128):
+            N = (K * bits + 63) // 64
+            if N > 4:
+                continue
+            n = 300
+            texts = [naive.random_text(rng, K, p_amb=0.2 if bits == 4 else 0.0) for _ in range(n)]
+            arr = np.array([naive.kmer_words(t, bits) for t in texts], dtype=np.uint64).reshape(n, N)
+            out = np.zeros(n, dtype=np.uint64)
+            rc = ctx.lib.kmers_fx_hash(ctx.handle, vp(arr), N, n, 99, vp(out), cap.MEM_HOST)
+            assert rc == 0
+            assert out.tolist() == [naive.fx_hash(r, 99) for r in arr.tolist()]
+            for op, fn in ((cap.OP_REVERSE, orc.reverse), (cap.OP_COMPLEMENT, orc.complement),
+                           (cap.OP_REVCOMP, orc.reverse_complement), (cap.OP_CANONICAL, orc.canonical_kmer)):
+                res = np.zeros((n, N), dtype=np.uint64)
+                rc = ctx.lib.kmers_transform(ctx.handle, op, vp(arr), K, bits, n, vp(res), cap.MEM_HOST)
+                assert rc == 0
+                exp = [fn(tuple(r), K, bits) for r in arr.tolist()]
+                assert [tuple(r) for r in res.tolist()] == exp, (bits, K, op)
+            flags = np.zeros(n, dtype=np.uint64)
+            rc = ctx.lib.kmers_transform(ctx.handle, cap.OP_ISCANONICAL, vp(arr), K, bits, n, vp(flags), cap.MEM_HOST)
+            assert rc == 0
+            assert flags.astype(bool).tolist() == [orc.iscanonical(tuple(r), K, bits) for r in arr.tolist()]
+
+
+def test_synth_generator_matches_oracle(km, ctx, orc):
+    for bits in (2, 4):
+        for amb in (0, 2621):
+            if bits == 2 and amb:
+                continue
+            n = 5000
+            d = ctx.alloc(n * 8)
+            rc = ctx.lib.kmers_synth_dna(ctx.handle, 0xABCDEF, 12345, n, bits, amb, d)
+            assert rc == 0
+            got = np.zeros(n, dtype=np.uint64)
+            ctx.d2h(got, d)
+            ctx.free(d)
+            assert np.array_equal(got, orc.synth_words(0xABCDEF, 12345, n, bits, amb))
+
+
+def test_bad_arguments(km, ctx):
+    cap = km._capi
+    words = naive.longseq_words("ACGTACGT", 4)
+    seq, keep = make_seq(km, words, 8, 4)
+    out = np.zeros((8, 1), dtype=np.uint64)
+    res = cap.Result()
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 0, 2, vp(out), None, 0, C.byref(res)) == cap.E_BADARG
+    assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), 3, 0, 2, vp(out), 0, C.byref(res)) == cap.E_BADARG
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 65, 2, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 4, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 2, vp(out), None, cap.ASYNC, C.byref(res)) == cap.E_BADARG
