@@ -17,7 +17,7 @@ struct CompactArgs {
     uint64_t first_bit;
     uint64_t n_cand;          // candidate starts = n_bases - K + 1
     uint64_t n_tiles;
-    uint32_t *counts;         // [n_tiles * 4] per (tile, wave)
+    uint32_t *counts;         // [n_tiles * WAVES] per (tile, wave)
     const uint64_t *offsets;  // exclusive scan of counts
     uint64_t *out_kmers;      // nullable
     long long *out_starts;    // nullable
@@ -61,11 +61,11 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
         }
         __syncthreads();
 
-        const uint32_t per_wave = a.tile_kmers / 4;
+        const uint32_t per_wave = a.tile_kmers / WAVES;
         const uint32_t r_begin = wave * per_wave;
         const uint32_t r_end = r_begin + per_wave < mt ? r_begin + per_wave : mt;
         uint64_t pos = 0;
-        if constexpr (EMIT) pos = a.offsets[tile * 4 + wave];
+        if constexpr (EMIT) pos = a.offsets[tile * WAVES + wave];
         uint32_t count = 0;
         const uint32_t passes = r_end > r_begin ? (r_end - r_begin + 63u) / 64u : 0u;  // wave-uniform
         for (uint32_t p = 0; p < passes; ++p) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
             }
         }
         if constexpr (!EMIT) {
-            if (lane == 0) a.counts[tile * 4 + wave] = count;
+            if (lane == 0) a.counts[tile * WAVES + wave] = count;
         }
     }
 }

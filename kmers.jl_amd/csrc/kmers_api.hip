@@ -144,13 +144,26 @@ void remember_source(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st) {
     ctx->err_bits = seq->src_bits;
 }
 
+// Default tile: about 16 KiB of output per workgroup (four 16-byte stores per lane), one tile
+// per workgroup.  Measured on MI355X (profiles/r01_tuning.md): shorter workgroups are bound by
+// workgroup launch + the exposed source-load latency, longer ones and persistent grid-stride
+// loops lose 10-20 % of the HBM write rate.
+static uint32_t default_tile(uint32_t out_bytes_per_kmer, uint32_t pass) {
+    uint32_t t = (16384u / std::max<uint32_t>(out_bytes_per_kmer, 1u)) / pass * pass;
+    return std::max<uint32_t>(pass, t);
+}
+
 template <int MODE>
 int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int n_words, bool vec_ok) {
     const uint32_t J = a.stride;
     const bool stride1 = (J == 1) && vec_ok;
-    uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : 4096u;
+    const uint32_t pass = (stride1 && n_words == 1 ? 2u : 1u) * BLOCK;  // kmers per workgroup pass
+    uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
+                         (MODE == MODE_CANON && a.out_b ? 8u : 0u);
+    if (MODE == MODE_XOR) out_bytes = 4u;  // nothing stored: long tiles
+    uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
     if (J > 1) tile = std::min<uint32_t>(tile, (uint32_t)(MAX_TILE_BASES / J));
-    tile = std::max<uint32_t>(512u, tile & ~511u);
+    tile = std::max<uint32_t>(pass, tile / pass * pass);
     if ((uint64_t)(tile - 1) * J + 1 > (uint64_t)MAX_TILE_BASES) return fail(ctx, KMERS_E_UNSUPPORTED, "stride too large for the tile kernel");
     a.tile_kmers = tile;
     a.n_tiles = (a.n_kmers + tile - 1) / tile;
@@ -263,10 +276,10 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.stride = (uint32_t)stride;
     a.index_origin = seq->index_origin;
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : 4096u;
-    tile = std::max<uint32_t>(512u, std::min<uint32_t>(tile, (uint32_t)MAX_TILE_BASES) & ~511u);
+    tile = std::max<uint32_t>(2u * BLOCK, std::min<uint32_t>(tile, (uint32_t)MAX_TILE_BASES) / (2u * BLOCK) * (2u * BLOCK));
     a.tile_kmers = tile;
     a.n_tiles = (n + tile - 1) / tile;
-    const uint64_t n_counts = a.n_tiles * 4;
+    const uint64_t n_counts = a.n_tiles * WAVES;
     // scratch: counts (u32) then offsets (u64, n_counts + 1)
     size_t counts_bytes = ((size_t)n_counts * 4 + 15) & ~(size_t)15;
     if (int rc = ensure_stage(ctx, 3, counts_bytes + ((size_t)n_counts + 1) * 8)) return rc;

@@ -15,7 +15,11 @@
 
 namespace kmers {
 
-constexpr int BLOCK = 256;
+#ifndef KMERS_BLOCK
+#define KMERS_BLOCK 256
+#endif
+constexpr int BLOCK = KMERS_BLOCK;             // threads per workgroup (multiple of 64)
+constexpr int WAVES = BLOCK / 64;
 constexpr int MAX_TILE_BASES = 16384;          // bases of 2-bit stream a tile may span (excl. overlap)
 constexpr int LDS_QWORDS = MAX_TILE_BASES / 32 + 16;
 
@@ -42,6 +46,7 @@ struct StreamArgs {
 // inline and call-free so the kernel needs no stack).  Inspected set = what the reference's
 // iterate() would have looked at before stopping: every symbol below inspect_end, except
 // (stride >= K) the gaps between kmers (src/iterators/SpacedKmers.jl:133-134).
+template <bool STRIDE1>
 __device__ __forceinline__ void report_ambiguous(unsigned long long *err_slot, uint64_t first_bit,
                                                  uint64_t inspect_end, uint32_t stride, uint32_t k,
                                                  uint64_t word_index, uint64_t bad) {
@@ -53,9 +58,12 @@ __device__ __forceinline__ void report_ambiguous(unsigned long long *err_slot, u
     const long long room = (long long)inspect_end - base0;  // symbols of this word below inspect_end
     if (room <= 0) return;
     if (room < 16) f &= (1ull << (uint32_t)(room * 4)) - 1ull;
-    if (stride >= k) {
-        for (uint32_t j = 0; j < 16; ++j)
-            if (((f >> (4 * j)) & 1ull) && ((uint64_t)(base0 + j) % stride) >= k) f &= ~(1ull << (4 * j));
+    if constexpr (!STRIDE1) {  // stride 1 has no gaps
+        if (stride >= k) {
+#pragma unroll 1
+            for (uint32_t j = 0; j < 16; ++j)
+                if (((f >> (4 * j)) & 1ull) && ((uint64_t)(base0 + j) % stride) >= k) f &= ~(1ull << (4 * j));
+        }
     }
     if (f) atomicMin(err_slot, (unsigned long long)(base0 + (long long)(__ffsll((long long)f) - 1) / 4));
 }
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
                 uint64_t bad;
                 uint32_t c = pack_4to2(x, bad);
                 reinterpret_cast<uint32_t *>(lds)[wi] = c;
-                if (bad) report_ambiguous(a.err_slot, a.first_bit, a.inspect_end, a.stride, k, w0 + wi, bad);
+                if (bad) report_ambiguous<STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, k, w0 + wi, bad);
             } else {
                 lds[wi] = x;
             }
