@@ -72,23 +72,25 @@ def cpu_baseline(k, bits, seed, total_bases, budget_s=12.0, chunk_bases=1 << 24)
            "sample": f"{done / 1e6:.0f} Mbase of the same synthetic LongDNA{{{bits}}} in {chunk_bases >> 20} Mi-base chunks, "
                      f"CanonicalDNAMers{{{k}}} + fx_hash materialised, 1 thread (the reference is single-threaded), "
                      f"C restatement of Kmers.jl (Julia absent from the image), gcc -O3 -march=native"}
-    # all host cores: contiguous chunks, one per thread (ctypes releases the GIL)
+    # all host cores: contiguous 1 Mi-base chunks, one stream per thread (ctypes releases the GIL)
     try:
         from concurrent.futures import ThreadPoolExecutor
         ncpu = len(os.sched_getaffinity(0))
-        bufs = [(np.zeros((chunk_bases, 1), np.uint64), np.zeros(chunk_bases, np.uint64)) for _ in range(ncpu)]
-        inputs = [orc.synth_words(seed, c * chunk_bases // per_word, chunk_bases // per_word + 1, bits)
-                  for c in range(ncpu)]
-        reps = max(1, int(4.0 / max(spent / max(done // chunk_bases, 1), 1e-3)))
+        small = 1 << 20
+        bufs = [(np.zeros((small, 1), np.uint64), np.zeros(small, np.uint64)) for _ in range(ncpu)]
+        inputs = [orc.synth_words(seed, c * small // per_word, small // per_word + 1, bits) for c in range(ncpu)]
+        rate1 = done / spent
+        reps = max(1, int(3.0 * rate1 / small))  # about 3 s per thread at the single-thread rate
 
         def work(i):
             for _ in range(reps):
-                orc.canonical(inputs[i], chunk_bases, bits, 2, k, seed=0, out=bufs[i][0], out_h=bufs[i][1])
+                orc.canonical(inputs[i], small, bits, 2, k, seed=0, out=bufs[i][0], out_h=bufs[i][1])
         t0 = time.perf_counter()
         with ThreadPoolExecutor(ncpu) as ex:
             list(ex.map(work, range(ncpu)))
         dt = time.perf_counter() - t0
-        one["all_cores"] = {"value": round(ncpu * reps * chunk_bases / dt / 1e9, 4), "unit": "Gbases/s", "cores": ncpu}
+        one["all_cores"] = {"value": round(ncpu * reps * small / dt / 1e9, 4), "unit": "Gbases/s", "cores": ncpu,
+                            "sample": f"{ncpu} threads x {reps} x 1 Mi-base chunks"}
     except Exception as e:  # the single-thread figure is the contract; this one is a bonus
         one["all_cores"] = {"error": str(e)}
     return one
@@ -116,16 +118,24 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the k-mer kernels have no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev  # one rank per GPU; wraps only in the 1-GPU debug mode below
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm.  KMERS_BENCH_BACKEND=gloo exists only to exercise the multi-rank
+        # logic on a 1-GPU box (ranks share the device; not a measurement).
+        backend = os.environ.get("KMERS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import kmers_jl_amd as km
-    from kmers_jl_amd.shard import exchange_halo, plan_shards
+    from kmers_jl_amd.shard import HaloExchanger, plan_shards
     cap = km._capi
-    ctx = km.Context(local_rank)
+    ctx = km.Context(dev_index)
     stream = torch.cuda.ExternalStream(ctx.lib.kmers_ctx_stream(ctx.handle), device=dev)
     if args.tile:
         ctx.set_param(cap.PARAM_TILE_KMERS, args.tile)
@@ -145,6 +155,7 @@ def main():
                   "kmers_synth_dna")
         out_k = torch.empty(sh.n_kmers * N, dtype=torch.int64, device=dev)
         out_h = None if args.no_hash else torch.empty(sh.n_kmers, dtype=torch.int64, device=dev)
+    halo = HaloExchanger(buf, sh, plan)
     seq = cap.Seq(buf.data_ptr(), sh.n_bases, 0, sh.first_kmer, bits, 0)
     res = cap.Result()
     flags = cap.MEM_DEVICE | cap.ASYNC
@@ -153,7 +164,7 @@ def main():
     def step(ev=None):
         with torch.cuda.stream(stream):
             if world > 1:
-                exchange_halo(buf, sh)
+                halo.exchange()
             if ev:
                 ev[0].record(stream)
             rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, out_k.data_ptr(), ph, 0, flags, C.byref(res))
@@ -240,7 +251,7 @@ def main():
                                    if not args.no_hash else
                                    f"CanonicalDNAMers{{{K}}} over {args.bases / 1e9:g} Gbase LongDNA{{{bits}}} per GPU",
                        "k": K, "src_bits": bits, "bases_per_gpu": args.bases,
-                       "sharding": "contiguous kmer-start ranges, (K-1)-base halo from rank+1 over RCCL each step"
+                       "sharding": f"contiguous kmer-start ranges, (K-1)-base halo from rank+1 over RCCL each step ({halo.transport})"
                                    if world > 1 else "single shard",
                        "seed": hex(seed)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

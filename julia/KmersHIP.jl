@@ -1,0 +1,239 @@
+# KmersHIP.jl -- the Julia side of the drop-in boundary: thin `@ccall` bindings of
+# include/kmers_hip.h plus the methods that route Kmers.jl's own iterator API to them.
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: neither `julia` nor BioSequences.jl exist in the build
+# image (see DESIGN.md).  It is the binding a Kmers.jl maintainer would add (INTEGRATION.md); the
+# same mapping is exercised through ctypes by kmers.jl_amd/host.py and tests/.
+#
+# Usage:
+#     using Kmers, BioSequences, KmersHIP
+#     seq  = randdnaseq(10^9)                               # LongDNA{4}
+#     v    = collect(CanonicalDNAMers{31}(seq))             # Vector{DNAKmer{31,1}}, computed on the MI355X
+#     v, h = KmersHIP.collect_with_hashes(CanonicalDNAMers{31}(seq))   # + fx_hash of every element
+#     for kmer in KmersHIP.gpu(CanonicalDNAMers{31}(seq)) ... end      # chunk-buffered iterate()
+module KmersHIP
+
+using Kmers
+using BioSequences
+
+const LIB = get(ENV, "KMERS_HIP_LIB",
+                joinpath(@__DIR__, "..", "kmers.jl_amd", "csrc", "libkmers_hip.so"))
+
+# ---- mirror of the C structs (include/kmers_hip.h) ------------------------------------------
+struct CSeq
+    words::Ptr{UInt64}
+    n_bases::UInt64
+    first_base::UInt64
+    index_origin::UInt64
+    src_bits::Int32
+    reserved::Int32
+end
+
+mutable struct CResult
+    status::Int32
+    err_enc::UInt32
+    err_pos::UInt64
+    n_out::UInt64
+    CResult() = new(0, 0, 0, 0)
+end
+
+const OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY = Int32.(0:6)
+const MEM_HOST, MEM_DEVICE, ASYNC = Int32(0), Int32(1), Int32(2)
+
+# ---- context (one per Julia thread) --------------------------------------------------------
+mutable struct Context
+    handle::Ptr{Cvoid}
+    function Context(device::Integer = 0)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = @ccall LIB.kmers_ctx_create(device::Cint, C_NULL::Ptr{Cvoid}, h::Ptr{Ptr{Cvoid}})::Cint
+        rc == OK || error("kmers_ctx_create failed ($rc): no usable MI355X / HIP device")
+        ctx = new(h[])
+        finalizer(c -> (@ccall LIB.kmers_ctx_destroy(c.handle::Ptr{Cvoid})::Cvoid), ctx)
+        return ctx
+    end
+end
+
+const CONTEXTS = Dict{Int, Context}()
+context() = get!(() -> Context(0), CONTEXTS, Threads.threadid())
+last_error(ctx::Context) = unsafe_string(@ccall LIB.kmers_last_error(ctx.handle::Ptr{Cvoid})::Cstring)
+
+# ---- helpers -------------------------------------------------------------------------------
+const NucSeq24 = LongSequence{<:Union{DNAAlphabet{2}, DNAAlphabet{4}, RNAAlphabet{2}, RNAAlphabet{4}}}
+const TwoBitAlphabet = Union{DNAAlphabet{2}, RNAAlphabet{2}}
+
+src_bits(s::LongSequence) = Int32(BioSequences.bits_per_symbol(Alphabet(s)))
+cseq(s::LongSequence) = CSeq(pointer(s.data), length(s) % UInt64, 0, 0, src_bits(s), 0)
+
+# Reproduce the reference's exception (src/construction.jl:108-110) from the C result.
+function check(ctx::Context, rc::Integer, res::CResult, ::Type{A}, s::LongSequence) where {A}
+    rc == OK && return nothing
+    if rc == E_ENCODE
+        sym = reinterpret(eltype(s), res.err_enc % UInt8)
+        throw(BioSequences.EncodeError(A(), sym))
+    end
+    error("libkmers_hip: status $rc: $(last_error(ctx))")
+end
+
+# ---- bulk forms of the iterators -----------------------------------------------------------
+"collect(FwKmers{A,K}(seq)) on the GPU (src/iterators/FwKmers.jl:57-115)"
+function Base.collect(it::FwKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: NucSeq24}
+    ctx, s = context(), it.seq
+    out = Vector{eltype(it)}(undef, length(it))
+    res = CResult()
+    GC.@preserve s out begin
+        rc = @ccall LIB.kmers_fw(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 2::Cint,
+                                 pointer(out)::Ptr{UInt64}, C_NULL::Ptr{UInt64}, MEM_HOST::Cint,
+                                 res::Ref{CResult})::Cint
+    end
+    check(ctx, rc, res, A, s)
+    return out
+end
+
+"collect(FwRvIterator{A,K}(seq)): (forward, reverse_complement) pairs (CanonicalKmers.jl:54-144)"
+function Base.collect(it::FwRvIterator{A, K, S}) where {A <: TwoBitAlphabet, K, S <: NucSeq24}
+    ctx, s = context(), it.seq
+    T = Kmers.derive_type(Kmer{A, K})
+    n = length(it)
+    fw, rv = Vector{T}(undef, n), Vector{T}(undef, n)
+    res = CResult()
+    GC.@preserve s fw rv begin
+        rc = @ccall LIB.kmers_fw(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 2::Cint,
+                                 pointer(fw)::Ptr{UInt64}, pointer(rv)::Ptr{UInt64}, MEM_HOST::Cint,
+                                 res::Ref{CResult})::Cint
+    end
+    check(ctx, rc, res, A, s)
+    return collect(zip(fw, rv))
+end
+
+"collect(CanonicalKmers{A,K}(seq)) (CanonicalKmers.jl:199-225)"
+function Base.collect(it::CanonicalKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: NucSeq24}
+    return first(collect_with_hashes(it; hashes = false))
+end
+
+"Canonical kmers and fx_hash.(kmers, seed) from one fused kernel (kmer.jl:255-261)."
+function collect_with_hashes(it::CanonicalKmers{A, K, S}; seed::UInt = zero(UInt),
+                             hashes::Bool = true) where {A <: TwoBitAlphabet, K, S <: NucSeq24}
+    ctx, s = context(), it.it.seq
+    n = length(it)
+    out = Vector{eltype(it)}(undef, n)
+    h = hashes ? Vector{UInt64}(undef, n) : UInt64[]
+    res = CResult()
+    GC.@preserve s out h begin
+        rc = @ccall LIB.kmers_canonical(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 2::Cint,
+                                        pointer(out)::Ptr{UInt64},
+                                        (hashes ? pointer(h) : Ptr{UInt64}(C_NULL))::Ptr{UInt64},
+                                        seed::UInt64, MEM_HOST::Cint, res::Ref{CResult})::Cint
+    end
+    check(ctx, rc, res, A, s)
+    return out, h
+end
+
+"collect(SpacedKmers{A,K,J}(seq)) (SpacedKmers.jl:83-139), strict semantics incl. EncodeError"
+function Base.collect(it::SpacedKmers{A, K, J, S}) where {A <: TwoBitAlphabet, K, J, S <: NucSeq24}
+    ctx, s = context(), it.seq
+    out = Vector{eltype(it)}(undef, length(it))
+    res = CResult()
+    GC.@preserve s out begin
+        rc = @ccall LIB.kmers_spaced(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, J::Cint, 2::Cint,
+                                     pointer(out)::Ptr{UInt64}, MEM_HOST::Cint, res::Ref{CResult})::Cint
+    end
+    check(ctx, rc, res, A, s)
+    return out
+end
+
+"collect(UnambiguousKmers{A,K}(seq)): (kmer, start) tuples (UnambiguousKmers.jl:59-148)"
+function Base.collect(it::UnambiguousKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: NucSeq24}
+    ctx, s = context(), it.it.seq
+    T = Kmers.derive_type(Kmer{A, K})
+    res = CResult()
+    GC.@preserve s begin   # count first (SizeUnknown, :33), then fill
+        rc = @ccall LIB.kmers_unambiguous(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 1::Cint,
+                                          C_NULL::Ptr{UInt64}, C_NULL::Ptr{Int64}, 0::UInt64, MEM_HOST::Cint,
+                                          res::Ref{CResult})::Cint
+        check(ctx, rc, res, A, s)
+        n = Int(res.n_out)
+        kmers, starts = Vector{T}(undef, n), Vector{Int}(undef, n)
+        GC.@preserve kmers starts begin
+            rc = @ccall LIB.kmers_unambiguous(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 1::Cint,
+                                              pointer(kmers)::Ptr{UInt64}, pointer(starts)::Ptr{Int64},
+                                              n::UInt64, MEM_HOST::Cint, res::Ref{CResult})::Cint
+        end
+        check(ctx, rc, res, A, s)
+        return collect(zip(kmers, starts))
+    end
+end
+
+# ---- element-wise functions on vectors of kmers ----------------------------------------------
+"fx_hash.(v, h) (src/kmer.jl:255-261)"
+function Kmers.fx_hash(v::Vector{Kmer{A, K, N}}, h::UInt = zero(UInt)) where {A, K, N}
+    ctx = context()
+    out = Vector{UInt64}(undef, length(v))
+    GC.@preserve v out begin
+        rc = @ccall LIB.kmers_fx_hash(ctx.handle::Ptr{Cvoid}, pointer(v)::Ptr{UInt64}, N::Cint,
+                                      length(v)::UInt64, h::UInt64, pointer(out)::Ptr{UInt64}, MEM_HOST::Cint)::Cint
+    end
+    rc == OK || error("kmers_fx_hash: status $rc: $(last_error(ctx))")
+    return out
+end
+
+for (op, fn) in ((0, :reverse), (1, :complement), (2, :reverse_complement), (3, :canonical))
+    mod = fn === :reverse ? :Base : :BioSequences
+    @eval function $mod.$fn(v::Vector{Kmer{A, K, N}}) where {A <: NucleicAcidAlphabet, K, N}
+        ctx = context()
+        out = similar(v)
+        bits = BioSequences.bits_per_symbol(A())
+        GC.@preserve v out begin
+            rc = @ccall LIB.kmers_transform(ctx.handle::Ptr{Cvoid}, $op::Cint, pointer(v)::Ptr{UInt64}, K::Cint,
+                                            bits::Cint, length(v)::UInt64, pointer(out)::Ptr{UInt64},
+                                            MEM_HOST::Cint)::Cint
+        end
+        rc == OK || error("kmers_transform: status $rc: $(last_error(ctx))")
+        return out
+    end
+end
+
+# ---- chunk-buffered iterate(): `for kmer in gpu(it)` -----------------------------------------
+"""
+    gpu(it; chunk = 1 << 24)
+
+Wrap a Kmers.jl iterator so that `Base.iterate` pulls elements from GPU-computed chunks.  The
+state is `(buffer, index_in_buffer, next_start)`; a chunk is a view of the sequence
+(`first_base`, K-1 symbols of overlap), exactly how a resumed reference iterator would restart.
+"""
+struct GPUIterator{I}
+    it::I
+    chunk::Int
+end
+gpu(it; chunk::Int = 1 << 24) = GPUIterator(it, chunk)
+Base.length(g::GPUIterator) = length(g.it)
+Base.eltype(::Type{GPUIterator{I}}) where {I} = eltype(I)
+
+function fill_chunk(g::GPUIterator{<:CanonicalKmers{A, K}}, start::Int) where {A, K}
+    s = g.it.it.seq
+    n = min(g.chunk, length(g.it) - start + 1)
+    n <= 0 && return nothing
+    ctx = context()
+    buf = Vector{eltype(g.it)}(undef, n)
+    res = CResult()
+    view = CSeq(pointer(s.data), (n + K - 1) % UInt64, (start - 1) % UInt64, (start - 1) % UInt64, src_bits(s), 0)
+    GC.@preserve s buf begin
+        rc = @ccall LIB.kmers_canonical(ctx.handle::Ptr{Cvoid}, Ref(view)::Ptr{CSeq}, K::Cint, 2::Cint,
+                                        pointer(buf)::Ptr{UInt64}, C_NULL::Ptr{UInt64}, 0::UInt64,
+                                        MEM_HOST::Cint, res::Ref{CResult})::Cint
+    end
+    check(ctx, rc, res, A, s)
+    return buf
+end
+
+function Base.iterate(g::GPUIterator, state = (eltype(g)[], 1, 1))
+    (buf, i, next_start) = state
+    if i > length(buf)
+        buf = fill_chunk(g, next_start)
+        buf === nothing && return nothing
+        next_start += length(buf)
+        i = 1
+    end
+    return (@inbounds(buf[i]), (buf, i + 1, next_start))
+end
+
+end # module

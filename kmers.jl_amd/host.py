@@ -670,6 +670,11 @@ def _batch(x):
 def fx_hash(x, h=0, ctx=None):
     """fx_hash(x::Kmer, h::UInt) (src/kmer.jl:255-261) for one Kmer or a KmerArray."""
     ctx = ctx or default_context()
+    if isinstance(x, Kmer) and x.K == 0:  # fx_hash of a 0-mer folds nothing: the library returns the seed
+        out = np.zeros(1, dtype=np.uint64)
+        ctx.check(ctx.lib.kmers_fx_hash(ctx.handle, out.ctypes.data_as(C.c_void_p), 0, 1, h & MASK64,
+                                        out.ctypes.data_as(C.c_void_p), _capi.MEM_HOST), "kmers_fx_hash")
+        return int(out[0])
     arr, single = _batch(x)
     n = len(arr)
     out = np.zeros(max(n, 1), dtype=np.uint64)

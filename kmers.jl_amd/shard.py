@@ -63,24 +63,55 @@ def plan_shards(n_bases, k, n_shards, src_bits):
     return out
 
 
-def exchange_halo(buf, shard, group=None):
-    """One neighbour step: append the first `halo_words` words of rank+1 to this rank's buffer.
+class HaloExchanger:
+    """The one neighbour step of the path: after `exchange()`, words
+    [n_own_words, n_own_words + halo_words) of this rank's buffer hold the first words of rank+1.
 
-    `buf` is a 1-D int64 tensor of n_own_words + halo_words elements whose first n_own_words hold
-    this rank's words (CPU tensor under gloo, HBM tensor under nccl/RCCL).  Every rank of the
-    group must call this.  Returns the list of posted requests already waited on."""
-    import torch.distributed as dist
-    ops = []
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    if shard.send_words and rank > 0:
-        ops.append(dist.P2POp(dist.isend, buf[:shard.send_words], rank - 1, group))
-    if shard.halo_words and rank < world - 1:
-        ops.append(dist.P2POp(dist.irecv, buf[shard.n_own_words:shard.n_own_words + shard.halo_words],
-                              rank + 1, group))
-    if not ops:
-        return []
-    reqs = dist.batch_isend_irecv(ops)
-    for r in reqs:
-        r.wait()
-    return reqs
+    `buf` is a 1-D int64 tensor (HBM tensor under nccl/RCCL, CPU tensor under gloo) whose first
+    n_own_words elements are this rank's words.  Two transports, same result:
+      "p2p"       ncclSend/ncclRecv between neighbours (batch_isend_irecv), the minimal exchange;
+      "allgather" every rank contributes its first `width` words and keeps rank+1's piece -- the
+                  default: one ordinary collective of a few dozen bytes, no per-pair communicator
+                  set-up; the payload is latency-bound either way (<= 32 B per rank).
+    Buffers are allocated once; exchange() allocates nothing."""
+
+    def __init__(self, buf, shard, plan, group=None, transport=None):
+        import os
+
+        import torch
+        import torch.distributed as dist
+        self.dist, self.buf, self.shard, self.group = dist, buf, shard, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.transport = transport or os.environ.get("KMERS_HALO_TRANSPORT", "allgather")
+        self.width = max([s.halo_words for s in plan] + [1])
+        if self.world > 1 and self.transport == "allgather":
+            self.send = torch.zeros(self.width, dtype=buf.dtype, device=buf.device)
+            self.pieces = [torch.zeros(self.width, dtype=buf.dtype, device=buf.device) for _ in range(self.world)]
+
+    def exchange(self):
+        if self.world == 1:
+            return
+        sh, buf, dist = self.shard, self.buf, self.dist
+        if self.transport == "p2p":
+            ops = []
+            if sh.send_words and self.rank > 0:
+                ops.append(dist.P2POp(dist.isend, buf[:sh.send_words], self.rank - 1, self.group))
+            if sh.halo_words and self.rank < self.world - 1:
+                ops.append(dist.P2POp(dist.irecv, buf[sh.n_own_words:sh.n_own_words + sh.halo_words],
+                                      self.rank + 1, self.group))
+            if ops:
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+            return
+        n = min(self.width, sh.n_own_words)
+        if n:
+            self.send[:n].copy_(buf[:n])
+        dist.all_gather(self.pieces, self.send, group=self.group)
+        if sh.halo_words:
+            buf[sh.n_own_words:sh.n_own_words + sh.halo_words].copy_(self.pieces[self.rank + 1][:sh.halo_words])
+
+
+def exchange_halo(buf, shard, group=None, plan=None, transport=None):
+    """One-shot form of HaloExchanger (allocates its workspace on every call)."""
+    HaloExchanger(buf, shard, plan or [shard], group, transport).exchange()

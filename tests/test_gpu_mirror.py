@@ -1,0 +1,189 @@
+"""The reference's own iterator tests, re-expressed against the host mirror (kmers_jl_amd), which
+runs everything through libkmers_hip.so.  Mirrors test/runtests.jl:660-889 and the docstring
+examples of src/iterators/*.jl.  Run with -m gpu."""
+import re
+
+import numpy as np
+import pytest
+
+import naive
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def km():
+    import kmers_jl_amd
+    return kmers_jl_amd
+
+
+def texts(xs):
+    return [str(x) for x in xs]
+
+
+def test_docstring_examples(km, kats):
+    # FwKmers.jl:14-22
+    c = kats["G5_fw"]["cases"][0]
+    it = km.FwDNAMers[3](km.LongDNA[4](c["seq"]))
+    assert texts(km.collect(it)) == c["kmers"] and len(it) == 6
+    assert it.eltype == ("Kmer", km.DNAAlphabet[2], 3, 1)
+    # docs/src/iteration.md:19-21  only(FwDNAMers{3}(rna"UGU")) == mer"TGT"d
+    assert km.collect(km.FwDNAMers[3](km.LongRNA[4]("UGU")))[0] == km.mer("TGT")
+    # CanonicalKmers.jl:192-196
+    g = kats["G4_canonical"]
+    assert texts(km.collect(km.CanonicalRNAMers[3](km.LongDNA[4](g["seq"])))) == g["kmers"]
+    # UnambiguousKmers.jl:20-26
+    g = kats["G6_unambiguous"]
+    got = km.collect(km.UnambiguousRNAMers[4](km.LongDNA[4](g["seq"])))
+    assert [(str(k), i) for k, i in got] == [tuple(x) for x in g["items"]]
+    # SpacedKmers.jl:16-20 and :70-75
+    for c in kats["G7_spaced"]["cases"]:
+        assert texts(km.collect(km.SpacedDNAMers[c["K"], c["J"]](km.LongDNA[4](c["seq"])))) == c["kmers"]
+    assert texts(km.collect(km.each_codon(km.LongDNA[2]("TGACGATCGAC")))) == ["TGA", "CGA", "TCG"]
+
+
+def test_smaller_than_k_and_aliases(km):
+    # test/runtests.jl:668-672
+    assert len(km.FwDNAMers[3](km.LongDNA[4]("TA"))) == 0
+    assert km.collect(km.FwDNAMers[3](km.LongDNA[4]("TA"))).tolist() == []
+    assert km.collect(km.CanonicalDNAMers[8](km.LongDNA[2](""))).tolist() == []
+    assert isinstance(km.FwKmers[km.DNAAlphabet[2], 3](km.LongDNA[4]("TAGA")), km.FwKmers)
+    with pytest.raises(km.KmersError, match="K must be at least 1"):
+        km.FwDNAMers[0](km.LongDNA[4]("TAGA"))
+    with pytest.raises(km.KmersError, match="J must be at least 1"):
+        km.SpacedDNAMers[3, 0](km.LongDNA[4]("TAGA"))
+
+
+def test_conversible_alphabets(km, kats):
+    # test/runtests.jl:674-690 (2-bit kmer alphabets; 4-bit kmer alphabets are row f3)
+    g = kats["G14_property_seqs"]
+    for text in g["fw_two_bit"] + g["fw_four_bit"]:
+        for src in (km.LongDNA[2], km.LongDNA[4], km.LongRNA[2], km.LongRNA[4]):
+            for alias, alph in ((km.FwDNAMers, "dna2"), (km.FwRNAMers, "rna2")):
+                v1 = km.collect(alias[3](src(text)))
+                assert [k.data for k in v1] == naive.fw_kmers(text, 3, alph)
+
+
+def test_ambiguous_sources_throw(km, kats):
+    # test/runtests.jl:691-694; FwKmers.jl:24-25 "cannot encode D in RNAAlphabet{2}"
+    for c in kats["G12_errors"]["cases"]:
+        seq = km.LongDNA[4](c["seq"])
+        if c["iter"] == "fw":
+            its = [km.FwDNAMers[c["K"]](seq), km.CanonicalDNAMers[c["K"]](seq), km.FwRvDNAIterator[c["K"]](seq)]
+        else:
+            its = [km.SpacedDNAMers[c["K"], c["J"]](seq)]
+        for it in its:
+            with pytest.raises(km.EncodeError) as e:
+                km.collect(it)
+            assert e.value.position == c["err_pos"] and e.value.symbol == c["err_symbol"]
+    with pytest.raises(km.EncodeError, match=re.escape("cannot encode D in RNAAlphabet{2}")):
+        km.collect(km.FwRNAMers[3](km.LongRNA[4]("UGCDUGAVC")))
+
+
+def test_iteration_yields_until_the_throw(km):
+    """`for x in it` yields exactly what the reference yields before throwing (FwKmers.jl:104-115)."""
+    text = "ACGTTGCAAC" + "W" + "ACGT"
+    it = km.FwDNAMers[4](km.LongDNA[4](text))
+    got = []
+    with pytest.raises(km.EncodeError) as e:
+        for k in it:
+            got.append(str(k))
+    assert e.value.position == 11
+    assert got == [text[i:i + 4] for i in range(0, 7)]  # windows ending before symbol 11
+    # spaced, J >= K: the gap symbol is never inspected, the next kmer's is
+    it = km.SpacedDNAMers[3, 4](km.LongDNA[4]("TAGWTAGATAWA"))
+    got = []
+    with pytest.raises(km.EncodeError) as e:
+        for k in it:
+            got.append(str(k))
+    assert got == ["TAG", "TAG"] and e.value.position == 11
+
+
+def test_fwrv_and_canonical_vs_naive(km, kats):
+    # test/runtests.jl:739-761, :774-787
+    g = kats["G14_property_seqs"]
+    for text in g["fwrv"]:
+        for src in (km.LongDNA[2], km.LongDNA[4], km.LongRNA[2], km.LongRNA[4]):
+            got = km.collect(km.FwRvDNAIterator[4](src(text)))
+            assert [(a.data, b.data) for a, b in got] == naive.fwrv(text, 4, 2)
+    for text in g["canonical"]:
+        for src in (km.LongDNA[2], km.LongDNA[4]):
+            got = km.collect(km.CanonicalDNAMers[5](src(text)))
+            assert [k.data for k in got] == naive.canonical(text, 5, 2)
+            # equivalent to calling canonical on each FwKmers element (CanonicalKmers.jl:179-181)
+            fw = km.collect(km.FwDNAMers[5](src(text)))
+            assert km.canonical(fw) == got
+
+
+def test_unambiguous_vs_filter(km, kats):
+    # test/runtests.jl:803-847
+    g = kats["G14_property_seqs"]
+    for text in g["unambiguous"]:
+        for K in (3, 4):
+            got = km.collect(km.UnambiguousDNAMers[K](km.LongDNA[4](text)))
+            assert [(k.data, i) for k, i in got] == naive.unambiguous(text, K)
+    s = km.LongDNA[2]("TATCGGATAGGCAAA")
+    it = km.UnambiguousRNAMers[4](s)
+    assert len(it) == 12  # HasLength for 2-bit sources (UnambiguousKmers.jl:34-37)
+    assert [(k.data, i) for k, i in km.collect(it)] == naive.unambiguous(str(s), 4)
+    with pytest.raises(TypeError):
+        len(km.UnambiguousDNAMers[4](km.LongDNA[4]("ACGT")))
+
+
+def test_spaced_vs_naive(km, kats):
+    # test/runtests.jl:849-867 (2-bit kmer alphabets)
+    for c in kats["G14_property_seqs"]["spaced"]:
+        if c["dst"] != "dna2":
+            continue
+        for K, J in c["KJ"]:
+            for src in (km.LongDNA[2], km.LongDNA[4]):
+                it = km.SpacedDNAMers[K, J](src(c["seq"]))
+                got = km.collect(it)
+                assert [k.data for k in got] == naive.spaced(c["seq"], K, J, 2)
+                assert len(it) == len(got)
+
+
+def test_fx_hash_known_answers(km, kats):
+    # test/runtests.jl:903-910 (nucleotide cases)
+    assert km.fx_hash(km.mer("TAGCTAG")) == 0xA76409341339D05A
+    assert km.fx_hash(km.mer("UGAUGCA", "r")) == 0xDD7C97AE4CA204B4
+    assert km.fx_hash(km.mer("", "r")) == 0
+    x, y = km.fx_hash(km.mer("TAGCTAG")), km.fx_hash(km.mer("TAGCTAG"), 1)
+    assert x != y  # kmer.jl:240-250
+
+
+def test_transform_known_answers(km, kats):
+    # test/runtests.jl:438-485
+    g = kats["G10_iscanonical"]
+    for t in g["true"]:
+        if t:
+            assert km.iscanonical(km.mer(t)) is True
+    for t in g["false"]:
+        assert km.iscanonical(km.mer(t)) is False
+    assert str(km.reverse_complement(km.mer("AGCTAGG"))) == "CCTAGCT"
+    assert str(km.reverse(km.mer("AGCTAGG"))) == "GGATCGA"
+    assert str(km.complement(km.mer("AGCTAGG"))) == "TCGATCC"
+    assert str(km.canonical(km.mer("TTGAA"))) == "TTCAA"
+    rng = np.random.default_rng(1)
+    for K in (5, 31, 32, 33, 64):
+        ts = [naive.random_text(rng, K) for _ in range(50)]
+        arr = km.KmerArray(km.DNAAlphabet[2], K, np.array([naive.kmer_words(t, 2) for t in ts], dtype=np.uint64))
+        assert texts(km.reverse_complement(arr)) == [naive.revcomp_text(t) for t in ts]
+
+
+def test_big_chunked_iteration_matches_collect(km, orc):
+    """Chunk-buffered iterate() == collect() on a sequence longer than one chunk."""
+    L, K = 300_000, 31
+    words = orc.synth_words(5, 0, (L * 4 + 63) // 64, 4)
+    seq = km.LongSequence(km.DNAAlphabet[4], words, L)
+    it = km.CanonicalDNAMers[K](seq)
+    it.CHUNK = 1 << 16
+    whole = km.collect(it)
+    ek, _, _ = orc.canonical(words, L, 4, 2, K)
+    assert np.array_equal(whole.words, ek)
+    assert sum(1 for _ in it) == L - K + 1
+    first = [k.data for _, k in zip(range(70000), it)]
+    assert first == [tuple(int(x) for x in r) for r in ek[:70000]]
+    km_h, hs = it.collect_with_hashes(seed=3)
+    _, eh, _ = orc.canonical(words, L, 4, 2, K, seed=3)
+    assert np.array_equal(hs, eh) and km_h == whole

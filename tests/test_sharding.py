@@ -50,14 +50,14 @@ def test_plan_covers_everything_once():
                     assert plan[-1].halo_words == 0 and plan[0].send_words == 0
 
 
-def _worker(rank, world, port, k, bits, n_bases, q):
+def _worker(rank, world, port, k, bits, n_bases, q, transport):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import kmers_jl_amd  # noqa: F401
-        from kmers_jl_amd.shard import exchange_halo, plan_shards
+        from kmers_jl_amd.shard import HaloExchanger, plan_shards
         from oracle import pyoracle
         orc = pyoracle.get()
         plan = plan_shards(n_bases, k, world, bits)
@@ -66,7 +66,9 @@ def _worker(rank, world, port, k, bits, n_bases, q):
         own = orc.synth_words(4242, sh.first_word, sh.n_own_words, bits)
         buf = torch.zeros(sh.n_own_words + sh.halo_words + 1, dtype=torch.int64)
         buf[:sh.n_own_words] = torch.from_numpy(own.view(np.int64).copy())
-        exchange_halo(buf, sh)
+        hx = HaloExchanger(buf, sh, plan, transport=transport)
+        hx.exchange()
+        hx.exchange()  # idempotent: the bench calls it every step
         words = buf.numpy().view(np.uint64)
         kmers, hashes, res = orc.canonical(words, sh.n_bases, bits, 2, k, seed=5)
         assert res.status == 0
@@ -76,16 +78,16 @@ def _worker(rank, world, port, k, bits, n_bases, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,transport", [(2, "allgather"), (3, "allgather"), (2, "p2p")])
 @pytest.mark.parametrize("bits", [2, 4])
-def test_halo_exchange_gloo(world, bits):
+def test_halo_exchange_gloo(world, bits, transport):
     from oracle import pyoracle
     orc = pyoracle.get()
     for k, n_bases in ((31, 20_011), (33, 7_000), (3, 999)):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = free_port()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, k, bits, n_bases, q)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, k, bits, n_bases, q, transport)) for r in range(world)]
         for p in procs:
             p.start()
         parts = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
