@@ -88,6 +88,7 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 /* launch tunables (bench / tuning; 0 restores the default) */
 #define KMERS_PARAM_TILE_KMERS 1 /* kmers per workgroup tile (multiple of 512) */
 #define KMERS_PARAM_MAX_GRID 2   /* cap on workgroups per launch (persistent grid-stride above it) */
+#define KMERS_PARAM_STAMPS_PTR 3 /* diagnostic builds (-DKMERS_STAMPS) only: device buffer for in-kernel stamps */
 int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
 
 /* device memory for hosts without their own HIP binding */

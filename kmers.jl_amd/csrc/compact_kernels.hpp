@@ -83,7 +83,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
             if constexpr (EMIT) {
                 if (ok) {
                     uint64_t fw[N], rc[N];
-                    window<N>(lds, 2u * (r + b0), k, mask, fw, rc);
+                    window<N, 2>(lds, 2u * (r + b0), k, mask, fw, rc);
                     uint64_t o = pos + __popcll(bal & ((1ull << lane) - 1ull));
                     if (a.out_kmers) {
 #pragma unroll

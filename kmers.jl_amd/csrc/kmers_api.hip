@@ -33,6 +33,7 @@ struct kmers_ctx {
     int err_bits = 0;
     int64_t tile_kmers = 0;  // 0 = default
     int64_t max_grid = 0;    // 0 = default
+    int64_t stamps_ptr = 0;  // diagnostic builds only (KMERS_PARAM_STAMPS_PTR)
 };
 
 namespace {
@@ -153,34 +154,58 @@ static uint32_t default_tile(uint32_t out_bytes_per_kmer, uint32_t pass) {
     return std::max<uint32_t>(pass, t);
 }
 
+template <int MODE, int SB, int DB>
+void launch_widths(int n_words, bool s1, dim3 grid, dim3 block, hipStream_t st, const StreamArgs &a) {
+#define LAUNCH(NN)                                                                                   \
+    do {                                                                                             \
+        if (s1) hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, true>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, false>), grid, block, 0, st, a);    \
+    } while (0)
+    switch (n_words) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+}
+
 template <int MODE>
-int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int n_words, bool vec_ok) {
+int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int n_words, bool vec_ok) {
     const uint32_t J = a.stride;
     const bool stride1 = (J == 1) && vec_ok;
     const uint32_t pass = (stride1 && n_words == 1 ? 2u : 1u) * BLOCK;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
                          (MODE == MODE_CANON && a.out_b ? 8u : 0u);
     if (MODE == MODE_XOR) out_bytes = 4u;  // nothing stored: long tiles
+    const uint32_t max_tile_symbols = (uint32_t)MAX_TILE_BITS / (uint32_t)dst_bits;
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
-    if (J > 1) tile = std::min<uint32_t>(tile, (uint32_t)(MAX_TILE_BASES / J));
+    tile = std::min<uint32_t>(tile, max_tile_symbols / J);
     tile = std::max<uint32_t>(pass, tile / pass * pass);
-    if ((uint64_t)(tile - 1) * J + 1 > (uint64_t)MAX_TILE_BASES) return fail(ctx, KMERS_E_UNSUPPORTED, "stride too large for the tile kernel");
+    if ((uint64_t)(tile - 1) * J + 1 > (uint64_t)max_tile_symbols) return fail(ctx, KMERS_E_UNSUPPORTED, "stride too large for the tile kernel");
     a.tile_kmers = tile;
     a.n_tiles = (a.n_kmers + tile - 1) / tile;
+    a.stamps = reinterpret_cast<uint64_t *>(ctx->stamps_ptr);
     uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap));
     dim3 block(BLOCK);
-#define LAUNCH(SB, NN, S1) hipLaunchKernelGGL((stream_kernel<SB, NN, MODE, S1>), grid, block, 0, ctx->stream, a)
-    if (src_bits == 4) {
-        if (n_words == 1) { if (stride1) LAUNCH(4, 1, true); else LAUNCH(4, 1, false); }
-        else              { if (stride1) LAUNCH(4, 2, true); else LAUNCH(4, 2, false); }
-    } else {
-        if (n_words == 1) { if (stride1) LAUNCH(2, 1, true); else LAUNCH(2, 1, false); }
-        else              { if (stride1) LAUNCH(2, 2, true); else LAUNCH(2, 2, false); }
-    }
-#undef LAUNCH
+    if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, grid, block, ctx->stream, a);
+    else if (src_bits == 2 && dst_bits == 2) launch_widths<MODE, 2, 2>(n_words, stride1, grid, block, ctx->stream, a);
+    else if (src_bits == 4 && dst_bits == 4) launch_widths<MODE, 4, 4>(n_words, stride1, grid, block, ctx->stream, a);
+    else launch_widths<MODE, 2, 4>(n_words, stride1, grid, block, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return KMERS_OK;
+}
+
+// stride > what a tile can stage: one lane per kmer
+template <int SB, int DB>
+void launch_gather(int n_words, dim3 grid, dim3 block, hipStream_t st, const StreamArgs &a) {
+    switch (n_words) {
+        case 1: hipLaunchKernelGGL((gather_kernel<SB, DB, 1>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((gather_kernel<SB, DB, 2>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((gather_kernel<SB, DB, 3>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((gather_kernel<SB, DB, 4>), grid, block, 0, st, a); break;
+    }
 }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -211,8 +236,8 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
         if (out_a) { if (int rc = ensure_stage(ctx, 1, bytes_a)) return rc; d_a = (uint64_t *)ctx->stage[1]; }
         if (out_b) { if (int rc = ensure_stage(ctx, 2, bytes_b)) return rc; d_b = (uint64_t *)ctx->stage[2]; }
     }
-    if (nw == 2 && ((d_a && !aligned16(d_a)) || (d_b && !b_is_hash && !aligned16(d_b))))
-        return fail(ctx, KMERS_E_BADARG, "two-word kmer outputs must be 16-byte aligned");
+    if ((nw == 2 || nw == 4) && ((d_a && !aligned16(d_a)) || (d_b && !b_is_hash && !aligned16(d_b))))
+        return fail(ctx, KMERS_E_BADARG, "two- and four-word kmer outputs must be 16-byte aligned");
 
     StreamArgs a{};
     a.src = st.d_words;
@@ -228,22 +253,19 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     a.stride = (uint32_t)stride;
 
     int rc;
-    if (stride > 32) {
-        // gather path (forward kmers only: kmers_spaced)
+    if ((uint64_t)stride * (uint64_t)dst_bits > 64) {
+        // gather path (forward kmers only: kmers_spaced); a tile would stage mostly unused symbols
         dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
-        if (seq->src_bits == 4) {
-            if (nw == 1) hipLaunchKernelGGL((gather_kernel<4, 1>), grid, block, 0, ctx->stream, a);
-            else hipLaunchKernelGGL((gather_kernel<4, 2>), grid, block, 0, ctx->stream, a);
-        } else {
-            if (nw == 1) hipLaunchKernelGGL((gather_kernel<2, 1>), grid, block, 0, ctx->stream, a);
-            else hipLaunchKernelGGL((gather_kernel<2, 2>), grid, block, 0, ctx->stream, a);
-        }
+        if (seq->src_bits == 4 && dst_bits == 2) launch_gather<4, 2>(nw, grid, block, ctx->stream, a);
+        else if (seq->src_bits == 2 && dst_bits == 2) launch_gather<2, 2>(nw, grid, block, ctx->stream, a);
+        else if (seq->src_bits == 4 && dst_bits == 4) launch_gather<4, 4>(nw, grid, block, ctx->stream, a);
+        else launch_gather<2, 4>(nw, grid, block, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
         rc = KMERS_OK;
     } else {
         const bool vec_ok = (!d_a || aligned16(d_a)) && (!d_b || aligned16(d_b));
-        rc = mode == MODE_FW ? launch_stream<MODE_FW>(ctx, a, seq->src_bits, nw, vec_ok)
-                             : launch_stream<MODE_CANON>(ctx, a, seq->src_bits, nw, vec_ok);
+        rc = mode == MODE_FW ? launch_stream<MODE_FW>(ctx, a, seq->src_bits, dst_bits, nw, vec_ok)
+                             : launch_stream<MODE_CANON>(ctx, a, seq->src_bits, dst_bits, nw, vec_ok);
     }
     if (rc) return rc;
     if (flags & KMERS_ASYNC) {
@@ -350,9 +372,9 @@ uint64_t kmers_count(uint64_t n_bases, int k, int stride) {
 
 int kmers_supported(int src_bits, int dst_bits, int k, int stride) {
     if (src_bits != 2 && src_bits != 4) return 0;
-    if (dst_bits != 2) return 0;  // 4-bit kmer alphabets: SURVEY.md section 8 row f3 (next)
-    if (k < 1 || k > 64 || stride < 1) return 0;
-    return 1;
+    if (dst_bits != 2 && dst_bits != 4) return 0;
+    if (k < 1 || stride < 1) return 0;
+    return n_coding_elements(k, dst_bits) <= 4;  // K <= 128 (2-bit kmers) / K <= 64 (4-bit kmers)
 }
 
 int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out) {
@@ -399,6 +421,7 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value) {
     if (!ctx) return KMERS_E_BADARG;
     if (param == KMERS_PARAM_TILE_KMERS) ctx->tile_kmers = value;
     else if (param == KMERS_PARAM_MAX_GRID) ctx->max_grid = value;
+    else if (param == KMERS_PARAM_STAMPS_PTR) ctx->stamps_ptr = value;
     else return fail(ctx, KMERS_E_BADARG, "unknown parameter");
     return KMERS_OK;
 }
@@ -484,10 +507,10 @@ int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, 
         // fused consumer: persistent grid, one atomic per wave at the very end
         int64_t saved = ctx->max_grid;
         ctx->max_grid = 256 * 8;
-        int rc = launch_stream<MODE_XOR>(ctx, a, seq->src_bits, kmers_words_per_kmer(k, dst_bits), true);
+        int rc = launch_stream<MODE_XOR>(ctx, a, seq->src_bits, dst_bits, kmers_words_per_kmer(k, dst_bits), true);
         ctx->max_grid = saved;
         if (rc) return rc;
-    } else if (int rc = launch_stream<MODE_XOR>(ctx, a, seq->src_bits, kmers_words_per_kmer(k, dst_bits), true)) {
+    } else if (int rc = launch_stream<MODE_XOR>(ctx, a, seq->src_bits, dst_bits, kmers_words_per_kmer(k, dst_bits), true)) {
         return rc;
     }
     HIP_TRY(ctx, hipMemcpyAsync(out_value, ctx->d_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -502,6 +525,7 @@ int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, u
         return rc;
     }
     if (flags & KMERS_ASYNC) return fail(ctx, KMERS_E_BADARG, "kmers_unambiguous is synchronous (data-dependent count)");
+    if (k > 64) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_unambiguous supports K <= 64");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return run_unambiguous(ctx, seq, k, stride, out_kmers, out_starts, capacity, flags, res);
 }

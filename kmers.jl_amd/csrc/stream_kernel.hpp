@@ -20,8 +20,9 @@ namespace kmers {
 #endif
 constexpr int BLOCK = KMERS_BLOCK;             // threads per workgroup (multiple of 64)
 constexpr int WAVES = BLOCK / 64;
-constexpr int MAX_TILE_BASES = 16384;          // bases of 2-bit stream a tile may span (excl. overlap)
-constexpr int LDS_QWORDS = MAX_TILE_BASES / 32 + 16;
+constexpr int MAX_TILE_BITS = 32768;           // LDS stream bits a tile may span (excl. overlap): 16384 2-bit symbols
+constexpr int MAX_TILE_BASES = MAX_TILE_BITS / 2;
+constexpr int LDS_QWORDS = MAX_TILE_BITS / 64 + 16;
 
 enum Mode { MODE_FW = 0, MODE_CANON = 1, MODE_XOR = 2 };
 
@@ -40,6 +41,7 @@ struct StreamArgs {
     uint32_t stride;
     uint32_t tile_kmers;
     uint32_t xor_canonical;  // MODE_XOR: 1 = canonical kmers, 0 = forward kmers
+    uint64_t *stamps;        // diagnostic builds (-DKMERS_STAMPS) only: per-workgroup s_memrealtime stamps
 };
 
 // First inspected ambiguous symbol of one 4-bit source word -> err_slot (rare path, kept
@@ -68,35 +70,78 @@ __device__ __forceinline__ void report_ambiguous(unsigned long long *err_slot, u
     if (f) atomicMin(err_slot, (unsigned long long)(base0 + (long long)(__ffsll((long long)f) - 1) / 4));
 }
 
-// forward / reverse-complement kmers (N words, head first) of the window whose first base
-// sits at stream bit `bit` of the LDS stream.
-template <int N>
+// ---- symbol-level helpers generic in the kmer alphabet width (DST = 2 or 4 bits) -------------
+// reverse the order of the DST-bit symbols of one word (BioSequences.reversebits)
+template <int DST>
+__device__ __forceinline__ uint64_t rev_symbols(uint64_t x) {
+    uint64_t r = rev2(x);
+    if constexpr (DST == 4) r = ((r >> 2) & 0x3333333333333333ull) | ((r & 0x3333333333333333ull) << 2);
+    return r;
+}
+// complement of every symbol of a word: 2-bit NOT; 4-bit = bit reversal inside each nibble
+// (A=0001<->T=1000, C=0010<->G=0100; gap and N are fixed points) -- complement_bitpar
+template <int DST>
+__device__ __forceinline__ uint64_t comp_symbols(uint64_t x) {
+    if constexpr (DST == 2) return ~x;
+    x = ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);
+    return ((x & 0xCCCCCCCCCCCCCCCCull) >> 2) | ((x & 0x3333333333333333ull) << 2);
+}
+// 2-bit codes of 16 symbols -> 16 one-hot nibbles (TwoToFour: 1 << code, construction_utils.jl:35)
+__device__ __forceinline__ uint64_t expand_2to4(uint32_t x) {
+    uint64_t t = x;
+    t = (t | (t << 16)) & 0x0000FFFF0000FFFFull;
+    t = (t | (t << 8)) & 0x00FF00FF00FF00FFull;
+    t = (t | (t << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    t = (t | (t << 2)) & 0x3333333333333333ull;  // code c in the low two bits of every nibble
+    const uint64_t M1 = 0x1111111111111111ull;
+    uint64_t c0 = t & M1, c1 = (t >> 1) & M1, n0 = c0 ^ M1, n1 = c1 ^ M1;
+    return (n1 & n0) | ((n1 & c0) << 1) | ((c1 & n0) << 2) | ((c1 & c0) << 3);
+}
+
+// forward / reverse-complement kmers (N words, head word first) of the window whose first
+// symbol sits at bit `bit` of the LDS stream (DST bits per symbol, little-endian by symbol).
+//   W  = K*DST stream bits, symbol j of the window at bits DST*j
+//   rc = comp(W)                     (the complement of symbol j belongs at big-endian slot K-1-j)
+//   fw = symbol-reversal(W) >> (64N - K*DST)
+// which equals K applications of shift_encoding / shift_first_encoding
+// (construction_utils.jl:129-134, kmer.jl:511-518) to a zero kmer.
+template <int N, int DST>
 __device__ __forceinline__ void window(const uint64_t *lds, uint32_t bit, uint32_t k, uint64_t mask,
                                        uint64_t (&fw)[N], uint64_t (&rc)[N]) {
-    uint32_t q = bit >> 6, s = bit & 63u;
-    if constexpr (N == 1) {
-        uint64_t W = funnel64(lds[q], lds[q + 1], s) & mask;
-        rc[0] = ~W & mask;
-        fw[0] = rev2(W) >> (64u - 2u * k);
-    } else {
-        static_assert(N == 2, "window: N must be 1 or 2");
-        uint64_t q0 = lds[q], q1 = lds[q + 1], q2 = lds[q + 2];
-        uint64_t Wlo = funnel64(q0, q1, s);
-        uint64_t Whi = funnel64(q1, q2, s) & mask;  // mask covers the 2K-64 bits of the head word
-        rc[0] = ~Whi & mask;
-        rc[1] = ~Wlo;
-        // 128-bit symbol reversal then right shift by 128-2K (0..62)
-        uint64_t hi = rev2(Wlo), lo = rev2(Whi);
-        uint32_t sh = 128u - 2u * k;
-        fw[1] = (lo >> sh) | ((hi << 1) << (63u - sh));
-        fw[0] = hi >> sh;
+    const uint32_t q = bit >> 6, s = bit & 63u;
+    uint64_t W[N], R[N];
+    uint64_t lo = lds[q];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        uint64_t hi = lds[q + j + 1];
+        W[j] = funnel64(lo, hi, s);
+        lo = hi;
     }
+    W[N - 1] &= mask;  // the head word of the kmer holds K*DST - 64(N-1) bits
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        rc[N - 1 - j] = comp_symbols<DST>(W[j]);
+        R[j] = rev_symbols<DST>(W[j]);
+    }
+    if constexpr (DST == 2) rc[0] &= mask;  // NOT sets the unused top bits (transformations.jl:24)
+    const uint32_t sh = 64u * N - (uint32_t)DST * k;  // 0..62
+    fw[0] = R[0] >> sh;
+#pragma unroll
+    for (int i = 1; i < N; ++i) fw[i] = (R[i] >> sh) | ((R[i - 1] << 1) << (63u - sh));
 }
 
 template <int N>
 __device__ __forceinline__ bool kmer_less(const uint64_t (&x)[N], const uint64_t (&y)[N]) {
-    if constexpr (N == 1) return x[0] < y[0];
-    else return x[0] < y[0] || (x[0] == y[0] && x[1] < y[1]);  // cmp(x.data, y.data) == -1, kmer.jl:176-178
+    // cmp(x.data, y.data) == -1: lexicographic, head word first (kmer.jl:176-178)
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (!decided && x[i] != y[i]) {
+            lt = x[i] < y[i];
+            decided = true;
+        }
+    }
+    return lt;
 }
 
 template <int N>
@@ -107,14 +152,48 @@ __device__ __forceinline__ uint64_t fx_hash(const uint64_t (&x)[N], uint64_t see
     return h;
 }
 
-template <int SRC_BITS, int N, int MODE, bool STRIDE1>
+// one kmer (N words) -> out[g*N ..]; 16-byte stores where the element size allows
+template <int N>
+__device__ __forceinline__ void store_kmer(uint64_t *out, uint64_t g, const uint64_t (&x)[N]) {
+    if constexpr (N == 1) {
+        out[g] = x[0];
+    } else if constexpr (N == 2) {
+        *reinterpret_cast<ulonglong2 *>(out + 2 * g) = make_ulonglong2(x[0], x[1]);
+    } else if constexpr (N == 4) {
+        *reinterpret_cast<ulonglong2 *>(out + 4 * g) = make_ulonglong2(x[0], x[1]);
+        *reinterpret_cast<ulonglong2 *>(out + 4 * g + 2) = make_ulonglong2(x[2], x[3]);
+    } else {
+#pragma unroll
+        for (int w = 0; w < N; ++w) out[g * N + w] = x[w];
+    }
+}
+
+// Phase 1 for one source word: recode into the DST-bit LDS stream (RecodingScheme,
+// src/construction.jl:75-100).  Returns the non-zero `bad` nibble map for FourToTwo.
+//   stream word index: SRC == DST: qword wi;  4->2: dword wi;  2->4: qwords 2wi, 2wi+1
+template <int SRC, int DST>
+__device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint64_t x) {
+    if constexpr (SRC == DST) {  // Copyable
+        lds[wi] = x;
+        return 0;
+    } else if constexpr (SRC == 4) {  // FourToTwo: trailing_zeros of a one-hot nibble, validated
+        uint64_t bad;
+        reinterpret_cast<uint32_t *>(lds)[wi] = pack_4to2(x, bad);
+        return bad;
+    } else {  // TwoToFour
+        lds[2 * wi] = expand_2to4((uint32_t)x);
+        lds[2 * wi + 1] = expand_2to4((uint32_t)(x >> 32));
+        return 0;
+    }
+}
+
+template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1>
 __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     __shared__ uint64_t lds[LDS_QWORDS];
     const uint32_t tid = threadIdx.x;
     const uint32_t k = a.k;
     const uint32_t J = STRIDE1 ? 1u : a.stride;
-    // N == 1: mask of the single word; N == 2: mask of the head word (2K-64 bits)
-    const uint64_t mask = head_mask((int)k, 2);
+    const uint64_t mask = head_mask((int)k, DST);  // mask of the kmer's head word
     constexpr uint32_t KPL = (STRIDE1 && N == 1) ? 2u : 1u;  // kmers per lane per pass -> 16 B stores
     uint64_t xacc = 0;
 
@@ -128,33 +207,41 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
         const uint64_t end_bit = bit0 + ((uint64_t)(mt - 1) * J + k) * SRC_BITS;
         const uint32_t nw = (uint32_t)(((end_bit + 63) >> 6) - w0);
 
+#ifdef KMERS_STAMPS
+        uint64_t t0 = __builtin_amdgcn_s_memrealtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#endif
         __syncthreads();  // previous tile's readers are done with the LDS stream
-        // ---- phase 1: source words -> 2-bit stream in LDS --------------------------------
+        // ---- phase 1: source words -> DST-bit stream in LDS ------------------------------
         for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
-            uint64_t x = a.src[w0 + wi];
-            if constexpr (SRC_BITS == 4) {
-                uint64_t bad;
-                uint32_t c = pack_4to2(x, bad);
-                reinterpret_cast<uint32_t *>(lds)[wi] = c;
+            uint64_t bad = stage_word<SRC_BITS, DST>(lds, wi, a.src[w0 + wi]);
+            if constexpr (SRC_BITS == 4 && DST == 2) {
                 if (bad) report_ambiguous<STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, k, w0 + wi, bad);
-            } else {
-                lds[wi] = x;
             }
         }
+#ifdef KMERS_STAMPS
+        t1 = __builtin_amdgcn_s_memrealtime();
+#endif
         __syncthreads();
+#ifdef KMERS_STAMPS
+        t2 = __builtin_amdgcn_s_memrealtime();
+#endif
 
         // ---- phase 2: windows -> kmers ---------------------------------------------------
         for (uint32_t r = tid * KPL; r < mt; r += BLOCK * KPL) {
             const uint64_t g = m0 + r;
             uint64_t fw[KPL][N], rc[KPL][N];
-            window<N>(lds, 2u * (r * J + b0), k, mask, fw[0], rc[0]);
+            window<N, DST>(lds, (uint32_t)DST * (r * J + b0), k, mask, fw[0], rc[0]);
             if constexpr (KPL == 2) {
-                // next window: one symbol further.  rc shifts right, fw shifts left
-                // (the reference's own rolling step, CanonicalKmers.jl:102-103).
-                uint32_t bit = 2u * (r + b0 + k);
-                uint64_t code = (lds[bit >> 6] >> (bit & 63u)) & 3u;
-                fw[1][0] = ((fw[0][0] << 2) | code) & mask;
-                rc[1][0] = (rc[0][0] >> 2) | ((code ^ 3u) << (2u * k - 2u));
+                // next window: one symbol further.  fw shifts left, rc shifts right with the
+                // complemented symbol on top (the reference's own rolling step,
+                // CanonicalKmers.jl:102-103, :115-118).
+                const uint32_t bit = (uint32_t)DST * (r + b0 + k);
+                const uint64_t sym = (lds[bit >> 6] >> (bit & 63u)) & ((1u << DST) - 1u);
+                uint64_t csym;
+                if constexpr (DST == 2) csym = sym ^ 3u;
+                else csym = ((sym & 1u) << 3) | ((sym & 2u) << 1) | ((sym & 4u) >> 1) | ((sym & 8u) >> 3);
+                fw[1][0] = ((fw[0][0] << DST) | sym) & mask;
+                rc[1][0] = (rc[0][0] >> DST) | (csym << ((uint32_t)DST * (k - 1u)));
             }
             const bool both = (KPL == 2) && (r + 1 < mt);
 
@@ -167,12 +254,9 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
                         a.out_a[g] = fw[0][0];
                         if (a.out_b) a.out_b[g] = rc[0][0];
                     }
-                } else if constexpr (N == 1) {
-                    a.out_a[g] = fw[0][0];
-                    if (a.out_b) a.out_b[g] = rc[0][0];
                 } else {
-                    *reinterpret_cast<ulonglong2 *>(a.out_a + 2 * g) = make_ulonglong2(fw[0][0], fw[0][1]);
-                    if (a.out_b) *reinterpret_cast<ulonglong2 *>(a.out_b + 2 * g) = make_ulonglong2(rc[0][0], rc[0][1]);
+                    store_kmer<N>(a.out_a, g, fw[0]);
+                    if (a.out_b) store_kmer<N>(a.out_b, g, rc[0]);
                 }
             } else {
                 // canonical: fw < rv ? fw : rv (CanonicalKmers.jl:224)
@@ -197,15 +281,21 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
                         if (a.out_a) a.out_a[g] = c[0][0];
                         if (a.out_b) a.out_b[g] = fx_hash<N>(c[0], a.seed);
                     }
-                } else if constexpr (N == 1) {
-                    if (a.out_a) a.out_a[g] = c[0][0];
-                    if (a.out_b) a.out_b[g] = fx_hash<N>(c[0], a.seed);
                 } else {
-                    if (a.out_a) *reinterpret_cast<ulonglong2 *>(a.out_a + 2 * g) = make_ulonglong2(c[0][0], c[0][1]);
+                    if (a.out_a) store_kmer<N>(a.out_a, g, c[0]);
                     if (a.out_b) a.out_b[g] = fx_hash<N>(c[0], a.seed);
                 }
             }
         }
+#ifdef KMERS_STAMPS
+        t3 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t4 = __builtin_amdgcn_s_memrealtime();
+        if (a.stamps && (tile & 1023u) == 0 && (tid & 63u) == 0) {
+            uint64_t *o = a.stamps + ((tile >> 10) * WAVES + (tid >> 6)) * 8;
+            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = tile;
+        }
+#endif
     }
 
     if constexpr (MODE == MODE_XOR) {
@@ -215,10 +305,10 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     }
 }
 
-// Direct (gather) kernel for large strides, where a tile would stage mostly unused bases:
-// one lane per kmer, symbols fetched one by one exactly like unsafe_extract
-// (src/construction_utils.jl:41-69).  Edge path, not bandwidth critical.
-template <int SRC_BITS, int N>
+// Direct (gather) kernel for large strides, where a tile would stage mostly unused symbols:
+// one lane per kmer, symbols fetched and shifted in one by one exactly like unsafe_extract
+// (src/construction_utils.jl:27-69).  Edge path, not bandwidth critical.
+template <int SRC_BITS, int DST, int N>
 __global__ __launch_bounds__(BLOCK) void gather_kernel(const StreamArgs a) {
     uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (g >= a.n_kmers) return;
@@ -230,18 +320,20 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(const StreamArgs a) {
         uint64_t bit = a.first_bit + (base + t) * SRC_BITS;
         uint64_t enc = (a.src[bit >> 6] >> (bit & 63u)) & ((1u << SRC_BITS) - 1u);
         uint64_t code = enc;
-        if constexpr (SRC_BITS == 4) {
+        if constexpr (SRC_BITS == 4 && DST == 2) {
             if (__popcll(enc) != 1) {
                 atomicMin(a.err_slot, (unsigned long long)(base + t));
                 return;
             }
             code = (uint64_t)(__ffsll((long long)enc) - 1);
+        } else if constexpr (SRC_BITS == 2 && DST == 4) {
+            code = 1ull << enc;
         }
-        if constexpr (N == 2) d[0] = (d[0] << 2) | (d[1] >> 62);
-        d[N - 1] = (d[N - 1] << 2) | code;
-    }
 #pragma unroll
-    for (int w = 0; w < N; ++w) a.out_a[g * N + w] = d[w];
+        for (int w = 0; w < N - 1; ++w) d[w] = (d[w] << DST) | (d[w + 1] >> (64 - DST));  // leftshift_carry
+        d[N - 1] = (d[N - 1] << DST) | code;
+    }
+    store_kmer<N>(a.out_a, g, d);
 }
 
 }  // namespace kmers

@@ -386,7 +386,7 @@ class AbstractKmerIterator(metaclass=_Parametric):
         if not self.ctx.lib.kmers_supported(self.seq.alphabet.bits, alphabet.bits, K, stride):
             raise UnsupportedError(
                 f"Kmer{{{alphabet},{K}}} from {self.seq.alphabet} is outside the kernels' coverage "
-                "(2-bit kmer alphabets, K <= 64)")
+                "(kmers of at most 4 words: K <= 128 for 2-bit, K <= 64 for 4-bit alphabets)")
 
     # Base.eltype (src/iterators/common.jl:13-15)
     @property

@@ -44,7 +44,8 @@ def test_geometry_helpers(km):
     assert lib.kmers_count(10, 3, 1) == 8 and lib.kmers_count(2, 3, 1) == 0
     assert lib.kmers_count(8, 3, 2) == 3 and lib.kmers_count(11, 3, 3) == 3
     assert lib.kmers_count(10**10, 31, 1) == 10**10 - 30
-    assert lib.kmers_supported(4, 2, 31, 1) == 1 and lib.kmers_supported(4, 2, 65, 1) == 0
+    assert lib.kmers_supported(4, 2, 31, 1) == 1 and lib.kmers_supported(4, 2, 128, 1) == 1
+    assert lib.kmers_supported(4, 2, 129, 1) == 0 and lib.kmers_supported(2, 4, 64, 1) == 1 and lib.kmers_supported(2, 4, 65, 1) == 0
 
 
 def test_no_cpu_fallback(km):

@@ -55,13 +55,21 @@ def test_smaller_than_k_and_aliases(km):
 
 
 def test_conversible_alphabets(km, kats):
-    # test/runtests.jl:674-690 (2-bit kmer alphabets; 4-bit kmer alphabets are row f3)
+    # test/runtests.jl:674-690: every source alphabet x every kmer alphabet
     g = kats["G14_property_seqs"]
     for text in g["fw_two_bit"] + g["fw_four_bit"]:
         for src in (km.LongDNA[2], km.LongDNA[4], km.LongRNA[2], km.LongRNA[4]):
-            for alias, alph in ((km.FwDNAMers, "dna2"), (km.FwRNAMers, "rna2")):
-                v1 = km.collect(alias[3](src(text)))
-                assert [k.data for k in v1] == naive.fw_kmers(text, 3, alph)
+            for alphabet in (km.DNAAlphabet[2], km.DNAAlphabet[4], km.RNAAlphabet[2], km.RNAAlphabet[4]):
+                v1 = km.collect(km.FwKmers[alphabet, 3](src(text)))
+                assert [k.data for k in v1] == naive.fw_kmers(text, 3, alphabet.bits)
+    # docstring of FwRvIterator (CanonicalKmers.jl:14-18): 4-bit kmers
+    g3 = kats["G3_fwrv"]
+    got = km.collect(km.FwRvIterator[km.DNAAlphabet[4], 3](km.LongDNA[4](g3["seq"])))
+    assert [(str(a), str(b)) for a, b in got] == [tuple(p) for p in g3["pairs"]]
+    # 4-bit kmers keep ambiguous symbols (Copyable): test/runtests.jl:857, :866
+    amb = "TAGCCWKMMNAGCTV"
+    got = km.collect(km.SpacedKmers[km.RNAAlphabet[4], 2, 3](km.LongDNA[4](amb)))
+    assert [k.data for k in got] == naive.spaced(amb, 2, 3, 4)
 
 
 def test_ambiguous_sources_throw(km, kats):

@@ -102,6 +102,52 @@ def test_fw_and_revcomp_parity(km, ctx, orc, bits):
             assert rc == 0 and np.array_equal(fw2, efw)
 
 
+@pytest.mark.parametrize("src,dst", [(2, 2), (4, 2), (2, 4), (4, 4)])
+def test_all_recoding_schemes_and_wide_kmers(km, ctx, orc, src, dst):
+    """Every RecodingScheme between 2- and 4-bit alphabets (construction.jl:75-100: Copyable,
+    FourToTwo, TwoToFour) and kmers of 1..4 words, as in test/runtests.jl:674-690, :749-760."""
+    cap = km._capi
+    per = 64 // dst
+    ks = sorted({1, 3, per - 1, per, per + 1, 2 * per - 1, 2 * per, 2 * per + 1, 3 * per, 3 * per + 1, 4 * per - 1, 4 * per})
+    rng = np.random.default_rng(src * 10 + dst)
+    for K in ks:
+        N = (K * dst + 63) // 64
+        for L in (K, K + 9, 3000, 17001):
+            if src == 4 and dst == 4:  # Copyable 4 -> 4 keeps ambiguous symbols
+                text = naive.random_text(rng, L, p_amb=0.1)
+                words = naive.longseq_words(text, 4)
+            else:
+                words = orc.synth_words(K + L, 2, (L * src + 63) // 64 + 1, src)
+            n = L - K + 1
+            fw = np.zeros((n, N), dtype=np.uint64)
+            rv = np.zeros((n, N), dtype=np.uint64)
+            ck = np.zeros((n, N), dtype=np.uint64)
+            hs = np.zeros(n, dtype=np.uint64)
+            res = cap.Result()
+            seq, keep = make_seq(km, words, L, src)
+            rc = ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, dst, vp(fw), vp(rv), cap.MEM_HOST, C.byref(res))
+            assert rc == 0, (K, L, ctx.last_error())
+            rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, vp(ck), vp(hs), 17, cap.MEM_HOST, C.byref(res))
+            assert rc == 0, (K, L, ctx.last_error())
+            efw, erv, _ = orc.fwrv(words, L, src, dst, K)
+            ek, eh, _ = orc.canonical(words, L, src, dst, K, seed=17)
+            assert np.array_equal(fw, efw), (K, L)
+            assert np.array_equal(rv, erv), (K, L)
+            assert np.array_equal(ck, ek) and np.array_equal(hs, eh), (K, L)
+        # spaced, tile and gather paths
+        for J in (3, 40):
+            L = 5000
+            words = orc.synth_words(K, 0, (L * src + 63) // 64 + 1, src)
+            n = (L - K) // J + 1
+            out = np.zeros((n, N), dtype=np.uint64)
+            res = cap.Result()
+            seq, keep = make_seq(km, words, L, src)
+            rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, dst, vp(out), cap.MEM_HOST, C.byref(res))
+            assert rc == 0, (K, J, ctx.last_error())
+            ek, _ = orc.spaced(words, L, src, dst, K, J)
+            assert np.array_equal(out, ek), (K, J)
+
+
 def test_offset_views(km, ctx, orc):
     """first_base != 0 (LongSubSeq / halo shards): same result as the oracle on the re-packed view."""
     cap = km._capi
@@ -341,6 +387,7 @@ def test_bad_arguments(km, ctx):
     res = cap.Result()
     assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 0, 2, vp(out), None, 0, C.byref(res)) == cap.E_BADARG
     assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), 3, 0, 2, vp(out), 0, C.byref(res)) == cap.E_BADARG
-    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 65, 2, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
-    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 4, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 129, 2, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 65, 4, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 8, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
     assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 2, vp(out), None, cap.ASYNC, C.byref(res)) == cap.E_BADARG

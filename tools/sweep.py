@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--libs", default=cap.library_path())
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--no-hash", action="store_true")
+    ap.add_argument("--prefetch", default="0", help="prefetch distances in tiles")
     ap.add_argument("--b-offsets", default="0", help="byte offsets of the second output array inside its allocation")
     ap.add_argument("--mode", default="canonical", choices=["canonical", "fw", "fwrc"])
     a = ap.parse_args()
@@ -55,9 +56,11 @@ def main():
         for t in a.tiles.split(","):
             for g in a.grids.split(","):
                 for off in a.b_offsets.split(","):
-                    variants.append((os.path.basename(path), lib, h, int(t), int(g), int(off)))
+                    for pf in a.prefetch.split(","):
+                        variants.append((os.path.basename(path), lib, h, int(t), int(g), int(off), int(pf)))
     lib0, h0 = variants[0][1], variants[0][2]
     buf = torch.zeros(nw + 2, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the generator on the library's
     assert lib0.kmers_synth_dna(h0, 12345, 0, nw, bits, 0, buf.data_ptr()) == 0
     out_a = torch.empty(n * N, dtype=torch.int64, device=dev)
     max_off = max(int(o) for o in a.b_offsets.split(","))
@@ -67,7 +70,7 @@ def main():
     bpk = bits / 8 + 8 * N + (0 if out_b is None else (8 * N if a.mode == "fwrc" else 8))
     times = {i: [] for i in range(len(variants))}
     for rnd in range(a.rounds + 1):
-        for i, (name, lib, h, t, g, off) in enumerate(variants):
+        for i, (name, lib, h, t, g, off, pf) in enumerate(variants):
             pb = out_b.data_ptr() + off if out_b is not None else None
             lib.kmers_ctx_set_param(h, cap.PARAM_TILE_KMERS, t)
             lib.kmers_ctx_set_param(h, cap.PARAM_MAX_GRID, g)
@@ -85,11 +88,11 @@ def main():
             if rnd:
                 times[i].append(e0.elapsed_time(e1))
     print(f"# mode={a.mode} K={K} src_bits={bits} bases={L} bytes/kmer={bpk} rounds={a.rounds}")
-    print(f"{'lib':28s} {'tile':>6s} {'grid':>8s} {'b_off':>9s} {'med ms':>9s} {'min ms':>9s} {'GB/s(med)':>10s} {'frac8T':>7s}")
-    for i, (name, lib, h, t, g, off) in enumerate(variants):
+    print(f"{'lib':28s} {'tile':>6s} {'grid':>8s} {'b_off':>9s} {'pf':>6s} {'med ms':>9s} {'min ms':>9s} {'GB/s(med)':>10s} {'frac8T':>7s}")
+    for i, (name, lib, h, t, g, off, pf) in enumerate(variants):
         med, mn = float(np.median(times[i])), float(np.min(times[i]))
         gbs = bpk * n / (med * 1e-3) / 1e9
-        print(f"{name:28s} {t:6d} {g:8d} {off:9d} {med:9.4f} {mn:9.4f} {gbs:10.1f} {gbs / 8000:7.4f}")
+        print(f"{name:28s} {t:6d} {g:8d} {off:9d} {pf:6d} {med:9.4f} {mn:9.4f} {gbs:10.1f} {gbs / 8000:7.4f}")
 
 
 if __name__ == "__main__":
