@@ -12,7 +12,9 @@
  *
  * Data formats (bit-identical to the reference):
  *   input  = LongSequence.data :: Vector{UInt64}, symbol i (1-based) at bits
- *            [((i-1)*bps) mod 64, +bps) of word ((i-1)*bps) div 64   (bps = 2 or 4)
+ *            [((i-1)*bps) mod 64, +bps) of word ((i-1)*bps) div 64   (bps = 2 or 4),
+ *            or ASCII bytes (src_bits = 8: String / Vector{UInt8} sources, one byte per symbol,
+ *            `words` then points at the bytes; AsciiEncode, src/construction.jl:94-95)
  *   output = Vector{Kmer{A,K,N}} memory: N = cld(K*bps_dst, 64) UInt64 per element,
  *            data[1] first, first symbol in the most significant used bits, unused
  *            bits = top bits of data[1] = 0                        (src/kmer.jl:32-44)
@@ -71,8 +73,8 @@ typedef struct {
     uint64_t n_bases;      /* LongSequence.len */
     uint64_t first_base;   /* 0-based symbol offset of the view inside words[] */
     uint64_t index_origin; /* 0 for a whole sequence */
-    int32_t src_bits;      /* 2 (DNA/RNAAlphabet{2}) or 4 (DNA/RNAAlphabet{4}) */
-    int32_t reserved;
+    int32_t src_bits;      /* 2 (DNA/RNAAlphabet{2}), 4 (DNA/RNAAlphabet{4}) or 8 (ASCII bytes: String, Vector{UInt8}) */
+    int32_t alphabet;      /* ASCII sources only: 0 = the kmer alphabet is DNA (T valid), 1 = RNA (U valid) */
 } kmers_seq;
 
 /* ---- library / context ------------------------------------------------------- */

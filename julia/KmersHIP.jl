@@ -26,7 +26,7 @@ struct CSeq
     first_base::UInt64
     index_origin::UInt64
     src_bits::Int32
-    reserved::Int32
+    alphabet::Int32
 end
 
 mutable struct CResult

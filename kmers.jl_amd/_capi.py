@@ -26,7 +26,7 @@ class Result(C.Structure):
 
 class Seq(C.Structure):
     _fields_ = [("words", C.c_void_p), ("n_bases", C.c_uint64), ("first_base", C.c_uint64),
-                ("index_origin", C.c_uint64), ("src_bits", C.c_int32), ("reserved", C.c_int32)]
+                ("index_origin", C.c_uint64), ("src_bits", C.c_int32), ("alphabet", C.c_int32)]
 
 
 # every symbol include/kmers_hip.h declares: name -> (restype, argtypes)

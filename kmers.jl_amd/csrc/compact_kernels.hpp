@@ -25,13 +25,20 @@ struct CompactArgs {
     uint32_t k;
     uint32_t stride;          // keep windows with (start0 % stride) == 0
     uint32_t tile_kmers;      // multiple of 256
+    const uint8_t *ascii_lut; // SRC_BITS == 8: the reference's ASCII_SKIPPING_LUT (common.jl:22-32)
+    unsigned long long *err_slot;  // SRC_BITS == 8: first invalid byte (0xff in the table) -> EncodeError
+    uint64_t n_bases;         // SRC_BITS == 8: every byte below n_bases is inspected (UnambiguousKmers.jl:117-123)
 };
 
 template <int SRC_BITS, int N, bool EMIT>
 __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a) {
     __shared__ uint64_t lds[LDS_QWORDS];
     __shared__ uint64_t amb[MAX_TILE_BASES / 64 + 8];
+    __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if constexpr (SRC_BITS == 8) {
+        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = a.ascii_lut[i];
+    }
     const uint32_t k = a.k;
     const uint64_t mask = head_mask((int)k, 2);
     const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
@@ -49,7 +56,20 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
         __syncthreads();
         for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
             uint64_t x = a.src[w0 + wi];
-            if constexpr (SRC_BITS == 4) {
+            if constexpr (SRC_BITS == 8) {
+                uint32_t codes = 0, flags = 0;
+                uint64_t f = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    uint32_t v = lut[(x >> (8 * j)) & 0xffu];
+                    codes |= (v & 3u) << (2 * j);
+                    flags |= (v >= 0xf0u ? 1u : 0u) << j;             // 0xf0: ambiguous -> skip the window
+                    f |= (uint64_t)(v == 0xffu ? 1u : 0u) << (8 * j);  // 0xff: not a nucleotide -> throw
+                }
+                reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)codes;
+                reinterpret_cast<uint8_t *>(amb)[wi] = (uint8_t)flags;
+                if (f) report_bad_symbols<8, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, w0 + wi, f);
+            } else if constexpr (SRC_BITS == 4) {
                 uint64_t bad;
                 uint32_t c = pack_4to2(x, bad);
                 reinterpret_cast<uint32_t *>(lds)[wi] = c;

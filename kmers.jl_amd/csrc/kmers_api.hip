@@ -11,6 +11,7 @@
 #include <new>
 #include <string>
 
+#include "ascii_tables.hpp"
 #include "batch_kernels.hpp"
 #include "compact_kernels.hpp"
 #include "stream_kernel.hpp"
@@ -23,6 +24,7 @@ struct kmers_ctx {
     bool own_stream = false;
     unsigned long long *d_err = nullptr;  // first offending symbol (0-based), ~0 = none
     uint64_t *d_scratch = nullptr;        // 64 words of device scratch
+    uint8_t *d_luts = nullptr;            // 5 x 256 B: ascii_encode {2,4}-bit x {DNA,RNA}, then ASCII_SKIPPING_LUT
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_cap[4] = {0, 0, 0, 0};
     std::string last_error;
@@ -78,7 +80,10 @@ int check_common(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int ds
     if (!seq) return fail(ctx, KMERS_E_BADARG, "seq is NULL");
     if (k < 1) return fail(ctx, KMERS_E_BADARG, "K must be at least 1");
     if (stride < 1) return fail(ctx, KMERS_E_BADARG, "J must be at least 1");
-    if (seq->src_bits != 2 && seq->src_bits != 4) return fail(ctx, KMERS_E_BADARG, "src_bits must be 2 or 4");
+    if (seq->src_bits != 2 && seq->src_bits != 4 && seq->src_bits != 8)
+        return fail(ctx, KMERS_E_BADARG, "src_bits must be 2, 4 or 8 (ASCII bytes)");
+    if (seq->src_bits == 8 && (flags & KMERS_MEM_DEVICE) && (reinterpret_cast<uintptr_t>(seq->words) & 7u))
+        return fail(ctx, KMERS_E_BADARG, "device ASCII buffers must be 8-byte aligned");
     if (seq->n_bases && !seq->words) return fail(ctx, KMERS_E_BADARG, "seq.words is NULL");
     if ((flags & KMERS_ASYNC) && !(flags & KMERS_MEM_DEVICE))
         return fail(ctx, KMERS_E_BADARG, "KMERS_ASYNC requires KMERS_MEM_DEVICE");
@@ -98,6 +103,15 @@ int stage_sequence(kmers_ctx *ctx, const kmers_seq *seq, int flags, Staged *out)
     if (flags & KMERS_MEM_DEVICE) {
         out->d_words = seq->words;
         out->first_bit = bit0;
+        return KMERS_OK;
+    }
+    if (seq->src_bits == 8) {  // bytes: copy exactly the view (the host pointer need not be aligned)
+        size_t nbytes = (size_t)seq->n_bases;
+        if (int rc = ensure_stage(ctx, 0, nbytes + 16)) return rc;
+        if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], reinterpret_cast<const char *>(seq->words) + seq->first_base,
+                                                nbytes, hipMemcpyHostToDevice, ctx->stream));
+        out->d_words = static_cast<const uint64_t *>(ctx->stage[0]);
+        out->first_bit = 0;
         return KMERS_OK;
     }
     uint64_t w0 = bit0 >> 6;
@@ -131,11 +145,15 @@ int collect(kmers_ctx *ctx, kmers_result *res, uint64_t n_out) {
     if (res) {
         res->status = KMERS_E_ENCODE;
         res->err_pos = (uint64_t)pos + 1 + ctx->err_origin;
-        res->err_enc = (uint32_t)((word >> (bit & 63u)) & ((1u << ctx->err_bits) - 1u));
+        res->err_enc = (uint32_t)((word >> (bit & 63u)) & ((1ull << ctx->err_bits) - 1ull));
         res->n_out = 0;
     }
-    ctx->last_error = "EncodeError: ambiguous symbol cannot be encoded in a 2-bit alphabet";
+    ctx->last_error = "EncodeError: symbol cannot be encoded in the kmer alphabet";
     return KMERS_E_ENCODE;
+}
+
+const uint8_t *ascii_table(kmers_ctx *ctx, int dst_bits, bool rna) {
+    return ctx->d_luts + 256 * ((dst_bits == 4 ? 2 : 0) + (rna ? 1 : 0));
 }
 
 void remember_source(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st) {
@@ -189,7 +207,9 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap));
     dim3 block(BLOCK);
-    if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, grid, block, ctx->stream, a);
+    if (src_bits == 8 && dst_bits == 2) launch_widths<MODE, 8, 2>(n_words, stride1, grid, block, ctx->stream, a);
+    else if (src_bits == 8) launch_widths<MODE, 8, 4>(n_words, stride1, grid, block, ctx->stream, a);
+    else if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, grid, block, ctx->stream, a);
     else if (src_bits == 2 && dst_bits == 2) launch_widths<MODE, 2, 2>(n_words, stride1, grid, block, ctx->stream, a);
     else if (src_bits == 4 && dst_bits == 4) launch_widths<MODE, 4, 4>(n_words, stride1, grid, block, ctx->stream, a);
     else launch_widths<MODE, 2, 4>(n_words, stride1, grid, block, ctx->stream, a);
@@ -251,12 +271,15 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     a.err_slot = ctx->d_err;
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
+    a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
 
     int rc;
     if ((uint64_t)stride * (uint64_t)dst_bits > 64) {
         // gather path (forward kmers only: kmers_spaced); a tile would stage mostly unused symbols
         dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
-        if (seq->src_bits == 4 && dst_bits == 2) launch_gather<4, 2>(nw, grid, block, ctx->stream, a);
+        if (seq->src_bits == 8 && dst_bits == 2) launch_gather<8, 2>(nw, grid, block, ctx->stream, a);
+        else if (seq->src_bits == 8) launch_gather<8, 4>(nw, grid, block, ctx->stream, a);
+        else if (seq->src_bits == 4 && dst_bits == 2) launch_gather<4, 2>(nw, grid, block, ctx->stream, a);
         else if (seq->src_bits == 2 && dst_bits == 2) launch_gather<2, 2>(nw, grid, block, ctx->stream, a);
         else if (seq->src_bits == 4 && dst_bits == 4) launch_gather<4, 4>(nw, grid, block, ctx->stream, a);
         else launch_gather<2, 4>(nw, grid, block, ctx->stream, a);
@@ -283,8 +306,16 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
 int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uint64_t *out_kmers,
                     int64_t *out_starts, uint64_t capacity, int flags, kmers_result *res) {
     const int nw = kmers_words_per_kmer(k, 2);
-    const uint64_t n = kmers_count(seq->n_bases, k, 1);
-    if (n == 0) return KMERS_OK;
+    uint64_t n = kmers_count(seq->n_bases, k, 1);
+    const bool ascii = seq->src_bits == 8;
+    // An ASCII source is scanned to its end even when it is shorter than K: an invalid byte
+    // still throws (UnambiguousKmers.jl:117-123).  Validate with 1-symbol windows, emit nothing.
+    const bool validate_only = ascii && n == 0 && seq->n_bases > 0;
+    if (n == 0 && !validate_only) return KMERS_OK;
+    if (validate_only) {
+        n = seq->n_bases;
+        k = 1;
+    }
     Staged st;
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
     remember_source(ctx, seq, st);
@@ -294,6 +325,9 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.src = st.d_words;
     a.first_bit = st.first_bit;
     a.n_cand = n;
+    a.ascii_lut = ctx->d_luts + 1024;
+    a.err_slot = ctx->d_err;
+    a.n_bases = seq->n_bases;
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
     a.index_origin = seq->index_origin;
@@ -313,8 +347,9 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
 #define UL(SB, NN, EM) hipLaunchKernelGGL((unambiguous_kernel<SB, NN, EM>), grid, block, 0, ctx->stream, a)
 #define UDISPATCH(EM)                                                         \
     do {                                                                      \
-        if (seq->src_bits == 4) { if (nw == 1) UL(4, 1, EM); else UL(4, 2, EM); } \
-        else                    { if (nw == 1) UL(2, 1, EM); else UL(2, 2, EM); } \
+        if (seq->src_bits == 8) { if (nw == 1) UL(8, 1, EM); else UL(8, 2, EM); }      \
+        else if (seq->src_bits == 4) { if (nw == 1) UL(4, 1, EM); else UL(4, 2, EM); } \
+        else                    { if (nw == 1) UL(2, 1, EM); else UL(2, 2, EM); }      \
     } while (0)
     UDISPATCH(false);
     HIP_TRY(ctx, hipGetLastError());
@@ -323,6 +358,10 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     uint64_t total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, offsets + n_counts, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ascii) {  // an invalid byte anywhere in the source is an EncodeError
+        if (int erc = collect(ctx, res, total)) return erc;
+    }
+    if (validate_only) total = 0;
     if (res) res->n_out = total;
     if (total > capacity || (!out_kmers && !out_starts)) {
         // capacity query (both outputs NULL) or buffers too small: report the count only
@@ -371,7 +410,7 @@ uint64_t kmers_count(uint64_t n_bases, int k, int stride) {
 }
 
 int kmers_supported(int src_bits, int dst_bits, int k, int stride) {
-    if (src_bits != 2 && src_bits != 4) return 0;
+    if (src_bits != 2 && src_bits != 4 && src_bits != 8) return 0;
     if (dst_bits != 2 && dst_bits != 4) return 0;
     if (k < 1 || stride < 1) return 0;
     return n_coding_elements(k, dst_bits) <= 4;  // K <= 128 (2-bit kmers) / K <= 64 (4-bit kmers)
@@ -392,7 +431,15 @@ int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return KMERS_E_HIP; }
         ctx->own_stream = true;
     }
+    uint8_t luts[5 * 256];
+    build_ascii_encode_table(2, false, luts);
+    build_ascii_encode_table(2, true, luts + 256);
+    build_ascii_encode_table(4, false, luts + 512);
+    build_ascii_encode_table(4, true, luts + 768);
+    build_ascii_skipping_table(luts + 1024);
     if (hipMalloc(&ctx->d_err, 8) != hipSuccess || hipMalloc(&ctx->d_scratch, 64 * 8) != hipSuccess ||
+        hipMalloc(&ctx->d_luts, sizeof luts) != hipSuccess ||
+        hipMemcpy(ctx->d_luts, luts, sizeof luts, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
         kmers_ctx_destroy(ctx);
@@ -410,6 +457,7 @@ void kmers_ctx_destroy(kmers_ctx *ctx) {
         if (p) (void)hipFree(p);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_luts) (void)hipFree(ctx->d_luts);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -503,6 +551,7 @@ int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, 
     a.k = (uint32_t)k;
     a.stride = 1;
     a.xor_canonical = canonical ? 1u : 0u;
+    a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
     if (ctx->max_grid <= 0) {
         // fused consumer: persistent grid, one atomic per wave at the very end
         int64_t saved = ctx->max_grid;

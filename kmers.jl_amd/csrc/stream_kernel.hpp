@@ -42,32 +42,39 @@ struct StreamArgs {
     uint32_t tile_kmers;
     uint32_t xor_canonical;  // MODE_XOR: 1 = canonical kmers, 0 = forward kmers
     uint64_t *stamps;        // diagnostic builds (-DKMERS_STAMPS) only: per-workgroup s_memrealtime stamps
+    const uint8_t *ascii_lut; // SRC_BITS == 8: 256-entry byte -> symbol table (ascii_tables.hpp)
 };
 
-// First inspected ambiguous symbol of one 4-bit source word -> err_slot (rare path, kept
-// inline and call-free so the kernel needs no stack).  Inspected set = what the reference's
-// iterate() would have looked at before stopping: every symbol below inspect_end, except
-// (stride >= K) the gaps between kmers (src/iterators/SpacedKmers.jl:133-134).
-template <bool STRIDE1>
-__device__ __forceinline__ void report_ambiguous(unsigned long long *err_slot, uint64_t first_bit,
-                                                 uint64_t inspect_end, uint32_t stride, uint32_t k,
-                                                 uint64_t word_index, uint64_t bad) {
-    uint64_t f = (bad | (bad >> 1) | (bad >> 2)) & 0x1111111111111111ull;  // bit 4j = symbol j is ambiguous
-    // symbol index of nibble 0 of this word; negative inside the first word of an offset view
-    // (both terms are multiples of 4, so the division is exact)
-    const long long base0 = ((long long)(word_index * 64) - (long long)first_bit) / 4;
-    if (base0 < 0) f &= ~0ull << (uint32_t)(-base0 * 4);
+// First inspected offending symbol of one source word -> err_slot (rare path, kept inline and
+// call-free so the kernel needs no stack).  `f` holds one flag per symbol at bit SRC_BITS*j.
+// Inspected set = what the reference's iterate() would have looked at before stopping: every
+// symbol below inspect_end, except (stride >= K) the gaps between kmers
+// (src/iterators/SpacedKmers.jl:133-134).
+template <int SRC_BITS, bool STRIDE1>
+__device__ __forceinline__ void report_bad_symbols(unsigned long long *err_slot, uint64_t first_bit,
+                                                   uint64_t inspect_end, uint32_t stride, uint32_t k,
+                                                   uint64_t word_index, uint64_t f) {
+    constexpr int PER = 64 / SRC_BITS;
+    // symbol index of symbol 0 of this word; negative inside the first word of an offset view
+    // (both terms are multiples of SRC_BITS, so the division is exact)
+    const long long base0 = ((long long)(word_index * 64) - (long long)first_bit) / SRC_BITS;
+    if (base0 < 0) f &= ~0ull << (uint32_t)(-base0 * SRC_BITS);
     const long long room = (long long)inspect_end - base0;  // symbols of this word below inspect_end
     if (room <= 0) return;
-    if (room < 16) f &= (1ull << (uint32_t)(room * 4)) - 1ull;
+    if (room < PER) f &= (1ull << (uint32_t)(room * SRC_BITS)) - 1ull;
     if constexpr (!STRIDE1) {  // stride 1 has no gaps
         if (stride >= k) {
 #pragma unroll 1
-            for (uint32_t j = 0; j < 16; ++j)
-                if (((f >> (4 * j)) & 1ull) && ((uint64_t)(base0 + j) % stride) >= k) f &= ~(1ull << (4 * j));
+            for (uint32_t j = 0; j < (uint32_t)PER; ++j)
+                if (((f >> (SRC_BITS * j)) & 1ull) && ((uint64_t)(base0 + j) % stride) >= k) f &= ~(1ull << (SRC_BITS * j));
         }
     }
-    if (f) atomicMin(err_slot, (unsigned long long)(base0 + (long long)(__ffsll((long long)f) - 1) / 4));
+    if (f) atomicMin(err_slot, (unsigned long long)(base0 + (long long)(__ffsll((long long)f) - 1) / SRC_BITS));
+}
+
+// 4-bit source: flags of the symbols with count_ones != 1, from pack_4to2's `bad`
+__device__ __forceinline__ uint64_t flags_from_bad4(uint64_t bad) {
+    return (bad | (bad >> 1) | (bad >> 2)) & 0x1111111111111111ull;
 }
 
 // ---- symbol-level helpers generic in the kmer alphabet width (DST = 2 or 4 bits) -------------
@@ -169,17 +176,30 @@ __device__ __forceinline__ void store_kmer(uint64_t *out, uint64_t g, const uint
 }
 
 // Phase 1 for one source word: recode into the DST-bit LDS stream (RecodingScheme,
-// src/construction.jl:75-100).  Returns the non-zero `bad` nibble map for FourToTwo.
+// src/construction.jl:75-100).  Returns one flag per offending symbol at bit SRC*j (FourToTwo:
+// count_ones != 1; AsciiEncode: byte outside the alphabet), 0 otherwise.
 //   stream word index: SRC == DST: qword wi;  4->2: dword wi;  2->4: qwords 2wi, 2wi+1
 template <int SRC, int DST>
-__device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint64_t x) {
-    if constexpr (SRC == DST) {  // Copyable
+__device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint64_t x, const uint8_t *lut) {
+    if constexpr (SRC == 8) {  // AsciiEncode: 8 bytes -> 8 symbols through the alphabet's table
+        uint32_t codes = 0;
+        uint64_t f = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t v = lut[(x >> (8 * j)) & 0xffu];
+            codes |= (v & 0xfu) << (DST * j);
+            f |= (uint64_t)(v >> 7) << (8 * j);  // 0x80: not a symbol of the alphabet
+        }
+        if constexpr (DST == 2) reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)codes;
+        else reinterpret_cast<uint32_t *>(lds)[wi] = codes;
+        return f;
+    } else if constexpr (SRC == DST) {  // Copyable
         lds[wi] = x;
         return 0;
     } else if constexpr (SRC == 4) {  // FourToTwo: trailing_zeros of a one-hot nibble, validated
         uint64_t bad;
         reinterpret_cast<uint32_t *>(lds)[wi] = pack_4to2(x, bad);
-        return bad;
+        return bad ? flags_from_bad4(bad) : 0;
     } else {  // TwoToFour
         lds[2 * wi] = expand_2to4((uint32_t)x);
         lds[2 * wi + 1] = expand_2to4((uint32_t)(x >> 32));
@@ -190,10 +210,14 @@ __device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint6
 template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1>
 __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     __shared__ uint64_t lds[LDS_QWORDS];
+    __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t k = a.k;
     const uint32_t J = STRIDE1 ? 1u : a.stride;
     const uint64_t mask = head_mask((int)k, DST);  // mask of the kmer's head word
+    if constexpr (SRC_BITS == 8) {
+        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = a.ascii_lut[i];  // visible after the tile loop's first barrier
+    }
     constexpr uint32_t KPL = (STRIDE1 && N == 1) ? 2u : 1u;  // kmers per lane per pass -> 16 B stores
     uint64_t xacc = 0;
 
@@ -213,9 +237,9 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
         __syncthreads();  // previous tile's readers are done with the LDS stream
         // ---- phase 1: source words -> DST-bit stream in LDS ------------------------------
         for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
-            uint64_t bad = stage_word<SRC_BITS, DST>(lds, wi, a.src[w0 + wi]);
-            if constexpr (SRC_BITS == 4 && DST == 2) {
-                if (bad) report_ambiguous<STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, k, w0 + wi, bad);
+            uint64_t f = stage_word<SRC_BITS, DST>(lds, wi, a.src[w0 + wi], lut);
+            if constexpr ((SRC_BITS == 4 && DST == 2) || SRC_BITS == 8) {
+                if (f) report_bad_symbols<SRC_BITS, STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, k, w0 + wi, f);
             }
         }
 #ifdef KMERS_STAMPS
@@ -318,9 +342,15 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(const StreamArgs a) {
     for (int w = 0; w < N; ++w) d[w] = 0;
     for (uint32_t t = 0; t < a.k; ++t) {
         uint64_t bit = a.first_bit + (base + t) * SRC_BITS;
-        uint64_t enc = (a.src[bit >> 6] >> (bit & 63u)) & ((1u << SRC_BITS) - 1u);
+        uint64_t enc = (a.src[bit >> 6] >> (bit & 63u)) & ((1ull << SRC_BITS) - 1ull);
         uint64_t code = enc;
-        if constexpr (SRC_BITS == 4 && DST == 2) {
+        if constexpr (SRC_BITS == 8) {
+            code = a.ascii_lut[enc];
+            if (code & 0x80u) {
+                atomicMin(a.err_slot, (unsigned long long)(base + t));
+                return;
+            }
+        } else if constexpr (SRC_BITS == 4 && DST == 2) {
             if (__popcll(enc) != 1) {
                 atomicMin(a.err_slot, (unsigned long long)(base + t));
                 return;

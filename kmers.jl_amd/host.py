@@ -193,6 +193,10 @@ class LongSequence:
     def __len__(self):
         return self.len
 
+    @property
+    def src_bits(self):
+        return self.alphabet.bits
+
     def __str__(self):
         inv = _decode_table(self.alphabet)
         b = self.alphabet.bits
@@ -233,11 +237,34 @@ LongDNA = _LongFamily(DNAAlphabet)
 LongRNA = _LongFamily(RNAAlphabet)
 
 
+class AsciiSource:
+    """A String / Vector{UInt8} source (AsciiEncode, src/construction.jl:94-95): one byte per symbol."""
+    alphabet = None
+    src_bits = 8
+
+    def __init__(self, source):
+        raw = source.encode("latin-1") if isinstance(source, str) else bytes(source)
+        self.len = len(raw)
+        pad = (-self.len) % 8 + 8  # whole 8-byte words plus one spare word
+        self.data = np.frombuffer(raw + b"\0" * pad, dtype=np.uint8)
+        self._dev = None
+
+    def __len__(self):
+        return self.len
+
+    def __str__(self):
+        return self.data[:self.len].tobytes().decode("latin-1")
+
+    device_words = LongSequence.device_words
+    __del__ = LongSequence.__del__
+
+
 def _as_sequence(s):
-    if isinstance(s, LongSequence):
+    if isinstance(s, (LongSequence, AsciiSource)):
         return s
-    raise UnsupportedError(
-        "only LongSequence sources are supported (String / byte sources are SURVEY.md section 8 row f1)")
+    if isinstance(s, (str, bytes, bytearray, np.ndarray)):
+        return AsciiSource(s)
+    raise UnsupportedError(f"unsupported source type {type(s).__name__}")
 
 
 # --------------------------------------------------------------------------------------------
@@ -356,7 +383,10 @@ class KmerArray:
 # --------------------------------------------------------------------------------------------
 # iterators
 def _raise_encode(alphabet, seq, res):
-    sym = _decode_table(seq.alphabet)[res.err_enc] if seq.alphabet.bits == 4 else "?"
+    if seq.src_bits == 8:  # EncodeError(A, repr(byte)), FwKmers.jl:124-126
+        sym = f"0x{res.err_enc:02x} (Char {chr(res.err_enc)!r})"
+    else:
+        sym = _decode_table(seq.alphabet)[res.err_enc] if seq.src_bits == 4 else "?"
     raise EncodeError(alphabet, sym, int(res.err_pos), int(res.err_enc))
 
 
@@ -383,9 +413,9 @@ class AbstractKmerIterator(metaclass=_Parametric):
         self.seq = _as_sequence(seq)
         self.ctx = ctx or default_context()
         self.N = n_coding_elements(K, alphabet.bits)
-        if not self.ctx.lib.kmers_supported(self.seq.alphabet.bits, alphabet.bits, K, stride):
+        if not self.ctx.lib.kmers_supported(self.seq.src_bits, alphabet.bits, K, stride):
             raise UnsupportedError(
-                f"Kmer{{{alphabet},{K}}} from {self.seq.alphabet} is outside the kernels' coverage "
+                f"Kmer{{{alphabet},{K}}} from {self.seq.alphabet or 'ASCII bytes'} is outside the kernels' coverage "
                 "(kmers of at most 4 words: K <= 128 for 2-bit, K <= 64 for 4-bit alphabets)")
 
     # Base.eltype (src/iterators/common.jl:13-15)
@@ -398,7 +428,7 @@ class AbstractKmerIterator(metaclass=_Parametric):
 
     def _view(self, first_base, n_bases):
         return _capi.Seq(self.seq.device_words(self.ctx), n_bases, first_base, first_base,
-                         self.seq.alphabet.bits, 0)
+                         self.seq.src_bits, 1 if self.alphabet.kind == "RNA" else 0)
 
     def _wrap(self, arrays, lo, hi):
         raise NotImplementedError
@@ -599,7 +629,7 @@ class UnambiguousKmers(AbstractKmerIterator):
         return p
 
     def __len__(self):
-        if self.seq.alphabet.bits == 2 and self.lattice == 1:
+        if self.seq.src_bits == 2 and self.lattice == 1:
             return super().__len__()
         raise TypeError("UnambiguousKmers over a 4-bit source is SizeUnknown")  # :33
 
@@ -607,8 +637,10 @@ class UnambiguousKmers(AbstractKmerIterator):
         lib, ctx = self.ctx.lib, self.ctx
         view = self._view(0, self.seq.len)
         res = _capi.Result()
-        ctx.check(lib.kmers_unambiguous(ctx.handle, C.byref(view), self.K, self.lattice, None, None, 0,
-                                        _capi.MEM_DEVICE, C.byref(res)), "kmers_unambiguous(count)")
+        rc = ctx.check(lib.kmers_unambiguous(ctx.handle, C.byref(view), self.K, self.lattice, None, None, 0,
+                                             _capi.MEM_DEVICE, C.byref(res)), "kmers_unambiguous(count)")
+        if rc == _capi.E_ENCODE:
+            _raise_encode(self.alphabet, self.seq, res)
         n = int(res.n_out)
         km = np.zeros((n, self.N), dtype=np.uint64)
         st = np.zeros(n, dtype=np.int64)
@@ -649,10 +681,18 @@ SpacedDNAMers = _alias(SpacedKmers, DNAAlphabet)           # SpacedKmers.jl:46-4
 SpacedRNAMers = _alias(SpacedKmers, RNAAlphabet)           # SpacedKmers.jl:49-50
 
 
-def each_codon(seq, ctx=None):
-    """each_codon(s::BioSequence) (SpacedKmers.jl:80-81)."""
-    fam = RNAAlphabet if seq.alphabet.kind == "RNA" else DNAAlphabet
+def each_codon(*args, ctx=None):
+    """each_codon(s::BioSequence) / each_codon(DNA | RNA, s) (SpacedKmers.jl:77-81)."""
+    if len(args) == 2:
+        kind, seq = args
+        fam = RNAAlphabet if kind in ("RNA", RNA) else DNAAlphabet
+    else:
+        (seq,) = args
+        fam = RNAAlphabet if seq.alphabet.kind == "RNA" else DNAAlphabet
     return SpacedKmers(fam[2], 3, 3, seq, ctx=ctx)
+
+
+DNA, RNA = "DNA", "RNA"
 
 
 def collect(it):

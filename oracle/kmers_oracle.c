@@ -141,11 +141,73 @@ INL int throw_uncertain(orc_result *res, uint64_t pos, uint64_t enc) {
     return ORC_E_ENCODE;
 }
 
+/* ---- AsciiEncode sources (src_bps codes ORC_SRC_ASCII_DNA / _RNA) -----------------------------
+ * BioSequences.ascii_encode(A, byte) restated (absent dependency): the byte's symbol in the KMER's
+ * alphabet A, or 0x80 when the byte is not a symbol of A.  2-bit: ACGT (DNA) / ACGU (RNA), either
+ * case.  4-bit: the IUPAC letters "-ACMGRSVTWYHKDBN" (T->U for RNA), either case, value = the
+ * one-hot/OR encoding.  Call sites: FwKmers.jl:123, CanonicalKmers.jl:156, construction_utils.jl:81,229 */
+static uint8_t ascii_encode(int dst_bps, int rna, uint8_t byte) {
+    static const char iupac[] = "-ACMGRSVTWYHKDBN";
+    uint8_t c = byte;
+    if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+    if (rna) {
+        if (c == 'T') return 0x80;
+        if (c == 'U') c = 'T';
+    } else if (c == 'U') {
+        return 0x80;
+    }
+    if (byte >= 0x80) return 0x80;
+    if (dst_bps == 2) {
+        switch (c) {
+            case 'A': return 0;
+            case 'C': return 1;
+            case 'G': return 2;
+            case 'T': return 3;
+            default: return 0x80;
+        }
+    }
+    for (int v = 0; v < 16; ++v)
+        if (c == (uint8_t)iupac[v]) return (uint8_t)v;
+    return 0x80;
+}
+
+/* ASCII_SKIPPING_LUT of the reference itself (src/iterators/common.jl:22-32): 0..3 for
+ * "Aa","cC","gG","TtUu"; 0xf0 for "-MRSVWYHKDBN" either case; 0xff otherwise. */
+static uint8_t ascii_skipping_lut(uint8_t byte) {
+    switch (byte) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': case 'U': case 'u': return 3;
+        default: break;
+    }
+    static const char amb[] = "-MRSVWYHKDBN";
+    for (int i = 0; amb[i]; ++i)
+        if (byte == (uint8_t)amb[i] || (amb[i] != '-' && byte == (uint8_t)(amb[i] + 32))) return 0xf0;
+    return 0xff;
+}
+
+void orc_ascii_tables(int dst_bps, int rna, uint8_t *encode_lut, uint8_t *skipping_lut) {
+    for (int b = 0; b < 256; ++b) {
+        if (encode_lut) encode_lut[b] = ascii_encode(dst_bps, rna, (uint8_t)b);
+        if (skipping_lut) skipping_lut[b] = ascii_skipping_lut((uint8_t)b);
+    }
+}
+
+#define IS_ASCII(src_bps) ((src_bps) == ORC_SRC_ASCII_DNA || (src_bps) == ORC_SRC_ASCII_RNA)
+
 /* One checked/recoded symbol fetch, per RecodingScheme (src/construction.jl:75-100):
  * same width -> Copyable, 4->2 FourToTwo, 2->4 TwoToFour.
  * Returns 0 and the encoding to shift in, or ORC_E_ENCODE. */
 INL int fetch_recoded(const uint64_t *seq, uint64_t i, const int src_bps, const int dst_bps,
                       uint64_t *enc_out, orc_result *res) {
+    if (IS_ASCII(src_bps)) { /* AsciiEncode: FwKmers.jl:117-129, construction_utils.jl:71-88, :220-236 */
+        uint8_t byte = ((const uint8_t *)seq)[i - 1];
+        uint8_t encoding = ascii_encode(dst_bps, src_bps == ORC_SRC_ASCII_RNA, byte);
+        if (encoding > 0x7f) return throw_uncertain(res, i, byte); /* EncodeError(A, byte) */
+        *enc_out = encoding;
+        return 0;
+    }
     uint64_t encoding = extract_encoded_element(seq, i, src_bps);
     if (src_bps == dst_bps) { /* Copyable: construction_utils.jl:65, FwKmers.jl:91 */
         *enc_out = encoding;
@@ -368,8 +430,16 @@ INL int fwrv_impl(const uint64_t *seq, uint64_t len, const int src_bps, const in
         }
         res->n_out++;
         if (i > len) return 0;                                              /* :100,:113,:124,:137 */
-        uint64_t encoding = extract_encoded_element(seq, i, src_bps);
         uint64_t fenc, renc;
+        if (IS_ASCII(src_bps)) {                     /* AsciiEncode: :146-174 */
+            if (fetch_recoded(seq, i, src_bps, dst_bps, &fenc, res)) return ORC_E_ENCODE;
+            renc = dst_bps == 4 ? complement_nibble(fenc) : (fenc ^ 0x03); /* :161-165 */
+            shift_encoding(fw, N, K, dst_bps, fenc);
+            shift_first_encoding(rv, N, K, dst_bps, renc);
+            ++i;
+            continue;
+        }
+        uint64_t encoding = extract_encoded_element(seq, i, src_bps);
         if (src_bps == 2 && dst_bps == 2) {          /* Copyable, TwoBit: :94-105 */
             fenc = encoding;
             renc = encoding ^ 0x03;
@@ -415,6 +485,28 @@ INL int unambiguous_impl(const uint64_t *seq, uint64_t len, const int src_bps, c
     for (int w = 0; w < N; ++w) kmer[w] = 0;
     int64_t remaining = K;
     uint64_t index = 1;
+    if (IS_ASCII(src_bps)) { /* :109-132 with ASCII_SKIPPING_LUT */
+        for (;;) {
+            while (remaining != 0) {
+                if (index > len) return 0;
+                uint8_t byte = ((const uint8_t *)seq)[index - 1];
+                index += 1;
+                uint8_t encoding = ascii_skipping_lut(byte);
+                if (encoding == 0xff) return throw_uncertain(res, index - 1, byte); /* :122-123 */
+                if (encoding == 0xf0) {
+                    remaining = K;
+                } else {
+                    remaining -= 1;
+                    shift_encoding(kmer, N, K, 2, encoding);
+                }
+            }
+            if (out_kmers)
+                for (int w = 0; w < N; ++w) out_kmers[res->n_out * N + w] = kmer[w];
+            if (out_starts) out_starts[res->n_out] = (int64_t)index - K;
+            res->n_out++;
+            remaining = 1;
+        }
+    }
     for (;;) {
         while (remaining != 0) { /* :140-146 */
             if (index > len) return 0;
@@ -458,7 +550,7 @@ INL int spaced_impl(const uint64_t *seq, uint64_t len, const int src_bps, const 
  * timing is of specialised code (Julia specialises on A, K, N at compile time). */
 static int check_args(int src_bps, int dst_bps, int K, orc_result *res) {
     memset(res, 0, sizeof *res);
-    if ((src_bps != 2 && src_bps != 4) || (dst_bps != 2 && dst_bps != 4) || K < 1 ||
+    if ((src_bps != 2 && src_bps != 4 && !IS_ASCII(src_bps)) || (dst_bps != 2 && dst_bps != 4) || K < 1 ||
         n_coding_elements(K, dst_bps) > ORC_MAX_N) {
         res->status = ORC_E_BADARG; /* FwKmers.jl:31-35 "K must be at least 1" */
         return ORC_E_BADARG;

@@ -29,6 +29,11 @@ extern "C" {
 
 #define ORC_MAX_N 8 /* words per kmer supported by the oracle (K <= 256 2-bit) */
 
+/* src_bps codes for AsciiEncode sources: `seq` is then a byte string (1 byte per symbol) and the
+ * validity table is the one of the KMER's alphabet (DNA: T, RNA: U). */
+#define ORC_SRC_ASCII_DNA 8
+#define ORC_SRC_ASCII_RNA 9
+
 #define ORC_OK 0
 #define ORC_E_ENCODE 1 /* BioSequences.EncodeError: src/construction.jl:108-110 */
 #define ORC_E_BADARG 2
@@ -88,6 +93,10 @@ int orc_spaced(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, int 
 /* XOR-reduce consumer of test/benchmark.jl:9-15 over CanonicalKmers / FwKmers */
 uint64_t orc_reduce_xor_canonical(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, int K,
                                   orc_result *res);
+
+/* BioSequences.ascii_encode table of a kmer alphabet and the reference's ASCII_SKIPPING_LUT
+ * (src/iterators/common.jl:22-32); 256 bytes each, either may be NULL */
+void orc_ascii_tables(int dst_bps, int rna, uint8_t *encode_lut, uint8_t *skipping_lut);
 
 /* ---- synthetic input (the build's own generator) ---- */
 uint64_t orc_synth_rand64(uint64_t seed, uint64_t idx);

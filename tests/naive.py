@@ -66,6 +66,14 @@ def longseq_words(text, alphabet):
     return np.array(out, dtype=np.uint64)
 
 
+def ascii_words(text):
+    """A String / byte source as the oracle and the C ABI take it: the bytes, zero padded to whole
+    8-byte words (+1 spare), viewed as uint64 (byte i = bits 8i.. of word i // 8)."""
+    raw = text.encode("latin-1") if isinstance(text, str) else bytes(text)
+    raw = raw + b"\0" * ((-len(raw)) % 8 + 8)
+    return np.frombuffer(raw, dtype=np.uint64).copy()
+
+
 def revcomp_text(text):
     return "".join(COMP[c] for c in reversed(text.upper()))
 

@@ -151,6 +151,34 @@ def test_spaced_vs_naive(km, kats):
                 assert len(it) == len(got)
 
 
+def test_string_sources(km, kats):
+    """String / byte sources (test/runtests.jl:713-725, :774-801, :836-847, :850-870)."""
+    s = "TaghWS-TGnADbkWWMSTV"
+    T = km.FwKmers[km.DNAAlphabet[4], 4]
+    mers = km.collect(T(s))
+    for source in (s, s.encode(), bytearray(s.encode()), np.frombuffer(s.encode(), dtype=np.uint8)):
+        assert km.collect(T(source)) == mers
+    assert mers == km.collect(T(km.LongDNA[4](s)))
+    with pytest.raises(km.EncodeError):
+        km.collect(km.FwDNAMers[3]("TAGTCGTAGPATGC"))
+    with pytest.raises(km.EncodeError, match=re.escape("cannot encode 0x4e (Char 'N') in DNAAlphabet{2}")):
+        km.collect(km.FwRvDNAIterator[3]("AGNGT"))                       # CanonicalKmers.jl:20-22
+    for text in kats["G14_property_seqs"]["canonical"]:
+        got = km.collect(km.CanonicalDNAMers[5](text))
+        assert [k.data for k in got] == naive.canonical(text, 5, 2)
+    assert km.collect(km.CanonicalKmers[km.DNAAlphabet[2], 4]("TAGTGTCGATGATC")) == \
+        km.collect(km.CanonicalDNAMers[4]("TAGTGTCGATGATC"))
+    for text in kats["G14_property_seqs"]["unambiguous"]:
+        got = km.collect(km.UnambiguousDNAMers[4](text))
+        assert [(k.data, i) for k, i in got] == naive.unambiguous(text, 4)
+    with pytest.raises(km.EncodeError):
+        km.collect(km.UnambiguousDNAMers[3]("TAGTCGTAGPATGC"))
+    with pytest.raises(km.EncodeError):
+        km.collect(km.SpacedDNAMers[3, 4]("TAGAWWWW"))                   # test/runtests.jl:868-869
+    assert texts(km.collect(km.each_codon(km.DNA, "TGACGATCGAC"))) == ["TGA", "CGA", "TCG"]  # SpacedKmers.jl:70-75
+    assert texts(km.collect(km.each_codon(km.RNA, b"UAUGCUGAA"))) == ["UAU", "GCU", "GAA"]
+
+
 def test_fx_hash_known_answers(km, kats):
     # test/runtests.jl:903-910 (nucleotide cases)
     assert km.fx_hash(km.mer("TAGCTAG")) == 0xA76409341339D05A

@@ -148,6 +148,117 @@ def test_all_recoding_schemes_and_wide_kmers(km, ctx, orc, src, dst):
             assert np.array_equal(out, ek), (K, J)
 
 
+def ascii_seq(km, text_or_bytes, L, alphabet=0, first_base=0):
+    words = naive.ascii_words(text_or_bytes)
+    return km._capi.Seq(words.ctypes.data, L, first_base, 0, 8, alphabet), words
+
+
+def test_ascii_sources(km, ctx, orc):
+    """AsciiEncode sources (String / Vector{UInt8}): FwKmers.jl:117-129, CanonicalKmers.jl:146-174,
+    SpacedKmers.jl:109-139, UnambiguousKmers.jl:109-132; same results and the same EncodeError
+    (position, offending byte) as the oracle."""
+    cap = km._capi
+    rng = np.random.default_rng(88)
+    for rna in (0, 1):
+        for dst in (2, 4):
+            for K in (1, 4, 16, 17, 31, 33, 64):
+                N = (K * dst + 63) // 64
+                for L in (K - 1, K, K + 11, 4099, 20011):
+                    if L < 0:
+                        continue
+                    text = naive.random_text(rng, L, p_amb=0.05 if dst == 4 else 0.0)
+                    text = "".join(c.lower() if rng.random() < 0.3 else c for c in text)
+                    if rna:
+                        text = text.replace("T", "U").replace("t", "u")
+                    seq, keep = ascii_seq(km, text, L, rna)
+                    n = max(0, L - K + 1)
+                    fw = np.zeros((max(n, 1), N), np.uint64)
+                    rv = np.zeros((max(n, 1), N), np.uint64)
+                    ck = np.zeros((max(n, 1), N), np.uint64)
+                    hs = np.zeros(max(n, 1), np.uint64)
+                    res = cap.Result()
+                    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, dst, vp(fw), vp(rv), 0, C.byref(res)) == 0
+                    assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, vp(ck), vp(hs), 5, 0, C.byref(res)) == 0
+                    efw, erv, er = orc.fwrv(keep, L, 8 + rna, dst, K)
+                    ek, eh, _ = orc.canonical(keep, L, 8 + rna, dst, K, seed=5)
+                    assert er.status == 0
+                    assert np.array_equal(fw[:n], efw) and np.array_equal(rv[:n], erv), (rna, dst, K, L)
+                    assert np.array_equal(ck[:n], ek) and np.array_equal(hs[:n], eh)
+    # spaced: tile path and gather path
+    for K, J in ((3, 2), (21, 3), (5, 40), (33, 33)):
+        L = 9000
+        text = naive.random_text(rng, L)
+        seq, keep = ascii_seq(km, text, L)
+        n = (L - K) // J + 1
+        N = (2 * K + 63) // 64
+        out = np.zeros((n, N), np.uint64)
+        res = cap.Result()
+        assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, 2, vp(out), 0, C.byref(res)) == 0
+        ek, _ = orc.spaced(keep, L, 8, 2, K, J)
+        assert np.array_equal(out, ek)
+    # offset view into a byte buffer (unaligned host pointer arithmetic is the library's job)
+    text = naive.random_text(rng, 5000)
+    for first in (1, 3, 8, 13, 1001):
+        seq, keep = ascii_seq(km, text, 3000, 0, first)
+        out = np.zeros((3000 - 30, 1), np.uint64)
+        res = cap.Result()
+        assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 31, 2, vp(out), None, 0, C.byref(res)) == 0
+        ek, _ = orc.fw_kmers(naive.ascii_words(text[first:first + 3000]), 3000, 8, 2, 31)
+        assert np.array_equal(out, ek), first
+
+
+def test_ascii_errors(km, ctx, orc):
+    cap = km._capi
+    rng = np.random.default_rng(89)
+    bad_bytes = [ord("P"), ord("X"), ord("\n"), ord(" "), 0xC3, ord("U"), ord("n"), 0]
+    for dst in (2, 4):
+        for K in (3, 31):
+            for L in (K, 300, 10000):
+                for _ in range(4):
+                    raw = bytearray(naive.random_text(rng, L).encode())
+                    for p in rng.integers(0, L, size=2):
+                        raw[p] = bad_bytes[int(rng.integers(0, len(bad_bytes)))]
+                    seq, keep = ascii_seq(km, bytes(raw), L)
+                    out = np.zeros((L, (K * dst + 63) // 64), np.uint64)
+                    res = cap.Result()
+                    rc = ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, dst, vp(out), None, 0, C.byref(res))
+                    _, er = orc.fw_kmers(keep, L, 8, dst, K)
+                    assert (rc, res.err_pos, res.err_enc) == (er.status, er.err_pos, er.err_enc), (dst, K, L, bytes(raw[:40]))
+                    # UnambiguousKmers: IUPAC letters are skipped, other bytes throw (common.jl:22-32)
+                    if dst == 2:
+                        rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, None, None, 0, 0, C.byref(res))
+                        _, _, er = orc.unambiguous(keep, L, 8, K)
+                        assert (rc, res.err_pos if rc else 0, res.err_enc if rc else 0) == \
+                            (er.status, er.err_pos, er.err_enc), (K, L)
+    # a source shorter than K is still scanned by UnambiguousKmers (UnambiguousKmers.jl:117-123)
+    seq, keep = ascii_seq(km, "AC!", 3)
+    res = cap.Result()
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), 5, 1, None, None, 0, 0, C.byref(res)) == cap.E_ENCODE
+    assert (res.err_pos, res.err_enc) == (3, ord("!"))
+    seq, keep = ascii_seq(km, "ACN", 3)
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), 5, 1, None, None, 0, 0, C.byref(res)) == 0
+    assert res.n_out == 0
+
+
+def test_ascii_unambiguous(km, ctx, orc):
+    rng = np.random.default_rng(90)
+    cap = km._capi
+    for K in (3, 21, 33):
+        for L in (K, 700, 40000):
+            text = naive.random_text(rng, L, p_amb=0.05)
+            text = "".join(c.lower() if rng.random() < 0.5 else c for c in text)
+            seq, keep = ascii_seq(km, text, L)
+            res = cap.Result()
+            assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, None, None, 0, 0, C.byref(res)) == 0
+            n = int(res.n_out)
+            N = (2 * K + 63) // 64
+            kmers = np.zeros((max(n, 1), N), np.uint64)
+            starts = np.zeros(max(n, 1), np.int64)
+            assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, vp(kmers), vp(starts), n, 0, C.byref(res)) == 0
+            ek, es, _ = orc.unambiguous(keep, L, 8, K)
+            assert np.array_equal(kmers[:n], ek) and np.array_equal(starts[:n], es)
+
+
 def test_offset_views(km, ctx, orc):
     """first_base != 0 (LongSubSeq / halo shards): same result as the oracle on the re-packed view."""
     cap = km._capi
