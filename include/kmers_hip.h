@@ -139,6 +139,19 @@ int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride,
 int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, int canonical,
                      uint64_t *out_value, int flags, kmers_result *res);
 
+/* Fused consumer of docs/src/minhash.md:31-35, `sketch(fx_hash, CanonicalKmers{A,K}(seq), s)`:
+ * the s smallest DISTINCT values of fx_hash(canonical kmer, seed), ascending, written to
+ * out_hashes (HOST memory, room for s values); res->n_out = values written (< s when the
+ * sequence has fewer distinct hashes).  No per-kmer output is materialised.  (MinHash.jl is an
+ * absent third-party package; "bottom-s distinct, sorted" is its published sketch definition.) */
+int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t seed, uint64_t s,
+                  uint64_t *out_hashes, int flags, kmers_result *res);
+
+/* Fused consumer of docs/src/composition.md:28-39: out_counts[as_integer(kmer)] += 1 for every
+ * kmer of FwKmers{DNA/RNAAlphabet{2},K}(seq); out_counts has 4^K uint32 entries (K <= 12). */
+int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out_counts, int flags,
+                      kmers_result *res);
+
 /* ---- element-wise operations on arrays of kmers ------------------------------ */
 /* fx_hash(x::Kmer, h::UInt) (kmer.jl:255-261) over n kmers of n_words words each */
 int kmers_fx_hash(kmers_ctx *ctx, const uint64_t *kmers, int n_words, uint64_t n, uint64_t seed,

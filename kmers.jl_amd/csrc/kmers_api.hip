@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "ascii_tables.hpp"
 #include "batch_kernels.hpp"
@@ -195,7 +196,7 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     const uint32_t pass = (stride1 && n_words == 1 ? 2u : 1u) * BLOCK;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
                          (MODE == MODE_CANON && a.out_b ? 8u : 0u);
-    if (MODE == MODE_XOR) out_bytes = 4u;  // nothing stored: long tiles
+    if (MODE == MODE_XOR || MODE == MODE_SKETCH || MODE == MODE_COUNT) out_bytes = 4u;  // nothing streamed out: long tiles
     const uint32_t max_tile_symbols = (uint32_t)MAX_TILE_BITS / (uint32_t)dst_bits;
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);
@@ -393,6 +394,25 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     return KMERS_OK;
 }
 
+// Common launch of a fused-consumer mode (nothing materialised per kmer).
+template <int MODE>
+int launch_fused(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, int dst_bits, StreamArgs &a) {
+    a.src = st.d_words;
+    a.first_bit = st.first_bit;
+    a.n_bases = seq->n_bases;
+    a.n_kmers = kmers_count(seq->n_bases, k, 1);
+    a.inspect_end = seq->n_bases;
+    a.err_slot = ctx->d_err;
+    a.k = (uint32_t)k;
+    a.stride = 1;
+    a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+    int64_t saved = ctx->max_grid;
+    if (ctx->max_grid <= 0) ctx->max_grid = 256 * 8;  // persistent grid: no output stream to pace
+    int rc = launch_stream<MODE>(ctx, a, seq->src_bits, dst_bits, kmers_words_per_kmer(k, dst_bits), true);
+    ctx->max_grid = saved;
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -563,6 +583,105 @@ int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, 
         return rc;
     }
     HIP_TRY(ctx, hipMemcpyAsync(out_value, ctx->d_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
+    return collect(ctx, res, n);
+}
+
+int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t seed, uint64_t s,
+                  uint64_t *out_hashes, int flags, kmers_result *res) {
+    clear(res);
+    if (int rc = check_common(ctx, seq, k, 1, dst_bits, flags & ~KMERS_ASYNC)) {
+        if (res) res->status = rc;
+        return rc;
+    }
+    if (flags & KMERS_ASYNC) return fail(ctx, KMERS_E_BADARG, "kmers_minhash is synchronous");
+    if (s == 0 || !out_hashes) return fail(ctx, KMERS_E_BADARG, "sketch size must be positive and out_hashes non-NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = kmers_count(seq->n_bases, k, 1);
+    if (n == 0) return KMERS_OK;
+    Staged st;
+    if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
+    remember_source(ctx, seq, st);
+
+    // Candidate buffer in HBM; the host keeps the running bottom-s set (a few thousand values).
+    const uint64_t cap = std::max<uint64_t>((uint64_t)1 << 16, 8 * s);
+    if (int rc = ensure_stage(ctx, 3, (size_t)(cap + 2) * 8)) return rc;
+    uint64_t *d_cand = static_cast<uint64_t *>(ctx->stage[3]);
+    uint64_t *d_counter = d_cand + cap;
+    std::vector<uint64_t> best, chunk_vals;
+    uint64_t threshold = ~0ull;  // hashes strictly below it are candidates
+    uint64_t done = 0;
+    // Geometric chunks: with the threshold at the s-th smallest value seen so far, a chunk as
+    // long as everything before it yields about s new candidates, so the buffer stays small.
+    uint64_t chunk = std::min<uint64_t>(n, cap / 2);
+    while (done < n) {
+        uint64_t m = std::min<uint64_t>(chunk, n - done);
+        kmers_seq view = *seq;
+        Staged vst = st;
+        vst.first_bit = st.first_bit + done * (uint64_t)seq->src_bits;
+        view.n_bases = m + (uint64_t)k - 1;
+        HIP_TRY(ctx, hipMemsetAsync(d_counter, 0, 8, ctx->stream));
+        ctx->err_first_bit = vst.first_bit;  // error positions of this launch are relative to the chunk
+        ctx->err_origin = seq->index_origin + done;
+        StreamArgs a{};
+        a.out_a = d_cand;
+        a.out_b = d_counter;
+        a.seed = seed;
+        a.threshold = threshold;
+        a.capacity = cap;
+        if (int rc = launch_fused<MODE_SKETCH>(ctx, &view, vst, k, dst_bits, a)) return rc;
+        uint64_t count = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&count, d_counter, 8, hipMemcpyDeviceToHost, ctx->stream));
+        // chunks run in sequence order, so the first chunk that reports an EncodeError holds the
+        // first offending symbol of the whole sequence
+        if (int erc = collect(ctx, res, 0)) return erc;
+        const uint64_t got = std::min<uint64_t>(count, cap);
+        chunk_vals.resize(got);
+        if (got) HIP_TRY(ctx, hipMemcpy(chunk_vals.data(), d_cand, got * 8, hipMemcpyDeviceToHost));
+        best.insert(best.end(), chunk_vals.begin(), chunk_vals.end());
+        std::sort(best.begin(), best.end());
+        best.erase(std::unique(best.begin(), best.end()), best.end());
+        if (best.size() > s) best.resize(s);
+        if (best.size() == s) threshold = best.back();  // only values below the current s-th smallest matter
+        if (count > cap) {
+            // buffer overflow (adversarial order): the threshold just tightened, redo this chunk
+            if (m > 1) chunk = std::max<uint64_t>(1, m / 2);
+            continue;
+        }
+        done += m;
+        chunk = std::max<uint64_t>(chunk, done);  // next chunk as long as everything so far
+    }
+    std::memcpy(out_hashes, best.data(), best.size() * 8);
+    if (res) res->n_out = best.size();
+    return KMERS_OK;
+}
+
+int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out_counts, int flags, kmers_result *res) {
+    clear(res);
+    if (int rc = check_common(ctx, seq, k, 1, 2, flags & ~KMERS_ASYNC)) {
+        if (res) res->status = rc;
+        return rc;
+    }
+    if (k > 12) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_composition supports K <= 12 (4^K counters)");
+    if (!out_counts) return fail(ctx, KMERS_E_BADARG, "out_counts is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bins = (size_t)1 << (2 * k);
+    const bool dev = flags & KMERS_MEM_DEVICE;
+    uint32_t *d_counts = out_counts;
+    if (!dev) {
+        if (int rc = ensure_stage(ctx, 1, bins * 4)) return rc;
+        d_counts = static_cast<uint32_t *>(ctx->stage[1]);
+    }
+    HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, bins * 4, ctx->stream));
+    const uint64_t n = kmers_count(seq->n_bases, k, 1);
+    if (n) {
+        Staged st;
+        if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
+        remember_source(ctx, seq, st);
+        StreamArgs a{};
+        a.out_a = reinterpret_cast<uint64_t *>(d_counts);
+        if (int rc = launch_fused<MODE_COUNT>(ctx, seq, st, k, 2, a)) return rc;
+    }
+    if (!dev) HIP_TRY(ctx, hipMemcpyAsync(out_counts, d_counts, bins * 4, hipMemcpyDeviceToHost, ctx->stream));
     return collect(ctx, res, n);
 }
 

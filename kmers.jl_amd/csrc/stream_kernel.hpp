@@ -24,7 +24,7 @@ constexpr int MAX_TILE_BITS = 32768;           // LDS stream bits a tile may spa
 constexpr int MAX_TILE_BASES = MAX_TILE_BITS / 2;
 constexpr int LDS_QWORDS = MAX_TILE_BITS / 64 + 16;
 
-enum Mode { MODE_FW = 0, MODE_CANON = 1, MODE_XOR = 2 };
+enum Mode { MODE_FW = 0, MODE_CANON = 1, MODE_XOR = 2, MODE_SKETCH = 3, MODE_COUNT = 4 };
 
 struct StreamArgs {
     const uint64_t *src;     // LongSequence.data in HBM
@@ -43,6 +43,10 @@ struct StreamArgs {
     uint32_t xor_canonical;  // MODE_XOR: 1 = canonical kmers, 0 = forward kmers
     uint64_t *stamps;        // diagnostic builds (-DKMERS_STAMPS) only: per-workgroup s_memrealtime stamps
     const uint8_t *ascii_lut; // SRC_BITS == 8: 256-entry byte -> symbol table (ascii_tables.hpp)
+    // MODE_SKETCH: hashes below `threshold` are appended to out_a[0..capacity) through the counter out_b[0]
+    // MODE_COUNT : out_a = uint32 counts[4^K] indexed by as_integer(forward kmer)
+    uint64_t threshold;
+    uint64_t capacity;
 };
 
 // First inspected offending symbol of one source word -> err_slot (rare path, kept inline and
@@ -294,7 +298,28 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
                 if constexpr (MODE == MODE_XOR) {
                     const bool can = a.xor_canonical != 0;
                     xacc ^= can ? c[0][0] : fw[0][0];
-                    if (both) xacc ^= can ? c[1][0] : fw[1][0];
+                    if constexpr (KPL == 2) {
+                        if (both) xacc ^= can ? c[1][0] : fw[1][0];
+                    }
+                } else if constexpr (MODE == MODE_SKETCH) {
+                    // bottom-s MinHash candidates: fx_hash(canonical kmer) below the running threshold
+#pragma unroll
+                    for (uint32_t e = 0; e < KPL; ++e) {
+                        if (e == 0 || both) {
+                            const uint64_t h = fx_hash<N>(c[e], a.seed);
+                            if (h < a.threshold) {
+                                unsigned long long pos = atomicAdd(reinterpret_cast<unsigned long long *>(a.out_b), 1ull);
+                                if (pos < a.capacity) a.out_a[pos] = h;
+                            }
+                        }
+                    }
+                } else if constexpr (MODE == MODE_COUNT) {
+                    // kmer composition: counts[as_integer(kmer)] += 1 (docs/src/composition.md:31-33)
+                    uint32_t *counts = reinterpret_cast<uint32_t *>(a.out_a);
+                    atomicAdd(counts + (uint32_t)fw[0][0], 1u);
+                    if constexpr (KPL == 2) {
+                        if (both) atomicAdd(counts + (uint32_t)fw[1][0], 1u);
+                    }
                 } else if constexpr (KPL == 2) {
                     if (both) {
                         if (a.out_a) *reinterpret_cast<ulonglong2 *>(a.out_a + g) = make_ulonglong2(c[0][0], c[1][0]);

@@ -699,6 +699,42 @@ def collect(it):
     return it.collect()
 
 
+def sketch(f, it, s, seed=0):
+    """MinHash.sketch(fx_hash, CanonicalKmers{A,K}(seq), s) (docs/src/minhash.md:31-35): the s
+    smallest distinct fx_hash values of the canonical kmers, ascending, from one fused pass."""
+    if f is not fx_hash or not isinstance(it, CanonicalKmers):
+        raise UnsupportedError("the fused sketch is sketch(fx_hash, CanonicalKmers, s)")
+    out = np.zeros(max(int(s), 1), dtype=np.uint64)
+    res = _capi.Result()
+    view = it._view(0, it.seq.len)
+    rc = it.ctx.check(it.ctx.lib.kmers_minhash(it.ctx.handle, C.byref(view), it.K, it.alphabet.bits, seed & MASK64,
+                                                int(s), out.ctypes.data_as(C.c_void_p), _capi.MEM_DEVICE,
+                                                C.byref(res)), "kmers_minhash")
+    if rc == _capi.E_ENCODE:
+        _raise_encode(it.alphabet, it.seq, res)
+    return out[:int(res.n_out)]
+
+
+def composition(it):
+    """Kmer composition counts (docs/src/composition.md:28-39): counts[as_integer(kmer)] over
+    FwKmers{DNA/RNAAlphabet{2},K}(seq), 4^K uint32 counters, one fused pass."""
+    if not isinstance(it, FwKmers) or it.alphabet.bits != 2:
+        raise UnsupportedError("composition(FwKmers over a 2-bit kmer alphabet)")
+    counts = np.zeros(4 ** it.K, dtype=np.uint32)
+    d = it.ctx.alloc(counts.nbytes)
+    res = _capi.Result()
+    try:
+        view = it._view(0, it.seq.len)
+        rc = it.ctx.check(it.ctx.lib.kmers_composition(it.ctx.handle, C.byref(view), it.K, d, _capi.MEM_DEVICE,
+                                                        C.byref(res)), "kmers_composition")
+        if rc == _capi.E_ENCODE:
+            _raise_encode(it.alphabet, it.seq, res)
+        it.ctx.d2h(counts, d)
+    finally:
+        it.ctx.free(d)
+    return counts
+
+
 # --------------------------------------------------------------------------------------------
 # element-wise functions (Kmer or KmerArray)
 def _batch(x):

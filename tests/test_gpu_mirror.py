@@ -223,3 +223,19 @@ def test_big_chunked_iteration_matches_collect(km, orc):
     km_h, hs = it.collect_with_hashes(seed=3)
     _, eh, _ = orc.canonical(words, L, 4, 2, K, seed=3)
     assert np.array_equal(hs, eh) and km_h == whole
+
+
+def test_fused_consumers(km, orc):
+    """sketch(fx_hash, CanonicalDNAMers{16}(seq), 1000) (docs/src/minhash.md:34) and the composition
+    recipe (docs/src/composition.md:28-39) through the mirror."""
+    L = 400_000
+    words = orc.synth_words(9, 0, (L * 4 + 63) // 64, 4)
+    seq = km.LongSequence(km.DNAAlphabet[4], words, L)
+    sk = km.sketch(km.fx_hash, km.CanonicalDNAMers[16](seq), 1000)
+    _, eh, _ = orc.canonical(words, L, 4, 2, 16)
+    assert np.array_equal(sk, np.unique(eh)[:1000])
+    assert np.array_equal(km.sketch(km.fx_hash, km.CanonicalDNAMers[16]("ACGTTGCAAGGCTTACGATCGA"), 1000),
+                          np.unique(orc.canonical(naive.ascii_words("ACGTTGCAAGGCTTACGATCGA"), 22, 8, 2, 16)[1]))
+    comp = km.composition(km.FwDNAMers[4](seq))
+    fw, _ = orc.fw_kmers(words, L, 4, 2, 4)
+    assert np.array_equal(comp, np.bincount(fw[:, 0].astype(np.int64), minlength=256).astype(np.uint32))

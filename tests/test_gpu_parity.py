@@ -502,3 +502,59 @@ def test_bad_arguments(km, ctx):
     assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 65, 4, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
     assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 8, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
     assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 2, vp(out), None, cap.ASYNC, C.byref(res)) == cap.E_BADARG
+
+
+def test_minhash_sketch(km, ctx, orc):
+    """Fused bottom-s MinHash of fx_hash(canonical kmer) (docs/src/minhash.md:31-35) == the s smallest
+    distinct hashes of the materialised iteration."""
+    cap = km._capi
+    rng = np.random.default_rng(5)
+    for bits in (2, 4):
+        for K in (5, 16, 31, 33):
+            for L, s in ((K - 1, 10), (K, 10), (2000, 50), (2000, 5000), (300_000, 1000), (3_000_000, 1000), (3_000_000, 20_000)):
+                if L < 0:
+                    continue
+                words = orc.synth_words(3 + K, 0, (L * bits + 63) // 64 + 1, bits)
+                seq, keep = make_seq(km, words, L, bits)
+                out = np.zeros(s, dtype=np.uint64)
+                res = cap.Result()
+                rc = ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, 2, 7, s, vp(out), cap.MEM_HOST, C.byref(res))
+                assert rc == 0, ctx.last_error()
+                _, eh, _ = orc.canonical(words, L, bits, 2, K, seed=7)
+                exp = np.unique(eh)[:s]
+                assert res.n_out == len(exp) and np.array_equal(out[:len(exp)], exp), (bits, K, L, s)
+    # low-complexity input: few distinct kmers, many duplicates
+    text = "ACGTTGCA" * 50_000
+    words = naive.longseq_words(text, 4)
+    seq, keep = make_seq(km, words, len(text), 4)
+    out = np.zeros(1000, dtype=np.uint64)
+    res = cap.Result()
+    assert ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), 21, 2, 0, 1000, vp(out), cap.MEM_HOST, C.byref(res)) == 0
+    _, eh, _ = orc.canonical(words, len(text), 4, 2, 21)
+    exp = np.unique(eh)
+    assert res.n_out == len(exp) <= 8 and np.array_equal(out[:len(exp)], exp)
+    # sorted (decreasing hash order would overflow a naive buffer) and an ambiguous symbol far into the sequence
+    L = 2_000_000
+    words = orc.synth_words(1, 0, (L * 4 + 63) // 64 + 1, 4).copy()
+    pos = 1_234_567
+    words[(pos * 4) >> 6] |= np.uint64(0xF) << np.uint64((pos * 4) & 63)
+    seq, keep = make_seq(km, words, L, 4)
+    rc = ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), 31, 2, 0, 1000, vp(out), cap.MEM_HOST, C.byref(res))
+    assert rc == cap.E_ENCODE and res.err_pos == pos + 1 and res.err_enc == 0xF
+
+
+def test_composition(km, ctx, orc):
+    """counts[as_integer(kmer)] over FwDNAMers{K} (docs/src/composition.md:28-39)."""
+    cap = km._capi
+    for bits in (2, 4):
+        for K in (1, 4, 6, 8, 11):
+            L = 500_000
+            words = orc.synth_words(K, 0, (L * bits + 63) // 64 + 1, bits)
+            seq, keep = make_seq(km, words, L, bits)
+            counts = np.zeros(4 ** K, dtype=np.uint32)
+            res = cap.Result()
+            assert ctx.lib.kmers_composition(ctx.handle, C.byref(seq), K, vp(counts), cap.MEM_HOST, C.byref(res)) == 0
+            fw, _ = orc.fw_kmers(words, L, bits, 2, K)
+            exp = np.bincount(fw[:, 0].astype(np.int64), minlength=4 ** K).astype(np.uint32)
+            assert np.array_equal(counts, exp), (bits, K)
+            assert counts.sum() == L - K + 1
