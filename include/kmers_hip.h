@@ -162,6 +162,8 @@ int kmers_fx_hash(kmers_ctx *ctx, const uint64_t *kmers, int n_words, uint64_t n
 #define KMERS_OP_REVCOMP 2     /* transformations.jl:32-34 */
 #define KMERS_OP_CANONICAL 3   /* transformations.jl:36-39 */
 #define KMERS_OP_ISCANONICAL 4 /* transformations.jl:41 ; out = one uint64 0/1 per kmer */
+#define KMERS_OP_TO_LONGSEQ 5  /* LongSequence{A}(kmer).data, construction.jl:289-324; out = N words per kmer */
+#define KMERS_OP_COUNT_GC 6    /* count(isGC, kmer), counting.jl:1-8 (2-bit); out = one uint64 per kmer */
 int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bits, uint64_t n,
                     uint64_t *out, int flags);
 

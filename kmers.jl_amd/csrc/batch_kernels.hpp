@@ -78,6 +78,26 @@ __global__ __launch_bounds__(256) void transform_kernel(int op, const uint64_t *
         uint64_t x[NW], y[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) x[w] = y[w] = in[i * NW + w];
+        if (op == 6) {  // count(isGC, kmer), src/counting.jl:1-8 (2-bit alphabets)
+            uint32_t n_gc = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) n_gc += __popcll((x[w] ^ (x[w] >> 1)) & 0x5555555555555555ull);
+            out[i] = n_gc;
+            continue;
+        }
+        if (op == 5) {  // LongSequence{A}(kmer).data, src/construction.jl:289-324
+            // = the symbol reversal of the kmer's 64*NW-bit value after moving the unused bits to the bottom
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                uint64_t chunk = (x[w] << 1) << (bu == 0 ? 63u : bu - 1u);  // left_shift(kmer[w] & left_mask, bu)
+                if (bu == 0) chunk = x[w];
+                if (w + 1 < NW && bu != 0) chunk |= x[w + 1] >> (64u - bu);
+                y[w] = reverse_symbols<BITS>(chunk);
+            }
+#pragma unroll
+            for (int w = 0; w < NW; ++w) out[i * NW + w] = y[w];
+            continue;
+        }
         if (op == 0) {
             kmer_reverse<NW, BITS>(y, bu);
         } else if (op == 1) {
@@ -103,6 +123,17 @@ __global__ __launch_bounds__(256) void transform_kernel(int op, const uint64_t *
         }
 #pragma unroll
         for (int w = 0; w < NW; ++w) out[i * NW + w] = y[w];
+    }
+}
+
+// ---- sum `replicas` copies of a uint32 histogram into out (composition, mid-size K) ----------
+__global__ __launch_bounds__(256) void reduce_replicas_kernel(const uint32_t *__restrict__ rep, uint32_t replicas,
+                                                               size_t bins, uint32_t *__restrict__ out) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < bins; i += stride) {
+        uint32_t s = 0;
+        for (uint32_t r = 0; r < replicas; ++r) s += rep[r * bins + i];
+        out[i] = s;
     }
 }
 

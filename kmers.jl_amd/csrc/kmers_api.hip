@@ -174,11 +174,11 @@ static uint32_t default_tile(uint32_t out_bytes_per_kmer, uint32_t pass) {
 }
 
 template <int MODE, int SB, int DB>
-void launch_widths(int n_words, bool s1, dim3 grid, dim3 block, hipStream_t st, const StreamArgs &a) {
+void launch_widths(int n_words, bool s1, dim3 grid, dim3 block, hipStream_t st, const StreamArgs &a, size_t dyn_lds) {
 #define LAUNCH(NN)                                                                                   \
     do {                                                                                             \
-        if (s1) hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, true>), grid, block, 0, st, a);  \
-        else hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, false>), grid, block, 0, st, a);    \
+        if (s1) hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, true>), grid, block, dyn_lds, st, a);  \
+        else hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, false>), grid, block, dyn_lds, st, a);    \
     } while (0)
     switch (n_words) {
         case 1: LAUNCH(1); break;
@@ -190,7 +190,7 @@ void launch_widths(int n_words, bool s1, dim3 grid, dim3 block, hipStream_t st, 
 }
 
 template <int MODE>
-int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int n_words, bool vec_ok) {
+int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int n_words, bool vec_ok, size_t dyn_lds = 0) {
     const uint32_t J = a.stride;
     const bool stride1 = (J == 1) && vec_ok;
     const uint32_t pass = (stride1 && n_words == 1 ? 2u : 1u) * BLOCK;  // kmers per workgroup pass
@@ -208,12 +208,12 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap));
     dim3 block(BLOCK);
-    if (src_bits == 8 && dst_bits == 2) launch_widths<MODE, 8, 2>(n_words, stride1, grid, block, ctx->stream, a);
-    else if (src_bits == 8) launch_widths<MODE, 8, 4>(n_words, stride1, grid, block, ctx->stream, a);
-    else if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, grid, block, ctx->stream, a);
-    else if (src_bits == 2 && dst_bits == 2) launch_widths<MODE, 2, 2>(n_words, stride1, grid, block, ctx->stream, a);
-    else if (src_bits == 4 && dst_bits == 4) launch_widths<MODE, 4, 4>(n_words, stride1, grid, block, ctx->stream, a);
-    else launch_widths<MODE, 2, 4>(n_words, stride1, grid, block, ctx->stream, a);
+    if (src_bits == 8 && dst_bits == 2) launch_widths<MODE, 8, 2>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 8) launch_widths<MODE, 8, 4>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 2 && dst_bits == 2) launch_widths<MODE, 2, 2>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 4 && dst_bits == 4) launch_widths<MODE, 4, 4>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
+    else launch_widths<MODE, 2, 4>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
     HIP_TRY(ctx, hipGetLastError());
     return KMERS_OK;
 }
@@ -396,7 +396,7 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
 
 // Common launch of a fused-consumer mode (nothing materialised per kmer).
 template <int MODE>
-int launch_fused(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, int dst_bits, StreamArgs &a) {
+int launch_fused(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, int dst_bits, StreamArgs &a, size_t dyn_lds = 0) {
     a.src = st.d_words;
     a.first_bit = st.first_bit;
     a.n_bases = seq->n_bases;
@@ -408,7 +408,7 @@ int launch_fused(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, 
     a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
     int64_t saved = ctx->max_grid;
     if (ctx->max_grid <= 0) ctx->max_grid = 256 * 8;  // persistent grid: no output stream to pace
-    int rc = launch_stream<MODE>(ctx, a, seq->src_bits, dst_bits, kmers_words_per_kmer(k, dst_bits), true);
+    int rc = launch_stream<MODE>(ctx, a, seq->src_bits, dst_bits, kmers_words_per_kmer(k, dst_bits), true, dyn_lds);
     ctx->max_grid = saved;
     return rc;
 }
@@ -610,8 +610,8 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
     std::vector<uint64_t> best, chunk_vals;
     uint64_t threshold = ~0ull;  // hashes strictly below it are candidates
     uint64_t done = 0;
-    // Geometric chunks: with the threshold at the s-th smallest value seen so far, a chunk as
-    // long as everything before it yields about s new candidates, so the buffer stays small.
+    // Geometric chunks: with the threshold at the s-th smallest value seen so far, a chunk r times
+    // as long as everything before it yields about r*s new candidates, so the buffer stays small.
     uint64_t chunk = std::min<uint64_t>(n, cap / 2);
     while (done < n) {
         uint64_t m = std::min<uint64_t>(chunk, n - done);
@@ -648,7 +648,7 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
             continue;
         }
         done += m;
-        chunk = std::max<uint64_t>(chunk, done);  // next chunk as long as everything so far
+        chunk = std::max<uint64_t>(chunk, 3 * done);  // next chunk 3x everything so far: about 3s candidates (< cap)
     }
     std::memcpy(out_hashes, best.data(), best.size() * 8);
     if (res) res->n_out = best.size();
@@ -671,15 +671,32 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
         if (int rc = ensure_stage(ctx, 1, bins * 4)) return rc;
         d_counts = static_cast<uint32_t *>(ctx->stage[1]);
     }
-    HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, bins * 4, ctx->stream));
+    // K <= 6: histogram private to each workgroup in LDS (<= 16 KiB), flushed once.
+    // K = 7..10: one replica of the global counters per XCD (contention), summed afterwards.
+    // K >= 11: the counters are numerous enough for plain global atomics.
+    const bool in_lds = k <= 6;
+    const uint32_t replicas = (!in_lds && k <= 10) ? 8u : 1u;
+    uint32_t *d_work = d_counts;
+    if (replicas > 1) {
+        if (int rc = ensure_stage(ctx, 3, bins * 4 * replicas)) return rc;
+        d_work = static_cast<uint32_t *>(ctx->stage[3]);
+    }
+    HIP_TRY(ctx, hipMemsetAsync(d_work, 0, bins * 4 * replicas, ctx->stream));
     const uint64_t n = kmers_count(seq->n_bases, k, 1);
     if (n) {
         Staged st;
         if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
         remember_source(ctx, seq, st);
         StreamArgs a{};
-        a.out_a = reinterpret_cast<uint64_t *>(d_counts);
-        if (int rc = launch_fused<MODE_COUNT>(ctx, seq, st, k, 2, a)) return rc;
+        a.out_a = reinterpret_cast<uint64_t *>(d_work);
+        a.capacity = in_lds ? bins : 0;
+        a.threshold = replicas;
+        if (int rc = launch_fused<MODE_COUNT>(ctx, seq, st, k, 2, a, in_lds ? bins * 4 : 0)) return rc;
+    }
+    if (replicas > 1) {
+        hipLaunchKernelGGL(reduce_replicas_kernel, dim3((unsigned)std::min<size_t>((bins + 255) / 256, 4096)), dim3(256), 0,
+                           ctx->stream, d_work, replicas, bins, d_counts);
+        HIP_TRY(ctx, hipGetLastError());
     }
     if (!dev) HIP_TRY(ctx, hipMemcpyAsync(out_counts, d_counts, bins * 4, hipMemcpyDeviceToHost, ctx->stream));
     return collect(ctx, res, n);
@@ -732,7 +749,8 @@ int kmers_fx_hash(kmers_ctx *ctx, const uint64_t *kmers, int n_words, uint64_t n
 int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bits, uint64_t n, uint64_t *out,
                     int flags) {
     if (!ctx) return KMERS_E_BADARG;
-    if (op < 0 || op > 4 || k < 1 || (bits != 2 && bits != 4)) return fail(ctx, KMERS_E_BADARG, "bad transform arguments");
+    if (op < 0 || op > 6 || k < 1 || (bits != 2 && bits != 4)) return fail(ctx, KMERS_E_BADARG, "bad transform arguments");
+    if (op == KMERS_OP_COUNT_GC && bits != 2) return fail(ctx, KMERS_E_UNSUPPORTED, "count(isGC) is defined for 2-bit kmers (src/counting.jl:1)");
     const int nw = n_coding_elements(k, bits);
     if (nw > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_transform supports up to 4 words per kmer");
     if (n == 0) return KMERS_OK;
@@ -741,7 +759,7 @@ int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bi
     const bool dev = flags & KMERS_MEM_DEVICE;
     const uint64_t *d_in = kmers;
     uint64_t *d_out = out;
-    size_t in_bytes = (size_t)n * nw * 8, out_bytes = (size_t)n * (op == KMERS_OP_ISCANONICAL ? 1 : nw) * 8;
+    size_t in_bytes = (size_t)n * nw * 8, out_bytes = (size_t)n * ((op == KMERS_OP_ISCANONICAL || op == KMERS_OP_COUNT_GC) ? 1 : nw) * 8;
     if (!dev) {
         if (int rc = ensure_stage(ctx, 0, in_bytes + 8)) return rc;
         if (int rc = ensure_stage(ctx, 1, out_bytes)) return rc;

@@ -764,7 +764,7 @@ def _transform(op, x, ctx=None):
     ctx = ctx or default_context()
     arr, single = _batch(x)
     n = len(arr)
-    width = 1 if op == _capi.OP_ISCANONICAL else arr.N
+    width = 1 if op in (_capi.OP_ISCANONICAL, _capi.OP_COUNT_GC) else arr.N
     out = np.zeros((max(n, 1), width), dtype=np.uint64)
     if n:
         ctx.check(ctx.lib.kmers_transform(ctx.handle, op, arr.words.ctypes.data_as(C.c_void_p), arr.K,
@@ -772,6 +772,12 @@ def _transform(op, x, ctx=None):
                                           _capi.MEM_HOST), "kmers_transform")
     if op == _capi.OP_ISCANONICAL:
         return bool(out[0, 0]) if single else out[:n, 0].astype(bool)
+    if op == _capi.OP_COUNT_GC:
+        return int(out[0, 0]) if single else out[:n, 0].astype(np.int64)
+    if op == _capi.OP_TO_LONGSEQ:
+        if single:
+            return LongSequence(arr.alphabet, out[0], arr.K)
+        return out[:n]
     res = KmerArray(arr.alphabet, arr.K, out[:n])
     return res[0] if single else res
 
@@ -794,6 +800,14 @@ def canonical(x, ctx=None):
 
 def iscanonical(x, ctx=None):
     return _transform(_capi.OP_ISCANONICAL, x, ctx)         # transformations.jl:41
+
+
+def count_gc(x, ctx=None):
+    return _transform(_capi.OP_COUNT_GC, x, ctx)           # count(isGC, kmer), counting.jl:1-8
+
+
+def to_longsequence(x, ctx=None):
+    return _transform(_capi.OP_TO_LONGSEQ, x, ctx)         # LongSequence{A}(kmer), construction.jl:289-324
 
 
 def as_integer(x):

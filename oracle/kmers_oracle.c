@@ -324,6 +324,14 @@ int orc_iscanonical(const uint64_t *in, int K, int bps) {
 int orc_cmp(const uint64_t *x, const uint64_t *y, int N) { return kmer_cmp(x, y, N); }
 uint64_t orc_fx_hash(const uint64_t *kmer, int N, uint64_t h) { return fx_hash(kmer, N, h); }
 
+/* src/counting.jl:1-8: BioSequences._n_gc(x::Kmer{<:TwoBit}) = count(isGC, x) */
+int orc_n_gc(const uint64_t *kmer, int N) {
+    uint64_t mask = 0x5555555555555555ull;
+    int n = 0;
+    for (int i = 0; i < N; ++i) n += count_ones64((kmer[i] ^ (kmer[i] >> 1)) & mask);
+    return n;
+}
+
 /* src/kmer.jl:305-326 -- value returned as (hi, lo) of a UInt128; the return
  * value is the width in bits of the Julia result type (8,16,32,64,128), or -1
  * for the ArgumentError branch. */

@@ -69,6 +69,7 @@ void orc_canonical_kmer(const uint64_t *in, int K, int bps, uint64_t *out);     
 int orc_iscanonical(const uint64_t *in, int K, int bps);                        /* src/transformations.jl:41 */
 int orc_cmp(const uint64_t *x, const uint64_t *y, int N);                       /* src/kmer.jl:176-178 */
 uint64_t orc_fx_hash(const uint64_t *kmer, int N, uint64_t h);                  /* src/kmer.jl:255-261 */
+int orc_n_gc(const uint64_t *kmer, int N);                                      /* src/counting.jl:1-8 */
 int orc_as_integer(const uint64_t *kmer, int K, int bps, uint64_t *hi, uint64_t *lo);   /* src/kmer.jl:305-326 */
 int orc_from_integer(uint64_t hi, uint64_t lo, int K, int bps, uint64_t *out);          /* src/kmer.jl:361-384 */
 int orc_kmer_from_longseq(const uint64_t *seq, uint64_t len, int K, int bps, uint64_t *out); /* src/construction.jl:213-219 */

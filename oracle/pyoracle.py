@@ -76,6 +76,7 @@ class Oracle:
         L.orc_from_integer.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, _u64p]
         L.orc_kmer_from_longseq.argtypes = [_u64p, C.c_uint64, C.c_int, C.c_int, _u64p]
         L.orc_longseq_from_kmer.argtypes = [_u64p, C.c_int, C.c_int, _u64p]
+        L.orc_n_gc.argtypes = [_u64p, C.c_int]
         L.orc_synth_rand64.restype = C.c_uint64
         L.orc_synth_rand64.argtypes = [C.c_uint64, C.c_uint64]
         L.orc_synth_words.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _u64p]
@@ -183,6 +184,9 @@ class Oracle:
 
     def fx_hash(self, w, seed=0):
         return int(self.lib.orc_fx_hash(_ptr(self._kw(w)), len(w), seed))
+
+    def n_gc(self, w):
+        return int(self.lib.orc_n_gc(_ptr(self._kw(w)), len(w)))
 
     def shift_encoding(self, w, K, bps, enc):
         a = self._kw(w)

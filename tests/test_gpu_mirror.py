@@ -200,6 +200,10 @@ def test_transform_known_answers(km, kats):
     assert str(km.reverse(km.mer("AGCTAGG"))) == "GGATCGA"
     assert str(km.complement(km.mer("AGCTAGG"))) == "TCGATCC"
     assert str(km.canonical(km.mer("TTGAA"))) == "TTCAA"
+    for text, n in kats["G13_gc_count"]["cases"]:                      # test/runtests.jl:1021-1027
+        if text:
+            assert km.count_gc(km.mer(text.replace("U", "T"))) == n
+    assert str(km.to_longsequence(km.mer("TAGCTAGGACA"))) == "TAGCTAGGACA"   # construction.jl:289-324
     rng = np.random.default_rng(1)
     for K in (5, 31, 32, 33, 64):
         ts = [naive.random_text(rng, K) for _ in range(50)]

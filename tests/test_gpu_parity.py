@@ -469,6 +469,14 @@ def test_batch_fx_hash_and_transforms(km, ctx, orc):
                 assert rc == 0
                 exp = [fn(tuple(r), K, bits) for r in arr.tolist()]
                 assert [tuple(r) for r in res.tolist()] == exp, (bits, K, op)
+            ls = np.zeros((n, N), dtype=np.uint64)
+            rc = ctx.lib.kmers_transform(ctx.handle, cap.OP_TO_LONGSEQ, vp(arr), K, bits, n, vp(ls), cap.MEM_HOST)
+            assert rc == 0
+            assert [list(r) for r in ls.tolist()] == [list(naive.longseq_words(t, bits)[:N]) for t in texts], (bits, K)
+            if bits == 2:
+                gc = np.zeros(n, dtype=np.uint64)
+                rc = ctx.lib.kmers_transform(ctx.handle, cap.OP_COUNT_GC, vp(arr), K, bits, n, vp(gc), cap.MEM_HOST)
+                assert rc == 0 and gc.tolist() == [sum(c in "GC" for c in t) for t in texts]
             flags = np.zeros(n, dtype=np.uint64)
             rc = ctx.lib.kmers_transform(ctx.handle, cap.OP_ISCANONICAL, vp(arr), K, bits, n, vp(flags), cap.MEM_HOST)
             assert rc == 0

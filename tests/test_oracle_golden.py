@@ -160,6 +160,12 @@ def test_g12_errors(orc, kats):
         assert res.err_enc == naive.DNA4[c["err_symbol"]], c
 
 
+def test_g13_gc_count(orc, kats):
+    # test/runtests.jl:1021-1027 (src/counting.jl:1-8)
+    for text, n in kats["G13_gc_count"]["cases"]:
+        assert orc.n_gc(naive.kmer_words(text, 2)) == n, text
+
+
 def test_g14_reference_property_sequences(orc, kats):
     """The fixed sequences of the reference's differential tests, checked against the
     naive slicer (test/runtests.jl:674-690, :697-711, :739-761, :774-787, :805-847, :850-867)."""
