@@ -1,0 +1,251 @@
+"""BASELINE.json configs at their FULL sizes on one MI355X, through the C ABI with resident data.
+Outputs this large cannot be compared element by element with the CPU oracle in reasonable time,
+so each config is checked by size-independent properties evaluated on the GPU over EVERY element
+(hash/canonical/rolling/involution identities, a checksum of checksums across shards) plus oracle
+comparisons of windows at the places that matter (start, end, shard and tile boundaries)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+FX = 0x517CC1B727220A95
+GOLDEN = 0x9E3779B97F4A7C15
+
+
+@pytest.fixture(scope="module")
+def km():
+    import kmers_jl_amd
+    return kmers_jl_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(km):
+    c = km.Context(0)
+    yield c
+    c.close()
+
+
+def dev_empty(n):
+    return torch.empty(int(n), dtype=torch.int64, device="cuda:0")
+
+
+def synth(ctx, seed, first_word, n_words, bits, amb=0):
+    buf = dev_empty(n_words + 2)
+    ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, first_word, n_words, bits, amb, buf.data_ptr()), "synth")
+    return buf
+
+
+def xor_fold(t):
+    while t.numel() > 1:
+        h = t.numel() // 2
+        rest = t[2 * h:]
+        t = torch.bitwise_xor(t[:h], t[h:2 * h])
+        if rest.numel():
+            t = torch.cat([t, rest])
+    return int(t.item()) & (2**64 - 1)
+
+
+def chunks(n, step=1 << 27):
+    for lo in range(0, n, step):
+        yield lo, min(n, lo + step)
+
+
+def host_u64(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_c1_fw21_one_mbase_full_compare(km, ctx, orc):
+    """configs[0]: FwDNAMers{21} over 1 Mbase LongDNA{4} -- small enough for a full comparison."""
+    cap = km._capi
+    L, K, bits = 1_000_000, 21, 4
+    seed = GOLDEN ^ 1
+    nw = (L * bits + 63) // 64
+    buf = synth(ctx, seed, 0, nw, bits)
+    out = dev_empty(L - K + 1)
+    res = cap.Result()
+    seq = cap.Seq(buf.data_ptr(), L, 0, 0, bits, 0)
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, out.data_ptr(), None, cap.MEM_DEVICE, C.byref(res)) == 0
+    assert res.n_out == 999_980
+    ek, _ = orc.fw_kmers(orc.synth_words(seed, 0, nw, bits), L, bits, 2, K)
+    assert np.array_equal(host_u64(out), ek[:, 0])
+
+
+def test_c2_canonical31_hash_one_gbase(km, ctx, orc):
+    """configs[1]: CanonicalDNAMers{31} + fx_hash over 1 Gbase LongDNA{4}."""
+    cap = km._capi
+    L, K, bits = 1_000_000_000, 31, 4
+    seed = GOLDEN ^ 2
+    n = L - K + 1
+    nw = (L * bits + 63) // 64
+    buf = synth(ctx, seed, 0, nw, bits)
+    seq = cap.Seq(buf.data_ptr(), L, 0, 0, bits, 0)
+    res = cap.Result()
+    ck, hs, fw, rc = dev_empty(n), dev_empty(n), dev_empty(n), dev_empty(n)
+    assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, ck.data_ptr(), hs.data_ptr(), 0, cap.MEM_DEVICE,
+                                   C.byref(res)) == 0 and res.n_out == n
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, fw.data_ptr(), rc.data_ptr(), cap.MEM_DEVICE,
+                            C.byref(res)) == 0
+    mask = (1 << 62) - 1
+    cmul = torch.tensor(FX, dtype=torch.int64, device="cuda:0")
+    folded = 0
+    for lo, hi in chunks(n):
+        f, r, c, h = fw[lo:hi], rc[lo:hi], ck[lo:hi], hs[lo:hi]
+        assert bool(torch.equal(h, c * cmul))                              # fx_hash(x) = x * C for one word, seed 0
+        assert bool(torch.equal(c, torch.minimum(f, r)))                   # fw < rv ? fw : rv (62-bit values: signed == unsigned)
+        assert int(torch.max(f)) <= mask and int(torch.max(r)) <= mask     # unused top bits are zero
+        hi2 = min(n, hi + 1)
+        fa, fb = fw[lo:hi2 - 1], fw[lo + 1:hi2]
+        assert bool(torch.equal(fb >> 2, fa & (mask >> 2)))                # shift_encoding: window moves by one symbol
+        ra, rb = rc[lo:hi2 - 1], rc[lo + 1:hi2]
+        assert bool(torch.equal(rb & (mask >> 2), ra >> 2))                # shift_first_encoding on the other strand
+        assert bool(torch.equal((rb >> 60) ^ 3, fb & 3))                   # the symbol entering rc is the complement
+        folded ^= xor_fold(c.contiguous())
+    xr = C.c_uint64()
+    assert ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, 2, 1, C.byref(xr), cap.MEM_DEVICE, C.byref(res)) == 0
+    assert folded == xr.value
+    # canonical is idempotent and agrees with the element-wise transform
+    again = dev_empty(n)
+    assert ctx.lib.kmers_transform(ctx.handle, cap.OP_CANONICAL, fw.data_ptr(), K, 2, n, again.data_ptr(), cap.MEM_DEVICE) == 0
+    assert bool(torch.equal(again, ck))
+    # oracle windows: start, an unaligned middle, the end
+    per = 64 // bits
+    probe = 1 << 20
+    for first in (0, (n // 3 // per) * per, ((n - probe) // per) * per):
+        nb = min(probe, n - first) + K - 1
+        w = orc.synth_words(seed, first // per, (nb * bits + 63) // 64 + 1, bits)
+        ek, eh, _ = orc.canonical(w, nb, bits, 2, K)
+        assert np.array_equal(host_u64(ck[first:first + len(ek)]), ek[:, 0])
+        assert np.array_equal(host_u64(hs[first:first + len(eh)]), eh)
+
+
+def test_c3_canonical31_ten_gbase_two_bit_eight_shards(km, ctx, orc):
+    """configs[2]: CanonicalDNAMers{31} over 10 Gbase LongDNA{2} sharded 8 ways with a (K-1)-base halo.
+    The 8 shards run one after another on this device exactly as 8 ranks would (own words + the halo
+    words of the next shard); the XOR of the shard checksums must equal the checksum of one pass over
+    the whole sequence, and the kmers that straddle every shard boundary are compared with the oracle."""
+    from kmers_jl_amd.shard import plan_shards
+    cap = km._capi
+    L, K, bits, world = 10_000_000_000, 31, 2, 8
+    seed = GOLDEN ^ 3
+    plan = plan_shards(L, K, world, bits)
+    assert sum(s.n_kmers for s in plan) == L - K + 1
+    res = cap.Result()
+    total_xor = 0
+    out = dev_empty(max(s.n_kmers for s in plan))
+    for sh in plan:
+        buf = dev_empty(sh.n_own_words + sh.halo_words + 2)
+        ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, sh.first_word, sh.n_own_words, bits, 0, buf.data_ptr()), "synth")
+        if sh.halo_words:  # what rank+1 would send: its first halo_words words
+            ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, sh.first_word + sh.n_own_words, sh.halo_words, bits, 0,
+                                              buf.data_ptr() + 8 * sh.n_own_words), "synth halo")
+        seq = cap.Seq(buf.data_ptr(), sh.n_bases, 0, sh.first_kmer, bits, 0)
+        assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, out.data_ptr(), None, 0, cap.MEM_DEVICE,
+                                       C.byref(res)) == 0 and res.n_out == sh.n_kmers
+        for lo, hi in chunks(sh.n_kmers):
+            total_xor ^= xor_fold(out[lo:hi].contiguous())
+        # the last 4096 kmers of the shard use the halo: compare with the oracle on the global sequence
+        tail = 4096
+        first = sh.first_kmer + sh.n_kmers - tail
+        fw_word = first // 32
+        nb = tail + K - 1 + (first - fw_word * 32)
+        w = orc.synth_words(seed, fw_word, (nb * bits + 63) // 64 + 1, bits)
+        ek, _, _ = orc.canonical(w, nb, bits, 2, K, hashes=False)
+        assert np.array_equal(host_u64(out[sh.n_kmers - tail:sh.n_kmers]), ek[first - fw_word * 32:, 0][:tail])
+        del buf
+    # one pass over the whole 10 Gbase (2.5 GB of words) with the fused consumer
+    nw = (L * bits + 63) // 64
+    whole = synth(ctx, seed, 0, nw, bits)
+    seq = cap.Seq(whole.data_ptr(), L, 0, 0, bits, 0)
+    xr = C.c_uint64()
+    assert ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, 2, 1, C.byref(xr), cap.MEM_DEVICE, C.byref(res)) == 0
+    assert total_xor == xr.value
+
+
+def test_c4_fw63_revcomp_one_gbase(km, ctx, orc):
+    """configs[3]: FwDNAMers{63} (two-word kmers) + reverse_complement over 1 Gbase LongDNA{4}."""
+    cap = km._capi
+    L, K, bits = 1_000_000_000, 63, 4
+    seed = GOLDEN ^ 4
+    n = L - K + 1
+    nw = (L * bits + 63) // 64
+    buf = synth(ctx, seed, 0, nw, bits)
+    seq = cap.Seq(buf.data_ptr(), L, 0, 0, bits, 0)
+    res = cap.Result()
+    fw, rc, tmp = dev_empty(2 * n), dev_empty(2 * n), dev_empty(2 * n)
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, fw.data_ptr(), rc.data_ptr(), cap.MEM_DEVICE,
+                            C.byref(res)) == 0 and res.n_out == n
+    # reverse_complement(fw) == rc and reverse_complement is an involution (transformations.jl:32-34)
+    assert ctx.lib.kmers_transform(ctx.handle, cap.OP_REVCOMP, fw.data_ptr(), K, 2, n, tmp.data_ptr(), cap.MEM_DEVICE) == 0
+    assert bool(torch.equal(tmp, rc))
+    assert ctx.lib.kmers_transform(ctx.handle, cap.OP_REVCOMP, rc.data_ptr(), K, 2, n, tmp.data_ptr(), cap.MEM_DEVICE) == 0
+    assert bool(torch.equal(tmp, fw))
+    # head words use 62 bits; rolling relation across the two words of consecutive kmers
+    f = fw.view(-1, 2)
+    M62 = (1 << 62) - 1
+    for lo, hi in chunks(n - 1):
+        a, b = f[lo:hi], f[lo + 1:hi + 1]
+        assert int(torch.max(a[:, 0])) <= M62 and int(torch.min(a[:, 0])) >= 0
+        # shift_encoding on a two-word kmer (leftshift_carry, tuple_bitflipping.jl:24-33):
+        # lo' = lo << 2 | code ; hi' = (hi << 2 | lo >> 62) & mask
+        assert bool(torch.equal((b[:, 1] >> 2) & M62, a[:, 1] & M62))
+        assert bool(torch.equal(b[:, 0], ((a[:, 0] << 2) | ((a[:, 1] >> 62) & 3)) & M62))
+    per = 64 // bits
+    probe = 1 << 19
+    for first in (0, ((n - probe) // per) * per):
+        nb = min(probe, n - first) + K - 1
+        w = orc.synth_words(seed, first // per, (nb * bits + 63) // 64 + 1, bits)
+        efw, erv, _ = orc.fwrv(w, nb, bits, 2, K)
+        assert np.array_equal(host_u64(f[first:first + len(efw)]), efw)
+        assert np.array_equal(host_u64(rc.view(-1, 2)[first:first + len(erv)]), erv)
+
+
+def test_c5_spaced21_3_one_gbase_strict_and_skip(km, ctx, orc):
+    """configs[4]: SpacedDNAMers{21,3} over 1 Gbase LongDNA{4}.  Strict (the reference's SpacedKmers)
+    on a clean sequence and on one with N at p = 0.04 (must raise at the first N inside the lattice),
+    and the labelled skip variant = UnambiguousDNAMers{21} restricted to the stride lattice."""
+    cap = km._capi
+    L, K, J, bits = 1_000_000_000, 21, 3, 4
+    seed = GOLDEN ^ 5
+    nw = (L * bits + 63) // 64
+    n = (L - K) // J + 1
+    clean = synth(ctx, seed, 0, nw, bits)
+    seq = cap.Seq(clean.data_ptr(), L, 0, 0, bits, 0)
+    res = cap.Result()
+    sp = dev_empty(n)
+    assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, 2, sp.data_ptr(), cap.MEM_DEVICE, C.byref(res)) == 0
+    assert res.n_out == n == 333_333_327
+    # every third forward kmer
+    fw = dev_empty(L - K + 1)
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, fw.data_ptr(), None, cap.MEM_DEVICE, C.byref(res)) == 0
+    assert bool(torch.equal(sp, fw[::J]))
+    del fw
+    # ambiguous copy: strict semantics throw at the first N (every symbol up to the last kmer is inspected)
+    amb = synth(ctx, seed, 0, nw, bits, 2621)
+    seq_a = cap.Seq(amb.data_ptr(), L, 0, 0, bits, 0)
+    tmp = dev_empty(n)
+    rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq_a), K, J, 2, tmp.data_ptr(), cap.MEM_DEVICE, C.byref(res))
+    w = orc.synth_words(seed, 0, 4096, bits, 2621)
+    _, eres = orc.spaced(w, 4096 * 16, bits, 2, K, J)
+    assert rc == cap.E_ENCODE and eres.status == 1
+    assert (res.err_pos, res.err_enc) == (eres.err_pos, eres.err_enc)
+    # skip variant: windows on the lattice without ambiguous symbols, with their 1-based starts
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq_a), K, J, None, None, 0, cap.MEM_DEVICE, C.byref(res)) == 0
+    m = int(res.n_out)
+    kmers, starts = dev_empty(m), dev_empty(m)
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq_a), K, J, kmers.data_ptr(), starts.data_ptr(), m,
+                                     cap.MEM_DEVICE, C.byref(res)) == 0 and res.n_out == m
+    assert 0.40 * n < m < 0.45 * n                                    # (1 - 0.04)^21 = 0.424 of the lattice
+    assert bool(torch.all(starts[1:] > starts[:-1]))                  # iteration order
+    assert bool(torch.all((starts - 1) % J == 0))
+    assert bool(torch.equal(kmers, sp[(starts - 1) // J]))            # same kmer as strict Spaced on the clean copy
+    # exact comparison with the oracle on the first 8 Mbase
+    Lp = 8_000_000
+    w = orc.synth_words(seed, 0, Lp * bits // 64 + 1, bits, 2621)
+    ek, es, _ = orc.unambiguous(w, Lp, bits, K)
+    keep = (es - 1) % J == 0
+    cnt = int(keep.sum())
+    assert np.array_equal(host_u64(kmers[:cnt]), ek[keep][:, 0])
+    assert np.array_equal(starts[:cnt].cpu().numpy(), es[keep])
