@@ -7,10 +7,21 @@
 namespace kmers {
 
 // ---- fx_hash over n kmers of NW words ----------------------------------------------------
+// Short-lived workgroups, 16-byte accesses (the same launch-shape lesson as the stream kernel:
+// profiles/r01_tuning.md): one-word kmers are processed two per lane.
 template <int NW>
 __global__ __launch_bounds__(256) void fx_hash_kernel(const uint64_t *__restrict__ kmers, uint64_t n,
                                                        uint64_t seed, uint64_t *__restrict__ out) {
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    if constexpr (NW == 1) {
+        const uint64_t pairs = n / 2;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+            ulonglong2 x = reinterpret_cast<const ulonglong2 *>(kmers)[i];
+            reinterpret_cast<ulonglong2 *>(out)[i] = make_ulonglong2(fx_step(seed, x.x), fx_step(seed, x.y));
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = fx_step(seed, kmers[n - 1]);
+        return;
+    }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint64_t h = seed;
 #pragma unroll

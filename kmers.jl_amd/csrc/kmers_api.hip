@@ -332,16 +332,19 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
     a.index_origin = seq->index_origin;
-    uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : 4096u;
-    tile = std::max<uint32_t>(2u * BLOCK, std::min<uint32_t>(tile, (uint32_t)MAX_TILE_BASES) / (2u * BLOCK) * (2u * BLOCK));
+    // about 16 KiB of (kmer, start) output per workgroup, as for the stream kernel
+    uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(8u * nw + 8u, BLOCK);
+    tile = std::max<uint32_t>((uint32_t)BLOCK, std::min<uint32_t>(tile, (uint32_t)MAX_TILE_BASES) / BLOCK * BLOCK);
     a.tile_kmers = tile;
     a.n_tiles = (n + tile - 1) / tile;
     const uint64_t n_counts = a.n_tiles * WAVES;
-    // scratch: counts (u32) then offsets (u64, n_counts + 1)
+    // scratch: counts (u32), offsets (u64, n_counts + 1), segment sums (u64, n_seg + 1)
     size_t counts_bytes = ((size_t)n_counts * 4 + 15) & ~(size_t)15;
-    if (int rc = ensure_stage(ctx, 3, counts_bytes + ((size_t)n_counts + 1) * 8)) return rc;
+    const uint64_t n_seg = (n_counts + SCAN_SEG - 1) / SCAN_SEG;
+    if (int rc = ensure_stage(ctx, 3, counts_bytes + ((size_t)n_counts + 1) * 8 + ((size_t)n_seg + 1) * 8)) return rc;
     a.counts = static_cast<uint32_t *>(ctx->stage[3]);
     uint64_t *offsets = reinterpret_cast<uint64_t *>(static_cast<char *>(ctx->stage[3]) + counts_bytes);
+    uint64_t *seg_sums = offsets + n_counts + 1;
     a.offsets = offsets;
     uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap)), block(BLOCK);
@@ -354,7 +357,9 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     } while (0)
     UDISPATCH(false);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, a.counts, n_counts, offsets);
+    hipLaunchKernelGGL(scan_segment_sums_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, a.counts, n_counts, seg_sums);
+    hipLaunchKernelGGL(scan_segments_kernel, dim3(1), dim3(1024), 0, ctx->stream, seg_sums, n_seg);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, a.counts, n_counts, seg_sums, n_seg, offsets);
     HIP_TRY(ctx, hipGetLastError());
     uint64_t total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, offsets + n_counts, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -732,11 +737,17 @@ int kmers_fx_hash(kmers_ctx *ctx, const uint64_t *kmers, int n_words, uint64_t n
         d_in = (const uint64_t *)ctx->stage[0];
         d_out = (uint64_t *)ctx->stage[1];
     }
-    dim3 block(256), grid((unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16));
+    // one pass per workgroup (short-lived workgroups write fastest); NW == 1 takes two kmers per lane
+    // and needs 16-byte aligned arrays, else it falls back to the generic-width kernel
+    const bool pair_ok = n_words == 1 && aligned16(d_in) && aligned16(d_out);
+    const uint64_t work_items = pair_ok ? (n + 1) / 2 : n;
+    dim3 block(256), grid((unsigned)std::min<uint64_t>((work_items + 255) / 256, (uint64_t)1 << 30));
+    if (n_words == 1 && !pair_ok) n_words = -1;
     switch (n_words) {
         case 0: hipLaunchKernelGGL(fx_hash_kernel_any, grid, block, 0, ctx->stream, d_in, 0, n, seed, d_out); break;  // 0-mer: the seed
         case 1: hipLaunchKernelGGL((fx_hash_kernel<1>), grid, block, 0, ctx->stream, d_in, n, seed, d_out); break;
         case 2: hipLaunchKernelGGL((fx_hash_kernel<2>), grid, block, 0, ctx->stream, d_in, n, seed, d_out); break;
+        case -1: hipLaunchKernelGGL(fx_hash_kernel_any, grid, block, 0, ctx->stream, d_in, 1, n, seed, d_out); break;
         default: hipLaunchKernelGGL(fx_hash_kernel_any, grid, block, 0, ctx->stream, d_in, n_words, n, seed, d_out); break;
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -767,7 +778,7 @@ int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bi
         d_in = (const uint64_t *)ctx->stage[0];
         d_out = (uint64_t *)ctx->stage[1];
     }
-    dim3 block(256), grid((unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16));
+    dim3 block(256), grid((unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)1 << 30));  // one pass per workgroup
 #define TL(NW_, B_) hipLaunchKernelGGL((transform_kernel<NW_, B_>), grid, block, 0, ctx->stream, op, d_in, n, k, d_out)
     if (bits == 2) { if (nw == 1) TL(1, 2); else if (nw == 2) TL(2, 2); else if (nw == 3) TL(3, 2); else TL(4, 2); }
     else           { if (nw == 1) TL(1, 4); else if (nw == 2) TL(2, 4); else if (nw == 3) TL(3, 4); else TL(4, 4); }
