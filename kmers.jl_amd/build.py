@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libkmers_hip.so")
 SOURCES = ["kmers_api.hip"]
-HEADERS = ["device_bits.hpp", "stream_kernel.hpp", "compact_kernels.hpp", "batch_kernels.hpp",
+HEADERS = ["device_bits.hpp", "stream_kernel.hpp", "compact_kernels.hpp", "batch_kernels.hpp", "ascii_tables.hpp",
            os.path.join("..", "..", "include", "kmers_hip.h")]
 
 
@@ -29,11 +29,13 @@ def build(force=False, verbose=False):
     """Compile the HIP kernels + C ABI for gfx950.  Returns the path of the shared library."""
     if not force and not stale():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = f"{LIB}.{os.getpid()}.tmp"  # atomic replace: concurrent builders / loaders never see a partial file
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-array-bounds",
+           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
+    os.replace(tmp, LIB)
     return LIB
 
 

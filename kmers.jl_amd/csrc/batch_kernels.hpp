@@ -79,61 +79,108 @@ __device__ __forceinline__ void kmer_reverse(uint64_t (&d)[NW], uint32_t bu) {
     }
 }
 
+// one kmer through `op`; returns false when the result is a single flag/count in y[0]
 template <int NW, int BITS>
+__device__ __forceinline__ bool transform_one(int op, const uint64_t (&x)[NW], uint64_t (&y)[NW], uint64_t mask, uint32_t bu) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) y[w] = x[w];
+    if (op == 6) {  // count(isGC, kmer), src/counting.jl:1-8 (2-bit alphabets)
+        uint32_t n_gc = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) n_gc += __popcll((x[w] ^ (x[w] >> 1)) & 0x5555555555555555ull);
+        y[0] = n_gc;
+        return false;
+    }
+    if (op == 5) {  // LongSequence{A}(kmer).data, src/construction.jl:289-324:
+        // move the unused bits to the bottom (_fill_shift!), then reverse the symbols of every word
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            uint64_t chunk = x[w];
+            if (bu != 0) {
+                chunk = x[w] << bu;
+                if (w + 1 < NW) chunk |= x[w + 1] >> (64u - bu);
+            }
+            y[w] = reverse_symbols<BITS>(chunk);
+        }
+        return true;
+    }
+    if (op == 0) {
+        kmer_reverse<NW, BITS>(y, bu);
+    } else if (op == 1) {
+        kmer_complement<NW, BITS>(y, mask);
+    } else {
+        kmer_complement<NW, BITS>(y, mask);
+        kmer_reverse<NW, BITS>(y, bu);  // reverse_complement = reverse(complement(x)), :32-34
+    }
+    if (op >= 3) {
+        // lexicographic tuple compare, head first (kmer.jl:176-178)
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            if (c == 0) c = x[w] < y[w] ? -1 : (x[w] > y[w] ? 1 : 0);
+        if (op == 4) {
+            y[0] = c <= 0 ? 1ull : 0ull;  // iscanonical: x <= rc (:41)
+            return false;
+        }
+        if (c == -1) {  // canonical: ifelse(x < rc, x, rc) (:36-39)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) y[w] = x[w];
+        }
+    }
+    return true;
+}
+
+// VEC: 16-byte accesses (one-word kmers two per lane; two- and four-word kmers as ulonglong2);
+// needs 16-byte aligned arrays.  One pass per workgroup (launch-shape lesson, r01_tuning.md).
+template <int NW, int BITS, bool VEC>
 __global__ __launch_bounds__(256) void transform_kernel(int op, const uint64_t *__restrict__ in, uint64_t n, int k,
                                                          uint64_t *__restrict__ out) {
     const uint64_t mask = head_mask(k, BITS);
     const uint32_t bu = (uint32_t)bits_unused(k, BITS);
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (VEC && NW == 1) {
+        const uint64_t pairs = n / 2;
+        for (uint64_t i = t0; i < pairs; i += stride) {
+            ulonglong2 v = reinterpret_cast<const ulonglong2 *>(in)[i];
+            uint64_t xa[1] = {v.x}, xb[1] = {v.y}, ya[1], yb[1];
+            bool wide = transform_one<1, BITS>(op, xa, ya, mask, bu);
+            transform_one<1, BITS>(op, xb, yb, mask, bu);
+            (void)wide;  // one-word kmers: flags and kmers have the same 8-byte size
+            reinterpret_cast<ulonglong2 *>(out)[i] = make_ulonglong2(ya[0], yb[0]);
+        }
+        if ((n & 1) && t0 == 0) {
+            uint64_t xa[1] = {in[n - 1]}, ya[1];
+            transform_one<1, BITS>(op, xa, ya, mask, bu);
+            out[n - 1] = ya[0];
+        }
+        return;
+    }
+    for (uint64_t i = t0; i < n; i += stride) {
         uint64_t x[NW], y[NW];
+        if constexpr (VEC && (NW == 2 || NW == 4)) {
 #pragma unroll
-        for (int w = 0; w < NW; ++w) x[w] = y[w] = in[i * NW + w];
-        if (op == 6) {  // count(isGC, kmer), src/counting.jl:1-8 (2-bit alphabets)
-            uint32_t n_gc = 0;
+            for (int w = 0; w < NW; w += 2) {
+                ulonglong2 v = reinterpret_cast<const ulonglong2 *>(in + i * NW)[w / 2];
+                x[w] = v.x;
+                x[w + 1] = v.y;
+            }
+        } else {
 #pragma unroll
-            for (int w = 0; w < NW; ++w) n_gc += __popcll((x[w] ^ (x[w] >> 1)) & 0x5555555555555555ull);
-            out[i] = n_gc;
+            for (int w = 0; w < NW; ++w) x[w] = in[i * NW + w];
+        }
+        if (!transform_one<NW, BITS>(op, x, y, mask, bu)) {
+            out[i] = y[0];
             continue;
         }
-        if (op == 5) {  // LongSequence{A}(kmer).data, src/construction.jl:289-324
-            // = the symbol reversal of the kmer's 64*NW-bit value after moving the unused bits to the bottom
+        if constexpr (VEC && (NW == 2 || NW == 4)) {
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                uint64_t chunk = (x[w] << 1) << (bu == 0 ? 63u : bu - 1u);  // left_shift(kmer[w] & left_mask, bu)
-                if (bu == 0) chunk = x[w];
-                if (w + 1 < NW && bu != 0) chunk |= x[w + 1] >> (64u - bu);
-                y[w] = reverse_symbols<BITS>(chunk);
-            }
+            for (int w = 0; w < NW; w += 2)
+                reinterpret_cast<ulonglong2 *>(out + i * NW)[w / 2] = make_ulonglong2(y[w], y[w + 1]);
+        } else {
 #pragma unroll
             for (int w = 0; w < NW; ++w) out[i * NW + w] = y[w];
-            continue;
         }
-        if (op == 0) {
-            kmer_reverse<NW, BITS>(y, bu);
-        } else if (op == 1) {
-            kmer_complement<NW, BITS>(y, mask);
-        } else {
-            kmer_complement<NW, BITS>(y, mask);
-            kmer_reverse<NW, BITS>(y, bu);  // reverse_complement = reverse(complement(x)), :32-34
-        }
-        if (op >= 3) {
-            // lexicographic tuple compare, head first (kmer.jl:176-178)
-            int c = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
-                if (c == 0) c = x[w] < y[w] ? -1 : (x[w] > y[w] ? 1 : 0);
-            if (op == 4) {
-                out[i] = c <= 0 ? 1ull : 0ull;  // iscanonical: x <= rc (:41)
-                continue;
-            }
-            if (c == -1) {  // canonical: ifelse(x < rc, x, rc) (:36-39)
-#pragma unroll
-                for (int w = 0; w < NW; ++w) y[w] = x[w];
-            }
-        }
-#pragma unroll
-        for (int w = 0; w < NW; ++w) out[i * NW + w] = y[w];
     }
 }
 

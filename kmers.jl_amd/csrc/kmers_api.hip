@@ -778,8 +778,14 @@ int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bi
         d_in = (const uint64_t *)ctx->stage[0];
         d_out = (uint64_t *)ctx->stage[1];
     }
-    dim3 block(256), grid((unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)1 << 30));  // one pass per workgroup
-#define TL(NW_, B_) hipLaunchKernelGGL((transform_kernel<NW_, B_>), grid, block, 0, ctx->stream, op, d_in, n, k, d_out)
+    const bool vec = aligned16(d_in) && aligned16(d_out) && nw != 3;
+    const uint64_t items = (vec && nw == 1) ? (n + 1) / 2 : n;
+    dim3 block(256), grid((unsigned)std::min<uint64_t>((items + 255) / 256, (uint64_t)1 << 30));  // one pass per workgroup
+#define TL(NW_, B_)                                                                                                      \
+    do {                                                                                                                 \
+        if (vec) hipLaunchKernelGGL((transform_kernel<NW_, B_, true>), grid, block, 0, ctx->stream, op, d_in, n, k, d_out);  \
+        else hipLaunchKernelGGL((transform_kernel<NW_, B_, false>), grid, block, 0, ctx->stream, op, d_in, n, k, d_out);     \
+    } while (0)
     if (bits == 2) { if (nw == 1) TL(1, 2); else if (nw == 2) TL(2, 2); else if (nw == 3) TL(3, 2); else TL(4, 2); }
     else           { if (nw == 1) TL(1, 4); else if (nw == 2) TL(2, 4); else if (nw == 3) TL(3, 4); else TL(4, 4); }
 #undef TL

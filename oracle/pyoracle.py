@@ -30,9 +30,11 @@ def build(native=False, out_dir=None):
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
         return out
     march = "-march=native" if native else "-march=x86-64-v2"
+    tmp = f"{out}.{os.getpid()}.tmp"  # atomic: several ranks may call this at once
     cmd = ["gcc", "-O3", "-std=c11", "-fPIC", "-Wall", "-Wextra", "-Wno-return-type", march,
-           "-shared", "-o", out, src]
+           "-shared", "-o", tmp, src]
     subprocess.run(cmd, check=True)
+    os.replace(tmp, out)
     return out
 
 
