@@ -54,6 +54,10 @@ extern "C" {
 #define KMERS_MEM_HOST 0x0   /* sequence/output pointers are host memory (staged through HBM) */
 #define KMERS_MEM_DEVICE 0x1 /* sequence/output pointers are device (HBM) memory              */
 #define KMERS_ASYNC 0x2      /* device memory only: enqueue and return; collect status with kmers_sync */
+#define KMERS_OUT_TUPLES 0x4 /* array-of-structs output = the eltype of the tuple-yielding iterators, written to the
+                              * FIRST output pointer (second must be NULL): kmers_fw -> Tuple{Kmer,Kmer} (fw, rc; eltype of
+                              * FwRvIterator, CanonicalKmers.jl:44-45), kmers_canonical -> Tuple{Kmer,UInt64} (kmer, fx_hash),
+                              * kmers_unambiguous -> Tuple{Kmer,Int} (kmer, start; UnambiguousKmers.jl:39-41) */
 
 typedef struct kmers_ctx kmers_ctx; /* one per host thread / HIP stream; not thread-safe */
 

@@ -38,7 +38,7 @@ mutable struct CResult
 end
 
 const OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY = Int32.(0:6)
-const MEM_HOST, MEM_DEVICE, ASYNC = Int32(0), Int32(1), Int32(2)
+const MEM_HOST, MEM_DEVICE, ASYNC, OUT_TUPLES = Int32(0), Int32(1), Int32(2), Int32(4)
 
 # ---- context (one per Julia thread) --------------------------------------------------------
 mutable struct Context
@@ -89,20 +89,20 @@ function Base.collect(it::FwKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: 
     return out
 end
 
-"collect(FwRvIterator{A,K}(seq)): (forward, reverse_complement) pairs (CanonicalKmers.jl:54-144)"
+"collect(FwRvIterator{A,K}(seq)): (forward, reverse_complement) pairs (CanonicalKmers.jl:54-144).
+The library writes `Vector{Tuple{T,T}}` memory directly (KMERS_OUT_TUPLES)."
 function Base.collect(it::FwRvIterator{A, K, S}) where {A <: TwoBitAlphabet, K, S <: NucSeq24}
     ctx, s = context(), it.seq
     T = Kmers.derive_type(Kmer{A, K})
-    n = length(it)
-    fw, rv = Vector{T}(undef, n), Vector{T}(undef, n)
+    out = Vector{Tuple{T, T}}(undef, length(it))
     res = CResult()
-    GC.@preserve s fw rv begin
+    GC.@preserve s out begin
         rc = @ccall LIB.kmers_fw(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 2::Cint,
-                                 pointer(fw)::Ptr{UInt64}, pointer(rv)::Ptr{UInt64}, MEM_HOST::Cint,
+                                 pointer(out)::Ptr{UInt64}, C_NULL::Ptr{UInt64}, (MEM_HOST | OUT_TUPLES)::Cint,
                                  res::Ref{CResult})::Cint
     end
     check(ctx, rc, res, A, s)
-    return collect(zip(fw, rv))
+    return out
 end
 
 "collect(CanonicalKmers{A,K}(seq)) (CanonicalKmers.jl:199-225)"
@@ -152,14 +152,14 @@ function Base.collect(it::UnambiguousKmers{A, K, S}) where {A <: TwoBitAlphabet,
                                           res::Ref{CResult})::Cint
         check(ctx, rc, res, A, s)
         n = Int(res.n_out)
-        kmers, starts = Vector{T}(undef, n), Vector{Int}(undef, n)
-        GC.@preserve kmers starts begin
+        out = Vector{Tuple{T, Int}}(undef, n)   # eltype of UnambiguousKmers (:39-41), written in place
+        GC.@preserve out begin
             rc = @ccall LIB.kmers_unambiguous(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 1::Cint,
-                                              pointer(kmers)::Ptr{UInt64}, pointer(starts)::Ptr{Int64},
-                                              n::UInt64, MEM_HOST::Cint, res::Ref{CResult})::Cint
+                                              pointer(out)::Ptr{UInt64}, C_NULL::Ptr{Int64},
+                                              n::UInt64, (MEM_HOST | OUT_TUPLES)::Cint, res::Ref{CResult})::Cint
         end
         check(ctx, rc, res, A, s)
-        return collect(zip(kmers, starts))
+        return out
     end
 end
 

@@ -28,6 +28,7 @@ struct CompactArgs {
     const uint8_t *ascii_lut; // SRC_BITS == 8: the reference's ASCII_SKIPPING_LUT (common.jl:22-32)
     unsigned long long *err_slot;  // SRC_BITS == 8: first invalid byte (0xff in the table) -> EncodeError
     uint64_t n_bases;         // SRC_BITS == 8: every byte below n_bases is inspected (UnambiguousKmers.jl:117-123)
+    uint32_t tuples;          // 1: out_kmers receives Tuple{Kmer,Int} elements (N + 1 words each), out_starts unused
 };
 
 template <int SRC_BITS, int N, bool EMIT>
@@ -105,11 +106,17 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
                     uint64_t fw[N], rc[N];
                     window<N, 2>(lds, 2u * (r + b0), k, mask, fw, rc);
                     uint64_t o = pos + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (a.out_kmers) {
+                    if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
 #pragma unroll
-                        for (int w = 0; w < N; ++w) a.out_kmers[o * N + w] = fw[w];
+                        for (int w = 0; w < N; ++w) a.out_kmers[o * (N + 1) + w] = fw[w];
+                        a.out_kmers[o * (N + 1) + N] = g + 1 + a.index_origin;
+                    } else {
+                        if (a.out_kmers) {
+#pragma unroll
+                            for (int w = 0; w < N; ++w) a.out_kmers[o * N + w] = fw[w];
+                        }
+                        if (a.out_starts) a.out_starts[o] = (long long)(g + 1 + a.index_origin);
                     }
-                    if (a.out_starts) a.out_starts[o] = (long long)(g + 1 + a.index_origin);
                 }
                 pos += __popcll(bal);
             } else {

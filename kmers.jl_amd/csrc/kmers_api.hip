@@ -175,6 +175,17 @@ static uint32_t default_tile(uint32_t out_bytes_per_kmer, uint32_t pass) {
 
 template <int MODE, int SB, int DB>
 void launch_widths(int n_words, bool s1, dim3 grid, dim3 block, hipStream_t st, const StreamArgs &a, size_t dyn_lds) {
+    if constexpr (MODE == MODE_FW || MODE == MODE_CANON) {
+        if (a.tuples) {  // array-of-structs outputs: one kmer per lane per pass
+            switch (n_words) {
+                case 1: hipLaunchKernelGGL((stream_kernel<SB, DB, 1, MODE, false, true>), grid, block, dyn_lds, st, a); break;
+                case 2: hipLaunchKernelGGL((stream_kernel<SB, DB, 2, MODE, false, true>), grid, block, dyn_lds, st, a); break;
+                case 3: hipLaunchKernelGGL((stream_kernel<SB, DB, 3, MODE, false, true>), grid, block, dyn_lds, st, a); break;
+                default: hipLaunchKernelGGL((stream_kernel<SB, DB, 4, MODE, false, true>), grid, block, dyn_lds, st, a); break;
+            }
+            return;
+        }
+    }
 #define LAUNCH(NN)                                                                                   \
     do {                                                                                             \
         if (s1) hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, true>), grid, block, dyn_lds, st, a);  \
@@ -192,10 +203,11 @@ void launch_widths(int n_words, bool s1, dim3 grid, dim3 block, hipStream_t st, 
 template <int MODE>
 int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int n_words, bool vec_ok, size_t dyn_lds = 0) {
     const uint32_t J = a.stride;
-    const bool stride1 = (J == 1) && vec_ok;
+    const bool stride1 = (J == 1) && vec_ok && !a.tuples;
     const uint32_t pass = (stride1 && n_words == 1 ? 2u : 1u) * BLOCK;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
                          (MODE == MODE_CANON && a.out_b ? 8u : 0u);
+    if (a.tuples) out_bytes = MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u;
     if (MODE == MODE_XOR || MODE == MODE_SKETCH || MODE == MODE_COUNT) out_bytes = 4u;  // nothing streamed out: long tiles
     const uint32_t max_tile_symbols = (uint32_t)MAX_TILE_BITS / (uint32_t)dst_bits;
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
@@ -251,14 +263,21 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     remember_source(ctx, seq, st);
 
     const bool dev = flags & KMERS_MEM_DEVICE;
+    const bool tuples = (flags & KMERS_OUT_TUPLES) != 0;
+    if (tuples) {
+        if (out_b || !out_a) return fail(ctx, KMERS_E_BADARG, "KMERS_OUT_TUPLES: one interleaved output in the first pointer, second must be NULL");
+        if (stride != 1) return fail(ctx, KMERS_E_BADARG, "KMERS_OUT_TUPLES applies to kmers_fw / kmers_canonical / kmers_unambiguous");
+    }
     uint64_t *d_a = out_a, *d_b = out_b;
-    const size_t bytes_a = (size_t)n * nw * 8, bytes_b = (size_t)n * (b_is_hash ? 1 : nw) * 8;
+    const size_t tuple_words = mode == MODE_FW ? 2 * (size_t)nw : (size_t)nw + 1;
+    const size_t bytes_a = (size_t)n * (tuples ? tuple_words : (size_t)nw) * 8, bytes_b = (size_t)n * (b_is_hash ? 1 : nw) * 8;
     if (!dev) {
         if (out_a) { if (int rc = ensure_stage(ctx, 1, bytes_a)) return rc; d_a = (uint64_t *)ctx->stage[1]; }
         if (out_b) { if (int rc = ensure_stage(ctx, 2, bytes_b)) return rc; d_b = (uint64_t *)ctx->stage[2]; }
     }
     if ((nw == 2 || nw == 4) && ((d_a && !aligned16(d_a)) || (d_b && !b_is_hash && !aligned16(d_b))))
         return fail(ctx, KMERS_E_BADARG, "two- and four-word kmer outputs must be 16-byte aligned");
+    if (tuples && !aligned16(d_a)) return fail(ctx, KMERS_E_BADARG, "tuple outputs must be 16-byte aligned");
 
     StreamArgs a{};
     a.src = st.d_words;
@@ -273,6 +292,7 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
     a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+    a.tuples = tuples ? 1u : 0u;
 
     int rc;
     if ((uint64_t)stride * (uint64_t)dst_bits > 64) {
@@ -369,6 +389,8 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     }
     if (validate_only) total = 0;
     if (res) res->n_out = total;
+    const bool tuples = (flags & KMERS_OUT_TUPLES) != 0;
+    if (tuples && out_starts) return fail(ctx, KMERS_E_BADARG, "KMERS_OUT_TUPLES: out_starts must be NULL");
     if (total > capacity || (!out_kmers && !out_starts)) {
         // capacity query (both outputs NULL) or buffers too small: report the count only
         if (total > capacity && (out_kmers || out_starts)) {
@@ -380,13 +402,14 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     if (total == 0) return KMERS_OK;
     uint64_t *d_k = out_kmers;
     long long *d_s = reinterpret_cast<long long *>(out_starts);
-    const size_t kb = (size_t)total * nw * 8, sb = (size_t)total * 8;
+    const size_t kb = (size_t)total * (tuples ? nw + 1 : nw) * 8, sb = (size_t)total * 8;
     if (!dev) {
         if (out_kmers) { if (int rc = ensure_stage(ctx, 1, kb)) return rc; d_k = (uint64_t *)ctx->stage[1]; }
         if (out_starts) { if (int rc = ensure_stage(ctx, 2, sb)) return rc; d_s = (long long *)ctx->stage[2]; }
     }
     a.out_kmers = d_k;
     a.out_starts = d_s;
+    a.tuples = tuples ? 1u : 0u;
     UDISPATCH(true);
 #undef UDISPATCH
 #undef UL

@@ -48,6 +48,7 @@ struct StreamArgs {
     //              capacity = bins that fit the dynamic LDS histogram (0 = none), threshold = replicas
     uint64_t threshold;
     uint64_t capacity;
+    uint32_t tuples;          // 1: array-of-structs output in out_a (Tuple{Kmer,Kmer} / Tuple{Kmer,UInt64}), out_b unused
 };
 
 // First inspected offending symbol of one source word -> err_slot (rare path, kept inline and
@@ -171,9 +172,10 @@ __device__ __forceinline__ void store_kmer(uint64_t *out, uint64_t g, const uint
         out[g] = x[0];
     } else if constexpr (N == 2) {
         *reinterpret_cast<ulonglong2 *>(out + 2 * g) = make_ulonglong2(x[0], x[1]);
-    } else if constexpr (N == 4) {
-        *reinterpret_cast<ulonglong2 *>(out + 4 * g) = make_ulonglong2(x[0], x[1]);
-        *reinterpret_cast<ulonglong2 *>(out + 4 * g + 2) = make_ulonglong2(x[2], x[3]);
+    } else if constexpr (N % 2 == 0) {
+#pragma unroll
+        for (int w = 0; w < N; w += 2)
+            *reinterpret_cast<ulonglong2 *>(out + (uint64_t)N * g + w) = make_ulonglong2(x[w], x[w + 1]);
     } else {
 #pragma unroll
         for (int w = 0; w < N; ++w) out[g * N + w] = x[w];
@@ -212,7 +214,7 @@ __device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint6
     }
 }
 
-template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1>
+template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1, bool TUPLES = false>
 __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     __shared__ uint64_t lds[LDS_QWORDS];
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     if constexpr (SRC_BITS == 8) {
         for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = a.ascii_lut[i];  // visible after the tile loop's first barrier
     }
-    constexpr uint32_t KPL = (STRIDE1 && N == 1) ? 2u : 1u;  // kmers per lane per pass -> 16 B stores
+    constexpr uint32_t KPL = (STRIDE1 && N == 1 && !TUPLES) ? 2u : 1u;  // kmers per lane per pass -> 16 B stores
     uint64_t xacc = 0;
     // MODE_COUNT: where this workgroup accumulates.  4^K <= capacity: a private histogram in dynamic
     // LDS, flushed once at the end (K <= 6); else global counters, one replica per XCD for mid-size
@@ -288,7 +290,16 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
             }
             const bool both = (KPL == 2) && (r + 1 < mt);
 
-            if constexpr (MODE == MODE_FW) {
+            if constexpr (MODE == MODE_FW && TUPLES) {
+                // Tuple{Kmer,Kmer} elements of FwRvIterator (CanonicalKmers.jl:44-45): fw words, then rc words
+                uint64_t t[2 * N];
+#pragma unroll
+                for (int w = 0; w < N; ++w) {
+                    t[w] = fw[0][w];
+                    t[N + w] = rc[0][w];
+                }
+                store_kmer<2 * N>(a.out_a, g, t);
+            } else if constexpr (MODE == MODE_FW) {
                 if constexpr (KPL == 2) {
                     if (both) {
                         *reinterpret_cast<ulonglong2 *>(a.out_a + g) = make_ulonglong2(fw[0][0], fw[1][0]);
@@ -334,6 +345,13 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
                     if constexpr (KPL == 2) {
                         if (both) atomicAdd(count_base + (uint32_t)fw[1][0], 1u);
                     }
+                } else if constexpr (TUPLES) {
+                    // Tuple{Kmer,UInt64} elements: the canonical kmer, then its fx_hash
+                    uint64_t t[N + 1];
+#pragma unroll
+                    for (int w = 0; w < N; ++w) t[w] = c[0][w];
+                    t[N] = fx_hash<N>(c[0], a.seed);
+                    store_kmer<N + 1>(a.out_a, g, t);
                 } else if constexpr (KPL == 2) {
                     if (both) {
                         if (a.out_a) *reinterpret_cast<ulonglong2 *>(a.out_a + g) = make_ulonglong2(c[0][0], c[1][0]);

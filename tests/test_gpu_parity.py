@@ -566,3 +566,47 @@ def test_composition(km, ctx, orc):
             exp = np.bincount(fw[:, 0].astype(np.int64), minlength=4 ** K).astype(np.uint32)
             assert np.array_equal(counts, exp), (bits, K)
             assert counts.sum() == L - K + 1
+
+
+def test_tuple_layouts(km, ctx, orc):
+    """KMERS_OUT_TUPLES: outputs laid out as the eltype of the tuple-yielding iterators --
+    Vector{Tuple{Kmer,Kmer}} (FwRvIterator, CanonicalKmers.jl:44-45), Vector{Tuple{Kmer,UInt64}},
+    Vector{Tuple{Kmer,Int}} (UnambiguousKmers.jl:39-41) -- equal the interleaved separate arrays."""
+    cap = km._capi
+    rng = np.random.default_rng(123)
+    for bits in (2, 4):
+        for K in (5, 31, 33, 64, 70):
+            N = (2 * K + 63) // 64
+            for L in (K, 1000, 9973):
+                words = orc.synth_words(K + bits, 0, (L * bits + 63) // 64 + 1, bits)
+                n = L - K + 1
+                seq, keep = make_seq(km, words, L, bits)
+                res = cap.Result()
+                efw, erv, _ = orc.fwrv(words, L, bits, 2, K)
+                ek, eh, _ = orc.canonical(words, L, bits, 2, K, seed=11)
+                t = np.zeros((n, 2 * N), dtype=np.uint64)
+                rc = ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, vp(t), None, cap.OUT_TUPLES, C.byref(res))
+                assert rc == 0, ctx.last_error()
+                assert np.array_equal(t, np.concatenate([efw, erv], axis=1)), (bits, K, L)
+                t = np.zeros((n, N + 1), dtype=np.uint64)
+                rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, vp(t), None, 11, cap.OUT_TUPLES, C.byref(res))
+                assert rc == 0, ctx.last_error()
+                assert np.array_equal(t, np.concatenate([ek, eh[:, None]], axis=1)), (bits, K, L)
+    for K in (4, 31, 40):
+        N = (2 * K + 63) // 64
+        text = naive.random_text(rng, 20000, p_amb=0.03)
+        words = naive.longseq_words(text, 4)
+        seq, keep = make_seq(km, words, len(text), 4)
+        res = cap.Result()
+        assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, None, None, 0, 0, C.byref(res)) == 0
+        m = int(res.n_out)
+        t = np.zeros((m, N + 1), dtype=np.uint64)
+        assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, vp(t), None, m, cap.OUT_TUPLES, C.byref(res)) == 0
+        ek, es, _ = orc.unambiguous(words, len(text), 4, K)
+        assert np.array_equal(t, np.concatenate([ek, es.astype(np.uint64)[:, None]], axis=1))
+    # misuse
+    out = np.zeros((10, 2), dtype=np.uint64)
+    seq, keep = make_seq(km, naive.longseq_words("ACGTACGTAC", 4), 10, 4)
+    res = cap.Result()
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 2, vp(out), vp(out), cap.OUT_TUPLES, C.byref(res)) == cap.E_BADARG
+    assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), 3, 2, 2, vp(out), cap.OUT_TUPLES, C.byref(res)) == cap.E_BADARG
