@@ -58,17 +58,29 @@ context() = get!(() -> Context(0), CONTEXTS, Threads.threadid())
 last_error(ctx::Context) = unsafe_string(@ccall LIB.kmers_last_error(ctx.handle::Ptr{Cvoid})::Cstring)
 
 # ---- helpers -------------------------------------------------------------------------------
-const NucSeq24 = LongSequence{<:Union{DNAAlphabet{2}, DNAAlphabet{4}, RNAAlphabet{2}, RNAAlphabet{4}}}
+const NucAlphabet24 = Union{DNAAlphabet{2}, DNAAlphabet{4}, RNAAlphabet{2}, RNAAlphabet{4}}
+const NucSeq24 = LongSequence{<:NucAlphabet24}
+const ByteSource = Union{String, SubString{String}, Vector{UInt8}, Base.CodeUnits{UInt8, String}}
+const Source = Union{NucSeq24, ByteSource}          # every source a RecodingScheme other than Generic covers
 const TwoBitAlphabet = Union{DNAAlphabet{2}, RNAAlphabet{2}}
 
-src_bits(s::LongSequence) = Int32(BioSequences.bits_per_symbol(Alphabet(s)))
-cseq(s::LongSequence) = CSeq(pointer(s.data), length(s) % UInt64, 0, 0, src_bits(s), 0)
+dst_bits(::Type{A}) where {A} = Int32(BioSequences.bits_per_symbol(A()))
+isrna(::Type{A}) where {A} = Int32(A <: RNAAlphabet)
+
+# kmers_seq of a source for kmer alphabet A (the ASCII validity table is A's: construction.jl:94-95)
+cseq(s::LongSequence, ::Type{A}) where {A} =
+    CSeq(pointer(s.data), length(s) % UInt64, 0, 0, Int32(BioSequences.bits_per_symbol(Alphabet(s))), 0)
+cseq(s::ByteSource, ::Type{A}) where {A} =
+    CSeq(Ptr{UInt64}(pointer(s)), ncodeunits_or_length(s) % UInt64, 0, 0, Int32(8), isrna(A))
+ncodeunits_or_length(s::AbstractString) = ncodeunits(s)
+ncodeunits_or_length(s) = length(s)
 
 # Reproduce the reference's exception (src/construction.jl:108-110) from the C result.
-function check(ctx::Context, rc::Integer, res::CResult, ::Type{A}, s::LongSequence) where {A}
+function check(ctx::Context, rc::Integer, res::CResult, ::Type{A}, s) where {A}
     rc == OK && return nothing
     if rc == E_ENCODE
-        sym = reinterpret(eltype(s), res.err_enc % UInt8)
+        # LongSequence sources: the offending symbol; byte sources: repr(byte) (FwKmers.jl:124-126)
+        sym = s isa LongSequence ? reinterpret(eltype(s), res.err_enc % UInt8) : repr(res.err_enc % UInt8)
         throw(BioSequences.EncodeError(A(), sym))
     end
     error("libkmers_hip: status $rc: $(last_error(ctx))")
@@ -76,12 +88,12 @@ end
 
 # ---- bulk forms of the iterators -----------------------------------------------------------
 "collect(FwKmers{A,K}(seq)) on the GPU (src/iterators/FwKmers.jl:57-115)"
-function Base.collect(it::FwKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: NucSeq24}
+function Base.collect(it::FwKmers{A, K, S}) where {A <: NucAlphabet24, K, S <: Source}
     ctx, s = context(), it.seq
     out = Vector{eltype(it)}(undef, length(it))
     res = CResult()
     GC.@preserve s out begin
-        rc = @ccall LIB.kmers_fw(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 2::Cint,
+        rc = @ccall LIB.kmers_fw(ctx.handle::Ptr{Cvoid}, Ref(cseq(s, A))::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
                                  pointer(out)::Ptr{UInt64}, C_NULL::Ptr{UInt64}, MEM_HOST::Cint,
                                  res::Ref{CResult})::Cint
     end
@@ -91,13 +103,13 @@ end
 
 "collect(FwRvIterator{A,K}(seq)): (forward, reverse_complement) pairs (CanonicalKmers.jl:54-144).
 The library writes `Vector{Tuple{T,T}}` memory directly (KMERS_OUT_TUPLES)."
-function Base.collect(it::FwRvIterator{A, K, S}) where {A <: TwoBitAlphabet, K, S <: NucSeq24}
+function Base.collect(it::FwRvIterator{A, K, S}) where {A <: NucAlphabet24, K, S <: Source}
     ctx, s = context(), it.seq
     T = Kmers.derive_type(Kmer{A, K})
     out = Vector{Tuple{T, T}}(undef, length(it))
     res = CResult()
     GC.@preserve s out begin
-        rc = @ccall LIB.kmers_fw(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 2::Cint,
+        rc = @ccall LIB.kmers_fw(ctx.handle::Ptr{Cvoid}, Ref(cseq(s, A))::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
                                  pointer(out)::Ptr{UInt64}, C_NULL::Ptr{UInt64}, (MEM_HOST | OUT_TUPLES)::Cint,
                                  res::Ref{CResult})::Cint
     end
@@ -106,20 +118,20 @@ function Base.collect(it::FwRvIterator{A, K, S}) where {A <: TwoBitAlphabet, K, 
 end
 
 "collect(CanonicalKmers{A,K}(seq)) (CanonicalKmers.jl:199-225)"
-function Base.collect(it::CanonicalKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: NucSeq24}
+function Base.collect(it::CanonicalKmers{A, K, S}) where {A <: NucAlphabet24, K, S <: Source}
     return first(collect_with_hashes(it; hashes = false))
 end
 
 "Canonical kmers and fx_hash.(kmers, seed) from one fused kernel (kmer.jl:255-261)."
 function collect_with_hashes(it::CanonicalKmers{A, K, S}; seed::UInt = zero(UInt),
-                             hashes::Bool = true) where {A <: TwoBitAlphabet, K, S <: NucSeq24}
+                             hashes::Bool = true) where {A <: NucAlphabet24, K, S <: Source}
     ctx, s = context(), it.it.seq
     n = length(it)
     out = Vector{eltype(it)}(undef, n)
     h = hashes ? Vector{UInt64}(undef, n) : UInt64[]
     res = CResult()
     GC.@preserve s out h begin
-        rc = @ccall LIB.kmers_canonical(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 2::Cint,
+        rc = @ccall LIB.kmers_canonical(ctx.handle::Ptr{Cvoid}, Ref(cseq(s, A))::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
                                         pointer(out)::Ptr{UInt64},
                                         (hashes ? pointer(h) : Ptr{UInt64}(C_NULL))::Ptr{UInt64},
                                         seed::UInt64, MEM_HOST::Cint, res::Ref{CResult})::Cint
@@ -129,12 +141,12 @@ function collect_with_hashes(it::CanonicalKmers{A, K, S}; seed::UInt = zero(UInt
 end
 
 "collect(SpacedKmers{A,K,J}(seq)) (SpacedKmers.jl:83-139), strict semantics incl. EncodeError"
-function Base.collect(it::SpacedKmers{A, K, J, S}) where {A <: TwoBitAlphabet, K, J, S <: NucSeq24}
+function Base.collect(it::SpacedKmers{A, K, J, S}) where {A <: NucAlphabet24, K, J, S <: Source}
     ctx, s = context(), it.seq
     out = Vector{eltype(it)}(undef, length(it))
     res = CResult()
     GC.@preserve s out begin
-        rc = @ccall LIB.kmers_spaced(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, J::Cint, 2::Cint,
+        rc = @ccall LIB.kmers_spaced(ctx.handle::Ptr{Cvoid}, Ref(cseq(s, A))::Ptr{CSeq}, K::Cint, J::Cint, dst_bits(A)::Cint,
                                      pointer(out)::Ptr{UInt64}, MEM_HOST::Cint, res::Ref{CResult})::Cint
     end
     check(ctx, rc, res, A, s)
@@ -142,19 +154,19 @@ function Base.collect(it::SpacedKmers{A, K, J, S}) where {A <: TwoBitAlphabet, K
 end
 
 "collect(UnambiguousKmers{A,K}(seq)): (kmer, start) tuples (UnambiguousKmers.jl:59-148)"
-function Base.collect(it::UnambiguousKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: NucSeq24}
+function Base.collect(it::UnambiguousKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: Source}
     ctx, s = context(), it.it.seq
     T = Kmers.derive_type(Kmer{A, K})
     res = CResult()
     GC.@preserve s begin   # count first (SizeUnknown, :33), then fill
-        rc = @ccall LIB.kmers_unambiguous(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 1::Cint,
+        rc = @ccall LIB.kmers_unambiguous(ctx.handle::Ptr{Cvoid}, Ref(cseq(s, A))::Ptr{CSeq}, K::Cint, 1::Cint,
                                           C_NULL::Ptr{UInt64}, C_NULL::Ptr{Int64}, 0::UInt64, MEM_HOST::Cint,
                                           res::Ref{CResult})::Cint
         check(ctx, rc, res, A, s)
         n = Int(res.n_out)
         out = Vector{Tuple{T, Int}}(undef, n)   # eltype of UnambiguousKmers (:39-41), written in place
         GC.@preserve out begin
-            rc = @ccall LIB.kmers_unambiguous(ctx.handle::Ptr{Cvoid}, Ref(cseq(s))::Ptr{CSeq}, K::Cint, 1::Cint,
+            rc = @ccall LIB.kmers_unambiguous(ctx.handle::Ptr{Cvoid}, Ref(cseq(s, A))::Ptr{CSeq}, K::Cint, 1::Cint,
                                               pointer(out)::Ptr{UInt64}, C_NULL::Ptr{Int64},
                                               n::UInt64, (MEM_HOST | OUT_TUPLES)::Cint, res::Ref{CResult})::Cint
         end
@@ -215,9 +227,10 @@ function fill_chunk(g::GPUIterator{<:CanonicalKmers{A, K}}, start::Int) where {A
     ctx = context()
     buf = Vector{eltype(g.it)}(undef, n)
     res = CResult()
-    view = CSeq(pointer(s.data), (n + K - 1) % UInt64, (start - 1) % UInt64, (start - 1) % UInt64, src_bits(s), 0)
+    base = cseq(s, A)
+    view = CSeq(base.words, (n + K - 1) % UInt64, (start - 1) % UInt64, (start - 1) % UInt64, base.src_bits, base.alphabet)
     GC.@preserve s buf begin
-        rc = @ccall LIB.kmers_canonical(ctx.handle::Ptr{Cvoid}, Ref(view)::Ptr{CSeq}, K::Cint, 2::Cint,
+        rc = @ccall LIB.kmers_canonical(ctx.handle::Ptr{Cvoid}, Ref(view)::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
                                         pointer(buf)::Ptr{UInt64}, C_NULL::Ptr{UInt64}, 0::UInt64,
                                         MEM_HOST::Cint, res::Ref{CResult})::Cint
     end
