@@ -5,8 +5,9 @@
 // ambiguous symbol (:140-146).  Here a window is emitted iff the K bits of a one-bit-per-
 // symbol ambiguity stream (staged in LDS next to the 2-bit code stream) are all zero, which
 // selects exactly the same windows.  The output count is data dependent, so the work is
-// count -> exclusive scan -> emit, with the order of the reference preserved: each
-// wavefront owns a contiguous quarter of its tile and compacts with ballot + popcount.
+// count (bit-parallel, 64 starts per lane) -> exclusive scan -> emit, with the order of the
+// reference preserved: in the emit pass each wavefront owns a contiguous quarter of its tile
+// and compacts with ballot + popcount.
 #pragma once
 #include "stream_kernel.hpp"
 
@@ -29,9 +30,11 @@ struct CompactArgs {
     unsigned long long *err_slot;  // SRC_BITS == 8: first invalid byte (0xff in the table) -> EncodeError
     uint64_t n_bases;         // SRC_BITS == 8: every byte below n_bases is inspected (UnambiguousKmers.jl:117-123)
     uint32_t tuples;          // 1: out_kmers receives Tuple{Kmer,Int} elements (N + 1 words each), out_starts unused
+    uint32_t stride_magic;    // ceil(2^32 / stride) for stride < 32768 (exact x % stride for x < 2^17), else 0
+    uint32_t group;           // tiles staged together per workgroup iteration (count pass: > 1, emit pass: 1)
 };
 
-template <int SRC_BITS, int N, bool EMIT>
+template <int SRC_BITS, int N>
 __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a) {
     __shared__ uint64_t lds[LDS_QWORDS];
     __shared__ uint64_t amb[MAX_TILE_BASES / 64 + 8];
@@ -44,10 +47,15 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
     const uint64_t mask = head_mask((int)k, 2);
     const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
 
-    for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const uint64_t m0 = tile * a.tile_kmers;
+    // A workgroup iteration stages `group` consecutive tiles at once; the emit pass runs with
+    // group = 1 (short-lived workgroups, the output stream sets the pace).
+    const uint32_t group = a.group;
+    const uint64_t n_groups = (a.n_tiles + group - 1) / group;
+    for (uint64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint64_t m0 = grp * group * a.tile_kmers;
         const uint64_t left = a.n_cand - m0;
-        const uint32_t mt = left < a.tile_kmers ? (uint32_t)left : a.tile_kmers;
+        const uint32_t span = group * a.tile_kmers;
+        const uint32_t mt = left < span ? (uint32_t)left : span;
         const uint64_t bit0 = a.first_bit + m0 * SRC_BITS;
         const uint64_t w0 = bit0 >> 6;
         const uint32_t b0 = (uint32_t)(bit0 & 63u) / SRC_BITS;
@@ -82,50 +90,143 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
         }
         __syncthreads();
 
-        const uint32_t per_wave = a.tile_kmers / WAVES;
-        const uint32_t r_begin = wave * per_wave;
-        const uint32_t r_end = r_begin + per_wave < mt ? r_begin + per_wave : mt;
-        uint64_t pos = 0;
-        if constexpr (EMIT) pos = a.offsets[tile * WAVES + wave];
-        uint32_t count = 0;
-        const uint32_t passes = r_end > r_begin ? (r_end - r_begin + 63u) / 64u : 0u;  // wave-uniform
-        for (uint32_t p = 0; p < passes; ++p) {
-            // the whole wave iterates together (ballot needs every lane); lanes past the end are invalid
-            const uint32_t r = r_begin + p * 64u + lane;
-            const bool in = r < r_end;
-            const uint64_t g = m0 + r;
-            bool ok = false;
-            if (in) {
-                uint32_t bit = r + b0;
-                uint64_t A = funnel64(amb[bit >> 6], amb[(bit >> 6) + 1], bit & 63u) & kmask;
-                ok = (A == 0) && (a.stride == 1 || (g % a.stride) == 0);
+        for (uint32_t j = 0; j < group; ++j) {
+            const uint64_t tile = grp * group + j;
+            if (tile >= a.n_tiles) break;
+            const uint32_t per_wave = a.tile_kmers / WAVES;
+            const uint32_t r_begin = j * a.tile_kmers + wave * per_wave;
+            const uint32_t r_end = r_begin + per_wave < mt ? r_begin + per_wave : mt;  // r_begin may exceed mt in the last tile
+            uint64_t pos = 0;
+            pos = a.offsets[tile * WAVES + wave];
+            // only starts on the stride lattice are candidates: the first one at or after r_begin
+            // is r_first, then every `stride`-th (stride 1: every start)
+            uint32_t r_first = r_begin;
+            if (a.stride > 1) {
+                const uint64_t rem = (m0 + r_begin) % a.stride;  // wave-uniform, once per (tile, wave)
+                r_first = r_begin + (rem ? (uint32_t)(a.stride - rem) : 0u);
             }
-            const uint64_t bal = __ballot(ok);
-            if constexpr (EMIT) {
-                if (ok) {
-                    uint64_t fw[N], rc[N];
-                    window<N, 2>(lds, 2u * (r + b0), k, mask, fw, rc);
-                    uint64_t o = pos + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
-#pragma unroll
-                        for (int w = 0; w < N; ++w) a.out_kmers[o * (N + 1) + w] = fw[w];
-                        a.out_kmers[o * (N + 1) + N] = g + 1 + a.index_origin;
-                    } else {
-                        if (a.out_kmers) {
-#pragma unroll
-                            for (int w = 0; w < N; ++w) a.out_kmers[o * N + w] = fw[w];
-                        }
-                        if (a.out_starts) a.out_starts[o] = (long long)(g + 1 + a.index_origin);
-                    }
+            const uint32_t n_lat = r_first < r_end ? (r_end - r_first + a.stride - 1u) / a.stride : 0u;
+            const uint32_t passes = (n_lat + 63u) / 64u;  // wave-uniform
+            for (uint32_t p = 0; p < passes; ++p) {
+                // the whole wave iterates together (ballot needs every lane); lanes past the end are invalid
+                const uint32_t li = p * 64u + lane;
+                const uint32_t r = r_first + li * a.stride;
+                const bool in = li < n_lat;
+                const uint64_t g = m0 + r;
+                bool ok = false;
+                if (in) {
+                    uint32_t bit = r + b0;
+                    uint64_t A = funnel64(amb[bit >> 6], amb[(bit >> 6) + 1], bit & 63u) & kmask;
+                    ok = A == 0;
                 }
-                pos += __popcll(bal);
-            } else {
-                count += __popcll(bal);
+                const uint64_t bal = __ballot(ok);
+                {
+                    if (ok) {
+                        uint64_t fw[N], rc[N];
+                        window<N, 2>(lds, 2u * (r + b0), k, mask, fw, rc);
+                        uint64_t o = pos + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
+    #pragma unroll
+                            for (int w = 0; w < N; ++w) a.out_kmers[o * (N + 1) + w] = fw[w];
+                            a.out_kmers[o * (N + 1) + N] = g + 1 + a.index_origin;
+                        } else {
+                            if (a.out_kmers) {
+    #pragma unroll
+                                for (int w = 0; w < N; ++w) a.out_kmers[o * N + w] = fw[w];
+                            }
+                            if (a.out_starts) a.out_starts[o] = (long long)(g + 1 + a.index_origin);
+                        }
+                    }
+                    pos += __popcll(bal);
+                }
             }
         }
-        if constexpr (!EMIT) {
-            if (lane == 0) a.counts[tile * WAVES + wave] = count;
+    }
+}
+
+// Count pass, bit-parallel: one lane resolves 64 candidate starts at once.  With g = the "good"
+// (unambiguous) bit of every symbol, start i is kept iff g[i..i+K) are all ones; AND-ing the
+// stream with itself shifted by 1, 2, 4, ... (binary decomposition of K) leaves exactly those
+// bits.  Counts are accumulated per (tile, wavefront) of the EMIT pass, which owns the layout.
+template <int SRC_BITS>
+__global__ __launch_bounds__(BLOCK) void unambiguous_count_kernel(const CompactArgs a) {
+    __shared__ uint64_t amb[MAX_TILE_BASES / 64 + 8];
+    __shared__ uint32_t cnt[MAX_TILE_BASES / 64];          // one counter per (tile, wave) of the group (>= 64 starts each)
+    __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = a.k;
+    const uint32_t per_wave = a.tile_kmers / WAVES;        // starts per (tile, wave), a multiple of 64
+    if constexpr (SRC_BITS == 8) {
+        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = a.ascii_lut[i];
+    }
+    const uint32_t group_starts = a.group * a.tile_kmers;  // whole tiles, <= MAX_TILE_BASES starts per iteration
+    const uint64_t n_groups = (a.n_cand + group_starts - 1) / group_starts;
+    for (uint64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint64_t m0 = grp * group_starts;            // first candidate start of the group (tile aligned)
+        const uint64_t left = a.n_cand - m0;
+        const uint32_t mt = left < group_starts ? (uint32_t)left : group_starts;
+        const uint64_t bit0 = a.first_bit + m0 * SRC_BITS;
+        const uint64_t w0 = bit0 >> 6;
+        const uint32_t b0 = (uint32_t)(bit0 & 63u) / SRC_BITS;
+        const uint64_t end_bit = bit0 + ((uint64_t)(mt - 1) + k) * SRC_BITS;
+        const uint32_t nw = (uint32_t)(((end_bit + 63) >> 6) - w0);
+        const uint32_t n_slots = (mt + per_wave - 1) / per_wave;
+
+        __syncthreads();
+        for (uint32_t i = tid; i < n_slots; i += BLOCK) cnt[i] = 0;
+        for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
+            uint64_t x = a.src[w0 + wi];
+            if constexpr (SRC_BITS == 8) {
+                uint32_t flags = 0;
+                uint64_t f = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    uint32_t v = lut[(x >> (8 * j)) & 0xffu];
+                    flags |= (v >= 0xf0u ? 1u : 0u) << j;
+                    f |= (uint64_t)(v == 0xffu ? 1u : 0u) << (8 * j);
+                }
+                reinterpret_cast<uint8_t *>(amb)[wi] = (uint8_t)flags;
+                if (f) report_bad_symbols<8, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, w0 + wi, f);
+            } else if constexpr (SRC_BITS == 4) {
+                uint64_t bad;
+                (void)pack_4to2(x, bad);
+                reinterpret_cast<uint16_t *>(amb)[wi] = (uint16_t)bad_bits16(bad);
+            } else {
+                reinterpret_cast<uint32_t *>(amb)[wi] = 0u;
+            }
         }
+        // (flag bits past the staged range only ever reach starts >= mt, which are masked out below)
+        __syncthreads();
+
+        const uint32_t n_q = (mt + 63u) / 64u;             // 64 starts per lane
+        for (uint32_t q = tid; q < n_q; q += BLOCK) {
+            const uint32_t bit = 64u * q + b0;
+            const uint32_t Q = bit >> 6, sft = bit & 63u;
+            uint64_t lo = ~funnel64(amb[Q], amb[Q + 1], sft), hi = ~funnel64(amb[Q + 1], amb[Q + 2], sft);
+            uint32_t have = 1;
+            while (have < k) {
+                const uint32_t step = have < k - have ? have : k - have;   // 1..63
+                const uint64_t slo = (lo >> step) | ((hi << 1) << (63u - step));
+                const uint64_t shi = hi >> step;
+                lo &= slo;
+                hi &= shi;
+                have += step;
+            }
+            uint64_t keep = lo;                            // bit j: start 64q + j begins K unambiguous symbols
+            const uint32_t valid = mt - 64u * q;           // starts of this qword that exist
+            if (valid < 64u) keep &= (1ull << valid) - 1ull;
+            if (a.stride > 1) {                            // keep only starts with (m0 + 64q + j) % stride == 0
+                const uint64_t rem = (m0 + 64ull * q) % a.stride;
+                uint64_t lat = 0;
+                for (uint64_t pbit = rem ? a.stride - rem : 0; pbit < 64; pbit += a.stride) lat |= 1ull << pbit;
+                keep &= lat;
+            }
+            const uint32_t c = (uint32_t)__popcll(keep);
+            if (c) atomicAdd(&cnt[(64u * q) / per_wave], c);
+        }
+        __syncthreads();
+        // slot i of the group = (tile, wave) number (m0 / per_wave + i) of the emit pass
+        for (uint32_t i = tid; i < n_slots; i += BLOCK) a.counts[m0 / per_wave + i] = cnt[i];
     }
 }
 

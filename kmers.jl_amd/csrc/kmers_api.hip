@@ -351,6 +351,8 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.n_bases = seq->n_bases;
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
+    // exact for x < 2^17 when stride < 2^15: x * (magic * stride - 2^32) < 2^32
+    a.stride_magic = (stride > 1 && stride < 32768) ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)stride - 1) / (uint64_t)stride) : 0u;
     a.index_origin = seq->index_origin;
     // about 16 KiB of (kmer, start) output per workgroup, as for the stream kernel
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(8u * nw + 8u, BLOCK);
@@ -367,15 +369,25 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     uint64_t *seg_sums = offsets + n_counts + 1;
     a.offsets = offsets;
     uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
+    // count pass: bit-parallel, several whole tiles per staging on a persistent grid (nothing is
+    // streamed out); emit pass: one tile per short-lived workgroup
+    a.group = std::max<uint32_t>(1u, 8192u / tile);
+    HIP_TRY(ctx, hipMemsetAsync(a.counts, 0, (size_t)n_counts * 4, ctx->stream));
+    {
+        const uint64_t n_groups = (n + (uint64_t)a.group * tile - 1) / ((uint64_t)a.group * tile);
+        dim3 cgrid((unsigned)std::min<uint64_t>(n_groups, 256 * 8)), cblock(BLOCK);
+        if (seq->src_bits == 8) hipLaunchKernelGGL((unambiguous_count_kernel<8>), cgrid, cblock, 0, ctx->stream, a);
+        else if (seq->src_bits == 4) hipLaunchKernelGGL((unambiguous_count_kernel<4>), cgrid, cblock, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((unambiguous_count_kernel<2>), cgrid, cblock, 0, ctx->stream, a);
+    }
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap)), block(BLOCK);
-#define UL(SB, NN, EM) hipLaunchKernelGGL((unambiguous_kernel<SB, NN, EM>), grid, block, 0, ctx->stream, a)
+#define UL(SB, NN, EM) hipLaunchKernelGGL((unambiguous_kernel<SB, NN>), grid, block, 0, ctx->stream, a)
 #define UDISPATCH(EM)                                                         \
     do {                                                                      \
         if (seq->src_bits == 8) { if (nw == 1) UL(8, 1, EM); else UL(8, 2, EM); }      \
         else if (seq->src_bits == 4) { if (nw == 1) UL(4, 1, EM); else UL(4, 2, EM); } \
         else                    { if (nw == 1) UL(2, 1, EM); else UL(2, 2, EM); }      \
     } while (0)
-    UDISPATCH(false);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(scan_segment_sums_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, a.counts, n_counts, seg_sums);
     hipLaunchKernelGGL(scan_segments_kernel, dim3(1), dim3(1024), 0, ctx->stream, seg_sums, n_seg);
@@ -410,6 +422,7 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.out_kmers = d_k;
     a.out_starts = d_s;
     a.tuples = tuples ? 1u : 0u;
+    a.group = 1;
     UDISPATCH(true);
 #undef UDISPATCH
 #undef UL

@@ -397,8 +397,8 @@ def test_spaced_skip_variant(km, ctx, orc):
     """BASELINE.json config 5 "with ambiguous-base skip" = the elements (kmer, i) of
     UnambiguousDNAMers{K}(seq) with (i-1) % J == 0 (docs/src/faq.md:28-33)."""
     rng = np.random.default_rng(37)
-    for K, J in [(21, 3), (5, 2), (31, 7)]:
-        L = 20000
+    for K, J in [(21, 3), (5, 2), (31, 7), (4, 1000), (3, 32767), (3, 40000)]:
+        L = 20000 if J < 1000 else 200000
         text = naive.random_text(rng, L, p_amb=0.04)
         words = naive.longseq_words(text, 4)
         kmers, starts = run_unambiguous(km, ctx, words, L, 4, K, stride=J)
