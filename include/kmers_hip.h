@@ -151,6 +151,15 @@ int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, 
 int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t seed, uint64_t s,
                   uint64_t *out_hashes, int flags, kmers_result *res);
 
+/* Minimizers, the kmer replacement the reference builds from its public primitives in
+ * docs/src/replacements.md:33-51 and test/benchmark.jl:96-110: element j is the kmer with the
+ * smallest fx_hash among the W consecutive kmers starting at symbol 1 + j*stride (windows that do
+ * not fit are not produced).  mode 0 reproduces the published `unsafe_extract_minimizer`
+ * literally (each new symbol is shifted into the current minimum), mode 1 is the true
+ * sliding-window minimum (leftmost on ties).  out_kmers: n * N words. */
+int kmers_minimizers(kmers_ctx *ctx, const kmers_seq *seq, int k, int w, int stride, int dst_bits, int mode,
+                     uint64_t *out_kmers, int flags, kmers_result *res);
+
 /* Fused consumer of docs/src/composition.md:28-39: out_counts[as_integer(kmer)] += 1 for every
  * kmer of FwKmers{DNA/RNAAlphabet{2},K}(seq); out_counts has 4^K uint32 entries (K <= 12). */
 int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out_counts, int flags,

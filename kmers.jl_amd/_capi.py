@@ -54,6 +54,7 @@ SYMBOLS = {
     "kmers_unambiguous": (C.c_int, [_P, _S, C.c_int, C.c_int, _P, _P, C.c_uint64, C.c_int, _R]),
     "kmers_reduce_xor": (C.c_int, [_P, _S, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int, _R]),
     "kmers_minhash": (C.c_int, [_P, _S, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int, _R]),
+    "kmers_minimizers": (C.c_int, [_P, _S, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _R]),
     "kmers_composition": (C.c_int, [_P, _S, C.c_int, _P, C.c_int, _R]),
     "kmers_fx_hash": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int]),
     "kmers_transform": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_uint64, _P, C.c_int]),

@@ -209,7 +209,9 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
                          (MODE == MODE_CANON && a.out_b ? 8u : 0u);
     if (a.tuples) out_bytes = MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u;
     if (MODE == MODE_XOR || MODE == MODE_SKETCH || MODE == MODE_COUNT) out_bytes = 4u;  // nothing streamed out: long tiles
-    const uint32_t max_tile_symbols = (uint32_t)MAX_TILE_BITS / (uint32_t)dst_bits;
+    if (MODE == MODE_MINIMIZER) out_bytes = 8u * n_words;
+    uint32_t max_tile_symbols = (uint32_t)MAX_TILE_BITS / (uint32_t)dst_bits;
+    if (MODE == MODE_MINIMIZER) max_tile_symbols -= std::min<uint32_t>(max_tile_symbols / 2, a.window_kmers);  // room for the longer overlap
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);
     tile = std::max<uint32_t>(pass, tile / pass * pass);
@@ -694,6 +696,55 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
     std::memcpy(out_hashes, best.data(), best.size() * 8);
     if (res) res->n_out = best.size();
     return KMERS_OK;
+}
+
+int kmers_minimizers(kmers_ctx *ctx, const kmers_seq *seq, int k, int w, int stride, int dst_bits, int mode,
+                     uint64_t *out_kmers, int flags, kmers_result *res) {
+    clear(res);
+    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags)) {
+        if (res) res->status = rc;
+        return rc;
+    }
+    if (w < 1 || w > 4096 || (mode != 0 && mode != 1)) return fail(ctx, KMERS_E_BADARG, "window must be 1..4096 kmers, mode 0 or 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int nw = kmers_words_per_kmer(k, dst_bits);
+    const uint64_t span = (uint64_t)k + (uint64_t)w - 1;
+    const uint64_t n = seq->n_bases < span ? 0 : (seq->n_bases - span) / (uint64_t)stride + 1;
+    if (n == 0) return KMERS_OK;
+    if (!out_kmers) return fail(ctx, KMERS_E_BADARG, "out_kmers is NULL");
+    if ((uint64_t)stride * (uint64_t)dst_bits > 64 * 8) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minimizers supports window strides up to 512 / dst_bits symbols");
+    Staged st;
+    if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
+    remember_source(ctx, seq, st);
+    const bool dev = flags & KMERS_MEM_DEVICE;
+    uint64_t *d_out = out_kmers;
+    const size_t bytes = (size_t)n * nw * 8;
+    if (!dev) {
+        if (int rc = ensure_stage(ctx, 1, bytes)) return rc;
+        d_out = static_cast<uint64_t *>(ctx->stage[1]);
+    }
+    if ((nw == 2 || nw == 4) && !aligned16(d_out)) return fail(ctx, KMERS_E_BADARG, "two- and four-word kmer outputs must be 16-byte aligned");
+    StreamArgs a{};
+    a.src = st.d_words;
+    a.first_bit = st.first_bit;
+    a.n_bases = seq->n_bases;
+    a.n_kmers = n;
+    a.inspect_end = (n - 1) * (uint64_t)stride + span;  // every symbol of every window is read
+    a.out_a = d_out;
+    a.err_slot = ctx->d_err;
+    a.k = (uint32_t)k;
+    a.stride = (uint32_t)stride;
+    a.window_kmers = (uint32_t)w;
+    a.minimizer_mode = (uint32_t)mode;
+    a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+    // strides >= span leave gaps the reference's loop never reads: restrict the validation to the windows
+    if (int rc = launch_stream<MODE_MINIMIZER>(ctx, a, seq->src_bits, dst_bits, nw, false)) return rc;
+    if (flags & KMERS_ASYNC) {
+        if (res) { res->status = KMERS_OK; res->n_out = n; }
+        return KMERS_OK;
+    }
+    if (!dev) HIP_TRY(ctx, hipMemcpyAsync(out_kmers, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return collect(ctx, res, n);
 }
 
 int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out_counts, int flags, kmers_result *res) {

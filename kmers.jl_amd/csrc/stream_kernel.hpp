@@ -24,7 +24,7 @@ constexpr int MAX_TILE_BITS = 32768;           // LDS stream bits a tile may spa
 constexpr int MAX_TILE_BASES = MAX_TILE_BITS / 2;
 constexpr int LDS_QWORDS = MAX_TILE_BITS / 64 + 16;
 
-enum Mode { MODE_FW = 0, MODE_CANON = 1, MODE_XOR = 2, MODE_SKETCH = 3, MODE_COUNT = 4 };
+enum Mode { MODE_FW = 0, MODE_CANON = 1, MODE_XOR = 2, MODE_SKETCH = 3, MODE_COUNT = 4, MODE_MINIMIZER = 5 };
 
 struct StreamArgs {
     const uint64_t *src;     // LongSequence.data in HBM
@@ -48,6 +48,10 @@ struct StreamArgs {
     //              capacity = bins that fit the dynamic LDS histogram (0 = none), threshold = replicas
     uint64_t threshold;
     uint64_t capacity;
+    // MODE_MINIMIZER: window = `window_kmers` consecutive kmers per element, elements `stride` apart;
+    //                 minimizer_mode 0 = the reference's published example, 1 = true sliding-window minimum
+    uint32_t window_kmers;
+    uint32_t minimizer_mode;
     uint32_t tuples;          // 1: array-of-structs output in out_a (Tuple{Kmer,Kmer} / Tuple{Kmer,UInt64}), out_b unused
 };
 
@@ -249,7 +253,8 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
         const uint64_t bit0 = a.first_bit + m0 * J * SRC_BITS;
         const uint64_t w0 = bit0 >> 6;
         const uint32_t b0 = (uint32_t)(bit0 & 63u) / SRC_BITS;
-        const uint64_t end_bit = bit0 + ((uint64_t)(mt - 1) * J + k) * SRC_BITS;
+        const uint32_t span = MODE == MODE_MINIMIZER ? k + a.window_kmers - 1u : k;  // symbols one element reads
+        const uint64_t end_bit = bit0 + ((uint64_t)(mt - 1) * J + span) * SRC_BITS;
         const uint32_t nw = (uint32_t)(((end_bit + 63) >> 6) - w0);
 
 #ifdef KMERS_STAMPS
@@ -290,7 +295,35 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
             }
             const bool both = (KPL == 2) && (r + 1 < mt);
 
-            if constexpr (MODE == MODE_FW && TUPLES) {
+            if constexpr (MODE == MODE_MINIMIZER) {
+                // docs/src/replacements.md:33-51: start from the window's first kmer, shift the next
+                // W-1 symbols in one at a time, keep the kmer with the smallest fx_hash
+                uint64_t best[N], cur[N];
+#pragma unroll
+                for (int w = 0; w < N; ++w) best[w] = cur[w] = fw[0][w];
+                uint64_t hash = fx_hash<N>(best, 0);
+                for (uint32_t off = 0; off + 1 < a.window_kmers; ++off) {
+                    const uint32_t bit = (uint32_t)DST * (r * J + b0 + k + off);
+                    const uint64_t sym = (lds[bit >> 6] >> (bit & 63u)) & ((1u << DST) - 1u);
+                    uint64_t nk[N];
+                    // mode 0 shifts into the CURRENT MINIMUM (as the published example does), mode 1 into the rolling kmer
+#pragma unroll
+                    for (int w = 0; w < N; ++w) nk[w] = a.minimizer_mode == 0 ? best[w] : cur[w];
+#pragma unroll
+                    for (int w = 0; w < N - 1; ++w) nk[w] = (nk[w] << DST) | (nk[w + 1] >> (64 - DST));  // shift_encoding
+                    nk[N - 1] = (nk[N - 1] << DST) | sym;
+                    nk[0] &= mask;
+#pragma unroll
+                    for (int w = 0; w < N; ++w) cur[w] = nk[w];
+                    const uint64_t nh = fx_hash<N>(nk, 0);
+                    if (nh < hash) {
+                        hash = nh;
+#pragma unroll
+                        for (int w = 0; w < N; ++w) best[w] = nk[w];
+                    }
+                }
+                store_kmer<N>(a.out_a, g, best);
+            } else if constexpr (MODE == MODE_FW && TUPLES) {
                 // Tuple{Kmer,Kmer} elements of FwRvIterator (CanonicalKmers.jl:44-45): fw words, then rc words
                 uint64_t t[2 * N];
 #pragma unroll

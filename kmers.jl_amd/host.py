@@ -715,6 +715,31 @@ def sketch(f, it, s, seed=0):
     return out[:int(res.n_out)]
 
 
+def minimizers(it, W, stride=1, mode=0):
+    """Minimizers over the kmers of a FwKmers iterator (docs/src/replacements.md:33-51,
+    test/benchmark.jl:96-119): element j = the kmer with the smallest fx_hash among the W kmers
+    starting at symbol 1 + j*stride.  mode 0 = the reference's published example literally
+    (symbols are shifted into the running minimum), mode 1 = true sliding-window minimum."""
+    if not isinstance(it, FwKmers):
+        raise UnsupportedError("minimizers(FwKmers, W)")
+    span = it.K + W - 1
+    n = 0 if it.seq.len < span else (it.seq.len - span) // stride + 1
+    out = np.zeros((n, it.N), dtype=np.uint64)
+    if n:
+        d = it.ctx.alloc(out.nbytes)
+        res = _capi.Result()
+        try:
+            view = it._view(0, it.seq.len)
+            rc = it.ctx.check(it.ctx.lib.kmers_minimizers(it.ctx.handle, C.byref(view), it.K, W, stride, it.alphabet.bits,
+                                                           mode, d, _capi.MEM_DEVICE, C.byref(res)), "kmers_minimizers")
+            if rc == _capi.E_ENCODE:
+                _raise_encode(it.alphabet, it.seq, res)
+            it.ctx.d2h(out, d)
+        finally:
+            it.ctx.free(d)
+    return KmerArray(it.alphabet, it.K, out)
+
+
 def composition(it):
     """Kmer composition counts (docs/src/composition.md:28-39): counts[as_integer(kmer)] over
     FwKmers{DNA/RNAAlphabet{2},K}(seq), 4^K uint32 counters, one fused pass."""

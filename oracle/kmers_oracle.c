@@ -553,6 +553,49 @@ INL int spaced_impl(const uint64_t *seq, uint64_t len, const int src_bps, const 
     }
 }
 
+/* Minimizers: the example the reference publishes on top of its public primitives
+ * (docs/src/replacements.md:33-51, test/benchmark.jl:96-110):
+ *     kmer = unsafe_extract(R, T, seq, i); hash = fx_hash(kmer)
+ *     for offset in 0:W-2
+ *         new_kmer = unsafe_shift_from(R, kmer, seq, i+K+offset, Val(1)); new_hash = fx_hash(new_kmer)
+ *         if new_hash < hash; hash = new_hash; kmer = new_kmer; end
+ * mode 0 restates it literally -- note that the symbol is shifted into `kmer`, the CURRENT MINIMUM,
+ * not into the previous window position.  mode 1 is the true sliding-window minimizer (the kmer
+ * with the smallest fx_hash among the W consecutive kmers, leftmost on ties).
+ * Windows start at i = 1, 1+stride, ... while the window fits (i + K + W - 2 <= len). */
+static int check_args(int src_bps, int dst_bps, int K, orc_result *res);
+
+int orc_minimizers(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, int K, int W, int stride,
+                   int mode, uint64_t *out_kmers, orc_result *res) {
+    if (check_args(src_bps, dst_bps, K, res)) return ORC_E_BADARG;
+    if (W < 1 || stride < 1) { res->status = ORC_E_BADARG; return ORC_E_BADARG; }
+    const int N = n_coding_elements(K, dst_bps);
+    const uint64_t span = (uint64_t)K + (uint64_t)W - 1;
+    if (len < span) return 0;
+    for (uint64_t i = 1; i + span - 1 <= len; i += (uint64_t)stride) {
+        uint64_t kmer[ORC_MAX_N], cur[ORC_MAX_N], nk[ORC_MAX_N];
+        if (unsafe_extract(seq, src_bps, dst_bps, N, K, i, kmer, res)) return ORC_E_ENCODE;
+        for (int w = 0; w < N; ++w) cur[w] = kmer[w];
+        uint64_t hash = fx_hash(kmer, N, 0);
+        for (int offset = 0; offset <= W - 2; ++offset) {
+            const uint64_t *from = mode == 0 ? kmer : cur;
+            for (int w = 0; w < N; ++w) nk[w] = from[w];
+            if (unsafe_shift_from(seq, src_bps, dst_bps, N, K, i + (uint64_t)K + (uint64_t)offset, 1, nk, res))
+                return ORC_E_ENCODE;
+            for (int w = 0; w < N; ++w) cur[w] = nk[w];
+            uint64_t new_hash = fx_hash(nk, N, 0);
+            if (new_hash < hash) {
+                hash = new_hash;
+                for (int w = 0; w < N; ++w) kmer[w] = nk[w];
+            }
+        }
+        if (out_kmers)
+            for (int w = 0; w < N; ++w) out_kmers[res->n_out * N + w] = kmer[w];
+        res->n_out++;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------ */
 /* public wrappers: constant-fold the common geometries so that the cpu_baseline
  * timing is of specialised code (Julia specialises on A, K, N at compile time). */

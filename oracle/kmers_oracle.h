@@ -91,6 +91,11 @@ int orc_unambiguous(const uint64_t *seq, uint64_t len, int src_bps, int K,
 int orc_spaced(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, int K, int J,
                uint64_t *out, orc_result *res); /* src/iterators/SpacedKmers.jl:83-139 */
 
+/* minimizers built from the public primitives: docs/src/replacements.md:33-51, test/benchmark.jl:96-110
+ * (mode 0 = the published example, literally; mode 1 = true sliding-window minimum) */
+int orc_minimizers(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, int K, int W, int stride,
+                   int mode, uint64_t *out_kmers, orc_result *res);
+
 /* XOR-reduce consumer of test/benchmark.jl:9-15 over CanonicalKmers / FwKmers */
 uint64_t orc_reduce_xor_canonical(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, int K,
                                   orc_result *res);

@@ -79,6 +79,7 @@ class Oracle:
         L.orc_kmer_from_longseq.argtypes = [_u64p, C.c_uint64, C.c_int, C.c_int, _u64p]
         L.orc_longseq_from_kmer.argtypes = [_u64p, C.c_int, C.c_int, _u64p]
         L.orc_n_gc.argtypes = [_u64p, C.c_int]
+        L.orc_minimizers.argtypes = [_u64p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u64p, R]
         L.orc_synth_rand64.restype = C.c_uint64
         L.orc_synth_rand64.argtypes = [C.c_uint64, C.c_uint64]
         L.orc_synth_words.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _u64p]
@@ -154,6 +155,16 @@ class Oracle:
         out = np.zeros((n, N), dtype=np.uint64)
         res = Result()
         self.lib.orc_spaced(_ptr(seq), length, src_bps, dst_bps, K, J, _ptr(out), C.byref(res))
+        return out[:res.n_out], res
+
+    def minimizers(self, seq, length, src_bps, dst_bps, K, W, stride, mode=0):
+        seq = self._seq(seq)
+        N = self.nwords(K, dst_bps)
+        span = K + W - 1
+        n = 0 if length < span else (length - span) // stride + 1
+        out = np.zeros((n, N), dtype=np.uint64)
+        res = Result()
+        self.lib.orc_minimizers(_ptr(seq), length, src_bps, dst_bps, K, W, stride, mode, _ptr(out), C.byref(res))
         return out[:res.n_out], res
 
     def reduce_xor_canonical(self, seq, length, src_bps, dst_bps, K):

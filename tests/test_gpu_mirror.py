@@ -240,6 +240,9 @@ def test_fused_consumers(km, orc):
     assert np.array_equal(sk, np.unique(eh)[:1000])
     assert np.array_equal(km.sketch(km.fx_hash, km.CanonicalDNAMers[16]("ACGTTGCAAGGCTTACGATCGA"), 1000),
                           np.unique(orc.canonical(naive.ascii_words("ACGTTGCAAGGCTTACGATCGA"), 22, 8, 2, 16)[1]))
+    mins = km.minimizers(km.FwDNAMers[8](seq), 20, stride=20)            # test/benchmark.jl:112-119 shape
+    exp, _ = orc.minimizers(words, L, 4, 2, 8, 20, 20, 0)
+    assert np.array_equal(mins.words, exp)
     comp = km.composition(km.FwDNAMers[4](seq))
     fw, _ = orc.fw_kmers(words, L, 4, 2, 4)
     assert np.array_equal(comp, np.bincount(fw[:, 0].astype(np.int64), minlength=256).astype(np.uint32))

@@ -610,3 +610,40 @@ def test_tuple_layouts(km, ctx, orc):
     res = cap.Result()
     assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 2, vp(out), vp(out), cap.OUT_TUPLES, C.byref(res)) == cap.E_BADARG
     assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), 3, 2, 2, vp(out), cap.OUT_TUPLES, C.byref(res)) == cap.E_BADARG
+
+
+def test_minimizers(km, ctx, orc):
+    """kmers_minimizers vs the oracle, both modes (docs/src/replacements.md:33-51, test/benchmark.jl:96-119)."""
+    cap = km._capi
+    for src in (2, 4):
+        for K, W, stride in [(8, 20, 20), (5, 9, 1), (31, 10, 7), (33, 5, 3), (64, 3, 40), (21, 50, 11), (4, 1, 2)]:
+            N = (2 * K + 63) // 64
+            for L in (K + W - 2, K + W - 1, 5000, 100_003):
+                words = orc.synth_words(K * W, 0, (L * src + 63) // 64 + 1, src)
+                span = K + W - 1
+                n = 0 if L < span else (L - span) // stride + 1
+                for mode in (0, 1):
+                    out = np.zeros((max(n, 1), N), dtype=np.uint64)
+                    res = cap.Result()
+                    seq, keep = make_seq(km, words, L, src)
+                    rc = ctx.lib.kmers_minimizers(ctx.handle, C.byref(seq), K, W, stride, 2, mode, vp(out), cap.MEM_HOST, C.byref(res))
+                    assert rc == 0, (K, W, stride, L, ctx.last_error())
+                    exp, eres = orc.minimizers(words, L, src, 2, K, W, stride, mode)
+                    assert res.n_out == n == len(exp)
+                    assert np.array_equal(out[:n], exp), (src, K, W, stride, L, mode)
+    # the benchmark's shape: K = 8, W = 20, windows every 20 symbols of a 2-bit sequence, XOR of data[1]
+    L = 10_000_000
+    words = orc.synth_words(439824, 0, L * 2 // 64 + 1, 2)
+    n = (L - 27) // 20 + 1
+    out = np.zeros((n, 1), dtype=np.uint64)
+    res = cap.Result()
+    seq, keep = make_seq(km, words, L, 2)
+    assert ctx.lib.kmers_minimizers(ctx.handle, C.byref(seq), 8, 20, 20, 2, 0, vp(out), cap.MEM_HOST, C.byref(res)) == 0
+    exp, _ = orc.minimizers(words, L, 2, 2, 8, 20, 20, 0)
+    assert int(np.bitwise_xor.reduce(out[:, 0])) == int(np.bitwise_xor.reduce(exp[:, 0]))
+    # an ambiguous symbol inside a window is an EncodeError at its position
+    text = "ACGT" * 30 + "N" + "ACGT" * 30
+    words = naive.longseq_words(text, 4)
+    seq, keep = make_seq(km, words, len(text), 4)
+    rc = ctx.lib.kmers_minimizers(ctx.handle, C.byref(seq), 5, 4, 3, 2, 1, vp(out), cap.MEM_HOST, C.byref(res))
+    assert rc == cap.E_ENCODE and res.err_pos == 121 and res.err_enc == 0xF

@@ -172,3 +172,46 @@ def test_synth_generator_matches_numpy_model(orc):
             assert a == b or a == 15
             na += a == 15
     assert 0.03 < na / (4096 * 16) < 0.05
+
+
+def test_minimizers_definition(orc):
+    """mode 1 = the kmer with the smallest fx_hash among W consecutive kmers (leftmost on ties);
+    mode 0 = the reference's published example, checked against a literal Python transcription of
+    docs/src/replacements.md:33-51 built on the naive packers."""
+    rng = np.random.default_rng(31)
+    for K, W, stride in [(5, 9, 1), (8, 20, 20), (31, 10, 7), (33, 5, 3), (4, 1, 2)]:
+        for src in (2, 4):
+            L = 600
+            text = naive.random_text(rng, L)
+            seq = naive.longseq_words(text, src)
+            fw = naive.fw_kmers(text, K, 2)
+            hs = [naive.fx_hash(w) for w in fw]
+            n = (L - (K + W - 1)) // stride + 1
+            got1, res = orc.minimizers(seq, L, src, 2, K, W, stride, mode=1)
+            assert res.status == 0 and len(got1) == n
+            exp1 = []
+            for j in range(n):
+                i = j * stride
+                best = min(range(i, i + W), key=lambda t: (hs[t], t))
+                exp1.append(fw[best])
+            assert rows(got1) == exp1
+            got0, res = orc.minimizers(seq, L, src, 2, K, W, stride, mode=0)
+            exp0 = []
+            mask = (1 << (2 * K)) - 1
+            for j in range(n):
+                i = j * stride
+                v = int.from_bytes(b"", "big")
+                kmer = 0
+                for w in fw[i]:
+                    kmer = (kmer << 64) | w
+                nwords = len(fw[i])
+                split = lambda x: tuple((x >> (64 * (nwords - 1 - t))) & (2**64 - 1) for t in range(nwords))
+                h = naive.fx_hash(split(kmer))
+                for off in range(W - 1):
+                    code = naive.DNA2[text[i + K + off]]
+                    nk = ((kmer << 2) | code) & mask   # shifted into the CURRENT MINIMUM, as published
+                    nh = naive.fx_hash(split(nk))
+                    if nh < h:
+                        h, kmer = nh, nk
+                exp0.append(split(kmer))
+            assert rows(got0) == exp0
