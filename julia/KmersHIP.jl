@@ -175,6 +175,55 @@ function Base.collect(it::UnambiguousKmers{A, K, S}) where {A <: TwoBitAlphabet,
     end
 end
 
+# ---- fused consumers (nothing materialised per kmer) -------------------------------------------
+"""
+    sketch(fx_hash, CanonicalKmers{A,K}(seq), s)
+
+The bottom-`s` MinHash of `docs/src/minhash.md:31-35` in one fused GPU pass: the `s` smallest
+distinct `fx_hash` values of the canonical kmers, ascending.
+"""
+function sketch(::typeof(fx_hash), it::CanonicalKmers{A, K, S}, s::Integer; seed::UInt = zero(UInt)) where {A <: NucAlphabet24, K, S <: Source}
+    ctx, src = context(), it.it.seq
+    out = Vector{UInt64}(undef, s)
+    res = CResult()
+    GC.@preserve src out begin
+        rc = @ccall LIB.kmers_minhash(ctx.handle::Ptr{Cvoid}, Ref(cseq(src, A))::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
+                                      seed::UInt64, s::UInt64, pointer(out)::Ptr{UInt64}, MEM_HOST::Cint,
+                                      res::Ref{CResult})::Cint
+    end
+    check(ctx, rc, res, A, src)
+    return resize!(out, res.n_out)
+end
+
+"Kmer composition counts of `docs/src/composition.md:28-39`: `counts[as_integer(kmer) + 1]` over `FwKmers{A,K}(seq)`."
+function composition(it::FwKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: Source}
+    ctx, src = context(), it.seq
+    counts = Vector{UInt32}(undef, 4^K)
+    res = CResult()
+    GC.@preserve src counts begin
+        rc = @ccall LIB.kmers_composition(ctx.handle::Ptr{Cvoid}, Ref(cseq(src, A))::Ptr{CSeq}, K::Cint,
+                                          pointer(counts)::Ptr{UInt32}, MEM_HOST::Cint, res::Ref{CResult})::Cint
+    end
+    check(ctx, rc, res, A, src)
+    return counts
+end
+
+"Minimizers (`docs/src/replacements.md:33-51`): `mode = 0` is the published `unsafe_extract_minimizer` literally, `1` the true sliding-window minimum."
+function minimizers(it::FwKmers{A, K, S}, W::Integer; stride::Integer = 1, mode::Integer = 0) where {A <: NucAlphabet24, K, S <: Source}
+    ctx, src = context(), it.seq
+    span = K + W - 1
+    n = length(src) < span ? 0 : (length(src) - span) ÷ stride + 1
+    out = Vector{eltype(it)}(undef, n)
+    res = CResult()
+    GC.@preserve src out begin
+        rc = @ccall LIB.kmers_minimizers(ctx.handle::Ptr{Cvoid}, Ref(cseq(src, A))::Ptr{CSeq}, K::Cint, W::Cint, stride::Cint,
+                                         dst_bits(A)::Cint, mode::Cint, pointer(out)::Ptr{UInt64}, MEM_HOST::Cint,
+                                         res::Ref{CResult})::Cint
+    end
+    check(ctx, rc, res, A, src)
+    return out
+end
+
 # ---- element-wise functions on vectors of kmers ----------------------------------------------
 "fx_hash.(v, h) (src/kmer.jl:255-261)"
 function Kmers.fx_hash(v::Vector{Kmer{A, K, N}}, h::UInt = zero(UInt)) where {A, K, N}
