@@ -30,7 +30,6 @@ struct CompactArgs {
     unsigned long long *err_slot;  // SRC_BITS == 8: first invalid byte (0xff in the table) -> EncodeError
     uint64_t n_bases;         // SRC_BITS == 8: every byte below n_bases is inspected (UnambiguousKmers.jl:117-123)
     uint32_t tuples;          // 1: out_kmers receives Tuple{Kmer,Int} elements (N + 1 words each), out_starts unused
-    uint32_t stride_magic;    // ceil(2^32 / stride) for stride < 32768 (exact x % stride for x < 2^17), else 0
     uint32_t group;           // tiles staged together per workgroup iteration (count pass: > 1, emit pass: 1)
 };
 

@@ -353,8 +353,6 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.n_bases = seq->n_bases;
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
-    // exact for x < 2^17 when stride < 2^15: x * (magic * stride - 2^32) < 2^32
-    a.stride_magic = (stride > 1 && stride < 32768) ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)stride - 1) / (uint64_t)stride) : 0u;
     a.index_origin = seq->index_origin;
     // about 16 KiB of (kmer, start) output per workgroup, as for the stream kernel
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(8u * nw + 8u, BLOCK);
