@@ -160,7 +160,8 @@ def main():
                   "kmers_synth_dna")
         out_k = torch.empty(sh.n_kmers * N, dtype=torch.int64, device=dev)
         out_h = None if args.no_hash else torch.empty(sh.n_kmers, dtype=torch.int64, device=dev)
-    halo = HaloExchanger(buf, sh, plan)
+        halo = HaloExchanger(buf, sh, plan)  # its workspace is filled on this stream too
+    torch.cuda.synchronize()
     seq = cap.Seq(buf.data_ptr(), sh.n_bases, 0, sh.first_kmer, bits, 0)
     res = cap.Result()
     flags = cap.MEM_DEVICE | cap.ASYNC

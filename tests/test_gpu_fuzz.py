@@ -1,0 +1,152 @@
+"""Seeded fuzz of the C ABI against the oracle: random source kind (2-bit, 4-bit, ASCII), kmer
+alphabet (2-/4-bit), K, length, offset view (first_base), stride, ambiguity rate and entry point.
+Results must be bit-identical and EncodeErrors must carry the oracle's position and symbol."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import naive
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def km():
+    import kmers_jl_amd
+    return kmers_jl_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(km):
+    c = km.Context(0)
+    yield c
+    c.close()
+
+
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_source(rng, src, L, first, p_amb, rna):
+    """Returns (words for the ABI incl. `first` leading symbols, oracle words of the view, oracle src code)."""
+    total = first + L
+    text = naive.random_text(rng, total, p_amb=p_amb if src != 2 else 0.0)
+    if src == 8:
+        text = "".join(c.lower() if rng.random() < 0.3 else c for c in text)
+        if rna:
+            text = text.replace("T", "U").replace("t", "u")
+        return naive.ascii_words(text), naive.ascii_words(text[first:]), 8 + rna
+    return naive.longseq_words(text, src), naive.longseq_words(text[first:], src), src
+
+
+def same_error(rc, res, eres, first_origin=0):
+    if eres.status == 0:
+        return rc == 0
+    return rc == 1 and res.err_pos == eres.err_pos + first_origin and res.err_enc == eres.err_enc
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_iterators(km, ctx, orc, seed):
+    cap = km._capi
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(120):
+        src = int(rng.choice([2, 4, 8]))
+        dst = int(rng.choice([2, 4]))
+        kmax = 128 if dst == 2 else 64
+        K = int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 96, kmax]))
+        K = min(K, kmax)
+        L = int(rng.choice([0, K - 1, K, K + 1, 100, 777, 4096, 5003, 20000]))
+        L = max(L, 0)
+        first = int(rng.choice([0, 0, 1, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1000]))
+        p_amb = float(rng.choice([0.0, 0.0, 0.002, 0.05]))
+        rna = int(rng.integers(0, 2))
+        N = (K * dst + 63) // 64
+        words, view_words, osrc = make_source(rng, src, L, first, p_amb, rna)
+        seq = cap.Seq(words.ctypes.data, L, first, 0, src, rna)
+        res = cap.Result()
+        tag = (seed, case, src, dst, K, L, first, p_amb)
+        n = max(0, L - K + 1)
+        which = int(rng.integers(0, 4))
+        if which == 0:  # forward + reverse complement
+            fw = np.zeros((max(n, 1), N), np.uint64)
+            rv = np.zeros((max(n, 1), N), np.uint64)
+            rc = ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, dst, vp(fw), vp(rv), 0, C.byref(res))
+            efw, erv, eres = orc.fwrv(view_words, L, osrc, dst, K)
+            assert same_error(rc, res, eres), tag
+            if rc == 0:
+                assert np.array_equal(fw[:n], efw) and np.array_equal(rv[:n], erv), tag
+        elif which == 1:  # canonical + hash
+            ck = np.zeros((max(n, 1), N), np.uint64)
+            hs = np.zeros(max(n, 1), np.uint64)
+            hseed = int(rng.integers(0, 2**63))
+            rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, vp(ck), vp(hs), hseed, 0, C.byref(res))
+            ek, eh, eres = orc.canonical(view_words, L, osrc, dst, K, seed=hseed)
+            assert same_error(rc, res, eres), tag
+            if rc == 0:
+                assert np.array_equal(ck[:n], ek) and np.array_equal(hs[:n], eh), tag
+        elif which == 2:  # spaced (tile and gather paths)
+            J = int(rng.choice([1, 2, 3, 7, 16, 31, 32, 33, 70, 500]))
+            m = 0 if L < K else (L - K) // J + 1
+            out = np.zeros((max(m, 1), N), np.uint64)
+            rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, dst, vp(out), 0, C.byref(res))
+            ek, eres = orc.spaced(view_words, L, osrc, dst, K, J)
+            assert same_error(rc, res, eres), tag + (J,)
+            if rc == 0:
+                assert res.n_out == m and np.array_equal(out[:m], ek), tag + (J,)
+        else:  # unambiguous (2-bit kmers, K <= 64)
+            K2 = min(K, 64)
+            N2 = (2 * K2 + 63) // 64
+            rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K2, 1, None, None, 0, 0, C.byref(res))
+            ek, es, eres = orc.unambiguous(view_words, L, osrc, K2)
+            assert same_error(rc, res, eres), tag
+            if rc == 0:
+                m = int(res.n_out)
+                assert m == len(ek), tag
+                kmers = np.zeros((max(m, 1), N2), np.uint64)
+                starts = np.zeros(max(m, 1), np.int64)
+                rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K2, 1, vp(kmers), vp(starts), m, 0, C.byref(res))
+                assert rc == 0 and np.array_equal(kmers[:m], ek) and np.array_equal(starts[:m], es), tag
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_fuzz_fused_consumers(km, ctx, orc, seed):
+    cap = km._capi
+    rng = np.random.default_rng(2000 + seed)
+    for case in range(60):
+        src = int(rng.choice([2, 4, 8]))
+        K = int(rng.choice([1, 4, 5, 8, 11, 16, 21, 31, 32, 33, 63]))
+        L = int(rng.choice([K - 1, K, 300, 4099, 30000]))
+        L = max(L, 0)
+        first = int(rng.choice([0, 1, 16, 33, 64]))
+        words, view_words, osrc = make_source(rng, src, L, first, 0.0, 0)
+        seq = cap.Seq(words.ctypes.data, L, first, 0, src, 0)
+        res = cap.Result()
+        tag = (seed, case, src, K, L, first)
+        # XOR reduce
+        val = C.c_uint64()
+        assert ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, 2, 1, C.byref(val), 0, C.byref(res)) == 0
+        exp, _ = orc.reduce_xor_canonical(view_words, L, osrc, 2, K)
+        assert val.value == exp, tag
+        # MinHash
+        s = int(rng.choice([1, 10, 1000]))
+        out = np.zeros(s, np.uint64)
+        assert ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, 2, 3, s, vp(out), 0, C.byref(res)) == 0
+        _, eh, _ = orc.canonical(view_words, L, osrc, 2, K, seed=3)
+        e = np.unique(eh)[:s]
+        assert res.n_out == len(e) and np.array_equal(out[:len(e)], e), tag
+        # composition
+        if K <= 11:
+            counts = np.zeros(4 ** K, np.uint32)
+            assert ctx.lib.kmers_composition(ctx.handle, C.byref(seq), K, vp(counts), 0, C.byref(res)) == 0
+            fw, _ = orc.fw_kmers(view_words, L, osrc, 2, K)
+            assert np.array_equal(counts, np.bincount(fw[:, 0].astype(np.int64), minlength=4 ** K).astype(np.uint32)), tag
+        # minimizers
+        W, stride, mode = int(rng.choice([1, 2, 9, 20])), int(rng.choice([1, 3, 20, 50])), int(rng.integers(0, 2))
+        span = K + W - 1
+        m = 0 if L < span else (L - span) // stride + 1
+        N = (2 * K + 63) // 64
+        outm = np.zeros((max(m, 1), N), np.uint64)
+        assert ctx.lib.kmers_minimizers(ctx.handle, C.byref(seq), K, W, stride, 2, mode, vp(outm), 0, C.byref(res)) == 0, tag
+        em, _ = orc.minimizers(view_words, L, osrc, 2, K, W, stride, mode)
+        assert res.n_out == m == len(em) and np.array_equal(outm[:m], em), tag + (W, stride, mode)
