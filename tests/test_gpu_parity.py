@@ -647,3 +647,36 @@ def test_minimizers(km, ctx, orc):
     seq, keep = make_seq(km, words, len(text), 4)
     rc = ctx.lib.kmers_minimizers(ctx.handle, C.byref(seq), 5, 4, 3, 2, 1, vp(out), cap.MEM_HOST, C.byref(res))
     assert rc == cap.E_ENCODE and res.err_pos == 121 and res.err_enc == 0xF
+
+
+def test_async_device_calls_and_sync(km, ctx, orc):
+    """KMERS_MEM_DEVICE | KMERS_ASYNC enqueues and returns; kmers_sync() reports the first EncodeError
+    seen since the last sync (position + encoding), then the context is clean again."""
+    cap = km._capi
+    L, K = 300_000, 31
+    words = orc.synth_words(99, 0, (L * 4 + 63) // 64 + 1, 4).copy()
+    n = L - K + 1
+    dw, dk, dh = ctx.alloc(words.nbytes + 8), ctx.alloc(n * 8), ctx.alloc(n * 8)
+    ctx.h2d(dw, words)
+    seq = cap.Seq(dw, L, 0, 0, 4, 0)
+    res = cap.Result()
+    flags = cap.MEM_DEVICE | cap.ASYNC
+    for _ in range(3):
+        assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, dk, dh, 0, flags, C.byref(res)) == 0
+    rc, sres = ctx.sync()
+    assert rc == 0 and sres.status == 0
+    got = np.zeros(n, np.uint64)
+    ctx.d2h(got, dk)
+    ek, _, _ = orc.canonical(words, L, 4, 2, K)
+    assert np.array_equal(got, ek[:, 0])
+    # poison symbol 200001 (1-based) with a gap, run async, collect at sync
+    pos = 200_000
+    words[(pos * 4) >> 6] &= ~(np.uint64(0xF) << np.uint64((pos * 4) & 63))
+    ctx.h2d(dw, words)
+    assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, dk, dh, 0, flags, C.byref(res)) == 0
+    rc, sres = ctx.sync()
+    assert rc == cap.E_ENCODE and sres.err_pos == pos + 1 and sres.err_enc == 0
+    rc, sres = ctx.sync()
+    assert rc == 0
+    for p in (dw, dk, dh):
+        ctx.free(p)

@@ -54,6 +54,16 @@ __global__ __launch_bounds__(256) void fill_windows(ulonglong2* __restrict__ a, 
         if (i < n) { a[i] = make_ulonglong2(v + i, v ^ i); b[i] = make_ulonglong2(v * i, v - i); }
     }
 }
+// G: one chunk per workgroup, but workgroup b writes chunk (b % 8) * (nchunks / 8) + b / 8: with round-robin
+// dispatch every XCD then owns one contiguous eighth of each array (XCD-aware remap, T1 of the guide)
+__global__ __launch_bounds__(256) void fill_xcd(ulonglong2* __restrict__ a, ulonglong2* __restrict__ b, size_t n, unsigned long long v, int passes) {
+    size_t nchunks = gridDim.x, per = nchunks / 8;
+    size_t c = blockIdx.x < per * 8 ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
+    for (int p = 0; p < passes; ++p) {
+        size_t i = (c * passes + p) * 256 + threadIdx.x;
+        if (i < n) { a[i] = make_ulonglong2(v + i, v ^ i); b[i] = make_ulonglong2(v * i, v - i); }
+    }
+}
 template <class F> float timeit(F f, int reps = 9) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     f(); CK(hipDeviceSynchronize());
@@ -85,6 +95,14 @@ int main() {
         snprintf(l, 128, "E  %d passes/workgroup unthrottled", per_tile / 256); RUN(l, hipLaunchKernelGGL(fill_tiled<-1>, dim3(nt), dim3(256), 0, 0, a, b, n, 1ull, per_tile));
         snprintf(l, 128, "E  %d passes/workgroup vmcnt(0)", per_tile / 256);    RUN(l, hipLaunchKernelGGL(fill_tiled<0>, dim3(nt), dim3(256), 0, 0, a, b, n, 1ull, per_tile));
         snprintf(l, 128, "E  %d passes/workgroup vmcnt(2)", per_tile / 256);    RUN(l, hipLaunchKernelGGL(fill_tiled<2>, dim3(nt), dim3(256), 0, 0, a, b, n, 1ull, per_tile));
+    }
+    for (int passes : {1, 2, 4}) {
+        unsigned g = (unsigned)((n + 256ull * passes - 1) / (256ull * passes));
+        char l[128];
+        snprintf(l, 128, "G  XCD-contiguous remap, %d passes/workgroup", passes);
+        RUN(l, hipLaunchKernelGGL(fill_xcd, dim3(g), dim3(256), 0, 0, a, b, n, 1ull, passes));
+        snprintf(l, 128, "   (reference: plain order, %d passes/workgroup)", passes);
+        RUN(l, hipLaunchKernelGGL(fill_tiled<-1>, dim3(g), dim3(256), 0, 0, a, b, n, 1ull, 256 * passes));
     }
     for (int P : {1, 2, 3, 4, 8}) {
         unsigned g = (unsigned)((n + 256ull * P - 1) / (256ull * P));
