@@ -265,7 +265,8 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
         for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
             uint64_t f = stage_word<SRC_BITS, DST>(lds, wi, a.src[w0 + wi], lut);
             if constexpr ((SRC_BITS == 4 && DST == 2) || SRC_BITS == 8) {
-                if (f) report_bad_symbols<SRC_BITS, STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, k, w0 + wi, f);
+                // `span` symbols per element are read (K, or K + W - 1 for minimizer windows): gaps start after them
+                if (f) report_bad_symbols<SRC_BITS, STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, span, w0 + wi, f);
             }
         }
 #ifdef KMERS_STAMPS

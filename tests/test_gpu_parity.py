@@ -647,6 +647,24 @@ def test_minimizers(km, ctx, orc):
     seq, keep = make_seq(km, words, len(text), 4)
     rc = ctx.lib.kmers_minimizers(ctx.handle, C.byref(seq), 5, 4, 3, 2, 1, vp(out), cap.MEM_HOST, C.byref(res))
     assert rc == cap.E_ENCODE and res.err_pos == 121 and res.err_enc == 0xF
+    # K <= stride < K + W - 1: every symbol is still read by some window; stride >= K + W - 1: gaps are not
+    rng = np.random.default_rng(4)
+    for K, W, stride in [(8, 20, 20), (8, 20, 26), (8, 20, 27), (8, 20, 40), (3, 2, 5)]:
+        for _ in range(6):
+            L = 3000
+            t = list(naive.random_text(rng, L))
+            for p in rng.integers(0, L, size=2):
+                t[p] = "N"
+            words = naive.longseq_words("".join(t), 4)
+            seq, keep = make_seq(km, words, L, 4)
+            n = (L - (K + W - 1)) // stride + 1
+            o = np.zeros((n, 1), dtype=np.uint64)
+            rc = ctx.lib.kmers_minimizers(ctx.handle, C.byref(seq), K, W, stride, 2, 0, vp(o), cap.MEM_HOST, C.byref(res))
+            exp, eres = orc.minimizers(words, L, 4, 2, K, W, stride, 0)
+            if eres.status == 0:
+                assert rc == 0 and np.array_equal(o, exp)
+            else:
+                assert rc == cap.E_ENCODE and (res.err_pos, res.err_enc) == (eres.err_pos, eres.err_enc), (K, W, stride)
 
 
 def test_async_device_calls_and_sync(km, ctx, orc):
