@@ -147,6 +147,22 @@ __device__ __forceinline__ void window(const uint64_t *lds, uint32_t bit, uint32
     for (int i = 1; i < N; ++i) fw[i] = (R[i] >> sh) | ((R[i - 1] << 1) << (63u - sh));
 }
 
+// One-word kmers, two per lane: the window of kmer r and the symbol that follows it (which turns it
+// into kmer r+1) both sit inside the same 128 stream bits, so one LDS read pair serves both.
+template <int DST>
+__device__ __forceinline__ void window1_and_next(const uint64_t *lds, uint32_t bit, uint32_t k, uint64_t mask,
+                                                 uint64_t &fw, uint64_t &rc, uint64_t &next_sym) {
+    const uint32_t q = bit >> 6, s = bit & 63u;
+    const uint64_t lo = lds[q], hi = lds[q + 1];
+    const uint64_t W0 = funnel64(lo, hi, s);                              // stream bits [s, s+64)
+    const uint64_t W1 = (W0 >> DST) | ((hi >> s) << (64 - DST));          // stream bits [s+DST, s+DST+64)
+    const uint64_t W = W0 & mask;
+    rc = comp_symbols<DST>(W);
+    if constexpr (DST == 2) rc &= mask;
+    fw = rev_symbols<DST>(W) >> (64u - (uint32_t)DST * k);
+    next_sym = (W1 >> ((uint32_t)DST * (k - 1u))) & ((1u << DST) - 1u);  // last symbol of the next window
+}
+
 template <int N>
 __device__ __forceinline__ bool kmer_less(const uint64_t (&x)[N], const uint64_t (&y)[N]) {
     // cmp(x.data, y.data) == -1: lexicographic, head word first (kmer.jl:176-178)
@@ -281,18 +297,19 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
         for (uint32_t r = tid * KPL; r < mt; r += BLOCK * KPL) {
             const uint64_t g = m0 + r;
             uint64_t fw[KPL][N], rc[KPL][N];
-            window<N, DST>(lds, (uint32_t)DST * (r * J + b0), k, mask, fw[0], rc[0]);
             if constexpr (KPL == 2) {
                 // next window: one symbol further.  fw shifts left, rc shifts right with the
                 // complemented symbol on top (the reference's own rolling step,
                 // CanonicalKmers.jl:102-103, :115-118).
-                const uint32_t bit = (uint32_t)DST * (r + b0 + k);
-                const uint64_t sym = (lds[bit >> 6] >> (bit & 63u)) & ((1u << DST) - 1u);
+                uint64_t sym;
+                window1_and_next<DST>(lds, (uint32_t)DST * (r + b0), k, mask, fw[0][0], rc[0][0], sym);
                 uint64_t csym;
                 if constexpr (DST == 2) csym = sym ^ 3u;
                 else csym = ((sym & 1u) << 3) | ((sym & 2u) << 1) | ((sym & 4u) >> 1) | ((sym & 8u) >> 3);
                 fw[1][0] = ((fw[0][0] << DST) | sym) & mask;
                 rc[1][0] = (rc[0][0] >> DST) | (csym << ((uint32_t)DST * (k - 1u)));
+            } else {
+                window<N, DST>(lds, (uint32_t)DST * (r * J + b0), k, mask, fw[0], rc[0]);
             }
             const bool both = (KPL == 2) && (r + 1 < mt);
 
