@@ -65,7 +65,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB
+    # KMERS_HIP_LIB selects another build of the SAME library (tuning variants, diagnostic builds)
+    return os.environ.get("KMERS_HIP_LIB") or _build.LIB
 
 
 def load():

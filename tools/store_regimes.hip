@@ -64,6 +64,23 @@ __global__ __launch_bounds__(256) void fill_xcd(ulonglong2* __restrict__ a, ulon
         if (i < n) { a[i] = make_ulonglong2(v + i, v ^ i); b[i] = make_ulonglong2(v * i, v - i); }
     }
 }
+// H: each lane writes 32 contiguous bytes per array as two 16-byte stores (lane stride 32 B): the
+// shape of a "4 kmers per lane" design; one workgroup covers 8 KiB per array in a single pass
+__global__ __launch_bounds__(256) void fill_wide(ulonglong2* __restrict__ a, ulonglong2* __restrict__ b, size_t n, unsigned long long v) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i + 1 < n) {
+        a[i] = make_ulonglong2(v + i, v ^ i); a[i + 1] = make_ulonglong2(v - i, v * i);
+        b[i] = make_ulonglong2(v * i, v - i); b[i + 1] = make_ulonglong2(v ^ i, v + i);
+    }
+}
+// I: like H but 64 contiguous bytes per lane (four 16-byte stores per array)
+__global__ __launch_bounds__(256) void fill_wide4(ulonglong2* __restrict__ a, ulonglong2* __restrict__ b, size_t n, unsigned long long v) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[i + j] = make_ulonglong2(v + i + j, v ^ i); b[i + j] = make_ulonglong2(v * i, v - i - j); }
+    }
+}
 template <class F> float timeit(F f, int reps = 9) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     f(); CK(hipDeviceSynchronize());
@@ -95,6 +112,12 @@ int main() {
         snprintf(l, 128, "E  %d passes/workgroup unthrottled", per_tile / 256); RUN(l, hipLaunchKernelGGL(fill_tiled<-1>, dim3(nt), dim3(256), 0, 0, a, b, n, 1ull, per_tile));
         snprintf(l, 128, "E  %d passes/workgroup vmcnt(0)", per_tile / 256);    RUN(l, hipLaunchKernelGGL(fill_tiled<0>, dim3(nt), dim3(256), 0, 0, a, b, n, 1ull, per_tile));
         snprintf(l, 128, "E  %d passes/workgroup vmcnt(2)", per_tile / 256);    RUN(l, hipLaunchKernelGGL(fill_tiled<2>, dim3(nt), dim3(256), 0, 0, a, b, n, 1ull, per_tile));
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        RUN("H  32 contiguous bytes per lane (2 x 16 B), 1 pass", hipLaunchKernelGGL(fill_wide, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, 0, a, b, n, 1ull));
+        RUN("I  64 contiguous bytes per lane (4 x 16 B), 1 pass", hipLaunchKernelGGL(fill_wide4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, 0, a, b, n, 1ull));
+        RUN("   (reference: 2 passes/workgroup, 16 B per lane per pass)", hipLaunchKernelGGL(fill_tiled<-1>, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, a, b, n, 1ull, 512));
+        RUN("   (reference: 1 pass/workgroup)", hipLaunchKernelGGL(fill_tiled<-1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a, b, n, 1ull, 256));
     }
     for (int passes : {1, 2, 4}) {
         unsigned g = (unsigned)((n + 256ull * passes - 1) / (256ull * passes));
