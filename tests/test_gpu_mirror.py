@@ -246,3 +246,24 @@ def test_fused_consumers(km, orc):
     comp = km.composition(km.FwDNAMers[4](seq))
     fw, _ = orc.fw_kmers(words, L, 4, 2, 4)
     assert np.array_equal(comp, np.bincount(fw[:, 0].astype(np.int64), minlength=256).astype(np.uint32))
+
+
+def test_plain_c_client(km, orc, tmp_path):
+    """examples/canonical_hashes.c: the C ABI from plain C, checked against the oracle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "kmers.jl_amd", "csrc")
+    exe = tmp_path / "canonical_hashes"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "canonical_hashes.c"),
+                    "-L", csrc, "-lkmers_hip", f"-Wl,-rpath,{csrc}", "-o", str(exe)], check=True)
+    text = "TTGCTAGGGATTCGAGGATCCTCTAGAGCGCGGCACGATCTTAGCACTTGCTAGGGATTCGAGGATC"
+    out = subprocess.run([str(exe), text], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    ek, eh, _ = orc.canonical(naive.ascii_words(text), len(text), 8, 2, 31)
+    assert f"{len(ek)} canonical 31-mers" in out.stdout
+    assert f"kmer[0] = 0x{int(ek[0, 0]):016x}  fx_hash = 0x{int(eh[0]):016x}" in out.stdout
+    sk = " ".join(f"{int(h):016x}" for h in np.unique(eh)[:8])
+    assert sk in out.stdout
+    bad = subprocess.run([str(exe), "ACGT" * 10 + "P" + "ACGT" * 10], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "cannot encode 0x50 (Char 'P') at position 41" in bad.stdout
