@@ -96,6 +96,69 @@ def cpu_baseline(k, bits, seed, total_bases, budget_s=12.0, chunk_bases=1 << 24)
     return one
 
 
+def other_configs(ctx, cap, stream, dev, reps=5):
+    """Kernel rates of the other BASELINE.json configs (parity-test cases, not the headline): C3 shape
+    per GPU, C4, C5 strict and skip.  Resident data, HIP events on the library's stream, median of reps."""
+    res = cap.Result()
+    out = {}
+
+    def timed(fn):
+        fn()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts))
+
+    def synth(seed, n_bases, bits, amb=0):
+        nw = (n_bases * bits + 63) // 64
+        b = torch.empty(nw + 2, dtype=torch.int64, device=dev)
+        ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, 0, nw, bits, amb, b.data_ptr()), "kmers_synth_dna")
+        return b
+
+    def entry(name, ms, n_bases, alg_bytes):
+        out[name] = {"kernel_ms": round(ms, 4), "Gbases_per_s": round(n_bases / ms / 1e6, 1),
+                     "GB_per_s": round(alg_bytes / ms / 1e6, 1), "frac_of_8TBps": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+
+    golden = 0x9E3779B97F4A7C15
+    with torch.cuda.stream(stream):
+        # C3: CanonicalDNAMers{31} over 10 Gbase LongDNA{2} sharded 8 ways -> 1.25 Gbase per GPU, kmers only
+        L, K = 1_250_000_000, 31
+        buf = synth(golden ^ 3, L, 2)
+        a = torch.empty(L, dtype=torch.int64, device=dev)
+        seq = cap.Seq(buf.data_ptr(), L, 0, 0, 2, 0)
+        ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), None, 0, cap.MEM_DEVICE, C.byref(res)))
+        entry("C3 CanonicalDNAMers{31}, 1.25 Gbase LongDNA{2} (one of 8 shards), 8.25 B/kmer", ms, L, 8.25 * (L - K + 1))
+        # C4: FwDNAMers{63} + reverse_complement over 1 Gbase LongDNA{4}
+        L, K = 1_000_000_000, 63
+        buf = synth(golden ^ 4, L, 4)
+        a = torch.empty(2 * L, dtype=torch.int64, device=dev)
+        b = torch.empty(2 * L, dtype=torch.int64, device=dev)
+        seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
+        ms = timed(lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), b.data_ptr(), cap.MEM_DEVICE, C.byref(res)))
+        entry("C4 FwDNAMers{63} + reverse_complement, 1 Gbase LongDNA{4}, 32.5 B/kmer", ms, L, 32.5 * (L - K + 1))
+        del b
+        # C5: SpacedDNAMers{21,3} over 1 Gbase LongDNA{4}: strict, and the skip variant with N at p = 0.04
+        K, J = 21, 3
+        n = (L - K) // J + 1
+        buf = synth(golden ^ 5, L, 4)
+        seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
+        ms = timed(lambda: ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, 2, a.data_ptr(), cap.MEM_DEVICE, C.byref(res)))
+        entry("C5 SpacedDNAMers{21,3} strict, 1 Gbase LongDNA{4}, 9.5 B/kmer", ms, L, 0.5 * L + 8.0 * n)
+        amb = synth(golden ^ 5, L, 4, 2621)
+        seqa = cap.Seq(amb.data_ptr(), L, 0, 0, 4, 0)
+        ctx.check(ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seqa), K, J, None, None, 0, cap.MEM_DEVICE, C.byref(res)), "count")
+        m = int(res.n_out)
+        st = torch.empty(m, dtype=torch.int64, device=dev)
+        ms = timed(lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seqa), K, J, a.data_ptr(), st.data_ptr(), m, cap.MEM_DEVICE, C.byref(res)))
+        entry(f"C5 skip variant (UnambiguousDNAMers{{21}} on the stride-3 lattice, p(N)=0.04, {m} kept), count+scan+emit", ms, L, 1.0 * L + 16.0 * m)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +171,7 @@ def main():
     ap.add_argument("--max-grid", type=int, default=0)
     ap.add_argument("--no-hash", action="store_true", help="materialise canonical kmers only (8.5 / 8.25 B per kmer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the extra C3/C4/C5 rates (N = 1 only)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -274,6 +338,13 @@ def main():
                          "bytes_per_kmer": bytes_per_kmer, "kmers_per_launch": n_kmers_rank},
             "verified": verified,
         }
+        if world == 1 and not args.no_other_configs:
+            try:  # informative extras; never allowed to break the headline line
+                del out_k, out_h, buf
+                torch.cuda.empty_cache()
+                line["other_configs"] = other_configs(ctx, cap, stream, dev)
+            except Exception as e:
+                line["other_configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, bits, seed, args.bases, args.cpu_budget)
         print(json.dumps(line), flush=True)
