@@ -95,6 +95,7 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 #define KMERS_PARAM_TILE_KMERS 1 /* kmers per workgroup tile (multiple of 512) */
 #define KMERS_PARAM_MAX_GRID 2   /* cap on workgroups per launch (persistent grid-stride above it) */
 #define KMERS_PARAM_STAMPS_PTR 3 /* diagnostic builds (-DKMERS_STAMPS) only: device buffer for in-kernel stamps */
+#define KMERS_PARAM_SKETCH_HOST_ONLY 4 /* kmers_minhash: 1 = use the host-feedback path even for small sketches (tests) */
 int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
 
 /* device memory for hosts without their own HIP binding */

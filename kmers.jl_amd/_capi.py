@@ -12,7 +12,7 @@ from . import build as _build
 OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY = range(7)
 MEM_HOST, MEM_DEVICE, ASYNC, OUT_TUPLES = 0, 1, 2, 4
 OP_REVERSE, OP_COMPLEMENT, OP_REVCOMP, OP_CANONICAL, OP_ISCANONICAL, OP_TO_LONGSEQ, OP_COUNT_GC = range(7)
-PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR = 1, 2, 3
+PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY = 1, 2, 3, 4
 
 STATUS_NAMES = {OK: "KMERS_OK", E_ENCODE: "KMERS_E_ENCODE", E_BADARG: "KMERS_E_BADARG",
                 E_HIP: "KMERS_E_HIP", E_NOMEM: "KMERS_E_NOMEM",

@@ -184,6 +184,73 @@ __global__ __launch_bounds__(256) void transform_kernel(int op, const uint64_t *
     }
 }
 
+// ---- MinHash sketch maintenance, entirely on the device ------------------------------------------
+// state[0] = number of values in best[], state[1] = threshold (values strictly below it are
+// candidates), state[2] = overflow flag (a chunk produced more candidates than the buffer holds),
+// state[3] = candidate counter.  One workgroup: merge best[] with the new candidates, bitonic-sort
+// ascending in LDS, drop duplicates, keep the s smallest, publish the new threshold, reset the counter.
+constexpr uint32_t SKETCH_LDS_VALUES = 16384;  // 128 KiB of dynamic LDS
+__global__ __launch_bounds__(1024) void sketch_prune_kernel(uint64_t *__restrict__ best, uint64_t *__restrict__ state,
+                                                             const uint64_t *__restrict__ cand, uint64_t cap, uint32_t s) {
+    extern __shared__ uint64_t v[];            // SKETCH_LDS_VALUES values
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t t = threadIdx.x;
+    const uint32_t nb = (uint32_t)state[0];
+    uint64_t cnt = state[3];
+    if (cnt > cap) {
+        if (t == 0) state[2] = 1;              // overflow: the host falls back to the feedback path
+        cnt = cap;
+    }
+    const uint32_t total = nb + (uint32_t)cnt;
+    uint32_t m = 1;
+    while (m < total) m <<= 1;                 // power of two >= total (<= SKETCH_LDS_VALUES by construction)
+    for (uint32_t i = t; i < m; i += 1024) v[i] = i < nb ? best[i] : (i < total ? cand[i - nb] : ~0ull);
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= m; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = t; i < m; i += 1024) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint64_t a0 = v[i], a1 = v[l];
+                    const bool up = (i & k2) == 0;
+                    if ((a0 > a1) == up) { v[i] = a1; v[l] = a0; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // distinct values among the first `total` (the padding sorts behind them)
+    const uint32_t per = (m + 1023) / 1024;    // consecutive values per thread
+    const uint32_t lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
+    uint32_t mine = 0;
+    for (uint32_t i = lo; i < hi; ++i) mine += (i == 0 || v[i] != v[i - 1]) ? 1u : 0u;
+    uint32_t incl = mine;
+    const uint32_t lane = t & 63u, wave = t >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t x = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += x;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
+    uint32_t pos = before + incl - mine;
+    uint32_t distinct = 0;
+    for (uint32_t w = 0; w < 16; ++w) distinct += wave_tot[w];
+    for (uint32_t i = lo; i < hi; ++i) {
+        if (i == 0 || v[i] != v[i - 1]) {
+            if (pos < s) best[pos] = v[i];
+            if (pos + 1 == s) state[1] = v[i];  // the s-th smallest distinct value is the new threshold
+            ++pos;
+        }
+    }
+    if (t == 0) {
+        state[0] = distinct < s ? distinct : s;
+        state[3] = 0;
+        if (distinct < s) state[1] = ~0ull;     // fewer than s values so far: everything is still a candidate
+    }
+}
+
 // ---- sum `replicas` copies of a uint32 histogram into out (composition, mid-size K) ----------
 __global__ __launch_bounds__(256) void reduce_replicas_kernel(const uint32_t *__restrict__ rep, uint32_t replicas,
                                                                size_t bins, uint32_t *__restrict__ out) {

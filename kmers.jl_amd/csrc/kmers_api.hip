@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -37,6 +38,7 @@ struct kmers_ctx {
     int64_t tile_kmers = 0;  // 0 = default
     int64_t max_grid = 0;    // 0 = default
     int64_t stamps_ptr = 0;  // diagnostic builds only (KMERS_PARAM_STAMPS_PTR)
+    bool sketch_host_only = false;  // KMERS_PARAM_SKETCH_HOST_ONLY: force the host-feedback MinHash path (tests)
 };
 
 namespace {
@@ -531,6 +533,7 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value) {
     if (param == KMERS_PARAM_TILE_KMERS) ctx->tile_kmers = value;
     else if (param == KMERS_PARAM_MAX_GRID) ctx->max_grid = value;
     else if (param == KMERS_PARAM_STAMPS_PTR) ctx->stamps_ptr = value;
+    else if (param == KMERS_PARAM_SKETCH_HOST_ONLY) ctx->sketch_host_only = value != 0;
     else return fail(ctx, KMERS_E_BADARG, "unknown parameter");
     return KMERS_OK;
 }
@@ -642,6 +645,67 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
     Staged st;
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
     remember_source(ctx, seq, st);
+
+    // ---- device-resident path (s <= 4096): the threshold and the running bottom-s set stay in HBM, a
+    // one-workgroup bitonic sort/unique kernel prunes between chunks, every round is enqueued without a
+    // host round trip.  Chunk r+1 is `ratio` times everything before it, which yields about ratio*s
+    // candidates (half the buffer); an adversarial order can overflow it -> flag -> feedback path below.
+    if (s <= 4096 && !ctx->sketch_host_only) {
+        const uint64_t dcap = SKETCH_LDS_VALUES - 4096;                 // candidates per round
+        // new candidates in a chunk of ratio*done kmers ~ ratio * Gamma(s): keep the buffer at mean + a wide
+        // margin (relative spread 1/sqrt(s); s = 1 needs ~18x for a 1e-8 overflow probability)
+        const double margin = 2.0 + 16.0 / std::sqrt((double)s);
+        const uint64_t ratio = std::max<uint64_t>(1, (uint64_t)((double)dcap / ((double)s * margin)));
+        if (int rc = ensure_stage(ctx, 3, (size_t)(dcap + 4096 + 8) * 8)) return rc;
+        uint64_t *d_cand = static_cast<uint64_t *>(ctx->stage[3]);
+        uint64_t *d_best = d_cand + dcap;
+        uint64_t *d_state = d_best + 4096;                              // [n_best, threshold, overflow, counter]
+        const uint64_t init_state[4] = {0, ~0ull, 0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(d_state, init_state, sizeof init_state, hipMemcpyHostToDevice, ctx->stream));
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_prune_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, SKETCH_LDS_VALUES * 8));
+            attr_set = true;
+        }
+        uint64_t done = 0, chunk = std::min<uint64_t>(n, dcap);         // first chunk: everything is a candidate
+        while (done < n) {
+            const uint64_t m = std::min<uint64_t>(chunk, n - done);
+            kmers_seq view = *seq;
+            Staged vst = st;
+            vst.first_bit = st.first_bit + done * (uint64_t)seq->src_bits;
+            view.n_bases = m + (uint64_t)k - 1;
+            StreamArgs a{};
+            a.out_a = d_cand;
+            a.out_b = d_state + 3;
+            a.seed = seed;
+            a.threshold_ptr = d_state + 1;
+            a.capacity = dcap;
+            if (int rc = launch_fused<MODE_SKETCH>(ctx, &view, vst, k, dst_bits, a)) return rc;
+            hipLaunchKernelGGL(sketch_prune_kernel, dim3(1), dim3(1024), SKETCH_LDS_VALUES * 8, ctx->stream, d_best, d_state,
+                               d_cand, dcap, (uint32_t)s);
+            HIP_TRY(ctx, hipGetLastError());
+            done += m;
+            chunk = std::max<uint64_t>(dcap / 2, ratio * done);
+        }
+        uint64_t h_state[4];
+        HIP_TRY(ctx, hipMemcpyAsync(h_state, d_state, sizeof h_state, hipMemcpyDeviceToHost, ctx->stream));
+        // an EncodeError anywhere in the sequence: report the first one (positions are relative to a chunk,
+        // so re-run the feedback path, which attributes it exactly)
+        unsigned long long epos = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&epos, ctx->d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (epos == NO_ERROR_POS && h_state[2] == 0) {
+            const uint64_t nb = h_state[0];
+            if (nb) HIP_TRY(ctx, hipMemcpy(out_hashes, d_best, nb * 8, hipMemcpyDeviceToHost));
+            if (res) { res->status = KMERS_OK; res->n_out = nb; }
+            return KMERS_OK;
+        }
+        if (epos != NO_ERROR_POS) {  // re-arm the slot; the feedback path below finds and reports the error
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
 
     // Candidate buffer in HBM; the host keeps the running bottom-s set (a few thousand values).
     const uint64_t cap = std::max<uint64_t>((uint64_t)1 << 16, 8 * s);

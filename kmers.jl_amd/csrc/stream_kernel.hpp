@@ -43,11 +43,13 @@ struct StreamArgs {
     uint32_t xor_canonical;  // MODE_XOR: 1 = canonical kmers, 0 = forward kmers
     uint64_t *stamps;        // diagnostic builds (-DKMERS_STAMPS) only: per-workgroup s_memrealtime stamps
     const uint8_t *ascii_lut; // SRC_BITS == 8: 256-entry byte -> symbol table (ascii_tables.hpp)
-    // MODE_SKETCH: hashes below `threshold` are appended to out_a[0..capacity) through the counter out_b[0]
+    // MODE_SKETCH: hashes below the threshold (threshold_ptr[0] when non-NULL, else `threshold`) are appended
+    //              to out_a[0..capacity) through the counter out_b[0]
     // MODE_COUNT : out_a = uint32 counts[replicas][4^K] indexed by as_integer(forward kmer);
     //              capacity = bins that fit the dynamic LDS histogram (0 = none), threshold = replicas
     uint64_t threshold;
     uint64_t capacity;
+    const uint64_t *threshold_ptr;  // MODE_SKETCH, device-resident sketch: the running threshold in HBM
     // MODE_MINIMIZER: window = `window_kmers` consecutive kmers per element, elements `stride` apart;
     //                 minimizer_mode 0 = the reference's published example, 1 = true sliding-window minimum
     uint32_t window_kmers;
@@ -251,6 +253,10 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     // LDS, flushed once at the end (K <= 6); else global counters, one replica per XCD for mid-size
     // K (threshold = replicas; workgroups b and b+8 share an XCD and its L2 -- speed only).
     extern __shared__ uint32_t lds_hist[];
+    uint64_t sketch_threshold = a.threshold;
+    if constexpr (MODE == MODE_SKETCH) {
+        if (a.threshold_ptr) sketch_threshold = *a.threshold_ptr;  // uniform; constant for the whole launch
+    }
     uint32_t *count_base = nullptr;
     if constexpr (MODE == MODE_COUNT) {
         const uint32_t bins = 1u << (2u * k);
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
                     for (uint32_t e = 0; e < KPL; ++e) {
                         if (e == 0 || both) {
                             const uint64_t h = fx_hash<N>(c[e], a.seed);
-                            if (h < a.threshold) {
+                            if (h < sketch_threshold) {
                                 unsigned long long pos = atomicAdd(reinterpret_cast<unsigned long long *>(a.out_b), 1ull);
                                 if (pos < a.capacity) a.out_a[pos] = h;
                             }

@@ -531,6 +531,32 @@ def test_minhash_sketch(km, ctx, orc):
                 _, eh, _ = orc.canonical(words, L, bits, 2, K, seed=7)
                 exp = np.unique(eh)[:s]
                 assert res.n_out == len(exp) and np.array_equal(out[:len(exp)], exp), (bits, K, L, s)
+    # the host-feedback path (used for s > 4096, and as the overflow fallback) gives the same sketch
+    L, K = 1_000_000, 21
+    words = orc.synth_words(77, 0, (L * 4 + 63) // 64 + 1, 4)
+    seq, keep = make_seq(km, words, L, 4)
+    _, eh, _ = orc.canonical(words, L, 4, 2, K, seed=1)
+    for s in (1, 2, 3, 100, 4096):
+        outs = []
+        for host_only in (0, 1):
+            ctx.set_param(cap.PARAM_SKETCH_HOST_ONLY, host_only)
+            out = np.zeros(s, dtype=np.uint64)
+            res = cap.Result()
+            assert ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, 2, 1, s, vp(out), cap.MEM_HOST, C.byref(res)) == 0
+            outs.append(out[:res.n_out].copy())
+        ctx.set_param(cap.PARAM_SKETCH_HOST_ONLY, 0)
+        exp = np.unique(eh)[:s]
+        assert np.array_equal(outs[0], exp) and np.array_equal(outs[1], exp), s
+    # adversarial order for the device path: hashes that keep decreasing overflow its buffer -> fallback
+    text = "".join("ACGT"[(i >> (2 * j)) & 3] for i in range(70000, 0, -1) for j in range(7, -1, -1))
+    words = naive.longseq_words(text, 2)
+    seq, keep = make_seq(km, words, len(text), 2)
+    out = np.zeros(1000, dtype=np.uint64)
+    res = cap.Result()
+    assert ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), 8, 2, 0, 1000, vp(out), cap.MEM_HOST, C.byref(res)) == 0
+    _, eh, _ = orc.canonical(words, len(text), 2, 2, 8)
+    exp = np.unique(eh)[:1000]
+    assert res.n_out == len(exp) and np.array_equal(out[:len(exp)], exp)
     # low-complexity input: few distinct kmers, many duplicates
     text = "ACGTTGCA" * 50_000
     words = naive.longseq_words(text, 4)
