@@ -178,8 +178,35 @@ int kmers_fx_hash(kmers_ctx *ctx, const uint64_t *kmers, int n_words, uint64_t n
 #define KMERS_OP_ISCANONICAL 4 /* transformations.jl:41 ; out = one uint64 0/1 per kmer */
 #define KMERS_OP_TO_LONGSEQ 5  /* LongSequence{A}(kmer).data, construction.jl:289-324; out = N words per kmer */
 #define KMERS_OP_COUNT_GC 6    /* count(isGC, kmer), counting.jl:1-8 (2-bit); out = one uint64 per kmer */
+#define KMERS_OP_AS_INTEGER 7   /* as_integer, kmer.jl:305-326: u64 (<= 64 coding bits) or little-endian u128 per kmer */
+#define KMERS_OP_FROM_INTEGER 8 /* from_integer, kmer.jl:361-384: the inverse; only the lowest K*bits bits are used */
 int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bits, uint64_t n,
                     uint64_t *out, int flags);
+
+/* ---- sharding one long sequence over the GPUs of a node ------- */
+/* The reference has no distributed code; kmer i depends only on symbols [i*stride, i*stride + k),
+ * so shard g owns a contiguous range of kmers (in iteration order) whose first symbol sits on a
+ * source-word boundary and on the stride lattice, and needs the first halo_words words of shard
+ * g+1 appended to its own words: one neighbour step, the only communication on the path.
+ * Outputs stay with the shard (concatenation in shard order == the reference's iteration order).
+ * Run a shard with kmers_seq{words = own words + halo, n_bases, first_base = 0,
+ * index_origin = first_base}; UnambiguousKmers shards additionally exchange their element
+ * counts (exclusive scan) to place outputs, and the first EncodeError is the minimum err_pos
+ * over shards. */
+typedef struct {
+    uint64_t first_kmer;  /* global 0-based ordinal of the first kmer owned */
+    uint64_t n_kmers;     /* kmers owned */
+    uint64_t first_base;  /* global 0-based symbol index of the view (= first_kmer * stride; word aligned) */
+    uint64_t n_bases;     /* symbols in the view: (n_kmers - 1) * stride + k, 0 if the shard is empty */
+    uint64_t first_word;  /* global index of the first source word owned */
+    uint64_t n_own_words; /* source words owned (the last shard keeps the tail) */
+    uint32_t halo_words;  /* words to receive from shard g+1 */
+    uint32_t send_words;  /* words to send to shard g-1 (its halo_words) */
+} kmers_shard;
+/* Pure host arithmetic (no context, no GPU).  src_bits 2, 4 or 8.  Sequences too short to give
+ * every shard a halo's worth of words are handled whole by shard 0 (the rest are empty). */
+int kmers_shard_plan(uint64_t n_bases, int k, uint64_t stride, int src_bits, int n_shards, int shard_id,
+                     kmers_shard *out);
 
 /* ---- synthetic input (bench / tests) -------------------------- */
 /* Fills out_dev (DEVICE memory) with words [first_word, first_word + n_words) of the

@@ -253,6 +253,47 @@ for (op, fn) in ((0, :reverse), (1, :complement), (2, :reverse_complement), (3, 
     end
 end
 
+"as_integer.(v) (src/kmer.jl:305-326) for kmers of up to 128 coding bits: Vector{UInt64} or Vector{UInt128}"
+function Kmers.as_integer(v::Vector{Kmer{A, K, N}}) where {A <: NucleicAcidAlphabet, K, N}
+    N <= 2 || throw(ArgumentError("Must have at most 128 bits in encoding"))
+    ctx = context()
+    out = Vector{N == 1 ? UInt64 : UInt128}(undef, length(v))   # little-endian u128 == two UInt64 (low, high)
+    bits = BioSequences.bits_per_symbol(A())
+    GC.@preserve v out begin
+        rc = @ccall LIB.kmers_transform(ctx.handle::Ptr{Cvoid}, 7::Cint, pointer(v)::Ptr{UInt64}, K::Cint, bits::Cint,
+                                        length(v)::UInt64, pointer(out)::Ptr{UInt64}, MEM_HOST::Cint)::Cint
+    end
+    rc == OK || error("kmers_transform: status $rc: $(last_error(ctx))")
+    return out
+end
+
+# ---- sharding one long sequence over several GPUs / processes ---------------------------------
+struct CShard
+    first_kmer::UInt64
+    n_kmers::UInt64
+    first_base::UInt64
+    n_bases::UInt64
+    first_word::UInt64
+    n_own_words::UInt64
+    halo_words::UInt32
+    send_words::UInt32
+end
+
+"""
+    shard_plan(seq_length, K, n_shards, shard_id; stride = 1, src_bits = 4)
+
+The contiguous, word- and stride-aligned range of kmers shard `shard_id` (0-based) owns, and the
+number of words it needs from its right neighbour (`kmers_shard_plan`, include/kmers_hip.h).
+Run the shard with `CSeq(pointer(own_words_plus_halo), n_bases, 0, first_base, ...)`.
+"""
+function shard_plan(len::Integer, K::Integer, n_shards::Integer, shard_id::Integer; stride::Integer = 1, src_bits::Integer = 4)
+    out = Ref{CShard}()
+    rc = @ccall LIB.kmers_shard_plan(len::UInt64, K::Cint, stride::UInt64, src_bits::Cint, n_shards::Cint,
+                                     shard_id::Cint, out::Ptr{CShard})::Cint
+    rc == OK || error("kmers_shard_plan: bad arguments")
+    return out[]
+end
+
 # ---- chunk-buffered iterate(): `for kmer in gpu(it)` -----------------------------------------
 """
     gpu(it; chunk = 1 << 24)

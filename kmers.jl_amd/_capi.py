@@ -11,7 +11,8 @@ from . import build as _build
 
 OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY = range(7)
 MEM_HOST, MEM_DEVICE, ASYNC, OUT_TUPLES = 0, 1, 2, 4
-OP_REVERSE, OP_COMPLEMENT, OP_REVCOMP, OP_CANONICAL, OP_ISCANONICAL, OP_TO_LONGSEQ, OP_COUNT_GC = range(7)
+(OP_REVERSE, OP_COMPLEMENT, OP_REVCOMP, OP_CANONICAL, OP_ISCANONICAL, OP_TO_LONGSEQ, OP_COUNT_GC, OP_AS_INTEGER,
+ OP_FROM_INTEGER) = range(9)
 PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY = 1, 2, 3, 4
 
 STATUS_NAMES = {OK: "KMERS_OK", E_ENCODE: "KMERS_E_ENCODE", E_BADARG: "KMERS_E_BADARG",
@@ -58,6 +59,7 @@ SYMBOLS = {
     "kmers_composition": (C.c_int, [_P, _S, C.c_int, _P, C.c_int, _R]),
     "kmers_fx_hash": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int]),
     "kmers_transform": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_uint64, _P, C.c_int]),
+    "kmers_shard_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
     "kmers_synth_dna": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _P]),
 }
 

@@ -104,6 +104,19 @@ __device__ __forceinline__ bool transform_one(int op, const uint64_t (&x)[NW], u
         }
         return true;
     }
+    if (op == 7 || op == 8) {
+        // as_integer / from_integer (kmer.jl:305-326, :361-384): the value is the word tuple read as
+        // one big-endian number; exported as u64 (NW == 1) or little-endian u128 (NW == 2).
+        // from_integer keeps only the lowest K*bits bits (head word masked).
+        if constexpr (NW == 2) {
+            y[0] = x[1];
+            y[1] = x[0];
+            if (op == 8) y[0] &= mask;
+        } else {
+            if (op == 8) y[0] &= mask;
+        }
+        return true;
+    }
     if (op == 0) {
         kmer_reverse<NW, BITS>(y, bu);
     } else if (op == 1) {

@@ -472,6 +472,55 @@ uint64_t kmers_count(uint64_t n_bases, int k, int stride) {
     return (n_bases - (uint64_t)k) / (uint64_t)stride + 1;  // SpacedKmers.jl:41; stride 1 == FwKmers.jl:42
 }
 
+int kmers_shard_plan(uint64_t n_bases, int k, uint64_t stride, int src_bits, int n_shards, int shard_id,
+                     kmers_shard *out) {
+    if (!out || k < 1 || stride < 1 || n_shards < 1 || shard_id < 0 || shard_id >= n_shards) return KMERS_E_BADARG;
+    if (src_bits != 2 && src_bits != 4 && src_bits != 8) return KMERS_E_BADARG;
+    const uint64_t bits = (uint64_t)src_bits, per_word = 64 / bits, K = (uint64_t)k, n = (uint64_t)n_shards;
+    const uint64_t m = n_bases < K ? 0 : (n_bases - K) / stride + 1;
+    const uint64_t total_words = (n_bases * bits + 63) / 64;
+    // shard boundaries sit on source-word boundaries AND on the stride lattice
+    uint64_t a = stride, b = per_word;
+    while (b) { uint64_t t = a % b; a = b; b = t; }
+    const uint64_t unit_kmers = per_word / a;  // lcm(stride, per_word) / stride
+    uint64_t per = (m + n - 1) / n;
+    per = per ? (per + unit_kmers - 1) / unit_kmers * unit_kmers : unit_kmers;
+    const uint64_t words_per_shard = per / unit_kmers * (stride / a);  // per * stride / per_word
+    const uint64_t overhang = K > stride ? K - stride : 0;             // symbols a shard's last window reaches past it
+    const uint64_t halo = (overhang * bits + 63) / 64;
+    const uint64_t g = (uint64_t)shard_id;
+    auto plan = [&](uint64_t q, kmers_shard *o) {
+        const uint64_t lo = m < q * per ? m : q * per, hi = m < (q + 1) * per ? m : (q + 1) * per;
+        const uint64_t fw = total_words < q * words_per_shard ? total_words : q * words_per_shard;
+        uint64_t lw = total_words;
+        if (q != n - 1 && (q + 1) * words_per_shard < total_words) lw = (q + 1) * words_per_shard;
+        const uint64_t nk = hi - lo;
+        const uint64_t need_end = nk ? (((lo + nk - 1) * stride + K) * bits + 63) / 64 : fw;
+        uint64_t h = 0;
+        if (q < n - 1 && need_end > lw) h = need_end - lw < halo ? need_end - lw : halo;
+        o->first_kmer = lo;
+        o->n_kmers = nk;
+        o->first_base = lo * stride;
+        o->n_bases = nk ? (nk - 1) * stride + K : 0;
+        o->first_word = fw;
+        o->n_own_words = lw - fw;
+        o->halo_words = (uint32_t)h;
+        o->send_words = 0;
+    };
+    if (m == 0 || (n > 1 && words_per_shard < halo + 1)) {  // too short to shard: shard 0 does it all
+        *out = kmers_shard{g ? m : 0, g ? 0 : m, g ? m * stride : 0, g ? 0 : n_bases, g ? total_words : 0,
+                           g ? 0 : total_words, 0, 0};
+        return KMERS_OK;
+    }
+    plan(g, out);
+    if (g > 0) {
+        kmers_shard left;
+        plan(g - 1, &left);
+        out->send_words = left.halo_words;
+    }
+    return KMERS_OK;
+}
+
 int kmers_supported(int src_bits, int dst_bits, int k, int stride) {
     if (src_bits != 2 && src_bits != 4 && src_bits != 8) return 0;
     if (dst_bits != 2 && dst_bits != 4) return 0;
@@ -909,10 +958,12 @@ int kmers_fx_hash(kmers_ctx *ctx, const uint64_t *kmers, int n_words, uint64_t n
 int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bits, uint64_t n, uint64_t *out,
                     int flags) {
     if (!ctx) return KMERS_E_BADARG;
-    if (op < 0 || op > 6 || k < 1 || (bits != 2 && bits != 4)) return fail(ctx, KMERS_E_BADARG, "bad transform arguments");
+    if (op < 0 || op > 8 || k < 1 || (bits != 2 && bits != 4)) return fail(ctx, KMERS_E_BADARG, "bad transform arguments");
     if (op == KMERS_OP_COUNT_GC && bits != 2) return fail(ctx, KMERS_E_UNSUPPORTED, "count(isGC) is defined for 2-bit kmers (src/counting.jl:1)");
     const int nw = n_coding_elements(k, bits);
     if (nw > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_transform supports up to 4 words per kmer");
+    if ((op == KMERS_OP_AS_INTEGER || op == KMERS_OP_FROM_INTEGER) && nw > 2)
+        return fail(ctx, KMERS_E_BADARG, "Must have at most 128 bits in encoding (src/kmer.jl:324)");
     if (n == 0) return KMERS_OK;
     if (!kmers || !out) return fail(ctx, KMERS_E_BADARG, "NULL kmer array");
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -835,10 +835,21 @@ def to_longsequence(x, ctx=None):
     return _transform(_capi.OP_TO_LONGSEQ, x, ctx)         # LongSequence{A}(kmer), construction.jl:289-324
 
 
-def as_integer(x):
-    """as_integer(x::Kmer) (src/kmer.jl:305-326): the on-wire integer form (<= 128 bits)."""
+def as_integer(x, ctx=None):
+    """as_integer(x::Kmer) (src/kmer.jl:305-326): the on-wire integer form (<= 128 bits).  A KmerArray
+    is exported on the device: a uint64 array (<= 64 coding bits) or an (n, 2) array of little-endian
+    u128 halves (low, high)."""
     if x.K * x.alphabet.bits > 128:
         raise KmersError("Must have at most 128 bits in encoding")
+    if isinstance(x, KmerArray):
+        ctx = ctx or default_context()
+        n = len(x)
+        out = np.zeros((max(n, 1), x.N), dtype=np.uint64)
+        if n:
+            ctx.check(ctx.lib.kmers_transform(ctx.handle, _capi.OP_AS_INTEGER, x.words.ctypes.data_as(C.c_void_p), x.K,
+                                              x.alphabet.bits, n, out.ctypes.data_as(C.c_void_p), _capi.MEM_HOST),
+                      "kmers_transform")
+        return out[:n, 0] if x.N == 1 else out[:n]
     v = 0
     for w in x.data:
         v = (v << 64) | w
@@ -850,6 +861,16 @@ def from_integer(alphabet, K, u):
     bits = K * alphabet.bits
     if bits > 128:
         raise KmersError("Kmer type must contain at most 128 bits")
+    if isinstance(u, np.ndarray):  # batch: uint64[n] or uint64[n, 2] (little-endian u128 halves)
+        ctx = default_context()
+        N = n_coding_elements(K, alphabet.bits)
+        u = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, N)
+        out = np.zeros((max(len(u), 1), N), dtype=np.uint64)
+        if len(u):
+            ctx.check(ctx.lib.kmers_transform(ctx.handle, _capi.OP_FROM_INTEGER, u.ctypes.data_as(C.c_void_p), K,
+                                              alphabet.bits, len(u), out.ctypes.data_as(C.c_void_p), _capi.MEM_HOST),
+                      "kmers_transform")
+        return KmerArray(alphabet, K, out[:len(u)])
     u &= (1 << bits) - 1 if bits else 0
     N = n_coding_elements(K, alphabet.bits)
     return Kmer(alphabet, K, tuple((u >> (64 * (N - 1 - i))) & MASK64 for i in range(N)))

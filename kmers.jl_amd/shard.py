@@ -8,58 +8,63 @@ source-word boundary, and needs the first ceil((K-1)*bits/64) words of shard g+1
 own words.  That one neighbour step is the only communication on the path; outputs stay on the
 rank that produced them (concatenation in rank order == the reference's iteration order).
 """
+import math
 from dataclasses import dataclass
 
 
 @dataclass(frozen=True)
 class Shard:
     rank: int
-    first_kmer: int      # global 0-based index of the first kmer start owned
+    first_kmer: int      # global 0-based ordinal of the first kmer owned
     n_kmers: int         # kmers owned
     first_word: int      # global index of the first source word owned
     n_own_words: int     # source words owned (== words this rank generates / is handed)
     halo_words: int      # words received from rank+1 (0 on the last shard)
-    n_bases: int         # symbols in this shard's view (own kmers' windows): n_kmers - 1 + K, 0 if empty
+    n_bases: int         # symbols in this shard's view: (n_kmers - 1) * stride + K, 0 if empty
     send_words: int      # words sent to rank-1 (0 on the first shard)
+    stride: int = 1
 
     @property
     def first_base(self):
-        return self.first_kmer  # stride 1: kmer i starts at symbol i
+        return self.first_kmer * self.stride  # kmer i starts at symbol i * stride
 
 
-def plan_shards(n_bases, k, n_shards, src_bits):
-    """Split kmer starts [0, n_bases-k+1) into n_shards contiguous word-aligned ranges."""
-    if k < 1 or n_shards < 1 or src_bits not in (2, 4):
+def plan_shards(n_bases, k, n_shards, src_bits, stride=1):
+    """Split the kmers of a length-n_bases sequence into n_shards contiguous ranges whose first symbol
+    sits on a source-word boundary and on the stride lattice (the same arithmetic as the C ABI's
+    kmers_shard_plan; tests hold the two equal)."""
+    if k < 1 or n_shards < 1 or stride < 1 or src_bits not in (2, 4, 8):
         raise ValueError("bad shard plan arguments")
     per_word = 64 // src_bits
-    n_kmers = max(0, n_bases - k + 1)
+    n_kmers = (n_bases - k) // stride + 1 if n_bases >= k else 0
     total_words = (n_bases * src_bits + 63) // 64
-    # starts per shard: equal split rounded up to a whole number of source words
+    unit = per_word // math.gcd(stride, per_word)  # kmers per lcm(stride, per_word) symbols
     per = -(-n_kmers // n_shards)
-    per = -(-per // per_word) * per_word if per else per_word
-    halo = ((k - 1) * src_bits + 63) // 64
-    if n_shards > 1 and per // per_word < halo + 1:
+    per = -(-per // unit) * unit if per else unit
+    words_per_shard = per * stride // per_word
+    halo = (max(0, k - stride) * src_bits + 63) // 64
+    if n_kmers == 0 or (n_shards > 1 and words_per_shard < halo + 1):
         # too short to give every shard at least a halo's worth of words: shard 0 does it all
-        first = Shard(0, 0, n_kmers, 0, total_words, 0, (n_kmers - 1 + k) if n_kmers else 0, 0)
-        return [first] + [Shard(g, n_kmers, 0, total_words, 0, 0, 0, 0) for g in range(1, n_shards)]
+        first = Shard(0, 0, n_kmers, 0, total_words, 0, n_bases, 0, stride)
+        return [first] + [Shard(g, n_kmers, 0, total_words, 0, 0, 0, 0, stride) for g in range(1, n_shards)]
     shards = []
     for g in range(n_shards):
         lo = min(n_kmers, g * per)
         hi = min(n_kmers, (g + 1) * per)
-        fw = min(total_words, g * per // per_word)
+        fw = min(total_words, g * words_per_shard)
         # own words: up to the next shard's first word (the last shard keeps the tail)
-        lw = total_words if g == n_shards - 1 else min(total_words, (g + 1) * per // per_word)
+        lw = total_words if g == n_shards - 1 else min(total_words, (g + 1) * words_per_shard)
         nk = hi - lo
         # words of the next shard this one needs to finish its last windows
-        need_end = ((lo + nk - 1 + k) * src_bits + 63) // 64 if nk else fw
+        need_end = (((lo + nk - 1) * stride + k) * src_bits + 63) // 64 if nk else fw
         h = max(0, min(halo, need_end - lw)) if g < n_shards - 1 else 0
-        shards.append(Shard(g, lo, nk, fw, lw - fw, h, (nk - 1 + k) if nk else 0, 0))
+        shards.append(Shard(g, lo, nk, fw, lw - fw, h, ((nk - 1) * stride + k) if nk else 0, 0, stride))
     # what each rank sends = what its left neighbour needs
     out = []
     for g, s in enumerate(shards):
         send = shards[g - 1].halo_words if g > 0 else 0
         out.append(Shard(s.rank, s.first_kmer, s.n_kmers, s.first_word, s.n_own_words, s.halo_words,
-                         s.n_bases, send))
+                         s.n_bases, send, stride))
     return out
 
 
@@ -115,3 +120,36 @@ class HaloExchanger:
 def exchange_halo(buf, shard, group=None, plan=None, transport=None):
     """One-shot form of HaloExchanger (allocates its workspace on every call)."""
     HaloExchanger(buf, shard, plan or [shard], group, transport).exchange()
+
+
+_NO_ERROR = (1 << 63) - 1
+
+
+def first_error(status, err_pos, err_enc, group=None, device="cpu"):
+    """The reference throws at the FIRST ambiguous symbol in sequence order
+    (FwKmers.jl:112, CanonicalKmers.jl:139): all_reduce(MIN) over the shards' (global 1-based
+    position, raw encoding) pairs.  Returns (status, err_pos, err_enc) identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    key = ((int(err_pos) << 8) | (int(err_enc) & 0xFF)) if status == 1 else _NO_ERROR
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = torch.tensor([key], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        key = int(t.item())
+    if key == _NO_ERROR:
+        return status if status != 1 else 0, 0, 0
+    return 1, key >> 8, key & 0xFF
+
+
+def output_offsets(n_local, group=None, device="cpu"):
+    """Exclusive scan of the shards' element counts (UnambiguousKmers has SizeUnknown,
+    UnambiguousKmers.jl:33): returns (offset of this rank's elements in the global output, total)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0, int(n_local)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([int(n_local)], dtype=torch.int64, device=device), group=group)
+    counts = [int(c.item()) for c in counts]
+    return sum(counts[:rank]), sum(counts)

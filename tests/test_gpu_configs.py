@@ -249,3 +249,53 @@ def test_c5_spaced21_3_one_gbase_strict_and_skip(km, ctx, orc):
     cnt = int(keep.sum())
     assert np.array_equal(host_u64(kmers[:cnt]), ek[keep][:, 0])
     assert np.array_equal(starts[:cnt].cpu().numpy(), es[keep])
+
+
+def test_synth_10k_fixture_on_device(km, ctx):
+    """tests/golden/synth_10k.json: device generator + HIP iterators against the committed values
+    (no oracle at run time)."""
+    import ctypes as C
+    import json
+    import os
+    cap = km._capi
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth_10k.json")))
+    L, seed = fx["n_bases"], int(fx["seed"], 16)
+    for c in fx["cases"]:
+        bits, K = c["src_bits"], c["K"]
+        res = cap.Result()
+        if c["iter"] == "canonical":
+            nw = (L * bits + 63) // 64
+            buf = synth(ctx, seed, 0, nw, bits)
+            src = host_u64(buf)
+            assert [f"0x{int(x):016x}" for x in src[:4]] == c["source_words_first4"]
+            assert int(np.bitwise_xor.reduce(src[:nw])) == int(c["source_xor"], 16)
+            N = (2 * K + 63) // 64
+            n = L - K + 1
+            km_d, hs_d = dev_empty(n * N), dev_empty(n)
+            seq = cap.Seq(buf.data_ptr(), L, 0, 0, bits, 0)
+            ctx.check(ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, km_d.data_ptr(), hs_d.data_ptr(), 0,
+                                              cap.MEM_DEVICE, C.byref(res)), "canonical")
+            kmers, hs = host_u64(km_d).reshape(n, N), host_u64(hs_d)
+            assert res.n_out == c["n"] == n
+            assert [int(np.bitwise_xor.reduce(kmers[:, j])) for j in range(N)] == [int(x, 16) for x in c["kmer_xor"]]
+            assert int(np.bitwise_xor.reduce(hs)) == int(c["hash_xor"], 16)
+            assert [int(x) for x in kmers[:16].reshape(-1)] == [int(x, 16) for x in c["first16"]]
+            assert [int(x) for x in kmers[-16:].reshape(-1)] == [int(x, 16) for x in c["last16"]]
+            assert [int(x) for x in hs[:16]] == [int(x, 16) for x in c["first16_hashes"]]
+            assert [int(x) for x in hs[-16:]] == [int(x, 16) for x in c["last16_hashes"]]
+        else:
+            buf = synth(ctx, int(c["seed"], 16), 0, L // 16 + 1, 4, c["ambig_per_65536"])
+            seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
+            for stride, n_key, xor_key in ((1, "n", "kmer_xor"), (3, "lattice3_n", "lattice3_kmer_xor")):
+                km_d, st_d = dev_empty(L), dev_empty(L)
+                ctx.check(ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, stride, km_d.data_ptr(), st_d.data_ptr(), L,
+                                                    cap.MEM_DEVICE, C.byref(res)), "unambiguous")
+                m = int(res.n_out)
+                assert m == c[n_key]
+                assert int(np.bitwise_xor.reduce(host_u64(km_d)[:m])) == int(c[xor_key], 16)
+                if stride == 1:
+                    st = st_d.cpu().numpy()[:m]
+                    assert int(st.sum()) == c["start_sum"] and [int(x) for x in st[:16]] == c["first16_starts"]
+            out = dev_empty(L)
+            rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, 3, 2, out.data_ptr(), cap.MEM_DEVICE, C.byref(res))
+            assert rc == 1 and (res.err_pos, res.err_enc) == (c["strict_spaced_error"]["pos"], c["strict_spaced_error"]["enc"])

@@ -188,7 +188,7 @@ def test_fx_hash_known_answers(km, kats):
     assert x != y  # kmer.jl:240-250
 
 
-def test_transform_known_answers(km, kats):
+def test_transform_known_answers(km, kats, orc):
     # test/runtests.jl:438-485
     g = kats["G10_iscanonical"]
     for t in g["true"]:
@@ -209,6 +209,21 @@ def test_transform_known_answers(km, kats):
         ts = [naive.random_text(rng, K) for _ in range(50)]
         arr = km.KmerArray(km.DNAAlphabet[2], K, np.array([naive.kmer_words(t, 2) for t in ts], dtype=np.uint64))
         assert texts(km.reverse_complement(arr)) == [naive.revcomp_text(t) for t in ts]
+        # batch as_integer / from_integer (kmer.jl:305-326, :361-384) against the oracle's scalar form
+        ints = km.as_integer(arr)
+        for row, t in zip(ints, ts):
+            val, _ = orc.as_integer(naive.kmer_words(t, 2), K, 2)
+            got = int(row) if arr.N == 1 else (int(row[1]) << 64) | int(row[0])
+            assert got == val == km.as_integer(km.mer(t))
+        dirty = ints.copy()
+        if K in (5, 31):    # one word with spare top bits: non-coding bits of u are ignored
+            dirty |= np.uint64(0xC000000000000000)
+        elif K == 33:       # u128: column 1 is the high half
+            dirty[:, 1] |= np.uint64(0xF000000000000000)
+        assert km.from_integer(km.DNAAlphabet[2], K, dirty) == arr
+        assert km.from_integer(km.DNAAlphabet[2], K, ints) == arr
+    with pytest.raises(km.KmersError):
+        km.as_integer(km.KmerArray(km.DNAAlphabet[2], 65, np.zeros((1, 3), np.uint64)))
 
 
 def test_big_chunked_iteration_matches_collect(km, orc):

@@ -221,3 +221,54 @@ def test_longseq_kmer_roundtrip(orc, bps):
         assert km == naive.kmer_words(text, bps)
         back = orc.longseq_from_kmer(km, K, bps)
         assert list(back) == list(ls[:len(back)])
+
+
+def test_synth_10k_fixture(orc):
+    """tests/golden/synth_10k.json: the committed generator + end-to-end pin.
+    The first and last 16 canonical kmers are also re-derived with the naive big-int slicer from the
+    decoded text, so the fixture is not only the oracle agreeing with itself."""
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth_10k.json")))
+    L, seed = fx["n_bases"], int(fx["seed"], 16)
+    for c in fx["cases"]:
+        bits = c["src_bits"]
+        if c["iter"] == "canonical":
+            n_words = (L * bits + 63) // 64
+            words = orc.synth_words(seed, 0, n_words + 1, bits)
+            assert [f"0x{int(x):016x}" for x in words[:4]] == c["source_words_first4"]
+            assert int(np.bitwise_xor.reduce(words[:n_words])) == int(c["source_xor"], 16)
+            km, hs, res = orc.canonical(words, L, bits, 2, c["K"])
+            assert res.status == 0 and len(km) == c["n"]
+            assert [int(np.bitwise_xor.reduce(km[:, j])) for j in range(km.shape[1])] == [int(x, 16) for x in c["kmer_xor"]]
+            assert int(np.bitwise_xor.reduce(hs)) == int(c["hash_xor"], 16)
+            # decode the LongSequence words symbol by symbol (LE packing) and slice naively
+            sym = "ACGT"
+            if bits == 2:
+                text = "".join(sym[(int(words[i // 32]) >> (2 * (i % 32))) & 3] for i in range(L))
+            else:
+                text = "".join(sym[((int(words[i // 16]) >> (4 * (i % 16))) & 15).bit_length() - 1] for i in range(L))
+            N = km.shape[1]
+            exp = naive.canonical(text[:c["K"] + 15], c["K"], 2) + naive.canonical(text[-(c["K"] + 15):], c["K"], 2)
+            flat = [int(x, 16) for x in c["first16"] + c["last16"]]
+            assert [tuple(flat[i * N:(i + 1) * N]) for i in range(32)] == exp
+            assert [int(x, 16) for x in c["first16_hashes"] + c["last16_hashes"]] == [naive.fx_hash(w) for w in exp]
+        else:
+            words = orc.synth_words(int(c["seed"], 16), 0, L // 16 + 1, 4, c["ambig_per_65536"])
+            km, st, res = orc.unambiguous(words, L, 4, c["K"])
+            assert len(km) == c["n"] and int(st.sum()) == c["start_sum"]
+            assert [int(x) for x in st[:16]] == c["first16_starts"]
+            assert int(np.bitwise_xor.reduce(km[:, 0])) == int(c["kmer_xor"], 16)
+            _, sres = orc.spaced(words, L, 4, 2, c["K"], 3)
+            assert sres.status == 1 and (sres.err_pos, sres.err_enc) == (c["strict_spaced_error"]["pos"], c["strict_spaced_error"]["enc"])
+
+
+def test_julia_comparison_tool_self_test():
+    """tests/golden/compare_with_julia.py (the tool that pins the oracle on vectors from the real
+    reference when Julia is available) runs, and oracle == naive model on the vectors it covers."""
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(__file__), "golden", "compare_with_julia.py")
+    r = subprocess.run([sys.executable, tool, "--self-test"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all vectors agree" in r.stdout, r.stdout + r.stderr
