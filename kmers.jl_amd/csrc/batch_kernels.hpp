@@ -264,17 +264,6 @@ __global__ __launch_bounds__(1024) void sketch_prune_kernel(uint64_t *__restrict
     }
 }
 
-// ---- sum `replicas` copies of a uint32 histogram into out (composition, mid-size K) ----------
-__global__ __launch_bounds__(256) void reduce_replicas_kernel(const uint32_t *__restrict__ rep, uint32_t replicas,
-                                                               size_t bins, uint32_t *__restrict__ out) {
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < bins; i += stride) {
-        uint32_t s = 0;
-        for (uint32_t r = 0; r < replicas; ++r) s += rep[r * bins + i];
-        out[i] = s;
-    }
-}
-
 // ---- synthetic input (the CPU checker restates the same generator) ------
 __global__ __launch_bounds__(256) void synth_kernel(uint64_t seed, uint64_t first_word, uint64_t n_words, int bits,
                                                      uint32_t ambig, uint64_t *__restrict__ out) {

@@ -16,6 +16,7 @@
 #include "ascii_tables.hpp"
 #include "batch_kernels.hpp"
 #include "compact_kernels.hpp"
+#include "composition_kernel.hpp"
 #include "stream_kernel.hpp"
 
 using namespace kmers;
@@ -38,6 +39,7 @@ struct kmers_ctx {
     int64_t tile_kmers = 0;  // 0 = default
     int64_t max_grid = 0;    // 0 = default
     int64_t stamps_ptr = 0;  // diagnostic builds only (KMERS_PARAM_STAMPS_PTR)
+    int n_cus = 256;                // multiProcessorCount
     bool sketch_host_only = false;  // KMERS_PARAM_SKETCH_HOST_ONLY: force the host-feedback MinHash path (tests)
 };
 
@@ -537,6 +539,8 @@ int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out) {
     kmers_ctx *ctx = new (std::nothrow) kmers_ctx();
     if (!ctx) return KMERS_E_NOMEM;
     ctx->device = device;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
     if (hip_stream) {
         ctx->stream = static_cast<hipStream_t>(hip_stream);
     } else {
@@ -874,32 +878,46 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
         if (int rc = ensure_stage(ctx, 1, bins * 4)) return rc;
         d_counts = static_cast<uint32_t *>(ctx->stage[1]);
     }
-    // K <= 6: histogram private to each workgroup in LDS (<= 16 KiB), flushed once.
-    // K = 7..10: one replica of the global counters per XCD (contention), summed afterwards.
-    // K >= 11: the counters are numerous enough for plain global atomics.
-    const bool in_lds = k <= 6;
-    const uint32_t replicas = (!in_lds && k <= 10) ? 8u : 1u;
-    uint32_t *d_work = d_counts;
-    if (replicas > 1) {
-        if (int rc = ensure_stage(ctx, 3, bins * 4 * replicas)) return rc;
-        d_work = static_cast<uint32_t *>(ctx->stage[3]);
-    }
-    HIP_TRY(ctx, hipMemsetAsync(d_work, 0, bins * 4 * replicas, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, bins * 4, ctx->stream));
     const uint64_t n = kmers_count(seq->n_bases, k, 1);
     if (n) {
         Staged st;
         if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
         remember_source(ctx, seq, st);
-        StreamArgs a{};
-        a.out_a = reinterpret_cast<uint64_t *>(d_work);
-        a.capacity = in_lds ? bins : 0;
-        a.threshold = replicas;
-        if (int rc = launch_fused<MODE_COUNT>(ctx, seq, st, k, 2, a, in_lds ? bins * 4 : 0)) return rc;
-    }
-    if (replicas > 1) {
-        hipLaunchKernelGGL(reduce_replicas_kernel, dim3((unsigned)std::min<size_t>((bins + 255) / 256, 4096)), dim3(256), 0,
-                           ctx->stream, d_work, replicas, bins, d_counts);
-        HIP_TRY(ctx, hipGetLastError());
+        if (k <= 10) {
+            // private 16-bit histograms in LDS, 65 536 bins per pass (composition_kernel.hpp):
+            // 0.4-0.6 ms per Gbase up to K = 8, 0.75 ms per pass beyond (K = 9: 4 passes, K = 10: 16)
+            CompositionArgs a{};
+            a.src = st.d_words;
+            a.first_bit = st.first_bit;
+            a.n_bases = seq->n_bases;
+            a.n_kmers = n;
+            a.n_tiles = (n + CTILE - 1) / CTILE;
+            a.counts = d_counts;
+            a.err_slot = ctx->d_err;
+            a.ascii_lut = ascii_table(ctx, 2, seq->alphabet != 0);
+            a.k = (uint32_t)k;
+            a.hist_words = (uint32_t)std::min<size_t>(bins, (size_t)1 << CBINS_LOG2) / 2;
+            const uint32_t passes = (uint32_t)std::max<size_t>(1, bins >> CBINS_LOG2);
+            const size_t dyn = (size_t)a.hist_words * 4;
+            const unsigned per_cu = dyn <= 64 * 1024 ? 2u : 1u;  // 1024-thread workgroups: at most two per CU
+            uint64_t resident = (uint64_t)ctx->n_cus * per_cu;
+            if (ctx->max_grid > 0) resident = std::min<uint64_t>(resident, (uint64_t)ctx->max_grid);
+            dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, resident)), block(CBLOCK);
+            auto kern = seq->src_bits == 8 ? composition_kernel<8> : (seq->src_bits == 4 ? composition_kernel<4> : composition_kernel<2>);
+            if (dyn > 48 * 1024)
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            for (uint32_t p = 0; p < passes; ++p) {
+                a.pass = p;
+                hipLaunchKernelGGL(kern, grid, block, dyn, ctx->stream, a);
+            }
+            HIP_TRY(ctx, hipGetLastError());
+        } else {
+            // 4^11 and 4^12 counters: 64+ passes would cost more than memory-side global atomics (37 ms per Gbase)
+            StreamArgs a{};
+            a.out_a = reinterpret_cast<uint64_t *>(d_counts);
+            if (int rc = launch_fused<MODE_COUNT>(ctx, seq, st, k, 2, a, 0)) return rc;
+        }
     }
     if (!dev) HIP_TRY(ctx, hipMemcpyAsync(out_counts, d_counts, bins * 4, hipMemcpyDeviceToHost, ctx->stream));
     return collect(ctx, res, n);

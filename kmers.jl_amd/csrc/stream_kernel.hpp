@@ -45,8 +45,7 @@ struct StreamArgs {
     const uint8_t *ascii_lut; // SRC_BITS == 8: 256-entry byte -> symbol table (ascii_tables.hpp)
     // MODE_SKETCH: hashes below the threshold (threshold_ptr[0] when non-NULL, else `threshold`) are appended
     //              to out_a[0..capacity) through the counter out_b[0]
-    // MODE_COUNT : out_a = uint32 counts[replicas][4^K] indexed by as_integer(forward kmer);
-    //              capacity = bins that fit the dynamic LDS histogram (0 = none), threshold = replicas
+    // MODE_COUNT : out_a = uint32 counts[4^K] indexed by as_integer(forward kmer), global atomics
     uint64_t threshold;
     uint64_t capacity;
     const uint64_t *threshold_ptr;  // MODE_SKETCH, device-resident sketch: the running threshold in HBM
@@ -249,24 +248,13 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     }
     constexpr uint32_t KPL = (STRIDE1 && N == 1 && !TUPLES) ? 2u : 1u;  // kmers per lane per pass -> 16 B stores
     uint64_t xacc = 0;
-    // MODE_COUNT: where this workgroup accumulates.  4^K <= capacity: a private histogram in dynamic
-    // LDS, flushed once at the end (K <= 6); else global counters, one replica per XCD for mid-size
-    // K (threshold = replicas; workgroups b and b+8 share an XCD and its L2 -- speed only).
-    extern __shared__ uint32_t lds_hist[];
     uint64_t sketch_threshold = a.threshold;
     if constexpr (MODE == MODE_SKETCH) {
         if (a.threshold_ptr) sketch_threshold = *a.threshold_ptr;  // uniform; constant for the whole launch
     }
+    // MODE_COUNT (K >= 11 only; smaller K use composition_kernel.hpp): plain global counters
     uint32_t *count_base = nullptr;
-    if constexpr (MODE == MODE_COUNT) {
-        const uint32_t bins = 1u << (2u * k);
-        if (bins <= a.capacity) {
-            for (uint32_t i = tid; i < bins; i += BLOCK) lds_hist[i] = 0;
-            count_base = lds_hist;  // zeroing is ordered before use by the tile loop's first barrier
-        } else {
-            count_base = reinterpret_cast<uint32_t *>(a.out_a) + (size_t)(blockIdx.x % (uint32_t)a.threshold) * bins;
-        }
-    }
+    if constexpr (MODE == MODE_COUNT) count_base = reinterpret_cast<uint32_t *>(a.out_a);
 
     for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const uint64_t m0 = tile * a.tile_kmers;
@@ -436,17 +424,6 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
 #endif
     }
 
-    if constexpr (MODE == MODE_COUNT) {
-        const uint32_t bins = 1u << (2u * k);
-        if (bins <= a.capacity) {
-            __syncthreads();
-            uint32_t *counts = reinterpret_cast<uint32_t *>(a.out_a);
-            for (uint32_t i = tid; i < bins; i += BLOCK) {
-                uint32_t v = lds_hist[i];
-                if (v) atomicAdd(counts + i, v);
-            }
-        }
-    }
     if constexpr (MODE == MODE_XOR) {
         // wavefront XOR-reduce (64 lanes), then one atomic per wave
         for (int off = 32; off > 0; off >>= 1) xacc ^= __shfl_xor(xacc, off, 64);

@@ -592,6 +592,53 @@ def test_composition(km, ctx, orc):
             exp = np.bincount(fw[:, 0].astype(np.int64), minlength=4 ** K).astype(np.uint32)
             assert np.array_equal(counts, exp), (bits, K)
             assert counts.sum() == L - K + 1
+    # K = 12 (global counters), an ASCII source, and an EncodeError through the composition kernel
+    L = 300_000
+    words = orc.synth_words(12, 0, L // 16 + 1, 4)
+    seq, keep = make_seq(km, words, L, 4)
+    counts = np.zeros(4 ** 12, dtype=np.uint32)
+    res = cap.Result()
+    assert ctx.lib.kmers_composition(ctx.handle, C.byref(seq), 12, vp(counts), cap.MEM_HOST, C.byref(res)) == 0
+    fw, _ = orc.fw_kmers(words, L, 4, 2, 12)
+    assert np.array_equal(counts, np.bincount(fw[:, 0].astype(np.int64), minlength=4 ** 12).astype(np.uint32))
+    text = naive.random_text(np.random.default_rng(3), 70_001)
+    aw = naive.ascii_words(text)
+    seq = cap.Seq(aw.ctypes.data, len(text), 0, 0, 8, 0)
+    counts = np.zeros(4 ** 8, dtype=np.uint32)
+    assert ctx.lib.kmers_composition(ctx.handle, C.byref(seq), 8, vp(counts), cap.MEM_HOST, C.byref(res)) == 0
+    exp = np.bincount(np.array([w[0] for w in naive.fw_kmers(text, 8, 2)], dtype=np.int64), minlength=4 ** 8)
+    assert np.array_equal(counts, exp.astype(np.uint32))
+    bad = text[:40_000] + "N" + text[40_001:]
+    w4 = naive.longseq_words(bad, 4)
+    seq, keep = make_seq(km, w4, len(bad), 4)
+    rc = ctx.lib.kmers_composition(ctx.handle, C.byref(seq), 8, vp(counts), cap.MEM_HOST, C.byref(res))
+    assert rc == cap.E_ENCODE and res.err_pos == 40_001 and res.err_enc == 0xF
+
+
+def test_composition_counter_overflow_paths(km, ctx, orc):
+    """The LDS histograms hold 16-bit counters: low-complexity input (every kmer in one bin, or half of
+    them) must take the measure-and-flush path and still count exactly.  KMERS_PARAM_MAX_GRID = 2 makes
+    two workgroups walk all the tiles, so 1.2 M kmers are enough to overflow a counter many times."""
+    cap = km._capi
+    ctx.set_param(cap.PARAM_MAX_GRID, 2)
+    try:
+        L = 1_200_000
+        rng = np.random.default_rng(9)
+        half = naive.random_text(rng, L // 2)
+        for name, text in (("polyA", "A" * L), ("polyT", "T" * L), ("half", "A" * (L // 2) + half),
+                           ("period2", "AC" * (L // 2))):
+            for bits in (2, 4):
+                words = naive.longseq_words(text, bits)
+                for K in (1, 3, 8, 9):
+                    seq, keep = make_seq(km, words, L, bits)
+                    counts = np.zeros(4 ** K, dtype=np.uint32)
+                    res = cap.Result()
+                    assert ctx.lib.kmers_composition(ctx.handle, C.byref(seq), K, vp(counts), cap.MEM_HOST, C.byref(res)) == 0
+                    fw, _ = orc.fw_kmers(words, L, bits, 2, K)
+                    exp = np.bincount(fw[:, 0].astype(np.int64), minlength=4 ** K).astype(np.uint32)
+                    assert np.array_equal(counts, exp), (name, bits, K)
+    finally:
+        ctx.set_param(cap.PARAM_MAX_GRID, 0)
 
 
 def test_tuple_layouts(km, ctx, orc):

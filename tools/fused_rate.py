@@ -32,7 +32,7 @@ for bits in (4, 2):
     out = np.zeros(1000, dtype=np.uint64)
     for K in (16, 31):
         timed(f"minhash sketch s=1000 K={K}", lambda: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, 2, 0, 1000, out.ctypes.data_as(C.c_void_p), cap.MEM_DEVICE, C.byref(res)))
-    for K in (4, 8):
+    for K in (4, 6, 7, 8, 9, 10, 11, 12):
         counts = ctx.alloc(4 ** K * 4)
         timed(f"composition K={K}", lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), K, counts, cap.MEM_DEVICE, C.byref(res)))
         ctx.free(counts)
