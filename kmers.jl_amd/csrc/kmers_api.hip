@@ -17,6 +17,7 @@
 #include "batch_kernels.hpp"
 #include "compact_kernels.hpp"
 #include "composition_kernel.hpp"
+#include "run_kernel.hpp"
 #include "stream_kernel.hpp"
 
 using namespace kmers;
@@ -458,6 +459,30 @@ int launch_fused(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, 
     return rc;
 }
 
+// Fused consumers of one-word 2-bit kmers: the rolling run kernel (run_kernel.hpp); everything else
+// (two- to four-word kmers, 4-bit kmer alphabets) goes through the stream kernel's fused modes.
+template <int RMODE, int SMODE>
+int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, int dst_bits, StreamArgs &a) {
+    if (dst_bits != 2 || k > 32) return launch_fused<SMODE>(ctx, seq, st, k, dst_bits, a);
+    a.src = st.d_words;
+    a.first_bit = st.first_bit;
+    a.n_bases = seq->n_bases;
+    a.n_kmers = kmers_count(seq->n_bases, k, 1);
+    a.inspect_end = seq->n_bases;
+    a.err_slot = ctx->d_err;
+    a.k = (uint32_t)k;
+    a.stride = 1;
+    a.ascii_lut = ascii_table(ctx, 2, seq->alphabet != 0);
+    a.n_tiles = (a.n_kmers + RTILE - 1) / RTILE;
+    const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)ctx->n_cus * 8;  // persistent grid
+    dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, resident)), block(RBLOCK);
+    if (seq->src_bits == 8) hipLaunchKernelGGL((run_kernel<8, RMODE>), grid, block, 0, ctx->stream, a);
+    else if (seq->src_bits == 4) hipLaunchKernelGGL((run_kernel<4, RMODE>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((run_kernel<2, RMODE>), grid, block, 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return KMERS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -658,27 +683,9 @@ int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, 
     remember_source(ctx, seq, st);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
     StreamArgs a{};
-    a.src = st.d_words;
-    a.first_bit = st.first_bit;
-    a.n_bases = seq->n_bases;
-    a.n_kmers = n;
-    a.inspect_end = seq->n_bases;
     a.out_a = ctx->d_scratch;
-    a.err_slot = ctx->d_err;
-    a.k = (uint32_t)k;
-    a.stride = 1;
     a.xor_canonical = canonical ? 1u : 0u;
-    a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
-    if (ctx->max_grid <= 0) {
-        // fused consumer: persistent grid, one atomic per wave at the very end
-        int64_t saved = ctx->max_grid;
-        ctx->max_grid = 256 * 8;
-        int rc = launch_stream<MODE_XOR>(ctx, a, seq->src_bits, dst_bits, kmers_words_per_kmer(k, dst_bits), true);
-        ctx->max_grid = saved;
-        if (rc) return rc;
-    } else if (int rc = launch_stream<MODE_XOR>(ctx, a, seq->src_bits, dst_bits, kmers_words_per_kmer(k, dst_bits), true)) {
-        return rc;
-    }
+    if (int rc = launch_consumer<RMODE_XOR, MODE_XOR>(ctx, seq, st, k, dst_bits, a)) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out_value, ctx->d_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
     return collect(ctx, res, n);
 }
@@ -734,7 +741,7 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
             a.seed = seed;
             a.threshold_ptr = d_state + 1;
             a.capacity = dcap;
-            if (int rc = launch_fused<MODE_SKETCH>(ctx, &view, vst, k, dst_bits, a)) return rc;
+            if (int rc = launch_consumer<RMODE_SKETCH, MODE_SKETCH>(ctx, &view, vst, k, dst_bits, a)) return rc;
             hipLaunchKernelGGL(sketch_prune_kernel, dim3(1), dim3(1024), SKETCH_LDS_VALUES * 8, ctx->stream, d_best, d_state,
                                d_cand, dcap, (uint32_t)s);
             HIP_TRY(ctx, hipGetLastError());
@@ -786,7 +793,7 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
         a.seed = seed;
         a.threshold = threshold;
         a.capacity = cap;
-        if (int rc = launch_fused<MODE_SKETCH>(ctx, &view, vst, k, dst_bits, a)) return rc;
+        if (int rc = launch_consumer<RMODE_SKETCH, MODE_SKETCH>(ctx, &view, vst, k, dst_bits, a)) return rc;
         uint64_t count = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&count, d_counter, 8, hipMemcpyDeviceToHost, ctx->stream));
         // chunks run in sequence order, so the first chunk that reports an EncodeError holds the

@@ -1,0 +1,135 @@
+// run_kernel.hpp -- fused consumers of one-word 2-bit kmers (K <= 32) that keep nothing per kmer:
+//   RMODE_XOR    the reference's own benchmark consumer (test/benchmark.jl:9-15): XOR of the
+//                canonical (or forward) kmers' data words;
+//   RMODE_SKETCH MinHash candidates: fx_hash(canonical kmer) below the running threshold
+//                (docs/src/minhash.md:31-35).
+// These are ALU-bound (0.25-0.5 B of source per kmer), so the kernel spends as few instructions
+// per kmer as the reference's own recurrence allows: a lane builds the first kmer of a RUN of 16
+// from the LDS window (symbol reversal, complement) and then ROLLS the forward and
+// reverse-complement kmers one symbol at a time -- shift_encoding / shift_first_encoding, exactly
+// the step of CanonicalKmers.jl:131-144 -- taking the entering symbols from the same 128 stream
+// bits it already holds.  The next tile's source words travel from HBM while the current tile
+// is consumed (register prefetch).
+#pragma once
+#include "stream_kernel.hpp"
+
+namespace kmers {
+
+constexpr int RBLOCK = 256;
+constexpr int RRUN = 16;                   // consecutive kmers per lane
+constexpr int RTILE = RBLOCK * RRUN;       // kmers per tile
+enum RunMode { RMODE_XOR = 0, RMODE_SKETCH = 1 };
+
+template <int SRC_BITS, int RMODE>
+__global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
+    __shared__ uint64_t lds[RTILE * 2 / 64 + 16];
+    __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = a.k;
+    const uint64_t mask = head_mask((int)k, 2);
+    if constexpr (SRC_BITS == 8) {
+        for (uint32_t i = tid; i < 256u; i += RBLOCK) lut[i] = a.ascii_lut[i];
+    }
+    uint64_t threshold = a.threshold;
+    if constexpr (RMODE == RMODE_SKETCH) {
+        if (a.threshold_ptr) threshold = *a.threshold_ptr;  // uniform; constant for the whole launch
+    }
+    const bool canonical = RMODE == RMODE_SKETCH || a.xor_canonical != 0;
+    uint64_t xacc = 0;
+
+    struct Geo { uint64_t w0; uint32_t b0, nw, mt; };
+    auto geometry = [&](uint64_t tile) {
+        Geo g;
+        const uint64_t m0 = tile * RTILE;
+        const uint64_t left = a.n_kmers - m0;
+        g.mt = left < (uint64_t)RTILE ? (uint32_t)left : (uint32_t)RTILE;
+        const uint64_t bit0 = a.first_bit + m0 * SRC_BITS;
+        g.w0 = bit0 >> 6;
+        g.b0 = (uint32_t)(bit0 & 63u) / SRC_BITS;
+        const uint64_t end_bit = bit0 + ((uint64_t)(g.mt - 1) + k) * SRC_BITS;
+        g.nw = (uint32_t)(((end_bit + 63) >> 6) - g.w0);
+        return g;
+    };
+    constexpr int PRE = (RTILE + 96) * SRC_BITS / 64 / RBLOCK + 1;  // source words per thread per tile
+    uint64_t pre[PRE];
+    auto prefetch = [&](const Geo &g) {
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const uint32_t wi = tid + (uint32_t)i * RBLOCK;
+            pre[i] = wi < g.nw ? a.src[g.w0 + wi] : 0;
+        }
+    };
+
+    auto consume = [&](uint64_t fw, uint64_t rc) {
+        const uint64_t c = canonical ? (fw < rc ? fw : rc) : fw;  // CanonicalKmers.jl:220-225
+        if constexpr (RMODE == RMODE_XOR) {
+            xacc ^= c;
+        } else {
+            const uint64_t h = fx_step(a.seed, c);  // fx_hash of a one-word kmer (kmer.jl:255-261)
+            if (h < threshold) {
+                unsigned long long pos = atomicAdd(reinterpret_cast<unsigned long long *>(a.out_b), 1ull);
+                if (pos < a.capacity) a.out_a[pos] = h;
+            }
+        }
+    };
+
+    uint64_t tile = blockIdx.x;
+    if (tile < a.n_tiles) prefetch(geometry(tile));
+    for (; tile < a.n_tiles; tile += gridDim.x) {
+        const Geo g = geometry(tile);
+        __syncthreads();  // previous tile's readers are done with the stream
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const uint32_t wi = tid + (uint32_t)i * RBLOCK;
+            if (wi < g.nw) {
+                const uint64_t f = stage_word<SRC_BITS, 2>(lds, wi, pre[i], lut);
+                if constexpr (SRC_BITS != 2) {
+                    if (f) report_bad_symbols<SRC_BITS, true>(a.err_slot, a.first_bit, a.inspect_end, 1u, k, g.w0 + wi, f);
+                }
+            }
+        }
+        if (tile + gridDim.x < a.n_tiles) prefetch(geometry(tile + gridDim.x));
+        __syncthreads();
+
+        const uint32_t r0 = tid * RRUN;
+        if (r0 < g.mt) {
+            const uint32_t cnt = g.mt - r0 < (uint32_t)RRUN ? g.mt - r0 : (uint32_t)RRUN;
+            const uint32_t bit = 2u * (r0 + g.b0);
+            const uint32_t q = bit >> 6, s = bit & 63u;
+            // 128 stream bits from the run's first symbol; bits past the staged stream only reach kmers j >= cnt
+            const uint64_t l0 = lds[q], l1 = lds[q + 1], l2 = lds[q + 2];
+            const uint64_t W0 = funnel64(l0, l1, s), W1 = funnel64(l1, l2, s);
+            // first kmer of the run (see stream_kernel.hpp `window`): fw = symbol-reversed window, rc = complement
+            uint64_t fw = rev2(W0 & mask) >> (64u - 2u * k);
+            uint64_t rc = ~W0 & mask;
+            // the 15 symbols that enter afterwards: stream symbols K, K+1, ... of the run
+            const uint32_t S = (uint32_t)(k == 32u ? W1 : funnel64(W0, W1, 2u * k));
+            const uint32_t top = 2u * (k - 1u);
+            consume(fw, rc);
+            if (cnt == (uint32_t)RRUN) {
+#pragma unroll
+                for (uint32_t j = 1; j < (uint32_t)RRUN; ++j) {
+                    const uint64_t sym = (S >> (2u * (j - 1u))) & 3u;
+                    fw = ((fw << 2) | sym) & mask;            // shift_encoding, construction_utils.jl:129-134
+                    rc = (rc >> 2) | ((sym ^ 3u) << top);     // shift_first_encoding of the complement, kmer.jl:511-518
+                    consume(fw, rc);
+                }
+            } else {
+                for (uint32_t j = 1; j < cnt; ++j) {
+                    const uint64_t sym = (S >> (2u * (j - 1u))) & 3u;
+                    fw = ((fw << 2) | sym) & mask;
+                    rc = (rc >> 2) | ((sym ^ 3u) << top);
+                    consume(fw, rc);
+                }
+            }
+        }
+    }
+
+    if constexpr (RMODE == RMODE_XOR) {
+        // wavefront XOR-reduce (64 lanes), then one atomic per wave
+        for (int off = 32; off > 0; off >>= 1) xacc ^= __shfl_xor(xacc, off, 64);
+        if ((tid & 63u) == 0) atomicXor(reinterpret_cast<unsigned long long *>(a.out_a), (unsigned long long)xacc);
+    }
+}
+
+}  // namespace kmers
