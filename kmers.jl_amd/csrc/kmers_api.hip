@@ -28,6 +28,7 @@ struct kmers_ctx {
     bool own_stream = false;
     unsigned long long *d_err = nullptr;  // first offending symbol (0-based), ~0 = none
     uint64_t *d_scratch = nullptr;        // 64 words of device scratch
+    uint64_t *d_recent = nullptr;         // MinHash: table of recently appended candidate hashes (RECENT_SLOTS entries)
     uint8_t *d_luts = nullptr;            // 5 x 256 B: ascii_encode {2,4}-bit x {DNA,RNA}, then ASCII_SKIPPING_LUT
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_cap[4] = {0, 0, 0, 0};
@@ -462,7 +463,7 @@ int launch_fused(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, 
 // Fused consumers of one-word 2-bit kmers: the rolling run kernel (run_kernel.hpp); everything else
 // (two- to four-word kmers, 4-bit kmer alphabets) goes through the stream kernel's fused modes.
 template <int RMODE, int SMODE>
-int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, int dst_bits, StreamArgs &a) {
+int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, int dst_bits, StreamArgs &a, size_t best_bytes = 0) {
     if (dst_bits != 2 || k > 32) return launch_fused<SMODE>(ctx, seq, st, k, dst_bits, a);
     a.src = st.d_words;
     a.first_bit = st.first_bit;
@@ -476,9 +477,9 @@ int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int 
     a.n_tiles = (a.n_kmers + RTILE - 1) / RTILE;
     const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)ctx->n_cus * 8;  // persistent grid
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, resident)), block(RBLOCK);
-    if (seq->src_bits == 8) hipLaunchKernelGGL((run_kernel<8, RMODE>), grid, block, 0, ctx->stream, a);
-    else if (seq->src_bits == 4) hipLaunchKernelGGL((run_kernel<4, RMODE>), grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL((run_kernel<2, RMODE>), grid, block, 0, ctx->stream, a);
+    if (seq->src_bits == 8) hipLaunchKernelGGL((run_kernel<8, RMODE>), grid, block, best_bytes, ctx->stream, a);
+    else if (seq->src_bits == 4) hipLaunchKernelGGL((run_kernel<4, RMODE>), grid, block, best_bytes, ctx->stream, a);
+    else hipLaunchKernelGGL((run_kernel<2, RMODE>), grid, block, best_bytes, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return KMERS_OK;
 }
@@ -599,6 +600,7 @@ void kmers_ctx_destroy(kmers_ctx *ctx) {
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_luts) (void)hipFree(ctx->d_luts);
+    if (ctx->d_recent) (void)hipFree(ctx->d_recent);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -706,6 +708,13 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
     remember_source(ctx, seq, st);
 
+    constexpr uint32_t RECENT_SLOTS = 1u << 16;
+    if (!ctx->d_recent) {
+        hipError_t e = hipMalloc(&ctx->d_recent, (size_t)RECENT_SLOTS * 8);
+        if (e != hipSuccess) return fail(ctx, KMERS_E_NOMEM, "hipMalloc(recent candidates)", e);
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_recent, 0xFF, (size_t)RECENT_SLOTS * 8, ctx->stream));
+
     // ---- device-resident path (s <= 4096): the threshold and the running bottom-s set stay in HBM, a
     // one-workgroup bitonic sort/unique kernel prunes between chunks, every round is enqueued without a
     // host round trip.  Chunk r+1 is `ratio` times everything before it, which yields about ratio*s
@@ -722,12 +731,8 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
         uint64_t *d_state = d_best + 4096;                              // [n_best, threshold, overflow, counter]
         const uint64_t init_state[4] = {0, ~0ull, 0, 0};
         HIP_TRY(ctx, hipMemcpyAsync(d_state, init_state, sizeof init_state, hipMemcpyHostToDevice, ctx->stream));
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_prune_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, SKETCH_LDS_VALUES * 8));
-            attr_set = true;
-        }
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_prune_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, SKETCH_LDS_VALUES * 8));
         uint64_t done = 0, chunk = std::min<uint64_t>(n, dcap);         // first chunk: everything is a candidate
         while (done < n) {
             const uint64_t m = std::min<uint64_t>(chunk, n - done);
@@ -740,8 +745,12 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
             a.out_b = d_state + 3;
             a.seed = seed;
             a.threshold_ptr = d_state + 1;
+            a.best = d_best;
+            a.best_n_ptr = d_state;
+            a.recent = ctx->d_recent;
+            a.recent_mask = RECENT_SLOTS - 1;
             a.capacity = dcap;
-            if (int rc = launch_consumer<RMODE_SKETCH, MODE_SKETCH>(ctx, &view, vst, k, dst_bits, a)) return rc;
+            if (int rc = launch_consumer<RMODE_SKETCH, MODE_SKETCH>(ctx, &view, vst, k, dst_bits, a, (size_t)s * 8)) return rc;
             hipLaunchKernelGGL(sketch_prune_kernel, dim3(1), dim3(1024), SKETCH_LDS_VALUES * 8, ctx->stream, d_best, d_state,
                                d_cand, dcap, (uint32_t)s);
             HIP_TRY(ctx, hipGetLastError());
@@ -768,6 +777,8 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
     }
 
     // Candidate buffer in HBM; the host keeps the running bottom-s set (a few thousand values).
+    // (The table of recent candidates starts empty: a device-path attempt may have left entries behind.)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_recent, 0xFF, (size_t)RECENT_SLOTS * 8, ctx->stream));
     const uint64_t cap = std::max<uint64_t>((uint64_t)1 << 16, 8 * s);
     if (int rc = ensure_stage(ctx, 3, (size_t)(cap + 2) * 8)) return rc;
     uint64_t *d_cand = static_cast<uint64_t *>(ctx->stage[3]);
@@ -793,6 +804,8 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
         a.seed = seed;
         a.threshold = threshold;
         a.capacity = cap;
+        a.recent = ctx->d_recent;
+        a.recent_mask = RECENT_SLOTS - 1;
         if (int rc = launch_consumer<RMODE_SKETCH, MODE_SKETCH>(ctx, &view, vst, k, dst_bits, a)) return rc;
         uint64_t count = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&count, d_counter, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -808,7 +821,9 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
         if (best.size() > s) best.resize(s);
         if (best.size() == s) threshold = best.back();  // only values below the current s-th smallest matter
         if (count > cap) {
-            // buffer overflow (adversarial order): the threshold just tightened, redo this chunk
+            // buffer overflow (adversarial order): the threshold just tightened, redo this chunk.  Dropped
+            // candidates are in the table of recent ones but nowhere else: forget them.
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_recent, 0xFF, (size_t)RECENT_SLOTS * 8, ctx->stream));
             if (m > 1) chunk = std::max<uint64_t>(1, m / 2);
             continue;
         }

@@ -31,8 +31,17 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
         for (uint32_t i = tid; i < 256u; i += RBLOCK) lut[i] = a.ascii_lut[i];
     }
     uint64_t threshold = a.threshold;
+    // RMODE_SKETCH: a copy of the current bottom-s set, so that hashes it already holds are dropped here
+    // instead of filling the candidate buffer -- in low-complexity sequence (poly-A, short tandem repeats)
+    // the same few small hashes recur millions of times.
+    extern __shared__ uint64_t sbest[];
+    uint32_t nb = 0;
     if constexpr (RMODE == RMODE_SKETCH) {
         if (a.threshold_ptr) threshold = *a.threshold_ptr;  // uniform; constant for the whole launch
+        if (a.best) {
+            nb = (uint32_t)*a.best_n_ptr;
+            for (uint32_t i = tid; i < nb; i += RBLOCK) sbest[i] = a.best[i];  // visible after the tile loop's first barrier
+        }
     }
     const bool canonical = RMODE == RMODE_SKETCH || a.xor_canonical != 0;
     uint64_t xacc = 0;
@@ -60,15 +69,22 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
         }
     };
 
+    uint64_t prev_h = ~0ull;  // last candidate of this lane: a homopolymer run repeats one kmer
     auto consume = [&](uint64_t fw, uint64_t rc) {
         const uint64_t c = canonical ? (fw < rc ? fw : rc) : fw;  // CanonicalKmers.jl:220-225
         if constexpr (RMODE == RMODE_XOR) {
             xacc ^= c;
         } else {
             const uint64_t h = fx_step(a.seed, c);  // fx_hash of a one-word kmer (kmer.jl:255-261)
-            if (h < threshold) {
-                unsigned long long pos = atomicAdd(reinterpret_cast<unsigned long long *>(a.out_b), 1ull);
-                if (pos < a.capacity) a.out_a[pos] = h;
+            if (h < threshold && h != prev_h) {
+                prev_h = h;
+                uint32_t lo = 0, hi = nb;  // lower_bound(sbest, h)
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sbest[mid] < h) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo == nb || sbest[lo] != h) sketch_candidate(a, h);
             }
         }
     };

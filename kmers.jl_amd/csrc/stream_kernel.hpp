@@ -49,6 +49,10 @@ struct StreamArgs {
     uint64_t threshold;
     uint64_t capacity;
     const uint64_t *threshold_ptr;  // MODE_SKETCH, device-resident sketch: the running threshold in HBM
+    const uint64_t *best;           // run kernel, device-resident sketch: the current bottom-s set (ascending) ...
+    const uint64_t *best_n_ptr;     // ... and its size; hashes already in it are not candidates again
+    uint64_t *recent;               // MODE_SKETCH: direct-mapped table of recently appended hashes (see sketch_candidate)
+    uint32_t recent_mask;           // its size - 1 (a power of two)
     // MODE_MINIMIZER: window = `window_kmers` consecutive kmers per element, elements `stride` apart;
     //                 minimizer_mode 0 = the reference's published example, 1 = true sliding-window minimum
     uint32_t window_kmers;
@@ -235,6 +239,23 @@ __device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint6
     }
 }
 
+
+// MinHash candidate h (already below the threshold): append it to out[] through the counter unless
+// the same value was appended recently.  Low-complexity sequence (poly-A, tandem repeats) repeats
+// a few hashes millions of times; without this filter they flood the candidate buffer.  `recent`
+// is a direct-mapped table in HBM: a plain (L1-bypassing) load rejects repeats cheaply, the
+// exchange makes "first to insert appends" exact; a collision merely evicts (the evicted value may
+// be appended again later -- harmless, the sketch keeps distinct values).
+__device__ __forceinline__ void sketch_candidate(const StreamArgs &a, uint64_t h) {
+    if (a.recent && h != ~0ull) {  // ~0 marks an empty slot
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(a.recent) + ((uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 40) & a.recent_mask);
+        if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == h) return;
+        if (atomicExch(slot, (unsigned long long)h) == h) return;
+    }
+    unsigned long long pos = atomicAdd(reinterpret_cast<unsigned long long *>(a.out_b), 1ull);
+    if (pos < a.capacity) a.out_a[pos] = h;
+}
+
 template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1, bool TUPLES = false>
 __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     __shared__ uint64_t lds[LDS_QWORDS];
@@ -378,10 +399,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
                     for (uint32_t e = 0; e < KPL; ++e) {
                         if (e == 0 || both) {
                             const uint64_t h = fx_hash<N>(c[e], a.seed);
-                            if (h < sketch_threshold) {
-                                unsigned long long pos = atomicAdd(reinterpret_cast<unsigned long long *>(a.out_b), 1ull);
-                                if (pos < a.capacity) a.out_a[pos] = h;
-                            }
+                            if (h < sketch_threshold) sketch_candidate(a, h);
                         }
                     }
                 } else if constexpr (MODE == MODE_COUNT) {

@@ -567,6 +567,24 @@ def test_minhash_sketch(km, ctx, orc):
     _, eh, _ = orc.canonical(words, len(text), 4, 2, 21)
     exp = np.unique(eh)
     assert res.n_out == len(exp) <= 8 and np.array_equal(out[:len(exp)], exp)
+    # genome-like mix: random sequence interrupted by poly-A / poly-T runs and short tandem repeats, whose
+    # few small hashes (poly-A hashes to 0) recur throughout; they are dropped against the running sketch
+    rng = np.random.default_rng(11)
+    parts = []
+    for _ in range(300):
+        parts.append(naive.random_text(rng, int(rng.integers(2000, 12000))))
+        parts.append(str(rng.choice(["A", "T", "AC", "AAG", "ACGT"])) * int(rng.integers(200, 3000)))
+    text = "".join(parts)
+    for bits in (2, 4):
+        words = naive.longseq_words(text, bits)
+        seq, keep = make_seq(km, words, len(text), bits)
+        for K, s in ((16, 1000), (31, 200)):
+            out = np.zeros(s, dtype=np.uint64)
+            res = cap.Result()
+            assert ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, 2, 0, s, vp(out), cap.MEM_HOST, C.byref(res)) == 0
+            _, eh, _ = orc.canonical(words, len(text), bits, 2, K)
+            exp = np.unique(eh)[:s]
+            assert res.n_out == len(exp) and np.array_equal(out[:len(exp)], exp), (bits, K, s)
     # sorted (decreasing hash order would overflow a naive buffer) and an ambiguous symbol far into the sequence
     L = 2_000_000
     words = orc.synth_words(1, 0, (L * 4 + 63) // 64 + 1, 4).copy()
