@@ -31,9 +31,12 @@ struct CompactArgs {
     uint64_t n_bases;         // SRC_BITS == 8: every byte below n_bases is inspected (UnambiguousKmers.jl:117-123)
     uint32_t tuples;          // 1: out_kmers receives Tuple{Kmer,Int} elements (N + 1 words each), out_starts unused
     uint32_t group;           // tiles staged together per workgroup iteration (count pass: > 1, emit pass: 1)
+    uint32_t vec16;           // emit pass: out_kmers / out_starts are 16-byte aligned (16-byte stores allowed)
 };
 
-template <int SRC_BITS, int N>
+// DENSE: compiled with the no-compaction fast path for wavefronts whose starts are all kept (the host
+// picks it when at least 90 % of the starts survive; the extra code costs the sparse case 10 %)
+template <int SRC_BITS, int N, bool DENSE = false>
 __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a) {
     __shared__ uint64_t lds[LDS_QWORDS];
     __shared__ uint64_t amb[MAX_TILE_BASES / 64 + 8];
@@ -61,6 +64,10 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
         const uint64_t end_bit = bit0 + ((uint64_t)(mt - 1) + k) * SRC_BITS;
         const uint32_t nw = (uint32_t)(((end_bit + 63) >> 6) - w0);
 
+        // this wavefront's output offset of the group's first tile: requested now so that its latency
+        // overlaps the source loads (the emit pass runs with group == 1)
+        const uint64_t tile0 = grp * group;
+        const uint64_t pos_first = a.offsets[tile0 * WAVES + wave];
         __syncthreads();
         for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
             uint64_t x = a.src[w0 + wi];
@@ -95,8 +102,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
             const uint32_t per_wave = a.tile_kmers / WAVES;
             const uint32_t r_begin = j * a.tile_kmers + wave * per_wave;
             const uint32_t r_end = r_begin + per_wave < mt ? r_begin + per_wave : mt;  // r_begin may exceed mt in the last tile
-            uint64_t pos = 0;
-            pos = a.offsets[tile * WAVES + wave];
+            uint64_t pos = j == 0 ? pos_first : a.offsets[tile * WAVES + wave];
             // only starts on the stride lattice are candidates: the first one at or after r_begin
             // is r_first, then every `stride`-th (stride 1: every start)
             uint32_t r_first = r_begin;
@@ -105,6 +111,49 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
                 r_first = r_begin + (rem ? (uint32_t)(a.stride - rem) : 0u);
             }
             const uint32_t n_lat = r_first < r_end ? (r_end - r_first + a.stride - 1u) / a.stride : 0u;
+            if constexpr (N == 1 && DENSE) {
+                // Dense wavefront (every one of its starts is kept -- the normal state of real sequence
+                // outside its N blocks): no compaction; two consecutive kmers per lane (the second by the
+                // rolling step) and 16-byte stores aligned to the parity of the output position.
+                bool dense = false;
+                if (a.stride == 1 && a.vec16 && !a.tuples && n_lat) {
+                    // dense <=> no ambiguity flag over the symbols its windows cover (wave-uniform test in LDS,
+                    // so that the output offset is not needed before the stores)
+                    const uint32_t lo = r_first + b0, hi = r_first + n_lat - 1u + k + b0;  // symbol range [lo, hi)
+                    const uint32_t q = (lo >> 6) + lane;
+                    uint64_t word = 0;
+                    if (q <= ((hi - 1u) >> 6)) {
+                        word = amb[q];
+                        if (q == (lo >> 6)) word &= ~0ull << (lo & 63u);
+                        if (q == ((hi - 1u) >> 6) && (hi & 63u)) word &= (1ull << (hi & 63u)) - 1ull;
+                    }
+                    dense = __ballot(word != 0) == 0;
+                }
+                if (dense) {
+                    const uint64_t origin = m0 + 1 + a.index_origin;  // start of candidate r is origin + r
+                    const uint32_t head = (uint32_t)(pos & 1u);
+                    auto single = [&](uint32_t e) {
+                        uint64_t fw[1], rc[1];
+                        window<1, 2>(lds, 2u * (r_first + e + b0), k, mask, fw, rc);
+                        if (a.out_kmers) a.out_kmers[pos + e] = fw[0];
+                        if (a.out_starts) a.out_starts[pos + e] = (long long)(origin + r_first + e);
+                    };
+                    if (head && lane == 0) single(0);
+                    const uint32_t pairs = (n_lat - head) >> 1;
+                    for (uint32_t i = lane; i < pairs; i += 64u) {
+                        const uint32_t e = head + 2u * i;
+                        uint64_t f0, r0, sym;
+                        window1_and_next<2>(lds, 2u * (r_first + e + b0), k, mask, f0, r0, sym);
+                        const uint64_t f1 = ((f0 << 2) | sym) & mask;
+                        if (a.out_kmers) *reinterpret_cast<ulonglong2 *>(a.out_kmers + pos + e) = make_ulonglong2(f0, f1);
+                        if (a.out_starts)
+                            *reinterpret_cast<ulonglong2 *>(a.out_starts + pos + e) =
+                                make_ulonglong2(origin + r_first + e, origin + r_first + e + 1);
+                    }
+                    if (((n_lat - head) & 1u) && lane == 0) single(n_lat - 1);
+                    continue;
+                }
+            }
             const uint32_t passes = (n_lat + 63u) / 64u;  // wave-uniform
             for (uint32_t p = 0; p < passes; ++p) {
                 // the whole wave iterates together (ballot needs every lane); lanes past the end are invalid

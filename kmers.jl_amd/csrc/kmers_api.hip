@@ -387,7 +387,11 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         else hipLaunchKernelGGL((unambiguous_count_kernel<2>), cgrid, cblock, 0, ctx->stream, a);
     }
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap)), block(BLOCK);
-#define UL(SB, NN, EM) hipLaunchKernelGGL((unambiguous_kernel<SB, NN>), grid, block, 0, ctx->stream, a)
+#define UL(SB, NN, EM)                                                                                     \
+    do {                                                                                                   \
+        if (NN == 1 && dense_path) hipLaunchKernelGGL((unambiguous_kernel<SB, 1, true>), grid, block, 0, ctx->stream, a); \
+        else hipLaunchKernelGGL((unambiguous_kernel<SB, NN>), grid, block, 0, ctx->stream, a);             \
+    } while (0)
 #define UDISPATCH(EM)                                                         \
     do {                                                                      \
         if (seq->src_bits == 8) { if (nw == 1) UL(8, 1, EM); else UL(8, 2, EM); }      \
@@ -427,6 +431,8 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     }
     a.out_kmers = d_k;
     a.out_starts = d_s;
+    a.vec16 = ((!d_k || aligned16(d_k)) && (!d_s || aligned16(d_s))) ? 1u : 0u;
+    const bool dense_path = a.vec16 && stride == 1 && !tuples && total >= n - n / 10;  // mostly clean sequence
     a.tuples = tuples ? 1u : 0u;
     a.group = 1;
     UDISPATCH(true);

@@ -372,6 +372,32 @@ def run_unambiguous(km, ctx, words, L, bits, K, stride=1, origin=0):
     return kmers[:n], starts[:n]
 
 
+def test_unambiguous_device_outputs_any_alignment(km, ctx, orc):
+    """Device-resident outputs, dense and sparse survivors: mostly clean sequence takes the kernel variant
+    whose all-kept wavefronts skip compaction and store 16 bytes per lane (16-byte aligned outputs only);
+    buffers that are only 8-byte aligned, and sparse survivors, take the compacting path."""
+    cap = km._capi
+    L, K = 400_003, 21
+    for amb in (0, 2, 2621):  # p(N) = 0, 3e-5 (99.9 % of the starts kept), 0.04
+        words = orc.synth_words(21 + amb, 0, L // 16 + 1, 4, amb)
+        ek, es, _ = orc.unambiguous(words, L, 4, K)
+        n = len(ek)
+        d_src = ctx.alloc(len(words) * 8 + 16)
+        ctx.h2d(d_src, words)
+        seq = cap.Seq(d_src, L, 0, 0, 4, 0)
+        res = cap.Result()
+        d_k, d_s = ctx.alloc(n * 8 + 32), ctx.alloc(n * 8 + 32)
+        for shift in (0, 8):
+            rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, d_k + shift, d_s + shift, n, cap.MEM_DEVICE, C.byref(res))
+            assert rc == 0 and res.n_out == n, ctx.last_error()
+            kmers, starts = np.zeros(n, np.uint64), np.zeros(n, np.int64)
+            ctx.d2h(kmers, d_k + shift)
+            ctx.d2h(starts, d_s + shift)
+            assert np.array_equal(kmers, ek[:, 0]) and np.array_equal(starts, es), (amb, shift)
+        for d in (d_src, d_k, d_s):
+            ctx.free(d)
+
+
 def test_unambiguous_parity(km, ctx, orc):
     """UnambiguousKmers (UnambiguousKmers.jl:64-77, :134-148): windows and 1-based starts."""
     rng = np.random.default_rng(31)
