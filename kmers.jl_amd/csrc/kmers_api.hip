@@ -26,8 +26,11 @@ struct kmers_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    unsigned long long *d_err = nullptr;  // first offending symbol (0-based), ~0 = none
-    uint64_t *d_scratch = nullptr;        // 64 words of device scratch
+    uint64_t *d_scratch = nullptr;        // 64 words of device scratch; word 0: reduction result, word 1: the error slot
+    unsigned long long *d_err = nullptr;  // = d_scratch + 1: first offending symbol (0-based), ~0 = none
+    uint64_t *h_result = nullptr;         // pinned host mirror of scratch words 0..1: one small D2H copy per call
+    char *h_bounce = nullptr;             // pinned bounce buffer for short host-pointer calls (FASTA-record sized):
+                                          // [0, BOUNCE_IN) source words, [BOUNCE_IN, BOUNCE_IN + BOUNCE_OUT) outputs
     uint64_t *d_recent = nullptr;         // MinHash: table of recently appended candidate hashes (RECENT_SLOTS entries)
     uint8_t *d_luts = nullptr;            // 5 x 256 B: ascii_encode {2,4}-bit x {DNA,RNA}, then ASCII_SKIPPING_LUT
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -46,6 +49,10 @@ struct kmers_ctx {
 };
 
 namespace {
+
+// Pageable host memory costs HIP about 10-15 us per small copy (internal staging + waits); a call on a
+// short sequence with host pointers makes three of them.  Copies that fit go through pinned memory instead.
+constexpr size_t BOUNCE_IN = 256 << 10, BOUNCE_OUT = 1 << 20;
 
 int fail(kmers_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
     if (ctx) {
@@ -115,8 +122,12 @@ int stage_sequence(kmers_ctx *ctx, const kmers_seq *seq, int flags, Staged *out)
     if (seq->src_bits == 8) {  // bytes: copy exactly the view (the host pointer need not be aligned)
         size_t nbytes = (size_t)seq->n_bases;
         if (int rc = ensure_stage(ctx, 0, nbytes + 16)) return rc;
-        if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], reinterpret_cast<const char *>(seq->words) + seq->first_base,
-                                                nbytes, hipMemcpyHostToDevice, ctx->stream));
+        const void *from = reinterpret_cast<const char *>(seq->words) + seq->first_base;
+        if (nbytes && nbytes <= BOUNCE_IN) {
+            std::memcpy(ctx->h_bounce, from, nbytes);
+            from = ctx->h_bounce;
+        }
+        if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], from, nbytes, hipMemcpyHostToDevice, ctx->stream));
         out->d_words = static_cast<const uint64_t *>(ctx->stage[0]);
         out->first_bit = 0;
         return KMERS_OK;
@@ -125,17 +136,24 @@ int stage_sequence(kmers_ctx *ctx, const kmers_seq *seq, int flags, Staged *out)
     uint64_t w1 = (bit0 + seq->n_bases * (uint64_t)seq->src_bits + 63) >> 6;
     size_t bytes = (size_t)(w1 - w0) * 8;
     if (int rc = ensure_stage(ctx, 0, bytes + 8)) return rc;
-    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], seq->words + w0, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const void *from = seq->words + w0;
+    if (bytes && bytes <= BOUNCE_IN) {
+        std::memcpy(ctx->h_bounce, from, bytes);
+        from = ctx->h_bounce;
+    }
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], from, bytes, hipMemcpyHostToDevice, ctx->stream));
     out->d_words = static_cast<const uint64_t *>(ctx->stage[0]);
     out->first_bit = bit0 & 63u;
     return KMERS_OK;
 }
 
 // Wait for the stream and turn the device error slot into a kmers_result.
-int collect(kmers_ctx *ctx, kmers_result *res, uint64_t n_out) {
-    unsigned long long pos = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&pos, ctx->d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
+int collect(kmers_ctx *ctx, kmers_result *res, uint64_t n_out, uint64_t *value_out = nullptr) {
+    // one 16-byte copy into pinned memory: the reduction word (if any) and the error slot
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_scratch, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long pos = ctx->h_result[1];
+    if (value_out) *value_out = ctx->h_result[0];
     if (pos == NO_ERROR_POS) {
         if (res) {
             res->status = KMERS_OK;
@@ -324,11 +342,19 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
         if (res) { res->status = KMERS_OK; res->n_out = n; }
         return KMERS_OK;
     }
+    const size_t need_a = out_a ? bytes_a : 0, need_b = out_b ? bytes_b : 0;
+    const bool bounce = !dev && need_a + need_b <= BOUNCE_OUT;
+    char *h_a = ctx->h_bounce + BOUNCE_IN, *h_b = h_a + need_a;
     if (!dev) {
-        if (out_a) HIP_TRY(ctx, hipMemcpyAsync(out_a, d_a, bytes_a, hipMemcpyDeviceToHost, ctx->stream));
-        if (out_b) HIP_TRY(ctx, hipMemcpyAsync(out_b, d_b, bytes_b, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_a) HIP_TRY(ctx, hipMemcpyAsync(bounce ? (void *)h_a : (void *)out_a, d_a, bytes_a, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_b) HIP_TRY(ctx, hipMemcpyAsync(bounce ? (void *)h_b : (void *)out_b, d_b, bytes_b, hipMemcpyDeviceToHost, ctx->stream));
     }
-    return collect(ctx, res, n);
+    rc = collect(ctx, res, n);
+    if (rc == KMERS_OK && bounce) {
+        if (out_a) std::memcpy(out_a, h_a, bytes_a);
+        if (out_b) std::memcpy(out_b, h_b, bytes_b);
+    }
+    return rc;
 }
 
 // UnambiguousKmers: count -> scan -> emit (compact_kernels.hpp)
@@ -585,7 +611,9 @@ int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out) {
     build_ascii_encode_table(4, false, luts + 512);
     build_ascii_encode_table(4, true, luts + 768);
     build_ascii_skipping_table(luts + 1024);
-    if (hipMalloc(&ctx->d_err, 8) != hipSuccess || hipMalloc(&ctx->d_scratch, 64 * 8) != hipSuccess ||
+    if (hipMalloc(&ctx->d_scratch, 64 * 8) != hipSuccess || hipHostMalloc(&ctx->h_result, 64, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(&ctx->h_bounce, BOUNCE_IN + BOUNCE_OUT, hipHostMallocDefault) != hipSuccess ||
+        (ctx->d_err = reinterpret_cast<unsigned long long *>(ctx->d_scratch + 1)) == nullptr ||
         hipMalloc(&ctx->d_luts, sizeof luts) != hipSuccess ||
         hipMemcpy(ctx->d_luts, luts, sizeof luts, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream) != hipSuccess ||
@@ -603,8 +631,9 @@ void kmers_ctx_destroy(kmers_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &p : ctx->stage)
         if (p) (void)hipFree(p);
-    if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_result) (void)hipHostFree(ctx->h_result);
+    if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
     if (ctx->d_luts) (void)hipFree(ctx->d_luts);
     if (ctx->d_recent) (void)hipFree(ctx->d_recent);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -694,8 +723,7 @@ int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, 
     a.out_a = ctx->d_scratch;
     a.xor_canonical = canonical ? 1u : 0u;
     if (int rc = launch_consumer<RMODE_XOR, MODE_XOR>(ctx, seq, st, k, dst_bits, a)) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out_value, ctx->d_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
-    return collect(ctx, res, n);
+    return collect(ctx, res, n, out_value);
 }
 
 int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t seed, uint64_t s,
@@ -719,7 +747,10 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
         hipError_t e = hipMalloc(&ctx->d_recent, (size_t)RECENT_SLOTS * 8);
         if (e != hipSuccess) return fail(ctx, KMERS_E_NOMEM, "hipMalloc(recent candidates)", e);
     }
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_recent, 0xFF, (size_t)RECENT_SLOTS * 8, ctx->stream));
+    // (a sequence that fits one round needs no duplicate filter: everything is a candidate once and the
+    // prune kernel deduplicates)
+    const bool one_round = n <= SKETCH_LDS_VALUES - 4096;
+    if (!one_round) HIP_TRY(ctx, hipMemsetAsync(ctx->d_recent, 0xFF, (size_t)RECENT_SLOTS * 8, ctx->stream));
 
     // ---- device-resident path (s <= 4096): the threshold and the running bottom-s set stay in HBM, a
     // one-workgroup bitonic sort/unique kernel prunes between chunks, every round is enqueued without a
@@ -735,8 +766,8 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
         uint64_t *d_cand = static_cast<uint64_t *>(ctx->stage[3]);
         uint64_t *d_best = d_cand + dcap;
         uint64_t *d_state = d_best + 4096;                              // [n_best, threshold, overflow, counter]
-        const uint64_t init_state[4] = {0, ~0ull, 0, 0};
-        HIP_TRY(ctx, hipMemcpyAsync(d_state, init_state, sizeof init_state, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(d_state, 0, 32, ctx->stream));       // {0, ~0, 0, 0} without a pageable H2D copy
+        HIP_TRY(ctx, hipMemsetAsync(d_state + 1, 0xFF, 8, ctx->stream));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_prune_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, SKETCH_LDS_VALUES * 8));
         uint64_t done = 0, chunk = std::min<uint64_t>(n, dcap);         // first chunk: everything is a candidate
@@ -753,7 +784,7 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
             a.threshold_ptr = d_state + 1;
             a.best = d_best;
             a.best_n_ptr = d_state;
-            a.recent = ctx->d_recent;
+            a.recent = one_round ? nullptr : ctx->d_recent;
             a.recent_mask = RECENT_SLOTS - 1;
             a.capacity = dcap;
             if (int rc = launch_consumer<RMODE_SKETCH, MODE_SKETCH>(ctx, &view, vst, k, dst_bits, a, (size_t)s * 8)) return rc;
@@ -763,16 +794,18 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
             done += m;
             chunk = std::max<uint64_t>(dcap / 2, ratio * done);
         }
-        uint64_t h_state[4];
-        HIP_TRY(ctx, hipMemcpyAsync(h_state, d_state, sizeof h_state, hipMemcpyDeviceToHost, ctx->stream));
+        // results through pinned memory, one wait: state, the error slot, and (optimistically) the sketch
+        uint64_t *h_state = reinterpret_cast<uint64_t *>(ctx->h_bounce), *h_best = h_state + 8;
+        HIP_TRY(ctx, hipMemcpyAsync(h_state, d_state, 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h_state + 4, ctx->d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h_best, d_best, (size_t)s * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         // an EncodeError anywhere in the sequence: report the first one (positions are relative to a chunk,
         // so re-run the feedback path, which attributes it exactly)
-        unsigned long long epos = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&epos, ctx->d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const unsigned long long epos = h_state[4];
         if (epos == NO_ERROR_POS && h_state[2] == 0) {
             const uint64_t nb = h_state[0];
-            if (nb) HIP_TRY(ctx, hipMemcpy(out_hashes, d_best, nb * 8, hipMemcpyDeviceToHost));
+            if (nb) std::memcpy(out_hashes, h_best, nb * 8);
             if (res) { res->status = KMERS_OK; res->n_out = nb; }
             return KMERS_OK;
         }
