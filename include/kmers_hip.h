@@ -183,6 +183,33 @@ int kmers_fx_hash(kmers_ctx *ctx, const uint64_t *kmers, int n_words, uint64_t n
 int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bits, uint64_t n,
                     uint64_t *out, int flags);
 
+/* ---- batches of records (reads, contigs, FASTA records) ------------------------------------ */
+/* The reference iterates one sequence at a time (`for record in reader ... CanonicalDNAMers{K}(seq)`,
+ * docs/src/minhash.md:31-35); a GPU call has a fixed cost of ~16 us, so short records go many at a
+ * time.  `pool` holds the symbols of all records (any layout: concatenated LongSequence data words,
+ * a FASTA buffer, ...); record i is the view [spans[i].first_base, +n_bases) of the pool, exactly a
+ * LongSubSeq.  One call produces, concatenated in record order, what the per-record iterator
+ * would: mode KMERS_BATCH_FW = FwKmers (out_a) and their reverse complements (out_b, nullable:
+ * FwRvIterator); mode KMERS_BATCH_CANONICAL = CanonicalKmers (out_a) and fx_hash(kmer, seed)
+ * (out_b, nullable).  out_offsets (host memory, n_spans + 1 entries, nullable) receives the element
+ * offset of every record (records shorter than k yield nothing and are never inspected,
+ * FwKmers.jl:63).  capacity = elements out_a / out_b can hold; if the batch needs more the call
+ * returns KMERS_E_CAPACITY with res->n_out = the number required (capacity 0 + NULL outputs = a size
+ * query).  KMERS_MEM_DEVICE applies to pool->words, out_a and out_b; out_offsets is always host memory;
+ * spans is host memory unless KMERS_SPANS_DEVICE is set (tens of millions of reads: keep them resident).  Kmers of one or two words (K <= 64 two-bit, K <= 32 four-bit).
+ * EncodeError: the first failing record in batch order wins, res->err_pos = 1-based position inside
+ * THAT record, res->err_enc = the raw symbol, res->n_out = the record's index in spans[]. */
+typedef struct {
+    uint64_t first_base; /* 0-based symbol offset of the record inside the pool view */
+    uint64_t n_bases;
+} kmers_span;
+#define KMERS_SPANS_DEVICE 8 /* flag of kmers_batch: `spans` points to HBM */
+#define KMERS_BATCH_FW 0
+#define KMERS_BATCH_CANONICAL 1
+int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int mode, int k,
+                int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
+                uint64_t capacity, int flags, kmers_result *res);
+
 /* ---- sharding one long sequence over the GPUs of a node ------- */
 /* The reference has no distributed code; kmer i depends only on symbols [i*stride, i*stride + k),
  * so shard g owns a contiguous range of kmers (in iteration order) whose first symbol sits on a

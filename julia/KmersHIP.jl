@@ -267,6 +267,59 @@ function Kmers.as_integer(v::Vector{Kmer{A, K, N}}) where {A <: NucleicAcidAlpha
     return out
 end
 
+# ---- batches of records: one launch for many short sequences ------------------------------------
+struct CSpan
+    first_base::UInt64
+    n_bases::UInt64
+end
+
+"""
+    collect_batch(CanonicalKmers{A,K}, seqs; hashes = false, seed = 0x0)
+    collect_batch(FwKmers{A,K}, seqs)
+
+`vcat((collect(It(s)) for s in seqs)...)` from one GPU launch (`kmers_batch`), plus the element offset of
+every record.  `seqs`: LongSequences of one alphabet.  The records' data words are concatenated into one
+pool (each record starts on a word boundary; a record is a view `(first_base, n_bases)` of the pool).
+Returns `(kmers, hashes_or_nothing, offsets)`; record `i` owns `kmers[offsets[i]+1 : offsets[i+1]]`.
+"""
+function collect_batch(::Type{It}, seqs::Vector{<:LongSequence}; hashes::Bool = false, seed::UInt = zero(UInt)) where {A, K, It <: Union{FwKmers{A, K}, CanonicalKmers{A, K}}}
+    ctx = context()
+    T = Kmers.derive_type(Kmer{A, K})
+    isempty(seqs) && return (T[], hashes ? UInt64[] : nothing, UInt64[0])
+    sbits = BioSequences.bits_per_symbol(Alphabet(first(seqs)))
+    per = 64 ÷ sbits
+    pool = UInt64[]
+    spans = Vector{CSpan}(undef, length(seqs))
+    for (i, s) in enumerate(seqs)
+        spans[i] = CSpan(length(pool) * per, length(s))
+        append!(pool, s.data)
+    end
+    push!(pool, zero(UInt64))
+    seq = CSeq(pointer(pool), (length(pool) - 1) * per, 0, 0, Int32(sbits), 0)
+    mode = It <: CanonicalKmers ? Int32(1) : Int32(0)
+    offsets = Vector{UInt64}(undef, length(seqs) + 1)
+    res = CResult()
+    call(out_a, out_b, cap) = GC.@preserve pool spans offsets begin
+        @ccall LIB.kmers_batch(ctx.handle::Ptr{Cvoid}, Ref(seq)::Ptr{CSeq}, pointer(spans)::Ptr{CSpan}, length(seqs)::UInt64,
+                               mode::Cint, K::Cint, dst_bits(A)::Cint, out_a::Ptr{Cvoid}, out_b::Ptr{Cvoid}, seed::UInt64,
+                               pointer(offsets)::Ptr{UInt64}, cap::UInt64, MEM_HOST::Cint, Ref(res)::Ptr{CResult})::Cint
+    end
+    rc = call(C_NULL, C_NULL, 0)                      # size query
+    rc == OK || error("kmers_batch: status $rc: $(last_error(ctx))")
+    total = Int(res.n_out)
+    kmers = Vector{T}(undef, total)
+    hs = hashes && mode == 1 ? Vector{UInt64}(undef, total) : nothing
+    GC.@preserve kmers hs begin
+        rc = call(pointer(kmers), hs === nothing ? C_NULL : pointer(hs), total)
+    end
+    if rc == E_ENCODE    # res.n_out = index of the failing record; the reference would have thrown there
+        bad = seqs[Int(res.n_out) + 1]
+        throw(BioSequences.EncodeError(A(), reinterpret(eltype(bad), res.err_enc % UInt8)))
+    end
+    rc == OK || error("kmers_batch: status $rc: $(last_error(ctx))")
+    return (kmers, hs, offsets)
+end
+
 # ---- sharding one long sequence over several GPUs / processes ---------------------------------
 struct CShard
     first_kmer::UInt64

@@ -11,6 +11,8 @@ from . import build as _build
 
 OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY = range(7)
 MEM_HOST, MEM_DEVICE, ASYNC, OUT_TUPLES = 0, 1, 2, 4
+BATCH_FW, BATCH_CANONICAL = 0, 1
+SPANS_DEVICE = 8
 (OP_REVERSE, OP_COMPLEMENT, OP_REVCOMP, OP_CANONICAL, OP_ISCANONICAL, OP_TO_LONGSEQ, OP_COUNT_GC, OP_AS_INTEGER,
  OP_FROM_INTEGER) = range(9)
 PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY = 1, 2, 3, 4
@@ -23,6 +25,10 @@ STATUS_NAMES = {OK: "KMERS_OK", E_ENCODE: "KMERS_E_ENCODE", E_BADARG: "KMERS_E_B
 class Result(C.Structure):
     _fields_ = [("status", C.c_int32), ("err_enc", C.c_uint32), ("err_pos", C.c_uint64),
                 ("n_out", C.c_uint64)]
+
+
+class Span(C.Structure):
+    _fields_ = [("first_base", C.c_uint64), ("n_bases", C.c_uint64)]
 
 
 class Seq(C.Structure):
@@ -59,6 +65,7 @@ SYMBOLS = {
     "kmers_composition": (C.c_int, [_P, _S, C.c_int, _P, C.c_int, _R]),
     "kmers_fx_hash": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int]),
     "kmers_transform": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_uint64, _P, C.c_int]),
+    "kmers_batch": (C.c_int, [_P, _S, _P, C.c_uint64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_uint64, _P, C.c_uint64, C.c_int, _R]),
     "kmers_shard_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
     "kmers_synth_dna": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _P]),
 }

@@ -346,11 +346,11 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restr
     }
     __syncthreads();
     // thread t owns 8 consecutive counts: local exclusive prefix, then a scan over the thread totals
-    uint32_t local[SCAN_SEG / 256];
+    uint64_t local[SCAN_SEG / 256];  // 64-bit: kmers_batch scans per-record counts of up to 2^32 - 1
     uint64_t sum = 0;
 #pragma unroll
     for (uint32_t j = 0; j < SCAN_SEG / 256; ++j) {
-        local[j] = (uint32_t)sum;
+        local[j] = sum;
         sum += c[t * (SCAN_SEG / 256) + j];
     }
     uint64_t incl = sum;

@@ -17,6 +17,7 @@
 #include "batch_kernels.hpp"
 #include "compact_kernels.hpp"
 #include "composition_kernel.hpp"
+#include "ragged_kernels.hpp"
 #include "run_kernel.hpp"
 #include "stream_kernel.hpp"
 
@@ -33,8 +34,8 @@ struct kmers_ctx {
                                           // [0, BOUNCE_IN) source words, [BOUNCE_IN, BOUNCE_IN + BOUNCE_OUT) outputs
     uint64_t *d_recent = nullptr;         // MinHash: table of recently appended candidate hashes (RECENT_SLOTS entries)
     uint8_t *d_luts = nullptr;            // 5 x 256 B: ascii_encode {2,4}-bit x {DNA,RNA}, then ASCII_SKIPPING_LUT
-    void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t stage_cap[4] = {0, 0, 0, 0};
+    void *stage[8] = {};      // 0 source, 1-2 outputs, 3 metadata / scratch, 4-5 recoded stream / flags, 6 tile index
+    size_t stage_cap[8] = {};
     std::string last_error;
     // what the most recent launch read, for decoding an EncodeError at sync time
     const uint64_t *err_words = nullptr;  // DEVICE pointer of the staged / resident words
@@ -982,6 +983,185 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
     }
     if (!dev) HIP_TRY(ctx, hipMemcpyAsync(out_counts, d_counts, bins * 4, hipMemcpyDeviceToHost, ctx->stream));
     return collect(ctx, res, n);
+}
+
+int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int mode, int k,
+                int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
+                uint64_t capacity, int flags, kmers_result *res) {
+    clear(res);
+    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE))) {
+        if (res) res->status = rc;
+        return rc;
+    }
+    if (flags & (KMERS_ASYNC | KMERS_OUT_TUPLES)) return fail(ctx, KMERS_E_BADARG, "kmers_batch is synchronous and writes separate arrays");
+    if (mode != KMERS_BATCH_FW && mode != KMERS_BATCH_CANONICAL) return fail(ctx, KMERS_E_BADARG, "unknown batch mode");
+    if (n_spans && !spans) return fail(ctx, KMERS_E_BADARG, "spans is NULL");
+    const int nw = kmers_words_per_kmer(k, dst_bits);
+    if (nw > 2) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_batch supports kmers of one or two words");
+    if (n_spans >= 0xFFFFFFFFull) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_batch supports fewer than 2^32 records per call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // ---- the ragged layout, on the device: spans -> HBM, elements per record, exclusive scan
+    const uint64_t n = n_spans;
+    if (n == 0) {
+        if (out_offsets) out_offsets[0] = 0;
+        return KMERS_OK;
+    }
+    const uint64_t n_seg = (n + SCAN_SEG - 1) / SCAN_SEG;
+    const size_t span_bytes = (size_t)n * 16, cnt_bytes = ((size_t)n * 4 + 15) & ~(size_t)15, off_bytes = ((size_t)n + 1) * 8,
+                 seg_bytes = ((size_t)n_seg + 2) * 8;
+    const bool spans_dev = (flags & KMERS_SPANS_DEVICE) != 0;
+    if (int rc = ensure_stage(ctx, 3, span_bytes + cnt_bytes + off_bytes + seg_bytes)) return rc;
+    char *meta = static_cast<char *>(ctx->stage[3]);
+    const RaggedSpan *d_spans = spans_dev ? reinterpret_cast<const RaggedSpan *>(spans) : reinterpret_cast<const RaggedSpan *>(meta);
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(meta + span_bytes);
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(meta + span_bytes + cnt_bytes);
+    uint64_t *d_seg = reinterpret_cast<uint64_t *>(meta + span_bytes + cnt_bytes + off_bytes);  // [n_seg + 1], then the bad-span flag
+    uint64_t *d_bad = d_seg + n_seg + 1;
+    if (!spans_dev) HIP_TRY(ctx, hipMemcpyAsync(meta, spans, span_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+    {
+        dim3 g((unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->n_cus * 16)), b(256);
+        hipLaunchKernelGGL(ragged_count_kernel, g, b, 0, ctx->stream, d_spans, n, (uint32_t)k, pool->n_bases, d_cnt, d_bad);
+        hipLaunchKernelGGL(scan_segment_sums_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, d_cnt, n, d_seg);
+        hipLaunchKernelGGL(scan_segments_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_seg, n_seg);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, d_cnt, n, d_seg, n_seg, d_off);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    uint64_t *h = reinterpret_cast<uint64_t *>(ctx->h_bounce);  // pinned: [total, bad]
+    HIP_TRY(ctx, hipMemcpyAsync(h, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + 1, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_offsets) HIP_TRY(ctx, hipMemcpyAsync(out_offsets, d_off, off_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t total = h[0];
+    if (h[1]) return fail(ctx, KMERS_E_BADARG, "a span reaches outside the pool (or holds 2^32 symbols or more)");
+    if (res) res->n_out = total;
+    if (total > capacity || (!out_a && !out_b)) {
+        if (total > capacity && (out_a || out_b)) {
+            if (res) res->status = KMERS_E_CAPACITY;
+            return fail(ctx, KMERS_E_CAPACITY, "output capacity too small");
+        }
+        return KMERS_OK;  // size query
+    }
+    if (total == 0) return KMERS_OK;
+    const uint64_t n_tiles = (total + RG_TILE - 1) / RG_TILE;
+    if (int rc = ensure_stage(ctx, 6, (size_t)n_tiles * 4 + 16)) return rc;
+    uint32_t *d_tile_rec = static_cast<uint32_t *>(ctx->stage[6]);
+    hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_off, n, n_tiles,
+                       d_tile_rec);
+    HIP_TRY(ctx, hipGetLastError());
+
+    Staged st;
+    if (int rc = stage_sequence(ctx, pool, flags, &st)) return rc;
+    const bool dev = flags & KMERS_MEM_DEVICE;
+    const int sb = pool->src_bits;
+    const uint64_t *src0 = st.d_words + (st.first_bit >> 6);        // word that holds pool symbol 0
+    const uint64_t origin = (st.first_bit & 63u) / (uint64_t)sb;     // its symbol offset inside that word
+    const uint64_t n_src_words = ((origin + pool->n_bases) * (uint64_t)sb + 63) / 64;
+
+    RaggedArgs a{};
+    a.rec_off = d_off;
+    a.spans = d_spans;
+    a.tile_rec = d_tile_rec;
+    a.n_records = n;
+    a.n_elems = total;
+    a.seed = seed;
+    a.err_slot = ctx->d_err;
+    a.k = (uint32_t)k;
+    a.stream_origin = origin;
+    if (sb == dst_bits) {  // Copyable: the pool is the stream, nothing can fail
+        a.stream = src0;
+        a.flags = nullptr;
+    } else {
+        const size_t stream_bytes = (size_t)n_src_words * 8 * dst_bits / sb + 16, flag_bytes = (size_t)n_src_words * 8 / sb + 16;
+        if (int rc = ensure_stage(ctx, 4, stream_bytes)) return rc;
+        RecodeArgs r{};
+        r.src = src0;
+        r.n_words = n_src_words;
+        r.stream = static_cast<uint64_t *>(ctx->stage[4]);
+        r.ascii_lut = ascii_table(ctx, dst_bits, pool->alphabet != 0);
+        if (sb != 2) {
+            if (int rc = ensure_stage(ctx, 5, flag_bytes)) return rc;
+            r.flags = static_cast<uint64_t *>(ctx->stage[5]);
+        }
+        dim3 rgrid((unsigned)std::min<uint64_t>((n_src_words + 255) / 256, (uint64_t)ctx->n_cus * 16)), rblock(256);
+        if (sb == 4) hipLaunchKernelGGL((recode_kernel<4, 2>), rgrid, rblock, 0, ctx->stream, r);
+        else if (sb == 2) hipLaunchKernelGGL((recode_kernel<2, 4>), rgrid, rblock, 0, ctx->stream, r);
+        else if (dst_bits == 2) hipLaunchKernelGGL((recode_kernel<8, 2>), rgrid, rblock, 0, ctx->stream, r);
+        else hipLaunchKernelGGL((recode_kernel<8, 4>), rgrid, rblock, 0, ctx->stream, r);
+        HIP_TRY(ctx, hipGetLastError());
+        a.stream = r.stream;
+        a.flags = r.flags;
+    }
+
+    uint64_t *d_a = out_a, *d_b = out_b;
+    const bool b_is_hash = mode == KMERS_BATCH_CANONICAL;
+    const size_t bytes_a = (size_t)total * nw * 8, bytes_b = (size_t)total * (b_is_hash ? 1 : nw) * 8;
+    if (!dev) {
+        if (out_a) { if (int rc = ensure_stage(ctx, 1, bytes_a)) return rc; d_a = (uint64_t *)ctx->stage[1]; }
+        if (out_b) { if (int rc = ensure_stage(ctx, 2, bytes_b)) return rc; d_b = (uint64_t *)ctx->stage[2]; }
+    }
+    if (nw == 2 && ((d_a && !aligned16(d_a)) || (d_b && !b_is_hash && !aligned16(d_b))))
+        return fail(ctx, KMERS_E_BADARG, "two-word kmer outputs must be 16-byte aligned");
+    a.out_a = d_a;
+    a.out_b = d_b;
+    const bool vec = (!d_a || aligned16(d_a)) && (!d_b || aligned16(d_b));
+    dim3 grid((unsigned)n_tiles), block(256);
+#define RG(DB, NN, MD)                                                                                         \
+    do {                                                                                                       \
+        if (vec) hipLaunchKernelGGL((ragged_kernel<DB, NN, MD, true>), grid, block, 0, ctx->stream, a);       \
+        else hipLaunchKernelGGL((ragged_kernel<DB, NN, MD, false>), grid, block, 0, ctx->stream, a);          \
+    } while (0)
+#define RGM(DB, NN) do { if (mode == KMERS_BATCH_FW) RG(DB, NN, MODE_FW); else RG(DB, NN, MODE_CANON); } while (0)
+    if (dst_bits == 2) { if (nw == 1) RGM(2, 1); else RGM(2, 2); }
+    else               { if (nw == 1) RGM(4, 1); else RGM(4, 2); }
+#undef RGM
+#undef RG
+    HIP_TRY(ctx, hipGetLastError());
+    if (!dev) {
+        if (out_a) HIP_TRY(ctx, hipMemcpyAsync(out_a, d_a, bytes_a, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_b) HIP_TRY(ctx, hipMemcpyAsync(out_b, d_b, bytes_b, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_scratch, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t g = ctx->h_result[1];
+    if (g == NO_ERROR_POS) {
+        if (res) res->status = KMERS_OK;
+        return KMERS_OK;
+    }
+    // EncodeError: element g is the first one whose window holds a symbol the kmer alphabet cannot encode;
+    // all earlier windows of its record were clean, so its first bad symbol is the record's first
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream));
+    std::vector<uint64_t> offs(n + 1);  // rare path: find the record on the host
+    HIP_TRY(ctx, hipMemcpyAsync(offs.data(), d_off, off_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t r = (uint64_t)(std::upper_bound(offs.begin(), offs.begin() + n, g) - offs.begin()) - 1;  // last record with off <= g
+    const uint64_t j = g - offs[r];                           // 0-based start of the window inside the record
+    kmers_span bad_span;
+    HIP_TRY(ctx, hipMemcpy(&bad_span, d_spans + r, sizeof bad_span, hipMemcpyDeviceToHost));
+    const uint64_t p0 = bad_span.first_base + j + origin;     // symbol index from src0
+    const uint64_t wlo = p0 * sb / 64, whi = ((p0 + k) * sb + 63) / 64;
+    std::vector<uint64_t> w(whi - wlo);
+    HIP_TRY(ctx, hipMemcpyAsync(w.data(), src0 + wlo, w.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint8_t table[256];
+    if (sb == 8) build_ascii_encode_table(dst_bits, pool->alphabet != 0, table);
+    for (uint64_t t = 0; t < (uint64_t)k; ++t) {
+        const uint64_t bit = (p0 + t) * sb - wlo * 64;
+        const uint32_t enc = (uint32_t)((w[bit >> 6] >> (bit & 63u)) & ((1ull << sb) - 1ull));
+        const bool bad = sb == 8 ? table[enc] == 0x80 : (sb == 4 && dst_bits == 2 && __builtin_popcount(enc) != 1);
+        if (bad) {
+            if (res) {
+                res->status = KMERS_E_ENCODE;
+                res->err_pos = j + t + 1;
+                res->err_enc = enc;
+                res->n_out = r;
+            }
+            ctx->last_error = "EncodeError: symbol cannot be encoded in the kmer alphabet";
+            return KMERS_E_ENCODE;
+        }
+    }
+    return fail(ctx, KMERS_E_HIP, "kmers_batch: a flagged window holds no offending symbol");
 }
 
 int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uint64_t *out_kmers,

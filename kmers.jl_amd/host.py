@@ -390,13 +390,23 @@ def _raise_encode(alphabet, seq, res):
     raise EncodeError(alphabet, sym, int(res.err_pos), int(res.err_enc))
 
 
+class _Bound:
+    """A parametrised iterator type, e.g. `CanonicalKmers[DNAAlphabet[2], 31]`: call it with a sequence."""
+
+    def __init__(self, cls, params):
+        self.cls, self.params = cls, params
+
+    def __call__(self, seq, ctx=None, **kw):
+        return self.cls(*self.cls._expand(self.params), seq, ctx=ctx, **kw)
+
+
 class _Parametric(type):
     """`Iterator[params](seq)` stands for Julia's `Iterator{params}(seq)`."""
 
     def __getitem__(cls, params):
         if not isinstance(params, tuple):
             params = (params,)
-        return lambda seq, ctx=None: cls(*cls._expand(params), seq, ctx=ctx)
+        return _Bound(cls, params)
 
 
 class AbstractKmerIterator(metaclass=_Parametric):
@@ -665,7 +675,7 @@ def _alias(cls, fam):
         def __getitem__(self, params):
             if not isinstance(params, tuple):
                 params = (params,)
-            return lambda seq, ctx=None, **kw: cls(fam[2], *params, seq, ctx=ctx, **kw)
+            return _Bound(cls, (fam[2],) + params)
     return _A()
 
 
@@ -697,6 +707,68 @@ DNA, RNA = "DNA", "RNA"
 
 def collect(it):
     return it.collect()
+
+
+def collect_batch(iterator, records, hashes=False, seed=0, ctx=None):
+    """Elements of `iterator(record)` for every record of a batch, concatenated in record order, from
+    ONE launch (include/kmers_hip.h `kmers_batch`): the reference's `for record in reader ...
+    CanonicalDNAMers{K}(sequence(record))` loop (docs/src/minhash.md:31-35) without the per-call cost.
+
+    iterator: a parametrised iterator type, e.g. `CanonicalDNAMers[31]`, `FwDNAMers[21]`,
+              `FwRvIterator[DNAAlphabet[2], 31]`.
+    records:  LongSequences of one alphabet, or str / bytes records (ASCII).
+    Returns (first, second, offsets): FwKmers -> (kmers, None, offsets); FwRvIterator -> (kmers,
+    reverse complements, offsets); CanonicalKmers -> (kmers, fx_hash values if `hashes` else None,
+    offsets).  Record i owns elements offsets[i]:offsets[i+1]."""
+    ctx = ctx or default_context()
+    cls, params = getattr(iterator, "cls", None), getattr(iterator, "params", None)
+    if cls not in (FwKmers, FwRvIterator, CanonicalKmers):
+        raise UnsupportedError("collect_batch(FwKmers / FwRvIterator / CanonicalKmers [alphabet, K], records)")
+    alphabet, K = cls._expand(params)
+    recs = [_as_sequence(r) for r in records]
+    src_bits = recs[0].src_bits if recs else 2
+    if any(r.src_bits != src_bits for r in recs):
+        raise UnsupportedError("all records of a batch must share one source type")
+    spans = (_capi.Span * max(len(recs), 1))()
+    if src_bits == 8:
+        pool = np.concatenate([r.data[:r.len] for r in recs] + [np.zeros(16, np.uint8)]) if recs else np.zeros(16, np.uint8)
+        pos = 0
+        for i, r in enumerate(recs):
+            spans[i] = _capi.Span(pos, r.len)
+            pos += r.len
+        n_pool = pos
+        pool = np.ascontiguousarray(pool)
+    else:
+        per = 64 // src_bits
+        pool = np.concatenate([r.data for r in recs] + [np.zeros(1, np.uint64)]) if recs else np.zeros(1, np.uint64)
+        w = 0
+        for i, r in enumerate(recs):
+            spans[i] = _capi.Span(w * per, r.len)
+            w += len(r.data)
+        n_pool = w * per
+    seq = _capi.Seq(pool.ctypes.data, n_pool, 0, 0, src_bits, 1 if alphabet.kind == "RNA" else 0)
+    res = _capi.Result()
+    offsets = np.zeros(len(recs) + 1, dtype=np.uint64)
+    mode = _capi.BATCH_CANONICAL if cls is CanonicalKmers else _capi.BATCH_FW
+    N = n_coding_elements(K, alphabet.bits)
+    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(recs), mode, K, alphabet.bits, None, None, seed & MASK64,
+                             offsets.ctypes.data_as(C.c_void_p), 0, _capi.MEM_HOST, C.byref(res))
+    ctx.check(rc, "kmers_batch")
+    total = int(res.n_out)
+    first = np.zeros((max(total, 1), N), dtype=np.uint64)
+    want_second = cls is FwRvIterator or (cls is CanonicalKmers and hashes)
+    second = np.zeros((max(total, 1), 1 if cls is CanonicalKmers else N), dtype=np.uint64) if want_second else None
+    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(recs), mode, K, alphabet.bits,
+                             first.ctypes.data_as(C.c_void_p), second.ctypes.data_as(C.c_void_p) if want_second else None,
+                             seed & MASK64, offsets.ctypes.data_as(C.c_void_p), total, _capi.MEM_HOST, C.byref(res))
+    if rc == _capi.E_ENCODE:
+        bad = recs[int(res.n_out)]
+        _raise_encode(alphabet, bad, res)
+    ctx.check(rc, "kmers_batch")
+    kmers = KmerArray(alphabet, K, first[:total])
+    if cls is FwRvIterator:
+        return kmers, KmerArray(alphabet, K, second[:total]), offsets.astype(np.int64)
+    return kmers, (second[:total, 0] if want_second else None), offsets.astype(np.int64)
 
 
 def sketch(f, it, s, seed=0):

@@ -1,0 +1,177 @@
+"""kmers_batch: many records (ragged, some empty or shorter than K) in one launch == the per-record
+iterators of the oracle, concatenated in record order; errors name the first failing record."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import naive
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def km():
+    import kmers_jl_amd
+    return kmers_jl_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(km):
+    c = km.Context(0)
+    yield c
+    c.close()
+
+
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def build_pool(texts, src, rng, scatter):
+    """Pool words + spans.  LongSequence pools place records at arbitrary symbol offsets (views of one
+    long sequence, with filler between them when `scatter`); byte pools are the joined text."""
+    import kmers_jl_amd as km
+    spans, pieces, pos = [], [], 0
+    for t in texts:
+        gap = naive.random_text(rng, int(rng.integers(0, 40))) if scatter else ""
+        pieces.append(gap + t)
+        spans.append((pos + len(gap), len(t)))
+        pos += len(gap) + len(t)
+    whole = "".join(pieces)
+    words = naive.ascii_words(whole) if src == 8 else naive.longseq_words(whole if whole else "A", src)
+    arr = (km._capi.Span * max(len(spans), 1))(*[km._capi.Span(a, b) for a, b in spans])
+    return words, arr, len(whole)
+
+
+def expected(orc, texts, src, dst, K, mode, seed):
+    outs_a, outs_b, offs = [], [], [0]
+    for t in texts:
+        if len(t) >= K:
+            w = naive.ascii_words(t) if src == 8 else naive.longseq_words(t, src)
+            if mode == 0:
+                a, b, res = orc.fwrv(w, len(t), src, dst, K)
+            else:
+                a, b, res = orc.canonical(w, len(t), src, dst, K, seed=seed)
+            assert res.status == 0
+            outs_a.append(a)
+            outs_b.append(b)
+        offs.append(offs[-1] + max(0, len(t) - K + 1))
+    N = (K * dst + 63) // 64
+    a = np.concatenate(outs_a) if outs_a else np.zeros((0, N), np.uint64)
+    b = np.concatenate(outs_b) if outs_b else np.zeros((0, N) if mode == 0 else (0,), np.uint64)
+    return a, b, np.array(offs, np.uint64)
+
+
+@pytest.mark.parametrize("src", [2, 4, 8])
+def test_batch_matches_per_record_iteration(km, ctx, orc, src):
+    cap = km._capi
+    rng = np.random.default_rng(100 + src)
+    for dst in (2, 4):
+        for K in (1, 5, 31, 32, 33, 64) if dst == 2 else (1, 7, 16, 17, 32):
+            for n_rec, scatter in ((1, False), (7, True), (300, True), (4000, False)):
+                lens = rng.choice([0, 1, K - 1, K, K + 1, 50, 151, 1000, 3000], n_rec)
+                texts = [naive.random_text(rng, int(max(0, l))) for l in lens]
+                if src == 8:
+                    texts = ["".join(c.lower() if rng.random() < 0.3 else c for c in t) for t in texts]
+                words, spans, n_pool = build_pool(texts, src, rng, scatter)
+                seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+                for mode in (cap.BATCH_FW, cap.BATCH_CANONICAL):
+                    ea, eb, eoff = expected(orc, texts, src, dst, K, mode, 9)
+                    total = int(eoff[-1])
+                    N = (K * dst + 63) // 64
+                    res = cap.Result()
+                    offs = np.zeros(n_rec + 1, np.uint64)
+                    # size query
+                    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, n_rec, mode, K, dst, None, None, 9, vp(offs), 0, 0, C.byref(res))
+                    assert rc == 0 and res.n_out == total and np.array_equal(offs, eoff), (src, dst, K, n_rec, mode)
+                    out_a = np.zeros((max(total, 1), N), np.uint64)
+                    out_b = np.zeros((max(total, 1), N) if mode == cap.BATCH_FW else max(total, 1), np.uint64)
+                    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, n_rec, mode, K, dst, vp(out_a), vp(out_b), 9, vp(offs),
+                                             total, 0, C.byref(res))
+                    assert rc == 0, ctx.last_error()
+                    assert np.array_equal(out_a[:total], ea) and np.array_equal(out_b[:total], eb), (src, dst, K, n_rec, mode)
+                    if total:  # too small a buffer is refused, with the required size
+                        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, n_rec, mode, K, dst, vp(out_a), None, 9, None,
+                                                 total - 1, 0, C.byref(res))
+                        assert rc == cap.E_CAPACITY and res.n_out == total
+
+
+def test_batch_device_pointers_and_unaligned_outputs(km, ctx, orc):
+    cap = km._capi
+    rng = np.random.default_rng(5)
+    K = 31
+    texts = [naive.random_text(rng, int(l)) for l in rng.integers(20, 400, 2000)]
+    words, spans, n_pool = build_pool(texts, 4, rng, True)
+    ea, eb, eoff = expected(orc, texts, 4, 2, K, cap.BATCH_CANONICAL, 0)
+    total = int(eoff[-1])
+    d_w = ctx.alloc(words.nbytes + 16)
+    ctx.h2d(d_w, words)
+    d_a, d_b = ctx.alloc(total * 8 + 32), ctx.alloc(total * 8 + 32)
+    seq = cap.Seq(d_w, n_pool, 0, 0, 4, 0)
+    res = cap.Result()
+    for shift in (0, 8):
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, K, 2, d_a + shift, d_b + shift, 0,
+                                 None, total, cap.MEM_DEVICE, C.byref(res))
+        assert rc == 0 and res.n_out == total, ctx.last_error()
+        a, b = np.zeros(total, np.uint64), np.zeros(total, np.uint64)
+        ctx.d2h(a, d_a + shift)
+        ctx.d2h(b, d_b + shift)
+        assert np.array_equal(a, ea[:, 0]) and np.array_equal(b, eb), shift
+    for d in (d_w, d_a, d_b):
+        ctx.free(d)
+
+
+def test_batch_encode_error_names_record_and_position(km, ctx, orc):
+    cap = km._capi
+    rng = np.random.default_rng(6)
+    K = 21
+    texts = [naive.random_text(rng, int(l)) for l in rng.integers(0, 300, 500)]
+    # ambiguity in records too short to be iterated is never inspected (FwKmers.jl:63)
+    texts[3] = "ACGTN"
+    # two bad records: the earlier one (in batch order) wins, at its first offending symbol
+    bad_late, bad_early = 400, 123
+    texts[bad_late] = naive.random_text(rng, 100) + "W" + naive.random_text(rng, 50)
+    texts[bad_early] = naive.random_text(rng, 77) + "R" + naive.random_text(rng, 10) + "N" + naive.random_text(rng, 30)
+    for src in (4, 8):
+        words, spans, n_pool = build_pool(texts, src, rng, True)
+        seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+        res = cap.Result()
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, K, 2, None, None, 0, None, 0, 0,
+                                 C.byref(res))
+        total = int(res.n_out)
+        out = np.zeros(total, np.uint64)
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, K, 2, vp(out), None, 0, None, total,
+                                 0, C.byref(res))
+        assert rc == cap.E_ENCODE and res.n_out == bad_early and res.err_pos == 78
+        assert res.err_enc == (naive.DNA4["R"] if src == 4 else ord("R"))
+        # the same pool with 4-bit kmers keeps the ambiguous symbols (Copyable / ascii_encode of a 4-bit alphabet)
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_FW, K, 4, None, None, 0, None, 0, 0, C.byref(res))
+        assert rc == 0
+    # the next call starts clean
+    texts[bad_late] = texts[bad_early] = "ACGT" * 30
+    words, spans, n_pool = build_pool(texts, 4, rng, False)
+    seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, 4, 0)
+    ea, _, eoff = expected(orc, texts, 4, 2, K, cap.BATCH_CANONICAL, 0)
+    out = np.zeros(int(eoff[-1]), np.uint64)
+    assert ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, K, 2, vp(out), None, 0, None, len(out),
+                               0, C.byref(res)) == 0
+    assert np.array_equal(out, ea[:, 0])
+
+
+def test_collect_batch_mirror(km, orc):
+    rng = np.random.default_rng(8)
+    texts = [naive.random_text(rng, int(l)) for l in rng.integers(0, 200, 300)]
+    kmers, hashes, offs = km.collect_batch(km.CanonicalDNAMers[15], [km.LongDNA[4](t) for t in texts], hashes=True, seed=2)
+    for i in (0, 17, 299):
+        exp = naive.canonical(texts[i], 15, 2)
+        got = kmers.words[offs[i]:offs[i + 1]]
+        assert [tuple(int(x) for x in r) for r in got] == exp
+        assert [int(h) for h in hashes[offs[i]:offs[i + 1]]] == [naive.fx_hash(w, 2) for w in exp]
+    fw, rv, offs = km.collect_batch(km.FwRvIterator[km.DNAAlphabet[2], 9], texts)   # String records
+    i = 5
+    assert [(tuple(int(x) for x in a), tuple(int(x) for x in b)) for a, b in zip(fw.words[offs[i]:offs[i + 1]], rv.words[offs[i]:offs[i + 1]])] \
+        == naive.fwrv(texts[i], 9, 2)
+    with pytest.raises(km.EncodeError):
+        km.collect_batch(km.FwDNAMers[4], ["ACGTACGT", "ACGNACGT"])
+    k, _, offs = km.collect_batch(km.FwDNAMers[4], [])
+    assert len(k) == 0 and list(offs) == [0]

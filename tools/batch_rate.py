@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Ragged batches through kmers_batch: N reads of a fixed or variable length from one resident pool,
+CanonicalDNAMers{31} + fx_hash per read, everything in HBM.  Reports the time of the whole call
+(layout kernels + recode + element kernel) and the rate in elements and source bases."""
+import ctypes as C
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import kmers_jl_amd as km
+cap = km._capi
+ctx = km.Context(0)
+dev = torch.device("cuda", 0)
+K = 31
+res = cap.Result()
+CASES = (("10 M reads x 150", 10_000_000, 150, 151, 4), ("10 M reads x 150", 10_000_000, 150, 151, 2),
+                                   ("10 M reads x 150 (ASCII)", 10_000_000, 150, 151, 8),
+                                   ("4 M reads x 50..600", 4_000_000, 50, 600, 4), ("100 k contigs x 2k..20k", 100_000, 2_000, 20_000, 4))
+if "--quick" in sys.argv:
+    CASES = CASES[:1]
+for label, n_reads, lo, hi, src in CASES:
+    rng = np.random.default_rng(1)
+    lens = rng.integers(lo, hi, n_reads).astype(np.uint64)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    n_pool = int(lens.sum())
+    if src == 8:
+        pool = torch.from_numpy(rng.choice(np.frombuffer(b"ACGT", np.uint8), n_pool + 16)).to(dev)
+        pool_ptr = pool.data_ptr()
+    else:
+        nw = (n_pool * src + 63) // 64
+        pool = torch.empty(nw + 2, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, 9, 0, nw, src, 0, pool.data_ptr()), "synth")
+        pool_ptr = pool.data_ptr()
+    spans_h = np.stack([starts, lens], axis=1).copy()
+    spans_d = torch.from_numpy(spans_h.view(np.int64)).to(dev)
+    total = int(np.maximum(lens.astype(np.int64) - K + 1, 0).sum())
+    out_k = torch.empty(total, dtype=torch.int64, device=dev)
+    out_h = torch.empty(total, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    seq = cap.Seq(pool_ptr, n_pool, 0, 0, src, 0)
+    for spans_ptr, flag, what in ((spans_h.ctypes.data, 0, "host spans"), (spans_d.data_ptr(), cap.SPANS_DEVICE, "resident spans")):
+        best = 1e9
+        for _ in range(4):
+            t0 = time.perf_counter()
+            rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans_ptr, n_reads, cap.BATCH_CANONICAL, K, 2, out_k.data_ptr(), out_h.data_ptr(),
+                                     0, None, total, cap.MEM_DEVICE | flag, C.byref(res))
+            best = min(best, time.perf_counter() - t0)
+            assert rc == 0 and res.n_out == total, ctx.last_error()
+        by = total * 16 + n_pool * src / 8
+        print(f"src={src} {label:28s} {what:15s} {best * 1e3:8.3f} ms  {total / best / 1e9:7.1f} G elements/s  {n_pool / best / 1e9:7.1f} Gbases/s  "
+              f"{by / best / 1e9:7.0f} GB/s", flush=True)
+    del pool, out_k, out_h, spans_d

@@ -1,0 +1,12 @@
+#!/bin/bash
+# The library must not contain FLAT memory instructions: on gfx950 a FLAT load whose address is
+# selected between the LDS aperture and HBM returned wrong data for whole wavefronts
+# ("Batches of records").  Compiles the device code to assembly and counts them.
+set -e
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="${TMPDIR:-/tmp}/kmers_isa_$$.s"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -Wno-array-bounds -o "$OUT" "$ROOT/kmers.jl_amd/csrc/kmers_api.hip" 2>/dev/null
+n=$(grep -c "flat_load\|flat_store\|flat_atomic" "$OUT" || true)
+rm -f "$OUT"
+echo "FLAT memory instructions: $n"
+test "$n" = "0"
