@@ -727,8 +727,8 @@ int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, 
     return collect(ctx, res, n, out_value);
 }
 
-int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t seed, uint64_t s,
-                  uint64_t *out_hashes, int flags, kmers_result *res) {
+static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t seed, uint64_t s,
+                        uint64_t *out_hashes, int flags, kmers_result *res) {
     clear(res);
     if (int rc = check_common(ctx, seq, k, 1, dst_bits, flags & ~KMERS_ASYNC)) {
         if (res) res->status = rc;
@@ -985,9 +985,9 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
     return collect(ctx, res, n);
 }
 
-int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int mode, int k,
-                int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
-                uint64_t capacity, int flags, kmers_result *res) {
+static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int mode, int k,
+                      int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
+                      uint64_t capacity, int flags, kmers_result *res) {
     clear(res);
     if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE))) {
         if (res) res->status = rc;
@@ -1162,6 +1162,30 @@ int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, 
         }
     }
     return fail(ctx, KMERS_E_HIP, "kmers_batch: a flagged window holds no offending symbol");
+}
+
+// The two entry points that allocate host memory (std::vector): no C++ exception may cross the C ABI.
+int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t seed, uint64_t s,
+                  uint64_t *out_hashes, int flags, kmers_result *res) {
+    try {
+        return minhash_impl(ctx, seq, k, dst_bits, seed, s, out_hashes, flags, res);
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, KMERS_E_NOMEM, "host allocation failed in kmers_minhash");
+    } catch (...) {
+        return fail(ctx, KMERS_E_HIP, "unexpected exception in kmers_minhash");
+    }
+}
+
+int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int mode, int k,
+                int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
+                uint64_t capacity, int flags, kmers_result *res) {
+    try {
+        return batch_impl(ctx, pool, spans, n_spans, mode, k, dst_bits, out_a, out_b, seed, out_offsets, capacity, flags, res);
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, KMERS_E_NOMEM, "host allocation failed in kmers_batch");
+    } catch (...) {
+        return fail(ctx, KMERS_E_HIP, "unexpected exception in kmers_batch");
+    }
 }
 
 int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uint64_t *out_kmers,
