@@ -156,6 +156,31 @@ def other_configs(ctx, cap, stream, dev, reps=5):
         st = torch.empty(m, dtype=torch.int64, device=dev)
         ms = timed(lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seqa), K, J, a.data_ptr(), st.data_ptr(), m, cap.MEM_DEVICE, C.byref(res)))
         entry(f"C5 skip variant (UnambiguousDNAMers{{21}} on the stride-3 lattice, p(N)=0.04, {m} kept), count+scan+emit", ms, L, 1.0 * L + 16.0 * m)
+        del amb, st
+        # fused consumers over the clean 1 Gbase LongDNA{4} (nothing materialised per kmer: no HBM roofline,
+        # reported as kernel time and Gbases/s)
+        val = C.c_uint64()
+        ms = timed(lambda: ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), 31, 2, 1, C.byref(val), cap.MEM_DEVICE, C.byref(res)))
+        out["fused XOR-reduce of CanonicalDNAMers{31} (test/benchmark.jl:9-15)"] = {"ms": round(ms, 4), "Gbases_per_s": round(L / ms / 1e6, 1)}
+        sk = np.zeros(1000, dtype=np.uint64)
+        ms = timed(lambda: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), 16, 2, 0, 1000, sk.ctypes.data_as(C.c_void_p), cap.MEM_DEVICE, C.byref(res)))
+        out["fused MinHash sketch(fx_hash, CanonicalDNAMers{16}, 1000) (docs/src/minhash.md:34)"] = {"ms": round(ms, 4), "Gbases_per_s": round(L / ms / 1e6, 1)}
+        counts = torch.empty(4 ** 8 // 2, dtype=torch.int64, device=dev)
+        for Kc in (4, 8):
+            ms = timed(lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), Kc, counts.data_ptr(), cap.MEM_DEVICE, C.byref(res)))
+            out[f"fused composition counts of FwDNAMers{{{Kc}}} (docs/src/composition.md:28-39)"] = {"ms": round(ms, 4), "Gbases_per_s": round(L / ms / 1e6, 1)}
+        # ragged batch: 8 M reads x 125 bases = the same 1 Gbase pool, CanonicalDNAMers{31} + fx_hash per read
+        n_reads, rl, Kb = 8_000_000, 125, 31
+        spans = torch.stack([torch.arange(n_reads, dtype=torch.int64, device=dev) * rl,
+                             torch.full((n_reads,), rl, dtype=torch.int64, device=dev)], dim=1).contiguous()
+        total = n_reads * (rl - Kb + 1)
+        b = torch.empty(total, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        ms = timed(lambda: ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans.data_ptr(), n_reads, cap.BATCH_CANONICAL, Kb, 2, a.data_ptr(),
+                                               b.data_ptr(), 0, None, total, cap.MEM_DEVICE | cap.SPANS_DEVICE, C.byref(res)))
+        out[f"kmers_batch: {n_reads} reads x {rl} bases, CanonicalDNAMers{{31}} + fx_hash per read"] = {
+            "ms": round(ms, 4), "G_elements_per_s": round(total / ms / 1e6, 1), "Gbases_per_s": round(n_reads * rl / ms / 1e6, 1),
+            "GB_per_s": round((16.0 * total + 0.5 * n_reads * rl) / ms / 1e6, 1)}
     return out
 
 
