@@ -175,3 +175,34 @@ def test_collect_batch_mirror(km, orc):
         km.collect_batch(km.FwDNAMers[4], ["ACGTACGT", "ACGNACGT"])
     k, _, offs = km.collect_batch(km.FwDNAMers[4], [])
     assert len(k) == 0 and list(offs) == [0]
+
+
+@pytest.mark.parametrize("src", [2, 4, 8])
+def test_batch_pool_is_itself_a_view(km, ctx, orc, src):
+    """pool.first_base != 0: the pool is a LongSubSeq of a longer buffer; spans are relative to the view."""
+    cap = km._capi
+    rng = np.random.default_rng(40 + src)
+    K = 21
+    texts = [naive.random_text(rng, int(l)) for l in rng.integers(0, 120, 400)]
+    for lead in (1, 5, 16, 33, 70):
+        prefix = naive.random_text(rng, lead)
+        whole = prefix + "".join(texts)
+        words = naive.ascii_words(whole) if src == 8 else naive.longseq_words(whole, src)
+        pos, spans = 0, []
+        for t in texts:
+            spans.append((pos, len(t)))
+            pos += len(t)
+        arr = (cap.Span * len(spans))(*[cap.Span(a, b) for a, b in spans])
+        seq = cap.Seq(words.ctypes.data, pos, lead, 0, src, 0)
+        ea, eb, eoff = expected(orc, texts, src, 2, K, cap.BATCH_CANONICAL, 4)
+        total = int(eoff[-1])
+        out_a, out_b = np.zeros(total, np.uint64), np.zeros(total, np.uint64)
+        res = cap.Result()
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), arr, len(spans), cap.BATCH_CANONICAL, K, 2, vp(out_a), vp(out_b), 4, None,
+                                 total, 0, C.byref(res))
+        assert rc == 0 and res.n_out == total, ctx.last_error()
+        assert np.array_equal(out_a, ea[:, 0]) and np.array_equal(out_b, eb), (src, lead)
+        # a span that leaves the view is refused
+        bad = (cap.Span * 1)(cap.Span(pos - 3, 10))
+        assert ctx.lib.kmers_batch(ctx.handle, C.byref(seq), bad, 1, cap.BATCH_CANONICAL, K, 2, None, None, 0, None, 0, 0,
+                                   C.byref(res)) == cap.E_BADARG
