@@ -299,3 +299,37 @@ def test_synth_10k_fixture_on_device(km, ctx):
             out = dev_empty(L)
             rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, 3, 2, out.data_ptr(), cap.MEM_DEVICE, C.byref(res))
             assert rc == 1 and (res.err_pos, res.err_enc) == (c["strict_spaced_error"]["pos"], c["strict_spaced_error"]["enc"])
+
+
+def test_batch_of_reads_over_the_c2_pool_full_size(km, ctx):
+    """8 M reads x 125 bases cut from the 1 Gbase C2 pool: read i, element j must equal window
+    125 i + j of the whole-pool CanonicalDNAMers{31} + fx_hash pass (no oracle at this size)."""
+    import ctypes as C
+    cap = km._capi
+    L, K, bits, R = 1_000_000_000, 31, 4, 125
+    n_reads = L // R
+    per = R - K + 1
+    nw = (L * bits + 63) // 64
+    buf = synth(ctx, GOLDEN ^ 2, 0, nw, bits)
+    seq = cap.Seq(buf.data_ptr(), L, 0, 0, bits, 0)
+    res = cap.Result()
+    n = L - K + 1
+    whole_k, whole_h = dev_empty(n), dev_empty(n)
+    ctx.check(ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, whole_k.data_ptr(), whole_h.data_ptr(), 7, cap.MEM_DEVICE,
+                                      C.byref(res)), "canonical")
+    spans = torch.stack([torch.arange(n_reads, dtype=torch.int64, device="cuda:0") * R,
+                         torch.full((n_reads,), R, dtype=torch.int64, device="cuda:0")], dim=1).contiguous()
+    total = n_reads * per
+    out_k, out_h = dev_empty(total), dev_empty(total)
+    torch.cuda.synchronize()
+    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans.data_ptr(), n_reads, cap.BATCH_CANONICAL, K, 2, out_k.data_ptr(),
+                             out_h.data_ptr(), 7, None, total, cap.MEM_DEVICE | cap.SPANS_DEVICE, C.byref(res))
+    assert rc == 0 and res.n_out == total, ctx.last_error()
+    step = 1 << 20  # reads per comparison chunk
+    for lo in range(0, n_reads, step):
+        hi = min(n_reads, lo + step)
+        # windows [125 i, 125 i + 95) of the whole-pool arrays, as a strided view
+        wk = torch.as_strided(whole_k, (hi - lo, per), (R, 1), lo * R)
+        wh = torch.as_strided(whole_h, (hi - lo, per), (R, 1), lo * R)
+        assert torch.equal(out_k[lo * per:hi * per].view(hi - lo, per), wk)
+        assert torch.equal(out_h[lo * per:hi * per].view(hi - lo, per), wh)
