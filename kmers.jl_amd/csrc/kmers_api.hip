@@ -493,11 +493,11 @@ int launch_fused(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, 
     return rc;
 }
 
-// Fused consumers of one-word 2-bit kmers: the rolling run kernel (run_kernel.hpp); everything else
-// (two- to four-word kmers, 4-bit kmer alphabets) goes through the stream kernel's fused modes.
+// Fused consumers of one- and two-word 2-bit kmers (K <= 64): the rolling run kernel (run_kernel.hpp);
+// everything else (three- and four-word kmers, 4-bit kmer alphabets) goes through the stream kernel's fused modes.
 template <int RMODE, int SMODE>
 int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, int dst_bits, StreamArgs &a, size_t best_bytes = 0) {
-    if (dst_bits != 2 || k > 32) return launch_fused<SMODE>(ctx, seq, st, k, dst_bits, a);
+    if (dst_bits != 2 || k > 64) return launch_fused<SMODE>(ctx, seq, st, k, dst_bits, a);
     a.src = st.d_words;
     a.first_bit = st.first_bit;
     a.n_bases = seq->n_bases;
@@ -510,9 +510,15 @@ int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int 
     a.n_tiles = (a.n_kmers + RTILE - 1) / RTILE;
     const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)ctx->n_cus * 8;  // persistent grid
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, resident)), block(RBLOCK);
-    if (seq->src_bits == 8) hipLaunchKernelGGL((run_kernel<8, RMODE>), grid, block, best_bytes, ctx->stream, a);
-    else if (seq->src_bits == 4) hipLaunchKernelGGL((run_kernel<4, RMODE>), grid, block, best_bytes, ctx->stream, a);
-    else hipLaunchKernelGGL((run_kernel<2, RMODE>), grid, block, best_bytes, ctx->stream, a);
+#define RUNK(SB)                                                                                             \
+    do {                                                                                                     \
+        if (k <= 32) hipLaunchKernelGGL((run_kernel<SB, RMODE, 1>), grid, block, best_bytes, ctx->stream, a); \
+        else hipLaunchKernelGGL((run_kernel<SB, RMODE, 2>), grid, block, best_bytes, ctx->stream, a);        \
+    } while (0)
+    if (seq->src_bits == 8) RUNK(8);
+    else if (seq->src_bits == 4) RUNK(4);
+    else RUNK(2);
+#undef RUNK
     HIP_TRY(ctx, hipGetLastError());
     return KMERS_OK;
 }

@@ -1,4 +1,4 @@
-// run_kernel.hpp -- fused consumers of one-word 2-bit kmers (K <= 32) that keep nothing per kmer:
+// run_kernel.hpp -- fused consumers of one- and two-word 2-bit kmers (K <= 64) that keep nothing per kmer:
 //   RMODE_XOR    the reference's own benchmark consumer (test/benchmark.jl:9-15): XOR of the
 //                canonical (or forward) kmers' data words;
 //   RMODE_SKETCH MinHash candidates: fx_hash(canonical kmer) below the running threshold
@@ -20,9 +20,9 @@ constexpr int RRUN = 16;                   // consecutive kmers per lane
 constexpr int RTILE = RBLOCK * RRUN;       // kmers per tile
 enum RunMode { RMODE_XOR = 0, RMODE_SKETCH = 1 };
 
-template <int SRC_BITS, int RMODE>
+template <int SRC_BITS, int RMODE, int N = 1>
 __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
-    __shared__ uint64_t lds[RTILE * 2 / 64 + 16];
+    __shared__ uint64_t lds[RTILE * 2 / 64 + 16];  // + K - 1 <= 63 symbols of overlap + 32 of misalignment + the (N+1)-th window word
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t k = a.k;
@@ -70,23 +70,26 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
     };
 
     uint64_t prev_h = ~0ull;  // last candidate of this lane: a homopolymer run repeats one kmer
-    auto consume = [&](uint64_t fw, uint64_t rc) {
-        const uint64_t c = canonical ? (fw < rc ? fw : rc) : fw;  // CanonicalKmers.jl:220-225
-        if constexpr (RMODE == RMODE_XOR) {
-            xacc ^= c;
-        } else {
-            const uint64_t h = fx_step(a.seed, c);  // fx_hash of a one-word kmer (kmer.jl:255-261)
-            if (h < threshold && h != prev_h) {
-                prev_h = h;
-                uint32_t lo = 0, hi = nb;  // lower_bound(sbest, h)
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (sbest[mid] < h) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (lo == nb || sbest[lo] != h) sketch_candidate(a, h);
+    auto candidate = [&](uint64_t h) {
+        if (h < threshold && h != prev_h) {
+            prev_h = h;
+            uint32_t lo = 0, hi = nb;  // lower_bound(sbest, h)
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (sbest[mid] < h) lo = mid + 1;
+                else hi = mid;
             }
+            if (lo == nb || sbest[lo] != h) sketch_candidate(a, h);
         }
+    };
+    // one kmer (N words, head first) and its reverse complement -> the consumer
+    auto consume = [&](const uint64_t (&fw)[N], const uint64_t (&rc)[N]) {
+        const bool lt = !canonical || kmer_less<N>(fw, rc);  // fw < rv ? fw : rv, CanonicalKmers.jl:220-225
+        uint64_t c[N];
+#pragma unroll
+        for (int w = 0; w < N; ++w) c[w] = lt ? fw[w] : rc[w];
+        if constexpr (RMODE == RMODE_XOR) xacc ^= c[0];            // the reducer of test/benchmark.jl:9-15: kmer.data[1]
+        else candidate(fx_hash<N>(c, a.seed));                      // kmer.jl:255-261
     };
 
     uint64_t tile = blockIdx.x;
@@ -112,31 +115,57 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
             const uint32_t cnt = g.mt - r0 < (uint32_t)RRUN ? g.mt - r0 : (uint32_t)RRUN;
             const uint32_t bit = 2u * (r0 + g.b0);
             const uint32_t q = bit >> 6, s = bit & 63u;
-            // 128 stream bits from the run's first symbol; bits past the staged stream only reach kmers j >= cnt
-            const uint64_t l0 = lds[q], l1 = lds[q + 1], l2 = lds[q + 2];
-            const uint64_t W0 = funnel64(l0, l1, s), W1 = funnel64(l1, l2, s);
+            // (N + 1) * 64 stream bits from the run's first symbol; bits past the staged stream only reach kmers j >= cnt
+            uint64_t W[N + 1];
+            {
+                uint64_t lo = lds[q];
+#pragma unroll
+                for (int j = 0; j <= N; ++j) {
+                    const uint64_t hi = lds[q + j + 1];
+                    W[j] = funnel64(lo, hi, s);
+                    lo = hi;
+                }
+            }
             // first kmer of the run (see stream_kernel.hpp `window`): fw = symbol-reversed window, rc = complement
-            uint64_t fw = rev2(W0 & mask) >> (64u - 2u * k);
-            uint64_t rc = ~W0 & mask;
+            uint64_t fw[N], rc[N];
+            {
+                uint64_t Wm[N], R[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) Wm[j] = W[j];
+                Wm[N - 1] &= mask;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    rc[N - 1 - j] = ~Wm[j];
+                    R[j] = rev2(Wm[j]);
+                }
+                rc[0] &= mask;
+                const uint32_t sh = 64u * N - 2u * k;  // 0..62
+                fw[0] = R[0] >> sh;
+#pragma unroll
+                for (int i = 1; i < N; ++i) fw[i] = (R[i] >> sh) | ((R[i - 1] << 1) << (63u - sh));
+            }
             // the 15 symbols that enter afterwards: stream symbols K, K+1, ... of the run
-            const uint32_t S = (uint32_t)(k == 32u ? W1 : funnel64(W0, W1, 2u * k));
-            const uint32_t top = 2u * (k - 1u);
+            const uint32_t kb = 2u * k - 64u * (N - 1);  // bit offset of symbol K inside W[N-1] : W[N] (1..64)
+            const uint32_t S = (uint32_t)(kb == 64u ? W[N] : funnel64(W[N - 1], W[N], kb));
+            const uint32_t top = 2u * (k - 1u) - 64u * (N - 1);  // bit of the first symbol inside the head word
             consume(fw, rc);
+            auto roll = [&](uint32_t j) {
+                const uint64_t sym = (S >> (2u * (j - 1u))) & 3u;
+                // shift_encoding (construction_utils.jl:129-134) / shift_first_encoding of the complement (kmer.jl:511-518)
+#pragma unroll
+                for (int w = 0; w < N - 1; ++w) fw[w] = (fw[w] << 2) | (fw[w + 1] >> 62);
+                fw[N - 1] = (fw[N - 1] << 2) | sym;
+                fw[0] &= mask;
+#pragma unroll
+                for (int w = N - 1; w > 0; --w) rc[w] = (rc[w] >> 2) | (rc[w - 1] << 62);
+                rc[0] = (rc[0] >> 2) | ((sym ^ 3u) << top);
+                consume(fw, rc);
+            };
             if (cnt == (uint32_t)RRUN) {
 #pragma unroll
-                for (uint32_t j = 1; j < (uint32_t)RRUN; ++j) {
-                    const uint64_t sym = (S >> (2u * (j - 1u))) & 3u;
-                    fw = ((fw << 2) | sym) & mask;            // shift_encoding, construction_utils.jl:129-134
-                    rc = (rc >> 2) | ((sym ^ 3u) << top);     // shift_first_encoding of the complement, kmer.jl:511-518
-                    consume(fw, rc);
-                }
+                for (uint32_t j = 1; j < (uint32_t)RRUN; ++j) roll(j);
             } else {
-                for (uint32_t j = 1; j < cnt; ++j) {
-                    const uint64_t sym = (S >> (2u * (j - 1u))) & 3u;
-                    fw = ((fw << 2) | sym) & mask;
-                    rc = (rc >> 2) | ((sym ^ 3u) << top);
-                    consume(fw, rc);
-                }
+                for (uint32_t j = 1; j < cnt; ++j) roll(j);
             }
         }
     }
