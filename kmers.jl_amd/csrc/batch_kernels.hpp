@@ -289,34 +289,50 @@ __global__ __launch_bounds__(1024) void sketch_prune_kernel(uint64_t *__restrict
     };
 
     // ---- the cut ------------------------------------------------------------------------------
+    // The first pivot assumes uniform hashes below the old threshold; if the count below it misses the
+    // window [s, limit] (or duplicates leave fewer than s distinct values) the pivot is rescaled by the
+    // observed density and the gather repeated, up to three times.
     const double target = 1.5 * (double)s + 8.0 * sqrt((double)s) + 32.0;
     uint32_t limit = 1;
     while ((double)limit < 1.25 * target) limit <<= 1;
-    if ((double)total > 1.3 * (double)limit && limit <= SKETCH_LDS_VALUES / 2) {
-        const double frac = target / (double)total;  // < 0.8
-        const uint64_t pivot = __umul64hi(old_threshold, (uint64_t)(frac * 18446744073709551616.0));
-        if (t == 0) sub_n = 0;
-        __syncthreads();
-        for (uint32_t i = t; i < total; i += 1024) {
-            const uint64_t x = value(i);
-            if (x < pivot) {
-                const uint32_t p = atomicAdd(&sub_n, 1u);
-                if (p < limit) v[p] = x;
-            }
-        }
-        __syncthreads();
-        const uint32_t c = sub_n;
-        if (c >= s && c <= limit) {
-            for (uint32_t i = c + t; i < limit; i += 1024) v[i] = ~0ull;
+    if ((double)total > 1.3 * (double)limit && limit <= SKETCH_LDS_VALUES) {
+        double frac = target / (double)total;  // < 0.8
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            const uint64_t pivot = frac >= 1.0 ? old_threshold : __umul64hi(old_threshold, (uint64_t)(frac * 18446744073709551616.0));
+            if (t == 0) sub_n = 0;
             __syncthreads();
-            if (dedupe(limit, c, true, false) >= s) return;  // uniform: every thread sees the same count
+            for (uint32_t i = t; i < total; i += 1024) {
+                const uint64_t x = value(i);
+                if (x < pivot || frac >= 1.0) {
+                    const uint32_t p = atomicAdd(&sub_n, 1u);
+                    if (p < limit) v[p] = x;
+                }
+            }
+            __syncthreads();
+            const uint32_t c = sub_n;
+            uint32_t distinct = 0;
+            if (c >= s && c <= limit) {
+                for (uint32_t i = c + t; i < limit; i += 1024) v[i] = ~0ull;
+                __syncthreads();
+                distinct = dedupe(limit, c, true, false);
+                if (distinct >= s) return;  // uniform: every thread sees the same count
+            }
+            __syncthreads();
+            if (frac >= 1.0) break;         // everything was below the pivot: nothing left to widen
+            // too few (or too many duplicates): widen; too many: narrow -- by the observed density
+            const double have = c > limit ? (double)c : (c >= s ? (double)distinct : (double)c);
+            frac *= (c > limit ? 0.8 : 1.25) * target / (have > 1.0 ? have : 1.0);
+            if (frac > 1.0) frac = 1.0;
         }
-        __syncthreads();
     }
 
     // ---- everything ---------------------------------------------------------------------------
+    if (total > SKETCH_LDS_VALUES) {           // does not fit the LDS sort: the host falls back to the feedback path
+        if (t == 0) state[2] = 1;
+        return;
+    }
     uint32_t m = 1;
-    while (m < total) m <<= 1;                 // power of two >= total (<= SKETCH_LDS_VALUES by construction)
+    while (m < total) m <<= 1;                 // power of two >= total
     for (uint32_t i = t; i < m; i += 1024) v[i] = i < total ? value(i) : ~0ull;
     __syncthreads();
     dedupe(m, total, false, true);

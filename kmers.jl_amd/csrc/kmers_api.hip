@@ -756,7 +756,7 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
     }
     // (a sequence that fits one round needs no duplicate filter: everything is a candidate once and the
     // prune kernel deduplicates)
-    const bool one_round = n <= SKETCH_LDS_VALUES - 4096;
+    const bool one_round = n <= SKETCH_LDS_VALUES - 4096;  // (also below the smallest candidate buffer)
     if (!one_round) HIP_TRY(ctx, hipMemsetAsync(ctx->d_recent, 0xFF, (size_t)RECENT_SLOTS * 8, ctx->stream));
 
     // ---- device-resident path (s <= 4096): the threshold and the running bottom-s set stay in HBM, a
@@ -764,7 +764,11 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
     // host round trip.  Chunk r+1 is `ratio` times everything before it, which yields about ratio*s
     // candidates (half the buffer); an adversarial order can overflow it -> flag -> feedback path below.
     if (s <= 4096 && !ctx->sketch_host_only) {
-        const uint64_t dcap = SKETCH_LDS_VALUES - 4096;                 // candidates per round
+        // candidates per round: the prune kernel's pivot cut needs only ~1.5 s values in LDS, so the buffer
+        // can be much larger than the LDS sort (fewer, longer rounds); for the largest sketches the cut does
+        // not fit and everything must (12288 + 4096 <= the LDS sort)
+        const bool cut_fits = 1.25 * (1.5 * (double)s + 8.0 * std::sqrt((double)s) + 32.0) <= (double)SKETCH_LDS_VALUES / 2;
+        const uint64_t dcap = cut_fits ? 65536 : SKETCH_LDS_VALUES - 4096;
         // new candidates in a chunk of ratio*done kmers ~ ratio * Gamma(s): keep the buffer at mean + a wide
         // margin (relative spread 1/sqrt(s); s = 1 needs ~18x for a 1e-8 overflow probability)
         const double margin = 2.0 + 16.0 / std::sqrt((double)s);

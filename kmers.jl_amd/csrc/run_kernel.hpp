@@ -69,6 +69,15 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
         }
     };
 
+    // Candidates of a tile are collected in LDS and appended to the global buffer with ONE atomic on its
+    // counter per tile: per-candidate atomics on that single word top out near 90 per microsecond, which
+    // made the early rounds (tens of thousands of candidates in a short chunk) 5-10x slower than their
+    // arithmetic (profiles/r01_tuning.md).
+    constexpr uint32_t CB = RMODE == RMODE_SKETCH ? 512u : 1u;
+    __shared__ uint64_t cbuf[CB];
+    __shared__ uint32_t ccount;
+    __shared__ unsigned long long cbase;
+    if (RMODE == RMODE_SKETCH && tid == 0) ccount = 0;  // visible after the tile loop's first barrier
     uint64_t prev_h = ~0ull;  // last candidate of this lane: a homopolymer run repeats one kmer
     auto candidate = [&](uint64_t h) {
         if (h < threshold && h != prev_h) {
@@ -79,7 +88,11 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
                 if (sbest[mid] < h) lo = mid + 1;
                 else hi = mid;
             }
-            if (lo == nb || sbest[lo] != h) sketch_candidate(a, h);
+            if ((lo == nb || sbest[lo] != h) && sketch_is_new(a, h)) {
+                const uint32_t p = atomicAdd(&ccount, 1u);
+                if (p < CB) cbuf[p] = h;
+                else sketch_append(a, h);  // the tile's LDS buffer is full: straight to the global one
+            }
         }
     };
     // one kmer (N words, head first) and its reverse complement -> the consumer
@@ -166,6 +179,20 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
                 for (uint32_t j = 1; j < (uint32_t)RRUN; ++j) roll(j);
             } else {
                 for (uint32_t j = 1; j < cnt; ++j) roll(j);
+            }
+        }
+        if constexpr (RMODE == RMODE_SKETCH) {
+            __syncthreads();
+            const uint32_t filled = ccount < CB ? ccount : CB;  // uniform
+            if (filled) {
+                if (tid == 0) cbase = atomicAdd(reinterpret_cast<unsigned long long *>(a.out_b), (unsigned long long)filled);
+                __syncthreads();
+                for (uint32_t i = tid; i < filled; i += RBLOCK) {
+                    const unsigned long long pos = cbase + i;
+                    if (pos < a.capacity) a.out_a[pos] = cbuf[i];
+                }
+                __syncthreads();
+                if (tid == 0) ccount = 0;  // ordered before the next tile's candidates by its two barriers
             }
         }
     }

@@ -246,14 +246,20 @@ __device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint6
 // is a direct-mapped table in HBM: a plain (L1-bypassing) load rejects repeats cheaply, the
 // exchange makes "first to insert appends" exact; a collision merely evicts (the evicted value may
 // be appended again later -- harmless, the sketch keeps distinct values).
-__device__ __forceinline__ void sketch_candidate(const StreamArgs &a, uint64_t h) {
+__device__ __forceinline__ bool sketch_is_new(const StreamArgs &a, uint64_t h) {
     if (a.recent && h != ~0ull) {  // ~0 marks an empty slot
         unsigned long long *slot = reinterpret_cast<unsigned long long *>(a.recent) + ((uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 40) & a.recent_mask);
-        if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == h) return;
-        if (atomicExch(slot, (unsigned long long)h) == h) return;
+        if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == h) return false;
+        if (atomicExch(slot, (unsigned long long)h) == h) return false;
     }
+    return true;
+}
+__device__ __forceinline__ void sketch_append(const StreamArgs &a, uint64_t h) {
     unsigned long long pos = atomicAdd(reinterpret_cast<unsigned long long *>(a.out_b), 1ull);
     if (pos < a.capacity) a.out_a[pos] = h;
+}
+__device__ __forceinline__ void sketch_candidate(const StreamArgs &a, uint64_t h) {
+    if (sketch_is_new(a, h)) sketch_append(a, h);
 }
 
 template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1, bool TUPLES = false>
