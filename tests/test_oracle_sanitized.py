@@ -49,3 +49,15 @@ def test_oracle_is_ub_free(tmp_path):
     """)
     out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "UBSAN-CLEAN" in out.stdout, out.stderr[-2000:]
+
+
+def test_oracle_under_address_sanitizer(tmp_path):
+    """tests/c/oracle_asan_main.c: every iterator and element-wise function of the oracle on exact-size heap
+    buffers (AddressSanitizer + UBSan): no access outside ceil(len * bps / 64) source words or n * N output
+    words.  (GPU AddressSanitizer is unavailable on this pool; the kernels' own reads are covered by the parity
+    tests on exact-size device buffers, tests/test_gpu_parity.py.)"""
+    exe = tmp_path / "orc_asan"
+    subprocess.run(["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "c", "oracle_asan_main.c"), os.path.join(ROOT, "oracle", "kmers_oracle.c")], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "no invalid access" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
