@@ -210,6 +210,16 @@ int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, 
                 int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
                 uint64_t capacity, int flags, kmers_result *res);
 
+/* One MinHash sketch per record (MinHash.jl is used on collections: one sketch per genome / FASTA record,
+ * docs/src/minhash.md:31-41): record i of the batch gets the s smallest distinct values of
+ * fx_hash(canonical kmer, seed) over CanonicalKmers{A,K}(record i), ascending, in
+ * out_hashes[i * s .. i * s + out_counts[i]) (out_counts[i] <= s; fewer when the record has fewer distinct
+ * kmers).  pool / spans / flags as for kmers_batch (KMERS_MEM_DEVICE covers pool->words, out_hashes and
+ * out_counts); s <= 2048.  EncodeError: as kmers_batch (res->n_out = the failing record). */
+int kmers_minhash_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k,
+                        int dst_bits, uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags,
+                        kmers_result *res);
+
 /* ---- sharding one long sequence over the GPUs of a node ------- */
 /* The reference has no distributed code; kmer i depends only on symbols [i*stride, i*stride + k),
  * so shard g owns a contiguous range of kmers (in iteration order) whose first symbol sits on a

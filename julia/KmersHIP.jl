@@ -320,6 +320,41 @@ function collect_batch(::Type{It}, seqs::Vector{<:LongSequence}; hashes::Bool = 
     return (kmers, hs, offsets)
 end
 
+"""
+    sketch_batch(fx_hash, CanonicalKmers{A,K}, seqs, s; seed = 0x0)
+
+`[MinHash.sketch(fx_hash, CanonicalKmers{A,K}(x), s) for x in seqs]` from one launch sequence
+(`kmers_minhash_batch`): a vector of ascending `Vector{UInt64}`, one per record.
+"""
+function sketch_batch(::typeof(fx_hash), ::Type{CanonicalKmers{A, K}}, seqs::Vector{<:LongSequence}, s::Integer; seed::UInt = zero(UInt)) where {A, K}
+    ctx = context()
+    isempty(seqs) && return Vector{UInt64}[]
+    sbits = BioSequences.bits_per_symbol(Alphabet(first(seqs)))
+    per = 64 ÷ sbits
+    pool = UInt64[]
+    spans = Vector{CSpan}(undef, length(seqs))
+    for (i, x) in enumerate(seqs)
+        spans[i] = CSpan(length(pool) * per, length(x))
+        append!(pool, x.data)
+    end
+    push!(pool, zero(UInt64))
+    seq = CSeq(pointer(pool), (length(pool) - 1) * per, 0, 0, Int32(sbits), 0)
+    out = Matrix{UInt64}(undef, s, length(seqs))      # column i = record i (column-major == the C layout)
+    counts = Vector{UInt64}(undef, length(seqs))
+    res = CResult()
+    rc = GC.@preserve pool spans out counts begin
+        @ccall LIB.kmers_minhash_batch(ctx.handle::Ptr{Cvoid}, Ref(seq)::Ptr{CSeq}, pointer(spans)::Ptr{CSpan}, length(seqs)::UInt64,
+                                       K::Cint, dst_bits(A)::Cint, seed::UInt64, s::UInt64, pointer(out)::Ptr{UInt64},
+                                       pointer(counts)::Ptr{UInt64}, MEM_HOST::Cint, Ref(res)::Ptr{CResult})::Cint
+    end
+    if rc == E_ENCODE
+        bad = seqs[Int(res.n_out) + 1]
+        throw(BioSequences.EncodeError(A(), reinterpret(eltype(bad), res.err_enc % UInt8)))
+    end
+    rc == OK || error("kmers_minhash_batch: status $rc: $(last_error(ctx))")
+    return [out[1:Int(counts[i]), i] for i in eachindex(seqs)]
+end
+
 # ---- sharding one long sequence over several GPUs / processes ---------------------------------
 struct CShard
     first_kmer::UInt64

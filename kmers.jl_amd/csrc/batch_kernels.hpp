@@ -338,6 +338,103 @@ __global__ __launch_bounds__(1024) void sketch_prune_kernel(uint64_t *__restrict
     dedupe(m, total, false, true);
 }
 
+// ---- one MinHash sketch per record of a batch ------------------------------------------------------
+// hashes[off[r] .. off[r+1]) are the fx_hash values of record r's canonical kmers (kmers_batch).  One
+// workgroup per record keeps the record's running bottom-s in LDS: values below the current threshold
+// are appended behind it; when the next tile might not fit, the buffer is sorted, deduplicated and cut
+// back to s values (the same merge the whole-sequence sketch does between rounds, per workgroup).
+// Output: out[r * s .. r * s + counts[r]) ascending, counts[r] <= s.
+constexpr uint32_t SEG_VALUES = 8192;   // 64 KiB of dynamic LDS
+constexpr uint32_t SEG_UNROLL = 4;      // hashes per thread per tile
+
+// ascending bitonic sort of v[0..m) by one 256-thread workgroup (same wave-local trick as above)
+__device__ __forceinline__ void bitonic_sort_lds256(uint64_t *v, uint32_t m, uint32_t t) {
+    for (uint32_t k2 = 2; k2 <= m; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t p = t; p < (m >> 1); p += 256) {
+                const uint32_t i = ((p & ~(j - 1u)) << 1) | (p & (j - 1u)), l = i | j;
+                const uint64_t a0 = v[i], a1 = v[l];
+                const bool up = (i & k2) == 0;
+                if ((a0 > a1) == up) { v[i] = a1; v[l] = a0; }
+            }
+            const uint32_t next_j = j > 1 ? j >> 1 : k2;
+            if (j > 64 || next_j > 64) __syncthreads();   // pairs p, p + 256, ... stay in one wavefront for j <= 64
+            else __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__restrict__ hashes, const uint64_t *__restrict__ off,
+                                                              uint32_t s, uint64_t *__restrict__ out, uint64_t *__restrict__ counts) {
+    extern __shared__ uint64_t v[];            // SEG_VALUES values: [0, nb) the running sketch, then candidates
+    __shared__ uint32_t fill;                  // candidates appended since the last merge
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint64_t r = blockIdx.x;
+    const uint64_t lo = off[r], hi = off[r + 1];
+    uint32_t nb = 0;
+    uint64_t threshold = ~0ull;                // values strictly below it are candidates (uniform)
+    if (t == 0) fill = 0;
+    __syncthreads();
+    constexpr uint32_t TILE = 256u * SEG_UNROLL;
+    for (uint64_t base = lo; base < hi || base == lo; base += TILE) {
+        if (base < hi) {
+#pragma unroll
+            for (uint32_t u = 0; u < SEG_UNROLL; ++u) {
+                const uint64_t i = base + t + 256u * u;
+                if (i < hi) {
+                    const uint64_t x = hashes[i];
+                    if (x < threshold || nb < s) v[nb + atomicAdd(&fill, 1u)] = x;  // room for a whole tile is guaranteed below
+                }
+            }
+        }
+        __syncthreads();
+        const bool last = base + TILE >= hi;
+        const uint32_t total = nb + fill;      // uniform
+        if (last || total + TILE > SEG_VALUES) {
+            // merge: sort everything, keep the s smallest distinct values
+            uint32_t m = 1;
+            while (m < total) m <<= 1;
+            for (uint32_t i = total + t; i < m; i += 256) v[i] = ~0ull;
+            __syncthreads();
+            bitonic_sort_lds256(v, m, t);
+            // distinct values among the first `total`: thread t owns positions [a, b)
+            const uint32_t per = (m + 255) / 256;
+            const uint32_t a = t * per < total ? t * per : total, b = a + per < total ? a + per : total;
+            uint64_t mine[SEG_VALUES / 256];
+            uint32_t n_mine = 0;
+            for (uint32_t i = a; i < b; ++i) {
+                const uint64_t x = v[i];
+                if (i == 0 || x != v[i - 1]) mine[n_mine++] = x;
+            }
+            uint32_t incl = n_mine;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(incl, d, 64);
+                if ((int)lane >= d) incl += y;
+            }
+            if (lane == 63) wave_tot[wave] = incl;
+            __syncthreads();                   // every thread has read its slice of v[]; wave totals visible
+            uint32_t before = 0, distinct = 0;
+            for (uint32_t w = 0; w < 4; ++w) {
+                if (w < wave) before += wave_tot[w];
+                distinct += wave_tot[w];
+            }
+            uint32_t pos = before + incl - n_mine;
+            for (uint32_t i = 0; i < n_mine; ++i, ++pos)
+                if (pos < s) v[pos] = mine[i];
+            __syncthreads();
+            nb = distinct < s ? distinct : s;
+            threshold = nb == s ? v[s - 1] : ~0ull;
+            if (t == 0) fill = 0;
+            __syncthreads();
+        }
+        if (last) break;
+    }
+    for (uint32_t i = t; i < nb; i += 256) out[r * (uint64_t)s + i] = v[i];
+    if (t == 0) counts[r] = nb;
+}
+
 // ---- synthetic input (the CPU checker restates the same generator) ------
 __global__ __launch_bounds__(256) void synth_kernel(uint64_t seed, uint64_t first_word, uint64_t n_words, int bits,
                                                      uint32_t ambig, uint64_t *__restrict__ out) {

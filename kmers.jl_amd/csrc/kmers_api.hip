@@ -54,6 +54,7 @@ namespace {
 // Pageable host memory costs HIP about 10-15 us per small copy (internal staging + waits); a call on a
 // short sequence with host pointers makes three of them.  Copies that fit go through pinned memory instead.
 constexpr size_t BOUNCE_IN = 256 << 10, BOUNCE_OUT = 1 << 20;
+constexpr int INTERNAL_OUT_DEVICE = 1 << 16;  // batch_impl: out_a / out_b are device pointers even if the pool is host memory
 
 int fail(kmers_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
     if (ctx) {
@@ -999,7 +1000,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
                       int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
                       uint64_t capacity, int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE))) {
+    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | INTERNAL_OUT_DEVICE))) {
         if (res) res->status = rc;
         return rc;
     }
@@ -1107,7 +1108,8 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     uint64_t *d_a = out_a, *d_b = out_b;
     const bool b_is_hash = mode == KMERS_BATCH_CANONICAL;
     const size_t bytes_a = (size_t)total * nw * 8, bytes_b = (size_t)total * (b_is_hash ? 1 : nw) * 8;
-    if (!dev) {
+    const bool out_dev = dev || (flags & INTERNAL_OUT_DEVICE);
+    if (!out_dev) {
         if (out_a) { if (int rc = ensure_stage(ctx, 1, bytes_a)) return rc; d_a = (uint64_t *)ctx->stage[1]; }
         if (out_b) { if (int rc = ensure_stage(ctx, 2, bytes_b)) return rc; d_b = (uint64_t *)ctx->stage[2]; }
     }
@@ -1128,7 +1130,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
 #undef RGM
 #undef RG
     HIP_TRY(ctx, hipGetLastError());
-    if (!dev) {
+    if (!out_dev) {
         if (out_a) HIP_TRY(ctx, hipMemcpyAsync(out_a, d_a, bytes_a, hipMemcpyDeviceToHost, ctx->stream));
         if (out_b) HIP_TRY(ctx, hipMemcpyAsync(out_b, d_b, bytes_b, hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -1195,6 +1197,69 @@ int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, 
         return fail(ctx, KMERS_E_NOMEM, "host allocation failed in kmers_batch");
     } catch (...) {
         return fail(ctx, KMERS_E_HIP, "unexpected exception in kmers_batch");
+    }
+}
+
+static int minhash_batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, int dst_bits,
+                              uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags, kmers_result *res) {
+    clear(res);
+    if (!ctx) return KMERS_E_BADARG;
+    if (s == 0 || s > SEG_VALUES / 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minhash_batch supports sketch sizes 1..2048");
+    if (n_spans && (!out_hashes || !out_counts)) return fail(ctx, KMERS_E_BADARG, "out_hashes / out_counts is NULL");
+    // 1. how many hashes in all
+    kmers_result q;
+    if (int rc = batch_impl(ctx, pool, spans, n_spans, KMERS_BATCH_CANONICAL, k, dst_bits, nullptr, nullptr, seed, nullptr, 0, flags, &q)) {
+        if (res) *res = q;
+        return rc;
+    }
+    if (n_spans == 0) return KMERS_OK;
+    const uint64_t total = q.n_out;
+    // 2. fx_hash of every canonical kmer of every record, in HBM
+    if (int rc = ensure_stage(ctx, 7, (size_t)std::max<uint64_t>(total, 1) * 8)) return rc;
+    uint64_t *d_hashes = static_cast<uint64_t *>(ctx->stage[7]);
+    if (int rc = batch_impl(ctx, pool, spans, n_spans, KMERS_BATCH_CANONICAL, k, dst_bits, nullptr, d_hashes, seed, nullptr, total,
+                            flags | INTERNAL_OUT_DEVICE, &q)) {
+        if (res) *res = q;  // EncodeError: q.n_out = the failing record, q.err_pos the position inside it
+        return rc;
+    }
+    // the element offsets of the records are still where batch_impl computed them (stage 3)
+    const size_t span_bytes = (size_t)n_spans * 16, cnt_bytes = ((size_t)n_spans * 4 + 15) & ~(size_t)15;
+    const uint64_t *d_off = reinterpret_cast<const uint64_t *>(static_cast<char *>(ctx->stage[3]) + span_bytes + cnt_bytes);
+    // 3. one workgroup per record: its bottom-s distinct hashes
+    const bool dev = flags & KMERS_MEM_DEVICE;
+    const size_t out_bytes = (size_t)n_spans * s * 8, cnt_out_bytes = (size_t)n_spans * 8;
+    uint64_t *d_out = out_hashes, *d_cnt = out_counts;
+    if (!dev) {
+        if (int rc = ensure_stage(ctx, 1, out_bytes)) return rc;
+        if (int rc = ensure_stage(ctx, 2, cnt_out_bytes)) return rc;
+        d_out = static_cast<uint64_t *>(ctx->stage[1]);
+        d_cnt = static_cast<uint64_t *>(ctx->stage[2]);
+    }
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(segment_sketch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     SEG_VALUES * 8));
+    hipLaunchKernelGGL(segment_sketch_kernel, dim3((unsigned)n_spans), dim3(256), SEG_VALUES * 8, ctx->stream, d_hashes, d_off, (uint32_t)s,
+                       d_out, d_cnt);
+    HIP_TRY(ctx, hipGetLastError());
+    if (!dev) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_hashes, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(out_counts, d_cnt, cnt_out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (res) {
+        res->status = KMERS_OK;
+        res->n_out = n_spans;
+    }
+    return KMERS_OK;
+}
+
+int kmers_minhash_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, int dst_bits,
+                        uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags, kmers_result *res) {
+    try {
+        return minhash_batch_impl(ctx, pool, spans, n_spans, k, dst_bits, seed, s, out_hashes, out_counts, flags, res);
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, KMERS_E_NOMEM, "host allocation failed in kmers_minhash_batch");
+    } catch (...) {
+        return fail(ctx, KMERS_E_HIP, "unexpected exception in kmers_minhash_batch");
     }
 }
 

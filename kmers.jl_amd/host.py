@@ -709,22 +709,9 @@ def collect(it):
     return it.collect()
 
 
-def collect_batch(iterator, records, hashes=False, seed=0, ctx=None):
-    """Elements of `iterator(record)` for every record of a batch, concatenated in record order, from
-    ONE launch (include/kmers_hip.h `kmers_batch`): the reference's `for record in reader ...
-    CanonicalDNAMers{K}(sequence(record))` loop (docs/src/minhash.md:31-35) without the per-call cost.
-
-    iterator: a parametrised iterator type, e.g. `CanonicalDNAMers[31]`, `FwDNAMers[21]`,
-              `FwRvIterator[DNAAlphabet[2], 31]`.
-    records:  LongSequences of one alphabet, or str / bytes records (ASCII).
-    Returns (first, second, offsets): FwKmers -> (kmers, None, offsets); FwRvIterator -> (kmers,
-    reverse complements, offsets); CanonicalKmers -> (kmers, fx_hash values if `hashes` else None,
-    offsets).  Record i owns elements offsets[i]:offsets[i+1]."""
-    ctx = ctx or default_context()
-    cls, params = getattr(iterator, "cls", None), getattr(iterator, "params", None)
-    if cls not in (FwKmers, FwRvIterator, CanonicalKmers):
-        raise UnsupportedError("collect_batch(FwKmers / FwRvIterator / CanonicalKmers [alphabet, K], records)")
-    alphabet, K = cls._expand(params)
+def _build_pool(records):
+    """Records -> (sequences, pool array, spans, pool symbols, source bits): LongSequence data words are
+    concatenated (every record starts on a word boundary), byte records are joined."""
     recs = [_as_sequence(r) for r in records]
     src_bits = recs[0].src_bits if recs else 2
     if any(r.src_bits != src_bits for r in recs):
@@ -746,6 +733,26 @@ def collect_batch(iterator, records, hashes=False, seed=0, ctx=None):
             spans[i] = _capi.Span(w * per, r.len)
             w += len(r.data)
         n_pool = w * per
+    return recs, pool, spans, n_pool, src_bits
+
+
+def collect_batch(iterator, records, hashes=False, seed=0, ctx=None):
+    """Elements of `iterator(record)` for every record of a batch, concatenated in record order, from
+    ONE launch (include/kmers_hip.h `kmers_batch`): the reference's `for record in reader ...
+    CanonicalDNAMers{K}(sequence(record))` loop (docs/src/minhash.md:31-35) without the per-call cost.
+
+    iterator: a parametrised iterator type, e.g. `CanonicalDNAMers[31]`, `FwDNAMers[21]`,
+              `FwRvIterator[DNAAlphabet[2], 31]`.
+    records:  LongSequences of one alphabet, or str / bytes records (ASCII).
+    Returns (first, second, offsets): FwKmers -> (kmers, None, offsets); FwRvIterator -> (kmers,
+    reverse complements, offsets); CanonicalKmers -> (kmers, fx_hash values if `hashes` else None,
+    offsets).  Record i owns elements offsets[i]:offsets[i+1]."""
+    ctx = ctx or default_context()
+    cls, params = getattr(iterator, "cls", None), getattr(iterator, "params", None)
+    if cls not in (FwKmers, FwRvIterator, CanonicalKmers):
+        raise UnsupportedError("collect_batch(FwKmers / FwRvIterator / CanonicalKmers [alphabet, K], records)")
+    alphabet, K = cls._expand(params)
+    recs, pool, spans, n_pool, src_bits = _build_pool(records)
     seq = _capi.Seq(pool.ctypes.data, n_pool, 0, 0, src_bits, 1 if alphabet.kind == "RNA" else 0)
     res = _capi.Result()
     offsets = np.zeros(len(recs) + 1, dtype=np.uint64)
@@ -769,6 +776,29 @@ def collect_batch(iterator, records, hashes=False, seed=0, ctx=None):
     if cls is FwRvIterator:
         return kmers, KmerArray(alphabet, K, second[:total]), offsets.astype(np.int64)
     return kmers, (second[:total, 0] if want_second else None), offsets.astype(np.int64)
+
+
+def sketch_batch(f, iterator, records, s, seed=0, ctx=None):
+    """[MinHash.sketch(fx_hash, CanonicalKmers{A,K}(r), s) for r in records] from one launch sequence
+    (`kmers_minhash_batch`): a list of ascending uint64 arrays, one per record (docs/src/minhash.md:31-41)."""
+    ctx = ctx or default_context()
+    cls, params = getattr(iterator, "cls", None), getattr(iterator, "params", None)
+    if f is not fx_hash or cls is not CanonicalKmers:
+        raise UnsupportedError("sketch_batch(fx_hash, CanonicalKmers[alphabet, K], records, s)")
+    alphabet, K = cls._expand(params)
+    recs, pool, spans, n_pool, src_bits = _build_pool(records)
+    if not recs:
+        return []
+    seq = _capi.Seq(pool.ctypes.data, n_pool, 0, 0, src_bits, 1 if alphabet.kind == "RNA" else 0)
+    out = np.zeros((len(recs), int(s)), dtype=np.uint64)
+    counts = np.zeros(len(recs), dtype=np.uint64)
+    res = _capi.Result()
+    rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq), spans, len(recs), K, alphabet.bits, seed & MASK64, int(s),
+                                     out.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), _capi.MEM_HOST, C.byref(res))
+    if rc == _capi.E_ENCODE:
+        _raise_encode(alphabet, recs[int(res.n_out)], res)
+    ctx.check(rc, "kmers_minhash_batch")
+    return [out[i, :int(counts[i])].copy() for i in range(len(recs))]
 
 
 def sketch(f, it, s, seed=0):

@@ -206,3 +206,46 @@ def test_batch_pool_is_itself_a_view(km, ctx, orc, src):
         bad = (cap.Span * 1)(cap.Span(pos - 3, 10))
         assert ctx.lib.kmers_batch(ctx.handle, C.byref(seq), bad, 1, cap.BATCH_CANONICAL, K, 2, None, None, 0, None, 0, 0,
                                    C.byref(res)) == cap.E_BADARG
+
+
+@pytest.mark.parametrize("src", [2, 4, 8])
+def test_minhash_batch_matches_per_record_sketches(km, ctx, orc, src):
+    """kmers_minhash_batch: record i's sketch == the s smallest distinct canonical hashes of record i."""
+    cap = km._capi
+    rng = np.random.default_rng(60 + src)
+    for K, s in ((5, 10), (16, 100), (21, 1000), (31, 2048), (40, 64)):
+        lens = rng.choice([0, K - 1, K, 50, 300, 5000, 40_000], 150)
+        texts = [naive.random_text(rng, int(max(0, l))) for l in lens]
+        texts[7] = "A" * 3000 + "ACGT" * 500          # low complexity: few distinct kmers
+        words, spans, n_pool = build_pool(texts, src, rng, True)
+        seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+        out = np.zeros((len(texts), s), np.uint64)
+        counts = np.zeros(len(texts), np.uint64)
+        res = cap.Result()
+        rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq), spans, len(texts), K, 2, 3, s, vp(out), vp(counts), 0, C.byref(res))
+        assert rc == 0 and res.n_out == len(texts), ctx.last_error()
+        for i, t in enumerate(texts):
+            if len(t) >= K:
+                w = naive.ascii_words(t) if src == 8 else naive.longseq_words(t, src)
+                _, eh, _ = orc.canonical(w, len(t), src, 2, K, seed=3)
+                exp = np.unique(eh)[:s]
+            else:
+                exp = np.zeros(0, np.uint64)
+            assert counts[i] == len(exp) and np.array_equal(out[i, :len(exp)], exp), (src, K, s, i, len(t))
+    # errors name the record; sizes beyond the LDS sort are refused
+    texts = ["ACGTACGTACGTACGTACGT", "ACGTACGTNACGTACGTACGTACGT"]
+    if src != 2:
+        words, spans, n_pool = build_pool(texts, src, rng, False)
+        seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+        rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq), spans, 2, 5, 2, 0, 10, vp(out), vp(counts), 0, C.byref(res))
+        assert rc == cap.E_ENCODE and res.n_out == 1 and res.err_pos == 9
+    assert ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq), spans, 2, 5, 2, 0, 5000, vp(out), vp(counts), 0, C.byref(res)) == cap.E_UNSUPPORTED
+
+
+def test_sketch_batch_mirror(km, orc):
+    rng = np.random.default_rng(61)
+    texts = [naive.random_text(rng, int(l)) for l in rng.integers(0, 3000, 40)]
+    sk = km.sketch_batch(km.fx_hash, km.CanonicalDNAMers[16], [km.LongDNA[2](t) for t in texts], 50)
+    for i, t in enumerate(texts):
+        one = km.sketch(km.fx_hash, km.CanonicalDNAMers[16](km.LongDNA[2](t)), 50) if len(t) >= 16 else np.zeros(0, np.uint64)
+        assert np.array_equal(sk[i], one), i
