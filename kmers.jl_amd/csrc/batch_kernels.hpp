@@ -374,62 +374,79 @@ __global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__r
     const uint64_t r = blockIdx.x;
     const uint64_t lo = off[r], hi = off[r + 1];
     uint32_t nb = 0;
-    uint64_t threshold = ~0ull;                // values strictly below it are candidates (uniform)
-    if (t == 0) fill = 0;
-    __syncthreads();
     constexpr uint32_t TILE = 256u * SEG_UNROLL;
-    for (uint64_t base = lo; base < hi || base == lo; base += TILE) {
-        if (base < hi) {
+    // Pass 0 (records with more than 4 s hashes): hashes are close to uniform, so a provisional threshold at
+    // the (1.5 s + slack) / n quantile of the 64-bit range leaves about 1.5 s candidates -- one sweep and one
+    // small sort instead of sorting thousands of values to keep s.  If fewer than s distinct values turn
+    // out to lie below it (skewed or heavily duplicated hashes), pass 1 repeats the record without it.
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint64_t n = hi - lo;
+        const double frac = n ? (1.5 * (double)s + 8.0 * sqrt((double)s) + 32.0) / (double)n : 1.0;
+        const bool provisional = pass == 0 && frac < 0.5;
+        uint64_t threshold = ~0ull;            // values strictly below it are candidates (uniform)
+        if (provisional) {
+            threshold = (uint64_t)(frac * 18446744073709551616.0);
+        } else if (pass == 0) {
+            pass = 1;                          // short record: the plain pass only
+        }
+        nb = 0;
+        if (t == 0) fill = 0;
+        __syncthreads();
+        for (uint64_t base = lo; base < hi || base == lo; base += TILE) {
+            if (base < hi) {
 #pragma unroll
-            for (uint32_t u = 0; u < SEG_UNROLL; ++u) {
-                const uint64_t i = base + t + 256u * u;
-                if (i < hi) {
-                    const uint64_t x = hashes[i];
-                    if (x < threshold || nb < s) v[nb + atomicAdd(&fill, 1u)] = x;  // room for a whole tile is guaranteed below
+                for (uint32_t u = 0; u < SEG_UNROLL; ++u) {
+                    const uint64_t i = base + t + 256u * u;
+                    if (i < hi) {
+                        const uint64_t x = hashes[i];
+                        // room for a whole tile is guaranteed by the merge condition below
+                        if (x < threshold || (!provisional && nb < s)) v[nb + atomicAdd(&fill, 1u)] = x;
+                    }
                 }
             }
+            __syncthreads();
+            const bool last = base + TILE >= hi;
+            const uint32_t total = nb + fill;  // uniform
+            if (last || total + TILE > SEG_VALUES) {
+                // merge: sort everything, keep the s smallest distinct values
+                uint32_t m = 1;
+                while (m < total) m <<= 1;
+                for (uint32_t i = total + t; i < m; i += 256) v[i] = ~0ull;
+                __syncthreads();
+                bitonic_sort_lds256(v, m, t);
+                // distinct values among the first `total`: thread t owns positions [a, b)
+                const uint32_t per = (m + 255) / 256;
+                const uint32_t a = t * per < total ? t * per : total, b = a + per < total ? a + per : total;
+                uint64_t mine[SEG_VALUES / 256];
+                uint32_t n_mine = 0;
+                for (uint32_t i = a; i < b; ++i) {
+                    const uint64_t x = v[i];
+                    if (i == 0 || x != v[i - 1]) mine[n_mine++] = x;
+                }
+                uint32_t incl = n_mine;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(incl, d, 64);
+                    if ((int)lane >= d) incl += y;
+                }
+                if (lane == 63) wave_tot[wave] = incl;
+                __syncthreads();               // every thread has read its slice of v[]; wave totals visible
+                uint32_t before = 0, distinct = 0;
+                for (uint32_t w = 0; w < 4; ++w) {
+                    if (w < wave) before += wave_tot[w];
+                    distinct += wave_tot[w];
+                }
+                uint32_t pos = before + incl - n_mine;
+                for (uint32_t i = 0; i < n_mine; ++i, ++pos)
+                    if (pos < s) v[pos] = mine[i];
+                __syncthreads();
+                nb = distinct < s ? distinct : s;
+                if (nb == s && v[s - 1] < threshold) threshold = v[s - 1];
+                if (t == 0) fill = 0;
+                __syncthreads();
+            }
+            if (last) break;
         }
-        __syncthreads();
-        const bool last = base + TILE >= hi;
-        const uint32_t total = nb + fill;      // uniform
-        if (last || total + TILE > SEG_VALUES) {
-            // merge: sort everything, keep the s smallest distinct values
-            uint32_t m = 1;
-            while (m < total) m <<= 1;
-            for (uint32_t i = total + t; i < m; i += 256) v[i] = ~0ull;
-            __syncthreads();
-            bitonic_sort_lds256(v, m, t);
-            // distinct values among the first `total`: thread t owns positions [a, b)
-            const uint32_t per = (m + 255) / 256;
-            const uint32_t a = t * per < total ? t * per : total, b = a + per < total ? a + per : total;
-            uint64_t mine[SEG_VALUES / 256];
-            uint32_t n_mine = 0;
-            for (uint32_t i = a; i < b; ++i) {
-                const uint64_t x = v[i];
-                if (i == 0 || x != v[i - 1]) mine[n_mine++] = x;
-            }
-            uint32_t incl = n_mine;
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(incl, d, 64);
-                if ((int)lane >= d) incl += y;
-            }
-            if (lane == 63) wave_tot[wave] = incl;
-            __syncthreads();                   // every thread has read its slice of v[]; wave totals visible
-            uint32_t before = 0, distinct = 0;
-            for (uint32_t w = 0; w < 4; ++w) {
-                if (w < wave) before += wave_tot[w];
-                distinct += wave_tot[w];
-            }
-            uint32_t pos = before + incl - n_mine;
-            for (uint32_t i = 0; i < n_mine; ++i, ++pos)
-                if (pos < s) v[pos] = mine[i];
-            __syncthreads();
-            nb = distinct < s ? distinct : s;
-            threshold = nb == s ? v[s - 1] : ~0ull;
-            if (t == 0) fill = 0;
-            __syncthreads();
-        }
-        if (last) break;
+        if (!provisional || nb == s) break;    // s distinct values below the provisional threshold: they are the answer
     }
     for (uint32_t i = t; i < nb; i += 256) out[r * (uint64_t)s + i] = v[i];
     if (t == 0) counts[r] = nb;
