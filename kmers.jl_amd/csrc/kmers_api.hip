@@ -782,9 +782,7 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
         HIP_TRY(ctx, hipMemsetAsync(d_state + 1, 0xFF, 8, ctx->stream));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_prune_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, SKETCH_LDS_VALUES * 8));
-        uint64_t done = 0, chunk = std::min<uint64_t>(n, dcap);         // first chunk: everything is a candidate
-        while (done < n) {
-            const uint64_t m = std::min<uint64_t>(chunk, n - done);
+        auto launch_chunk = [&](uint64_t done, uint64_t m) -> int {
             kmers_seq view = *seq;
             Staged vst = st;
             vst.first_bit = st.first_bit + done * (uint64_t)seq->src_bits;
@@ -803,11 +801,45 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
             hipLaunchKernelGGL(sketch_prune_kernel, dim3(1), dim3(1024), SKETCH_LDS_VALUES * 8, ctx->stream, d_best, d_state,
                                d_cand, dcap, (uint32_t)s);
             HIP_TRY(ctx, hipGetLastError());
+            return KMERS_OK;
+        };
+        uint64_t *h_state = reinterpret_cast<uint64_t *>(ctx->h_bounce), *h_best = h_state + 8;
+        // ---- single sweep with a provisional threshold: hashes are close to uniform, so the
+        // (1.5 s + slack) / n quantile of the 64-bit range should leave about 1.5 s candidates from the WHOLE
+        // sequence -- one candidate kernel and one merge instead of geometric rounds.  If at least s distinct
+        // values lie below it they are the sketch; otherwise (skewed or heavily duplicated hashes, or a
+        // sequence with fewer than s distinct kmers) the rounds below start from scratch.
+        const double frac = (1.5 * (double)s + 8.0 * std::sqrt((double)s) + 32.0) / (double)n;
+        if (cut_fits && !one_round && frac < 0.25) {
+            // (not through h_bounce: a short host source may still be on its way to HBM from there)
+            uint64_t *h_up = ctx->h_result + 4;  // pinned words 4..7: {n_best, threshold, overflow, counter}
+            h_up[0] = 0;
+            h_up[1] = (uint64_t)(frac * 18446744073709551616.0);
+            h_up[2] = h_up[3] = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(d_state, h_up, 32, hipMemcpyHostToDevice, ctx->stream));
+            if (int rc = launch_chunk(0, n)) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(h_state, d_state, 32, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(h_state + 4, ctx->d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(h_best, d_best, (size_t)s * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (h_state[4] == NO_ERROR_POS && h_state[2] == 0 && h_state[0] == s) {
+                std::memcpy(out_hashes, h_best, (size_t)s * 8);
+                if (res) { res->status = KMERS_OK; res->n_out = s; }
+                return KMERS_OK;
+            }
+            // not enough below the provisional threshold (or an EncodeError, handled by the paths below): start over
+            HIP_TRY(ctx, hipMemsetAsync(d_state, 0, 32, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(d_state + 1, 0xFF, 8, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_recent, 0xFF, (size_t)RECENT_SLOTS * 8, ctx->stream));
+        }
+        uint64_t done = 0, chunk = std::min<uint64_t>(n, dcap);         // first chunk: everything is a candidate
+        while (done < n) {
+            const uint64_t m = std::min<uint64_t>(chunk, n - done);
+            if (int rc = launch_chunk(done, m)) return rc;
             done += m;
             chunk = std::max<uint64_t>(dcap / 2, ratio * done);
         }
         // results through pinned memory, one wait: state, the error slot, and (optimistically) the sketch
-        uint64_t *h_state = reinterpret_cast<uint64_t *>(ctx->h_bounce), *h_best = h_state + 8;
         HIP_TRY(ctx, hipMemcpyAsync(h_state, d_state, 32, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(h_state + 4, ctx->d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(h_best, d_best, (size_t)s * 8, hipMemcpyDeviceToHost, ctx->stream));
