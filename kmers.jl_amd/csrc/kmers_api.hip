@@ -806,10 +806,11 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
         uint64_t *h_state = reinterpret_cast<uint64_t *>(ctx->h_bounce), *h_best = h_state + 8;
         // ---- single sweep with a provisional threshold: hashes are close to uniform, so the
         // (1.5 s + slack) / n quantile of the 64-bit range should leave about 1.5 s candidates from the WHOLE
-        // sequence -- one candidate kernel and one merge instead of geometric rounds.  If at least s distinct
+        // sequence (2.5 s with the factor below) -- one candidate kernel and one merge instead of geometric rounds.  If at least s distinct
         // values lie below it they are the sketch; otherwise (skewed or heavily duplicated hashes, or a
         // sequence with fewer than s distinct kmers) the rounds below start from scratch.
-        const double frac = (1.5 * (double)s + 8.0 * std::sqrt((double)s) + 32.0) / (double)n;
+        // (2.5 s rather than 1.5 s: in repeat-rich sequence half of the kmers below the threshold may be duplicates)
+        const double frac = (2.5 * (double)s + 8.0 * std::sqrt((double)s) + 32.0) / (double)n;
         if (cut_fits && !one_round && frac < 0.25) {
             // (not through h_bounce: a short host source may still be on its way to HBM from there)
             uint64_t *h_up = ctx->h_result + 4;  // pinned words 4..7: {n_best, threshold, overflow, counter}
@@ -822,6 +823,11 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
             HIP_TRY(ctx, hipMemcpyAsync(h_state + 4, ctx->d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipMemcpyAsync(h_best, d_best, (size_t)s * 8, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef KMERS_SKETCH_DEBUG
+            std::fprintf(stderr, "provisional sweep: n_best %llu threshold %llx overflow %llu counter %llu err %llx T0 %llx\n",
+                         (unsigned long long)h_state[0], (unsigned long long)h_state[1], (unsigned long long)h_state[2],
+                         (unsigned long long)h_state[3], (unsigned long long)h_state[4], (unsigned long long)h_up[1]);
+#endif
             if (h_state[4] == NO_ERROR_POS && h_state[2] == 0 && h_state[0] == s) {
                 std::memcpy(out_hashes, h_best, (size_t)s * 8);
                 if (res) { res->status = KMERS_OK; res->n_out = s; }

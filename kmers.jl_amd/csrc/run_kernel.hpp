@@ -75,6 +75,13 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
     // arithmetic (profiles/r01_tuning.md).
     constexpr uint32_t CB = RMODE == RMODE_SKETCH ? 512u : 1u;
     __shared__ uint64_t cbuf[CB];
+    // the workgroup's own recently seen candidates (direct-mapped, plain loads/stores: a stale or lost
+    // entry only costs a look at the global table): repeats of a homopolymer or tandem-repeat kmer stop here
+    constexpr uint32_t LC = RMODE == RMODE_SKETCH ? 256u : 1u;
+    __shared__ uint64_t lcache[LC];
+    if constexpr (RMODE == RMODE_SKETCH) {
+        for (uint32_t i = tid; i < LC; i += RBLOCK) lcache[i] = ~0ull;  // ~0 is never cached (see below)
+    }
     __shared__ uint32_t ccount;
     __shared__ unsigned long long cbase;
     if (RMODE == RMODE_SKETCH && tid == 0) ccount = 0;  // visible after the tile loop's first barrier
@@ -88,7 +95,13 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
                 if (sbest[mid] < h) lo = mid + 1;
                 else hi = mid;
             }
-            if ((lo == nb || sbest[lo] != h) && sketch_is_new(a, h)) {
+            bool fresh = lo == nb || sbest[lo] != h;
+            if (fresh && h != ~0ull) {
+                const uint32_t slot = (uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 56) & (LC - 1u);
+                if (lcache[slot] == h) fresh = false;
+                else lcache[slot] = h;
+            }
+            if (fresh && sketch_is_new(a, h)) {
                 const uint32_t p = atomicAdd(&ccount, 1u);
                 if (p < CB) cbuf[p] = h;
                 else sketch_append(a, h);  // the tile's LDS buffer is full: straight to the global one
