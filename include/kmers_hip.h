@@ -23,7 +23,8 @@
  * a kmers_result.  KMERS_E_ENCODE carries what the Julia shim needs to
  * `throw(BioSequences.EncodeError(A(), reinterpret(DNA, enc)))` exactly like
  * src/construction.jl:108-110: the 1-based position of the FIRST offending symbol
- * in sequence order and its raw 4-bit encoding.  On E_ENCODE the output buffers
+ * in sequence order and its raw source encoding (4-bit code, or the byte of an ASCII
+ * source).  On E_ENCODE the output buffers
  * are unspecified (the bulk form cannot "yield some, then throw").
  *
  * There is NO CPU fallback in this library: without a usable HIP device every
@@ -48,7 +49,7 @@ extern "C" {
 #define KMERS_E_HIP 3         /* HIP runtime failure / no device */
 #define KMERS_E_NOMEM 4
 #define KMERS_E_UNSUPPORTED 5 /* geometry outside what the kernels cover (see kmers_supported) */
-#define KMERS_E_CAPACITY 6    /* kmers_unambiguous: output capacity too small (res->n_out = needed) */
+#define KMERS_E_CAPACITY 6    /* kmers_unambiguous / kmers_batch: output capacity too small (res->n_out = needed) */
 
 /* flags */
 #define KMERS_MEM_HOST 0x0   /* sequence/output pointers are host memory (staged through HBM) */
@@ -65,7 +66,7 @@ typedef struct {
     int32_t status;   /* KMERS_OK or KMERS_E_* */
     uint32_t err_enc; /* E_ENCODE: raw source encoding of the offending symbol */
     uint64_t err_pos; /* E_ENCODE: 1-based index (index_origin added) of the offending symbol */
-    uint64_t n_out;   /* elements written */
+    uint64_t n_out;   /* elements written (kmers_batch / kmers_minhash_batch on E_ENCODE: index of the failing record) */
 } kmers_result;
 
 /* A borrowed view of a LongSequence (never mutated, never retained past the call:
@@ -196,7 +197,8 @@ int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bi
  * FwKmers.jl:63).  capacity = elements out_a / out_b can hold; if the batch needs more the call
  * returns KMERS_E_CAPACITY with res->n_out = the number required (capacity 0 + NULL outputs = a size
  * query).  KMERS_MEM_DEVICE applies to pool->words, out_a and out_b; out_offsets is always host memory;
- * spans is host memory unless KMERS_SPANS_DEVICE is set (tens of millions of reads: keep them resident).  Kmers of one or two words (K <= 64 two-bit, K <= 32 four-bit).
+ * spans is host memory unless KMERS_SPANS_DEVICE is set (tens of millions of reads: keep them
+ * resident).  Kmers of one or two words (K <= 64 two-bit, K <= 32 four-bit).
  * EncodeError: the first failing record in batch order wins, res->err_pos = 1-based position inside
  * THAT record, res->err_enc = the raw symbol, res->n_out = the record's index in spans[]. */
 typedef struct {
