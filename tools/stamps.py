@@ -15,11 +15,15 @@ for name, (res, args) in cap.SYMBOLS.items():
 h = C.c_void_p(); assert lib.kmers_ctx_create(0, None, C.byref(h)) == 0
 dev = torch.device("cuda", 0)
 K, L = 31, 1_000_000_000
-for bits, hashes, tile in ((4, True, 512), (4, True, 1024), (4, True, 2048), (2, True, 1024), (4, False, 2048)):
+for bits, hashes, tile in ((4, True, 512), (4, True, 1024), (4, True, 2048), (2, True, 1024), (4, False, 2048), (8, True, 1024), (8, True, 512)):
     nw = (L * bits + 63) // 64; n = L - K + 1
-    buf = torch.zeros(nw + 2, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()  # the fill runs on torch's stream, the generator on the library's
-    assert lib.kmers_synth_dna(h, 1, 0, nw, bits, 0, buf.data_ptr()) == 0
+    if bits == 8:
+        buf = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)[torch.randint(0, 4, (nw * 8 + 16,), device=dev)].view(torch.int64)
+        torch.cuda.synchronize()
+    else:
+        buf = torch.zeros(nw + 2, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the generator on the library's
+        assert lib.kmers_synth_dna(h, 1, 0, nw, bits, 0, buf.data_ptr()) == 0
     ok = torch.empty(n, dtype=torch.int64, device=dev)
     oh = torch.empty(n, dtype=torch.int64, device=dev) if hashes else None
     ntiles = (n + tile - 1) // tile
