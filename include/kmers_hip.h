@@ -144,6 +144,16 @@ int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride,
  * forward) kmers, nothing materialised.  *out_value is host memory. */
 int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, int canonical,
                      uint64_t *out_value, int flags, kmers_result *res);
+/* The same reducer over the other iterators of test/benchmark.jl:35-94 (`y ⊻= kmer.data[1]`, for
+ * UnambiguousKmers `first(x).data[1]`): iter = KMERS_ITER_FW / _CANONICAL (stride ignored),
+ * KMERS_ITER_SPACED (SpacedKmers{A,K,stride}, strict; stride * dst_bits <= 64) or
+ * KMERS_ITER_UNAMBIGUOUS (2-bit kmers, K <= 64; stride = 1 is the reference iterator). */
+#define KMERS_ITER_FW 0
+#define KMERS_ITER_CANONICAL 1
+#define KMERS_ITER_SPACED 2
+#define KMERS_ITER_UNAMBIGUOUS 3
+int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, int iter, int stride,
+                          uint64_t *out_value, int flags, kmers_result *res);
 
 /* Fused consumer of docs/src/minhash.md:31-35, `sketch(fx_hash, CanonicalKmers{A,K}(seq), s)`:
  * the s smallest DISTINCT values of fx_hash(canonical kmer, seed), ascending, written to

@@ -12,6 +12,7 @@ from . import build as _build
 OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY = range(7)
 MEM_HOST, MEM_DEVICE, ASYNC, OUT_TUPLES = 0, 1, 2, 4
 BATCH_FW, BATCH_CANONICAL = 0, 1
+ITER_FW, ITER_CANONICAL, ITER_SPACED, ITER_UNAMBIGUOUS = 0, 1, 2, 3
 SPANS_DEVICE = 8
 (OP_REVERSE, OP_COMPLEMENT, OP_REVCOMP, OP_CANONICAL, OP_ISCANONICAL, OP_TO_LONGSEQ, OP_COUNT_GC, OP_AS_INTEGER,
  OP_FROM_INTEGER) = range(9)
@@ -60,6 +61,7 @@ SYMBOLS = {
     "kmers_spaced": (C.c_int, [_P, _S, C.c_int, C.c_int, C.c_int, _P, C.c_int, _R]),
     "kmers_unambiguous": (C.c_int, [_P, _S, C.c_int, C.c_int, _P, _P, C.c_uint64, C.c_int, _R]),
     "kmers_reduce_xor": (C.c_int, [_P, _S, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int, _R]),
+    "kmers_reduce_xor_iter": (C.c_int, [_P, _S, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int, _R]),
     "kmers_minhash": (C.c_int, [_P, _S, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int, _R]),
     "kmers_minimizers": (C.c_int, [_P, _S, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _R]),
     "kmers_composition": (C.c_int, [_P, _S, C.c_int, _P, C.c_int, _R]),

@@ -32,11 +32,14 @@ struct CompactArgs {
     uint32_t tuples;          // 1: out_kmers receives Tuple{Kmer,Int} elements (N + 1 words each), out_starts unused
     uint32_t group;           // tiles staged together per workgroup iteration (count pass: > 1, emit pass: 1)
     uint32_t vec16;           // emit pass: out_kmers / out_starts are 16-byte aligned (16-byte stores allowed)
+    uint64_t *xor_out;        // XOR instantiation: the accumulator
 };
 
 // DENSE: compiled with the no-compaction fast path for wavefronts whose starts are all kept (the host
 // picks it when at least 90 % of the starts survive; the extra code costs the sparse case 10 %)
-template <int SRC_BITS, int N, bool DENSE = false>
+// XOR: no output arrays, no offsets: the head words of the kept kmers are XOR-folded into *xor_out (the reducer of
+// test/benchmark.jl:9-15 over UnambiguousKmers: `y ⊻= first(x).data[1]`)
+template <int SRC_BITS, int N, bool DENSE = false, bool XOR = false>
 __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a) {
     __shared__ uint64_t lds[LDS_QWORDS];
     __shared__ uint64_t amb[MAX_TILE_BASES / 64 + 8];
@@ -48,6 +51,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
     const uint32_t k = a.k;
     const uint64_t mask = head_mask((int)k, 2);
     const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+    uint64_t xacc = 0;  // XOR instantiation only
 
     // A workgroup iteration stages `group` consecutive tiles at once; the emit pass runs with
     // group = 1 (short-lived workgroups, the output stream sets the pace).
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
         // this wavefront's output offset of the group's first tile: requested now so that its latency
         // overlaps the source loads (the emit pass runs with group == 1)
         const uint64_t tile0 = grp * group;
-        const uint64_t pos_first = a.offsets[tile0 * WAVES + wave];
+        uint64_t pos_first = 0;
+        if constexpr (!XOR) pos_first = a.offsets[tile0 * WAVES + wave];
         __syncthreads();
         for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
             uint64_t x = a.src[w0 + wi];
@@ -102,7 +107,10 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
             const uint32_t per_wave = a.tile_kmers / WAVES;
             const uint32_t r_begin = j * a.tile_kmers + wave * per_wave;
             const uint32_t r_end = r_begin + per_wave < mt ? r_begin + per_wave : mt;  // r_begin may exceed mt in the last tile
-            uint64_t pos = j == 0 ? pos_first : a.offsets[tile * WAVES + wave];
+            uint64_t pos = pos_first;
+            if constexpr (!XOR) {
+                if (j != 0) pos = a.offsets[tile * WAVES + wave];
+            }
             // only starts on the stride lattice are candidates: the first one at or after r_begin
             // is r_first, then every `stride`-th (stride 1: every start)
             uint32_t r_first = r_begin;
@@ -173,7 +181,9 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
                         uint64_t fw[N], rc[N];
                         window<N, 2>(lds, 2u * (r + b0), k, mask, fw, rc);
                         uint64_t o = pos + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
+                        if constexpr (XOR) {
+                            xacc ^= fw[0];
+                        } else if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
     #pragma unroll
                             for (int w = 0; w < N; ++w) a.out_kmers[o * (N + 1) + w] = fw[w];
                             a.out_kmers[o * (N + 1) + N] = g + 1 + a.index_origin;
@@ -189,6 +199,10 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
                 }
             }
         }
+    }
+    if constexpr (XOR) {
+        for (int off = 32; off > 0; off >>= 1) xacc ^= __shfl_xor(xacc, off, 64);
+        if (lane == 0) atomicXor(reinterpret_cast<unsigned long long *>(a.xor_out), (unsigned long long)xacc);
     }
 }
 

@@ -734,6 +734,92 @@ int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, 
     return collect(ctx, res, n, out_value);
 }
 
+int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, int iter, int stride, uint64_t *out_value,
+                          int flags, kmers_result *res) {
+    if (iter == KMERS_ITER_FW || iter == KMERS_ITER_CANONICAL)
+        return kmers_reduce_xor(ctx, seq, k, dst_bits, iter == KMERS_ITER_CANONICAL, out_value, flags, res);
+    clear(res);
+    if (iter != KMERS_ITER_SPACED && iter != KMERS_ITER_UNAMBIGUOUS) return ctx ? fail(ctx, KMERS_E_BADARG, "unknown iterator") : KMERS_E_BADARG;
+    if (iter == KMERS_ITER_UNAMBIGUOUS) dst_bits = 2;
+    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags & ~KMERS_ASYNC)) {
+        if (res) res->status = rc;
+        return rc;
+    }
+    if (!out_value) return fail(ctx, KMERS_E_BADARG, "out_value is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out_value = 0;
+    const int nw = kmers_words_per_kmer(k, dst_bits);
+    if (iter == KMERS_ITER_SPACED) {
+        if ((uint64_t)stride * (uint64_t)dst_bits > 64) return fail(ctx, KMERS_E_UNSUPPORTED, "fused SpacedKmers reducer: stride * bits per symbol must be <= 64");
+        const uint64_t n = kmers_count(seq->n_bases, k, stride);
+        if (n == 0) return KMERS_OK;
+        Staged st;
+        if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
+        remember_source(ctx, seq, st);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
+        StreamArgs a{};
+        a.src = st.d_words;
+        a.first_bit = st.first_bit;
+        a.n_bases = seq->n_bases;
+        a.n_kmers = n;
+        a.inspect_end = (n - 1) * (uint64_t)stride + (uint64_t)k;
+        a.out_a = ctx->d_scratch;
+        a.err_slot = ctx->d_err;
+        a.k = (uint32_t)k;
+        a.stride = (uint32_t)stride;
+        a.xor_canonical = 0;
+        a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+        int64_t saved = ctx->max_grid;
+        if (ctx->max_grid <= 0) ctx->max_grid = (int64_t)ctx->n_cus * 8;  // persistent grid: nothing is streamed out
+        const int rc = launch_stream<MODE_XOR>(ctx, a, seq->src_bits, dst_bits, nw, true);
+        ctx->max_grid = saved;
+        if (rc) return rc;
+        return collect(ctx, res, n, out_value);
+    }
+    // UnambiguousKmers: the emit kernel's XOR instantiation (no count pass, no offsets)
+    if (k > 64) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_unambiguous supports K <= 64");
+    uint64_t n = kmers_count(seq->n_bases, k, 1);
+    const bool ascii = seq->src_bits == 8;
+    const bool validate_only = ascii && n == 0 && seq->n_bases > 0;  // invalid bytes still throw (UnambiguousKmers.jl:117-123)
+    if (n == 0 && !validate_only) return KMERS_OK;
+    int kk = k;
+    if (validate_only) {
+        n = seq->n_bases;
+        kk = 1;
+    }
+    Staged st;
+    if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
+    remember_source(ctx, seq, st);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
+    CompactArgs a{};
+    a.src = st.d_words;
+    a.first_bit = st.first_bit;
+    a.n_cand = n;
+    a.ascii_lut = ctx->d_luts + 1024;
+    a.err_slot = ctx->d_err;
+    a.n_bases = seq->n_bases;
+    a.k = (uint32_t)kk;
+    a.stride = (uint32_t)stride;
+    a.index_origin = seq->index_origin;
+    a.tile_kmers = 4096;          // nothing is streamed out: long tiles on a persistent grid
+    a.n_tiles = (n + a.tile_kmers - 1) / a.tile_kmers;
+    a.group = 1;
+    a.xor_out = ctx->d_scratch;
+    dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, (uint64_t)ctx->n_cus * 8)), block(BLOCK);
+    const bool two = kmers_words_per_kmer(kk, 2) == 2;
+#define UX(SB) do { if (two) hipLaunchKernelGGL((unambiguous_kernel<SB, 2, false, true>), grid, block, 0, ctx->stream, a); \
+                    else hipLaunchKernelGGL((unambiguous_kernel<SB, 1, false, true>), grid, block, 0, ctx->stream, a); } while (0)
+    if (seq->src_bits == 8) UX(8);
+    else if (seq->src_bits == 4) UX(4);
+    else UX(2);
+#undef UX
+    HIP_TRY(ctx, hipGetLastError());
+    uint64_t value = 0;
+    const int rc = collect(ctx, res, 0, &value);
+    if (rc == KMERS_OK && !validate_only) *out_value = value;
+    return rc;
+}
+
 static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t seed, uint64_t s,
                         uint64_t *out_hashes, int flags, kmers_result *res) {
     clear(res);

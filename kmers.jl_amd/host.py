@@ -778,6 +778,31 @@ def collect_batch(iterator, records, hashes=False, seed=0, ctx=None):
     return kmers, (second[:total, 0] if want_second else None), offsets.astype(np.int64)
 
 
+def reducer(it):
+    """The reducer of the reference's throughput benchmark (test/benchmark.jl:9-15):
+    `y = 0; for i in it; y ⊻= extract_kmer(i).data[1]; end` -- fused on the device, nothing materialised.
+    Works for FwKmers, FwRvIterator (first of the pair), CanonicalKmers, SpacedKmers and UnambiguousKmers."""
+    if isinstance(it, UnambiguousKmers):
+        code, stride = _capi.ITER_UNAMBIGUOUS, it.lattice
+    elif isinstance(it, SpacedKmers):
+        code, stride = _capi.ITER_SPACED, it.J
+    elif isinstance(it, CanonicalKmers):
+        code, stride = _capi.ITER_CANONICAL, 1
+    elif isinstance(it, (FwKmers, FwRvIterator)):
+        code, stride = _capi.ITER_FW, 1
+    else:
+        raise UnsupportedError("reducer(FwKmers | FwRvIterator | CanonicalKmers | SpacedKmers | UnambiguousKmers)")
+    val = C.c_uint64()
+    res = _capi.Result()
+    view = it._view(0, it.seq.len)
+    rc = it.ctx.lib.kmers_reduce_xor_iter(it.ctx.handle, C.byref(view), it.K, it.alphabet.bits, code, stride, C.byref(val),
+                                          _capi.MEM_DEVICE, C.byref(res))
+    if rc == _capi.E_ENCODE:
+        _raise_encode(it.alphabet, it.seq, res)
+    it.ctx.check(rc, "kmers_reduce_xor_iter")
+    return val.value
+
+
 def sketch_batch(f, iterator, records, s, seed=0, ctx=None):
     """[MinHash.sketch(fx_hash, CanonicalKmers{A,K}(r), s) for r in records] from one launch sequence
     (`kmers_minhash_batch`): a list of ascending uint64 arrays, one per record (docs/src/minhash.md:31-41)."""

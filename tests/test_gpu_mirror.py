@@ -282,3 +282,25 @@ def test_plain_c_client(km, orc, tmp_path):
     assert sk in out.stdout
     bad = subprocess.run([str(exe), "ACGT" * 10 + "P" + "ACGT" * 10], capture_output=True, text=True, timeout=120)
     assert bad.returncode == 1 and "cannot encode 0x50 (Char 'P') at position 41" in bad.stdout
+
+
+def test_reducer_of_the_reference_benchmark(km, orc):
+    """reducer(it) (test/benchmark.jl:9-15) over every iterator type == XOR of the collected elements' head words."""
+    rng = np.random.default_rng(12)
+    text = naive.random_text(rng, 30_000, p_amb=0.01)
+    clean = naive.random_text(rng, 30_000)
+    s4, s2 = km.LongDNA[4](text), km.LongDNA[2](clean)
+
+    def fold(arr):
+        return int(np.bitwise_xor.reduce(arr.words[:, 0])) if len(arr) else 0
+    assert km.reducer(km.FwDNAMers[7](s2)) == fold(km.collect(km.FwDNAMers[7](s2)))
+    assert km.reducer(km.FwRvIterator[km.DNAAlphabet[2], 7](s2)) == fold(km.collect(km.FwDNAMers[7](s2)))
+    assert km.reducer(km.CanonicalDNAMers[7](s2)) == fold(km.collect(km.CanonicalDNAMers[7](s2)))
+    assert km.reducer(km.SpacedDNAMers[7, 5](s2)) == fold(km.collect(km.SpacedDNAMers[7, 5](s2)))
+    un = 0
+    for kmer, _start in km.collect(km.UnambiguousDNAMers[7](s4)):
+        un ^= kmer.data[0]
+    assert km.reducer(km.UnambiguousDNAMers[7](s4)) == un
+    assert km.reducer(km.CanonicalDNAMers[7](clean)) == fold(km.collect(km.CanonicalDNAMers[7](clean)))   # String source
+    with pytest.raises(km.EncodeError):
+        km.reducer(km.SpacedDNAMers[7, 5](s4))

@@ -815,3 +815,44 @@ def test_async_device_calls_and_sync(km, ctx, orc):
     assert rc == 0
     for p in (dw, dk, dh):
         ctx.free(p)
+
+
+def test_reduce_xor_over_spaced_and_unambiguous(km, ctx, orc):
+    """kmers_reduce_xor_iter: the XOR reducer of test/benchmark.jl:9-15 fused over SpacedKmers and
+    UnambiguousKmers == XOR over the head words of the materialised iteration."""
+    cap = km._capi
+    rng = np.random.default_rng(77)
+    for src in (2, 4, 8):
+        for L in (0, 5, 40, 1000, 70_001):
+            text = naive.random_text(rng, L, p_amb=0.01 if src != 2 else 0.0)
+            clean = naive.random_text(rng, L)
+            for K in (1, 7, 21, 32, 33, 64):
+                for name, t in (("amb", text), ("clean", clean)):
+                    words = naive.ascii_words(t) if src == 8 else naive.longseq_words(t if t else "A", src)
+                    seq = cap.Seq(words.ctypes.data, L, 0, 0, src, 0)
+                    res = cap.Result()
+                    val = C.c_uint64(123)
+                    rc = ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), K, 2, cap.ITER_UNAMBIGUOUS, 1, C.byref(val), 0, C.byref(res))
+                    ek, _, eres = orc.unambiguous(words, L, src, K)
+                    assert rc == 0, (src, L, K, name, ctx.last_error())
+                    exp = int(np.bitwise_xor.reduce(ek[:, 0])) if len(ek) else 0
+                    assert val.value == exp, (src, L, K, name)
+                    for J in (1, 5, 7, 32):
+                        ek, eres = orc.spaced(words, L, src, 2, K, J)
+                        rc = ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), K, 2, cap.ITER_SPACED, J, C.byref(val), 0, C.byref(res))
+                        if eres.status == 1:
+                            assert rc == cap.E_ENCODE and res.err_pos == eres.err_pos and res.err_enc == eres.err_enc, (src, L, K, J, name)
+                        else:
+                            assert rc == 0 and val.value == (int(np.bitwise_xor.reduce(ek[:, 0])) if len(ek) else 0), (src, L, K, J, name)
+    # 4-bit kmers through the spaced reducer; fw / canonical are forwarded to kmers_reduce_xor
+    t = naive.random_text(rng, 5000, p_amb=0.05)
+    words = naive.longseq_words(t, 4)
+    seq = cap.Seq(words.ctypes.data, len(t), 0, 0, 4, 0)
+    res, val = cap.Result(), C.c_uint64()
+    ek, _ = orc.spaced(words, len(t), 4, 4, 9, 4)
+    assert ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), 9, 4, cap.ITER_SPACED, 4, C.byref(val), 0, C.byref(res)) == 0
+    assert val.value == int(np.bitwise_xor.reduce(ek[:, 0]))
+    exp, _ = orc.reduce_xor_canonical(words, len(t), 4, 4, 9)
+    assert ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), 9, 4, cap.ITER_CANONICAL, 1, C.byref(val), 0, C.byref(res)) == 0
+    assert val.value == exp
+    assert ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), 9, 2, cap.ITER_SPACED, 40, C.byref(val), 0, C.byref(res)) == cap.E_UNSUPPORTED

@@ -5,8 +5,8 @@ restatement beside it: 10 M symbols, K = 7, every iterator reduced by XOR over `
 
 Sources as in the reference: a 2-bit DNA LongSequence, a 4-bit RNA LongSequence (its iterators build
 4-bit kmers: `FwKmers{typeof(Alphabet(seq)), 7}`), and a String over "AaCcGgTt".  (The amino-acid
-rows are out of scope)  Fw / FwRv / Canonical use the fused XOR consumer; the
-others materialise their elements in HBM and fold them there.  Every GPU value is checked against the
+rows are out of scope)  Every iterator row uses the fused XOR consumer (`kmers_reduce_xor_iter`); the minimizer loop
+materialises its elements in HBM and folds them there.  Every GPU value is checked against the
 oracle's.  `--n` changes the length (the reference uses 10 M)."""
 import argparse
 import ctypes as C
@@ -106,26 +106,26 @@ with torch.cuda.stream(stream):
 
     for name, (host, d, src, dst) in sources.items():
         seq = seq_of(d, src)
-        out_k = torch.empty(N, dtype=torch.int64, device=dev)
-        out_s = torch.empty(N, dtype=torch.int64, device=dev)
+        val = C.c_uint64()
 
         def gpu():
-            ctx.check(ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, out_k.data_ptr(), out_s.data_ptr(), N, cap.MEM_DEVICE, C.byref(res)), "unambiguous")
-            return fold(out_k[:int(res.n_out)])
-        g, tg = best_of(gpu)
+            ctx.check(ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), K, 2, cap.ITER_UNAMBIGUOUS, 1, C.byref(val), cap.MEM_DEVICE,
+                                                    C.byref(res)), "xor unambiguous")
+            return val.value
+        g, tg = best_of(gpu, torch_work=False)
         (kmers, _, _), tc = cpu_time(lambda: orc.unambiguous(host, N, src, K))
         row("UnambiguousKmers", name, tg, tc, g == int(np.bitwise_xor.reduce(kmers[:, 0])))
 
     for J in (5, 7):
         for name, (host, d, src, dst) in sources.items():
             seq = seq_of(d, src)
-            n = (N - K) // J + 1
-            out_k = torch.empty(n, dtype=torch.int64, device=dev)
+            val = C.c_uint64()
 
             def gpu():
-                ctx.check(ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, dst, out_k.data_ptr(), cap.MEM_DEVICE, C.byref(res)), "spaced")
-                return fold(out_k)
-            g, tg = best_of(gpu)
+                ctx.check(ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), K, dst, cap.ITER_SPACED, J, C.byref(val), cap.MEM_DEVICE,
+                                                        C.byref(res)), "xor spaced")
+                return val.value
+            g, tg = best_of(gpu, torch_work=False)
             (kmers, _), tc = cpu_time(lambda: orc.spaced(host, N, src, dst, K, J))
             row(f"SpacedKmers, step {J}", name, tg, tc, g == int(np.bitwise_xor.reduce(kmers[:, 0])))
 
