@@ -363,6 +363,26 @@ def main():
                          "bytes_per_kmer": bytes_per_kmer, "kmers_per_launch": n_kmers_rank},
             "verified": verified,
         }
+        if world == 1:
+            try:  # what this device writes when it does nothing else: torch fills of the two output arrays
+                with torch.cuda.stream(stream):
+                    fills = []
+                    for _ in range(5):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(stream)
+                        out_k.fill_(1)
+                        if out_h is not None:
+                            out_h.fill_(2)
+                        e1.record(stream)
+                        torch.cuda.synchronize()
+                        fills.append(e0.elapsed_time(e1))
+                    fill_bytes = out_k.numel() * 8 + (out_h.numel() * 8 if out_h is not None else 0)
+                    fill_gbps = fill_bytes / (float(np.median(fills[1:])) * 1e-3) / 1e9
+                line["roofline"]["torch_fill_GBps"] = round(fill_gbps, 1)  # torch.Tensor.fill_ over the same two arrays, same run
+                line["roofline"]["vs_torch_fill"] = round(achieved / fill_gbps, 4)
+            except Exception as e:
+                line["roofline"]["torch_fill_GBps"] = None
+                log(f"fill measurement failed: {e!r}")
         if world == 1 and not args.no_other_configs:
             try:  # informative extras; never allowed to break the headline line
                 del out_k, out_h, buf
