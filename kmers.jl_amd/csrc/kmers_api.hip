@@ -389,8 +389,11 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.stride = (uint32_t)stride;
     a.index_origin = seq->index_origin;
     // about 16 KiB of (kmer, start) output per workgroup, as for the stream kernel
-    uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(8u * nw + 8u, BLOCK);
-    tile = std::max<uint32_t>((uint32_t)BLOCK, std::min<uint32_t>(tile, (uint32_t)MAX_TILE_BASES) / BLOCK * BLOCK);
+    // (a tile is measured in candidate starts; on a stride lattice only every stride-th is a candidate, so the tile
+    // grows with the stride to keep the work and the output per workgroup)
+    uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers
+                                        : default_tile(8u * nw + 8u, BLOCK) * (uint32_t)std::min<int>(std::max(stride, 1), 8);
+    tile = std::max<uint32_t>((uint32_t)BLOCK, std::min<uint32_t>(tile, (uint32_t)MAX_TILE_BASES / 2) / BLOCK * BLOCK);
     a.tile_kmers = tile;
     a.n_tiles = (n + tile - 1) / tile;
     const uint64_t n_counts = a.n_tiles * WAVES;
