@@ -33,6 +33,7 @@ struct CompactArgs {
     uint32_t group;           // tiles staged together per workgroup iteration (count pass: > 1, emit pass: 1)
     uint32_t vec16;           // emit pass: out_kmers / out_starts are 16-byte aligned (16-byte stores allowed)
     uint64_t *xor_out;        // XOR instantiation: the accumulator
+    uint32_t slot_mult;       // emit pass: its tile spans slot_mult tiles of the count pass (offsets are per count slot)
 };
 
 // DENSE: compiled with the no-compaction fast path for wavefronts whose starts are all kept (the host
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
         // overlaps the source loads (the emit pass runs with group == 1)
         const uint64_t tile0 = grp * group;
         uint64_t pos_first = 0;
-        if constexpr (!XOR) pos_first = a.offsets[tile0 * WAVES + wave];
+        if constexpr (!XOR) pos_first = a.offsets[(tile0 * WAVES + wave) * a.slot_mult];
         __syncthreads();
         for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
             uint64_t x = a.src[w0 + wi];
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
             const uint32_t r_end = r_begin + per_wave < mt ? r_begin + per_wave : mt;  // r_begin may exceed mt in the last tile
             uint64_t pos = pos_first;
             if constexpr (!XOR) {
-                if (j != 0) pos = a.offsets[tile * WAVES + wave];
+                if (j != 0) pos = a.offsets[(tile * WAVES + wave) * a.slot_mult];
             }
             // only starts on the stride lattice are candidates: the first one at or after r_begin
             // is r_first, then every `stride`-th (stride 1: every start)
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_count_kernel(const CompactA
             const uint32_t c = (uint32_t)__popcll(keep);
             if (c) atomicAdd(&cnt[(64u * q) / per_wave], c);
         }
+        lds_atomics_settle();
         __syncthreads();
         // slot i of the group = (tile, wave) number (m0 / per_wave + i) of the emit pass
         for (uint32_t i = tid; i < n_slots; i += BLOCK) a.counts[m0 / per_wave + i] = cnt[i];

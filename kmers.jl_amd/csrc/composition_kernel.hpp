@@ -110,6 +110,7 @@ __global__ __launch_bounds__(CBLOCK) void composition_kernel(const CompositionAr
 
         if (bound + mt > COUNTER_LIMIT) {
             // a counter MIGHT overflow during this tile: measure the true maximum
+            lds_atomics_settle();  // the previous tile's increments (see device_bits.hpp)
             __syncthreads();
             uint32_t mx = 0;
             for (uint32_t i = tid; i < words; i += CBLOCK) {
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(CBLOCK) void composition_kernel(const CompositionAr
             }
         }
     }
+    lds_atomics_settle();
     __syncthreads();
     flush();
 }

@@ -55,6 +55,13 @@ __device__ __forceinline__ uint32_t bad_bits16(uint64_t bad) {
     return (uint32_t)f & 0xFFFFu;
 }
 
+// Put this before the __syncthreads() that follows LDS atomics WITHOUT a return value (ds_add_u32, ds_max_u32 ...)
+// whose results other wavefronts read after the barrier.  hipcc emits a bare s_barrier there: its workgroup-scope
+// release relies on the LDS queue being in order, and under heavy same-address contention that was observed to be
+// false (a histogram word read after the barrier missed a whole tile of increments: the 16-bit composition counters
+// overflowed in 1-2 % of cold runs).  The explicit wait makes every wavefront's own LDS operations complete first.
+__device__ __forceinline__ void lds_atomics_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // reverse the order of the 32 two-bit symbols of a word (BioSequences.reversebits, bps = 2)
 __device__ __forceinline__ uint64_t rev2(uint64_t x) {
     uint64_t r = __brevll(x);

@@ -409,6 +409,7 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     // count pass: bit-parallel, several whole tiles per staging on a persistent grid (nothing is
     // streamed out); emit pass: one tile per short-lived workgroup
     a.group = std::max<uint32_t>(1u, 8192u / tile);
+    a.slot_mult = 1;
     HIP_TRY(ctx, hipMemsetAsync(a.counts, 0, (size_t)n_counts * 4, ctx->stream));
     {
         const uint64_t n_groups = (n + (uint64_t)a.group * tile - 1) / ((uint64_t)a.group * tile);
@@ -417,7 +418,7 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         else if (seq->src_bits == 4) hipLaunchKernelGGL((unambiguous_count_kernel<4>), cgrid, cblock, 0, ctx->stream, a);
         else hipLaunchKernelGGL((unambiguous_count_kernel<2>), cgrid, cblock, 0, ctx->stream, a);
     }
-    dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap)), block(BLOCK);
+    dim3 grid(1), block(BLOCK);  // the emit grid is set once the survivor density is known
 #define UL(SB, NN, EM)                                                                                     \
     do {                                                                                                   \
         if (NN == 1 && dense_path) hipLaunchKernelGGL((unambiguous_kernel<SB, 1, true>), grid, block, 0, ctx->stream, a); \
@@ -466,6 +467,17 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     const bool dense_path = a.vec16 && stride == 1 && !tuples && total >= n - n / 10;  // mostly clean sequence
     a.tuples = tuples ? 1u : 0u;
     a.group = 1;
+    // Sparse survivors: an emit tile spans several count tiles, so that a workgroup still writes about 16 KiB
+    // (offsets are kept per count slot; a wavefront needs only the offset of the first slot of its chunk).
+    {
+        const double density = (double)total / (double)((n + (uint64_t)stride - 1) / (uint64_t)stride);
+        uint32_t m = ctx->tile_kmers > 0 ? 1u : (uint32_t)std::min(8.0, std::max(1.0, std::floor(1.0 / std::max(density, 1e-3) + 0.5)));
+        m = std::max<uint32_t>(1u, std::min<uint32_t>(m, (uint32_t)(MAX_TILE_BASES / 2) / tile));
+        a.slot_mult = m;
+        a.tile_kmers = tile * m;
+        a.n_tiles = (n + a.tile_kmers - 1) / a.tile_kmers;
+        grid = dim3((unsigned)std::min<uint64_t>(a.n_tiles, cap));
+    }
     UDISPATCH(true);
 #undef UDISPATCH
 #undef UL

@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
             const uint64_t pos = off_l[i] - e0;  // > 0: slot 0 is the last record with off <= e0
             if (pos < (uint64_t)RG_TILE) atomicMax(&owner[(uint32_t)pos], i);
         }
+        lds_atomics_settle();
         __syncthreads();
         constexpr uint32_t PER = RG_TILE / 256;          // consecutive elements per thread
         uint32_t v[PER];
