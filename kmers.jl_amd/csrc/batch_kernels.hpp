@@ -225,11 +225,11 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t *v, uint32_t m, uint32
                 if ((a0 > a1) == up) { v[i] = a1; v[l] = a0; }
             }
             const uint32_t next_j = j > 1 ? j >> 1 : k2;  // the next phase starts at distance k2
-            if (j > 64 || next_j > 64) __syncthreads();
+            if (j > 64 || next_j > 64) block_sync();
             else __builtin_amdgcn_wave_barrier();
         }
     }
-    __syncthreads();
+    block_sync();
 }
 
 __global__ __launch_bounds__(1024) void sketch_prune_kernel(uint64_t *__restrict__ best, uint64_t *__restrict__ state,
@@ -262,9 +262,9 @@ __global__ __launch_bounds__(1024) void sketch_prune_kernel(uint64_t *__restrict
             uint32_t x = __shfl_up(incl, off, 64);
             if ((int)lane >= off) incl += x;
         }
-        __syncthreads();                           // wave_tot may still be read from an earlier call
+        block_sync();                           // wave_tot may still be read from an earlier call
         if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
+        block_sync();
         uint32_t before = 0, distinct = 0;
         for (uint32_t w = 0; w < 16; ++w) {
             if (w < wave) before += wave_tot[w];
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(1024) void sketch_prune_kernel(uint64_t *__restrict
         for (int attempt = 0; attempt < 3; ++attempt) {
             const uint64_t pivot = frac >= 1.0 ? old_threshold : __umul64hi(old_threshold, (uint64_t)(frac * 18446744073709551616.0));
             if (t == 0) sub_n = 0;
-            __syncthreads();
+            block_sync();
             for (uint32_t i = t; i < total; i += 1024) {
                 const uint64_t x = value(i);
                 if (x < pivot || frac >= 1.0) {
@@ -308,16 +308,16 @@ __global__ __launch_bounds__(1024) void sketch_prune_kernel(uint64_t *__restrict
                     if (p < limit) v[p] = x;
                 }
             }
-            __syncthreads();
+            block_sync();
             const uint32_t c = sub_n;
             uint32_t distinct = 0;
             if (c >= s && c <= limit) {
                 for (uint32_t i = c + t; i < limit; i += 1024) v[i] = ~0ull;
-                __syncthreads();
+                block_sync();
                 distinct = dedupe(limit, c, true, false);
                 if (distinct >= s) return;  // uniform: every thread sees the same count
             }
-            __syncthreads();
+            block_sync();
             if (frac >= 1.0) break;         // everything was below the pivot: nothing left to widen
             // too few (or too many duplicates): widen; too many: narrow -- by the observed density
             const double have = c > limit ? (double)c : (c >= s ? (double)distinct : (double)c);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(1024) void sketch_prune_kernel(uint64_t *__restrict
     uint32_t m = 1;
     while (m < total) m <<= 1;                 // power of two >= total
     for (uint32_t i = t; i < m; i += 1024) v[i] = i < total ? value(i) : ~0ull;
-    __syncthreads();
+    block_sync();
     dedupe(m, total, false, true);
 }
 
@@ -358,11 +358,11 @@ __device__ __forceinline__ void bitonic_sort_lds256(uint64_t *v, uint32_t m, uin
                 if ((a0 > a1) == up) { v[i] = a1; v[l] = a0; }
             }
             const uint32_t next_j = j > 1 ? j >> 1 : k2;
-            if (j > 64 || next_j > 64) __syncthreads();   // pairs p, p + 256, ... stay in one wavefront for j <= 64
+            if (j > 64 || next_j > 64) block_sync();   // pairs p, p + 256, ... stay in one wavefront for j <= 64
             else __builtin_amdgcn_wave_barrier();
         }
     }
-    __syncthreads();
+    block_sync();
 }
 
 __global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__restrict__ hashes, const uint64_t *__restrict__ off,
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__r
         }
         nb = 0;
         if (t == 0) fill = 0;
-        __syncthreads();
+        block_sync();
         for (uint64_t base = lo; base < hi || base == lo; base += TILE) {
             if (base < hi) {
 #pragma unroll
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__r
                     }
                 }
             }
-            __syncthreads();
+            block_sync();
             const bool last = base + TILE >= hi;
             const uint32_t total = nb + fill;  // uniform
             if (last || total + TILE > SEG_VALUES) {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__r
                 uint32_t m = 1;
                 while (m < total) m <<= 1;
                 for (uint32_t i = total + t; i < m; i += 256) v[i] = ~0ull;
-                __syncthreads();
+                block_sync();
                 bitonic_sort_lds256(v, m, t);
                 // distinct values among the first `total`: thread t owns positions [a, b)
                 const uint32_t per = (m + 255) / 256;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__r
                     if ((int)lane >= d) incl += y;
                 }
                 if (lane == 63) wave_tot[wave] = incl;
-                __syncthreads();               // every thread has read its slice of v[]; wave totals visible
+                block_sync();               // every thread has read its slice of v[]; wave totals visible
                 uint32_t before = 0, distinct = 0;
                 for (uint32_t w = 0; w < 4; ++w) {
                     if (w < wave) before += wave_tot[w];
@@ -438,11 +438,11 @@ __global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__r
                 uint32_t pos = before + incl - n_mine;
                 for (uint32_t i = 0; i < n_mine; ++i, ++pos)
                     if (pos < s) v[pos] = mine[i];
-                __syncthreads();
+                block_sync();
                 nb = distinct < s ? distinct : s;
                 if (nb == s && v[s - 1] < threshold) threshold = v[s - 1];
                 if (t == 0) fill = 0;
-                __syncthreads();
+                block_sync();
             }
             if (last) break;
         }

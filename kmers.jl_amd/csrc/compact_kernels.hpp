@@ -74,7 +74,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
         const uint64_t tile0 = grp * group;
         uint64_t pos_first = 0;
         if constexpr (!XOR) pos_first = a.offsets[(tile0 * WAVES + wave) * a.slot_mult];
-        __syncthreads();
+        block_sync();
         for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
             uint64_t x = a.src[w0 + wi];
             if constexpr (SRC_BITS == 8) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
                 reinterpret_cast<uint32_t *>(amb)[wi] = 0u;  // 32 symbols per 2-bit word, none ambiguous
             }
         }
-        __syncthreads();
+        block_sync();
 
         for (uint32_t j = 0; j < group; ++j) {
             const uint64_t tile = grp * group + j;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_count_kernel(const CompactA
         const uint32_t nw = (uint32_t)(((end_bit + 63) >> 6) - w0);
         const uint32_t n_slots = (mt + per_wave - 1) / per_wave;
 
-        __syncthreads();
+        block_sync();
         for (uint32_t i = tid; i < n_slots; i += BLOCK) cnt[i] = 0;
         for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
             uint64_t x = a.src[w0 + wi];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_count_kernel(const CompactA
             }
         }
         // (flag bits past the staged range only ever reach starts >= mt, which are masked out below)
-        __syncthreads();
+        block_sync();
 
         const uint32_t n_q = (mt + 63u) / 64u;             // 64 starts per lane
         for (uint32_t q = tid; q < n_q; q += BLOCK) {
@@ -287,8 +287,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_count_kernel(const CompactA
             const uint32_t c = (uint32_t)__popcll(keep);
             if (c) atomicAdd(&cnt[(64u * q) / per_wave], c);
         }
-        lds_atomics_settle();
-        __syncthreads();
+        block_sync();
         // slot i of the group = (tile, wave) number (m0 / per_wave + i) of the emit pass
         for (uint32_t i = tid; i < n_slots; i += BLOCK) a.counts[m0 / per_wave + i] = cnt[i];
     }
@@ -302,10 +301,10 @@ constexpr uint32_t SCAN_SEG = 2048;  // 256 threads x 8
 __device__ __forceinline__ uint64_t block_reduce_sum(uint64_t v, uint64_t *tmp) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63u) == 0) tmp[threadIdx.x >> 6] = v;
-    __syncthreads();
+    block_sync();
     uint64_t total = 0;
     for (uint32_t w = 0; w < blockDim.x / 64; ++w) total += tmp[w];
-    __syncthreads();
+    block_sync();
     return total;
 }
 
@@ -332,12 +331,12 @@ __global__ __launch_bounds__(1024) void scan_segments_kernel(uint64_t *__restric
     uint64_t s = 0;
     for (uint64_t i = lo; i < hi; ++i) s += seg_sums[i];
     part[t] = s;
-    __syncthreads();
+    block_sync();
     for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan of the partials
         uint64_t v = t >= d ? part[t - d] : 0;
-        __syncthreads();
+        block_sync();
         part[t] += v;
-        __syncthreads();
+        block_sync();
     }
     uint64_t run = t ? part[t - 1] : 0;
     for (uint64_t i = lo; i < hi; ++i) {
@@ -360,7 +359,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restr
         uint64_t i = base + t + 256u * j;
         c[t + 256u * j] = i < n ? counts[i] : 0u;
     }
-    __syncthreads();
+    block_sync();
     // thread t owns 8 consecutive counts: local exclusive prefix, then a scan over the thread totals
     uint64_t local[SCAN_SEG / 256];  // 64-bit: kmers_batch scans per-record counts of up to 2^32 - 1
     uint64_t sum = 0;
@@ -376,7 +375,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restr
         if ((int)lane >= off) incl += v;
     }
     if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
+    block_sync();
     uint64_t before = seg_sums[blockIdx.x];
     for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
     const uint64_t excl = before + incl - sum;

@@ -110,8 +110,7 @@ __global__ __launch_bounds__(CBLOCK) void composition_kernel(const CompositionAr
 
         if (bound + mt > COUNTER_LIMIT) {
             // a counter MIGHT overflow during this tile: measure the true maximum
-            lds_atomics_settle();  // the previous tile's increments (see device_bits.hpp)
-            __syncthreads();
+            block_sync();  // the previous tile's increments must have landed (see device_bits.hpp)
             uint32_t mx = 0;
             for (uint32_t i = tid; i < words; i += CBLOCK) {
                 const uint32_t v = hist[i];
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(CBLOCK) void composition_kernel(const CompositionAr
             }
             for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
             if ((tid & 63u) == 0) wave_max[tid >> 6] = mx;
-            __syncthreads();
+            block_sync();
             mx = 0;
 #pragma unroll
             for (int w = 0; w < CBLOCK / 64; ++w) mx = max(mx, wave_max[w]);
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(CBLOCK) void composition_kernel(const CompositionAr
         }
         bound += mt;
 
-        __syncthreads();  // previous tile's readers are done with the stream; histogram zeroing / flush visible
+        block_sync();  // previous tile's readers are done with the stream; histogram zeroing / flush visible
         // ---- phase 1: source words (already in registers) -> 2-bit stream in LDS (RecodingScheme,
         //      construction.jl:75-100); then the NEXT tile's words start their trip from HBM
 #pragma unroll
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(CBLOCK) void composition_kernel(const CompositionAr
             }
         }
         if (tile + gridDim.x < a.n_tiles) prefetch(geometry(tile + gridDim.x));
-        __syncthreads();
+        block_sync();
 
         // ---- phase 2: 16 consecutive forward kmers per lane from one 64-bit window ---------
         const uint32_t r0 = tid * CRUN;
@@ -182,8 +181,7 @@ __global__ __launch_bounds__(CBLOCK) void composition_kernel(const CompositionAr
             }
         }
     }
-    lds_atomics_settle();
-    __syncthreads();
+    block_sync();
     flush();
 }
 

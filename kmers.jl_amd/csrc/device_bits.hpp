@@ -61,6 +61,12 @@ __device__ __forceinline__ uint32_t bad_bits16(uint64_t bad) {
 // false (a histogram word read after the barrier missed a whole tile of increments: the 16-bit composition counters
 // overflowed in 1-2 % of cold runs).  The explicit wait makes every wavefront's own LDS operations complete first.
 __device__ __forceinline__ void lds_atomics_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Every workgroup barrier of these kernels: the wavefront's own LDS operations first, then the barrier (the wait
+// is what hipcc emits in most places anyway; making it unconditional removes the class of hazards above).
+__device__ __forceinline__ void block_sync() {
+    lds_atomics_settle();
+    __syncthreads();
+}
 
 // reverse the order of the 32 two-bit symbols of a word (BioSequences.reversebits, bps = 2)
 __device__ __forceinline__ uint64_t rev2(uint64_t x) {

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void recode_kernel(const RecodeArgs a) {
     __shared__ uint8_t lut[SRC == 8 ? 256 : 1];
     if constexpr (SRC == 8) {
         for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lut[i] = a.ascii_lut[i];
-        __syncthreads();
+        block_sync();
     }
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
     for (uint64_t wi = (uint64_t)blockIdx.x * 256u + threadIdx.x; wi < a.n_words; wi += stride) {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
         base_l[i] = r_lo + i < a.n_records ? a.spans[r_lo + i].first_base : 0;
     }
     for (uint32_t i = tid; i < (uint32_t)RG_TILE; i += 256u) owner[i] = 0;
-    __syncthreads();
+    block_sync();
     const bool covered = off_l[n_rec - 1] > e_last;
     if (covered) {
         // owner[e] = record slot of element e0 + e, without a search per element: every slot marks the
@@ -194,8 +194,7 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
             const uint64_t pos = off_l[i] - e0;  // > 0: slot 0 is the last record with off <= e0
             if (pos < (uint64_t)RG_TILE) atomicMax(&owner[(uint32_t)pos], i);
         }
-        lds_atomics_settle();
-        __syncthreads();
+        block_sync();
         constexpr uint32_t PER = RG_TILE / 256;          // consecutive elements per thread
         uint32_t v[PER];
 #pragma unroll
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
         if (lane == 63u) wave_max[wave] = m;
         uint32_t before = __shfl_up(m, 1, 64);           // maximum of the earlier lanes of this wavefront
         if (lane == 0) before = 0;
-        __syncthreads();
+        block_sync();
         for (uint32_t w = 0; w < wave; ++w) before = max(before, wave_max[w]);
 #pragma unroll
         for (uint32_t j = 0; j < PER; j += 4)
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                 make_uint4(max(v[j], before), max(v[j + 1], before), max(v[j + 2], before), max(v[j + 3], before));
         // first stream symbol of a slot's record minus its element offset: window of element g = delta + g
         for (uint32_t i = tid; i < n_rec; i += 256u) base_l[i] = base_l[i] - off_l[i] + a.stream_origin;
-        __syncthreads();
+        block_sync();
     }
     // Two separate instantiations of the element loop -- LDS lookups or global lookups -- rather than a
     // per-access select: hipcc turned `covered ? lds[i] : global[i]` into FLAT loads whose address is

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
     if (tile < a.n_tiles) prefetch(geometry(tile));
     for (; tile < a.n_tiles; tile += gridDim.x) {
         const Geo g = geometry(tile);
-        __syncthreads();  // previous tile's readers are done with the stream
+        block_sync();  // previous tile's readers are done with the stream
 #pragma unroll
         for (int i = 0; i < PRE; ++i) {
             const uint32_t wi = tid + (uint32_t)i * RBLOCK;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
             }
         }
         if (tile + gridDim.x < a.n_tiles) prefetch(geometry(tile + gridDim.x));
-        __syncthreads();
+        block_sync();
 
         const uint32_t r0 = tid * RRUN;
         if (r0 < g.mt) {
@@ -195,16 +195,16 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
             }
         }
         if constexpr (RMODE == RMODE_SKETCH) {
-            __syncthreads();
+            block_sync();
             const uint32_t filled = ccount < CB ? ccount : CB;  // uniform
             if (filled) {
                 if (tid == 0) cbase = atomicAdd(reinterpret_cast<unsigned long long *>(a.out_b), (unsigned long long)filled);
-                __syncthreads();
+                block_sync();
                 for (uint32_t i = tid; i < filled; i += RBLOCK) {
                     const unsigned long long pos = cbase + i;
                     if (pos < a.capacity) a.out_a[pos] = cbuf[i];
                 }
-                __syncthreads();
+                block_sync();
                 if (tid == 0) ccount = 0;  // ordered before the next tile's candidates by its two barriers
             }
         }

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
 #ifdef KMERS_STAMPS
         uint64_t t0 = __builtin_amdgcn_s_memrealtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 #endif
-        __syncthreads();  // previous tile's readers are done with the LDS stream
+        block_sync();  // previous tile's readers are done with the LDS stream
         // ---- phase 1: source words -> DST-bit stream in LDS ------------------------------
         for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
             uint64_t f = stage_word<SRC_BITS, DST>(lds, wi, a.src[w0 + wi], lut);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
 #ifdef KMERS_STAMPS
         t1 = __builtin_amdgcn_s_memrealtime();
 #endif
-        __syncthreads();
+        block_sync();
 #ifdef KMERS_STAMPS
         t2 = __builtin_amdgcn_s_memrealtime();
 #endif
