@@ -249,3 +249,35 @@ def test_sketch_batch_mirror(km, orc):
     for i, t in enumerate(texts):
         one = km.sketch(km.fx_hash, km.CanonicalDNAMers[16](km.LongDNA[2](t)), 50) if len(t) >= 16 else np.zeros(0, np.uint64)
         assert np.array_equal(sk[i], one), i
+
+
+def test_batch_tiles_crowded_with_empty_records(km, ctx, orc):
+    """Thousands of consecutive records that own nothing (shorter than K) inside one tile: the tile's slice of
+    the layout does not fit LDS and the lanes search the global arrays instead."""
+    cap = km._capi
+    rng = np.random.default_rng(90)
+    K = 25
+    texts = []
+    for block in range(6):
+        texts += [naive.random_text(rng, int(l)) for l in rng.integers(K, 400, 5)]
+        texts += [naive.random_text(rng, int(l)) for l in rng.integers(0, K, 3000)]   # own nothing
+    texts += [naive.random_text(rng, 5000)]
+    for src in (2, 4):
+        words, spans, n_pool = build_pool(texts, src, rng, False)
+        seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+        ea, eb, eoff = expected(orc, texts, src, 2, K, cap.BATCH_CANONICAL, 1)
+        total = int(eoff[-1])
+        out_a, out_b = np.zeros(total, np.uint64), np.zeros(total, np.uint64)
+        offs = np.zeros(len(texts) + 1, np.uint64)
+        res = cap.Result()
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, K, 2, vp(out_a), vp(out_b), 1, vp(offs),
+                                 total, 0, C.byref(res))
+        assert rc == 0 and res.n_out == total, ctx.last_error()
+        assert np.array_equal(offs, eoff) and np.array_equal(out_a, ea[:, 0]) and np.array_equal(out_b, eb), src
+        sk = np.zeros((len(texts), 20), np.uint64)
+        cnt = np.zeros(len(texts), np.uint64)
+        assert ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq), spans, len(texts), K, 2, 1, 20, vp(sk), vp(cnt), 0, C.byref(res)) == 0
+        for i in (0, 4, 5, 3004, len(texts) - 1):
+            n_i = int(eoff[i + 1] - eoff[i])
+            e = np.unique(eb[int(eoff[i]):int(eoff[i + 1])])[:20]
+            assert cnt[i] == len(e) and np.array_equal(sk[i, :len(e)], e), (src, i, n_i)
