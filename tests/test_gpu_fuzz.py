@@ -150,3 +150,68 @@ def test_fuzz_fused_consumers(km, ctx, orc, seed):
         assert ctx.lib.kmers_minimizers(ctx.handle, C.byref(seq), K, W, stride, 2, mode, vp(outm), 0, C.byref(res)) == 0, tag
         em, _ = orc.minimizers(view_words, L, osrc, 2, K, W, stride, mode)
         assert res.n_out == m == len(em) and np.array_equal(outm[:m], em), tag + (W, stride, mode)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_batches(km, ctx, orc, seed):
+    """Random batches: spans in arbitrary order, overlapping, nested, empty, shorter than K; random pool offset,
+    source kind, kmer alphabet, K, mode; plus per-record sketches on the same spans."""
+    cap = km._capi
+    rng = np.random.default_rng(3000 + seed)
+    for case in range(40):
+        src = int(rng.choice([2, 4, 8]))
+        dst = int(rng.choice([2, 4]))
+        K = int(rng.choice([1, 3, 15, 16, 17, 31, 32, 33, 64])) if dst == 2 else int(rng.choice([1, 5, 16, 17, 32]))
+        n_pool = int(rng.choice([0, 10, 500, 20_000]))
+        lead = int(rng.choice([0, 1, 17, 64]))
+        text = naive.random_text(rng, lead + n_pool, p_amb=0.0)
+        if src == 8:
+            text = "".join(c.lower() if rng.random() < 0.3 else c for c in text)
+        words = naive.ascii_words(text) if src == 8 else naive.longseq_words(text if text else "A", src)
+        n_rec = int(rng.choice([0, 1, 5, 300]))
+        spans = []
+        for _ in range(n_rec):
+            a = int(rng.integers(0, n_pool + 1))
+            ln = int(min(n_pool - a, rng.choice([0, 1, K - 1, K, K + 7, 200, 5000])))
+            spans.append((a, max(ln, 0)))
+        arr = (cap.Span * max(n_rec, 1))(*[cap.Span(a, b) for a, b in spans])
+        seq = cap.Seq(words.ctypes.data, n_pool, lead, 0, src, 0)
+        mode = int(rng.integers(0, 2))
+        N = (K * dst + 63) // 64
+        recs = [text[lead + a:lead + a + ln] for a, ln in spans]
+        exp_a, exp_b, offs = [], [], [0]
+        for t in recs:
+            if len(t) >= K:
+                w = naive.ascii_words(t) if src == 8 else naive.longseq_words(t, src)
+                if mode == 0:
+                    x, y, _ = orc.fwrv(w, len(t), src, dst, K)
+                else:
+                    x, y, _ = orc.canonical(w, len(t), src, dst, K, seed=case)
+                exp_a.append(x)
+                exp_b.append(y)
+            offs.append(offs[-1] + max(0, len(t) - K + 1))
+        total = offs[-1]
+        out_a = np.zeros((max(total, 1), N), np.uint64)
+        out_b = np.zeros((max(total, 1), N) if mode == 0 else max(total, 1), np.uint64)
+        got_off = np.zeros(n_rec + 1, np.uint64)
+        res = cap.Result()
+        tag = (seed, case, src, dst, K, n_pool, lead, n_rec, mode)
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), arr, n_rec, mode, K, dst, vp(out_a), vp(out_b), case, vp(got_off), total, 0,
+                                 C.byref(res))
+        assert rc == 0 and res.n_out == total, tag + (ctx.last_error(),)
+        assert [int(x) for x in got_off] == offs, tag
+        if total:
+            assert np.array_equal(out_a[:total], np.concatenate(exp_a)) and np.array_equal(out_b[:total], np.concatenate(exp_b)), tag
+        if dst == 2 and n_rec:
+            s = int(rng.choice([1, 7, 300]))
+            sk = np.zeros((n_rec, s), np.uint64)
+            cnt = np.zeros(n_rec, np.uint64)
+            assert ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq), arr, n_rec, K, 2, case, s, vp(sk), vp(cnt), 0, C.byref(res)) == 0, tag
+            for i, t in enumerate(recs):
+                if len(t) >= K:
+                    w = naive.ascii_words(t) if src == 8 else naive.longseq_words(t, src)
+                    _, eh, _ = orc.canonical(w, len(t), src, 2, K, seed=case)
+                    e = np.unique(eh)[:s]
+                else:
+                    e = np.zeros(0, np.uint64)
+                assert cnt[i] == len(e) and np.array_equal(sk[i, :len(e)], e), tag + (i, s)

@@ -16,4 +16,5 @@ for seed in range(lo, hi):
     tf.test_fuzz_iterators.__wrapped__(km, ctx, orc, seed) if hasattr(tf.test_fuzz_iterators, "__wrapped__") else tf.test_fuzz_iterators(km, ctx, orc, seed)
     if seed % 3 == 0:
         tf.test_fuzz_fused_consumers(km, ctx, orc, seed)
+    tf.test_fuzz_batches(km, ctx, orc, seed)
     print("seed", seed, "ok", flush=True)
