@@ -1231,8 +1231,10 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         r.stream = static_cast<uint64_t *>(ctx->stage[4]);
         r.ascii_lut = ascii_table(ctx, dst_bits, pool->alphabet != 0);
         if (sb != 2) {
-            if (int rc = ensure_stage(ctx, 5, flag_bytes)) return rc;
+            if (int rc = ensure_stage(ctx, 5, flag_bytes + 16)) return rc;
             r.flags = static_cast<uint64_t *>(ctx->stage[5]);
+            r.any_flag = reinterpret_cast<uint64_t *>(static_cast<char *>(ctx->stage[5]) + ((flag_bytes + 7) & ~(size_t)7));
+            HIP_TRY(ctx, hipMemsetAsync(r.any_flag, 0, 8, ctx->stream));
         }
         dim3 rgrid((unsigned)std::min<uint64_t>((n_src_words + 255) / 256, (uint64_t)ctx->n_cus * 16)), rblock(256);
         if (sb == 4) hipLaunchKernelGGL((recode_kernel<4, 2>), rgrid, rblock, 0, ctx->stream, r);
@@ -1242,6 +1244,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         HIP_TRY(ctx, hipGetLastError());
         a.stream = r.stream;
         a.flags = r.flags;
+        a.any_flag = r.any_flag;
     }
 
     uint64_t *d_a = out_a, *d_b = out_b;

@@ -35,6 +35,7 @@ struct RaggedSpan {              // == kmers_span of the C ABI
 struct RaggedArgs {
     const uint64_t *stream;      // DST-bit little-endian symbol stream (the pool itself for Copyable pools)
     const uint64_t *flags;       // one bit per stream symbol, NULL when nothing can fail (Copyable)
+    const uint64_t *any_flag;    // set by the recode pass if it flagged any symbol: clean pools skip the flag loads
     uint64_t stream_origin;      // stream symbol index of pool symbol 0
     const uint64_t *rec_off;     // [n + 1] element offset of every record (records shorter than K own nothing)
     const RaggedSpan *spans;     // [n] the records
@@ -53,6 +54,7 @@ struct RecodeArgs {
     uint64_t n_words;
     uint64_t *stream;
     uint64_t *flags;
+    uint64_t *any_flag;          // becomes non-zero if any symbol of the pool cannot be encoded
     const uint8_t *ascii_lut;
 };
 
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256) void recode_kernel(const RecodeArgs a) {
             uint64_t bad;
             reinterpret_cast<uint32_t *>(a.stream)[wi] = pack_4to2(x, bad);
             reinterpret_cast<uint16_t *>(a.flags)[wi] = (uint16_t)bad_bits16(bad);
+            if (bad) *a.any_flag = 1;  // rare; any writer, same value
         } else if constexpr (SRC == 8) {
             uint32_t codes = 0, f = 0;
 #pragma unroll
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(256) void recode_kernel(const RecodeArgs a) {
             if constexpr (DST == 2) reinterpret_cast<uint16_t *>(a.stream)[wi] = (uint16_t)codes;
             else reinterpret_cast<uint32_t *>(a.stream)[wi] = codes;
             reinterpret_cast<uint8_t *>(a.flags)[wi] = (uint8_t)f;
+            if (f) *a.any_flag = 1;
         } else {  // SRC 2 -> DST 4 (TwoToFour): 1 << code, nothing can fail
             a.stream[2 * wi] = expand_2to4((uint32_t)x);
             a.stream[2 * wi + 1] = expand_2to4((uint32_t)(x >> 32));
@@ -168,6 +172,8 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
     const uint32_t tid = threadIdx.x;
     const uint32_t k = a.k;
     const uint64_t mask = head_mask((int)k, DST);
+    // (the pool may hold flagged symbols outside every record, so a set any_flag only means "look")
+    const uint64_t *flags = (a.flags && *a.any_flag) ? a.flags : nullptr;
     const uint64_t tile = blockIdx.x;
     const uint64_t e0 = tile * RG_TILE;
     const uint64_t r_lo = a.tile_rec[tile];
@@ -254,11 +260,11 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
             uint64_t p;  // stream symbol index of the window
             if constexpr (COVERED) p = base_l[r] + g;
             else p = slot_base(r) + (g - slot_off(r)) + a.stream_origin;
-            if (a.flags) {
+            if (flags) {
                 const uint64_t fq = p >> 6;
                 const uint32_t fs = (uint32_t)(p & 63u);
-                uint64_t f = a.flags[fq] >> fs;
-                if (fs + k > 64u) f |= (a.flags[fq + 1] << 1) << (63u - fs);
+                uint64_t f = flags[fq] >> fs;
+                if (fs + k > 64u) f |= (flags[fq + 1] << 1) << (63u - fs);
                 if (k < 64u) f &= (1ull << k) - 1ull;
                 if (f) atomicMin(a.err_slot, (unsigned long long)g);
             }
@@ -303,11 +309,11 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                 if (same) {
                     const uint64_t p = base_l[o[0]] + g;
                     const uint32_t span = k + cnt - 1u;            // symbols the run reads
-                    if (a.flags) {
+                    if (flags) {
                         const uint64_t fq = p >> 6;
                         const uint32_t fs = (uint32_t)(p & 63u);
-                        uint64_t f = a.flags[fq] >> fs;
-                        if (fs + span > 64u) f |= (a.flags[fq + 1] << 1) << (63u - fs);
+                        uint64_t f = flags[fq] >> fs;
+                        if (fs + span > 64u) f |= (flags[fq + 1] << 1) << (63u - fs);
                         f &= (1ull << span) - 1ull;               // span <= 32 + 3
                         if (f) {                                   // the first element whose window holds a flagged symbol
                             const uint32_t first = (uint32_t)__builtin_ctzll(f);
