@@ -232,7 +232,7 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     const bool stride1 = (J == 1) && vec_ok && !a.tuples;
     const uint32_t pass = (stride1 && n_words == 1 ? 2u : 1u) * BLOCK;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
-                         (MODE == MODE_CANON && a.out_b ? 8u : 0u);
+                         (MODE == MODE_CANON && a.out_b ? 8u : 0u) + (MODE == MODE_FW && a.out_starts ? 8u : 0u);
     if (a.tuples) out_bytes = MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u;
     if (MODE == MODE_XOR || MODE == MODE_SKETCH || MODE == MODE_COUNT) out_bytes = 4u;  // nothing streamed out: long tiles
     if (MODE == MODE_MINIMIZER) out_bytes = 8u * n_words;
@@ -359,6 +359,28 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     return rc;
 }
 
+
+// UnambiguousKmers over a sequence in which every window survives (a 2-bit source, or a count pass that kept
+// everything): its elements are FwKmers plus the start indices 1, 2, ..., so the stream kernel writes them at
+// its two-array rate -- no compaction, no offsets.
+int emit_all_kept(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, uint64_t n, uint64_t *d_k, long long *d_s) {
+    StreamArgs a{};
+    a.src = st.d_words;
+    a.first_bit = st.first_bit;
+    a.n_bases = seq->n_bases;
+    a.n_kmers = n;
+    a.inspect_end = seq->n_bases;
+    a.out_a = d_k;
+    a.out_starts = d_s;
+    a.start_origin = seq->index_origin;
+    a.err_slot = ctx->d_err;
+    a.k = (uint32_t)k;
+    a.stride = 1;
+    a.ascii_lut = ascii_table(ctx, 2, seq->alphabet != 0);
+    const bool vec_ok = (!d_k || aligned16(d_k)) && (!d_s || aligned16(d_s));
+    return launch_stream<MODE_FW>(ctx, a, seq->src_bits, 2, kmers_words_per_kmer(k, 2), vec_ok);
+}
+
 // UnambiguousKmers: count -> scan -> emit (compact_kernels.hpp)
 int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uint64_t *out_kmers,
                     int64_t *out_starts, uint64_t capacity, int flags, kmers_result *res) {
@@ -410,8 +432,10 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     // streamed out); emit pass: one tile per short-lived workgroup
     a.group = std::max<uint32_t>(1u, 8192u / tile);
     a.slot_mult = 1;
-    HIP_TRY(ctx, hipMemsetAsync(a.counts, 0, (size_t)n_counts * 4, ctx->stream));
-    {
+    // a 2-bit source has no ambiguous symbols: every start survives, nothing to count
+    const bool known_all = seq->src_bits == 2 && stride == 1 && !validate_only;
+    if (!known_all) HIP_TRY(ctx, hipMemsetAsync(a.counts, 0, (size_t)n_counts * 4, ctx->stream));
+    if (!known_all) {
         const uint64_t n_groups = (n + (uint64_t)a.group * tile - 1) / ((uint64_t)a.group * tile);
         dim3 cgrid((unsigned)std::min<uint64_t>(n_groups, 256 * 8)), cblock(BLOCK);
         if (seq->src_bits == 8) hipLaunchKernelGGL((unambiguous_count_kernel<8>), cgrid, cblock, 0, ctx->stream, a);
@@ -431,13 +455,15 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         else                    { if (nw == 1) UL(2, 1, EM); else UL(2, 2, EM); }      \
     } while (0)
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(scan_segment_sums_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, a.counts, n_counts, seg_sums);
-    hipLaunchKernelGGL(scan_segments_kernel, dim3(1), dim3(1024), 0, ctx->stream, seg_sums, n_seg);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, a.counts, n_counts, seg_sums, n_seg, offsets);
-    HIP_TRY(ctx, hipGetLastError());
-    uint64_t total = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&total, offsets + n_counts, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t total = n;
+    if (!known_all) {
+        hipLaunchKernelGGL(scan_segment_sums_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, a.counts, n_counts, seg_sums);
+        hipLaunchKernelGGL(scan_segments_kernel, dim3(1), dim3(1024), 0, ctx->stream, seg_sums, n_seg);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, a.counts, n_counts, seg_sums, n_seg, offsets);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(&total, offsets + n_counts, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (ascii) {  // an invalid byte anywhere in the source is an EncodeError
         if (int erc = collect(ctx, res, total)) return erc;
     }
@@ -460,6 +486,16 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     if (!dev) {
         if (out_kmers) { if (int rc = ensure_stage(ctx, 1, kb)) return rc; d_k = (uint64_t *)ctx->stage[1]; }
         if (out_starts) { if (int rc = ensure_stage(ctx, 2, sb)) return rc; d_s = (long long *)ctx->stage[2]; }
+    }
+    if (total == n && stride == 1 && !tuples && !validate_only) {
+        // nothing was dropped: FwKmers + start indices at the stream kernel's rate
+        if (int rc = emit_all_kept(ctx, seq, st, k, n, d_k, d_s)) return rc;
+        if (!dev) {
+            if (out_kmers) HIP_TRY(ctx, hipMemcpyAsync(out_kmers, d_k, kb, hipMemcpyDeviceToHost, ctx->stream));
+            if (out_starts) HIP_TRY(ctx, hipMemcpyAsync(out_starts, d_s, sb, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return KMERS_OK;
     }
     a.out_kmers = d_k;
     a.out_starts = d_s;

@@ -58,6 +58,8 @@ struct StreamArgs {
     uint32_t window_kmers;
     uint32_t minimizer_mode;
     uint32_t tuples;          // 1: array-of-structs output in out_a (Tuple{Kmer,Kmer} / Tuple{Kmer,UInt64}), out_b unused
+    long long *out_starts;    // MODE_FW: 1-based start of every kmer (+ start_origin): UnambiguousKmers over a clean sequence
+    uint64_t start_origin;
 };
 
 // First inspected offending symbol of one source word -> err_slot (rare path, kept inline and
@@ -372,17 +374,21 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
                 }
                 store_kmer<2 * N>(a.out_a, g, t);
             } else if constexpr (MODE == MODE_FW) {
+                const uint64_t start = g + 1 + a.start_origin;
                 if constexpr (KPL == 2) {
                     if (both) {
-                        *reinterpret_cast<ulonglong2 *>(a.out_a + g) = make_ulonglong2(fw[0][0], fw[1][0]);
+                        if (a.out_a) *reinterpret_cast<ulonglong2 *>(a.out_a + g) = make_ulonglong2(fw[0][0], fw[1][0]);
                         if (a.out_b) *reinterpret_cast<ulonglong2 *>(a.out_b + g) = make_ulonglong2(rc[0][0], rc[1][0]);
+                        if (a.out_starts) *reinterpret_cast<ulonglong2 *>(a.out_starts + g) = make_ulonglong2(start, start + 1);
                     } else {
-                        a.out_a[g] = fw[0][0];
+                        if (a.out_a) a.out_a[g] = fw[0][0];
                         if (a.out_b) a.out_b[g] = rc[0][0];
+                        if (a.out_starts) a.out_starts[g] = (long long)start;
                     }
                 } else {
-                    store_kmer<N>(a.out_a, g, fw[0]);
+                    if (a.out_a) store_kmer<N>(a.out_a, g, fw[0]);
                     if (a.out_b) store_kmer<N>(a.out_b, g, rc[0]);
+                    if (a.out_starts) a.out_starts[g] = (long long)start;
                 }
             } else {
                 // canonical: fw < rv ? fw : rv (CanonicalKmers.jl:224)
