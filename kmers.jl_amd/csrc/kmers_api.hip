@@ -948,7 +948,9 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
         // sequence with fewer than s distinct kmers) the rounds below start from scratch.
         // (2.5 s rather than 1.5 s: in repeat-rich sequence half of the kmers below the threshold may be duplicates)
         const double frac = (2.5 * (double)s + 8.0 * std::sqrt((double)s) + 32.0) / (double)n;
-        if (cut_fits && !one_round && frac < 0.25) {
+        // (sketches too large for the pivot cut have the small buffer: 2.5 s + slack must still fit it with room to spare)
+        const bool sweep_fits = cut_fits || 2.5 * (double)s + 8.0 * std::sqrt((double)s) + 32.0 + 1024.0 <= (double)dcap;
+        if (sweep_fits && !one_round && frac < 0.25) {
             // (not through h_bounce: a short host source may still be on its way to HBM from there)
             uint64_t *h_up = ctx->h_result + 4;  // pinned words 4..7: {n_best, threshold, overflow, counter}
             h_up[0] = 0;
@@ -1012,6 +1014,42 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
     std::vector<uint64_t> best, chunk_vals;
     uint64_t threshold = ~0ull;  // hashes strictly below it are candidates
     uint64_t done = 0;
+    // One sweep with a provisional threshold first (see the device-resident path): about 2.5 s candidates from the
+    // whole sequence, sorted on the host; accepted if they hold at least s distinct values.
+    {
+        const double frac = (2.5 * (double)s + 8.0 * std::sqrt((double)s) + 32.0) / (double)n;
+        if (!ctx->sketch_host_only && frac < 0.25 && 3.0 * (double)s + 1024.0 < (double)cap) {
+            HIP_TRY(ctx, hipMemsetAsync(d_counter, 0, 8, ctx->stream));
+            StreamArgs a{};
+            a.out_a = d_cand;
+            a.out_b = d_counter;
+            a.seed = seed;
+            a.threshold = (uint64_t)(frac * 18446744073709551616.0);
+            a.capacity = cap;
+            a.recent = ctx->d_recent;
+            a.recent_mask = RECENT_SLOTS - 1;
+            if (int rc = launch_consumer<RMODE_SKETCH, MODE_SKETCH>(ctx, seq, st, k, dst_bits, a)) return rc;
+            uint64_t *h = reinterpret_cast<uint64_t *>(ctx->h_bounce);
+            HIP_TRY(ctx, hipMemcpyAsync(h, d_counter, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(h + 1, ctx->d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            const uint64_t count = h[0];
+            if (h[1] == NO_ERROR_POS && count <= cap) {
+                best.resize(count);
+                if (count) HIP_TRY(ctx, hipMemcpy(best.data(), d_cand, count * 8, hipMemcpyDeviceToHost));
+                std::sort(best.begin(), best.end());
+                best.erase(std::unique(best.begin(), best.end()), best.end());
+                if (best.size() >= s) {
+                    std::memcpy(out_hashes, best.data(), (size_t)s * 8);
+                    if (res) { res->status = KMERS_OK; res->n_out = s; }
+                    return KMERS_OK;
+                }
+            }
+            // not enough below the provisional threshold, or an EncodeError (the rounds below attribute it): start over
+            best.clear();
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_recent, 0xFF, (size_t)RECENT_SLOTS * 8, ctx->stream));
+        }
+    }
     // Geometric chunks: with the threshold at the s-th smallest value seen so far, a chunk r times
     // as long as everything before it yields about r*s new candidates, so the buffer stays small.
     uint64_t chunk = std::min<uint64_t>(n, cap / 2);

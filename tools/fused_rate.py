@@ -32,6 +32,9 @@ for bits in (4, 2):
     out = np.zeros(1000, dtype=np.uint64)
     for K in (16, 31):
         timed(f"minhash sketch s=1000 K={K}", lambda: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, 2, 0, 1000, out.ctypes.data_as(C.c_void_p), cap.MEM_DEVICE, C.byref(res)))
+    for s_big in (100, 4000, 20000):
+        big = np.zeros(s_big, dtype=np.uint64)
+        timed(f"minhash sketch s={s_big} K=21", lambda: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), 21, 2, 0, s_big, big.ctypes.data_as(C.c_void_p), cap.MEM_DEVICE, C.byref(res)))
     for K in (4, 6, 7, 8, 9, 10, 11, 12):
         counts = ctx.alloc(4 ** K * 4)
         timed(f"composition K={K}", lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), K, counts, cap.MEM_DEVICE, C.byref(res)))
