@@ -80,7 +80,7 @@ def cpu_baseline(k, bits, seed, total_bases, budget_s=12.0, chunk_bases=1 << 24)
         bufs = [(np.zeros((small, 1), np.uint64), np.zeros(small, np.uint64)) for _ in range(ncpu)]
         inputs = [orc.synth_words(seed, c * small // per_word, small // per_word + 1, bits) for c in range(ncpu)]
         rate1 = done / spent
-        reps = max(1, int(3.0 * rate1 / small))  # about 3 s per thread at the single-thread rate
+        reps = max(1, int(budget_s / 4.0 * rate1 / small))  # about a quarter of the budget per thread (3 s by default)
 
         def work(i):
             for _ in range(reps):

@@ -1,0 +1,42 @@
+"""bench.py's contract with the driver: one JSON line with the agreed keys (GPU), and a loud failure
+instead of a CPU fallback when no HIP device exists (CPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+    assert r.stdout.strip() == ""   # no JSON line is printed for a run that measured nothing
+
+
+@pytest.mark.gpu
+def test_bench_json_line_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--bases", "4000000",
+                        "--no-other-configs", "--cpu-budget", "0.3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "u64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == d["unit"]
+    assert d["verified"] is True and d["value"] > 0
