@@ -15,6 +15,7 @@ CPU except packing text into LongSequence words and unpacking kmers back to text
 (The Julia `@ccall` shim with the same mapping is julia/KmersHIP.jl, see INTEGRATION.md.)
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -102,6 +103,10 @@ class Context:
                 "no usable MI355X/HIP device (this library has no CPU fallback)")
         self.handle = h
         self.device = device
+        # test hook: run everything with a non-default workgroup tile (kmers per tile, a multiple of 512)
+        tile = os.environ.get("KMERS_TILE_KMERS")
+        if tile:
+            self.set_param(_capi.PARAM_TILE_KMERS, int(tile))
 
     def close(self):
         if getattr(self, "handle", None):
