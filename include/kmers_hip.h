@@ -216,6 +216,11 @@ typedef struct {
     uint64_t n_bases;
 } kmers_span;
 #define KMERS_SPANS_DEVICE 8 /* flag of kmers_batch: `spans` points to HBM */
+#define KMERS_BATCH_SKIP 16  /* flag of kmers_batch: an element whose window holds a symbol the kmer alphabet cannot encode
+                              * (N in a read, say) does not fail the call; it is written as all-ones in every output
+                              * array -- never a canonical kmer, and never a (kmer, reverse complement) pair -- so that
+                              * the kept elements are those of UnambiguousKmers{A,K}(record) at the same indices (the
+                              * composition docs/src/faq.md:28-33 describes); element offsets stay those of the strict call */
 #define KMERS_BATCH_FW 0
 #define KMERS_BATCH_CANONICAL 1
 int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int mode, int k,
@@ -227,7 +232,8 @@ int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, 
  * fx_hash(canonical kmer, seed) over CanonicalKmers{A,K}(record i), ascending, in
  * out_hashes[i * s .. i * s + out_counts[i]) (out_counts[i] <= s; fewer when the record has fewer distinct
  * kmers).  pool / spans / flags as for kmers_batch (KMERS_MEM_DEVICE covers pool->words, out_hashes and
- * out_counts); s <= 2048.  EncodeError: as kmers_batch (res->n_out = the failing record). */
+ * out_counts); s <= 2048.  EncodeError: as kmers_batch (res->n_out = the failing record); with KMERS_BATCH_SKIP
+ * windows over symbols that cannot be encoded are left out of the sketches instead. */
 int kmers_minhash_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k,
                         int dst_bits, uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags,
                         kmers_result *res);

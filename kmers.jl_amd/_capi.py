@@ -14,6 +14,7 @@ MEM_HOST, MEM_DEVICE, ASYNC, OUT_TUPLES = 0, 1, 2, 4
 BATCH_FW, BATCH_CANONICAL = 0, 1
 ITER_FW, ITER_CANONICAL, ITER_SPACED, ITER_UNAMBIGUOUS = 0, 1, 2, 3
 SPANS_DEVICE = 8
+BATCH_SKIP = 16
 (OP_REVERSE, OP_COMPLEMENT, OP_REVCOMP, OP_CANONICAL, OP_ISCANONICAL, OP_TO_LONGSEQ, OP_COUNT_GC, OP_AS_INTEGER,
  OP_FROM_INTEGER) = range(9)
 PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY = 1, 2, 3, 4

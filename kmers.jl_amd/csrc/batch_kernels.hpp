@@ -366,7 +366,8 @@ __device__ __forceinline__ void bitonic_sort_lds256(uint64_t *v, uint32_t m, uin
 }
 
 __global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__restrict__ hashes, const uint64_t *__restrict__ off,
-                                                              uint32_t s, uint64_t *__restrict__ out, uint64_t *__restrict__ counts) {
+                                                              uint32_t s, uint64_t *__restrict__ out, uint64_t *__restrict__ counts,
+                                                              uint32_t drop_all_ones) {
     extern __shared__ uint64_t v[];            // SEG_VALUES values: [0, nb) the running sketch, then candidates
     __shared__ uint32_t fill;                  // candidates appended since the last merge
     __shared__ uint32_t wave_tot[4];
@@ -400,7 +401,8 @@ __global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__r
                     if (i < hi) {
                         const uint64_t x = hashes[i];
                         // room for a whole tile is guaranteed by the merge condition below
-                        if (x < threshold || (!provisional && nb < s)) v[nb + atomicAdd(&fill, 1u)] = x;
+                        // (KMERS_BATCH_SKIP: all-ones marks a window over a symbol that cannot be encoded -- not a hash)
+                        if ((x < threshold || (!provisional && nb < s)) && !(drop_all_ones && x == ~0ull)) v[nb + atomicAdd(&fill, 1u)] = x;
                     }
                 }
             }

@@ -1213,7 +1213,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
                       int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
                       uint64_t capacity, int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | INTERNAL_OUT_DEVICE))) {
+    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP | INTERNAL_OUT_DEVICE))) {
         if (res) res->status = rc;
         return rc;
     }
@@ -1292,6 +1292,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     a.seed = seed;
     a.err_slot = ctx->d_err;
     a.k = (uint32_t)k;
+    a.skip = (flags & KMERS_BATCH_SKIP) ? 1u : 0u;
     a.stream_origin = origin;
     if (sb == dst_bits) {  // Copyable: the pool is the stream, nothing can fail
         a.stream = src0;
@@ -1454,7 +1455,7 @@ static int minhash_batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(segment_sketch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      SEG_VALUES * 8));
     hipLaunchKernelGGL(segment_sketch_kernel, dim3((unsigned)n_spans), dim3(256), SEG_VALUES * 8, ctx->stream, d_hashes, d_off, (uint32_t)s,
-                       d_out, d_cnt);
+                       d_out, d_cnt, (flags & KMERS_BATCH_SKIP) ? 1u : 0u);
     HIP_TRY(ctx, hipGetLastError());
     if (!dev) {
         HIP_TRY(ctx, hipMemcpyAsync(out_hashes, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -47,6 +47,7 @@ struct RaggedArgs {
     uint64_t seed;
     unsigned long long *err_slot;  // atomicMin of the first failing ELEMENT index
     uint32_t k;
+    uint32_t skip;               // 1: elements whose window holds a flagged symbol are written as all-ones instead of failing
 };
 
 struct RecodeArgs {
@@ -256,7 +257,8 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
             return a.spans[r_lo + r].first_base;
         };
         // element g of record slot r: forward kmer and reverse complement (and the flag test)
-        auto element = [&](uint64_t g, uint64_t r, uint64_t (&fw)[N], uint64_t (&rc)[N]) {
+        auto element = [&](uint64_t g, uint64_t r, uint64_t (&fw)[N], uint64_t (&rc)[N]) -> bool {
+            bool bad = false;
             uint64_t p;  // stream symbol index of the window
             if constexpr (COVERED) p = base_l[r] + g;
             else p = slot_base(r) + (g - slot_off(r)) + a.stream_origin;
@@ -266,9 +268,11 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                 uint64_t f = flags[fq] >> fs;
                 if (fs + k > 64u) f |= (flags[fq + 1] << 1) << (63u - fs);
                 if (k < 64u) f &= (1ull << k) - 1ull;
-                if (f) atomicMin(a.err_slot, (unsigned long long)g);
+                bad = f != 0;
+                if (bad && !a.skip) atomicMin(a.err_slot, (unsigned long long)g);
             }
             window_global<N, DST>(a.stream, p * (uint64_t)DST, k, mask, fw, rc);
+            return bad && a.skip;  // true: the caller writes the all-ones sentinel
         };
         auto finish = [&](const uint64_t (&fw)[N], const uint64_t (&rc)[N], uint64_t (&x)[N], uint64_t (&y)[N]) {
             // x -> out_a, y -> out_b (FW: reverse complement; CANON: y[0] = fx_hash)
@@ -309,17 +313,20 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                 if (same) {
                     const uint64_t p = base_l[o[0]] + g;
                     const uint32_t span = k + cnt - 1u;            // symbols the run reads
+                    uint64_t fbits = 0;                            // flagged symbols of the run (skip mode)
                     if (flags) {
                         const uint64_t fq = p >> 6;
                         const uint32_t fs = (uint32_t)(p & 63u);
                         uint64_t f = flags[fq] >> fs;
                         if (fs + span > 64u) f |= (flags[fq + 1] << 1) << (63u - fs);
                         f &= (1ull << span) - 1ull;               // span <= 32 + 3
-                        if (f) {                                   // the first element whose window holds a flagged symbol
+                        if (f && !a.skip) {                        // the first element whose window holds a flagged symbol
                             const uint32_t first = (uint32_t)__builtin_ctzll(f);
                             atomicMin(a.err_slot, (unsigned long long)(g + (first >= k ? first - k + 1u : 0u)));
                         }
+                        if (a.skip) fbits = f;
                     }
+                    const uint64_t kbits = k >= 64u ? ~0ull : (1ull << k) - 1ull;
                     const uint64_t bit = p * (uint64_t)DST;
                     const uint64_t q = bit >> 6;
                     const uint32_t sh = (uint32_t)(bit & 63u);
@@ -332,8 +339,8 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                     // symbols K, K+1, K+2 of the run
                     const uint32_t S = (uint32_t)((uint32_t)DST * k == 64u ? W1 : funnel64(W0, W1, (uint32_t)DST * k));
                     finish(fw, rc, x, y);
-                    X[ps][0] = x[0];
-                    Y[ps][0] = y[0];
+                    X[ps][0] = (fbits & kbits) ? ~0ull : x[0];
+                    Y[ps][0] = (fbits & kbits) ? ~0ull : y[0];
 #pragma unroll
                     for (uint32_t j = 1; j < RUN; ++j) {
                         if (j < cnt) {
@@ -344,18 +351,19 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                             fw[0] = ((fw[0] << DST) | sym) & mask;
                             rc[0] = (rc[0] >> DST) | (csym << top);
                             finish(fw, rc, x, y);
-                            X[ps][j] = x[0];
-                            Y[ps][j] = y[0];
+                            const bool masked = ((fbits >> j) & kbits) != 0;
+                            X[ps][j] = masked ? ~0ull : x[0];
+                            Y[ps][j] = masked ? ~0ull : y[0];
                         }
                     }
                 } else {
 #pragma unroll
                     for (uint32_t j = 0; j < RUN; ++j) {
                         if (j < cnt) {
-                            element(g + j, o[j], fw, rc);
+                            const bool masked = element(g + j, o[j], fw, rc);
                             finish(fw, rc, x, y);
-                            X[ps][j] = x[0];
-                            Y[ps][j] = y[0];
+                            X[ps][j] = masked ? ~0ull : x[0];
+                            Y[ps][j] = masked ? ~0ull : y[0];
                         }
                     }
                 }
@@ -384,8 +392,12 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                 const uint64_t g = e0 + e;
                 if (g > e_last) break;
                 uint64_t fw[N], rc[N], x[N], y[N];
-                element(g, record_of(g), fw, rc);
+                const bool masked = element(g, record_of(g), fw, rc);
                 finish(fw, rc, x, y);
+                if (masked) {
+#pragma unroll
+                    for (int w = 0; w < N; ++w) x[w] = y[w] = ~0ull;
+                }
                 if (a.out_a) store_kmer<N>(a.out_a, g, x);
                 if constexpr (MODE == MODE_FW) {
                     if (a.out_b) store_kmer<N>(a.out_b, g, y);

@@ -281,3 +281,48 @@ def test_batch_tiles_crowded_with_empty_records(km, ctx, orc):
             n_i = int(eoff[i + 1] - eoff[i])
             e = np.unique(eb[int(eoff[i]):int(eoff[i + 1])])[:20]
             assert cnt[i] == len(e) and np.array_equal(sk[i, :len(e)], e), (src, i, n_i)
+
+
+@pytest.mark.parametrize("src", [4, 8])
+def test_batch_skip_mode_masks_ambiguous_windows(km, ctx, orc, src):
+    """KMERS_BATCH_SKIP: reads with N do not fail; the elements whose window holds an ambiguous symbol are
+    all-ones, the others equal the strict result -- i.e. the kept ones are UnambiguousKmers of each record
+    (checked through the oracle's UnambiguousKmers: kept indices == its start positions)."""
+    cap = km._capi
+    rng = np.random.default_rng(70 + src)
+    for K in (5, 21, 31, 33):
+        texts = [naive.random_text(rng, int(l), p_amb=0.02) for l in rng.choice([0, K - 1, K, 60, 150, 151, 2000], 400)]
+        words, spans, n_pool = build_pool(texts, src, rng, True)
+        seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+        N = (2 * K + 63) // 64
+        offs = np.zeros(len(texts) + 1, np.uint64)
+        res = cap.Result()
+        assert ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, K, 2, None, None, 3, vp(offs), 0,
+                                   cap.BATCH_SKIP, C.byref(res)) == 0
+        total = int(res.n_out)
+        out_a, out_b = np.zeros((total, N), np.uint64), np.zeros(total, np.uint64)
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, K, 2, vp(out_a), vp(out_b), 3, None, total,
+                                 cap.BATCH_SKIP, C.byref(res))
+        assert rc == 0, ctx.last_error()
+        sk = np.zeros((len(texts), 50), np.uint64)
+        cnt = np.zeros(len(texts), np.uint64)
+        assert ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq), spans, len(texts), K, 2, 3, 50, vp(sk), vp(cnt), cap.BATCH_SKIP,
+                                           C.byref(res)) == 0
+        for i, t in enumerate(texts):
+            lo, hi = int(offs[i]), int(offs[i + 1])
+            assert hi - lo == max(0, len(t) - K + 1)
+            if hi == lo:
+                assert cnt[i] == 0
+                continue
+            w = naive.ascii_words(t) if src == 8 else naive.longseq_words(t, src)
+            uk, us, _ = orc.unambiguous(w, len(t), src, K)            # kept windows: (forward kmer, 1-based start)
+            kept = np.zeros(hi - lo, bool)
+            kept[us - 1] = True
+            got = out_a[lo:hi]
+            assert np.array_equal(~(got == np.uint64(0xFFFFFFFFFFFFFFFF)).all(axis=1), kept), (src, K, i)
+            canon = np.array([orc.canonical_kmer(tuple(int(x) for x in r), K, 2) for r in uk], dtype=np.uint64).reshape(-1, N)
+            assert np.array_equal(got[kept], canon), (src, K, i)
+            hashes = np.array([orc.fx_hash(tuple(int(x) for x in r), 3) for r in canon], dtype=np.uint64)
+            assert np.array_equal(out_b[lo:hi][kept], hashes) and (out_b[lo:hi][~kept] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+            e = np.unique(hashes)[:50]
+            assert cnt[i] == len(e) and np.array_equal(sk[i, :len(e)], e), (src, K, i)
