@@ -741,7 +741,7 @@ def _build_pool(records):
     return recs, pool, spans, n_pool, src_bits
 
 
-def collect_batch(iterator, records, hashes=False, seed=0, ctx=None):
+def collect_batch(iterator, records, hashes=False, seed=0, ctx=None, skip_ambiguous=False):
     """Elements of `iterator(record)` for every record of a batch, concatenated in record order, from
     ONE launch (include/kmers_hip.h `kmers_batch`): the reference's `for record in reader ...
     CanonicalDNAMers{K}(sequence(record))` loop (docs/src/minhash.md:31-35) without the per-call cost.
@@ -751,7 +751,8 @@ def collect_batch(iterator, records, hashes=False, seed=0, ctx=None):
     records:  LongSequences of one alphabet, or str / bytes records (ASCII).
     Returns (first, second, offsets): FwKmers -> (kmers, None, offsets); FwRvIterator -> (kmers,
     reverse complements, offsets); CanonicalKmers -> (kmers, fx_hash values if `hashes` else None,
-    offsets).  Record i owns elements offsets[i]:offsets[i+1]."""
+    offsets).  Record i owns elements offsets[i]:offsets[i+1].  skip_ambiguous=True (KMERS_BATCH_SKIP): windows over
+    symbols the kmer alphabet cannot encode are written as all-ones instead of raising EncodeError."""
     ctx = ctx or default_context()
     cls, params = getattr(iterator, "cls", None), getattr(iterator, "params", None)
     if cls not in (FwKmers, FwRvIterator, CanonicalKmers):
@@ -762,9 +763,10 @@ def collect_batch(iterator, records, hashes=False, seed=0, ctx=None):
     res = _capi.Result()
     offsets = np.zeros(len(recs) + 1, dtype=np.uint64)
     mode = _capi.BATCH_CANONICAL if cls is CanonicalKmers else _capi.BATCH_FW
+    mem = _capi.MEM_HOST | (_capi.BATCH_SKIP if skip_ambiguous else 0)
     N = n_coding_elements(K, alphabet.bits)
     rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(recs), mode, K, alphabet.bits, None, None, seed & MASK64,
-                             offsets.ctypes.data_as(C.c_void_p), 0, _capi.MEM_HOST, C.byref(res))
+                             offsets.ctypes.data_as(C.c_void_p), 0, mem, C.byref(res))
     ctx.check(rc, "kmers_batch")
     total = int(res.n_out)
     first = np.zeros((max(total, 1), N), dtype=np.uint64)
@@ -772,7 +774,7 @@ def collect_batch(iterator, records, hashes=False, seed=0, ctx=None):
     second = np.zeros((max(total, 1), 1 if cls is CanonicalKmers else N), dtype=np.uint64) if want_second else None
     rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(recs), mode, K, alphabet.bits,
                              first.ctypes.data_as(C.c_void_p), second.ctypes.data_as(C.c_void_p) if want_second else None,
-                             seed & MASK64, offsets.ctypes.data_as(C.c_void_p), total, _capi.MEM_HOST, C.byref(res))
+                             seed & MASK64, offsets.ctypes.data_as(C.c_void_p), total, mem, C.byref(res))
     if rc == _capi.E_ENCODE:
         bad = recs[int(res.n_out)]
         _raise_encode(alphabet, bad, res)

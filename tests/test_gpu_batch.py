@@ -326,3 +326,15 @@ def test_batch_skip_mode_masks_ambiguous_windows(km, ctx, orc, src):
             assert np.array_equal(out_b[lo:hi][kept], hashes) and (out_b[lo:hi][~kept] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
             e = np.unique(hashes)[:50]
             assert cnt[i] == len(e) and np.array_equal(sk[i, :len(e)], e), (src, K, i)
+
+
+def test_collect_batch_skip_ambiguous(km):
+    reads = ["ACGTACGTAC", "ACGTNACGTACG", "NNNN", "ACGTACGTACGTTT"]
+    with pytest.raises(km.EncodeError):
+        km.collect_batch(km.CanonicalDNAMers[4], reads)
+    kmers, _, offs = km.collect_batch(km.CanonicalDNAMers[4], reads, skip_ambiguous=True)
+    ones = np.uint64(0xFFFFFFFFFFFFFFFF)
+    rec1 = kmers.words[offs[1]:offs[2], 0]
+    assert list(rec1 == ones) == [False, True, True, True, True] + [False] * 4   # windows 2..5 cover the N
+    assert (kmers.words[offs[2]:offs[3], 0] == ones).all() and offs[3] - offs[2] == 1
+    assert not (kmers.words[offs[0]:offs[1], 0] == ones).any() and not (kmers.words[offs[3]:offs[4], 0] == ones).any()
