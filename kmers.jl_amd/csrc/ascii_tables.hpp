@@ -40,4 +40,45 @@ inline void build_ascii_skipping_table(uint8_t *t) {
     }
 }
 
+// The same tables WITHOUT memory: entry `c` of table `table` computed from two immediates, so that a kernel
+// fills its 256-byte LDS copy with no load from HBM in front of its first barrier (the byte loads of the table
+// used to add a whole global-load latency to every short-lived workgroup of the byte-source kernels).
+//   table 0 / 1: ascii_encode of the 2-bit DNA / RNA alphabet   2 / 3: of the 4-bit DNA / RNA alphabet
+//   table 4    : ASCII_SKIPPING_LUT
+#ifdef __HIPCC__
+#define KMERS_HD __host__ __device__
+#else
+#define KMERS_HD
+#endif
+constexpr int ASCII_TABLE_SKIPPING = 4;
+KMERS_HD inline uint8_t ascii_entry(uint32_t table, uint32_t c) {
+    // IUPAC value ("-ACMGRSVTWYHKDBN" index) of the letters a..p and q..z, one nibble each; t and u hold 8
+    //                  p o n m l k j i h g f e d c b a                      z y x w v u t s r q
+    const uint64_t LO = 0x00F30C00B400D2E1ull, HI = 0x0000000A09788650ull >> 0;
+    const uint32_t lower = c | 0x20u;
+    const bool letter = lower >= 0x61u && lower <= 0x7Au && (c & 0x40u);
+    uint32_t v = 0;
+    if (letter) {
+        const uint32_t idx = lower - 0x61u;
+        v = idx < 16u ? (uint32_t)(LO >> (4u * idx)) & 15u : (uint32_t)(HI >> (4u * (idx - 16u))) & 15u;
+        const bool rna = (table & 1u) != 0;
+        if (table != (uint32_t)ASCII_TABLE_SKIPPING) {
+            if (lower == 0x74u && rna) v = 0;   // 't' is not an RNA symbol
+            if (lower == 0x75u && !rna) v = 0;  // 'u' is not a DNA symbol
+        }
+    }
+    const bool one_hot = v != 0 && (v & (v - 1u)) == 0;
+    const uint32_t code = v == 1u ? 0u : v == 2u ? 1u : v == 4u ? 2u : 3u;  // trailing_zeros of a one-hot nibble
+    if (table == (uint32_t)ASCII_TABLE_SKIPPING) {
+        if (c == 0x2Du) return 0xf0;            // '-'
+        if (v == 0) return 0xff;
+        return one_hot ? (uint8_t)code : (uint8_t)0xf0;
+    }
+    if (table >= 2u) {                           // 4-bit alphabets: every IUPAC letter and the gap
+        if (c == 0x2Du) return 0;
+        return v ? (uint8_t)v : (uint8_t)0x80;
+    }
+    return one_hot ? (uint8_t)code : (uint8_t)0x80;
+}
+
 }  // namespace kmers

@@ -26,7 +26,7 @@ struct CompactArgs {
     uint32_t k;
     uint32_t stride;          // keep windows with (start0 % stride) == 0
     uint32_t tile_kmers;      // multiple of 256
-    const uint8_t *ascii_lut; // SRC_BITS == 8: the reference's ASCII_SKIPPING_LUT (common.jl:22-32)
+    uint32_t ascii_table;     // SRC_BITS == 8: ASCII_TABLE_SKIPPING = the reference's ASCII_SKIPPING_LUT (common.jl:22-32)
     unsigned long long *err_slot;  // SRC_BITS == 8: first invalid byte (0xff in the table) -> EncodeError
     uint64_t n_bases;         // SRC_BITS == 8: every byte below n_bases is inspected (UnambiguousKmers.jl:117-123)
     uint32_t tuples;          // 1: out_kmers receives Tuple{Kmer,Int} elements (N + 1 words each), out_starts unused
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if constexpr (SRC_BITS == 8) {
-        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = a.ascii_lut[i];
+        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);
     }
     const uint32_t k = a.k;
     const uint64_t mask = head_mask((int)k, 2);
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_count_kernel(const CompactA
     const uint32_t k = a.k;
     const uint32_t per_wave = a.tile_kmers / WAVES;        // starts per (tile, wave), a multiple of 64
     if constexpr (SRC_BITS == 8) {
-        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = a.ascii_lut[i];
+        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);
     }
     const uint32_t group_starts = a.group * a.tile_kmers;  // whole tiles, <= MAX_TILE_BASES starts per iteration
     const uint64_t n_groups = (a.n_cand + group_starts - 1) / group_starts;

@@ -40,7 +40,7 @@ struct CompositionArgs {
     uint64_t n_tiles;
     uint32_t *counts;              // 4^K global counters (zeroed by the host)
     unsigned long long *err_slot;
-    const uint8_t *ascii_lut;
+    uint32_t ascii_table;
     uint32_t k;
     uint32_t pass;                 // upper bits of the indices this launch counts (0 when 4^K <= 65536)
     uint32_t hist_words;           // LDS words in use: max(1, min(4^K, 65536) / 2)
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(CBLOCK) void composition_kernel(const CompositionAr
     const uint32_t bins_log2 = 2u * k < CBINS_LOG2 ? 2u * k : CBINS_LOG2;
     const uint64_t kmask = (k >= 32) ? ~0ull : ((1ull << (2u * k)) - 1ull);
     if constexpr (SRC_BITS == 8) {
-        for (uint32_t i = tid; i < 256u; i += CBLOCK) lut[i] = a.ascii_lut[i];
+        for (uint32_t i = tid; i < 256u; i += CBLOCK) lut[i] = ascii_entry(a.ascii_table, i);
     }
     for (uint32_t i = tid; i < words; i += CBLOCK) hist[i] = 0;
     uint32_t bound = 0;  // upper bound on the largest 16-bit counter of this workgroup (uniform)

@@ -33,7 +33,6 @@ struct kmers_ctx {
     char *h_bounce = nullptr;             // pinned bounce buffer for short host-pointer calls (FASTA-record sized):
                                           // [0, BOUNCE_IN) source words, [BOUNCE_IN, BOUNCE_IN + BOUNCE_OUT) outputs
     uint64_t *d_recent = nullptr;         // MinHash: table of recently appended candidate hashes (RECENT_SLOTS entries)
-    uint8_t *d_luts = nullptr;            // 5 x 256 B: ascii_encode {2,4}-bit x {DNA,RNA}, then ASCII_SKIPPING_LUT
     void *stage[8] = {};      // 0 source, 1-2 outputs, 3 metadata / scratch, 4-5 recoded stream / flags, 6 tile index
     size_t stage_cap[8] = {};
     std::string last_error;
@@ -179,9 +178,8 @@ int collect(kmers_ctx *ctx, kmers_result *res, uint64_t n_out, uint64_t *value_o
     return KMERS_E_ENCODE;
 }
 
-const uint8_t *ascii_table(kmers_ctx *ctx, int dst_bits, bool rna) {
-    return ctx->d_luts + 256 * ((dst_bits == 4 ? 2 : 0) + (rna ? 1 : 0));
-}
+// table id of ascii_entry(): BioSequences.ascii_encode of the kmer alphabet (ascii_tables.hpp)
+uint32_t ascii_table(kmers_ctx *, int dst_bits, bool rna) { return (dst_bits == 4 ? 2u : 0u) + (rna ? 1u : 0u); }
 
 void remember_source(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st) {
     ctx->err_words = st.d_words;
@@ -319,7 +317,7 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     a.err_slot = ctx->d_err;
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
-    a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+    a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet != 0);
     a.tuples = tuples ? 1u : 0u;
 
     int rc;
@@ -376,7 +374,7 @@ int emit_all_kept(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k,
     a.err_slot = ctx->d_err;
     a.k = (uint32_t)k;
     a.stride = 1;
-    a.ascii_lut = ascii_table(ctx, 2, seq->alphabet != 0);
+    a.ascii_table = ascii_table(ctx, 2, seq->alphabet != 0);
     const bool vec_ok = (!d_k || aligned16(d_k)) && (!d_s || aligned16(d_s));
     return launch_stream<MODE_FW>(ctx, a, seq->src_bits, 2, kmers_words_per_kmer(k, 2), vec_ok);
 }
@@ -404,7 +402,7 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.src = st.d_words;
     a.first_bit = st.first_bit;
     a.n_cand = n;
-    a.ascii_lut = ctx->d_luts + 1024;
+    a.ascii_table = (uint32_t)ASCII_TABLE_SKIPPING;
     a.err_slot = ctx->d_err;
     a.n_bases = seq->n_bases;
     a.k = (uint32_t)k;
@@ -537,7 +535,7 @@ int launch_fused(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, 
     a.err_slot = ctx->d_err;
     a.k = (uint32_t)k;
     a.stride = 1;
-    a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+    a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet != 0);
     int64_t saved = ctx->max_grid;
     if (ctx->max_grid <= 0) ctx->max_grid = 256 * 8;  // persistent grid: no output stream to pace
     int rc = launch_stream<MODE>(ctx, a, seq->src_bits, dst_bits, kmers_words_per_kmer(k, dst_bits), true, dyn_lds);
@@ -558,7 +556,7 @@ int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int 
     a.err_slot = ctx->d_err;
     a.k = (uint32_t)k;
     a.stride = 1;
-    a.ascii_lut = ascii_table(ctx, 2, seq->alphabet != 0);
+    a.ascii_table = ascii_table(ctx, 2, seq->alphabet != 0);
     a.n_tiles = (a.n_kmers + RTILE - 1) / RTILE;
     const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)ctx->n_cus * 8;  // persistent grid
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, resident)), block(RBLOCK);
@@ -664,17 +662,9 @@ int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return KMERS_E_HIP; }
         ctx->own_stream = true;
     }
-    uint8_t luts[5 * 256];
-    build_ascii_encode_table(2, false, luts);
-    build_ascii_encode_table(2, true, luts + 256);
-    build_ascii_encode_table(4, false, luts + 512);
-    build_ascii_encode_table(4, true, luts + 768);
-    build_ascii_skipping_table(luts + 1024);
     if (hipMalloc(&ctx->d_scratch, 64 * 8) != hipSuccess || hipHostMalloc(&ctx->h_result, 64, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(&ctx->h_bounce, BOUNCE_IN + BOUNCE_OUT, hipHostMallocDefault) != hipSuccess ||
         (ctx->d_err = reinterpret_cast<unsigned long long *>(ctx->d_scratch + 1)) == nullptr ||
-        hipMalloc(&ctx->d_luts, sizeof luts) != hipSuccess ||
-        hipMemcpy(ctx->d_luts, luts, sizeof luts, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
         kmers_ctx_destroy(ctx);
@@ -693,7 +683,6 @@ void kmers_ctx_destroy(kmers_ctx *ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
-    if (ctx->d_luts) (void)hipFree(ctx->d_luts);
     if (ctx->d_recent) (void)hipFree(ctx->d_recent);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -819,7 +808,7 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
         a.k = (uint32_t)k;
         a.stride = (uint32_t)stride;
         a.xor_canonical = 0;
-        a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+        a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet != 0);
         int64_t saved = ctx->max_grid;
         if (ctx->max_grid <= 0) ctx->max_grid = (int64_t)ctx->n_cus * 8;  // persistent grid: nothing is streamed out
         const int rc = launch_stream<MODE_XOR>(ctx, a, seq->src_bits, dst_bits, nw, true);
@@ -846,7 +835,7 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
     a.src = st.d_words;
     a.first_bit = st.first_bit;
     a.n_cand = n;
-    a.ascii_lut = ctx->d_luts + 1024;
+    a.ascii_table = (uint32_t)ASCII_TABLE_SKIPPING;
     a.err_slot = ctx->d_err;
     a.n_bases = seq->n_bases;
     a.k = (uint32_t)kk;
@@ -1137,7 +1126,7 @@ int kmers_minimizers(kmers_ctx *ctx, const kmers_seq *seq, int k, int w, int str
     a.stride = (uint32_t)stride;
     a.window_kmers = (uint32_t)w;
     a.minimizer_mode = (uint32_t)mode;
-    a.ascii_lut = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+    a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet != 0);
     // strides >= span leave gaps the reference's loop never reads: restrict the validation to the windows
     if (int rc = launch_stream<MODE_MINIMIZER>(ctx, a, seq->src_bits, dst_bits, nw, false)) return rc;
     if (flags & KMERS_ASYNC) {
@@ -1181,7 +1170,7 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
             a.n_tiles = (n + CTILE - 1) / CTILE;
             a.counts = d_counts;
             a.err_slot = ctx->d_err;
-            a.ascii_lut = ascii_table(ctx, 2, seq->alphabet != 0);
+            a.ascii_table = ascii_table(ctx, 2, seq->alphabet != 0);
             a.k = (uint32_t)k;
             a.hist_words = (uint32_t)std::min<size_t>(bins, (size_t)1 << CBINS_LOG2) / 2;
             const uint32_t passes = (uint32_t)std::max<size_t>(1, bins >> CBINS_LOG2);
@@ -1304,7 +1293,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         r.src = src0;
         r.n_words = n_src_words;
         r.stream = static_cast<uint64_t *>(ctx->stage[4]);
-        r.ascii_lut = ascii_table(ctx, dst_bits, pool->alphabet != 0);
+        r.ascii_table = ascii_table(ctx, dst_bits, pool->alphabet != 0);
         if (sb != 2) {
             if (int rc = ensure_stage(ctx, 5, flag_bytes + 16)) return rc;
             r.flags = static_cast<uint64_t *>(ctx->stage[5]);

@@ -56,7 +56,7 @@ struct RecodeArgs {
     uint64_t *stream;
     uint64_t *flags;
     uint64_t *any_flag;          // becomes non-zero if any symbol of the pool cannot be encoded
-    const uint8_t *ascii_lut;
+    uint32_t ascii_table;
 };
 
 // ---- the ragged layout, computed on the device (a batch may hold tens of millions of records) ------
@@ -105,7 +105,7 @@ template <int SRC, int DST>
 __global__ __launch_bounds__(256) void recode_kernel(const RecodeArgs a) {
     __shared__ uint8_t lut[SRC == 8 ? 256 : 1];
     if constexpr (SRC == 8) {
-        for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lut[i] = a.ascii_lut[i];
+        for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lut[i] = ascii_entry(a.ascii_table, i);
         block_sync();
     }
     const uint64_t stride = (uint64_t)gridDim.x * 256u;

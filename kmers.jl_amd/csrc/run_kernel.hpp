@@ -28,7 +28,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
     const uint32_t k = a.k;
     const uint64_t mask = head_mask((int)k, 2);
     if constexpr (SRC_BITS == 8) {
-        for (uint32_t i = tid; i < 256u; i += RBLOCK) lut[i] = a.ascii_lut[i];
+        for (uint32_t i = tid; i < 256u; i += RBLOCK) lut[i] = ascii_entry(a.ascii_table, i);
     }
     uint64_t threshold = a.threshold;
     // RMODE_SKETCH: a copy of the current bottom-s set, so that hashes it already holds are dropped here

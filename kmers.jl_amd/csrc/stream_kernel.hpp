@@ -11,6 +11,7 @@
 // 16 bytes per lane per store instruction, lanes consecutive, so every wave store covers
 // whole 128-byte lines.  HBM-bound on the output: see DESIGN.md for bytes per kmer.
 #pragma once
+#include "ascii_tables.hpp"
 #include "device_bits.hpp"
 
 namespace kmers {
@@ -42,7 +43,7 @@ struct StreamArgs {
     uint32_t tile_kmers;
     uint32_t xor_canonical;  // MODE_XOR: 1 = canonical kmers, 0 = forward kmers
     uint64_t *stamps;        // diagnostic builds (-DKMERS_STAMPS) only: per-workgroup s_memrealtime stamps
-    const uint8_t *ascii_lut; // SRC_BITS == 8: 256-entry byte -> symbol table (ascii_tables.hpp)
+    uint32_t ascii_table;     // SRC_BITS == 8: which byte -> symbol table (ascii_entry(), ascii_tables.hpp)
     // MODE_SKETCH: hashes below the threshold (threshold_ptr[0] when non-NULL, else `threshold`) are appended
     //              to out_a[0..capacity) through the counter out_b[0]
     // MODE_COUNT : out_a = uint32 counts[4^K] indexed by as_integer(forward kmer), global atomics
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     const uint32_t J = STRIDE1 ? 1u : a.stride;
     const uint64_t mask = head_mask((int)k, DST);  // mask of the kmer's head word
     if constexpr (SRC_BITS == 8) {
-        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = a.ascii_lut[i];  // visible after the tile loop's first barrier
+        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);  // computed, not loaded; visible after the tile loop's first barrier
     }
     constexpr uint32_t KPL = (STRIDE1 && N == 1 && !TUPLES) ? 2u : 1u;  // kmers per lane per pass -> 16 B stores
     uint64_t xacc = 0;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(const StreamArgs a) {
         uint64_t enc = (a.src[bit >> 6] >> (bit & 63u)) & ((1ull << SRC_BITS) - 1ull);
         uint64_t code = enc;
         if constexpr (SRC_BITS == 8) {
-            code = a.ascii_lut[enc];
+            code = ascii_entry(a.ascii_table, (uint32_t)enc);
             if (code & 0x80u) {
                 atomicMin(a.err_slot, (unsigned long long)(base + t));
                 return;

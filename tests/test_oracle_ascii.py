@@ -93,3 +93,15 @@ def test_ascii_equals_longsequence_random(orc):
             km, st, res = orc.unambiguous(naive.ascii_words(amb.lower()), L, DNA_A, K)
             assert res.status == 0
             assert list(zip(rows(km), [int(x) for x in st])) == naive.unambiguous(amb, K)
+
+
+def test_computed_ascii_tables_equal_the_letter_list_tables(tmp_path):
+    """kmers.jl_amd/csrc/ascii_tables.hpp: ascii_entry() (what the kernels use: table entries computed from two
+    immediates, no memory) == the tables built from the letter lists, for all 5 x 256 entries (plain C++)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "ascii_entry_check"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(exe), os.path.join(root, "tests", "c", "ascii_entry_check.cpp")], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "agrees" in r.stdout, r.stdout
