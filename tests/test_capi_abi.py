@@ -80,14 +80,15 @@ def test_host_mirror_value_types(km):
 
 
 def test_header_is_plain_c_and_example_links(km, tmp_path):
-    """include/kmers_hip.h compiles as C99 and a plain-C client links against libkmers_hip.so."""
+    """include/kmers_hip.h compiles as C99 and plain-C clients link against libkmers_hip.so."""
     import subprocess
-    exe = tmp_path / "canonical_hashes"
-    csrc = os.path.join(ROOT, "kmers.jl_amd", "csrc")
-    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", "canonical_hashes.c"), "-L", csrc, "-lkmers_hip",
-                    f"-Wl,-rpath,{csrc}", "-o", str(exe)], check=True)
     import torch
-    if not torch.cuda.is_available():
-        out = subprocess.run([str(exe)], capture_output=True, text=True)
-        assert out.returncode == 2 and "no usable HIP device" in out.stderr  # fails loudly, no fallback
+    csrc = os.path.join(ROOT, "kmers.jl_amd", "csrc")
+    for name in ("canonical_hashes", "batch_reads"):
+        exe = tmp_path / name
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", name + ".c"), "-L", csrc, "-lkmers_hip",
+                        f"-Wl,-rpath,{csrc}", "-o", str(exe)], check=True)
+        if not torch.cuda.is_available():
+            out = subprocess.run([str(exe)], capture_output=True, text=True)
+            assert out.returncode == 2 and "no usable HIP device" in out.stderr  # fails loudly, no fallback

@@ -284,6 +284,37 @@ def test_plain_c_client(km, orc, tmp_path):
     assert bad.returncode == 1 and "cannot encode 0x50 (Char 'P') at position 41" in bad.stdout
 
 
+def test_plain_c_batch_client(km, orc, tmp_path):
+    """examples/batch_reads.c: kmers_batch / kmers_minhash_batch with KMERS_BATCH_SKIP from plain C, against the oracle."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "kmers.jl_amd", "csrc")
+    exe = tmp_path / "batch_reads"
+    src = os.path.join(root, "examples", "batch_reads.c")
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), src, "-L", csrc, "-lkmers_hip",
+                    f"-Wl,-rpath,{csrc}", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    reads = re.findall(r'^\s+"([ACGTN]+)",', open(src).read(), flags=re.M)
+    lines = out.stdout.strip().splitlines()
+    assert len(reads) == 4 and len(lines) == 4
+    for i, (read, line) in enumerate(zip(reads, lines)):
+        n = max(len(read) - 21 + 1, 0)
+        hashes, skipped = [], 0
+        for j in range(n):                                  # UnambiguousKmers composition, docs/src/faq.md:28-33
+            w = read[j:j + 21]
+            if "N" in w:
+                skipped += 1
+                continue
+            hashes.append(int(orc.canonical(naive.ascii_words(w), 21, 8, 2, 21)[1][0]))
+        sk = sorted(set(hashes))[:8]
+        exp = f"read {i}: {n} canonical 21-mers ({skipped} over an ambiguous call), sketch of {len(sk)}:" + \
+            "".join(f" {h:016x}" for h in sk)
+        assert line == exp
+
+
 def test_reducer_of_the_reference_benchmark(km, orc):
     """reducer(it) (test/benchmark.jl:9-15) over every iterator type == XOR of the collected elements' head words."""
     rng = np.random.default_rng(12)
