@@ -1257,12 +1257,15 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         return KMERS_OK;  // size query
     }
     if (total == 0) return KMERS_OK;
-    const uint64_t n_tiles = (total + RG_TILE - 1) / RG_TILE;
-    if (int rc = ensure_stage(ctx, 6, (size_t)n_tiles * 4 + 16)) return rc;
-    uint32_t *d_tile_rec = static_cast<uint32_t *>(ctx->stage[6]);
-    hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_off, n, n_tiles,
-                       d_tile_rec);
-    HIP_TRY(ctx, hipGetLastError());
+    // tile = 1..8 passes of 1024 elements: long tiles amortise the two rounds of loads every tile starts with
+    // (each about 5 us under the store load), short ones keep a small batch spread over the device
+    uint64_t passes = total / ((uint64_t)RG_PASS * (uint64_t)ctx->n_cus * 32u);
+    passes = std::min<uint64_t>(std::max<uint64_t>(passes, 1), (uint64_t)RG_MAX_PASSES);
+    if (const char *e = getenv("KMERS_RG_PASSES")) passes = std::min<uint64_t>(std::max<long>(atol(e), 1), (uint64_t)RG_MAX_PASSES);  // tests, tuning
+    const uint32_t tile_elems = (uint32_t)(passes * RG_PASS);
+    const uint64_t n_tiles = (total + tile_elems - 1) / tile_elems;
+    if (int rc = ensure_stage(ctx, 6, (size_t)n_tiles * sizeof(RaggedTile))) return rc;
+    RaggedTile *d_tiles = static_cast<RaggedTile *>(ctx->stage[6]);
 
     Staged st;
     if (int rc = stage_sequence(ctx, pool, flags, &st)) return rc;
@@ -1271,17 +1274,21 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     const uint64_t *src0 = st.d_words + (st.first_bit >> 6);        // word that holds pool symbol 0
     const uint64_t origin = (st.first_bit & 63u) / (uint64_t)sb;     // its symbol offset inside that word
     const uint64_t n_src_words = ((origin + pool->n_bases) * (uint64_t)sb + 63) / 64;
+    hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_spans, n, n_tiles,
+                       total, tile_elems, (uint32_t)k, (uint32_t)dst_bits, origin, d_tiles);
+    HIP_TRY(ctx, hipGetLastError());
 
     RaggedArgs a{};
     a.rec_off = d_off;
     a.spans = d_spans;
-    a.tile_rec = d_tile_rec;
+    a.tiles = d_tiles;
     a.n_records = n;
     a.n_elems = total;
     a.seed = seed;
     a.err_slot = ctx->d_err;
     a.k = (uint32_t)k;
     a.skip = (flags & KMERS_BATCH_SKIP) ? 1u : 0u;
+    a.tile = tile_elems;
     a.stream_origin = origin;
     if (sb == dst_bits) {  // Copyable: the pool is the stream, nothing can fail
         a.stream = src0;
@@ -1574,3 +1581,14 @@ int kmers_synth_dna(kmers_ctx *ctx, uint64_t seed, uint64_t first_word, uint64_t
 }
 
 }  // extern "C"
+
+#ifdef KMERS_RG_PROBE
+extern "C" int kmers_debug_rg_probe(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(kmers::rg_probe), 128) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(kmers::rg_probe), z, 128) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -7,13 +7,15 @@
 //   1. recode_kernel   (skipped for Copyable 2->2 / 4->4 pools): the pool's symbols -> a DST-bit
 //      stream in HBM + one "cannot be encoded" flag per symbol (RecodingScheme,
 //      src/construction.jl:75-100).  Elementwise, r B/base read, (DST+1)/8 B/base written.
-//   2. ragged_kernel: one tile of 1024 output elements per workgroup.  The host supplies, per tile,
-//      the first record it touches; the tile's slice of (element offset, first symbol) pairs is
-//      staged in LDS, every lane finds its record by binary search there, reads its window's stream
-//      words straight from HBM (neighbouring lanes share them through L1/L2) and derives the kmer
-//      exactly like `window()` of stream_kernel.hpp.  A window that covers a flagged symbol reports
-//      its element index (atomicMin): the smallest one is the first element the reference would
-//      have failed on, in record order, and its first flagged symbol the one it throws for.
+//   2. the layout pass: elements per record, exclusive scan, and one descriptor per tile of output
+//      elements (first record, record slots, the stretch of stream words its windows lie in).
+//   3. ragged_kernel: one tile (1024 .. 8192 output elements, chosen per call) per workgroup.  The
+//      tile's slice of (element offset, first symbol) pairs and its stretch of the stream are staged in
+//      LDS in one round of loads; every lane then finds its record by a search in LDS, cuts its window
+//      out of the staged words and derives the kmer exactly like `window()` of stream_kernel.hpp.  A
+//      window that covers a flagged symbol reports its element index (atomicMin): the smallest one is
+//      the first element the reference would have failed on, in record order, and its first flagged
+//      symbol the one it throws for.
 #pragma once
 #include <type_traits>
 
@@ -21,11 +23,34 @@
 
 namespace kmers {
 
-#ifndef KMERS_RG_TILE
-#define KMERS_RG_TILE 2048
+constexpr int RG_RUN = 4;                // consecutive elements per lane and pass (one-word kmers)
+constexpr int RG_PASS = 256 * RG_RUN;    // elements per workgroup and pass; a tile is 1..RG_MAX_PASSES passes (chosen per call)
+constexpr int RG_MAX_PASSES = 8;
+constexpr int RG_SLOTS = 448;            // records of a tile staged in LDS (more: the global-search path)
+constexpr int RG_STAGE = 1024;           // stream words of a tile staged in LDS (records in pool order: the usual case)
+
+struct RaggedTile {              // one per tile, written by the layout pass: everything the element kernel needs to start
+    uint64_t q_lo;               // ALL of its loads at once (slice of the record table, stream words, flag words).
+    uint64_t f_lo;               // Stream words [q_lo, q_lo + n_words) and flag words [f_lo, f_lo + n_fwords) hold the windows
+    uint32_t r_lo;               // of the tile's first and last element and what lies between them in the pool; n_words = 0
+    uint32_t n_slots;            // if that stretch is not ascending or longer than RG_STAGE words.  r_lo: the record that
+    uint32_t n_words;            // owns the tile's first element; n_slots: record slots to stage (up to the owner of the next
+    uint32_t n_fwords;           // tile's first element, plus one; at most RG_SLOTS + 1).
+};
+
+#ifdef KMERS_RG_PROBE  // diagnostic build only (tools/ragged_probe.py): time stamps of the kernel's phases, lane 0 of every wavefront
+__device__ unsigned long long rg_probe[16];
+#define RG_PROBE(i)                                                                                       \
+    do {                                                                                                  \
+        if ((threadIdx.x & 63u) == 0 && (blockIdx.x & 127u) == 5u) {                                      \
+            if ((i) == 0) rg_t0 = clock64();                                                              \
+            else atomicAdd(&rg_probe[i], (unsigned long long)(clock64() - rg_t0));                        \
+            if ((i) == 6) atomicAdd(&rg_probe[0], 1ull);                                                  \
+        }                                                                                                 \
+    } while (0)
+#else
+#define RG_PROBE(i) do {} while (0)
 #endif
-constexpr int RG_TILE = KMERS_RG_TILE;  // output elements per workgroup
-constexpr int RG_SLOTS = 256;            // records of a tile staged in LDS (more: the global-search path)
 
 struct RaggedSpan {              // == kmers_span of the C ABI
     uint64_t first_base;
@@ -39,7 +64,7 @@ struct RaggedArgs {
     uint64_t stream_origin;      // stream symbol index of pool symbol 0
     const uint64_t *rec_off;     // [n + 1] element offset of every record (records shorter than K own nothing)
     const RaggedSpan *spans;     // [n] the records
-    const uint32_t *tile_rec;    // [n_tiles + 1] the record that owns the first element of every tile; [n_tiles] = n - 1
+    const RaggedTile *tiles;     // [n_tiles]
     uint64_t n_records;
     uint64_t n_elems;
     uint64_t *out_a;             // FW: forward kmers, CANON: canonical kmers
@@ -48,6 +73,7 @@ struct RaggedArgs {
     unsigned long long *err_slot;  // atomicMin of the first failing ELEMENT index
     uint32_t k;
     uint32_t skip;               // 1: elements whose window holds a flagged symbol are written as all-ones instead of failing
+    uint32_t tile;               // output elements per workgroup: a multiple of RG_PASS
 };
 
 struct RecodeArgs {
@@ -77,24 +103,45 @@ __global__ __launch_bounds__(256) void ragged_count_kernel(const RaggedSpan *__r
     }
 }
 
-// the record that owns element t * RG_TILE: the LAST i with off[i] <= that element (records that own
-// nothing share their offset with the next one and are skipped by "last")
-__global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *__restrict__ off, uint64_t n, uint64_t n_tiles,
-                                                            uint32_t *__restrict__ tile_rec) {
+// One descriptor per tile.  owner(e) = the LAST record i with off[i] <= e (records that own nothing share
+// their offset with the next one and are skipped by "last").
+__global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *__restrict__ off, const RaggedSpan *__restrict__ spans,
+                                                            uint64_t n, uint64_t n_tiles, uint64_t n_elems, uint32_t tile,
+                                                            uint32_t k, uint32_t dst_bits, uint64_t stream_origin,
+                                                            RaggedTile *__restrict__ tiles) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (t > n_tiles) return;
-    if (t == n_tiles) {  // sentinel: lets the last tile size its slice like the others
-        tile_rec[t] = (uint32_t)(n - 1);
-        return;
+    if (t >= n_tiles) return;
+    auto owner = [&](uint64_t e, uint64_t lo) -> uint64_t {  // off[lo] <= e
+        uint64_t hi = n;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (off[mid] <= e) lo = mid;
+            else hi = mid;
+        }
+        return lo;
+    };
+    const uint64_t e0 = t * tile;
+    const uint64_t e_last = (e0 + tile < n_elems ? e0 + tile : n_elems) - 1;
+    const uint64_t r_lo = owner(e0, 0);
+    const uint64_t r_hi = owner(e_last, r_lo);
+    const uint64_t r_next = t + 1 < n_tiles ? owner(e_last + 1, r_hi) : n - 1;  // the last tile's slice ends with off[n]
+    const uint64_t want = r_next - r_lo + 2;
+    RaggedTile d;
+    d.r_lo = (uint32_t)r_lo;
+    d.n_slots = want < (uint64_t)(RG_SLOTS + 1) ? (uint32_t)want : (uint32_t)(RG_SLOTS + 1);
+    const uint64_t p_lo = spans[r_lo].first_base + (e0 - off[r_lo]) + stream_origin;            // first symbol of the first window
+    const uint64_t p_hi = spans[r_hi].first_base + (e_last - off[r_hi]) + k + stream_origin;    // one past the last window
+    d.q_lo = (p_lo * dst_bits) >> 6;
+    d.f_lo = p_lo >> 6;
+    d.n_words = d.n_fwords = 0;
+    if (p_hi > p_lo) {
+        const uint64_t nw = ((p_hi * dst_bits + 63) >> 6) - d.q_lo;
+        if (nw <= (uint64_t)RG_STAGE) {
+            d.n_words = (uint32_t)nw;
+            d.n_fwords = (uint32_t)(((p_hi + 63) >> 6) - d.f_lo);
+        }
     }
-    const uint64_t e = t * RG_TILE;
-    uint64_t lo = 0, hi = n;  // off[0] = 0 <= e
-    while (hi - lo > 1) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (off[mid] <= e) lo = mid;
-        else hi = mid;
-    }
-    tile_rec[t] = (uint32_t)lo;
+    tiles[t] = d;
 }
 
 // one source word -> its stream chunk + flag bits.  Stream/flag layout per source word wi:
@@ -135,18 +182,16 @@ __global__ __launch_bounds__(256) void recode_kernel(const RecodeArgs a) {
     }
 }
 
-// `window()` of stream_kernel.hpp with the stream words coming from HBM
-template <int N, int DST>
-__device__ __forceinline__ void window_global(const uint64_t *__restrict__ stream, uint64_t bit, uint32_t k, uint64_t mask,
-                                              uint64_t (&fw)[N], uint64_t (&rc)[N]) {
-    const uint64_t q = bit >> 6;
-    const uint32_t s = (uint32_t)(bit & 63u);
+// `window()` of stream_kernel.hpp with the stream words coming from `load(j)` = word j of the stream counted
+// from the one that holds `bit` (LDS or HBM)
+template <int N, int DST, class Load>
+__device__ __forceinline__ void window_words(Load load, uint32_t s, uint32_t k, uint64_t mask, uint64_t (&fw)[N], uint64_t (&rc)[N]) {
     uint64_t W[N], R[N];
-    uint64_t lo = stream[q];
+    uint64_t lo = load(0u);
     const uint32_t need = (s + (uint32_t)DST * k + 63u) >> 6;  // stream words the window touches (<= N + 1)
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        const uint64_t hi = (uint32_t)(j + 1) < need ? stream[q + j + 1] : 0;  // never read past the window's last word
+        const uint64_t hi = (uint32_t)(j + 1) < need ? load((uint32_t)(j + 1)) : 0;  // never read past the window's last word
         W[j] = funnel64(lo, hi, s);
         lo = hi;
     }
@@ -163,115 +208,111 @@ __device__ __forceinline__ void window_global(const uint64_t *__restrict__ strea
     for (int i = 1; i < N; ++i) fw[i] = (R[i] >> sh) | ((R[i - 1] << 1) << (63u - sh));
 }
 
-// VEC: out_a / out_b are 16-byte aligned (one-word kmers: two elements per lane, 16-byte stores)
+// VEC: out_a / out_b are 16-byte aligned (one-word kmers: RG_RUN elements per lane and pass, 16-byte stores)
 template <int DST, int N, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
-    __shared__ uint64_t off_l[RG_SLOTS + 1];
-    __shared__ uint64_t base_l[RG_SLOTS + 1];
-    __shared__ __attribute__((aligned(16))) uint32_t owner[RG_TILE];
-    __shared__ uint32_t wave_max[4];
+    __shared__ uint64_t off_l[RG_SLOTS + 1];    // element offset of every record slot of the tile
+    __shared__ uint64_t delta_l[RG_SLOTS + 1];  // first stream symbol of the slot's record minus that offset: window of element g = delta + g
+    __shared__ uint64_t src_l[RG_STAGE];
+    __shared__ uint64_t flg_l[RG_STAGE / 2 + 2];
     const uint32_t tid = threadIdx.x;
     const uint32_t k = a.k;
     const uint64_t mask = head_mask((int)k, DST);
     // (the pool may hold flagged symbols outside every record, so a set any_flag only means "look")
     const uint64_t *flags = (a.flags && *a.any_flag) ? a.flags : nullptr;
     const uint64_t tile = blockIdx.x;
-    const uint64_t e0 = tile * RG_TILE;
-    const uint64_t r_lo = a.tile_rec[tile];
-    const uint64_t e_last = (e0 + RG_TILE < a.n_elems ? e0 + RG_TILE : a.n_elems) - 1;
-    // offsets and first symbols of this tile's records go to LDS: r_lo .. the record that owns the next
-    // tile's first element, plus the one after it (its offset lies past this tile: the end of the
-    // search range; off[n] = n_elems closes the last tile).  At most RG_SLOTS + 1 slots: a tile crowded with
-    // records that own nothing is not covered, and its lanes search the global arrays instead
-    // (correct, just slower).
-    const uint64_t want = (uint64_t)a.tile_rec[tile + 1] - r_lo + 2;
-    const uint32_t n_rec = want < (uint64_t)(RG_SLOTS + 1) ? (uint32_t)want : (uint32_t)(RG_SLOTS + 1);
+    const uint64_t e0 = tile * a.tile;
+#ifdef KMERS_RG_PROBE
+    long long rg_t0 = 0;
+#endif
+    RG_PROBE(0);
+    const RaggedTile d = a.tiles[tile];
+    const uint64_t r_lo = d.r_lo;
+    const uint64_t e_last = (e0 + a.tile < a.n_elems ? e0 + a.tile : a.n_elems) - 1;
+    // Everything the tile reads is requested here, in ONE round of loads (a load takes about 5 us while the
+    // device is saturated with the stores of the other workgroups: rounds are what a tile's time is made of).
+    // Offsets and first symbols of the tile's records: r_lo .. the record that owns the next tile's first
+    // element, plus the one after it (its offset lies past this tile: the end of the search range;
+    // off[n] = n_elems closes the last tile).  At most RG_SLOTS + 1 slots: a tile crowded with short records
+    // is not covered, and its lanes search the global arrays instead (correct, just slower).  The stream
+    // (and flag) words between the tile's first and last window: records that lie in pool order (reads,
+    // contigs of one file) find all their windows there; a lane whose window lies elsewhere reads HBM.
+    const uint32_t n_rec = d.n_slots;
     for (uint32_t i = tid; i < n_rec; i += 256u) {
-        off_l[i] = a.rec_off[r_lo + i];
-        base_l[i] = r_lo + i < a.n_records ? a.spans[r_lo + i].first_base : 0;
+        const uint64_t o = a.rec_off[r_lo + i];
+        const uint64_t b = r_lo + i < a.n_records ? a.spans[r_lo + i].first_base : 0;
+        off_l[i] = o;
+        delta_l[i] = b - o + a.stream_origin;
     }
-    for (uint32_t i = tid; i < (uint32_t)RG_TILE; i += 256u) owner[i] = 0;
+    for (uint32_t i = tid; i < d.n_words; i += 256u) src_l[i] = a.stream[d.q_lo + i];
+    if (flags)
+        for (uint32_t i = tid; i < d.n_fwords; i += 256u) flg_l[i] = flags[d.f_lo + i];
+    RG_PROBE(1);
     block_sync();
+    RG_PROBE(2);
     const bool covered = off_l[n_rec - 1] > e_last;
-    if (covered) {
-        // owner[e] = record slot of element e0 + e, without a search per element: every slot marks the
-        // element it starts at (records that own nothing share a start with the next one: max wins),
-        // then a running maximum over the tile fills the rest.
-        for (uint32_t i = 1u + tid; i < n_rec; i += 256u) {
-            const uint64_t pos = off_l[i] - e0;  // > 0: slot 0 is the last record with off <= e0
-            if (pos < (uint64_t)RG_TILE) atomicMax(&owner[(uint32_t)pos], i);
-        }
-        block_sync();
-        constexpr uint32_t PER = RG_TILE / 256;          // consecutive elements per thread
-        uint32_t v[PER];
-#pragma unroll
-        for (uint32_t j = 0; j < PER; j += 4) {
-            const uint4 q = reinterpret_cast<uint4 *>(owner)[tid * (PER / 4) + j / 4];
-            v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
-        }
-#pragma unroll
-        for (uint32_t j = 1; j < PER; ++j) v[j] = max(v[j], v[j - 1]);
-        uint32_t m = v[PER - 1];                         // inclusive maximum up to this thread's last element
-        const uint32_t lane = tid & 63u, wave = tid >> 6;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t x = __shfl_up(m, d, 64);
-            if ((int)lane >= d) m = max(m, x);
-        }
-        if (lane == 63u) wave_max[wave] = m;
-        uint32_t before = __shfl_up(m, 1, 64);           // maximum of the earlier lanes of this wavefront
-        if (lane == 0) before = 0;
-        block_sync();
-        for (uint32_t w = 0; w < wave; ++w) before = max(before, wave_max[w]);
-#pragma unroll
-        for (uint32_t j = 0; j < PER; j += 4)
-            reinterpret_cast<uint4 *>(owner)[tid * (PER / 4) + j / 4] =
-                make_uint4(max(v[j], before), max(v[j + 1], before), max(v[j + 2], before), max(v[j + 3], before));
-        // first stream symbol of a slot's record minus its element offset: window of element g = delta + g
-        for (uint32_t i = tid; i < n_rec; i += 256u) base_l[i] = base_l[i] - off_l[i] + a.stream_origin;
-        block_sync();
-    }
     // Two separate instantiations of the element loop -- LDS lookups or global lookups -- rather than a
     // per-access select: hipcc turned `covered ? lds[i] : global[i]` into FLAT loads whose address is
     // selected between the LDS aperture and HBM, and that version produced wrong results for whole
-    // wavefronts, non-deterministically, on gfx950 (tools/ history, r01_tuning.md).
+    // wavefronts, non-deterministically, on gfx950 (tools/check_isa.sh, r01_tuning.md).
     auto run = [&](auto covered_tag) {
         constexpr bool COVERED = decltype(covered_tag)::value;
-        // record slot of element g: the last slot with off <= g (slot 0 always qualifies)
-        auto record_of = [&](uint64_t g) -> uint64_t {
+        // record slot of element g: the last slot with off <= g.  `from` = a slot known to qualify (slot 0
+        // always does; a lane's elements ascend, so its previous answer does).  The last staged slot's offset
+        // lies past the tile, so the search never leaves the slice.
+        auto slot_of = [&](uint64_t g, uint32_t from) -> uint32_t {
             if constexpr (COVERED) {
-                return owner[(uint32_t)(g - e0)];
+                uint32_t lo = from, hi = n_rec - 1u;
+                if (off_l[lo + 1u] > g) return lo;                 // long records: still the same one
+                while (lo + 8u < hi && off_l[lo + 8u] <= g) lo += 8u;  // a pass ahead is a few records ahead
+                if (lo + 8u < hi) hi = lo + 8u;
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (off_l[mid] <= g) lo = mid;
+                    else hi = mid;
+                }
+                return lo;
             } else {
-                uint64_t lo = r_lo, hi = a.n_records;
+                uint64_t lo = r_lo + from, hi = a.n_records;
                 while (hi - lo > 1) {
                     const uint64_t mid = (lo + hi) >> 1;
                     if (a.rec_off[mid] <= g) lo = mid;
                     else hi = mid;
                 }
-                return lo - r_lo;
+                return (uint32_t)(lo - r_lo);
             }
         };
-        auto slot_off = [&](uint64_t r) -> uint64_t {
-            return a.rec_off[r_lo + r];
-        };
-        auto slot_base = [&](uint64_t r) -> uint64_t {
-            return a.spans[r_lo + r].first_base;
-        };
         // element g of record slot r: forward kmer and reverse complement (and the flag test)
-        auto element = [&](uint64_t g, uint64_t r, uint64_t (&fw)[N], uint64_t (&rc)[N]) -> bool {
-            bool bad = false;
+        auto element = [&](uint64_t g, uint32_t r, uint64_t (&fw)[N], uint64_t (&rc)[N]) -> bool {
             uint64_t p;  // stream symbol index of the window
-            if constexpr (COVERED) p = base_l[r] + g;
-            else p = slot_base(r) + (g - slot_off(r)) + a.stream_origin;
+            if constexpr (COVERED) p = delta_l[r] + g;
+            else p = a.spans[r_lo + r].first_base + (g - a.rec_off[r_lo + r]) + a.stream_origin;
+            const uint64_t bit = p * (uint64_t)DST;
+            const uint64_t q = bit >> 6;
+            const uint32_t s = (uint32_t)(bit & 63u);
+            const uint32_t need = (s + (uint32_t)DST * k + 63u) >> 6;
+            const uint64_t rel = q - d.q_lo;  // (wraps for a window before the staged stretch)
+            const bool staged = COVERED && rel < (uint64_t)d.n_words && rel + need <= (uint64_t)d.n_words;
+            bool bad = false;
             if (flags) {
                 const uint64_t fq = p >> 6;
                 const uint32_t fs = (uint32_t)(p & 63u);
-                uint64_t f = flags[fq] >> fs;
-                if (fs + k > 64u) f |= (flags[fq + 1] << 1) << (63u - fs);
+                uint64_t f0, f1 = 0;
+                if (staged) {  // (the staged flag words cover the staged stream words)
+                    const uint32_t fr = (uint32_t)(fq - d.f_lo);
+                    f0 = flg_l[fr];
+                    if (fs + k > 64u) f1 = flg_l[fr + 1u];
+                } else {
+                    f0 = flags[fq];
+                    if (fs + k > 64u) f1 = flags[fq + 1];
+                }
+                uint64_t f = (f0 >> fs) | ((f1 << 1) << (63u - fs));
                 if (k < 64u) f &= (1ull << k) - 1ull;
                 bad = f != 0;
                 if (bad && !a.skip) atomicMin(a.err_slot, (unsigned long long)g);
             }
-            window_global<N, DST>(a.stream, p * (uint64_t)DST, k, mask, fw, rc);
+            if (staged) window_words<N, DST>([&](uint32_t j) { return src_l[(uint32_t)rel + j]; }, s, k, mask, fw, rc);
+            else window_words<N, DST>([&](uint32_t j) { return a.stream[q + j]; }, s, k, mask, fw, rc);
             return bad && a.skip;  // true: the caller writes the all-ones sentinel
         };
         auto finish = [&](const uint64_t (&fw)[N], const uint64_t (&rc)[N], uint64_t (&x)[N], uint64_t (&y)[N]) {
@@ -287,38 +328,46 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
             }
         };
         if constexpr (N == 1 && VEC && COVERED) {
-            // One-word kmers: a lane takes RUN = 4 consecutive elements.  They usually belong to one record,
-            // and then only the first is cut out of the stream; the others follow by the reference's own
+            // One-word kmers: a lane takes RUN = 4 consecutive elements per pass.  They usually belong to one
+            // record, and then only the first is cut out of the stream; the others follow by the reference's own
             // rolling step (shift_encoding / shift_first_encoding of the complement, CanonicalKmers.jl:131-144)
             // with the entering symbols taken from the words already loaded -- the gather is ALU-bound
             // otherwise (about 90 instructions per element against 45 this way).  Two 16-byte stores per
-            // array per lane.  Every pass is fetched before anything is stored.
-            constexpr uint32_t RUN = 4, PASSES = RG_TILE / (256 * RUN);
-            uint64_t X[PASSES][RUN], Y[PASSES][RUN];
+            // array per lane and pass, issued at once: with the windows in LDS nothing later waits behind them.
+            constexpr uint32_t RUN = RG_RUN;
             const uint32_t top = (uint32_t)DST * (k - 1u);
-#pragma unroll
-            for (uint32_t ps = 0; ps < PASSES; ++ps) {
-                const uint32_t e = RUN * tid + 256u * RUN * ps;
+            const uint64_t kbits = k >= 64u ? ~0ull : (1ull << k) - 1ull;
+            uint32_t r = 0;
+            for (uint32_t e = RUN * tid; e < a.tile; e += (uint32_t)RG_PASS) {
                 const uint64_t g = e0 + e;
-#pragma unroll
-                for (uint32_t j = 0; j < RUN; ++j) X[ps][j] = Y[ps][j] = 0;
-                if (g > e_last) continue;
+                if (g > e_last) break;
+                uint64_t X[RUN] = {0, 0, 0, 0}, Y[RUN] = {0, 0, 0, 0};
                 const uint32_t cnt = e_last - g + 1 < (uint64_t)RUN ? (uint32_t)(e_last - g + 1) : RUN;
-                const uint4 o4 = *reinterpret_cast<const uint4 *>(&owner[e]);
-                const uint32_t o[RUN] = {o4.x, o4.y, o4.z, o4.w};
-                bool same = true;
-#pragma unroll
-                for (uint32_t j = 1; j < RUN; ++j) same = same && (j >= cnt || o[j] == o[0]);
+                r = slot_of(g, r);
                 uint64_t fw[1], rc[1], x[1], y[1];
-                if (same) {
-                    const uint64_t p = base_l[o[0]] + g;
+                if (g + cnt - 1u < off_l[r + 1u]) {               // the whole run lies in record slot r
+                    const uint64_t p = delta_l[r] + g;
                     const uint32_t span = k + cnt - 1u;            // symbols the run reads
                     uint64_t fbits = 0;                            // flagged symbols of the run (skip mode)
+                    const uint64_t bit = p * (uint64_t)DST;
+                    const uint64_t q = bit >> 6;
+                    const uint32_t sh = (uint32_t)(bit & 63u);
+                    const uint32_t need = (sh + (uint32_t)DST * span + 63u) >> 6;  // 1..3 stream words
+                    const uint64_t rel = q - d.q_lo;                               // (wraps for a window before the stretch)
+                    const bool staged = rel < (uint64_t)d.n_words && rel + need <= (uint64_t)d.n_words;
                     if (flags) {
                         const uint64_t fq = p >> 6;
                         const uint32_t fs = (uint32_t)(p & 63u);
-                        uint64_t f = flags[fq] >> fs;
-                        if (fs + span > 64u) f |= (flags[fq + 1] << 1) << (63u - fs);
+                        uint64_t f0, f1 = 0;
+                        if (staged) {
+                            const uint32_t fr = (uint32_t)(fq - d.f_lo);
+                            f0 = flg_l[fr];
+                            if (fs + span > 64u) f1 = flg_l[fr + 1u];
+                        } else {
+                            f0 = flags[fq];
+                            if (fs + span > 64u) f1 = flags[fq + 1];
+                        }
+                        uint64_t f = (f0 >> fs) | ((f1 << 1) << (63u - fs));
                         f &= (1ull << span) - 1ull;               // span <= 32 + 3
                         if (f && !a.skip) {                        // the first element whose window holds a flagged symbol
                             const uint32_t first = (uint32_t)__builtin_ctzll(f);
@@ -326,12 +375,16 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                         }
                         if (a.skip) fbits = f;
                     }
-                    const uint64_t kbits = k >= 64u ? ~0ull : (1ull << k) - 1ull;
-                    const uint64_t bit = p * (uint64_t)DST;
-                    const uint64_t q = bit >> 6;
-                    const uint32_t sh = (uint32_t)(bit & 63u);
-                    const uint32_t need = (sh + (uint32_t)DST * span + 63u) >> 6;  // 1..3 stream words
-                    const uint64_t l0 = a.stream[q], l1 = need > 1u ? a.stream[q + 1] : 0, l2 = need > 2u ? a.stream[q + 2] : 0;
+                    uint64_t l0, l1 = 0, l2 = 0;
+                    if (staged) {
+                        l0 = src_l[(uint32_t)rel];
+                        if (need > 1u) l1 = src_l[(uint32_t)rel + 1u];
+                        if (need > 2u) l2 = src_l[(uint32_t)rel + 2u];
+                    } else {
+                        l0 = a.stream[q];
+                        if (need > 1u) l1 = a.stream[q + 1];
+                        if (need > 2u) l2 = a.stream[q + 2];
+                    }
                     const uint64_t W0 = funnel64(l0, l1, sh), W1 = funnel64(l1, l2, sh);
                     fw[0] = rev_symbols<DST>(W0 & mask) >> (64u - (uint32_t)DST * k);
                     rc[0] = comp_symbols<DST>(W0 & mask);
@@ -339,8 +392,8 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                     // symbols K, K+1, K+2 of the run
                     const uint32_t S = (uint32_t)((uint32_t)DST * k == 64u ? W1 : funnel64(W0, W1, (uint32_t)DST * k));
                     finish(fw, rc, x, y);
-                    X[ps][0] = (fbits & kbits) ? ~0ull : x[0];
-                    Y[ps][0] = (fbits & kbits) ? ~0ull : y[0];
+                    X[0] = (fbits & kbits) ? ~0ull : x[0];
+                    Y[0] = (fbits & kbits) ? ~0ull : y[0];
 #pragma unroll
                     for (uint32_t j = 1; j < RUN; ++j) {
                         if (j < cnt) {
@@ -352,47 +405,48 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                             rc[0] = (rc[0] >> DST) | (csym << top);
                             finish(fw, rc, x, y);
                             const bool masked = ((fbits >> j) & kbits) != 0;
-                            X[ps][j] = masked ? ~0ull : x[0];
-                            Y[ps][j] = masked ? ~0ull : y[0];
+                            X[j] = masked ? ~0ull : x[0];
+                            Y[j] = masked ? ~0ull : y[0];
                         }
                     }
-                } else {
+                } else {                                           // the run crosses into the next record(s)
+                    uint32_t rj = r;
 #pragma unroll
                     for (uint32_t j = 0; j < RUN; ++j) {
                         if (j < cnt) {
-                            const bool masked = element(g + j, o[j], fw, rc);
+                            while (off_l[rj + 1u] <= g + j) ++rj;  // (records that own nothing are stepped over)
+                            const bool masked = element(g + j, rj, fw, rc);
                             finish(fw, rc, x, y);
-                            X[ps][j] = masked ? ~0ull : x[0];
-                            Y[ps][j] = masked ? ~0ull : y[0];
+                            X[j] = masked ? ~0ull : x[0];
+                            Y[j] = masked ? ~0ull : y[0];
                         }
                     }
                 }
-            }
-#pragma unroll
-            for (uint32_t ps = 0; ps < PASSES; ++ps) {
-                const uint64_t g = e0 + RUN * tid + 256u * RUN * ps;
                 if (g + RUN - 1 <= e_last) {
                     if (a.out_a) {
-                        *reinterpret_cast<ulonglong2 *>(a.out_a + g) = make_ulonglong2(X[ps][0], X[ps][1]);
-                        *reinterpret_cast<ulonglong2 *>(a.out_a + g + 2) = make_ulonglong2(X[ps][2], X[ps][3]);
+                        *reinterpret_cast<ulonglong2 *>(a.out_a + g) = make_ulonglong2(X[0], X[1]);
+                        *reinterpret_cast<ulonglong2 *>(a.out_a + g + 2) = make_ulonglong2(X[2], X[3]);
                     }
                     if (a.out_b) {
-                        *reinterpret_cast<ulonglong2 *>(a.out_b + g) = make_ulonglong2(Y[ps][0], Y[ps][1]);
-                        *reinterpret_cast<ulonglong2 *>(a.out_b + g + 2) = make_ulonglong2(Y[ps][2], Y[ps][3]);
+                        *reinterpret_cast<ulonglong2 *>(a.out_b + g) = make_ulonglong2(Y[0], Y[1]);
+                        *reinterpret_cast<ulonglong2 *>(a.out_b + g + 2) = make_ulonglong2(Y[2], Y[3]);
                     }
                 } else {
                     for (uint32_t j = 0; j < RUN && g + j <= e_last; ++j) {
-                        if (a.out_a) a.out_a[g + j] = X[ps][j];
-                        if (a.out_b) a.out_b[g + j] = Y[ps][j];
+                        if (a.out_a) a.out_a[g + j] = X[j];
+                        if (a.out_b) a.out_b[g + j] = Y[j];
                     }
                 }
             }
+            RG_PROBE(4);
         } else {
-            for (uint32_t e = tid; e < (uint32_t)RG_TILE; e += 256u) {
+            uint32_t r = 0;
+            for (uint32_t e = tid; e < a.tile; e += 256u) {
                 const uint64_t g = e0 + e;
                 if (g > e_last) break;
                 uint64_t fw[N], rc[N], x[N], y[N];
-                const bool masked = element(g, record_of(g), fw, rc);
+                r = slot_of(g, r);
+                const bool masked = element(g, r, fw, rc);
                 finish(fw, rc, x, y);
                 if (masked) {
 #pragma unroll
@@ -409,6 +463,11 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
     };
     if (covered) run(std::integral_constant<bool, true>{});
     else run(std::integral_constant<bool, false>{});
+    RG_PROBE(5);
+#ifdef KMERS_RG_PROBE
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the stores have left
+    RG_PROBE(6);
+#endif
 }
 
 }  // namespace kmers
