@@ -283,6 +283,63 @@ def test_batch_tiles_crowded_with_empty_records(km, ctx, orc):
             assert cnt[i] == len(e) and np.array_equal(sk[i, :len(e)], e), (src, i, n_i)
 
 
+@pytest.mark.parametrize("passes", [1, 3, 8])
+def test_batch_tile_sizes_and_record_orders(km, ctx, orc, passes, monkeypatch):
+    """The tile (1024 elements x 1..8 passes, normally chosen from the batch size) forced to each extreme, over the
+    layouts that take different paths of the element kernel: reads in pool order (windows cut from the staged
+    stretch), the same records listed in shuffled order (windows outside the stretch: HBM), very short reads
+    (more record slots than LDS holds: global search), one- and two-word kmers, strict and skip mode."""
+    monkeypatch.setenv("KMERS_RG_PASSES", str(passes))
+    cap = km._capi
+    rng = np.random.default_rng(700 + passes)
+    layouts = {
+        "reads": [naive.random_text(rng, int(l)) for l in rng.integers(100, 260, 260)],
+        "short": [naive.random_text(rng, int(l)) for l in rng.integers(28, 45, 2500)],
+        "contigs": [naive.random_text(rng, int(l)) for l in (9000, 40, 17000, 5, 12000)],
+    }
+    for name, texts in layouts.items():
+        for src, K, mode in ((2, 31, cap.BATCH_CANONICAL), (4, 31, cap.BATCH_CANONICAL), (4, 40, cap.BATCH_FW), (8, 12, cap.BATCH_FW)):
+            for shuffled in (False, True):
+                words, spans, n_pool = build_pool(texts, src, rng, scatter=(src != 8))
+                order = rng.permutation(len(texts)) if shuffled else np.arange(len(texts))
+                listed = [texts[i] for i in order]
+                sp = (cap.Span * len(texts))(*[spans[int(i)] for i in order])
+                seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+                ea, eb, eoff = expected(orc, listed, src, 2, K, mode, 3)
+                total = int(eoff[-1])
+                N = (K * 2 + 63) // 64
+                out_a = np.zeros((total, N), np.uint64)
+                out_b = np.zeros((total, N) if mode == cap.BATCH_FW else total, np.uint64)
+                offs = np.zeros(len(texts) + 1, np.uint64)
+                res = cap.Result()
+                rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), sp, len(texts), mode, K, 2, vp(out_a), vp(out_b), 3, vp(offs), total, 0,
+                                         C.byref(res))
+                assert rc == 0 and res.n_out == total, ctx.last_error()
+                assert np.array_equal(offs, eoff), (name, src, K, shuffled)
+                assert np.array_equal(out_a, ea) and np.array_equal(out_b, eb), (name, src, K, shuffled)
+    # skip mode: the same elements with the windows over an N written as all-ones
+    texts = [naive.random_text(rng, int(l), p_amb=0.004) for l in rng.integers(100, 400, 200)]
+    for src in (4, 8):
+        words, spans, n_pool = build_pool(texts, src, rng, scatter=False)
+        seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+        total = sum(max(0, len(t) - 31 + 1) for t in texts)
+        out_a, out_b = np.zeros(total, np.uint64), np.zeros(total, np.uint64)
+        res = cap.Result()
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, 31, 2, vp(out_a), vp(out_b), 0, None, total,
+                                 cap.BATCH_SKIP, C.byref(res))
+        assert rc == 0 and res.n_out == total, ctx.last_error()
+        g = 0
+        for t in texts:
+            for j in range(max(0, len(t) - 31 + 1)):
+                w = t[j:j + 31]
+                if any(c not in "ACGT" for c in w):
+                    assert out_a[g] == out_b[g] == 0xFFFFFFFFFFFFFFFF, (src, g)
+                elif j % 7 == 0:   # (every seventh: the oracle call is per window here)
+                    ek, eh, _ = orc.canonical(naive.ascii_words(w), 31, 8, 2, 31)
+                    assert out_a[g] == ek[0, 0] and out_b[g] == eh[0], (src, g)
+                g += 1
+
+
 @pytest.mark.parametrize("src", [4, 8])
 def test_batch_skip_mode_masks_ambiguous_windows(km, ctx, orc, src):
     """KMERS_BATCH_SKIP: reads with N do not fail; the elements whose window holds an ambiguous symbol are
