@@ -227,6 +227,15 @@ int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, 
                 int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
                 uint64_t capacity, int flags, kmers_result *res);
 
+/* SpacedKmers{A,K,J}(record) for every record of a batch (each_codon over the coding sequences of a genome: K = J = 3;
+ * src/iterators/SpacedKmers.jl:23-42,77-139): record i yields (n_bases - k) / stride + 1 forward kmers, at symbols 0, J, 2J, ...
+ * of the record (none if it is shorter than k).  Strict like the reference's iterator: only the symbols inside a window are
+ * inspected (J > K leaves gaps that may hold anything, test/runtests.jl:866), and a window over a symbol the kmer alphabet
+ * cannot encode fails the call (EncodeError reported as by kmers_batch) unless KMERS_BATCH_SKIP marks it instead.  Everything
+ * else -- pool, spans, offsets, capacity / size query, flags -- as kmers_batch. */
+int kmers_batch_spaced(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, uint64_t stride,
+                       int dst_bits, uint64_t *out_kmers, uint64_t *out_offsets, uint64_t capacity, int flags, kmers_result *res);
+
 /* One MinHash sketch per record (MinHash.jl is used on collections: one sketch per genome / FASTA record,
  * docs/src/minhash.md:31-41): record i of the batch gets the s smallest distinct values of
  * fx_hash(canonical kmer, seed) over CanonicalKmers{A,K}(record i), ascending, in

@@ -321,6 +321,48 @@ function collect_batch(::Type{It}, seqs::Vector{<:LongSequence}; hashes::Bool = 
 end
 
 """
+    collect_batch(SpacedKmers{A,K,J}, seqs)
+
+`vcat((collect(SpacedKmers{A,K,J}(s)) for s in seqs)...)` from one GPU launch (`kmers_batch_spaced`), e.g.
+`each_codon` of every coding sequence of a genome.  Returns `(kmers, offsets)`.
+"""
+function collect_batch(::Type{SpacedKmers{A, K, J}}, seqs::Vector{<:LongSequence}) where {A, K, J}
+    ctx = context()
+    T = Kmers.derive_type(Kmer{A, K})
+    isempty(seqs) && return (T[], UInt64[0])
+    sbits = BioSequences.bits_per_symbol(Alphabet(first(seqs)))
+    per = 64 ÷ sbits
+    pool = UInt64[]
+    spans = Vector{CSpan}(undef, length(seqs))
+    for (i, s) in enumerate(seqs)
+        spans[i] = CSpan(length(pool) * per, length(s))
+        append!(pool, s.data)
+    end
+    push!(pool, zero(UInt64))
+    seq = CSeq(pointer(pool), (length(pool) - 1) * per, 0, 0, Int32(sbits), 0)
+    offsets = Vector{UInt64}(undef, length(seqs) + 1)
+    res = CResult()
+    call(out, cap) = GC.@preserve pool spans offsets begin
+        @ccall LIB.kmers_batch_spaced(ctx.handle::Ptr{Cvoid}, Ref(seq)::Ptr{CSeq}, pointer(spans)::Ptr{CSpan}, length(seqs)::UInt64,
+                                      K::Cint, J::UInt64, dst_bits(A)::Cint, out::Ptr{Cvoid}, pointer(offsets)::Ptr{UInt64},
+                                      cap::UInt64, MEM_HOST::Cint, Ref(res)::Ptr{CResult})::Cint
+    end
+    rc = call(C_NULL, 0)                              # size query
+    rc == OK || error("kmers_batch_spaced: status $rc: $(last_error(ctx))")
+    total = Int(res.n_out)
+    kmers = Vector{T}(undef, total)
+    GC.@preserve kmers begin
+        rc = call(pointer(kmers), total)
+    end
+    if rc == E_ENCODE
+        bad = seqs[Int(res.n_out) + 1]
+        throw(BioSequences.EncodeError(A(), reinterpret(eltype(bad), res.err_enc % UInt8)))
+    end
+    rc == OK || error("kmers_batch_spaced: status $rc: $(last_error(ctx))")
+    return (kmers, offsets)
+end
+
+"""
     sketch_batch(fx_hash, CanonicalKmers{A,K}, seqs, s; seed = 0x0)
 
 `[MinHash.sketch(fx_hash, CanonicalKmers{A,K}(x), s) for x in seqs]` from one launch sequence

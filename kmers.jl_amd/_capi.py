@@ -69,6 +69,7 @@ SYMBOLS = {
     "kmers_fx_hash": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int]),
     "kmers_transform": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_uint64, _P, C.c_int]),
     "kmers_batch": (C.c_int, [_P, _S, _P, C.c_uint64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_uint64, _P, C.c_uint64, C.c_int, _R]),
+    "kmers_batch_spaced": (C.c_int, [_P, _S, _P, C.c_uint64, C.c_int, C.c_uint64, C.c_int, _P, _P, C.c_uint64, C.c_int, _R]),
     "kmers_minhash_batch": (C.c_int, [_P, _S, _P, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, C.c_int, _R]),
     "kmers_shard_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
     "kmers_synth_dna": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _P]),

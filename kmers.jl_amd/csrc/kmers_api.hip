@@ -1200,8 +1200,10 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
 
 static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int mode, int k,
                       int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
-                      uint64_t capacity, int flags, kmers_result *res) {
+                      uint64_t capacity, int flags, kmers_result *res, uint64_t stride = 1) {
     clear(res);
+    if (stride == 0 || stride >= 0xFFFFFFFFull) return fail(ctx, KMERS_E_BADARG, "J must be at least 1 (and below 2^32)");
+    if (stride != 1 && mode != KMERS_BATCH_FW) return fail(ctx, KMERS_E_BADARG, "strided batches yield forward kmers (SpacedKmers)");
     if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP | INTERNAL_OUT_DEVICE))) {
         if (res) res->status = rc;
         return rc;
@@ -1235,7 +1237,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
     {
         dim3 g((unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->n_cus * 16)), b(256);
-        hipLaunchKernelGGL(ragged_count_kernel, g, b, 0, ctx->stream, d_spans, n, (uint32_t)k, pool->n_bases, d_cnt, d_bad);
+        hipLaunchKernelGGL(ragged_count_kernel, g, b, 0, ctx->stream, d_spans, n, (uint32_t)k, (uint32_t)stride, pool->n_bases, d_cnt, d_bad);
         hipLaunchKernelGGL(scan_segment_sums_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, d_cnt, n, d_seg);
         hipLaunchKernelGGL(scan_segments_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_seg, n_seg);
         hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, d_cnt, n, d_seg, n_seg, d_off);
@@ -1275,7 +1277,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     const uint64_t origin = (st.first_bit & 63u) / (uint64_t)sb;     // its symbol offset inside that word
     const uint64_t n_src_words = ((origin + pool->n_bases) * (uint64_t)sb + 63) / 64;
     hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_spans, n, n_tiles,
-                       total, tile_elems, (uint32_t)k, (uint32_t)dst_bits, origin, d_tiles);
+                       total, tile_elems, (uint32_t)k, (uint32_t)stride, (uint32_t)dst_bits, origin, d_tiles);
     HIP_TRY(ctx, hipGetLastError());
 
     RaggedArgs a{};
@@ -1289,6 +1291,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     a.k = (uint32_t)k;
     a.skip = (flags & KMERS_BATCH_SKIP) ? 1u : 0u;
     a.tile = tile_elems;
+    a.stride = (uint32_t)stride;
     a.stream_origin = origin;
     if (sb == dst_bits) {  // Copyable: the pool is the stream, nothing can fail
         a.stream = src0;
@@ -1361,7 +1364,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     HIP_TRY(ctx, hipMemcpyAsync(offs.data(), d_off, off_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t r = (uint64_t)(std::upper_bound(offs.begin(), offs.begin() + n, g) - offs.begin()) - 1;  // last record with off <= g
-    const uint64_t j = g - offs[r];                           // 0-based start of the window inside the record
+    const uint64_t j = (g - offs[r]) * stride;                // 0-based start of the window inside the record
     kmers_span bad_span;
     HIP_TRY(ctx, hipMemcpy(&bad_span, d_spans + r, sizeof bad_span, hipMemcpyDeviceToHost));
     const uint64_t p0 = bad_span.first_base + j + origin;     // symbol index from src0
@@ -1398,6 +1401,18 @@ int kmers_minhash(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uin
         return fail(ctx, KMERS_E_NOMEM, "host allocation failed in kmers_minhash");
     } catch (...) {
         return fail(ctx, KMERS_E_HIP, "unexpected exception in kmers_minhash");
+    }
+}
+
+int kmers_batch_spaced(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, uint64_t stride,
+                       int dst_bits, uint64_t *out_kmers, uint64_t *out_offsets, uint64_t capacity, int flags, kmers_result *res) {
+    try {
+        return batch_impl(ctx, pool, spans, n_spans, KMERS_BATCH_FW, k, dst_bits, out_kmers, nullptr, 0, out_offsets, capacity, flags, res,
+                          stride);
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, KMERS_E_NOMEM, "host allocation failed in kmers_batch_spaced");
+    } catch (...) {
+        return fail(ctx, KMERS_E_HIP, "unexpected exception in kmers_batch_spaced");
     }
 }
 

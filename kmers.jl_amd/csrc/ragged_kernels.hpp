@@ -74,6 +74,7 @@ struct RaggedArgs {
     uint32_t k;
     uint32_t skip;               // 1: elements whose window holds a flagged symbol are written as all-ones instead of failing
     uint32_t tile;               // output elements per workgroup: a multiple of RG_PASS
+    uint32_t stride;             // symbols between the windows of a record: 1, or J of SpacedKmers{A,K,J} (forward kmers only)
 };
 
 struct RecodeArgs {
@@ -89,7 +90,7 @@ struct RecodeArgs {
 // elements per record (FwKmers.jl:40-43) for the scan kernels of compact_kernels.hpp; bad[0] != 0 if a
 // span reaches outside the pool or a record is too long for the 32-bit count
 __global__ __launch_bounds__(256) void ragged_count_kernel(const RaggedSpan *__restrict__ spans, uint64_t n, uint32_t k,
-                                                            uint64_t pool_bases, uint32_t *__restrict__ counts,
+                                                            uint32_t step, uint64_t pool_bases, uint32_t *__restrict__ counts,
                                                             uint64_t *__restrict__ bad) {
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void ragged_count_kernel(const RaggedSpan *__r
             bad[0] = 1;
             counts[i] = 0;
         } else {
-            counts[i] = sp.n_bases < k ? 0u : (uint32_t)(sp.n_bases - k + 1u);
+            counts[i] = sp.n_bases < k ? 0u : (uint32_t)((sp.n_bases - k) / step + 1u);  // FwKmers.jl:40-43, SpacedKmers.jl:38-42
         }
     }
 }
@@ -107,12 +108,20 @@ __global__ __launch_bounds__(256) void ragged_count_kernel(const RaggedSpan *__r
 // their offset with the next one and are skipped by "last").
 __global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *__restrict__ off, const RaggedSpan *__restrict__ spans,
                                                             uint64_t n, uint64_t n_tiles, uint64_t n_elems, uint32_t tile,
-                                                            uint32_t k, uint32_t dst_bits, uint64_t stream_origin,
+                                                            uint32_t k, uint32_t step, uint32_t dst_bits, uint64_t stream_origin,
                                                             RaggedTile *__restrict__ tiles) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t >= n_tiles) return;
-    auto owner = [&](uint64_t e, uint64_t lo) -> uint64_t {  // off[lo] <= e
+    auto owner = [&](uint64_t e, uint64_t lo, bool near) -> uint64_t {  // off[lo] <= e; near: the answer is a few records ahead
         uint64_t hi = n;
+        if (near) {
+            uint64_t step = 1;
+            while (lo + step < n && off[lo + step] <= e) {
+                lo += step;
+                step <<= 1;
+            }
+            if (lo + step < n) hi = lo + step;
+        }
         while (hi - lo > 1) {
             const uint64_t mid = (lo + hi) >> 1;
             if (off[mid] <= e) lo = mid;
@@ -122,15 +131,15 @@ __global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *__res
     };
     const uint64_t e0 = t * tile;
     const uint64_t e_last = (e0 + tile < n_elems ? e0 + tile : n_elems) - 1;
-    const uint64_t r_lo = owner(e0, 0);
-    const uint64_t r_hi = owner(e_last, r_lo);
-    const uint64_t r_next = t + 1 < n_tiles ? owner(e_last + 1, r_hi) : n - 1;  // the last tile's slice ends with off[n]
+    const uint64_t r_lo = owner(e0, 0, false);
+    const uint64_t r_hi = owner(e_last, r_lo, true);
+    const uint64_t r_next = t + 1 < n_tiles ? owner(e_last + 1, r_hi, true) : n - 1;  // the last tile's slice ends with off[n]
     const uint64_t want = r_next - r_lo + 2;
     RaggedTile d;
     d.r_lo = (uint32_t)r_lo;
     d.n_slots = want < (uint64_t)(RG_SLOTS + 1) ? (uint32_t)want : (uint32_t)(RG_SLOTS + 1);
-    const uint64_t p_lo = spans[r_lo].first_base + (e0 - off[r_lo]) + stream_origin;            // first symbol of the first window
-    const uint64_t p_hi = spans[r_hi].first_base + (e_last - off[r_hi]) + k + stream_origin;    // one past the last window
+    const uint64_t p_lo = spans[r_lo].first_base + (e0 - off[r_lo]) * step + stream_origin;          // first symbol of the first window
+    const uint64_t p_hi = spans[r_hi].first_base + (e_last - off[r_hi]) * step + k + stream_origin;  // one past the last window
     d.q_lo = (p_lo * dst_bits) >> 6;
     d.f_lo = p_lo >> 6;
     d.n_words = d.n_fwords = 0;
@@ -212,7 +221,7 @@ __device__ __forceinline__ void window_words(Load load, uint32_t s, uint32_t k, 
 template <int DST, int N, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
     __shared__ uint64_t off_l[RG_SLOTS + 1];    // element offset of every record slot of the tile
-    __shared__ uint64_t delta_l[RG_SLOTS + 1];  // first stream symbol of the slot's record minus that offset: window of element g = delta + g
+    __shared__ uint64_t delta_l[RG_SLOTS + 1];  // first stream symbol of the slot's record minus offset * stride: window of element g = delta + g * stride
     __shared__ uint64_t src_l[RG_STAGE];
     __shared__ uint64_t flg_l[RG_STAGE / 2 + 2];
     const uint32_t tid = threadIdx.x;
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
         const uint64_t o = a.rec_off[r_lo + i];
         const uint64_t b = r_lo + i < a.n_records ? a.spans[r_lo + i].first_base : 0;
         off_l[i] = o;
-        delta_l[i] = b - o + a.stream_origin;
+        delta_l[i] = b - o * a.stride + a.stream_origin;
     }
     for (uint32_t i = tid; i < d.n_words; i += 256u) src_l[i] = a.stream[d.q_lo + i];
     if (flags)
@@ -285,8 +294,8 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
         // element g of record slot r: forward kmer and reverse complement (and the flag test)
         auto element = [&](uint64_t g, uint32_t r, uint64_t (&fw)[N], uint64_t (&rc)[N]) -> bool {
             uint64_t p;  // stream symbol index of the window
-            if constexpr (COVERED) p = delta_l[r] + g;
-            else p = a.spans[r_lo + r].first_base + (g - a.rec_off[r_lo + r]) + a.stream_origin;
+            if constexpr (COVERED) p = delta_l[r] + g * a.stride;
+            else p = a.spans[r_lo + r].first_base + (g - a.rec_off[r_lo + r]) * a.stride + a.stream_origin;
             const uint64_t bit = p * (uint64_t)DST;
             const uint64_t q = bit >> 6;
             const uint32_t s = (uint32_t)(bit & 63u);
@@ -327,7 +336,32 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                 y[0] = fx_hash<N>(x, a.seed);
             }
         };
+        auto one_by_one = [&]() {  // every lane one element at a time: multi-word kmers, unaligned outputs, uncovered tiles, strides
+            uint32_t r = 0;
+            for (uint32_t e = tid; e < a.tile; e += 256u) {
+                const uint64_t g = e0 + e;
+                if (g > e_last) break;
+                uint64_t fw[N], rc[N], x[N], y[N];
+                r = slot_of(g, r);
+                const bool masked = element(g, r, fw, rc);
+                finish(fw, rc, x, y);
+                if (masked) {
+#pragma unroll
+                    for (int w = 0; w < N; ++w) x[w] = y[w] = ~0ull;
+                }
+                if (a.out_a) store_kmer<N>(a.out_a, g, x);
+                if constexpr (MODE == MODE_FW) {
+                    if (a.out_b) store_kmer<N>(a.out_b, g, y);
+                } else {
+                    if (a.out_b) a.out_b[g] = y[0];
+                }
+            }
+        };
         if constexpr (N == 1 && VEC && COVERED) {
+            if (a.stride != 1u) {
+                one_by_one();
+                return;
+            }
             // One-word kmers: a lane takes RUN = 4 consecutive elements per pass.  They usually belong to one
             // record, and then only the first is cut out of the stream; the others follow by the reference's own
             // rolling step (shift_encoding / shift_first_encoding of the complement, CanonicalKmers.jl:131-144)
@@ -440,25 +474,7 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
             }
             RG_PROBE(4);
         } else {
-            uint32_t r = 0;
-            for (uint32_t e = tid; e < a.tile; e += 256u) {
-                const uint64_t g = e0 + e;
-                if (g > e_last) break;
-                uint64_t fw[N], rc[N], x[N], y[N];
-                r = slot_of(g, r);
-                const bool masked = element(g, r, fw, rc);
-                finish(fw, rc, x, y);
-                if (masked) {
-#pragma unroll
-                    for (int w = 0; w < N; ++w) x[w] = y[w] = ~0ull;
-                }
-                if (a.out_a) store_kmer<N>(a.out_a, g, x);
-                if constexpr (MODE == MODE_FW) {
-                    if (a.out_b) store_kmer<N>(a.out_b, g, y);
-                } else {
-                    if (a.out_b) a.out_b[g] = y[0];
-                }
-            }
+            one_by_one();
         }
     };
     if (covered) run(std::integral_constant<bool, true>{});

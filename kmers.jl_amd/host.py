@@ -747,17 +747,23 @@ def collect_batch(iterator, records, hashes=False, seed=0, ctx=None, skip_ambigu
     CanonicalDNAMers{K}(sequence(record))` loop (docs/src/minhash.md:31-35) without the per-call cost.
 
     iterator: a parametrised iterator type, e.g. `CanonicalDNAMers[31]`, `FwDNAMers[21]`,
-              `FwRvIterator[DNAAlphabet[2], 31]`.
+              `FwRvIterator[DNAAlphabet[2], 31]`, `SpacedDNAMers[3, 3]` (each_codon of every record:
+              `kmers_batch_spaced`).
     records:  LongSequences of one alphabet, or str / bytes records (ASCII).
-    Returns (first, second, offsets): FwKmers -> (kmers, None, offsets); FwRvIterator -> (kmers,
+    Returns (first, second, offsets): FwKmers / SpacedKmers -> (kmers, None, offsets); FwRvIterator -> (kmers,
     reverse complements, offsets); CanonicalKmers -> (kmers, fx_hash values if `hashes` else None,
     offsets).  Record i owns elements offsets[i]:offsets[i+1].  skip_ambiguous=True (KMERS_BATCH_SKIP): windows over
     symbols the kmer alphabet cannot encode are written as all-ones instead of raising EncodeError."""
     ctx = ctx or default_context()
     cls, params = getattr(iterator, "cls", None), getattr(iterator, "params", None)
-    if cls not in (FwKmers, FwRvIterator, CanonicalKmers):
-        raise UnsupportedError("collect_batch(FwKmers / FwRvIterator / CanonicalKmers [alphabet, K], records)")
-    alphabet, K = cls._expand(params)
+    if cls not in (FwKmers, FwRvIterator, CanonicalKmers, SpacedKmers):
+        raise UnsupportedError("collect_batch(FwKmers / FwRvIterator / CanonicalKmers [alphabet, K] or SpacedKmers [alphabet, K, J], records)")
+    if cls is SpacedKmers:
+        alphabet, K, J = cls._expand(params)
+        if not isinstance(J, int) or J < 1:
+            raise KmersError("J must be at least 1")      # SpacedKmers.jl:29-30
+    else:
+        alphabet, K = cls._expand(params)
     recs, pool, spans, n_pool, src_bits = _build_pool(records)
     seq = _capi.Seq(pool.ctypes.data, n_pool, 0, 0, src_bits, 1 if alphabet.kind == "RNA" else 0)
     res = _capi.Result()
@@ -765,16 +771,19 @@ def collect_batch(iterator, records, hashes=False, seed=0, ctx=None, skip_ambigu
     mode = _capi.BATCH_CANONICAL if cls is CanonicalKmers else _capi.BATCH_FW
     mem = _capi.MEM_HOST | (_capi.BATCH_SKIP if skip_ambiguous else 0)
     N = n_coding_elements(K, alphabet.bits)
-    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(recs), mode, K, alphabet.bits, None, None, seed & MASK64,
-                             offsets.ctypes.data_as(C.c_void_p), 0, mem, C.byref(res))
-    ctx.check(rc, "kmers_batch")
+    poff = offsets.ctypes.data_as(C.c_void_p)
+
+    def call(pa, pb, cap):
+        if cls is SpacedKmers:
+            return ctx.lib.kmers_batch_spaced(ctx.handle, C.byref(seq), spans, len(recs), K, J, alphabet.bits, pa, poff, cap, mem, C.byref(res))
+        return ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(recs), mode, K, alphabet.bits, pa, pb, seed & MASK64, poff, cap, mem,
+                                   C.byref(res))
+    ctx.check(call(None, None, 0), "kmers_batch")
     total = int(res.n_out)
     first = np.zeros((max(total, 1), N), dtype=np.uint64)
     want_second = cls is FwRvIterator or (cls is CanonicalKmers and hashes)
     second = np.zeros((max(total, 1), 1 if cls is CanonicalKmers else N), dtype=np.uint64) if want_second else None
-    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(recs), mode, K, alphabet.bits,
-                             first.ctypes.data_as(C.c_void_p), second.ctypes.data_as(C.c_void_p) if want_second else None,
-                             seed & MASK64, offsets.ctypes.data_as(C.c_void_p), total, mem, C.byref(res))
+    rc = call(first.ctypes.data_as(C.c_void_p), second.ctypes.data_as(C.c_void_p) if want_second else None, total)
     if rc == _capi.E_ENCODE:
         bad = recs[int(res.n_out)]
         _raise_encode(alphabet, bad, res)

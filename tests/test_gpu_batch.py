@@ -178,6 +178,72 @@ def test_collect_batch_mirror(km, orc):
 
 
 @pytest.mark.parametrize("src", [2, 4, 8])
+def test_batch_spaced_matches_per_record_iteration(km, ctx, orc, src, monkeypatch):
+    """kmers_batch_spaced == SpacedKmers{A,K,J}(record) record by record (SpacedKmers.jl:38-42,92-139): J < K (shift-ins),
+    J == K (each_codon), J > K (gaps that are never inspected), one- and two-word kmers, 2- and 4-bit kmer alphabets."""
+    cap = km._capi
+    rng = np.random.default_rng(300 + src)
+    for passes in ("1", "8"):
+        monkeypatch.setenv("KMERS_RG_PASSES", passes)
+        for dst, K, J in ((2, 3, 3), (2, 21, 3), (2, 5, 9), (2, 40, 7), (4, 7, 2), (4, 20, 20), (2, 1, 1)):
+            for n_rec, scatter in ((1, False), (9, True), (1500, False)):
+                lens = rng.choice([0, 1, K - 1, K, K + 1, K + J - 1, K + J, 60, 301, 2000], n_rec)
+                texts = [naive.random_text(rng, int(max(0, l))) for l in lens]
+                words, spans, n_pool = build_pool(texts, src, rng, scatter and src != 8)
+                seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+                exp, eoff = [], [0]
+                for t in texts:
+                    if len(t) >= K:
+                        w = naive.ascii_words(t) if src == 8 else naive.longseq_words(t, src)
+                        e, r = orc.spaced(w, len(t), src, dst, K, J)
+                        assert r.status == 0
+                        exp.append(e)
+                    eoff.append(eoff[-1] + (0 if len(t) < K else (len(t) - K) // J + 1))
+                N = (K * dst + 63) // 64
+                exp = np.concatenate(exp) if exp else np.zeros((0, N), np.uint64)
+                total = eoff[-1]
+                res = cap.Result()
+                offs = np.zeros(n_rec + 1, np.uint64)
+                rc = ctx.lib.kmers_batch_spaced(ctx.handle, C.byref(seq), spans, n_rec, K, J, dst, None, vp(offs), 0, 0, C.byref(res))
+                assert rc == 0 and res.n_out == total and list(offs) == eoff, (src, dst, K, J, n_rec)
+                out = np.zeros((max(total, 1), N), np.uint64)
+                rc = ctx.lib.kmers_batch_spaced(ctx.handle, C.byref(seq), spans, n_rec, K, J, dst, vp(out), vp(offs), total, 0, C.byref(res))
+                assert rc == 0 and res.n_out == total, ctx.last_error()
+                assert np.array_equal(out[:total], exp), (src, dst, K, J, n_rec, passes)
+    monkeypatch.delenv("KMERS_RG_PASSES")
+    if src == 2:
+        return
+    # strictness: a window over an ambiguous symbol fails with the record and the position; a gap symbol between
+    # windows (J > K) is never inspected (test/runtests.jl:866-869)
+    texts = ["ACGTACGTACGT", "TAGAWWWW", "ACGT"]
+    words, spans, n_pool = build_pool(texts, src, rng, False)
+    seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+    res = cap.Result()
+    out = np.zeros((16, 1), np.uint64)
+    rc = ctx.lib.kmers_batch_spaced(ctx.handle, C.byref(seq), spans, 3, 3, 4, 2, vp(out), None, 16, 0, C.byref(res))
+    assert rc == cap.E_ENCODE and res.n_out == 1 and res.err_pos == 5 and res.err_enc == (ord("W") if src == 8 else 0b1001)
+    texts = ["ACGNACGNACG", "TTTNTTT"]                       # K = 3, J = 4: every N falls between two windows
+    words, spans, n_pool = build_pool(texts, src, rng, False)
+    seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+    rc = ctx.lib.kmers_batch_spaced(ctx.handle, C.byref(seq), spans, 2, 3, 4, 2, vp(out), None, 16, 0, C.byref(res))
+    assert rc == 0 and res.n_out == 5
+    assert [int(x) for x in out[:5, 0]] == [naive.kmer_words(t, 2)[0] for t in ("ACG", "ACG", "ACG", "TTT", "TTT")]
+    # skip mode marks instead of failing
+    texts = ["ACGTNCGTACGT"]
+    words, spans, n_pool = build_pool(texts, src, rng, False)
+    seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+    rc = ctx.lib.kmers_batch_spaced(ctx.handle, C.byref(seq), spans, 1, 4, 2, 2, vp(out), None, 16, cap.BATCH_SKIP, C.byref(res))
+    assert rc == 0 and res.n_out == 5
+    want = [naive.kmer_words(t, 2)[0] if "N" not in t else 0xFFFFFFFFFFFFFFFF for t in ("ACGT", "GTNC", "NCGT", "GTAC", "ACGT")]
+    assert [int(x) for x in out[:5, 0]] == want
+    # the mirror: each_codon of every gene
+    genes = ["ATGGCCTAA", "ATGTTTGGGCCCTGA", "AT"]
+    kmers, none, offs = km.collect_batch(km.SpacedDNAMers[3, 3], [km.LongDNA[4](g) for g in genes] if src == 4 else genes)
+    assert none is None and list(offs) == [0, 3, 8, 8]
+    assert [str(k) for k in kmers] == ["ATG", "GCC", "TAA", "ATG", "TTT", "GGG", "CCC", "TGA"]
+
+
+@pytest.mark.parametrize("src", [2, 4, 8])
 def test_batch_pool_is_itself_a_view(km, ctx, orc, src):
     """pool.first_base != 0: the pool is a LongSubSeq of a longer buffer; spans are relative to the view."""
     cap = km._capi
