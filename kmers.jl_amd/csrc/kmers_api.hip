@@ -1263,6 +1263,9 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     // (each about 5 us under the store load), short ones keep a small batch spread over the device
     uint64_t passes = total / ((uint64_t)RG_PASS * (uint64_t)ctx->n_cus * 32u);
     passes = std::min<uint64_t>(std::max<uint64_t>(passes, 1), (uint64_t)RG_MAX_PASSES);
+    // ... but not longer than the record slots staged in LDS allow (very short reads: many records per pass)
+    const uint64_t per_pass = (n * (uint64_t)RG_PASS + total - 1) / total;  // records per pass, on average
+    passes = std::min<uint64_t>(passes, std::max<uint64_t>(1, (uint64_t)(RG_SLOTS * 7 / 8) / std::max<uint64_t>(per_pass, 1)));
     if (const char *e = getenv("KMERS_RG_PASSES")) passes = std::min<uint64_t>(std::max<long>(atol(e), 1), (uint64_t)RG_MAX_PASSES);  // tests, tuning
     const uint32_t tile_elems = (uint32_t)(passes * RG_PASS);
     const uint64_t n_tiles = (total + tile_elems - 1) / tile_elems;

@@ -17,7 +17,7 @@ K = 31
 res = cap.Result()
 CASES = (("10 M reads x 150", 10_000_000, 150, 151, 4), ("10 M reads x 150", 10_000_000, 150, 151, 2),
                                    ("10 M reads x 150 (ASCII)", 10_000_000, 150, 151, 8),
-                                   ("4 M reads x 50..600", 4_000_000, 50, 600, 4), ("100 k contigs x 2k..20k", 100_000, 2_000, 20_000, 4))
+                                   ("4 M reads x 50..600", 4_000_000, 50, 600, 4), ("30 M reads x 36", 30_000_000, 36, 37, 2), ("100 k contigs x 2k..20k", 100_000, 2_000, 20_000, 4))
 if "--quick" in sys.argv:
     CASES = CASES[:1]
 for label, n_reads, lo, hi, src in CASES:
