@@ -208,7 +208,7 @@ int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bi
  * returns KMERS_E_CAPACITY with res->n_out = the number required (capacity 0 + NULL outputs = a size
  * query).  KMERS_MEM_DEVICE applies to pool->words, out_a and out_b; out_offsets is always host memory;
  * spans is host memory unless KMERS_SPANS_DEVICE is set (tens of millions of reads: keep them
- * resident).  Kmers of one or two words (K <= 64 two-bit, K <= 32 four-bit).
+ * resident).  Kmers of up to four words (K <= 128 two-bit, K <= 64 four-bit), as everywhere in this library.
  * EncodeError: the first failing record in batch order wins, res->err_pos = 1-based position inside
  * THAT record, res->err_enc = the raw symbol, res->n_out = the record's index in spans[]. */
 typedef struct {

@@ -1212,7 +1212,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     if (mode != KMERS_BATCH_FW && mode != KMERS_BATCH_CANONICAL) return fail(ctx, KMERS_E_BADARG, "unknown batch mode");
     if (n_spans && !spans) return fail(ctx, KMERS_E_BADARG, "spans is NULL");
     const int nw = kmers_words_per_kmer(k, dst_bits);
-    if (nw > 2) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_batch supports kmers of one or two words");
+    if (nw > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_batch supports kmers of at most four words");
     if (n_spans >= 0xFFFFFFFFull) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_batch supports fewer than 2^32 records per call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
@@ -1332,20 +1332,22 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         if (out_a) { if (int rc = ensure_stage(ctx, 1, bytes_a)) return rc; d_a = (uint64_t *)ctx->stage[1]; }
         if (out_b) { if (int rc = ensure_stage(ctx, 2, bytes_b)) return rc; d_b = (uint64_t *)ctx->stage[2]; }
     }
-    if (nw == 2 && ((d_a && !aligned16(d_a)) || (d_b && !b_is_hash && !aligned16(d_b))))
-        return fail(ctx, KMERS_E_BADARG, "two-word kmer outputs must be 16-byte aligned");
+    if ((nw == 2 || nw == 4) && ((d_a && !aligned16(d_a)) || (d_b && !b_is_hash && !aligned16(d_b))))
+        return fail(ctx, KMERS_E_BADARG, "two- and four-word kmer outputs must be 16-byte aligned");
     a.out_a = d_a;
     a.out_b = d_b;
     const bool vec = (!d_a || aligned16(d_a)) && (!d_b || aligned16(d_b));
     dim3 grid((unsigned)n_tiles), block(256);
 #define RG(DB, NN, MD)                                                                                         \
     do {                                                                                                       \
-        if (vec) hipLaunchKernelGGL((ragged_kernel<DB, NN, MD, true>), grid, block, 0, ctx->stream, a);       \
+        if (vec && NN == 1) hipLaunchKernelGGL((ragged_kernel<DB, NN, MD, NN == 1>), grid, block, 0, ctx->stream, a);  \
         else hipLaunchKernelGGL((ragged_kernel<DB, NN, MD, false>), grid, block, 0, ctx->stream, a);          \
     } while (0)
 #define RGM(DB, NN) do { if (mode == KMERS_BATCH_FW) RG(DB, NN, MODE_FW); else RG(DB, NN, MODE_CANON); } while (0)
-    if (dst_bits == 2) { if (nw == 1) RGM(2, 1); else RGM(2, 2); }
-    else               { if (nw == 1) RGM(4, 1); else RGM(4, 2); }
+#define RGN(DB) do { if (nw == 1) RGM(DB, 1); else if (nw == 2) RGM(DB, 2); else if (nw == 3) RGM(DB, 3); else RGM(DB, 4); } while (0)
+    if (dst_bits == 2) RGN(2);
+    else RGN(4);
+#undef RGN
 #undef RGM
 #undef RG
     HIP_TRY(ctx, hipGetLastError());

@@ -67,7 +67,7 @@ def test_batch_matches_per_record_iteration(km, ctx, orc, src):
     cap = km._capi
     rng = np.random.default_rng(100 + src)
     for dst in (2, 4):
-        for K in (1, 5, 31, 32, 33, 64) if dst == 2 else (1, 7, 16, 17, 32):
+        for K in (1, 5, 31, 32, 33, 64, 65, 100, 128) if dst == 2 else (1, 7, 16, 17, 32, 33, 64):
             for n_rec, scatter in ((1, False), (7, True), (300, True), (4000, False)):
                 lens = rng.choice([0, 1, K - 1, K, K + 1, 50, 151, 1000, 3000], n_rec)
                 texts = [naive.random_text(rng, int(max(0, l))) for l in lens]
