@@ -338,6 +338,29 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
         };
         auto one_by_one = [&]() {  // every lane one element at a time: multi-word kmers, unaligned outputs, uncovered tiles, strides
             uint32_t r = 0;
+            if constexpr (N == 1 && VEC) {  // (one-word kmers: two neighbours per lane, one 16-byte store per array)
+                for (uint32_t e = 2u * tid; e < a.tile; e += 512u) {
+                    const uint64_t g = e0 + e;
+                    if (g > e_last) break;
+                    uint64_t fw[1], rc[1], x0[1], y0[1], x1[1] = {0}, y1[1] = {0};
+                    r = slot_of(g, r);
+                    const bool m0 = element(g, r, fw, rc);
+                    finish(fw, rc, x0, y0);
+                    if (m0) x0[0] = y0[0] = ~0ull;
+                    const bool two = g + 1 <= e_last;
+                    if (two) {
+                        const bool m1 = element(g + 1, slot_of(g + 1, r), fw, rc);
+                        finish(fw, rc, x1, y1);
+                        if (m1) x1[0] = y1[0] = ~0ull;
+                        if (a.out_a) *reinterpret_cast<ulonglong2 *>(a.out_a + g) = make_ulonglong2(x0[0], x1[0]);
+                        if (a.out_b) *reinterpret_cast<ulonglong2 *>(a.out_b + g) = make_ulonglong2(y0[0], y1[0]);
+                    } else {
+                        if (a.out_a) a.out_a[g] = x0[0];
+                        if (a.out_b) a.out_b[g] = y0[0];
+                    }
+                }
+                return;
+            }
             for (uint32_t e = tid; e < a.tile; e += 256u) {
                 const uint64_t g = e0 + e;
                 if (g > e_last) break;
