@@ -367,8 +367,8 @@ __device__ __forceinline__ void bitonic_sort_lds256(uint64_t *v, uint32_t m, uin
 
 __global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__restrict__ hashes, const uint64_t *__restrict__ off,
                                                               uint32_t s, uint64_t *__restrict__ out, uint64_t *__restrict__ counts,
-                                                              uint32_t drop_all_ones) {
-    extern __shared__ uint64_t v[];            // SEG_VALUES values: [0, nb) the running sketch, then candidates
+                                                              uint32_t drop_all_ones, uint32_t cap) {
+    extern __shared__ uint64_t v[];            // cap values (a power of two, s + a tile <= cap <= SEG_VALUES): [0, nb) the running sketch, then candidates
     __shared__ uint32_t fill;                  // candidates appended since the last merge
     __shared__ uint32_t wave_tot[4];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__r
             block_sync();
             const bool last = base + TILE >= hi;
             const uint32_t total = nb + fill;  // uniform
-            if (last || total + TILE > SEG_VALUES) {
+            if (last || total + TILE > cap) {
                 // merge: sort everything, keep the s smallest distinct values
                 uint32_t m = 1;
                 while (m < total) m <<= 1;

@@ -1468,10 +1468,18 @@ static int minhash_batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers
         d_out = static_cast<uint64_t *>(ctx->stage[1]);
         d_cnt = static_cast<uint64_t *>(ctx->stage[2]);
     }
+    // LDS per workgroup = the candidate buffer.  Short records (one tile of hashes) need room for the sketch and that
+    // tile: 16 KiB keeps eight workgroups on a CU.  Long records leave about 1.8 s candidates below the provisional
+    // threshold: 32 KiB holds them without a merge half way.  (1 M reads x 1 kbase: 46 ms with the 64 KiB buffer ->
+    // 19 ms with 16 KiB; 100 k records x 10 kbases: 15 -> 9 ms with 32 KiB.)
+    const uint32_t seg_tile = 256u * SEG_UNROLL;
+    uint32_t cap = total / n_spans <= seg_tile ? 2048u : 4096u;
+    while (cap < (uint32_t)s + seg_tile) cap <<= 1;
+    if (const char *e = getenv("KMERS_SEG_CAP")) cap = std::max<uint32_t>(cap, std::min<uint32_t>((uint32_t)atol(e), SEG_VALUES));  // tuning
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(segment_sketch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      SEG_VALUES * 8));
-    hipLaunchKernelGGL(segment_sketch_kernel, dim3((unsigned)n_spans), dim3(256), SEG_VALUES * 8, ctx->stream, d_hashes, d_off, (uint32_t)s,
-                       d_out, d_cnt, (flags & KMERS_BATCH_SKIP) ? 1u : 0u);
+    hipLaunchKernelGGL(segment_sketch_kernel, dim3((unsigned)n_spans), dim3(256), (size_t)cap * 8, ctx->stream, d_hashes, d_off, (uint32_t)s,
+                       d_out, d_cnt, (flags & KMERS_BATCH_SKIP) ? 1u : 0u, cap);
     HIP_TRY(ctx, hipGetLastError());
     if (!dev) {
         HIP_TRY(ctx, hipMemcpyAsync(out_hashes, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
