@@ -191,6 +191,26 @@ __global__ __launch_bounds__(256) void recode_kernel(const RecodeArgs a) {
     }
 }
 
+// is any of the k flag bits that start at bit fs of flag word load(0) set?  (k up to 128: up to three words)
+template <class Load>
+__device__ __forceinline__ bool any_flag_in(Load load, uint32_t fs, uint32_t k) {
+    uint64_t f = load(0u) >> fs;
+    const uint32_t have = 64u - fs;
+    if (have >= k) return (k < 64u ? (f & ((1ull << k) - 1ull)) : f) != 0;
+    uint32_t left = k - have;
+    for (uint32_t i = 1; left; ++i) {
+        uint64_t w = load(i);
+        if (left < 64u) {
+            w &= (1ull << left) - 1ull;
+            left = 0;
+        } else {
+            left -= 64u;
+        }
+        f |= w;
+    }
+    return f != 0;
+}
+
 // `window()` of stream_kernel.hpp with the stream words coming from `load(j)` = word j of the stream counted
 // from the one that holds `bit` (LDS or HBM)
 template <int N, int DST, class Load>
@@ -305,19 +325,12 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
             bool bad = false;
             if (flags) {
                 const uint64_t fq = p >> 6;
-                const uint32_t fs = (uint32_t)(p & 63u);
-                uint64_t f0, f1 = 0;
                 if (staged) {  // (the staged flag words cover the staged stream words)
                     const uint32_t fr = (uint32_t)(fq - d.f_lo);
-                    f0 = flg_l[fr];
-                    if (fs + k > 64u) f1 = flg_l[fr + 1u];
+                    bad = any_flag_in([&](uint32_t i) { return flg_l[fr + i]; }, (uint32_t)(p & 63u), k);
                 } else {
-                    f0 = flags[fq];
-                    if (fs + k > 64u) f1 = flags[fq + 1];
+                    bad = any_flag_in([&](uint32_t i) { return flags[fq + i]; }, (uint32_t)(p & 63u), k);
                 }
-                uint64_t f = (f0 >> fs) | ((f1 << 1) << (63u - fs));
-                if (k < 64u) f &= (1ull << k) - 1ull;
-                bad = f != 0;
                 if (bad && !a.skip) atomicMin(a.err_slot, (unsigned long long)g);
             }
             if (staged) window_words<N, DST>([&](uint32_t j) { return src_l[(uint32_t)rel + j]; }, s, k, mask, fw, rc);

@@ -407,6 +407,58 @@ def test_batch_tile_sizes_and_record_orders(km, ctx, orc, passes, monkeypatch):
 
 
 @pytest.mark.parametrize("src", [4, 8])
+def test_batch_long_kmers_see_every_symbol(km, ctx, orc, src):
+    """Windows of more than 64 symbols (three- and four-word kmers) span up to three words of the flag stream: an
+    ambiguous symbol anywhere in the window -- the record's last symbol included -- fails the call (strict) or marks
+    exactly the windows over it (skip)."""
+    cap = km._capi
+    rng = np.random.default_rng(40 + src)
+    for K in (65, 100, 128):
+        texts = []
+        for i in range(60):
+            t = list(naive.random_text(rng, int(rng.integers(K, K + 200))))
+            if i >= 7:                                   # the first records are clean
+                t[len(t) - 1 if i % 5 == 0 else int(rng.integers(0, len(t)))] = "N"
+            texts.append("".join(t))
+        words, spans, n_pool = build_pool(texts, src, rng, scatter=(src != 8))
+        seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+        total = sum(len(t) - K + 1 for t in texts)
+        N = (2 * K + 63) // 64
+        out_a, out_b = np.zeros((total, N), np.uint64), np.zeros(total, np.uint64)
+        res = cap.Result()
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, K, 2, vp(out_a), vp(out_b), 0, None, total, 0,
+                                 C.byref(res))
+        assert rc == cap.E_ENCODE and res.n_out == 7 and res.err_pos == texts[7].index("N") + 1, (K, res.n_out, res.err_pos)
+        assert res.err_enc == (ord("N") if src == 8 else 0b1111)
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, K, 2, vp(out_a), vp(out_b), 0, None, total,
+                                 cap.BATCH_SKIP, C.byref(res))
+        assert rc == 0 and res.n_out == total, ctx.last_error()
+        g = 0
+        for i, t in enumerate(texts):
+            n_i = len(t) - K + 1
+            marked = np.array(["N" in t[j:j + K] for j in range(n_i)])
+            got = out_a[g:g + n_i]
+            assert np.array_equal((got == np.uint64(0xFFFFFFFFFFFFFFFF)).all(axis=1), marked), (K, i)
+            assert np.array_equal(out_b[g:g + n_i] == np.uint64(0xFFFFFFFFFFFFFFFF), marked), (K, i)
+            if not marked.all():
+                j = int(np.flatnonzero(~marked)[0])
+                ek, eh, _ = orc.canonical(naive.ascii_words(t[j:j + K]), K, 8, 2, K)
+                assert np.array_equal(got[j], ek[0]) and out_b[g + j] == eh[0], (K, i, j)
+            g += n_i
+        # per-record sketches leave the marked windows out
+        sk = np.zeros((len(texts), 16), np.uint64)
+        cnt = np.zeros(len(texts), np.uint64)
+        assert ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq), spans, len(texts), K, 2, 0, 16, vp(sk), vp(cnt), cap.BATCH_SKIP, C.byref(res)) == 0
+        g = 0
+        for i, t in enumerate(texts):
+            n_i = len(t) - K + 1
+            h = out_b[g:g + n_i]
+            e = np.unique(h[h != np.uint64(0xFFFFFFFFFFFFFFFF)])[:16]
+            assert cnt[i] == len(e) and np.array_equal(sk[i, :len(e)], e), (K, i)
+            g += n_i
+
+
+@pytest.mark.parametrize("src", [4, 8])
 def test_batch_skip_mode_masks_ambiguous_windows(km, ctx, orc, src):
     """KMERS_BATCH_SKIP: reads with N do not fail; the elements whose window holds an ambiguous symbol are
     all-ones, the others equal the strict result -- i.e. the kept ones are UnambiguousKmers of each record
