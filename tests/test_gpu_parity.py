@@ -282,7 +282,7 @@ def test_encode_errors_match_oracle(km, ctx, orc):
     (construction.jl:108-110; raise sites FwKmers.jl:112, CanonicalKmers.jl:139)."""
     cap = km._capi
     rng = np.random.default_rng(21)
-    for K in (1, 3, 31, 33):
+    for K in (1, 3, 31, 33, 65, 128):
         for L in (K, 500, 20000):
             for trial in range(4):
                 text = list(naive.random_text(rng, L))
