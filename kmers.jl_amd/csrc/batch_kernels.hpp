@@ -338,13 +338,15 @@ __global__ __launch_bounds__(1024) void sketch_prune_kernel(uint64_t *__restrict
     dedupe(m, total, false, true);
 }
 
-// ---- one MinHash sketch per record of a batch ------------------------------------------------------
-// hashes[off[r] .. off[r+1]) are the fx_hash values of record r's canonical kmers (kmers_batch).  One
-// workgroup per record keeps the record's running bottom-s in LDS: values below the current threshold
+// ---- one MinHash sketch per record of a batch (record_sketch_kernel.hpp) --------------------------
+// One workgroup per record keeps the record's running bottom-s in LDS: hashes below the current threshold
 // are appended behind it; when the next tile might not fit, the buffer is sorted, deduplicated and cut
 // back to s values (the same merge the whole-sequence sketch does between rounds, per workgroup).
-// Output: out[r * s .. r * s + counts[r]) ascending, counts[r] <= s.
-constexpr uint32_t SEG_VALUES = 8192;   // 64 KiB of dynamic LDS
+// Records with more than about 3 s hashes first try a provisional threshold at the (1.5 s + slack) / n
+// quantile of the 64-bit range, which leaves about 1.8 s candidates -- one sweep and one small sort instead
+// of sorting thousands of values to keep s; if fewer than s distinct values turn out to lie below it
+// (skewed or heavily duplicated hashes) the record is swept again without it.
+constexpr uint32_t SEG_VALUES = 8192;   // largest candidate buffer (64 KiB of dynamic LDS; 2048 or 4096 values are what calls use)
 constexpr uint32_t SEG_UNROLL = 4;      // hashes per thread per tile
 
 // ascending bitonic sort of v[0..m) by one 256-thread workgroup (same wave-local trick as above)
@@ -365,93 +367,40 @@ __device__ __forceinline__ void bitonic_sort_lds256(uint64_t *v, uint32_t m, uin
     block_sync();
 }
 
-__global__ __launch_bounds__(256) void segment_sketch_kernel(const uint64_t *__restrict__ hashes, const uint64_t *__restrict__ off,
-                                                              uint32_t s, uint64_t *__restrict__ out, uint64_t *__restrict__ counts,
-                                                              uint32_t drop_all_ones, uint32_t cap) {
-    extern __shared__ uint64_t v[];            // cap values (a power of two, s + a tile <= cap <= SEG_VALUES): [0, nb) the running sketch, then candidates
-    __shared__ uint32_t fill;                  // candidates appended since the last merge
-    __shared__ uint32_t wave_tot[4];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint64_t r = blockIdx.x;
-    const uint64_t lo = off[r], hi = off[r + 1];
-    uint32_t nb = 0;
-    constexpr uint32_t TILE = 256u * SEG_UNROLL;
-    // Pass 0 (records with more than 4 s hashes): hashes are close to uniform, so a provisional threshold at
-    // the (1.5 s + slack) / n quantile of the 64-bit range leaves about 1.5 s candidates -- one sweep and one
-    // small sort instead of sorting thousands of values to keep s.  If fewer than s distinct values turn
-    // out to lie below it (skewed or heavily duplicated hashes), pass 1 repeats the record without it.
-    for (int pass = 0; pass < 2; ++pass) {
-        const uint64_t n = hi - lo;
-        const double frac = n ? (1.5 * (double)s + 8.0 * sqrt((double)s) + 32.0) / (double)n : 1.0;
-        const bool provisional = pass == 0 && frac < 0.5;
-        uint64_t threshold = ~0ull;            // values strictly below it are candidates (uniform)
-        if (provisional) {
-            threshold = (uint64_t)(frac * 18446744073709551616.0);
-        } else if (pass == 0) {
-            pass = 1;                          // short record: the plain pass only
-        }
-        nb = 0;
-        if (t == 0) fill = 0;
-        block_sync();
-        for (uint64_t base = lo; base < hi || base == lo; base += TILE) {
-            if (base < hi) {
-#pragma unroll
-                for (uint32_t u = 0; u < SEG_UNROLL; ++u) {
-                    const uint64_t i = base + t + 256u * u;
-                    if (i < hi) {
-                        const uint64_t x = hashes[i];
-                        // room for a whole tile is guaranteed by the merge condition below
-                        // (KMERS_BATCH_SKIP: all-ones marks a window over a symbol that cannot be encoded -- not a hash)
-                        if ((x < threshold || (!provisional && nb < s)) && !(drop_all_ones && x == ~0ull)) v[nb + atomicAdd(&fill, 1u)] = x;
-                    }
-                }
-            }
-            block_sync();
-            const bool last = base + TILE >= hi;
-            const uint32_t total = nb + fill;  // uniform
-            if (last || total + TILE > cap) {
-                // merge: sort everything, keep the s smallest distinct values
-                uint32_t m = 1;
-                while (m < total) m <<= 1;
-                for (uint32_t i = total + t; i < m; i += 256) v[i] = ~0ull;
-                block_sync();
-                bitonic_sort_lds256(v, m, t);
-                // distinct values among the first `total`: thread t owns positions [a, b)
-                const uint32_t per = (m + 255) / 256;
-                const uint32_t a = t * per < total ? t * per : total, b = a + per < total ? a + per : total;
-                uint64_t mine[SEG_VALUES / 256];
-                uint32_t n_mine = 0;
-                for (uint32_t i = a; i < b; ++i) {
-                    const uint64_t x = v[i];
-                    if (i == 0 || x != v[i - 1]) mine[n_mine++] = x;
-                }
-                uint32_t incl = n_mine;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t y = __shfl_up(incl, d, 64);
-                    if ((int)lane >= d) incl += y;
-                }
-                if (lane == 63) wave_tot[wave] = incl;
-                block_sync();               // every thread has read its slice of v[]; wave totals visible
-                uint32_t before = 0, distinct = 0;
-                for (uint32_t w = 0; w < 4; ++w) {
-                    if (w < wave) before += wave_tot[w];
-                    distinct += wave_tot[w];
-                }
-                uint32_t pos = before + incl - n_mine;
-                for (uint32_t i = 0; i < n_mine; ++i, ++pos)
-                    if (pos < s) v[pos] = mine[i];
-                block_sync();
-                nb = distinct < s ? distinct : s;
-                if (nb == s && v[s - 1] < threshold) threshold = v[s - 1];
-                if (t == 0) fill = 0;
-                block_sync();
-            }
-            if (last) break;
-        }
-        if (!provisional || nb == s) break;    // s distinct values below the provisional threshold: they are the answer
+// merge step of the per-record sketches: sorts v[0, total), keeps the s smallest distinct values in v[0, nb), returns nb
+__device__ __forceinline__ uint32_t segment_merge(uint64_t *v, uint32_t total, uint32_t s, uint32_t t, uint32_t *wave_tot) {
+    const uint32_t lane = t & 63u, wave = t >> 6;
+    uint32_t m = 1;
+    while (m < total) m <<= 1;
+    for (uint32_t i = total + t; i < m; i += 256) v[i] = ~0ull;
+    block_sync();
+    bitonic_sort_lds256(v, m, t);
+    // distinct values among the first `total`: thread t owns positions [a, b)
+    const uint32_t per = (m + 255) / 256;
+    const uint32_t a = t * per < total ? t * per : total, b = a + per < total ? a + per : total;
+    uint64_t mine[SEG_VALUES / 256];
+    uint32_t n_mine = 0;
+    for (uint32_t i = a; i < b; ++i) {
+        const uint64_t x = v[i];
+        if (i == 0 || x != v[i - 1]) mine[n_mine++] = x;
     }
-    for (uint32_t i = t; i < nb; i += 256) out[r * (uint64_t)s + i] = v[i];
-    if (t == 0) counts[r] = nb;
+    uint32_t incl = n_mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += y;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    block_sync();               // every thread has read its slice of v[]; wave totals visible
+    uint32_t before = 0, distinct = 0;
+    for (uint32_t w = 0; w < 4; ++w) {
+        if (w < wave) before += wave_tot[w];
+        distinct += wave_tot[w];
+    }
+    uint32_t pos = before + incl - n_mine;
+    for (uint32_t i = 0; i < n_mine; ++i, ++pos)
+        if (pos < s) v[pos] = mine[i];
+    block_sync();
+    return distinct < s ? distinct : s;
 }
 
 // ---- synthetic input (the CPU checker restates the same generator) ------

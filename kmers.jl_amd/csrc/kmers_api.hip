@@ -18,6 +18,7 @@
 #include "compact_kernels.hpp"
 #include "composition_kernel.hpp"
 #include "ragged_kernels.hpp"
+#include "record_sketch_kernel.hpp"
 #include "run_kernel.hpp"
 #include "stream_kernel.hpp"
 
@@ -1198,6 +1199,78 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
     return collect(ctx, res, n);
 }
 
+// The pool as a DST-bit symbol stream: the pool itself when the kmer alphabet has the source's width (Copyable,
+// nothing can fail), else the output of the recode pass (stream in stage 4, flag bits in stage 5).
+struct PoolStream {
+    const uint64_t *stream = nullptr, *flags = nullptr, *any_flag = nullptr;
+};
+static int pool_stream(kmers_ctx *ctx, const kmers_seq *pool, const uint64_t *src0, uint64_t origin, uint64_t n_src_words, int dst_bits,
+                       PoolStream *out) {
+    (void)origin;
+    const int sb = pool->src_bits;
+    if (sb == dst_bits) {
+        out->stream = src0;
+        return KMERS_OK;
+    }
+    const size_t stream_bytes = (size_t)n_src_words * 8 * dst_bits / sb + 16, flag_bytes = (size_t)n_src_words * 8 / sb + 16;
+    if (int rc = ensure_stage(ctx, 4, stream_bytes)) return rc;
+    RecodeArgs r{};
+    r.src = src0;
+    r.n_words = n_src_words;
+    r.stream = static_cast<uint64_t *>(ctx->stage[4]);
+    r.ascii_table = ascii_table(ctx, dst_bits, pool->alphabet != 0);
+    if (sb != 2) {
+        if (int rc = ensure_stage(ctx, 5, flag_bytes + 16)) return rc;
+        r.flags = static_cast<uint64_t *>(ctx->stage[5]);
+        r.any_flag = reinterpret_cast<uint64_t *>(static_cast<char *>(ctx->stage[5]) + ((flag_bytes + 7) & ~(size_t)7));
+        HIP_TRY(ctx, hipMemsetAsync(r.any_flag, 0, 8, ctx->stream));
+    }
+    if (n_src_words) {
+        dim3 rgrid((unsigned)std::min<uint64_t>((n_src_words + 255) / 256, (uint64_t)ctx->n_cus * 16)), rblock(256);
+        if (sb == 4) hipLaunchKernelGGL((recode_kernel<4, 2>), rgrid, rblock, 0, ctx->stream, r);
+        else if (sb == 2) hipLaunchKernelGGL((recode_kernel<2, 4>), rgrid, rblock, 0, ctx->stream, r);
+        else if (dst_bits == 2) hipLaunchKernelGGL((recode_kernel<8, 2>), rgrid, rblock, 0, ctx->stream, r);
+        else hipLaunchKernelGGL((recode_kernel<8, 4>), rgrid, rblock, 0, ctx->stream, r);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    out->stream = r.stream;
+    out->flags = r.flags;
+    out->any_flag = r.any_flag;
+    return KMERS_OK;
+}
+
+// EncodeError of a batch: the window that starts at symbol j (0-based) of record r holds the record's first symbol
+// that the kmer alphabet cannot encode (all earlier windows of the record were clean); find it on the host.
+static int report_window_error(kmers_ctx *ctx, const kmers_seq *pool, const uint64_t *src0, uint64_t origin, const RaggedSpan *d_spans,
+                               uint64_t r, uint64_t j, int k, int dst_bits, kmers_result *res) {
+    const int sb = pool->src_bits;
+    kmers_span bad_span;
+    HIP_TRY(ctx, hipMemcpy(&bad_span, d_spans + r, sizeof bad_span, hipMemcpyDeviceToHost));
+    const uint64_t p0 = bad_span.first_base + j + origin;     // symbol index from src0
+    const uint64_t wlo = p0 * sb / 64, whi = ((p0 + k) * sb + 63) / 64;
+    std::vector<uint64_t> w(whi - wlo);
+    HIP_TRY(ctx, hipMemcpyAsync(w.data(), src0 + wlo, w.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint8_t table[256];
+    if (sb == 8) build_ascii_encode_table(dst_bits, pool->alphabet != 0, table);
+    for (uint64_t t = 0; t < (uint64_t)k; ++t) {
+        const uint64_t bit = (p0 + t) * sb - wlo * 64;
+        const uint32_t enc = (uint32_t)((w[bit >> 6] >> (bit & 63u)) & ((1ull << sb) - 1ull));
+        const bool bad = sb == 8 ? table[enc] == 0x80 : (sb == 4 && dst_bits == 2 && __builtin_popcount(enc) != 1);
+        if (bad) {
+            if (res) {
+                res->status = KMERS_E_ENCODE;
+                res->err_pos = j + t + 1;
+                res->err_enc = enc;
+                res->n_out = r;
+            }
+            ctx->last_error = "EncodeError: symbol cannot be encoded in the kmer alphabet";
+            return KMERS_E_ENCODE;
+        }
+    }
+    return fail(ctx, KMERS_E_HIP, "kmers_batch: a flagged window holds no offending symbol");
+}
+
 static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int mode, int k,
                       int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
                       uint64_t capacity, int flags, kmers_result *res, uint64_t stride = 1) {
@@ -1296,33 +1369,11 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     a.tile = tile_elems;
     a.stride = (uint32_t)stride;
     a.stream_origin = origin;
-    if (sb == dst_bits) {  // Copyable: the pool is the stream, nothing can fail
-        a.stream = src0;
-        a.flags = nullptr;
-    } else {
-        const size_t stream_bytes = (size_t)n_src_words * 8 * dst_bits / sb + 16, flag_bytes = (size_t)n_src_words * 8 / sb + 16;
-        if (int rc = ensure_stage(ctx, 4, stream_bytes)) return rc;
-        RecodeArgs r{};
-        r.src = src0;
-        r.n_words = n_src_words;
-        r.stream = static_cast<uint64_t *>(ctx->stage[4]);
-        r.ascii_table = ascii_table(ctx, dst_bits, pool->alphabet != 0);
-        if (sb != 2) {
-            if (int rc = ensure_stage(ctx, 5, flag_bytes + 16)) return rc;
-            r.flags = static_cast<uint64_t *>(ctx->stage[5]);
-            r.any_flag = reinterpret_cast<uint64_t *>(static_cast<char *>(ctx->stage[5]) + ((flag_bytes + 7) & ~(size_t)7));
-            HIP_TRY(ctx, hipMemsetAsync(r.any_flag, 0, 8, ctx->stream));
-        }
-        dim3 rgrid((unsigned)std::min<uint64_t>((n_src_words + 255) / 256, (uint64_t)ctx->n_cus * 16)), rblock(256);
-        if (sb == 4) hipLaunchKernelGGL((recode_kernel<4, 2>), rgrid, rblock, 0, ctx->stream, r);
-        else if (sb == 2) hipLaunchKernelGGL((recode_kernel<2, 4>), rgrid, rblock, 0, ctx->stream, r);
-        else if (dst_bits == 2) hipLaunchKernelGGL((recode_kernel<8, 2>), rgrid, rblock, 0, ctx->stream, r);
-        else hipLaunchKernelGGL((recode_kernel<8, 4>), rgrid, rblock, 0, ctx->stream, r);
-        HIP_TRY(ctx, hipGetLastError());
-        a.stream = r.stream;
-        a.flags = r.flags;
-        a.any_flag = r.any_flag;
-    }
+    PoolStream ps;
+    if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;
+    a.stream = ps.stream;
+    a.flags = ps.flags;
+    a.any_flag = ps.any_flag;
 
     uint64_t *d_a = out_a, *d_b = out_b;
     const bool b_is_hash = mode == KMERS_BATCH_CANONICAL;
@@ -1370,31 +1421,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t r = (uint64_t)(std::upper_bound(offs.begin(), offs.begin() + n, g) - offs.begin()) - 1;  // last record with off <= g
     const uint64_t j = (g - offs[r]) * stride;                // 0-based start of the window inside the record
-    kmers_span bad_span;
-    HIP_TRY(ctx, hipMemcpy(&bad_span, d_spans + r, sizeof bad_span, hipMemcpyDeviceToHost));
-    const uint64_t p0 = bad_span.first_base + j + origin;     // symbol index from src0
-    const uint64_t wlo = p0 * sb / 64, whi = ((p0 + k) * sb + 63) / 64;
-    std::vector<uint64_t> w(whi - wlo);
-    HIP_TRY(ctx, hipMemcpyAsync(w.data(), src0 + wlo, w.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    uint8_t table[256];
-    if (sb == 8) build_ascii_encode_table(dst_bits, pool->alphabet != 0, table);
-    for (uint64_t t = 0; t < (uint64_t)k; ++t) {
-        const uint64_t bit = (p0 + t) * sb - wlo * 64;
-        const uint32_t enc = (uint32_t)((w[bit >> 6] >> (bit & 63u)) & ((1ull << sb) - 1ull));
-        const bool bad = sb == 8 ? table[enc] == 0x80 : (sb == 4 && dst_bits == 2 && __builtin_popcount(enc) != 1);
-        if (bad) {
-            if (res) {
-                res->status = KMERS_E_ENCODE;
-                res->err_pos = j + t + 1;
-                res->err_enc = enc;
-                res->n_out = r;
-            }
-            ctx->last_error = "EncodeError: symbol cannot be encoded in the kmer alphabet";
-            return KMERS_E_ENCODE;
-        }
-    }
-    return fail(ctx, KMERS_E_HIP, "kmers_batch: a flagged window holds no offending symbol");
+    return report_window_error(ctx, pool, src0, origin, d_spans, r, j, k, dst_bits, res);
 }
 
 // The two entry points that allocate host memory (std::vector): no C++ exception may cross the C ABI.
@@ -1433,34 +1460,42 @@ int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, 
     }
 }
 
-static int minhash_batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, int dst_bits,
-                              uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags, kmers_result *res) {
-    clear(res);
-    if (!ctx) return KMERS_E_BADARG;
-    if (s == 0 || s > SEG_VALUES / 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minhash_batch supports sketch sizes 1..2048");
-    if (n_spans && (!out_hashes || !out_counts)) return fail(ctx, KMERS_E_BADARG, "out_hashes / out_counts is NULL");
-    // 1. how many hashes in all
-    kmers_result q;
-    if (int rc = batch_impl(ctx, pool, spans, n_spans, KMERS_BATCH_CANONICAL, k, dst_bits, nullptr, nullptr, seed, nullptr, 0, flags, &q)) {
-        if (res) *res = q;
+// kmers_minhash_batch, fused: the recode pass (if the pool needs one), then one workgroup per record that derives the
+// record's hashes tile by tile and keeps its bottom-s (record_sketch_kernel.hpp).  No layout pass, no hash array.
+static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, int dst_bits,
+                               uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags, kmers_result *res) {
+    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP))) {
+        if (res) res->status = rc;
         return rc;
     }
+    if (flags & (KMERS_ASYNC | KMERS_OUT_TUPLES)) return fail(ctx, KMERS_E_BADARG, "kmers_minhash_batch is synchronous");
+    if (n_spans && !spans) return fail(ctx, KMERS_E_BADARG, "spans is NULL");
+    const int nw = kmers_words_per_kmer(k, dst_bits);
+    if (nw > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minhash_batch supports kmers of at most four words");
     if (n_spans == 0) return KMERS_OK;
-    const uint64_t total = q.n_out;
-    // 2. fx_hash of every canonical kmer of every record, in HBM
-    if (int rc = ensure_stage(ctx, 7, (size_t)std::max<uint64_t>(total, 1) * 8)) return rc;
-    uint64_t *d_hashes = static_cast<uint64_t *>(ctx->stage[7]);
-    if (int rc = batch_impl(ctx, pool, spans, n_spans, KMERS_BATCH_CANONICAL, k, dst_bits, nullptr, d_hashes, seed, nullptr, total,
-                            flags | INTERNAL_OUT_DEVICE, &q)) {
-        if (res) *res = q;  // EncodeError: q.n_out = the failing record, q.err_pos the position inside it
-        return rc;
-    }
-    // the element offsets of the records are still where batch_impl computed them (stage 3)
-    const size_t span_bytes = (size_t)n_spans * 16, cnt_bytes = ((size_t)n_spans * 4 + 15) & ~(size_t)15;
-    const uint64_t *d_off = reinterpret_cast<const uint64_t *>(static_cast<char *>(ctx->stage[3]) + span_bytes + cnt_bytes);
-    // 3. one workgroup per record: its bottom-s distinct hashes
+    if (n_spans >= 0xFFFFFFFFull) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minhash_batch supports fewer than 2^32 records per call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = n_spans;
+    const bool spans_dev = (flags & KMERS_SPANS_DEVICE) != 0;
+    const size_t span_bytes = (size_t)n * 16;
+    if (int rc = ensure_stage(ctx, 3, span_bytes + 16)) return rc;
+    char *meta = static_cast<char *>(ctx->stage[3]);
+    const RaggedSpan *d_spans = spans_dev ? reinterpret_cast<const RaggedSpan *>(spans) : reinterpret_cast<const RaggedSpan *>(meta);
+    uint64_t *d_bad = reinterpret_cast<uint64_t *>(meta + span_bytes);
+    if (!spans_dev) HIP_TRY(ctx, hipMemcpyAsync(meta, spans, span_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+
+    Staged st;
+    if (int rc = stage_sequence(ctx, pool, flags, &st)) return rc;
     const bool dev = flags & KMERS_MEM_DEVICE;
-    const size_t out_bytes = (size_t)n_spans * s * 8, cnt_out_bytes = (size_t)n_spans * 8;
+    const int sb = pool->src_bits;
+    const uint64_t *src0 = st.d_words + (st.first_bit >> 6);        // word that holds pool symbol 0
+    const uint64_t origin = (st.first_bit & 63u) / (uint64_t)sb;     // its symbol offset inside that word
+    const uint64_t n_src_words = ((origin + pool->n_bases) * (uint64_t)sb + 63) / 64;
+    PoolStream ps;
+    if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;
+
+    const size_t out_bytes = (size_t)n * s * 8, cnt_out_bytes = (size_t)n * 8;
     uint64_t *d_out = out_hashes, *d_cnt = out_counts;
     if (!dev) {
         if (int rc = ensure_stage(ctx, 1, out_bytes)) return rc;
@@ -1468,29 +1503,68 @@ static int minhash_batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers
         d_out = static_cast<uint64_t *>(ctx->stage[1]);
         d_cnt = static_cast<uint64_t *>(ctx->stage[2]);
     }
-    // LDS per workgroup = the candidate buffer.  Short records (one tile of hashes) need room for the sketch and that
-    // tile: 16 KiB keeps eight workgroups on a CU.  Long records leave about 1.8 s candidates below the provisional
-    // threshold: 32 KiB holds them without a merge half way.  (1 M reads x 1 kbase: 46 ms with the 64 KiB buffer ->
-    // 19 ms with 16 KiB; 100 k records x 10 kbases: 15 -> 9 ms with 32 KiB.)
-    const uint32_t seg_tile = 256u * SEG_UNROLL;
-    uint32_t cap = total / n_spans <= seg_tile ? 2048u : 4096u;
-    while (cap < (uint32_t)s + seg_tile) cap <<= 1;
+    // LDS per workgroup = the candidate buffer (+ 0.8 KiB of staged stream).  Short records (one tile of windows) need room
+    // for the sketch and that tile: 16 KiB keeps eight workgroups on a CU.  Long records leave about 1.8 s candidates
+    // below the provisional threshold: 32 KiB holds them without a merge half way.
+    uint32_t cap = pool->n_bases / n <= RS_TILE ? 2048u : 4096u;
+    while (cap < (uint32_t)s + RS_TILE) cap <<= 1;
     if (const char *e = getenv("KMERS_SEG_CAP")) cap = std::max<uint32_t>(cap, std::min<uint32_t>((uint32_t)atol(e), SEG_VALUES));  // tuning
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(segment_sketch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     SEG_VALUES * 8));
-    hipLaunchKernelGGL(segment_sketch_kernel, dim3((unsigned)n_spans), dim3(256), (size_t)cap * 8, ctx->stream, d_hashes, d_off, (uint32_t)s,
-                       d_out, d_cnt, (flags & KMERS_BATCH_SKIP) ? 1u : 0u, cap);
+    RecordSketchArgs a{};
+    a.stream = ps.stream;
+    a.flags = ps.flags;
+    a.any_flag = ps.any_flag;
+    a.stream_origin = origin;
+    a.spans = d_spans;
+    a.pool_bases = pool->n_bases;
+    a.seed = seed;
+    a.out = d_out;
+    a.counts = d_cnt;
+    a.err_slot = ctx->d_err;
+    a.bad = d_bad;
+    a.k = (uint32_t)k;
+    a.s = (uint32_t)s;
+    a.skip = (flags & KMERS_BATCH_SKIP) ? 1u : 0u;
+    a.cap = cap;
+    const size_t lds = ((size_t)cap + RS_STAGE + RS_FSTAGE) * 8;
+    dim3 grid((unsigned)n), block(256);
+#define RS(DB, NN)                                                                                                                      \
+    do {                                                                                                                                \
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(record_sketch_kernel<DB, NN>),                                  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SEG_VALUES + RS_STAGE + RS_FSTAGE) * 8))); \
+        hipLaunchKernelGGL((record_sketch_kernel<DB, NN>), grid, block, lds, ctx->stream, a);                                           \
+    } while (0)
+#define RSN(DB) do { if (nw == 1) RS(DB, 1); else if (nw == 2) RS(DB, 2); else if (nw == 3) RS(DB, 3); else RS(DB, 4); } while (0)
+    if (dst_bits == 2) RSN(2);
+    else RSN(4);
+#undef RSN
+#undef RS
     HIP_TRY(ctx, hipGetLastError());
     if (!dev) {
         HIP_TRY(ctx, hipMemcpyAsync(out_hashes, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(out_counts, d_cnt, cnt_out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_scratch, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result + 2, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t g = ctx->h_result[1];
+    if (g != NO_ERROR_POS) HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream));
+    if (ctx->h_result[2]) return fail(ctx, KMERS_E_BADARG, "a span reaches outside the pool (or holds 2^32 symbols or more)");
+    if (g != NO_ERROR_POS)  // (record << 32 | window): the first failing record in batch order, its first failing window
+        return report_window_error(ctx, pool, src0, origin, d_spans, g >> 32, g & 0xFFFFFFFFull, k, dst_bits, res);
     if (res) {
         res->status = KMERS_OK;
         res->n_out = n_spans;
     }
     return KMERS_OK;
+}
+
+static int minhash_batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, int dst_bits,
+                              uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags, kmers_result *res) {
+    clear(res);
+    if (!ctx) return KMERS_E_BADARG;
+    if (s == 0 || s > SEG_VALUES / 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minhash_batch supports sketch sizes 1..2048");
+    if (n_spans && (!out_hashes || !out_counts)) return fail(ctx, KMERS_E_BADARG, "out_hashes / out_counts is NULL");
+    return minhash_batch_fused(ctx, pool, spans, n_spans, k, dst_bits, seed, s, out_hashes, out_counts, flags, res);
 }
 
 int kmers_minhash_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, int dst_bits,
