@@ -47,6 +47,8 @@ struct kmers_ctx {
     int64_t stamps_ptr = 0;  // diagnostic builds only (KMERS_PARAM_STAMPS_PTR)
     int n_cus = 256;                // multiProcessorCount
     bool sketch_host_only = false;  // KMERS_PARAM_SKETCH_HOST_ONLY: force the host-feedback MinHash path (tests)
+    int64_t batch_passes = 0;       // KMERS_PARAM_BATCH_PASSES (tests, tuning); 0 = default
+    int64_t sketch_batch_lds = 0;   // KMERS_PARAM_SKETCH_BATCH_LDS (tuning); 0 = default
 };
 
 namespace {
@@ -698,6 +700,8 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value) {
     else if (param == KMERS_PARAM_MAX_GRID) ctx->max_grid = value;
     else if (param == KMERS_PARAM_STAMPS_PTR) ctx->stamps_ptr = value;
     else if (param == KMERS_PARAM_SKETCH_HOST_ONLY) ctx->sketch_host_only = value != 0;
+    else if (param == KMERS_PARAM_BATCH_PASSES) ctx->batch_passes = value;
+    else if (param == KMERS_PARAM_SKETCH_BATCH_LDS) ctx->sketch_batch_lds = value;
     else return fail(ctx, KMERS_E_BADARG, "unknown parameter");
     return KMERS_OK;
 }
@@ -1339,7 +1343,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     // ... but not longer than the record slots staged in LDS allow (very short reads: many records per pass)
     const uint64_t per_pass = (n * (uint64_t)RG_PASS + total - 1) / total;  // records per pass, on average
     passes = std::min<uint64_t>(passes, std::max<uint64_t>(1, (uint64_t)(RG_SLOTS * 7 / 8) / std::max<uint64_t>(per_pass, 1)));
-    if (const char *e = getenv("KMERS_RG_PASSES")) passes = std::min<uint64_t>(std::max<long>(atol(e), 1), (uint64_t)RG_MAX_PASSES);  // tests, tuning
+    if (ctx->batch_passes > 0) passes = std::min<uint64_t>((uint64_t)ctx->batch_passes, (uint64_t)RG_MAX_PASSES);  // tests, tuning
     const uint32_t tile_elems = (uint32_t)(passes * RG_PASS);
     const uint64_t n_tiles = (total + tile_elems - 1) / tile_elems;
     if (int rc = ensure_stage(ctx, 6, (size_t)n_tiles * sizeof(RaggedTile))) return rc;
@@ -1508,7 +1512,8 @@ static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmer
     // below the provisional threshold: 32 KiB holds them without a merge half way.
     uint32_t cap = pool->n_bases / n <= RS_TILE ? 2048u : 4096u;
     while (cap < (uint32_t)s + RS_TILE) cap <<= 1;
-    if (const char *e = getenv("KMERS_SEG_CAP")) cap = std::max<uint32_t>(cap, std::min<uint32_t>((uint32_t)atol(e), SEG_VALUES));  // tuning
+    if (ctx->sketch_batch_lds == 2048 || ctx->sketch_batch_lds == 4096 || ctx->sketch_batch_lds == 8192)  // tuning (a power of two)
+        cap = std::max<uint32_t>(cap, (uint32_t)ctx->sketch_batch_lds);
     RecordSketchArgs a{};
     a.stream = ps.stream;
     a.flags = ps.flags;

@@ -178,13 +178,13 @@ def test_collect_batch_mirror(km, orc):
 
 
 @pytest.mark.parametrize("src", [2, 4, 8])
-def test_batch_spaced_matches_per_record_iteration(km, ctx, orc, src, monkeypatch):
+def test_batch_spaced_matches_per_record_iteration(km, ctx, orc, src):
     """kmers_batch_spaced == SpacedKmers{A,K,J}(record) record by record (SpacedKmers.jl:38-42,92-139): J < K (shift-ins),
     J == K (each_codon), J > K (gaps that are never inspected), one- and two-word kmers, 2- and 4-bit kmer alphabets."""
     cap = km._capi
     rng = np.random.default_rng(300 + src)
-    for passes in ("1", "8"):
-        monkeypatch.setenv("KMERS_RG_PASSES", passes)
+    for passes in (1, 8):
+        ctx.set_param(cap.PARAM_BATCH_PASSES, passes)
         for dst, K, J in ((2, 3, 3), (2, 21, 3), (2, 5, 9), (2, 40, 7), (4, 7, 2), (4, 20, 20), (2, 1, 1)):
             for n_rec, scatter in ((1, False), (9, True), (1500, False)):
                 lens = rng.choice([0, 1, K - 1, K, K + 1, K + J - 1, K + J, 60, 301, 2000], n_rec)
@@ -210,7 +210,7 @@ def test_batch_spaced_matches_per_record_iteration(km, ctx, orc, src, monkeypatc
                 rc = ctx.lib.kmers_batch_spaced(ctx.handle, C.byref(seq), spans, n_rec, K, J, dst, vp(out), vp(offs), total, 0, C.byref(res))
                 assert rc == 0 and res.n_out == total, ctx.last_error()
                 assert np.array_equal(out[:total], exp), (src, dst, K, J, n_rec, passes)
-    monkeypatch.delenv("KMERS_RG_PASSES")
+    ctx.set_param(cap.PARAM_BATCH_PASSES, 0)
     if src == 2:
         return
     # strictness: a window over an ambiguous symbol fails with the record and the position; a gap symbol between
@@ -350,13 +350,13 @@ def test_batch_tiles_crowded_with_empty_records(km, ctx, orc):
 
 
 @pytest.mark.parametrize("passes", [1, 3, 8])
-def test_batch_tile_sizes_and_record_orders(km, ctx, orc, passes, monkeypatch):
+def test_batch_tile_sizes_and_record_orders(km, ctx, orc, passes):
     """The tile (1024 elements x 1..8 passes, normally chosen from the batch size) forced to each extreme, over the
     layouts that take different paths of the element kernel: reads in pool order (windows cut from the staged
     stretch), the same records listed in shuffled order (windows outside the stretch: HBM), very short reads
     (more record slots than LDS holds: global search), one- and two-word kmers, strict and skip mode."""
-    monkeypatch.setenv("KMERS_RG_PASSES", str(passes))
     cap = km._capi
+    ctx.set_param(cap.PARAM_BATCH_PASSES, passes)
     rng = np.random.default_rng(700 + passes)
     layouts = {
         "reads": [naive.random_text(rng, int(l)) for l in rng.integers(100, 260, 260)],
@@ -404,6 +404,7 @@ def test_batch_tile_sizes_and_record_orders(km, ctx, orc, passes, monkeypatch):
                     ek, eh, _ = orc.canonical(naive.ascii_words(w), 31, 8, 2, 31)
                     assert out_a[g] == ek[0, 0] and out_b[g] == eh[0], (src, g)
                 g += 1
+    ctx.set_param(cap.PARAM_BATCH_PASSES, 0)
 
 
 @pytest.mark.parametrize("src", [4, 8])

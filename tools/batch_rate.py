@@ -16,6 +16,8 @@ dev = torch.device("cuda", 0)
 K = int(os.environ.get("BATCH_K", "31"))   # BATCH_K=63: two-word kmers
 NW = (2 * K + 63) // 64
 res = cap.Result()
+if "--passes" in sys.argv:   # force the tile length (1..8 passes of 1024 elements) instead of the per-call choice
+    ctx.set_param(cap.PARAM_BATCH_PASSES, int(sys.argv[sys.argv.index("--passes") + 1]))
 CASES = (("10 M reads x 150", 10_000_000, 150, 151, 4), ("10 M reads x 150", 10_000_000, 150, 151, 2),
                                    ("10 M reads x 150 (ASCII)", 10_000_000, 150, 151, 8),
                                    ("4 M reads x 50..600", 4_000_000, 50, 600, 4), ("30 M reads x 36", 30_000_000, 36, 37, 2), ("100 k contigs x 2k..20k", 100_000, 2_000, 20_000, 4))

@@ -14,6 +14,8 @@ ctx = km.Context(0)
 dev = torch.device("cuda", 0)
 K, s = 16, 1000
 res = cap.Result()
+if "--lds" in sys.argv:      # force the candidate buffer (2048 / 4096 / 8192 values per workgroup)
+    ctx.set_param(cap.PARAM_SKETCH_BATCH_LDS, int(sys.argv[sys.argv.index("--lds") + 1]))
 for label, n_rec, lo, hi in (("100 k records x 5-15 kbases", 100_000, 5_000, 15_000), ("10 k genomes x 50-150 kbases", 10_000, 50_000, 150_000),
                              ("1 M reads x 1 kbase", 1_000_000, 1_000, 1_001)):
     rng = np.random.default_rng(2)
