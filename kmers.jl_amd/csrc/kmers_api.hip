@@ -1510,8 +1510,10 @@ static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmer
     // LDS per workgroup = the candidate buffer (+ 0.8 KiB of staged stream).  Short records (one tile of windows) need room
     // for the sketch and that tile: 16 KiB keeps eight workgroups on a CU.  Long records leave about 1.8 s candidates
     // below the provisional threshold: 32 KiB holds them without a merge half way.
-    uint32_t cap = pool->n_bases / n <= RS_TILE ? 2048u : 4096u;
-    while (cap < (uint32_t)s + RS_TILE) cap <<= 1;
+    const bool long_records = pool->n_bases / n > 1024;
+    const uint32_t run = long_records ? 8u : 4u, rs_tile = 256u * run;
+    uint32_t cap = long_records ? 4096u : 2048u;
+    while (cap < (uint32_t)s + rs_tile) cap <<= 1;
     if (ctx->sketch_batch_lds == 2048 || ctx->sketch_batch_lds == 4096 || ctx->sketch_batch_lds == 8192)  // tuning (a power of two)
         cap = std::max<uint32_t>(cap, (uint32_t)ctx->sketch_batch_lds);
     RecordSketchArgs a{};
@@ -1532,15 +1534,17 @@ static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmer
     a.cap = cap;
     const size_t lds = ((size_t)cap + RS_STAGE + RS_FSTAGE) * 8;
     dim3 grid((unsigned)n), block(256);
-#define RS(DB, NN)                                                                                                                      \
+#define RS(DB, NN, RR)                                                                                                                  \
     do {                                                                                                                                \
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(record_sketch_kernel<DB, NN>),                                  \
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(record_sketch_kernel<DB, NN, RR>),                              \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SEG_VALUES + RS_STAGE + RS_FSTAGE) * 8))); \
-        hipLaunchKernelGGL((record_sketch_kernel<DB, NN>), grid, block, lds, ctx->stream, a);                                           \
+        hipLaunchKernelGGL((record_sketch_kernel<DB, NN, RR>), grid, block, lds, ctx->stream, a);                                       \
     } while (0)
-#define RSN(DB) do { if (nw == 1) RS(DB, 1); else if (nw == 2) RS(DB, 2); else if (nw == 3) RS(DB, 3); else RS(DB, 4); } while (0)
+#define RSR(DB, NN) do { if (run == 8u) RS(DB, NN, 8); else RS(DB, NN, 4); } while (0)
+#define RSN(DB) do { if (nw == 1) RSR(DB, 1); else if (nw == 2) RSR(DB, 2); else if (nw == 3) RSR(DB, 3); else RSR(DB, 4); } while (0)
     if (dst_bits == 2) RSN(2);
     else RSN(4);
+#undef RSR
 #undef RSN
 #undef RS
     HIP_TRY(ctx, hipGetLastError());

@@ -13,9 +13,10 @@
 
 namespace kmers {
 
-constexpr uint32_t RS_TILE = 256u * SEG_UNROLL;  // windows per tile
-constexpr uint32_t RS_STAGE = 80;                // stream words of a tile: (1024 + 127 symbols) * 4 bits / 64 + slack
-constexpr uint32_t RS_FSTAGE = 24;               // flag words of a tile
+// windows per tile = 256 * RUN; RUN = 4 (short records: the candidate buffer needs room for the sketch and one tile)
+// or 8 (long records: half the per-run set-up and half the barriers per window)
+constexpr uint32_t RS_STAGE = 144;               // stream words of a tile: (2048 + 127 symbols) * 4 bits / 64 + slack
+constexpr uint32_t RS_FSTAGE = 40;               // flag words of a tile
 
 struct RecordSketchArgs {
     const uint64_t *stream;      // DST-bit symbol stream (the pool itself for Copyable pools)
@@ -32,8 +33,9 @@ struct RecordSketchArgs {
     uint32_t k, s, skip, cap;
 };
 
-template <int DST, int N>
+template <int DST, int N, int RUN>
 __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchArgs a) {
+    constexpr uint32_t RS_TILE = 256u * RUN;
     extern __shared__ uint64_t v[];            // cap candidate values, then the staging area
     __shared__ uint32_t fill;
     __shared__ uint32_t wave_tot[4];
@@ -77,11 +79,11 @@ __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchAr
                     for (uint32_t i = t; i < nf; i += 256u) flg_t[i] = flags[f0 + i];
                 }
                 block_sync();
-                const uint32_t e = SEG_UNROLL * t;                // this lane's first window of the tile
+                const uint32_t e = (uint32_t)RUN * t;                // this lane's first window of the tile
                 if (e < nel) {
-                    const uint32_t cnt = nel - e < SEG_UNROLL ? nel - e : SEG_UNROLL;
-                    uint64_t hv[SEG_UNROLL];
-                    bool keep[SEG_UNROLL];
+                    const uint32_t cnt = nel - e < (uint32_t)RUN ? nel - e : (uint32_t)RUN;
+                    uint64_t hv[(uint32_t)RUN];
+                    bool keep[(uint32_t)RUN];
                     const uint64_t p = ps + e;
                     const uint64_t bit = p * (uint64_t)DST;
                     const uint32_t rel = (uint32_t)((bit >> 6) - q0);
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchAr
                             const uint32_t fr = (uint32_t)((p >> 6) - f0), fs = (uint32_t)(p & 63u);
                             uint64_t f = flg_t[fr] >> fs;
                             if (fs + span > 64u) f |= (flg_t[fr + 1u] << 1) << (63u - fs);
-                            fbits = f & ((1ull << span) - 1ull);  // span <= 32 + 3
+                            fbits = f & ((1ull << span) - 1ull);  // span <= 32 + 7
                         }
                         const uint64_t kbits = k >= 64u ? ~0ull : (1ull << k) - 1ull;
                         const uint32_t need = (sh + (uint32_t)DST * span + 63u) >> 6;  // 1..3 stream words
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchAr
                         const uint32_t S = (uint32_t)((uint32_t)DST * k == 64u ? W1 : funnel64(W0, W1, (uint32_t)DST * k));
                         const uint32_t top = (uint32_t)DST * (k - 1u);
 #pragma unroll
-                        for (uint32_t j = 0; j < SEG_UNROLL; ++j) {
+                        for (uint32_t j = 0; j < (uint32_t)RUN; ++j) {
                             keep[j] = false;
                             hv[j] = 0;
                             if (j < cnt) {
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchAr
                         }
                     } else {
 #pragma unroll
-                        for (uint32_t j = 0; j < SEG_UNROLL; ++j) {
+                        for (uint32_t j = 0; j < (uint32_t)RUN; ++j) {
                             keep[j] = false;
                             hv[j] = 0;
                             if (j < cnt) {
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchAr
                     (void)rel;
                     (void)sh;
 #pragma unroll
-                    for (uint32_t j = 0; j < SEG_UNROLL; ++j)  // room for a whole tile is guaranteed by the merge condition below
+                    for (uint32_t j = 0; j < (uint32_t)RUN; ++j)  // room for a whole tile is guaranteed by the merge condition below
                         if (keep[j] && (hv[j] < threshold || (!provisional && nb < s))) v[nb + atomicAdd(&fill, 1u)] = hv[j];
                 }
             }
