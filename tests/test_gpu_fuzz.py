@@ -161,7 +161,8 @@ def test_fuzz_batches(km, ctx, orc, seed):
     for case in range(40):
         src = int(rng.choice([2, 4, 8]))
         dst = int(rng.choice([2, 4]))
-        K = int(rng.choice([1, 3, 15, 16, 17, 31, 32, 33, 64])) if dst == 2 else int(rng.choice([1, 5, 16, 17, 32]))
+        K = int(rng.choice([1, 3, 15, 16, 17, 31, 32, 33, 64, 65, 100, 128])) if dst == 2 else int(rng.choice([1, 5, 16, 17, 32, 33, 64]))
+        ctx.set_param(cap.PARAM_BATCH_PASSES, int(rng.choice([0, 0, 1, 3, 8])))   # tile length: per-call choice, or forced
         n_pool = int(rng.choice([0, 10, 500, 20_000]))
         lead = int(rng.choice([0, 1, 17, 64]))
         text = naive.random_text(rng, lead + n_pool, p_amb=0.0)
@@ -202,6 +203,19 @@ def test_fuzz_batches(km, ctx, orc, seed):
         assert [int(x) for x in got_off] == offs, tag
         if total:
             assert np.array_equal(out_a[:total], np.concatenate(exp_a)) and np.array_equal(out_b[:total], np.concatenate(exp_b)), tag
+        # SpacedKmers{A,K,J} of every record (kmers_batch_spaced)
+        J = int(rng.choice([1, 2, 3, K, K + 5]))
+        exp_s, offs_s = [], [0]
+        for t in recs:
+            if len(t) >= K:
+                w = naive.ascii_words(t) if src == 8 else naive.longseq_words(t, src)
+                exp_s.append(orc.spaced(w, len(t), src, dst, K, J)[0])
+            offs_s.append(offs_s[-1] + (0 if len(t) < K else (len(t) - K) // J + 1))
+        out_s = np.zeros((max(offs_s[-1], 1), N), np.uint64)
+        rc = ctx.lib.kmers_batch_spaced(ctx.handle, C.byref(seq), arr, n_rec, K, J, dst, vp(out_s), vp(got_off), offs_s[-1], 0, C.byref(res))
+        assert rc == 0 and res.n_out == offs_s[-1] and [int(x) for x in got_off] == offs_s, tag + (J, ctx.last_error())
+        if offs_s[-1]:
+            assert np.array_equal(out_s[:offs_s[-1]], np.concatenate(exp_s)), tag + (J,)
         if dst == 2 and n_rec:
             s = int(rng.choice([1, 7, 300]))
             sk = np.zeros((n_rec, s), np.uint64)
@@ -215,3 +229,4 @@ def test_fuzz_batches(km, ctx, orc, seed):
                 else:
                     e = np.zeros(0, np.uint64)
                 assert cnt[i] == len(e) and np.array_equal(sk[i, :len(e)], e), tag + (i, s)
+    ctx.set_param(cap.PARAM_BATCH_PASSES, 0)
