@@ -1,6 +1,8 @@
 #!/bin/bash
 # Everything committed under profiles/ comes from this script, run on the GPU box from the repo root:
-#   gpurun -- 'bash tools/refresh_evidence.sh'        then here:   python tools/collect_evidence.py
+#   rm -rf gpurun_out/prof gpurun_out/evidence   (on the build host: gpurun merges files back, it never deletes stale ones)
+#   gpurun -- 'bash tools/refresh_evidence.sh'
+#   python tools/collect_evidence.py
 # It writes under gpurun_out/evidence/ (merged back by gpurun); collect_evidence.py turns that into profiles/r01_*.
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
