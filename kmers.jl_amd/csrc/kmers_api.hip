@@ -1343,6 +1343,9 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     // ... but not longer than the record slots staged in LDS allow (very short reads: many records per pass)
     const uint64_t per_pass = (n * (uint64_t)RG_PASS + total - 1) / total;  // records per pass, on average
     passes = std::min<uint64_t>(passes, std::max<uint64_t>(1, (uint64_t)(RG_SLOTS * 7 / 8) / std::max<uint64_t>(per_pass, 1)));
+    // ... nor than the stretch of the stream a tile can stage (records lying far apart in the pool: a FASTQ buffer)
+    const uint64_t words_per_pass = (uint64_t)(1.1 * (double)pool->n_bases / (double)total * RG_PASS * dst_bits / 64.0) + 1;
+    passes = std::min<uint64_t>(passes, std::max<uint64_t>(1, (uint64_t)(RG_STAGE * 7 / 8) / words_per_pass));
     if (ctx->batch_passes > 0) passes = std::min<uint64_t>((uint64_t)ctx->batch_passes, (uint64_t)RG_MAX_PASSES);  // tests, tuning
     const uint32_t tile_elems = (uint32_t)(passes * RG_PASS);
     const uint64_t n_tiles = (total + tile_elems - 1) / tile_elems;
