@@ -45,6 +45,8 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
     __shared__ uint64_t lds[LDS_QWORDS];
     __shared__ uint64_t amb[MAX_TILE_BASES / 64 + 8];
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
+    constexpr uint32_t KEEP_PASSES = 4;                         // ballot rounds (64 starts each) per compaction round
+    __shared__ uint16_t kept[XOR ? 1 : WAVES * 64 * KEEP_PASSES];  // per wavefront: the kept candidates of a round
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if constexpr (SRC_BITS == 8) {
         for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);
@@ -164,39 +166,59 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
                 }
             }
             const uint32_t passes = (n_lat + 63u) / 64u;  // wave-uniform
-            for (uint32_t p = 0; p < passes; ++p) {
-                // the whole wave iterates together (ballot needs every lane); lanes past the end are invalid
-                const uint32_t li = p * 64u + lane;
-                const uint32_t r = r_first + li * a.stride;
-                const bool in = li < n_lat;
-                const uint64_t g = m0 + r;
-                bool ok = false;
-                if (in) {
-                    uint32_t bit = r + b0;
-                    uint64_t A = funnel64(amb[bit >> 6], amb[(bit >> 6) + 1], bit & 63u) & kmask;
-                    ok = A == 0;
+            // is candidate li (of this wavefront's chunk of the tile) a window of K unambiguous symbols?
+            auto kept_at = [&](uint32_t li) -> bool {
+                const uint32_t bit = r_first + li * a.stride + b0;
+                return (funnel64(amb[bit >> 6], amb[(bit >> 6) + 1], bit & 63u) & kmask) == 0;
+            };
+            if constexpr (XOR) {
+                for (uint32_t p = 0; p < passes; ++p) {
+                    const uint32_t li = p * 64u + lane;
+                    if (li < n_lat && kept_at(li)) {
+                        uint64_t fw[N], rc[N];
+                        window<N, 2>(lds, 2u * (r_first + li * a.stride + b0), k, mask, fw, rc);
+                        xacc ^= fw[0];
+                    }
                 }
-                const uint64_t bal = __ballot(ok);
-                {
-                    if (ok) {
+            } else {
+                // Survivors are sparse here (the dense case left above): first the indices of the kept candidates of
+                // up to 256 starts are compacted into a wavefront-private list in LDS (ballot + popcount, the order of
+                // the reference), then the list is worked off with every lane busy and the stores of a wavefront
+                // contiguous -- instead of cutting windows and storing with a quarter of the lanes.
+                uint16_t *mine = kept + wave * (64u * KEEP_PASSES);
+                for (uint32_t p0 = 0; p0 < passes; p0 += KEEP_PASSES) {
+                    uint32_t cnt = 0;
+                    const uint32_t p1 = p0 + KEEP_PASSES < passes ? p0 + KEEP_PASSES : passes;
+                    for (uint32_t p = p0; p < p1; ++p) {  // the whole wave iterates together (ballot needs every lane)
+                        const uint32_t li = p * 64u + lane;
+                        const bool ok = li < n_lat && kept_at(li);
+                        const uint64_t bal = __ballot(ok);
+                        if (ok) mine[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)li;
+                        cnt += __popcll(bal);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t i = lane; i < cnt; i += 64u) {
+                        const uint32_t r = r_first + (uint32_t)mine[i] * a.stride;
+                        const uint64_t g = m0 + r;
                         uint64_t fw[N], rc[N];
                         window<N, 2>(lds, 2u * (r + b0), k, mask, fw, rc);
-                        uint64_t o = pos + __popcll(bal & ((1ull << lane) - 1ull));
-                        if constexpr (XOR) {
-                            xacc ^= fw[0];
-                        } else if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
-    #pragma unroll
+                        const uint64_t o = pos + i;
+                        if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
+#pragma unroll
                             for (int w = 0; w < N; ++w) a.out_kmers[o * (N + 1) + w] = fw[w];
                             a.out_kmers[o * (N + 1) + N] = g + 1 + a.index_origin;
                         } else {
                             if (a.out_kmers) {
-    #pragma unroll
+#pragma unroll
                                 for (int w = 0; w < N; ++w) a.out_kmers[o * N + w] = fw[w];
                             }
                             if (a.out_starts) a.out_starts[o] = (long long)(g + 1 + a.index_origin);
                         }
                     }
-                    pos += __popcll(bal);
+                    pos += cnt;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next round
                 }
             }
         }
