@@ -41,12 +41,12 @@ struct CompactArgs {
 // XOR: no output arrays, no offsets: the head words of the kept kmers are XOR-folded into *xor_out (the reducer of
 // test/benchmark.jl:9-15 over UnambiguousKmers: `y ⊻= first(x).data[1]`)
 template <int SRC_BITS, int N, bool DENSE = false, bool XOR = false>
-__global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a) {
+__global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const CompactArgs a) {  // 8 waves per SIMD: at most 64 VGPRs (65 without)
     __shared__ uint64_t lds[LDS_QWORDS];
     __shared__ uint64_t amb[MAX_TILE_BASES / 64 + 8];
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
-    constexpr uint32_t KEEP_PASSES = 4;                         // ballot rounds (64 starts each) per compaction round
-    __shared__ uint16_t kept[XOR ? 1 : WAVES * 64 * KEEP_PASSES];  // per wavefront: the kept candidates of a round
+    constexpr uint32_t KEEP_ROUND = 1024;                       // starts per wavefront and compaction round (16 per lane)
+    __shared__ uint16_t kept[XOR ? 1 : WAVES * KEEP_ROUND];     // per wavefront: the kept starts of a round
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if constexpr (SRC_BITS == 8) {
         for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);
@@ -181,44 +181,88 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_kernel(const CompactArgs a)
                     }
                 }
             } else {
-                // Survivors are sparse here (the dense case left above): first the indices of the kept candidates of
-                // up to 256 starts are compacted into a wavefront-private list in LDS (ballot + popcount, the order of
-                // the reference), then the list is worked off with every lane busy and the stores of a wavefront
-                // contiguous -- instead of cutting windows and storing with a quarter of the lanes.
-                uint16_t *mine = kept + wave * (64u * KEEP_PASSES);
-                for (uint32_t p0 = 0; p0 < passes; p0 += KEEP_PASSES) {
-                    uint32_t cnt = 0;
-                    const uint32_t p1 = p0 + KEEP_PASSES < passes ? p0 + KEEP_PASSES : passes;
-                    for (uint32_t p = p0; p < p1; ++p) {  // the whole wave iterates together (ballot needs every lane)
-                        const uint32_t li = p * 64u + lane;
-                        const bool ok = li < n_lat && kept_at(li);
-                        const uint64_t bal = __ballot(ok);
-                        if (ok) mine[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)li;
-                        cnt += __popcll(bal);
-                    }
+                // Survivors are sparse here (the dense case left above).  Round by round (up to 1024 starts of this
+                // wavefront's chunk of the tile): every lane resolves its slice of consecutive starts bit-parallel, as the
+                // count pass does (good bits AND-ed with themselves shifted by 1, 2, 4, ...: bit j survives iff K
+                // unambiguous symbols begin there), the kept starts are listed in LDS in the reference's order (prefix
+                // sum of the popcounts), and the list is worked off with every lane busy and the stores of a wavefront
+                // contiguous.  (Testing start by start with a ballot per 64 cost three times the instructions: the
+                // kernel is bound by its integer work.)
+                uint16_t *mine = kept + wave * KEEP_ROUND;
+                auto emit_listed = [&](uint32_t cnt) {  // list entries = starts relative to r_begin
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     for (uint32_t i = lane; i < cnt; i += 64u) {
-                        const uint32_t r = r_first + (uint32_t)mine[i] * a.stride;
+                        const uint32_t r = r_begin + (uint32_t)mine[i];
                         const uint64_t g = m0 + r;
                         uint64_t fw[N], rc[N];
                         window<N, 2>(lds, 2u * (r + b0), k, mask, fw, rc);
-                        const uint64_t o = pos + i;
+                        const uint64_t o2 = pos + i;
                         if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
 #pragma unroll
-                            for (int w = 0; w < N; ++w) a.out_kmers[o * (N + 1) + w] = fw[w];
-                            a.out_kmers[o * (N + 1) + N] = g + 1 + a.index_origin;
+                            for (int wd = 0; wd < N; ++wd) a.out_kmers[o2 * (N + 1) + wd] = fw[wd];
+                            a.out_kmers[o2 * (N + 1) + N] = g + 1 + a.index_origin;
                         } else {
                             if (a.out_kmers) {
 #pragma unroll
-                                for (int w = 0; w < N; ++w) a.out_kmers[o * N + w] = fw[w];
+                                for (int wd = 0; wd < N; ++wd) a.out_kmers[o2 * N + wd] = fw[wd];
                             }
-                            if (a.out_starts) a.out_starts[o] = (long long)(g + 1 + a.index_origin);
+                            if (a.out_starts) a.out_starts[o2] = (long long)(g + 1 + a.index_origin);
                         }
                     }
                     pos += cnt;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next round
+                };
+                if (a.stride > 1) {
+                    // a stride lattice: only every stride-th start is a candidate; those are tested one per lane (ballot +
+                    // popcount, four rounds of 64 per list)
+                    for (uint32_t p0 = 0; p0 < passes; p0 += 4u) {
+                        uint32_t cnt = 0;
+                        const uint32_t p1 = p0 + 4u < passes ? p0 + 4u : passes;
+                        for (uint32_t p = p0; p < p1; ++p) {  // the whole wave iterates together (ballot needs every lane)
+                            const uint32_t li = p * 64u + lane;
+                            const bool ok = li < n_lat && kept_at(li);
+                            const uint64_t bal = __ballot(ok);
+                            if (ok) mine[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(r_first + li * a.stride - r_begin);
+                            cnt += __popcll(bal);
+                        }
+                        emit_listed(cnt);
+                    }
+                    continue;
+                }
+                for (uint32_t done = r_begin; done < r_end; done += KEEP_ROUND) {
+                    const uint32_t n_round = r_end - done < KEEP_ROUND ? r_end - done : KEEP_ROUND;
+                    const uint32_t w = (n_round + 63u) / 64u;         // starts per lane: 1 .. KEEP_ROUND / 64
+                    const uint32_t s0 = done + lane * w;              // this lane's first start (tile-relative)
+                    uint64_t keep = 0;
+                    if (s0 < done + n_round) {
+                        const uint32_t bit = s0 + b0;
+                        const uint32_t Q = bit >> 6, sft = bit & 63u;
+                        uint64_t lo = ~funnel64(amb[Q], amb[Q + 1], sft), hi = ~funnel64(amb[Q + 1], amb[Q + 2], sft);
+                        uint32_t have = 1;
+                        while (have < k) {
+                            const uint32_t step = have < k - have ? have : k - have;   // 1..63
+                            lo &= (lo >> step) | ((hi << 1) << (63u - step));
+                            hi &= hi >> step;
+                            have += step;
+                        }
+                        const uint32_t valid = done + n_round - s0 < w ? done + n_round - s0 : w;  // starts of the slice that exist
+                        keep = lo & ((1ull << valid) - 1ull);         // w <= 16
+                    }
+                    const uint32_t c = (uint32_t)__popcll(keep);
+                    uint32_t incl = c;
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t y = __shfl_up(incl, d, 64);
+                        if ((int)lane >= d) incl += y;
+                    }
+                    const uint32_t cnt = __shfl(incl, 63, 64);
+                    uint32_t o = incl - c;
+                    while (keep) {
+                        mine[o++] = (uint16_t)(s0 - r_begin + (uint32_t)__builtin_ctzll(keep));
+                        keep &= keep - 1ull;
+                    }
+                    emit_listed(cnt);
                 }
             }
         }
