@@ -50,6 +50,7 @@ extern "C" {
 #define KMERS_E_NOMEM 4
 #define KMERS_E_UNSUPPORTED 5 /* geometry outside what the kernels cover (see kmers_supported) */
 #define KMERS_E_CAPACITY 6    /* kmers_unambiguous / kmers_batch: output capacity too small (res->n_out = needed) */
+#define KMERS_E_NCCL 7        /* an RCCL call failed (kmers_last_error has ncclGetErrorString) */
 
 /* flags */
 #define KMERS_MEM_HOST 0x0   /* sequence/output pointers are host memory (staged through HBM) */
@@ -89,7 +90,11 @@ int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out);
 void kmers_ctx_destroy(kmers_ctx *ctx);
 void *kmers_ctx_stream(kmers_ctx *ctx);
 const char *kmers_last_error(kmers_ctx *ctx);
-/* wait for KMERS_ASYNC work; reports the first EncodeError seen since the last sync */
+/* Wait for KMERS_ASYNC work; reports the first EncodeError seen since the last sync.  The kernels record the offending
+ * symbol itself next to its position (index_origin + position, 1-based) at fault time, so nothing is read back from a
+ * sequence here: if several asynchronous launches (shards of one sequence, or unrelated sequences) ran since the last
+ * sync, the error with the smallest reported position wins.  Sequence and output buffers of an asynchronous call must
+ * stay valid until the work has run (this call, or later work on the same stream, has completed). */
 int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 
 /* launch tunables (bench / tuning; 0 restores the default) */
@@ -222,7 +227,11 @@ typedef struct {
                               * (N in a read, say) does not fail the call; it is written as all-ones in every output
                               * array -- never a canonical kmer, and never a (kmer, reverse complement) pair -- so that
                               * the kept elements are those of UnambiguousKmers{A,K}(record) at the same indices (the
-                              * composition docs/src/faq.md:28-33 describes); element offsets stay those of the strict call */
+                              * composition docs/src/faq.md:28-33 describes); element offsets stay those of the strict call.
+                              * That equivalence holds for 2- and 4-bit pools.  An 8-bit (ASCII) pool is read through the kmer
+                              * alphabet's ascii_encode table, like FwKmers over a String: every byte outside it is marked --
+                              * including U for DNA kmers, T for RNA kmers and non-nucleotide bytes, which UnambiguousKmers
+                              * would keep as 3 / throw on (its ASCII_SKIPPING_LUT, src/iterators/common.jl:22-32) */
 #define KMERS_BATCH_FW 0
 #define KMERS_BATCH_CANONICAL 1
 int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int mode, int k,
@@ -273,6 +282,46 @@ typedef struct {
  * every shard a halo's worth of words are handled whole by shard 0 (the rest are empty). */
 int kmers_shard_plan(uint64_t n_bases, int k, uint64_t stride, int src_bits, int n_shards, int shard_id,
                      kmers_shard *out);
+
+/* ---- the communication of the sharded path, on RCCL -----------------
+ * The reference has no distributed code; what makes its iterators shardable is that iterate()
+ * carries nothing from one kmer to the next but the previous K-1 symbols (FwKmers.jl:57-66,
+ * CanonicalKmers.jl:94-105).  Three exchanges complete the semantics across shards, all on the
+ * context's stream through an ncclComm_t (RCCL: xGMI between the GPUs of a node):
+ *   kmers_halo_exchange          the first halo_words words of shard g+1 -> the end of shard g's words
+ *                                (grouped ncclSend / ncclRecv between neighbours, <= 32 B per pair)
+ *   kmers_first_error_allreduce  the reference throws at the FIRST offending symbol in sequence
+ *                                order (FwKmers.jl:112, CanonicalKmers.jl:139): ncclAllReduce(min)
+ *   kmers_offsets_allgather      UnambiguousKmers is SizeUnknown (UnambiguousKmers.jl:33): shard
+ *                                element counts -> this shard's offset in the global output
+ * `nccl_comm` is an ncclComm_t: one made by kmers_comm_create, or any communicator of the host
+ * program's own RCCL binding whose rank r runs shard r (one rank per GPU, rank order = shard order). */
+#define KMERS_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+/* ncclGetUniqueId: ONE rank calls it and the host program hands the bytes to the others over any
+ * channel it has (MPI, Distributed.jl, a torch.distributed store, a file). */
+int kmers_comm_id(void *out_id);
+/* ncclCommInitRank on the context's device; collective over the n_ranks callers. */
+int kmers_comm_create(kmers_ctx *ctx, const void *id, int n_ranks, int rank, void **out_nccl_comm);
+int kmers_comm_destroy(kmers_ctx *ctx, void *nccl_comm);
+int kmers_comm_rank(kmers_ctx *ctx, void *nccl_comm, int *out_rank, int *out_n_ranks);
+/* One grouped ncclSend + ncclRecv of 64-bit words on the context's stream (enqueue only; ordered
+ * with the context's kernels).  A peer < 0 or a zero count skips that half; peer == own rank is a
+ * device copy through RCCL.  The building block of kmers_halo_exchange. */
+int kmers_comm_sendrecv(kmers_ctx *ctx, void *nccl_comm, const uint64_t *send_dev, uint64_t send_words, int send_peer,
+                        uint64_t *recv_dev, uint64_t recv_words, int recv_peer);
+/* words_dev = this shard's buffer in HBM: n_own_words own words followed by room for halo_words.
+ * Sends words_dev[0, send_words) to rank - 1 and receives words_dev[n_own_words, +halo_words) from
+ * rank + 1 (shard = kmers_shard_plan(..., n_ranks, rank)).  Enqueue only: the next kernel of this
+ * context sees the halo.  Every rank of the communicator must call it (ranks with nothing to send
+ * or receive enqueue nothing). */
+int kmers_halo_exchange(kmers_ctx *ctx, void *nccl_comm, const kmers_shard *shard, uint64_t *words_dev);
+/* In: this shard's result (status KMERS_OK or KMERS_E_ENCODE with GLOBAL err_pos, i.e. the shard ran
+ * with index_origin = shard.first_base).  Out, identical on every rank: the first EncodeError of the
+ * whole sequence (smallest err_pos) or KMERS_OK.  n_out is left alone.  Synchronous. */
+int kmers_first_error_allreduce(kmers_ctx *ctx, void *nccl_comm, kmers_result *res);
+/* Exclusive scan of the shards' element counts: *out_offset = elements of shards 0..rank-1,
+ * *out_total = elements of all shards.  Synchronous. */
+int kmers_offsets_allgather(kmers_ctx *ctx, void *nccl_comm, uint64_t n_local, uint64_t *out_offset, uint64_t *out_total);
 
 /* ---- synthetic input (bench / tests) -------------------------- */
 /* Fills out_dev (DEVICE memory) with words [first_word, first_word + n_words) of the

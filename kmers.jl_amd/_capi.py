@@ -9,7 +9,8 @@ import os
 
 from . import build as _build
 
-OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY = range(7)
+OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY, E_NCCL = range(8)
+COMM_ID_BYTES = 128
 MEM_HOST, MEM_DEVICE, ASYNC, OUT_TUPLES = 0, 1, 2, 4
 BATCH_FW, BATCH_CANONICAL = 0, 1
 ITER_FW, ITER_CANONICAL, ITER_SPACED, ITER_UNAMBIGUOUS = 0, 1, 2, 3
@@ -21,7 +22,7 @@ PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY, PARA
 
 STATUS_NAMES = {OK: "KMERS_OK", E_ENCODE: "KMERS_E_ENCODE", E_BADARG: "KMERS_E_BADARG",
                 E_HIP: "KMERS_E_HIP", E_NOMEM: "KMERS_E_NOMEM",
-                E_UNSUPPORTED: "KMERS_E_UNSUPPORTED", E_CAPACITY: "KMERS_E_CAPACITY"}
+                E_UNSUPPORTED: "KMERS_E_UNSUPPORTED", E_CAPACITY: "KMERS_E_CAPACITY", E_NCCL: "KMERS_E_NCCL"}
 
 
 class Result(C.Structure):
@@ -31,6 +32,12 @@ class Result(C.Structure):
 
 class Span(C.Structure):
     _fields_ = [("first_base", C.c_uint64), ("n_bases", C.c_uint64)]
+
+
+class ShardPlan(C.Structure):
+    """kmers_shard of include/kmers_hip.h"""
+    _fields_ = [("first_kmer", C.c_uint64), ("n_kmers", C.c_uint64), ("first_base", C.c_uint64), ("n_bases", C.c_uint64),
+                ("first_word", C.c_uint64), ("n_own_words", C.c_uint64), ("halo_words", C.c_uint32), ("send_words", C.c_uint32)]
 
 
 class Seq(C.Structure):
@@ -72,6 +79,14 @@ SYMBOLS = {
     "kmers_batch_spaced": (C.c_int, [_P, _S, _P, C.c_uint64, C.c_int, C.c_uint64, C.c_int, _P, _P, C.c_uint64, C.c_int, _R]),
     "kmers_minhash_batch": (C.c_int, [_P, _S, _P, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, C.c_int, _R]),
     "kmers_shard_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
+    "kmers_comm_id": (C.c_int, [_P]),
+    "kmers_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "kmers_comm_destroy": (C.c_int, [_P, _P]),
+    "kmers_comm_rank": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "kmers_comm_sendrecv": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_int, _P, C.c_uint64, C.c_int]),
+    "kmers_halo_exchange": (C.c_int, [_P, _P, C.POINTER(ShardPlan), _P]),
+    "kmers_first_error_allreduce": (C.c_int, [_P, _P, _R]),
+    "kmers_offsets_allgather": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kmers_synth_dna": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _P]),
 }
 

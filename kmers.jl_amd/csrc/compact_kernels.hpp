@@ -91,7 +91,7 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const CompactArgs
                 }
                 reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)codes;
                 reinterpret_cast<uint8_t *>(amb)[wi] = (uint8_t)flags;
-                if (f) report_bad_symbols<8, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, w0 + wi, f);
+                if (f) report_bad_symbols<8, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, w0 + wi, f, x, a.index_origin);
             } else if constexpr (SRC_BITS == 4) {
                 uint64_t bad;
                 uint32_t c = pack_4to2(x, bad);
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(BLOCK) void unambiguous_count_kernel(const CompactA
                     f |= (uint64_t)(v == 0xffu ? 1u : 0u) << (8 * j);
                 }
                 reinterpret_cast<uint8_t *>(amb)[wi] = (uint8_t)flags;
-                if (f) report_bad_symbols<8, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, w0 + wi, f);
+                if (f) report_bad_symbols<8, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, w0 + wi, f, x, a.index_origin);
             } else if constexpr (SRC_BITS == 4) {
                 uint64_t bad;
                 (void)pack_4to2(x, bad);

@@ -40,6 +40,7 @@ struct CompositionArgs {
     uint64_t n_tiles;
     uint32_t *counts;              // 4^K global counters (zeroed by the host)
     unsigned long long *err_slot;
+    uint64_t err_origin;           // added to reported positions (kmers_seq.index_origin)
     uint32_t ascii_table;
     uint32_t k;
     uint32_t pass;                 // upper bits of the indices this launch counts (0 when 4^K <= 65536)
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(CBLOCK) void composition_kernel(const CompositionAr
             if (wi < g.nw) {
                 const uint64_t f = stage_word<SRC_BITS, 2>(lds, wi, pre[i], lut);
                 if constexpr (SRC_BITS != 2) {
-                    if (f) report_bad_symbols<SRC_BITS, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, g.w0 + wi, f);
+                    if (f) report_bad_symbols<SRC_BITS, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, g.w0 + wi, f, pre[i], a.err_origin);
                 }
             }
         }

@@ -1,0 +1,65 @@
+// context.hpp -- the context behind the C ABI's opaque kmers_ctx, and the error helpers shared by the
+// translation units of libkmers_hip.so (kmers_api.hip: iterators and consumers; comm_api.hip: RCCL).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/kmers_hip.h"
+
+struct kmers_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t *d_scratch = nullptr;        // 64 words of device scratch; word 0: reduction result, word 1: the error slot
+    unsigned long long *d_err = nullptr;  // = d_scratch + 1: first offending symbol (0-based), ~0 = none
+    uint64_t *h_result = nullptr;         // pinned host mirror of scratch words 0..1: one small D2H copy per call
+    char *h_bounce = nullptr;             // pinned bounce buffer for short host-pointer calls (FASTA-record sized):
+                                          // [0, BOUNCE_IN) source words, [BOUNCE_IN, BOUNCE_IN + BOUNCE_OUT) outputs
+    uint64_t *d_recent = nullptr;         // MinHash: table of recently appended candidate hashes (RECENT_SLOTS entries)
+    void *stage[8] = {};      // 0 source, 1-2 outputs, 3 metadata / scratch, 4-5 recoded stream / flags, 6 tile index, 7 RCCL scratch
+    size_t stage_cap[8] = {};
+    std::string last_error;
+    int64_t tile_kmers = 0;  // 0 = default
+    int64_t max_grid = 0;    // 0 = default
+    int64_t stamps_ptr = 0;  // diagnostic builds only (KMERS_PARAM_STAMPS_PTR)
+    int n_cus = 256;                // multiProcessorCount
+    bool sketch_host_only = false;  // KMERS_PARAM_SKETCH_HOST_ONLY: force the host-feedback MinHash path (tests)
+    int64_t batch_passes = 0;       // KMERS_PARAM_BATCH_PASSES (tests, tuning); 0 = default
+    int64_t sketch_batch_lds = 0;   // KMERS_PARAM_SKETCH_BATCH_LDS (tuning); 0 = default
+};
+
+namespace kmers {
+
+inline int fail(kmers_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        ctx->last_error = what;
+        if (e != hipSuccess) {
+            ctx->last_error += ": ";
+            ctx->last_error += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                             \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) return fail(ctx, KMERS_E_HIP, #call, e_); \
+    } while (0)
+
+// grow-only device staging buffers owned by the context
+inline int ensure_stage(kmers_ctx *ctx, int slot, size_t bytes) {
+    if (bytes <= ctx->stage_cap[slot]) return KMERS_OK;
+    if (ctx->stage[slot]) (void)hipFree(ctx->stage[slot]);
+    ctx->stage[slot] = nullptr;
+    ctx->stage_cap[slot] = 0;
+    size_t cap = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&ctx->stage[slot], cap);
+    if (e != hipSuccess) return fail(ctx, KMERS_E_NOMEM, "hipMalloc(staging)", e);
+    ctx->stage_cap[slot] = cap;
+    return KMERS_OK;
+}
+
+}  // namespace kmers

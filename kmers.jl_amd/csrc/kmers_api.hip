@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ascii_tables.hpp"
+#include "context.hpp"
 #include "batch_kernels.hpp"
 #include "compact_kernels.hpp"
 #include "composition_kernel.hpp"
@@ -24,68 +25,12 @@
 
 using namespace kmers;
 
-struct kmers_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    uint64_t *d_scratch = nullptr;        // 64 words of device scratch; word 0: reduction result, word 1: the error slot
-    unsigned long long *d_err = nullptr;  // = d_scratch + 1: first offending symbol (0-based), ~0 = none
-    uint64_t *h_result = nullptr;         // pinned host mirror of scratch words 0..1: one small D2H copy per call
-    char *h_bounce = nullptr;             // pinned bounce buffer for short host-pointer calls (FASTA-record sized):
-                                          // [0, BOUNCE_IN) source words, [BOUNCE_IN, BOUNCE_IN + BOUNCE_OUT) outputs
-    uint64_t *d_recent = nullptr;         // MinHash: table of recently appended candidate hashes (RECENT_SLOTS entries)
-    void *stage[8] = {};      // 0 source, 1-2 outputs, 3 metadata / scratch, 4-5 recoded stream / flags, 6 tile index
-    size_t stage_cap[8] = {};
-    std::string last_error;
-    // what the most recent launch read, for decoding an EncodeError at sync time
-    const uint64_t *err_words = nullptr;  // DEVICE pointer of the staged / resident words
-    uint64_t err_first_bit = 0;
-    uint64_t err_origin = 0;
-    int err_bits = 0;
-    int64_t tile_kmers = 0;  // 0 = default
-    int64_t max_grid = 0;    // 0 = default
-    int64_t stamps_ptr = 0;  // diagnostic builds only (KMERS_PARAM_STAMPS_PTR)
-    int n_cus = 256;                // multiProcessorCount
-    bool sketch_host_only = false;  // KMERS_PARAM_SKETCH_HOST_ONLY: force the host-feedback MinHash path (tests)
-    int64_t batch_passes = 0;       // KMERS_PARAM_BATCH_PASSES (tests, tuning); 0 = default
-    int64_t sketch_batch_lds = 0;   // KMERS_PARAM_SKETCH_BATCH_LDS (tuning); 0 = default
-};
-
 namespace {
 
 // Pageable host memory costs HIP about 10-15 us per small copy (internal staging + waits); a call on a
 // short sequence with host pointers makes three of them.  Copies that fit go through pinned memory instead.
 constexpr size_t BOUNCE_IN = 256 << 10, BOUNCE_OUT = 1 << 20;
 constexpr int INTERNAL_OUT_DEVICE = 1 << 16;  // batch_impl: out_a / out_b are device pointers even if the pool is host memory
-
-int fail(kmers_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
-    if (ctx) {
-        ctx->last_error = what;
-        if (e != hipSuccess) {
-            ctx->last_error += ": ";
-            ctx->last_error += hipGetErrorString(e);
-        }
-    }
-    return code;
-}
-
-#define HIP_TRY(ctx, call)                                             \
-    do {                                                               \
-        hipError_t e_ = (call);                                        \
-        if (e_ != hipSuccess) return fail(ctx, KMERS_E_HIP, #call, e_); \
-    } while (0)
-
-int ensure_stage(kmers_ctx *ctx, int slot, size_t bytes) {
-    if (bytes <= ctx->stage_cap[slot]) return KMERS_OK;
-    if (ctx->stage[slot]) (void)hipFree(ctx->stage[slot]);
-    ctx->stage[slot] = nullptr;
-    ctx->stage_cap[slot] = 0;
-    size_t cap = bytes + bytes / 8 + 4096;
-    hipError_t e = hipMalloc(&ctx->stage[slot], cap);
-    if (e != hipSuccess) return fail(ctx, KMERS_E_NOMEM, "hipMalloc(staging)", e);
-    ctx->stage_cap[slot] = cap;
-    return KMERS_OK;
-}
 
 void clear(kmers_result *res) {
     if (res) std::memset(res, 0, sizeof *res);
@@ -165,16 +110,15 @@ int collect(kmers_ctx *ctx, kmers_result *res, uint64_t n_out, uint64_t *value_o
         }
         return KMERS_OK;
     }
-    // EncodeError: fetch the raw encoding of the offending symbol, re-arm the slot
-    uint64_t bit = ctx->err_first_bit + (uint64_t)pos * (uint64_t)ctx->err_bits;
-    uint64_t word = 0;
-    HIP_TRY(ctx, hipMemcpy(&word, ctx->err_words + (bit >> 6), 8, hipMemcpyDeviceToHost));
+    // EncodeError: the slot holds error_key = (global 0-based position << 8) | raw symbol, written by the kernel at fault
+    // time (stream_kernel.hpp); nothing is read back from the sequence, which the caller of an asynchronous launch may
+    // already have released.  Re-arm the slot.
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (res) {
         res->status = KMERS_E_ENCODE;
-        res->err_pos = (uint64_t)pos + 1 + ctx->err_origin;
-        res->err_enc = (uint32_t)((word >> (bit & 63u)) & ((1ull << ctx->err_bits) - 1ull));
+        res->err_pos = (uint64_t)(pos >> 8) + 1;
+        res->err_enc = (uint32_t)(pos & 0xffull);
         res->n_out = 0;
     }
     ctx->last_error = "EncodeError: symbol cannot be encoded in the kmer alphabet";
@@ -183,13 +127,6 @@ int collect(kmers_ctx *ctx, kmers_result *res, uint64_t n_out, uint64_t *value_o
 
 // table id of ascii_entry(): BioSequences.ascii_encode of the kmer alphabet (ascii_tables.hpp)
 uint32_t ascii_table(kmers_ctx *, int dst_bits, bool rna) { return (dst_bits == 4 ? 2u : 0u) + (rna ? 1u : 0u); }
-
-void remember_source(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st) {
-    ctx->err_words = st.d_words;
-    ctx->err_first_bit = st.first_bit;
-    ctx->err_origin = seq->index_origin;
-    ctx->err_bits = seq->src_bits;
-}
 
 // Default tile: about 16 KiB of output per workgroup (four 16-byte stores per lane), one tile
 // per workgroup.  Measured on MI355X (profiles/r01_tuning.md): shorter workgroups are bound by
@@ -289,7 +226,6 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     }
     Staged st;
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
-    remember_source(ctx, seq, st);
 
     const bool dev = flags & KMERS_MEM_DEVICE;
     const bool tuples = (flags & KMERS_OUT_TUPLES) != 0;
@@ -318,6 +254,7 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     a.out_b = d_b;
     a.seed = seed;
     a.err_slot = ctx->d_err;
+    a.err_origin = seq->index_origin;
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
     a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet != 0);
@@ -375,6 +312,7 @@ int emit_all_kept(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k,
     a.out_starts = d_s;
     a.start_origin = seq->index_origin;
     a.err_slot = ctx->d_err;
+    a.err_origin = seq->index_origin;
     a.k = (uint32_t)k;
     a.stride = 1;
     a.ascii_table = ascii_table(ctx, 2, seq->alphabet != 0);
@@ -398,7 +336,6 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     }
     Staged st;
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
-    remember_source(ctx, seq, st);
     const bool dev = flags & KMERS_MEM_DEVICE;
 
     CompactArgs a{};
@@ -488,8 +425,10 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         if (out_kmers) { if (int rc = ensure_stage(ctx, 1, kb)) return rc; d_k = (uint64_t *)ctx->stage[1]; }
         if (out_starts) { if (int rc = ensure_stage(ctx, 2, sb)) return rc; d_s = (long long *)ctx->stage[2]; }
     }
-    if (total == n && stride == 1 && !tuples && !validate_only) {
-        // nothing was dropped: FwKmers + start indices at the stream kernel's rate
+    if (total == n && stride == 1 && !tuples && !validate_only && !ascii) {
+        // nothing was dropped: FwKmers + start indices at the stream kernel's rate.  (Not for byte sources: this iterator
+        // reads them through ASCII_SKIPPING_LUT, where T and U both mean 3 whatever the kmer alphabet
+        // (src/iterators/common.jl:22-32), while the stream kernel would apply the alphabet's ascii_encode table.)
         if (int rc = emit_all_kept(ctx, seq, st, k, n, d_k, d_s)) return rc;
         if (!dev) {
             if (out_kmers) HIP_TRY(ctx, hipMemcpyAsync(out_kmers, d_k, kb, hipMemcpyDeviceToHost, ctx->stream));
@@ -536,6 +475,7 @@ int launch_fused(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, 
     a.n_kmers = kmers_count(seq->n_bases, k, 1);
     a.inspect_end = seq->n_bases;
     a.err_slot = ctx->d_err;
+    a.err_origin = seq->index_origin;
     a.k = (uint32_t)k;
     a.stride = 1;
     a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet != 0);
@@ -557,6 +497,7 @@ int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int 
     a.n_kmers = kmers_count(seq->n_bases, k, 1);
     a.inspect_end = seq->n_bases;
     a.err_slot = ctx->d_err;
+    a.err_origin = seq->index_origin;
     a.k = (uint32_t)k;
     a.stride = 1;
     a.ascii_table = ascii_table(ctx, 2, seq->alphabet != 0);
@@ -770,7 +711,6 @@ int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, 
     if (n == 0) return KMERS_OK;
     Staged st;
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
-    remember_source(ctx, seq, st);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
     StreamArgs a{};
     a.out_a = ctx->d_scratch;
@@ -800,7 +740,6 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
         if (n == 0) return KMERS_OK;
         Staged st;
         if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
-        remember_source(ctx, seq, st);
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
         StreamArgs a{};
         a.src = st.d_words;
@@ -810,6 +749,7 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
         a.inspect_end = (n - 1) * (uint64_t)stride + (uint64_t)k;
         a.out_a = ctx->d_scratch;
         a.err_slot = ctx->d_err;
+        a.err_origin = seq->index_origin;
         a.k = (uint32_t)k;
         a.stride = (uint32_t)stride;
         a.xor_canonical = 0;
@@ -834,7 +774,6 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
     }
     Staged st;
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
-    remember_source(ctx, seq, st);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
     CompactArgs a{};
     a.src = st.d_words;
@@ -879,7 +818,6 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
     if (n == 0) return KMERS_OK;
     Staged st;
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
-    remember_source(ctx, seq, st);
 
     constexpr uint32_t RECENT_SLOTS = 1u << 16;
     if (!ctx->d_recent) {
@@ -918,6 +856,7 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
             Staged vst = st;
             vst.first_bit = st.first_bit + done * (uint64_t)seq->src_bits;
             view.n_bases = m + (uint64_t)k - 1;
+            view.index_origin = seq->index_origin + done;
             StreamArgs a{};
             a.out_a = d_cand;
             a.out_b = d_state + 3;
@@ -1054,8 +993,7 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
         vst.first_bit = st.first_bit + done * (uint64_t)seq->src_bits;
         view.n_bases = m + (uint64_t)k - 1;
         HIP_TRY(ctx, hipMemsetAsync(d_counter, 0, 8, ctx->stream));
-        ctx->err_first_bit = vst.first_bit;  // error positions of this launch are relative to the chunk
-        ctx->err_origin = seq->index_origin + done;
+        view.index_origin = seq->index_origin + done;  // error positions of this launch are relative to the chunk
         StreamArgs a{};
         a.out_a = d_cand;
         a.out_b = d_counter;
@@ -1110,7 +1048,6 @@ int kmers_minimizers(kmers_ctx *ctx, const kmers_seq *seq, int k, int w, int str
     if ((uint64_t)stride * (uint64_t)dst_bits > 64 * 8) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minimizers supports window strides up to 512 / dst_bits symbols");
     Staged st;
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
-    remember_source(ctx, seq, st);
     const bool dev = flags & KMERS_MEM_DEVICE;
     uint64_t *d_out = out_kmers;
     const size_t bytes = (size_t)n * nw * 8;
@@ -1127,6 +1064,7 @@ int kmers_minimizers(kmers_ctx *ctx, const kmers_seq *seq, int k, int w, int str
     a.inspect_end = (n - 1) * (uint64_t)stride + span;  // every symbol of every window is read
     a.out_a = d_out;
     a.err_slot = ctx->d_err;
+    a.err_origin = seq->index_origin;
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
     a.window_kmers = (uint32_t)w;
@@ -1163,7 +1101,6 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
     if (n) {
         Staged st;
         if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
-        remember_source(ctx, seq, st);
         if (k <= 10) {
             // private 16-bit histograms in LDS, 65 536 bins per pass (composition_kernel.hpp):
             // 0.4-0.6 ms per Gbase up to K = 8, 0.75 ms per pass beyond (K = 9: 4 passes, K = 10: 16)
@@ -1175,6 +1112,7 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
             a.n_tiles = (n + CTILE - 1) / CTILE;
             a.counts = d_counts;
             a.err_slot = ctx->d_err;
+            a.err_origin = seq->index_origin;
             a.ascii_table = ascii_table(ctx, 2, seq->alphabet != 0);
             a.k = (uint32_t)k;
             a.hist_words = (uint32_t)std::min<size_t>(bins, (size_t)1 << CBINS_LOG2) / 2;

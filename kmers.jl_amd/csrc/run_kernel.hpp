@@ -129,7 +129,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
             if (wi < g.nw) {
                 const uint64_t f = stage_word<SRC_BITS, 2>(lds, wi, pre[i], lut);
                 if constexpr (SRC_BITS != 2) {
-                    if (f) report_bad_symbols<SRC_BITS, true>(a.err_slot, a.first_bit, a.inspect_end, 1u, k, g.w0 + wi, f);
+                    if (f) report_bad_symbols<SRC_BITS, true>(a.err_slot, a.first_bit, a.inspect_end, 1u, k, g.w0 + wi, f, pre[i], a.err_origin);
                 }
             }
         }

@@ -36,7 +36,8 @@ struct StreamArgs {
     uint64_t *out_a;         // FW: forward kmers   CANON: canonical kmers (nullable)  XOR: accumulator
     uint64_t *out_b;         // FW: reverse complements (nullable)   CANON: hashes (nullable)
     uint64_t seed;           // fx_hash seed
-    unsigned long long *err_slot;  // atomicMin of the first offending symbol (0-based)
+    unsigned long long *err_slot;  // atomicMin of error_key(first offending symbol): position (0-based + err_origin) << 8 | raw symbol
+    uint64_t err_origin;           // kmers_seq.index_origin (+ the chunk offset of chunked launches)
     uint64_t n_tiles;
     uint32_t k;
     uint32_t stride;
@@ -68,10 +69,15 @@ struct StreamArgs {
 // Inspected set = what the reference's iterate() would have looked at before stopping: every
 // symbol below inspect_end, except (stride >= K) the gaps between kmers
 // (src/iterators/SpacedKmers.jl:133-134).
+// The slot receives error_key = (global 0-based position << 8) | raw source encoding, so that the host can build the
+// reference's EncodeError (construction.jl:108-110) from the slot alone: nothing is re-read from the sequence after the
+// launch (the caller may have freed it; several asynchronous launches may share one slot -- the smallest position wins).
+__device__ __forceinline__ unsigned long long error_key(uint64_t pos, uint64_t enc) { return (pos << 8) | (enc & 0xffull); }
+
 template <int SRC_BITS, bool STRIDE1>
 __device__ __forceinline__ void report_bad_symbols(unsigned long long *err_slot, uint64_t first_bit,
                                                    uint64_t inspect_end, uint32_t stride, uint32_t k,
-                                                   uint64_t word_index, uint64_t f) {
+                                                   uint64_t word_index, uint64_t f, uint64_t x, uint64_t origin) {
     constexpr int PER = 64 / SRC_BITS;
     // symbol index of symbol 0 of this word; negative inside the first word of an offset view
     // (both terms are multiples of SRC_BITS, so the division is exact)
@@ -87,7 +93,10 @@ __device__ __forceinline__ void report_bad_symbols(unsigned long long *err_slot,
                 if (((f >> (SRC_BITS * j)) & 1ull) && ((uint64_t)(base0 + j) % stride) >= k) f &= ~(1ull << (SRC_BITS * j));
         }
     }
-    if (f) atomicMin(err_slot, (unsigned long long)(base0 + (long long)(__ffsll((long long)f) - 1) / SRC_BITS));
+    if (f) {
+        const uint32_t j = (uint32_t)(__ffsll((long long)f) - 1) / SRC_BITS;  // first offending symbol of the word
+        atomicMin(err_slot, error_key((uint64_t)(base0 + (long long)j) + origin, (x >> (SRC_BITS * j)) & ((1ull << SRC_BITS) - 1ull)));
+    }
 }
 
 // 4-bit source: flags of the symbols with count_ones != 1, from pack_4to2's `bad`
@@ -303,10 +312,11 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
         block_sync();  // previous tile's readers are done with the LDS stream
         // ---- phase 1: source words -> DST-bit stream in LDS ------------------------------
         for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
-            uint64_t f = stage_word<SRC_BITS, DST>(lds, wi, a.src[w0 + wi], lut);
+            const uint64_t x = a.src[w0 + wi];
+            uint64_t f = stage_word<SRC_BITS, DST>(lds, wi, x, lut);
             if constexpr ((SRC_BITS == 4 && DST == 2) || SRC_BITS == 8) {
                 // `span` symbols per element are read (K, or K + W - 1 for minimizer windows): gaps start after them
-                if (f) report_bad_symbols<SRC_BITS, STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, span, w0 + wi, f);
+                if (f) report_bad_symbols<SRC_BITS, STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, span, w0 + wi, f, x, a.err_origin);
             }
         }
 #ifdef KMERS_STAMPS
@@ -480,12 +490,12 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(const StreamArgs a) {
         if constexpr (SRC_BITS == 8) {
             code = ascii_entry(a.ascii_table, (uint32_t)enc);
             if (code & 0x80u) {
-                atomicMin(a.err_slot, (unsigned long long)(base + t));
+                atomicMin(a.err_slot, error_key(base + t + a.err_origin, enc));
                 return;
             }
         } else if constexpr (SRC_BITS == 4 && DST == 2) {
             if (__popcll(enc) != 1) {
-                atomicMin(a.err_slot, (unsigned long long)(base + t));
+                atomicMin(a.err_slot, error_key(base + t + a.err_origin, enc));
                 return;
             }
             code = (uint64_t)(__ffsll((long long)enc) - 1);

@@ -1,6 +1,9 @@
 """Contiguous sharding of one long LongSequence over the GPUs of a node, with the (K-1)-base
-halo exchanged between neighbours over torch.distributed (backend "nccl" = RCCL over xGMI on
-the GPU box, "gloo" in the CPU tests).
+halo exchanged between neighbours: on the GPU box through the C ABI's RCCL entry points
+(`NativeComm`: kmers_halo_exchange / kmers_first_error_allreduce / kmers_offsets_allgather on the
+context's stream, xGMI between the GPUs of a node; torch.distributed only carries the 128-byte
+ncclUniqueId), and over torch.distributed itself ("gloo") in the CPU tests, which exercise the same
+plan and the same semantics without a GPU (`HaloExchanger`, `first_error`, `output_offsets`).
 
 The reference has no distributed code; kmer i depends only on symbols
 [i, i+K), so shard g owns a contiguous range of kmer START positions whose first symbol sits on a
@@ -89,10 +92,17 @@ class HaloExchanger:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.transport = transport or os.environ.get("KMERS_HALO_TRANSPORT", "allgather")
+        if self.transport not in ("allgather", "p2p"):
+            raise ValueError(f"unknown halo transport {self.transport!r} (allgather, p2p; RCCL behind the C ABI: shard.NativeComm)")
         self.width = max([s.halo_words for s in plan] + [1])
+        # gloo moves host memory: a buffer in HBM (ranks sharing one device while debugging) is staged through the host
+        self.via_host = bool(self.world > 1 and buf.is_cuda and dist.get_backend(group) == "gloo")
+        wdev = "cpu" if self.via_host else buf.device
+        if self.world > 1:
+            self.send = torch.zeros(self.width, dtype=buf.dtype, device=wdev)
+            self.recv = torch.zeros(self.width, dtype=buf.dtype, device=wdev)
         if self.world > 1 and self.transport == "allgather":
-            self.send = torch.zeros(self.width, dtype=buf.dtype, device=buf.device)
-            self.pieces = [torch.zeros(self.width, dtype=buf.dtype, device=buf.device) for _ in range(self.world)]
+            self.pieces = [torch.zeros(self.width, dtype=buf.dtype, device=wdev) for _ in range(self.world)]
 
     def exchange(self):
         if self.world == 1:
@@ -101,13 +111,15 @@ class HaloExchanger:
         if self.transport == "p2p":
             ops = []
             if sh.send_words and self.rank > 0:
-                ops.append(dist.P2POp(dist.isend, buf[:sh.send_words], self.rank - 1, self.group))
+                self.send[:sh.send_words].copy_(buf[:sh.send_words])
+                ops.append(dist.P2POp(dist.isend, self.send[:sh.send_words], self.rank - 1, self.group))
             if sh.halo_words and self.rank < self.world - 1:
-                ops.append(dist.P2POp(dist.irecv, buf[sh.n_own_words:sh.n_own_words + sh.halo_words],
-                                      self.rank + 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, self.recv[:sh.halo_words], self.rank + 1, self.group))
             if ops:
                 for r in dist.batch_isend_irecv(ops):
                     r.wait()
+            if sh.halo_words and self.rank < self.world - 1:
+                buf[sh.n_own_words:sh.n_own_words + sh.halo_words].copy_(self.recv[:sh.halo_words])
             return
         n = min(self.width, sh.n_own_words)
         if n:
@@ -153,3 +165,85 @@ def output_offsets(n_local, group=None, device="cpu"):
     dist.all_gather(counts, torch.tensor([int(n_local)], dtype=torch.int64, device=device), group=group)
     counts = [int(c.item()) for c in counts]
     return sum(counts[:rank]), sum(counts)
+
+
+class NativeComm:
+    """The RCCL communicator of the C ABI (include/kmers_hip.h, "the communication of the sharded path").
+    rank r of the communicator runs shard r.  `bootstrap(ctx)` makes one over the ranks of an initialised
+    torch.distributed group of ANY backend: rank 0 asks RCCL for an ncclUniqueId and the 128 bytes travel
+    over the group's store -- torch moves no sequence data."""
+
+    def __init__(self, ctx, handle, rank, n_ranks):
+        self.ctx, self.handle, self.rank, self.n_ranks = ctx, handle, rank, n_ranks
+
+    @classmethod
+    def create(cls, ctx, id_bytes, n_ranks, rank):
+        import ctypes as C
+
+        from . import _capi as cap
+        if len(id_bytes) != cap.COMM_ID_BYTES:
+            raise ValueError("an ncclUniqueId has 128 bytes")
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(id_bytes), cap.COMM_ID_BYTES)
+        ctx.check(ctx.lib.kmers_comm_create(ctx.handle, buf, n_ranks, rank, C.byref(h)), "kmers_comm_create")
+        return cls(ctx, h, rank, n_ranks)
+
+    @staticmethod
+    def new_id(lib):
+        import ctypes as C
+
+        from . import _capi as cap
+        buf = C.create_string_buffer(cap.COMM_ID_BYTES)
+        rc = lib.kmers_comm_id(buf)
+        if rc != 0:
+            raise RuntimeError(f"kmers_comm_id failed with {cap.STATUS_NAMES.get(rc, rc)}")
+        return bytes(buf.raw)
+
+    @classmethod
+    def bootstrap(cls, ctx, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return cls.create(ctx, cls.new_id(ctx.lib), 1, 0)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_id(ctx.lib) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls.create(ctx, box[0], world, rank)
+
+    def _shard_struct(self, shard):
+        from . import _capi as cap
+        return cap.ShardPlan(shard.first_kmer, shard.n_kmers, shard.first_base, shard.n_bases, shard.first_word,
+                             shard.n_own_words, shard.halo_words, shard.send_words)
+
+    def halo_exchange(self, shard, words_ptr):
+        """Enqueue the neighbour step on the context's stream (kmers_halo_exchange)."""
+        import ctypes as C
+        cs = shard if not isinstance(shard, Shard) else self._shard_struct(shard)
+        self.ctx.check(self.ctx.lib.kmers_halo_exchange(self.ctx.handle, self.handle, C.byref(cs), words_ptr), "kmers_halo_exchange")
+
+    def sendrecv(self, send_ptr, send_words, send_peer, recv_ptr, recv_words, recv_peer):
+        self.ctx.check(self.ctx.lib.kmers_comm_sendrecv(self.ctx.handle, self.handle, send_ptr, send_words, send_peer,
+                                                        recv_ptr, recv_words, recv_peer), "kmers_comm_sendrecv")
+
+    def first_error(self, status, err_pos=0, err_enc=0):
+        """kmers_first_error_allreduce: (status, err_pos, err_enc) of the first EncodeError over all shards."""
+        import ctypes as C
+
+        from . import _capi as cap
+        res = cap.Result(int(status), int(err_enc), int(err_pos), 0)
+        rc = self.ctx.lib.kmers_first_error_allreduce(self.ctx.handle, self.handle, C.byref(res))
+        if rc not in (cap.OK, cap.E_ENCODE):
+            self.ctx.check(rc, "kmers_first_error_allreduce")
+        return int(res.status), int(res.err_pos), int(res.err_enc)
+
+    def output_offsets(self, n_local):
+        """kmers_offsets_allgather: (offset of this shard's elements in the global output, total)."""
+        import ctypes as C
+        off, tot = C.c_uint64(), C.c_uint64()
+        self.ctx.check(self.ctx.lib.kmers_offsets_allgather(self.ctx.handle, self.handle, int(n_local), C.byref(off), C.byref(tot)),
+                       "kmers_offsets_allgather")
+        return int(off.value), int(tot.value)
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.kmers_comm_destroy(self.ctx.handle, self.handle)
+            self.handle = None

@@ -259,6 +259,34 @@ def test_ascii_unambiguous(km, ctx, orc):
             assert np.array_equal(kmers[:n], ek) and np.array_equal(starts[:n], es)
 
 
+def test_ascii_unambiguous_clean_text_of_the_other_alphabet(km, ctx, orc):
+    """UnambiguousKmers reads bytes through ASCII_SKIPPING_LUT, in which T and U are the same symbol for DNA and RNA kmers
+    alike (src/iterators/common.jl:22-32): UnambiguousDNAMers over clean "ACGU" text and UnambiguousRNAMers over clean
+    "ACGT" text keep EVERY window (the all-kept case), and leave no error behind for the next call on the context."""
+    rng = np.random.default_rng(91)
+    cap = km._capi
+    for alphabet, letters in ((0, "ACGU"), (1, "ACGT"), (0, "acgu"), (1, "ACGTacgtUu")):
+        for K in (4, 31, 33):
+            for L in (K, 5000, 70001):
+                text = "".join(letters[i] for i in rng.integers(0, len(letters), L))
+                seq, keep = ascii_seq(km, text, L, alphabet=alphabet)
+                res = cap.Result()
+                assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, None, None, 0, 0, C.byref(res)) == 0
+                n = int(res.n_out)
+                assert n == L - K + 1
+                N = (2 * K + 63) // 64
+                kmers = np.zeros((n, N), np.uint64)
+                starts = np.zeros(n, np.int64)
+                assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, vp(kmers), vp(starts), n, 0, C.byref(res)) == 0
+                ek, es, _ = orc.unambiguous(keep, L, 8, K)
+                assert np.array_equal(kmers, ek) and np.array_equal(starts, es), (alphabet, letters, K, L)
+                # the context's error slot must still be clean: a strict call on valid input succeeds
+                ok_text = "ACGT" * 20
+                seq2, keep2 = ascii_seq(km, ok_text, len(ok_text), alphabet=0)
+                out = np.zeros((len(ok_text) - 3, 1), np.uint64)
+                assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq2), 4, 2, vp(out), None, 0, C.byref(res)) == 0, (res.status, res.err_pos)
+
+
 def test_offset_views(km, ctx, orc):
     """first_base != 0 (LongSubSeq / halo shards): same result as the oracle on the re-packed view."""
     cap = km._capi
