@@ -18,12 +18,16 @@ def test_bench_refuses_to_run_without_a_gpu():
                        timeout=300)
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
     assert r.stdout.strip() == ""   # no JSON line is printed for a run that measured nothing
+    # the N-rank launcher refuses in the parent, before it starts anything
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout) and r.stdout.strip() == ""
 
 
 @pytest.mark.gpu
 def test_bench_json_line_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--bases", "4000000",
-                        "--no-other-configs", "--cpu-budget", "0.3"], capture_output=True, text=True, timeout=600)
+                        "--no-other-configs", "--no-pmc", "--cpu-budget", "0.3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -36,7 +40,7 @@ def test_bench_json_line_contract():
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf and "traffic_source" in rf
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == d["unit"]
     assert d["verified"] is True and d["value"] > 0

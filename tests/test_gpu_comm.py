@@ -1,0 +1,140 @@
+"""The communication of the sharded path behind the C ABI (include/kmers_hip.h: kmers_comm_*, kmers_halo_exchange,
+kmers_first_error_allreduce, kmers_offsets_allgather) on a real RCCL communicator.  A 1-GPU box admits one rank per
+communicator (RCCL refuses two ranks on one device), so the hardware legs here are: the communicator life cycle, a grouped
+ncclSend/ncclRecv through kmers_comm_sendrecv (peer = self), the two reductions on one rank, and `bench.py --gpus 2`
+end to end with two ranks sharing the device over gloo (both torch transports).  The N > 1 RCCL run itself is the driver's."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def km():
+    import kmers_jl_amd
+    return kmers_jl_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(km):
+    c = km.Context(0)
+    yield c
+    c.close()
+
+
+def test_single_rank_communicator(km, ctx):
+    from kmers_jl_amd.shard import NativeComm, plan_shards
+    cap = km._capi
+    ident = NativeComm.new_id(ctx.lib)
+    assert len(ident) == cap.COMM_ID_BYTES
+    comm = NativeComm.create(ctx, ident, 1, 0)
+    r, n = C.c_int(-1), C.c_int(-1)
+    assert ctx.lib.kmers_comm_rank(ctx.handle, comm.handle, C.byref(r), C.byref(n)) == 0 and (r.value, n.value) == (0, 1)
+    # grouped ncclSend + ncclRecv on the context's stream (peer = this rank): words [0, 4) -> words [10, 14)
+    host = np.arange(1, 17, dtype=np.uint64) * np.uint64(0x0123456789ABCDEF)
+    d = ctx.alloc(host.nbytes)
+    ctx.h2d(d, host)
+    comm.sendrecv(d, 4, 0, d + 80, 4, 0)
+    back = np.zeros_like(host)
+    ctx.d2h(back, d)   # same stream: ordered after the exchange
+    want = host.copy()
+    want[10:14] = host[0:4]
+    assert np.array_equal(back, want)
+    # a one-shard plan has no neighbour: the exchange enqueues nothing and succeeds
+    plan = plan_shards(10_000, 31, 1, 4)
+    comm.halo_exchange(plan[0], d)
+    # a two-shard plan on a one-rank communicator: rank 0 of 1 neither sends (rank 0) nor receives (last rank)
+    comm.halo_exchange(plan_shards(10_000, 31, 2, 4)[0], d)
+    ctx.d2h(back, d)
+    assert np.array_equal(back, want)
+    # the two reductions
+    assert comm.first_error(0) == (0, 0, 0)
+    assert comm.first_error(1, err_pos=123_456_789_012, err_enc=0xF) == (1, 123_456_789_012, 0xF)
+    assert comm.first_error(1, err_pos=7, err_enc=ord("!")) == (1, 7, ord("!"))
+    assert comm.output_offsets(0) == (0, 0)
+    assert comm.output_offsets(987_654_321_000) == (0, 987_654_321_000)
+    # bad arguments come back as statuses, never as aborts
+    res = cap.Result(cap.E_HIP, 0, 0, 0)
+    assert ctx.lib.kmers_first_error_allreduce(ctx.handle, comm.handle, C.byref(res)) == cap.E_BADARG
+    assert ctx.lib.kmers_halo_exchange(ctx.handle, None, None, None) == cap.E_BADARG
+    assert ctx.lib.kmers_comm_sendrecv(ctx.handle, comm.handle, None, 4, 0, None, 0, -1) == cap.E_BADARG
+    ctx.free(d)
+    comm.close()
+
+
+def run_bench(extra_args, env_extra, timeout=900):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args, capture_output=True, text=True, timeout=timeout, env=env)
+    return r
+
+
+@pytest.mark.parametrize("transport", ["allgather", "p2p"])
+def test_bench_launches_two_ranks_by_itself(transport):
+    """`python bench.py --gpus 2` exactly as the driver calls it (no torchrun around it): the parent starts the ranks.  Two
+    ranks share the one device over gloo here, which exercises the launcher, the shard plan, the halo step and the
+    verification of both shards; the line must report what really ran."""
+    r = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--bases", "8000000", "--no-other-configs", "--no-cpu-baseline", "--no-pmc"],
+                  {"KMERS_BENCH_BACKEND": "gloo", "KMERS_HALO_TRANSPORT": transport})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["scaling"] == "weak"
+    assert d["config"]["backend"] == "gloo" and d["config"]["halo_transport"] == transport
+    assert "gloo" in d["config"]["sharding"] and "RCCL" not in d["config"]["sharding"]
+    assert d["value"] > 0 and d["roofline"]["kmers_per_launch"] > 0
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count()
+    r = run_bench(["--gpus", str(n + 1), "--steps", "1", "--warmup", "0", "--bases", "1000000"], {"KMERS_BENCH_BACKEND": "nccl"})
+    assert r.returncode != 0 and r.stdout.strip() == "" and "one GPU per rank" in r.stderr
+
+
+def test_rank_started_with_the_wrong_world_size_fails():
+    """A rank whose WORLD_SIZE differs from --gpus must not print a line for a job that is not the one asked for."""
+    r = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--bases", "1000000", "--no-other-configs", "--no-cpu-baseline", "--no-pmc"],
+                  {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+def test_async_launches_share_one_error_slot(km, ctx):
+    """Several KMERS_ASYNC launches between two kmers_sync calls: the kernels record (position, symbol) at fault time,
+    so the sync needs no sequence any more -- the smallest reported position wins, with the right symbol, even when the
+    failing launch was not the last one and its source has been overwritten since."""
+    import naive
+    cap = km._capi
+    rng = np.random.default_rng(5)
+    K = 31
+    clean = naive.random_text(rng, 50_000)
+    bad = list(naive.random_text(rng, 3_000))
+    bad[1234] = "N"
+    bad[2500] = "R"
+    w_clean = naive.longseq_words(clean, 4)
+    w_bad = naive.longseq_words("".join(bad), 4)
+    d_clean, d_bad = ctx.alloc(w_clean.nbytes + 8), ctx.alloc(w_bad.nbytes + 8)
+    ctx.h2d(d_clean, w_clean)
+    ctx.h2d(d_bad, w_bad)
+    out = ctx.alloc(50_000 * 8)
+    res = cap.Result()
+    flags = cap.MEM_DEVICE | cap.ASYNC
+    s_bad = cap.Seq(d_bad, len(bad), 0, 1_000_000, 4, 0)      # a shard whose positions start at 1 000 000
+    s_clean = cap.Seq(d_clean, len(clean), 0, 0, 4, 0)
+    assert ctx.lib.kmers_canonical(ctx.handle, C.byref(s_bad), K, 2, out, None, 0, flags, C.byref(res)) == 0
+    assert ctx.lib.kmers_canonical(ctx.handle, C.byref(s_clean), K, 2, out, None, 0, flags, C.byref(res)) == 0
+    ctx.h2d(d_bad, np.zeros_like(w_bad))                      # the failing source is gone before the sync
+    rc, sres = ctx.sync()
+    assert rc == cap.E_ENCODE and sres.err_pos == 1_000_000 + 1235 and sres.err_enc == 0xF, (rc, sres.err_pos, sres.err_enc)
+    rc, sres = ctx.sync()                                      # the slot is re-armed
+    assert rc == 0
+    for p in (d_clean, d_bad, out):
+        ctx.free(p)

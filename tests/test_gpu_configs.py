@@ -121,6 +121,53 @@ def test_c2_canonical31_hash_one_gbase(km, ctx, orc):
         assert np.array_equal(host_u64(hs[first:first + len(eh)]), eh)
 
 
+def test_north_star_canonical31_hash_ten_gbase_one_gpu(km, ctx, orc):
+    """BASELINE.json north_star: canonical 31-mers + fx_hash over 10 Gbase LongDNA{4} on ONE GPU (5 GB in, 160 GB of kmers
+    and hashes out; CanonicalKmers.jl:131-144, kmer.jl:255-261).  Properties over all 9 999 999 970 elements, the fused
+    reducer as a checksum, oracle windows at the start, in the middle, across the 2^32-element boundary and at the end."""
+    cap = km._capi
+    L, K, bits = 10_000_000_000, 31, 4
+    torch.cuda.empty_cache()
+    free_b, _ = torch.cuda.mem_get_info(0)
+    if free_b < 172e9:
+        pytest.skip(f"needs 165 GB of HBM, {free_b / 1e9:.0f} GB free")
+    seed = GOLDEN ^ 10
+    n = L - K + 1
+    nw = (L * bits + 63) // 64
+    buf = synth(ctx, seed, 0, nw, bits)
+    seq = cap.Seq(buf.data_ptr(), L, 0, 0, bits, 0)
+    res = cap.Result()
+    ck, hs = dev_empty(n), dev_empty(n)
+    assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, ck.data_ptr(), hs.data_ptr(), 0, cap.MEM_DEVICE,
+                                   C.byref(res)) == 0 and res.n_out == n
+    mask = (1 << 62) - 1
+    cmul = torch.tensor(FX, dtype=torch.int64, device="cuda:0")
+    folded = 0
+    for lo, hi in chunks(n, 1 << 28):
+        c, h = ck[lo:hi], hs[lo:hi]
+        assert bool(torch.equal(h, c * cmul))                              # fx_hash(x) = x * C for one word, seed 0
+        assert int(torch.max(c)) <= mask and int(torch.min(c)) >= 0        # unused top bits are zero
+        folded ^= xor_fold(c.contiguous())
+    xr = C.c_uint64()
+    assert ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, 2, 1, C.byref(xr), cap.MEM_DEVICE, C.byref(res)) == 0
+    assert folded == xr.value
+    # canonical kmers are fixed points of canonical(): idempotence over the first 2^30 elements via the element-wise transform
+    m = 1 << 30
+    again = dev_empty(m)
+    assert ctx.lib.kmers_transform(ctx.handle, cap.OP_CANONICAL, ck.data_ptr(), K, 2, m, again.data_ptr(), cap.MEM_DEVICE) == 0
+    assert bool(torch.equal(again, ck[:m]))
+    del again
+    per = 64 // bits
+    probe = 1 << 20
+    for first in (0, (n // 3 // per) * per, (1 << 32) - (probe // 2), ((n - probe) // per) * per):
+        first = first // per * per
+        nb = min(probe, n - first) + K - 1
+        w = orc.synth_words(seed, first // per, (nb * bits + 63) // 64 + 1, bits)
+        ek, eh, _ = orc.canonical(w, nb, bits, 2, K)
+        assert np.array_equal(host_u64(ck[first:first + len(ek)]), ek[:, 0]), first
+        assert np.array_equal(host_u64(hs[first:first + len(eh)]), eh), first
+
+
 def test_c3_canonical31_ten_gbase_two_bit_eight_shards(km, ctx, orc):
     """configs[2]: CanonicalDNAMers{31} over 10 Gbase LongDNA{2} sharded 8 ways with a (K-1)-base halo.
     The 8 shards run one after another on this device exactly as 8 ranks would (own words + the halo
