@@ -215,16 +215,25 @@ def other_configs(ctx, cap, stream, dev, reps=5):
     out = {}
 
     def timed(fn):
+        """HIP events on the library's stream around one call, median of reps.  Entry points with an asynchronous form
+        (KMERS_ASYNC: kmers_canonical / kmers_fw / kmers_spaced) are timed in it, like the headline step: the events then
+        bracket the kernel alone; around a synchronous call they would also bracket the host's wake-up after its stream
+        wait and its next launch (measured: +0.25 ms on a 1.6 ms kernel, tools/diag_c3.py, profiles/r02_tuning.md)."""
         fn()
         ts = []
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
             e0.record(stream)
             fn()
             e1.record(stream)
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
+        rc, _ = ctx.sync()
+        assert rc == 0, ctx.last_error()
         return float(np.median(ts))
+
+    ASYNC = cap.MEM_DEVICE | cap.ASYNC
 
     def synth(seed, n_bases, bits, amb=0):
         nw = (n_bases * bits + 63) // 64
@@ -247,7 +256,7 @@ def other_configs(ctx, cap, stream, dev, reps=5):
             a = torch.empty(n, dtype=torch.int64, device=dev)
             h = torch.empty(n, dtype=torch.int64, device=dev)
             seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
-            ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), h.data_ptr(), 0, cap.MEM_DEVICE, C.byref(res)))
+            ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), h.data_ptr(), 0, ASYNC, C.byref(res)))
             ok = verify_canonical(ctx, cap, stream, dev, buf, L, 0, 0, 4, K, 1, seed10, a, h, n)
             entry("N1 north star: CanonicalDNAMers{31} + fx_hash, 10 Gbase LongDNA{4}, one GPU, 16.5 B/kmer", ms, L, 16.5 * n, verified=ok)
             del buf, a, h
@@ -259,7 +268,7 @@ def other_configs(ctx, cap, stream, dev, reps=5):
         buf = synth(GOLDEN ^ 3, L, 2)
         a = torch.empty(L, dtype=torch.int64, device=dev)
         seq = cap.Seq(buf.data_ptr(), L, 0, 0, 2, 0)
-        ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), None, 0, cap.MEM_DEVICE, C.byref(res)))
+        ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), None, 0, ASYNC, C.byref(res)))
         entry("C3 CanonicalDNAMers{31}, 1.25 Gbase LongDNA{2} (one of 8 shards), 8.25 B/kmer", ms, L, 8.25 * (L - K + 1))
         # C4: FwDNAMers{63} + reverse_complement over 1 Gbase LongDNA{4}
         L, K = 1_000_000_000, 63
@@ -267,7 +276,7 @@ def other_configs(ctx, cap, stream, dev, reps=5):
         a = torch.empty(2 * L, dtype=torch.int64, device=dev)
         b = torch.empty(2 * L, dtype=torch.int64, device=dev)
         seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
-        ms = timed(lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), b.data_ptr(), cap.MEM_DEVICE, C.byref(res)))
+        ms = timed(lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), b.data_ptr(), ASYNC, C.byref(res)))
         entry("C4 FwDNAMers{63} + reverse_complement, 1 Gbase LongDNA{4}, 32.5 B/kmer", ms, L, 32.5 * (L - K + 1))
         del b
         # C5: SpacedDNAMers{21,3} over 1 Gbase LongDNA{4}: strict, and the skip variant with N at p = 0.04
@@ -275,7 +284,7 @@ def other_configs(ctx, cap, stream, dev, reps=5):
         n = (L - K) // J + 1
         buf = synth(GOLDEN ^ 5, L, 4)
         seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
-        ms = timed(lambda: ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, 2, a.data_ptr(), cap.MEM_DEVICE, C.byref(res)))
+        ms = timed(lambda: ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, 2, a.data_ptr(), ASYNC, C.byref(res)))
         entry("C5 SpacedDNAMers{21,3} strict, 1 Gbase LongDNA{4}, 9.5 B/kmer", ms, L, 0.5 * L + 8.0 * n)
         amb = synth(GOLDEN ^ 5, L, 4, 2621)
         seqa = cap.Seq(amb.data_ptr(), L, 0, 0, 4, 0)

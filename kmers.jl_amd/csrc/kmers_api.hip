@@ -16,7 +16,7 @@
 #include "ascii_tables.hpp"
 #include "context.hpp"
 #include "batch_kernels.hpp"
-#include "compact_kernels.hpp"
+#include "unambiguous_kernel.hpp"
 #include "composition_kernel.hpp"
 #include "ragged_kernels.hpp"
 #include "record_sketch_kernel.hpp"
@@ -138,7 +138,7 @@ static uint32_t default_tile(uint32_t out_bytes_per_kmer, uint32_t pass) {
 }
 
 template <int MODE, int SB, int DB>
-void launch_widths(int n_words, bool s1, dim3 grid, dim3 block, hipStream_t st, const StreamArgs &a, size_t dyn_lds) {
+void launch_widths(int n_words, bool s1, bool pair, dim3 grid, dim3 block, hipStream_t st, const StreamArgs &a, size_t dyn_lds) {
     if constexpr (MODE == MODE_FW || MODE == MODE_CANON) {
         if (a.tuples) {  // array-of-structs outputs: one kmer per lane per pass
             switch (n_words) {
@@ -147,6 +147,12 @@ void launch_widths(int n_words, bool s1, dim3 grid, dim3 block, hipStream_t st, 
                 case 3: hipLaunchKernelGGL((stream_kernel<SB, DB, 3, MODE, false, true>), grid, block, dyn_lds, st, a); break;
                 default: hipLaunchKernelGGL((stream_kernel<SB, DB, 4, MODE, false, true>), grid, block, dyn_lds, st, a); break;
             }
+            return;
+        }
+    }
+    if constexpr (MODE == MODE_FW || MODE == MODE_XOR) {
+        if (pair) {  // strided one-word kmers, two lattice kmers per lane (16-byte stores)
+            hipLaunchKernelGGL((stream_kernel<SB, DB, 1, MODE, false, false, true>), grid, block, dyn_lds, st, a);
             return;
         }
     }
@@ -168,7 +174,8 @@ template <int MODE>
 int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int n_words, bool vec_ok, size_t dyn_lds = 0) {
     const uint32_t J = a.stride;
     const bool stride1 = (J == 1) && vec_ok && !a.tuples;
-    const uint32_t pass = (stride1 && n_words == 1 ? 2u : 1u) * BLOCK;  // kmers per workgroup pass
+    const bool pair = (MODE == MODE_FW || MODE == MODE_XOR) && J > 1 && vec_ok && !a.tuples && n_words == 1;
+    const uint32_t pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * BLOCK;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
                          (MODE == MODE_CANON && a.out_b ? 8u : 0u) + (MODE == MODE_FW && a.out_starts ? 8u : 0u);
     if (a.tuples) out_bytes = MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u;
@@ -186,12 +193,12 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap));
     dim3 block(BLOCK);
-    if (src_bits == 8 && dst_bits == 2) launch_widths<MODE, 8, 2>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
-    else if (src_bits == 8) launch_widths<MODE, 8, 4>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
-    else if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
-    else if (src_bits == 2 && dst_bits == 2) launch_widths<MODE, 2, 2>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
-    else if (src_bits == 4 && dst_bits == 4) launch_widths<MODE, 4, 4>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
-    else launch_widths<MODE, 2, 4>(n_words, stride1, grid, block, ctx->stream, a, dyn_lds);
+    if (src_bits == 8 && dst_bits == 2) launch_widths<MODE, 8, 2>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 8) launch_widths<MODE, 8, 4>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 2 && dst_bits == 2) launch_widths<MODE, 2, 2>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 4 && dst_bits == 4) launch_widths<MODE, 4, 4>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
+    else launch_widths<MODE, 2, 4>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
     HIP_TRY(ctx, hipGetLastError());
     return KMERS_OK;
 }
@@ -320,7 +327,35 @@ int emit_all_kept(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k,
     return launch_stream<MODE_FW>(ctx, a, seq->src_bits, 2, kmers_words_per_kmer(k, 2), vec_ok);
 }
 
-// UnambiguousKmers: count -> scan -> emit (compact_kernels.hpp)
+// Launch of the single-pass UnambiguousKmers kernel (unambiguous_kernel.hpp) in one of its modes.
+template <int UMODE>
+void launch_unambiguous(kmers_ctx *ctx, int src_bits, int nw, dim3 grid, const UnambArgs &a) {
+    dim3 block(BLOCK);
+#define UW(SB)                                                                                                  \
+    do {                                                                                                        \
+        switch (nw) {                                                                                           \
+            case 1: hipLaunchKernelGGL((unambiguous_kernel<SB, 1, UMODE>), grid, block, 0, ctx->stream, a); break; \
+            case 2: hipLaunchKernelGGL((unambiguous_kernel<SB, 2, UMODE>), grid, block, 0, ctx->stream, a); break; \
+            case 3: hipLaunchKernelGGL((unambiguous_kernel<SB, 3, UMODE>), grid, block, 0, ctx->stream, a); break; \
+            default: hipLaunchKernelGGL((unambiguous_kernel<SB, 4, UMODE>), grid, block, 0, ctx->stream, a); break; \
+        }                                                                                                       \
+    } while (0)
+    if constexpr (UMODE == UMODE_COUNT) nw = 1;  // counting does not depend on the kmer width
+    if (src_bits == 8) UW(8);
+    else if (src_bits == 4) UW(4);
+    else UW(2);
+#undef UW
+}
+
+uint32_t unambiguous_tile(kmers_ctx *ctx) {
+    // candidate starts per tile: a multiple of 1024 (one wavefront round), at most UTILE_MAX.  Long tiles keep the rate of
+    // tile descriptors low enough for the look-back.
+    uint32_t t = ctx->tile_kmers > 0 ? (uint32_t)std::min<int64_t>(ctx->tile_kmers, UTILE_MAX) : UTILE_MAX;
+    return std::max<uint32_t>(UROUND, t / UROUND * UROUND);
+}
+
+// UnambiguousKmers: ONE pass over the source (unambiguous_kernel.hpp): tile descriptors + decoupled look-back inside the
+// emitting kernel; the element count is known when the kernel has run.
 int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uint64_t *out_kmers,
                     int64_t *out_starts, uint64_t capacity, int flags, kmers_result *res) {
     const int nw = kmers_words_per_kmer(k, 2);
@@ -334,90 +369,53 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         n = seq->n_bases;
         k = 1;
     }
+    const bool tuples = (flags & KMERS_OUT_TUPLES) != 0;
+    if (tuples && out_starts) return fail(ctx, KMERS_E_BADARG, "KMERS_OUT_TUPLES: out_starts must be NULL");
     Staged st;
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
     const bool dev = flags & KMERS_MEM_DEVICE;
+    const bool query = !out_kmers && !out_starts;  // size query: count only
 
-    CompactArgs a{};
+    UnambArgs a{};
     a.src = st.d_words;
     a.first_bit = st.first_bit;
     a.n_cand = n;
+    a.n_bases = seq->n_bases;
     a.ascii_table = (uint32_t)ASCII_TABLE_SKIPPING;
     a.err_slot = ctx->d_err;
-    a.n_bases = seq->n_bases;
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
     a.index_origin = seq->index_origin;
-    // about 16 KiB of (kmer, start) output per workgroup, as for the stream kernel
-    // (a tile is measured in candidate starts; on a stride lattice only every stride-th is a candidate, so the tile
-    // grows with the stride to keep the work and the output per workgroup)
-    uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers
-                                        : default_tile(8u * nw + 8u, BLOCK) * (uint32_t)std::min<int>(std::max(stride, 1), 8);
-    tile = std::max<uint32_t>((uint32_t)BLOCK, std::min<uint32_t>(tile, (uint32_t)MAX_TILE_BASES / 2) / BLOCK * BLOCK);
-    a.tile_kmers = tile;
-    a.n_tiles = (n + tile - 1) / tile;
-    const uint64_t n_counts = a.n_tiles * WAVES;
-    // scratch: counts (u32), offsets (u64, n_counts + 1), segment sums (u64, n_seg + 1)
-    size_t counts_bytes = ((size_t)n_counts * 4 + 15) & ~(size_t)15;
-    const uint64_t n_seg = (n_counts + SCAN_SEG - 1) / SCAN_SEG;
-    if (int rc = ensure_stage(ctx, 3, counts_bytes + ((size_t)n_counts + 1) * 8 + ((size_t)n_seg + 1) * 8)) return rc;
-    a.counts = static_cast<uint32_t *>(ctx->stage[3]);
-    uint64_t *offsets = reinterpret_cast<uint64_t *>(static_cast<char *>(ctx->stage[3]) + counts_bytes);
-    uint64_t *seg_sums = offsets + n_counts + 1;
-    a.offsets = offsets;
-    uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
-    // count pass: bit-parallel, several whole tiles per staging on a persistent grid (nothing is
-    // streamed out); emit pass: one tile per short-lived workgroup
-    a.group = std::max<uint32_t>(1u, 8192u / tile);
-    a.slot_mult = 1;
-    // a 2-bit source has no ambiguous symbols: every start survives, nothing to count
+    a.tile_starts = unambiguous_tile(ctx);
+    a.n_tiles = (n + a.tile_starts - 1) / a.tile_starts;
+    a.tuples = tuples ? 1u : 0u;
+    const uint64_t cap_grid = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
+
+    // a 2-bit source has no ambiguous symbols: every start survives, nothing to resolve
     const bool known_all = seq->src_bits == 2 && stride == 1 && !validate_only;
-    if (!known_all) HIP_TRY(ctx, hipMemsetAsync(a.counts, 0, (size_t)n_counts * 4, ctx->stream));
-    if (!known_all) {
-        const uint64_t n_groups = (n + (uint64_t)a.group * tile - 1) / ((uint64_t)a.group * tile);
-        dim3 cgrid((unsigned)std::min<uint64_t>(n_groups, 256 * 8)), cblock(BLOCK);
-        if (seq->src_bits == 8) hipLaunchKernelGGL((unambiguous_count_kernel<8>), cgrid, cblock, 0, ctx->stream, a);
-        else if (seq->src_bits == 4) hipLaunchKernelGGL((unambiguous_count_kernel<4>), cgrid, cblock, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((unambiguous_count_kernel<2>), cgrid, cblock, 0, ctx->stream, a);
-    }
-    dim3 grid(1), block(BLOCK);  // the emit grid is set once the survivor density is known
-#define UL(SB, NN, EM)                                                                                     \
-    do {                                                                                                   \
-        if (NN == 1 && dense_path) hipLaunchKernelGGL((unambiguous_kernel<SB, 1, true>), grid, block, 0, ctx->stream, a); \
-        else hipLaunchKernelGGL((unambiguous_kernel<SB, NN>), grid, block, 0, ctx->stream, a);             \
-    } while (0)
-#define UDISPATCH(EM)                                                         \
-    do {                                                                      \
-        if (seq->src_bits == 8) { if (nw == 1) UL(8, 1, EM); else UL(8, 2, EM); }      \
-        else if (seq->src_bits == 4) { if (nw == 1) UL(4, 1, EM); else UL(4, 2, EM); } \
-        else                    { if (nw == 1) UL(2, 1, EM); else UL(2, 2, EM); }      \
-    } while (0)
-    HIP_TRY(ctx, hipGetLastError());
     uint64_t total = n;
-    if (!known_all) {
-        hipLaunchKernelGGL(scan_segment_sums_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, a.counts, n_counts, seg_sums);
-        hipLaunchKernelGGL(scan_segments_kernel, dim3(1), dim3(1024), 0, ctx->stream, seg_sums, n_seg);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, a.counts, n_counts, seg_sums, n_seg, offsets);
+    // Host-memory outputs are staged through HBM buffers of exactly `total` elements, so the host path counts first
+    // (it is PCIe-bound anyway); device outputs and their capacity are used as they are: one pass.
+    const bool count_first = !known_all && (query || validate_only || !dev);
+    if (count_first) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
+        a.total = reinterpret_cast<unsigned long long *>(ctx->d_scratch);
+        dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, std::min<uint64_t>(cap_grid, (uint64_t)ctx->n_cus * 8)));
+        launch_unambiguous<UMODE_COUNT>(ctx, seq->src_bits, nw, grid, a);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipMemcpyAsync(&total, offsets + n_counts, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    if (ascii) {  // an invalid byte anywhere in the source is an EncodeError
-        if (int erc = collect(ctx, res, total)) return erc;
+        // an invalid byte anywhere in an ASCII source is an EncodeError (collect reads the error slot and the count)
+        if (int erc = collect(ctx, res, 0, &total)) return erc;
     }
     if (validate_only) total = 0;
     if (res) res->n_out = total;
-    const bool tuples = (flags & KMERS_OUT_TUPLES) != 0;
-    if (tuples && out_starts) return fail(ctx, KMERS_E_BADARG, "KMERS_OUT_TUPLES: out_starts must be NULL");
-    if (total > capacity || (!out_kmers && !out_starts)) {
-        // capacity query (both outputs NULL) or buffers too small: report the count only
-        if (total > capacity && (out_kmers || out_starts)) {
+    if (query) return KMERS_OK;
+    if (known_all || count_first) {
+        if (total > capacity) {
             if (res) res->status = KMERS_E_CAPACITY;
             return fail(ctx, KMERS_E_CAPACITY, "output capacity too small");
         }
-        return KMERS_OK;
+        if (total == 0) return KMERS_OK;
     }
-    if (total == 0) return KMERS_OK;
     uint64_t *d_k = out_kmers;
     long long *d_s = reinterpret_cast<long long *>(out_starts);
     const size_t kb = (size_t)total * (tuples ? nw + 1 : nw) * 8, sb = (size_t)total * 8;
@@ -425,39 +423,37 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         if (out_kmers) { if (int rc = ensure_stage(ctx, 1, kb)) return rc; d_k = (uint64_t *)ctx->stage[1]; }
         if (out_starts) { if (int rc = ensure_stage(ctx, 2, sb)) return rc; d_s = (long long *)ctx->stage[2]; }
     }
-    if (total == n && stride == 1 && !tuples && !validate_only && !ascii) {
-        // nothing was dropped: FwKmers + start indices at the stream kernel's rate.  (Not for byte sources: this iterator
-        // reads them through ASCII_SKIPPING_LUT, where T and U both mean 3 whatever the kmer alphabet
-        // (src/iterators/common.jl:22-32), while the stream kernel would apply the alphabet's ascii_encode table.)
+    if (known_all && !tuples) {
+        // nothing can be dropped: FwKmers + start indices at the stream kernel's rate
         if (int rc = emit_all_kept(ctx, seq, st, k, n, d_k, d_s)) return rc;
-        if (!dev) {
-            if (out_kmers) HIP_TRY(ctx, hipMemcpyAsync(out_kmers, d_k, kb, hipMemcpyDeviceToHost, ctx->stream));
-            if (out_starts) HIP_TRY(ctx, hipMemcpyAsync(out_starts, d_s, sb, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        if (int rc = ensure_stage(ctx, 3, ((size_t)a.n_tiles + 2) * 8)) return rc;
+        unsigned long long *scratch = static_cast<unsigned long long *>(ctx->stage[3]);
+        HIP_TRY(ctx, hipMemsetAsync(scratch, 0, ((size_t)a.n_tiles + 2) * 8, ctx->stream));
+        a.desc = scratch;
+        a.ticket = scratch + a.n_tiles;
+        a.out_kmers = d_k;
+        a.out_starts = d_s;
+        a.capacity = dev ? capacity : total;
+        a.vec16 = ((!d_k || aligned16(d_k)) && (!d_s || aligned16(d_s))) ? 1u : 0u;
+        dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap_grid));
+        launch_unambiguous<UMODE_EMIT>(ctx, seq->src_bits, nw, grid, a);
+        HIP_TRY(ctx, hipGetLastError());
+        // the last tile's inclusive prefix is the element count
+        uint64_t *h = ctx->h_result + 2;  // pinned
+        HIP_TRY(ctx, hipMemcpyAsync(h, a.desc + (a.n_tiles - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (ascii) {  // an invalid byte anywhere in the source is an EncodeError
+            if (int erc = collect(ctx, res, 0)) return erc;
+        } else {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        return KMERS_OK;
+        total = *h & DESC_VALUE;
+        if (res) res->n_out = total;
+        if (total > capacity) {  // the kernel stored nothing at or beyond the capacity
+            if (res) res->status = KMERS_E_CAPACITY;
+            return fail(ctx, KMERS_E_CAPACITY, "output capacity too small");
+        }
     }
-    a.out_kmers = d_k;
-    a.out_starts = d_s;
-    a.vec16 = ((!d_k || aligned16(d_k)) && (!d_s || aligned16(d_s))) ? 1u : 0u;
-    const bool dense_path = a.vec16 && stride == 1 && !tuples && total >= n - n / 10;  // mostly clean sequence
-    a.tuples = tuples ? 1u : 0u;
-    a.group = 1;
-    // Sparse survivors: an emit tile spans several count tiles, so that a workgroup still writes about 16 KiB
-    // (offsets are kept per count slot; a wavefront needs only the offset of the first slot of its chunk).
-    {
-        const double density = (double)total / (double)((n + (uint64_t)stride - 1) / (uint64_t)stride);
-        uint32_t m = ctx->tile_kmers > 0 ? 1u : (uint32_t)std::min(8.0, std::max(1.0, std::floor(1.0 / std::max(density, 1e-3) + 0.5)));
-        m = std::max<uint32_t>(1u, std::min<uint32_t>(m, (uint32_t)(MAX_TILE_BASES / 2) / tile));
-        a.slot_mult = m;
-        a.tile_kmers = tile * m;
-        a.n_tiles = (n + a.tile_kmers - 1) / a.tile_kmers;
-        grid = dim3((unsigned)std::min<uint64_t>(a.n_tiles, cap));
-    }
-    UDISPATCH(true);
-#undef UDISPATCH
-#undef UL
-    HIP_TRY(ctx, hipGetLastError());
     if (!dev) {
         if (out_kmers) HIP_TRY(ctx, hipMemcpyAsync(out_kmers, d_k, kb, hipMemcpyDeviceToHost, ctx->stream));
         if (out_starts) HIP_TRY(ctx, hipMemcpyAsync(out_starts, d_s, sb, hipMemcpyDeviceToHost, ctx->stream));
@@ -761,8 +757,7 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
         if (rc) return rc;
         return collect(ctx, res, n, out_value);
     }
-    // UnambiguousKmers: the emit kernel's XOR instantiation (no count pass, no offsets)
-    if (k > 64) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_unambiguous supports K <= 64");
+    // UnambiguousKmers: the single-pass kernel's XOR mode (no descriptors, no look-back: nothing is placed)
     uint64_t n = kmers_count(seq->n_bases, k, 1);
     const bool ascii = seq->src_bits == 8;
     const bool validate_only = ascii && n == 0 && seq->n_bases > 0;  // invalid bytes still throw (UnambiguousKmers.jl:117-123)
@@ -775,28 +770,21 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
     Staged st;
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
-    CompactArgs a{};
+    UnambArgs a{};
     a.src = st.d_words;
     a.first_bit = st.first_bit;
     a.n_cand = n;
+    a.n_bases = seq->n_bases;
     a.ascii_table = (uint32_t)ASCII_TABLE_SKIPPING;
     a.err_slot = ctx->d_err;
-    a.n_bases = seq->n_bases;
     a.k = (uint32_t)kk;
     a.stride = (uint32_t)stride;
     a.index_origin = seq->index_origin;
-    a.tile_kmers = 4096;          // nothing is streamed out: long tiles on a persistent grid
-    a.n_tiles = (n + a.tile_kmers - 1) / a.tile_kmers;
-    a.group = 1;
-    a.xor_out = ctx->d_scratch;
-    dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, (uint64_t)ctx->n_cus * 8)), block(BLOCK);
-    const bool two = kmers_words_per_kmer(kk, 2) == 2;
-#define UX(SB) do { if (two) hipLaunchKernelGGL((unambiguous_kernel<SB, 2, false, true>), grid, block, 0, ctx->stream, a); \
-                    else hipLaunchKernelGGL((unambiguous_kernel<SB, 1, false, true>), grid, block, 0, ctx->stream, a); } while (0)
-    if (seq->src_bits == 8) UX(8);
-    else if (seq->src_bits == 4) UX(4);
-    else UX(2);
-#undef UX
+    a.tile_starts = UTILE_MAX;    // nothing is streamed out: long tiles on a persistent grid
+    a.n_tiles = (n + a.tile_starts - 1) / a.tile_starts;
+    a.total = reinterpret_cast<unsigned long long *>(ctx->d_scratch);
+    dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, (uint64_t)ctx->n_cus * 8));
+    launch_unambiguous<UMODE_XOR>(ctx, seq->src_bits, kmers_words_per_kmer(kk, 2), grid, a);
     HIP_TRY(ctx, hipGetLastError());
     uint64_t value = 0;
     const int rc = collect(ctx, res, 0, &value);
@@ -1536,7 +1524,6 @@ int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, u
         return rc;
     }
     if (flags & KMERS_ASYNC) return fail(ctx, KMERS_E_BADARG, "kmers_unambiguous is synchronous (data-dependent count)");
-    if (k > 64) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_unambiguous supports K <= 64");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return run_unambiguous(ctx, seq, k, stride, out_kmers, out_starts, capacity, flags, res);
 }

@@ -274,7 +274,10 @@ __device__ __forceinline__ void sketch_candidate(const StreamArgs &a, uint64_t h
     if (sketch_is_new(a, h)) sketch_append(a, h);
 }
 
-template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1, bool TUPLES = false>
+// PAIR (strided kernels, one-word kmers): a lane takes two neighbouring lattice kmers, each cut from its own window, so
+// that SpacedKmers output is stored 16 bytes per lane like the stride-1 kernels' (SpacedKmers.jl:121-139 yields the same
+// elements whichever lane cuts them).
+template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1, bool TUPLES = false, bool PAIR = false>
 __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     __shared__ uint64_t lds[LDS_QWORDS];
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
@@ -285,7 +288,8 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     if constexpr (SRC_BITS == 8) {
         for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);  // computed, not loaded; visible after the tile loop's first barrier
     }
-    constexpr uint32_t KPL = (STRIDE1 && N == 1 && !TUPLES) ? 2u : 1u;  // kmers per lane per pass -> 16 B stores
+    static_assert(!PAIR || (!STRIDE1 && N == 1 && !TUPLES && (MODE == MODE_FW || MODE == MODE_XOR)), "PAIR: strided one-word kmers");
+    constexpr uint32_t KPL = ((STRIDE1 || PAIR) && N == 1 && !TUPLES) ? 2u : 1u;  // kmers per lane per pass -> 16 B stores
     uint64_t xacc = 0;
     uint64_t sketch_threshold = a.threshold;
     if constexpr (MODE == MODE_SKETCH) {
@@ -311,12 +315,26 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
 #endif
         block_sync();  // previous tile's readers are done with the LDS stream
         // ---- phase 1: source words -> DST-bit stream in LDS ------------------------------
-        for (uint32_t wi = tid; wi < nw; wi += BLOCK) {
-            const uint64_t x = a.src[w0 + wi];
-            uint64_t f = stage_word<SRC_BITS, DST>(lds, wi, x, lut);
-            if constexpr ((SRC_BITS == 4 && DST == 2) || SRC_BITS == 8) {
-                // `span` symbols per element are read (K, or K + W - 1 for minimizer windows): gaps start after them
-                if (f) report_bad_symbols<SRC_BITS, STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, span, w0 + wi, f, x, a.err_origin);
+        // (strided tiles span several words per lane -- 769 for 4096 SpacedDNAMers{21,3} windows of a 4-bit source: all of a
+        // lane's loads are issued before the first is used, so that the tile pays one memory latency, not one per round)
+        constexpr uint32_t PRE = STRIDE1 ? 1u : 4u;
+        for (uint32_t base = 0; base < nw; base += PRE * BLOCK) {
+            uint64_t x[PRE];
+#pragma unroll
+            for (uint32_t j = 0; j < PRE; ++j) {
+                const uint32_t wi = base + j * BLOCK + tid;
+                x[j] = wi < nw ? a.src[w0 + wi] : 0;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < PRE; ++j) {
+                const uint32_t wi = base + j * BLOCK + tid;
+                if (wi < nw) {
+                    uint64_t f = stage_word<SRC_BITS, DST>(lds, wi, x[j], lut);
+                    if constexpr ((SRC_BITS == 4 && DST == 2) || SRC_BITS == 8) {
+                        // `span` symbols per element are read (K, or K + W - 1 for minimizer windows): gaps start after them
+                        if (f) report_bad_symbols<SRC_BITS, STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, span, w0 + wi, f, x[j], a.err_origin);
+                    }
+                }
             }
         }
 #ifdef KMERS_STAMPS
@@ -331,7 +349,11 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
         for (uint32_t r = tid * KPL; r < mt; r += BLOCK * KPL) {
             const uint64_t g = m0 + r;
             uint64_t fw[KPL][N], rc[KPL][N];
-            if constexpr (KPL == 2) {
+            if constexpr (PAIR) {
+                window<N, DST>(lds, (uint32_t)DST * (r * J + b0), k, mask, fw[0], rc[0]);
+                if (r + 1 < mt) window<N, DST>(lds, (uint32_t)DST * ((r + 1) * J + b0), k, mask, fw[1], rc[1]);
+                else fw[1][0] = rc[1][0] = 0;
+            } else if constexpr (KPL == 2) {
                 // next window: one symbol further.  fw shifts left, rc shifts right with the
                 // complemented symbol on top (the reference's own rolling step,
                 // CanonicalKmers.jl:102-103, :115-118).

@@ -1,0 +1,454 @@
+// unambiguous_kernel.hpp -- UnambiguousKmers (src/iterators/UnambiguousKmers.jl:59-148) in ONE pass over the source:
+// every window of K unambiguous symbols together with its 1-based start index, in the reference's order.
+//
+// The reference walks the sequence with a `remaining` counter that every ambiguous symbol resets (:140-146).  Here a
+// window is kept iff the K bits of a one-bit-per-symbol ambiguity stream (staged in LDS next to the 2-bit code stream)
+// are all zero, which selects exactly the same windows.  The output position of a kept window is the number of kept
+// windows before it -- a prefix sum over the whole sequence -- and it is resolved INSIDE the emitting kernel:
+//
+//   tile     a workgroup draws a ticket (tiles are numbered in the order workgroups start), stages its source words once,
+//            resolves all of its candidate starts bit-parallel (64 starts per lane: the "good" bits AND-ed with themselves
+//            shifted by 1, 2, 4, ...), and publishes its kept count as an AGGREGATE in its tile descriptor;
+//   look-back   one wavefront then sums the descriptors of the preceding tiles, nearest first, 64 per step, until it meets
+//            one that already holds an inclusive PREFIX (decoupled look-back: it never waits for a predecessor's prefix,
+//            only for aggregates, which every started tile publishes unconditionally -- no circular wait), publishes its
+//            own inclusive prefix and hands the exclusive one to the workgroup;
+//   emit     every wavefront lists the kept starts of 1024 candidates at a time in LDS (their order is the reference's) and
+//            works the list off with every lane busy: window cut + contiguous stores.  A stretch with nothing dropped
+//            (real sequence outside its N blocks) skips the list: two kmers per lane, 16-byte stores.
+//
+// A descriptor is ONE 64-bit word (status in the top two bits, count below) moved with relaxed agent-scope atomics, so
+// no fence is needed: the word is the whole hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, "8-B agent atomics
+// both sides").  The source is read once; there is no count pass, no scan launch and no host round trip before the emit.
+#pragma once
+#include "stream_kernel.hpp"
+
+namespace kmers {
+
+constexpr uint32_t UTILE_MAX = 32768;    // candidate starts per tile (a multiple of 1024), at most
+constexpr uint32_t UROUND = 1024;        // starts per wavefront round (16 per lane)
+constexpr uint64_t DESC_VALUE = (1ull << 62) - 1ull;
+constexpr uint64_t DESC_AGGREGATE = 1ull << 62, DESC_PREFIX = 2ull << 62;
+        // descriptors per lane and look-back step (256 per step)
+
+enum UMode { UMODE_EMIT = 0, UMODE_COUNT = 1, UMODE_XOR = 2 };
+
+struct UnambArgs {
+    const uint64_t *src;
+    uint64_t first_bit;
+    uint64_t n_cand;               // candidate starts = n_bases - K + 1
+    uint64_t n_bases;              // SRC_BITS == 8: every byte below n_bases is inspected (UnambiguousKmers.jl:117-123)
+    uint64_t n_tiles;
+    unsigned long long *desc;      // EMIT: [n_tiles] tile descriptors, zeroed before the launch
+    unsigned long long *ticket;    // EMIT: zeroed; tile ids are drawn in the order workgroups start
+    unsigned long long *total;     // COUNT: += kept starts;  XOR: ^= head words of the kept kmers
+    uint64_t *out_kmers;           // nullable
+    long long *out_starts;         // nullable
+    uint64_t capacity;             // elements the outputs hold: nothing is stored at or beyond it
+    uint64_t index_origin;
+    unsigned long long *err_slot;  // SRC_BITS == 8: first invalid byte (0xff in the table) -> EncodeError
+    uint32_t k;
+    uint32_t stride;               // keep windows with (start0 % stride) == 0
+    uint32_t tile_starts;          // multiple of 1024, <= UTILE_MAX
+    uint32_t ascii_table;          // SRC_BITS == 8: ASCII_TABLE_SKIPPING = the reference's ASCII_SKIPPING_LUT (common.jl:22-32)
+    uint32_t tuples;               // 1: out_kmers receives Tuple{Kmer,Int} elements (N + 1 words each), out_starts unused
+    uint32_t vec16;                // out_kmers / out_starts are 16-byte aligned (16-byte stores allowed)
+};
+
+__device__ __forceinline__ unsigned long long desc_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void desc_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// bit j of the result: K unambiguous symbols begin at symbol (bit + j) of the flag stream (one bit per symbol, set =
+// ambiguous).  The window of start j spans flag bits [j, j + K): up to 64 + 127 bits for 64 starts and K <= 128.
+__device__ __forceinline__ uint64_t keep_qword(const uint64_t *amb, uint32_t bit, uint32_t k) {
+    const uint32_t Q = bit >> 6, sft = bit & 63u;
+    uint64_t lo = ~funnel64(amb[Q], amb[Q + 1], sft), mid = ~funnel64(amb[Q + 1], amb[Q + 2], sft);
+    if (k <= 65) {
+        uint32_t have = 1;
+        while (have < k) {
+            const uint32_t step = have < k - have ? have : k - have;  // 1..32: good[j..j+have) & good[j+step..j+step+have)
+            lo &= (lo >> step) | ((mid << 1) << (63u - step));
+            mid &= mid >> step;  // (the bits shifted in from beyond `mid` are never needed: have + step <= 65)
+            have += step;
+        }
+        return lo;
+    }
+    uint64_t hi = ~funnel64(amb[Q + 2], amb[Q + 3], sft);
+    uint32_t have = 1;
+    while (have < k) {
+        uint32_t step = have < k - have ? have : k - have;
+        if (step > 32u) step = 32u;
+        lo &= (lo >> step) | ((mid << 1) << (63u - step));
+        mid &= (mid >> step) | ((hi << 1) << (63u - step));
+        hi &= hi >> step;
+        have += step;
+    }
+    return lo;
+}
+
+template <int SRC_BITS, int N, int UMODE>
+__global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a) {
+    constexpr uint32_t STREAM_QWORDS = (UTILE_MAX + 128 + 64) / 32 + 4;   // 2-bit codes of the tile + its K-1 overlap
+    constexpr uint32_t AMB_QWORDS = (UTILE_MAX + 128 + 64) / 64 + 6;
+    constexpr uint32_t MAXQ = UTILE_MAX / 64;
+    __shared__ uint64_t lds[STREAM_QWORDS];
+    __shared__ uint64_t amb[AMB_QWORDS];
+    __shared__ uint64_t keepm[MAXQ];                                     // bit j of keepm[q]: start 64q + j is kept
+    __shared__ uint32_t pre[MAXQ + 1];                                   // kept starts of the tile before qword q
+    __shared__ uint16_t kept[UMODE == UMODE_COUNT ? 1 : WAVES * UROUND]; // per wavefront: the kept starts of a round
+    __shared__ uint64_t s_tile, s_base;
+    __shared__ uint32_t s_wave_total[WAVES];
+    __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if constexpr (SRC_BITS == 8) {
+        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);
+    }
+    const uint32_t k = a.k;
+    const uint64_t mask = head_mask((int)k, 2);
+    const uint32_t T = a.tile_starts;
+    uint64_t acc = 0;  // COUNT: kept starts; XOR: fold of the head words
+
+    // EMIT: one tile per workgroup, drawn from the ticket counter; COUNT / XOR: a persistent grid strides over the tiles
+    for (uint64_t it = blockIdx.x; it < a.n_tiles; it += gridDim.x) {
+        uint64_t tile = it;
+        if constexpr (UMODE == UMODE_EMIT) {
+#ifdef KMERS_UNAMB_NO_TICKET  // timing experiment only: relies on in-order dispatch
+            if (tid == 0) s_tile = it;
+#else
+            if (tid == 0) s_tile = atomicAdd(a.ticket, 1ull);
+#endif
+        }
+        block_sync();  // also: the previous tile's readers are done with the LDS arrays
+        if constexpr (UMODE == UMODE_EMIT) tile = s_tile;
+        const uint64_t m0 = tile * T;
+        const uint64_t left = a.n_cand - m0;
+        const uint32_t mt = left < T ? (uint32_t)left : T;
+        const uint64_t bit0 = a.first_bit + m0 * SRC_BITS;
+        const uint64_t w0 = bit0 >> 6;
+        const uint32_t b0 = (uint32_t)(bit0 & 63u) / SRC_BITS;
+        const uint64_t end_bit = bit0 + ((uint64_t)(mt - 1) + k) * SRC_BITS;
+        const uint32_t nw = (uint32_t)(((end_bit + 63) >> 6) - w0);
+        const uint32_t nq = (mt + 63u) >> 6;
+
+        // ---- stage: source words -> 2-bit codes + one ambiguity flag per symbol ------------------------------------
+        // (four loads per lane are in flight before the first is used: a 32768-start tile of a 4-bit source is 2050 words)
+        constexpr uint32_t PRE = 4;
+        for (uint32_t wbase = 0; wbase < nw; wbase += PRE * BLOCK) {
+            uint64_t xs[PRE];
+#pragma unroll
+            for (uint32_t j = 0; j < PRE; ++j) {
+                const uint32_t wi = wbase + tid + j * BLOCK;
+                xs[j] = wi < nw ? a.src[w0 + wi] : 0;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < PRE; ++j) {
+                const uint32_t wi = wbase + tid + j * BLOCK;
+                const uint64_t x = xs[j];
+                if (wi < nw) {
+                    if constexpr (SRC_BITS == 8) {
+                        uint32_t codes = 0, flags = 0;
+                        uint64_t f = 0;
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            uint32_t v = lut[(x >> (8 * b)) & 0xffu];
+                            codes |= (v & 3u) << (2 * b);
+                            flags |= (v >= 0xf0u ? 1u : 0u) << b;             // 0xf0: ambiguous -> skip the window
+                            f |= (uint64_t)(v == 0xffu ? 1u : 0u) << (8 * b);  // 0xff: not a nucleotide -> throw
+                        }
+                        reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)codes;
+                        reinterpret_cast<uint8_t *>(amb)[wi] = (uint8_t)flags;
+                        if (f) report_bad_symbols<8, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, w0 + wi, f, x, a.index_origin);
+                    } else if constexpr (SRC_BITS == 4) {
+                        uint64_t bad;
+                        uint32_t c = pack_4to2(x, bad);
+                        reinterpret_cast<uint32_t *>(lds)[wi] = c;
+                        reinterpret_cast<uint16_t *>(amb)[wi] = (uint16_t)bad_bits16(bad);
+                    } else {
+                        lds[wi] = x;
+                        reinterpret_cast<uint32_t *>(amb)[wi] = 0u;  // 32 symbols per 2-bit word, none ambiguous
+                    }
+                }
+            }
+        }
+        // (flag and code bits past the staged words only ever reach starts >= mt, which are masked out below)
+        block_sync();
+
+        // ---- resolve: keep mask of every candidate start, kept starts before every qword ------------------------------
+        // thread t owns qwords 2t and 2t + 1 of the keep mask (64 starts each)
+        uint32_t tile_total = 0;
+        {
+            uint32_t c2[2];
+#pragma unroll
+            for (uint32_t h = 0; h < 2; ++h) {
+                const uint32_t q = 2u * tid + h;
+                uint64_t keep = 0;
+                if (q < nq) {
+                    keep = keep_qword(amb, 64u * q + b0, k);
+                    const uint32_t valid = mt - 64u * q;  // starts of this qword that exist
+                    if (valid < 64u) keep &= (1ull << valid) - 1ull;
+                    if (a.stride > 1) {                   // keep only starts with (m0 + 64q + j) % stride == 0
+                        const uint64_t rem = (m0 + 64ull * q) % a.stride;
+                        uint64_t lat = 0;
+                        for (uint64_t pbit = rem ? a.stride - rem : 0; pbit < 64; pbit += a.stride) lat |= 1ull << pbit;
+                        keep &= lat;
+                    }
+                }
+                keepm[q] = keep;
+                c2[h] = (uint32_t)__popcll(keep);
+            }
+            const uint32_t c = c2[0] + c2[1];
+            uint32_t incl = c;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(incl, d, 64);
+                if ((int)lane >= d) incl += y;
+            }
+            if (lane == 63) s_wave_total[wave] = incl;
+            block_sync();
+            uint32_t before = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < (uint32_t)WAVES; ++w) {
+                const uint32_t wt = s_wave_total[w];
+                if (w < wave) before += wt;
+                tile_total += wt;
+            }
+            pre[2u * tid] = before + incl - c;
+            pre[2u * tid + 1u] = before + incl - c + c2[0];
+            if (tid == 0) pre[MAXQ] = tile_total;
+        }
+        if constexpr (UMODE == UMODE_COUNT) {
+            if (tid == 0) acc += tile_total;
+        }
+        if (wave == 0) {
+            if constexpr (UMODE == UMODE_EMIT) {
+                // ---- publish the aggregate, look back for the exclusive prefix, publish the inclusive prefix -------
+                uint64_t excl = 0;
+#ifdef KMERS_UNAMB_NO_LOOKBACK  // timing experiment only: positions are wrong
+                if (true) {
+                    excl = (m0 / 4) % (a.capacity > 2 * UTILE_MAX ? a.capacity - 2 * UTILE_MAX : 1);
+                    if (lane == 0) desc_store(a.desc + tile, DESC_PREFIX | (uint64_t)tile_total);
+                } else
+#endif
+                if (tile == 0) {
+                    if (lane == 0) desc_store(a.desc, DESC_PREFIX | (uint64_t)tile_total);
+                } else {
+                    if (lane == 0) desc_store(a.desc + tile, DESC_AGGREGATE | (uint64_t)tile_total);
+                    long long pos = (long long)tile - 1;  // the nearest predecessor not yet accounted for
+                    uint64_t part = 0;                    // this lane's share of the sum
+                    for (;;) {
+                        // 64 descriptors per step, lane l the l-th nearest; before tile 0: prefix 0
+                        const long long idx = pos - (long long)lane;
+                        uint64_t e = idx >= 0 ? desc_load(a.desc + idx) : DESC_PREFIX;
+                        uint32_t fp;
+                        for (;;) {
+                            const uint32_t st = (uint32_t)(e >> 62);
+                            const uint64_t bp = __ballot(st == 2u);
+                            fp = bp ? (uint32_t)__builtin_ctzll(bp) : 64u;               // the nearest prefix of this step
+                            const bool wait = st == 0u && lane < fp;                      // a nearer tile has not published yet
+                            if (__ballot(wait) == 0) break;
+                            __builtin_amdgcn_s_sleep(8);
+                            if (wait) e = desc_load(a.desc + idx);                        // only the missing ones are read again
+                        }
+                        if (lane <= fp) part += e & DESC_VALUE;  // aggregates up to and including the prefix
+                        if (fp < 64u) break;
+                        pos -= 64;
+                    }
+                    excl = wave_sum64(part);
+                    if (lane == 0) desc_store(a.desc + tile, DESC_PREFIX | ((excl + (uint64_t)tile_total) & DESC_VALUE));
+                }
+                if (lane == 0) s_base = excl;
+            }
+        }
+        if constexpr (UMODE == UMODE_COUNT) continue;  // (the loop's first barrier protects the LDS arrays)
+        block_sync();
+        const uint64_t base = UMODE == UMODE_EMIT ? s_base : 0;
+
+        // ---- emit: wavefront w takes rounds w, w + WAVES, ... of 1024 candidate starts -------------------------------
+        uint16_t *mine = kept + wave * UROUND;
+        for (uint32_t r_begin = wave * UROUND; r_begin < mt; r_begin += WAVES * UROUND) {
+            const uint32_t n_round = mt - r_begin < UROUND ? mt - r_begin : UROUND;
+            const uint32_t q0 = r_begin >> 6;
+            const uint32_t q = q0 + (lane >> 2), sl = 16u * (lane & 3u);
+            const uint64_t km = q < nq ? keepm[q] : 0;
+            uint32_t keep16 = (uint32_t)(km >> sl) & 0xffffu;
+            const uint32_t round_off = pre[q0];
+            const uint32_t q1 = q0 + 16u;
+            const uint32_t cnt = (q1 < nq ? pre[q1] : pre[MAXQ]) - round_off;  // kept starts of this round
+            uint64_t pos = base + round_off;                                    // output index of the round's first
+            if (cnt == 0) continue;
+            const uint64_t origin = m0 + 1 + a.index_origin;                     // start of candidate r is origin + r
+            if constexpr (N == 1 && UMODE == UMODE_EMIT) {
+                // Dense round (every one of its starts is kept -- the normal state of real sequence outside its N
+                // blocks): no list; two consecutive kmers per lane (the second by the reference's rolling step,
+                // construction_utils.jl:129-134) and 16-byte stores aligned to the parity of the output position.
+                if (cnt == n_round && a.vec16 && !a.tuples && pos + cnt <= a.capacity) {
+                    const uint32_t head = (uint32_t)(pos & 1u);
+                    auto single = [&](uint32_t e) {
+                        uint64_t fw[1], rc[1];
+                        window<1, 2>(lds, 2u * (r_begin + e + b0), k, mask, fw, rc);
+                        if (a.out_kmers) a.out_kmers[pos + e] = fw[0];
+                        if (a.out_starts) a.out_starts[pos + e] = (long long)(origin + r_begin + e);
+                    };
+                    if (head && lane == 0) single(0);
+                    const uint32_t pairs = (cnt - head) >> 1;
+                    for (uint32_t i = lane; i < pairs; i += 64u) {
+                        const uint32_t e = head + 2u * i;
+                        uint64_t f0, r0, sym;
+                        window1_and_next<2>(lds, 2u * (r_begin + e + b0), k, mask, f0, r0, sym);
+                        const uint64_t f1 = ((f0 << 2) | sym) & mask;
+                        if (a.out_kmers) *reinterpret_cast<ulonglong2 *>(a.out_kmers + pos + e) = make_ulonglong2(f0, f1);
+                        if (a.out_starts)
+                            *reinterpret_cast<ulonglong2 *>(a.out_starts + pos + e) =
+                                make_ulonglong2(origin + r_begin + e, origin + r_begin + e + 1);
+                    }
+                    if (((cnt - head) & 1u) && lane == 0) single(cnt - 1);
+                    continue;
+                }
+            }
+            // list the kept starts of the round in LDS, in order: this lane's slice of 16 starts begins at list index o
+            uint32_t o = pre[q] - round_off + (uint32_t)__popcll(km & ((1ull << sl) - 1ull));
+            const uint32_t s0 = (lane << 4);  // round-relative index of the slice's first start
+            while (keep16) {
+                mine[o++] = (uint16_t)(s0 + (uint32_t)__builtin_ctz(keep16));
+                keep16 &= keep16 - 1u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < cnt; i += 64u) {
+                const uint32_t r = r_begin + (uint32_t)mine[i];
+                uint64_t fw[N], rc[N];
+                window<N, 2>(lds, 2u * (r + b0), k, mask, fw, rc);
+                if constexpr (UMODE == UMODE_XOR) {
+                    acc ^= fw[0];
+                } else {
+                    const uint64_t o2 = pos + i;
+                    if (o2 < a.capacity) {
+                        if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
+#pragma unroll
+                            for (int wd = 0; wd < N; ++wd) a.out_kmers[o2 * (N + 1) + wd] = fw[wd];
+                            a.out_kmers[o2 * (N + 1) + N] = origin + r;
+                        } else {
+                            if (a.out_kmers) {
+#pragma unroll
+                                for (int wd = 0; wd < N; ++wd) a.out_kmers[o2 * N + wd] = fw[wd];
+                            }
+                            if (a.out_starts) a.out_starts[o2] = (long long)(origin + r);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next round
+        }
+    }
+    if constexpr (UMODE == UMODE_COUNT) {
+        if (tid == 0 && acc) atomicAdd(a.total, (unsigned long long)acc);
+    }
+    if constexpr (UMODE == UMODE_XOR) {
+        for (int off = 32; off > 0; off >>= 1) acc ^= __shfl_xor(acc, off, 64);
+        if (lane == 0 && acc) atomicXor(a.total, (unsigned long long)acc);
+    }
+}
+
+// ---- exclusive scan of n 32-bit counts into 64-bit offsets (offsets[n] = total): the layout pass of kmers_batch ----
+// Three coalesced kernels: per-segment sums -> scan of the segment sums (one workgroup) ->
+// per-segment rescan with the segment's base.  A segment is SCAN_SEG consecutive counts.
+constexpr uint32_t SCAN_SEG = 2048;  // 256 threads x 8
+
+__device__ __forceinline__ uint64_t block_reduce_sum(uint64_t v, uint64_t *tmp) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63u) == 0) tmp[threadIdx.x >> 6] = v;
+    block_sync();
+    uint64_t total = 0;
+    for (uint32_t w = 0; w < blockDim.x / 64; ++w) total += tmp[w];
+    block_sync();
+    return total;
+}
+
+__global__ __launch_bounds__(256) void scan_segment_sums_kernel(const uint32_t *__restrict__ counts, uint64_t n,
+                                                                 uint64_t *__restrict__ seg_sums) {
+    __shared__ uint64_t tmp[4];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_SEG;
+    uint64_t v = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_SEG / 256; ++j) {
+        uint64_t i = base + threadIdx.x + 256u * j;
+        if (i < n) v += counts[i];
+    }
+    uint64_t total = block_reduce_sum(v, tmp);
+    if (threadIdx.x == 0) seg_sums[blockIdx.x] = total;
+}
+
+// in-place exclusive scan of the segment sums; seg_sums[n_seg] = grand total
+__global__ __launch_bounds__(1024) void scan_segments_kernel(uint64_t *__restrict__ seg_sums, uint64_t n_seg) {
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint64_t chunk = (n_seg + 1023) / 1024;
+    const uint64_t lo = (uint64_t)t * chunk < n_seg ? (uint64_t)t * chunk : n_seg, hi = lo + chunk < n_seg ? lo + chunk : n_seg;
+    uint64_t s = 0;
+    for (uint64_t i = lo; i < hi; ++i) s += seg_sums[i];
+    part[t] = s;
+    block_sync();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan of the partials
+        uint64_t v = t >= d ? part[t - d] : 0;
+        block_sync();
+        part[t] += v;
+        block_sync();
+    }
+    uint64_t run = t ? part[t - 1] : 0;
+    for (uint64_t i = lo; i < hi; ++i) {
+        uint64_t c = seg_sums[i];
+        seg_sums[i] = run;
+        run += c;
+    }
+    if (t == 1023) seg_sums[n_seg] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restrict__ counts, uint64_t n,
+                                                          const uint64_t *__restrict__ seg_sums, uint64_t n_seg,
+                                                          uint64_t *__restrict__ offsets) {
+    __shared__ uint32_t c[SCAN_SEG];
+    __shared__ uint64_t wave_tot[4];
+    const uint32_t t = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_SEG;
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_SEG / 256; ++j) {
+        uint64_t i = base + t + 256u * j;
+        c[t + 256u * j] = i < n ? counts[i] : 0u;
+    }
+    block_sync();
+    // thread t owns 8 consecutive counts: local exclusive prefix, then a scan over the thread totals
+    uint64_t local[SCAN_SEG / 256];  // 64-bit: kmers_batch scans per-record counts of up to 2^32 - 1
+    uint64_t sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_SEG / 256; ++j) {
+        local[j] = sum;
+        sum += c[t * (SCAN_SEG / 256) + j];
+    }
+    uint64_t incl = sum;
+    const uint32_t lane = t & 63u, wave = t >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint64_t v = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    block_sync();
+    uint64_t before = seg_sums[blockIdx.x];
+    for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
+    const uint64_t excl = before + incl - sum;
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_SEG / 256; ++j) {
+        uint64_t i = base + (uint64_t)t * (SCAN_SEG / 256) + j;
+        if (i < n) offsets[i] = excl + local[j];
+    }
+    if (blockIdx.x == 0 && t == 0) offsets[n] = seg_sums[n_seg];
+}
+
+}  // namespace kmers

@@ -40,12 +40,13 @@ def main():
     ap.add_argument("--no-hash", action="store_true")
     ap.add_argument("--prefetch", default="0", help="prefetch distances in tiles")
     ap.add_argument("--b-offsets", default="0", help="byte offsets of the second output array inside its allocation")
-    ap.add_argument("--mode", default="canonical", choices=["canonical", "fw", "fwrc"])
+    ap.add_argument("--mode", default="canonical", choices=["canonical", "fw", "fwrc", "spaced"])
+    ap.add_argument("--stride", type=int, default=3)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     K, bits, L = a.k, a.src_bits, a.bases
-    n = L - K + 1
+    n = L - K + 1 if a.mode != "spaced" else (L - K) // a.stride + 1
     N = (2 * K + 63) // 64
     nw = (L * bits + 63) // 64
     variants = []
@@ -64,10 +65,12 @@ def main():
     assert lib0.kmers_synth_dna(h0, 12345, 0, nw, bits, 0, buf.data_ptr()) == 0
     out_a = torch.empty(n * N, dtype=torch.int64, device=dev)
     max_off = max(int(o) for o in a.b_offsets.split(","))
-    out_b = None if (a.no_hash or a.mode == "fw") else torch.empty(n * (N if a.mode == "fwrc" else 1) + max_off // 8 + 2, dtype=torch.int64, device=dev)
+    out_b = None if (a.no_hash or a.mode in ("fw", "spaced")) else torch.empty(n * (N if a.mode == "fwrc" else 1) + max_off // 8 + 2, dtype=torch.int64, device=dev)
     seq = cap.Seq(buf.data_ptr(), L, 0, 0, bits, 0)
     res = cap.Result()
     bpk = bits / 8 + 8 * N + (0 if out_b is None else (8 * N if a.mode == "fwrc" else 8))
+    if a.mode == "spaced":
+        bpk = bits / 8 * a.stride + 8 * N
     times = {i: [] for i in range(len(variants))}
     for rnd in range(a.rounds + 1):
         for i, (name, lib, h, t, g, off, pf) in enumerate(variants):
@@ -78,7 +81,9 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record(stream)
-            if a.mode == "canonical":
+            if a.mode == "spaced":
+                rc = lib.kmers_spaced(h, C.byref(seq), K, a.stride, 2, out_a.data_ptr(), cap.MEM_DEVICE | cap.ASYNC, C.byref(res))
+            elif a.mode == "canonical":
                 rc = lib.kmers_canonical(h, C.byref(seq), K, 2, out_a.data_ptr(), pb, 0, cap.MEM_DEVICE | cap.ASYNC, C.byref(res))
             else:
                 rc = lib.kmers_fw(h, C.byref(seq), K, 2, out_a.data_ptr(), pb, cap.MEM_DEVICE | cap.ASYNC, C.byref(res))
