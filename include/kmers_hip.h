@@ -154,7 +154,7 @@ int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, 
 /* The same reducer over the other iterators of test/benchmark.jl:35-94 (`y ⊻= kmer.data[1]`, for
  * UnambiguousKmers `first(x).data[1]`): iter = KMERS_ITER_FW / _CANONICAL (stride ignored),
  * KMERS_ITER_SPACED (SpacedKmers{A,K,stride}, strict; stride * dst_bits <= 64) or
- * KMERS_ITER_UNAMBIGUOUS (2-bit kmers, K <= 64; stride = 1 is the reference iterator). */
+ * KMERS_ITER_UNAMBIGUOUS (2-bit kmers; stride = 1 is the reference iterator). */
 #define KMERS_ITER_FW 0
 #define KMERS_ITER_CANONICAL 1
 #define KMERS_ITER_SPACED 2

@@ -389,6 +389,7 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.tile_starts = unambiguous_tile(ctx);
     a.n_tiles = (n + a.tile_starts - 1) / a.tile_starts;
     a.tuples = tuples ? 1u : 0u;
+    a.stamps = reinterpret_cast<uint64_t *>(ctx->stamps_ptr);
     const uint64_t cap_grid = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
 
     // a 2-bit source has no ambiguous symbols: every start survives, nothing to resolve

@@ -9,7 +9,7 @@
 //   tile     a workgroup draws a ticket (tiles are numbered in the order workgroups start), stages its source words once,
 //            resolves all of its candidate starts bit-parallel (64 starts per lane: the "good" bits AND-ed with themselves
 //            shifted by 1, 2, 4, ...), and publishes its kept count as an AGGREGATE in its tile descriptor;
-//   look-back   one wavefront then sums the descriptors of the preceding tiles, nearest first, 64 per step, until it meets
+//   look-back   one wavefront then sums the descriptors of the preceding tiles, nearest first, 256 per step, until it meets
 //            one that already holds an inclusive PREFIX (decoupled look-back: it never waits for a predecessor's prefix,
 //            only for aggregates, which every started tile publishes unconditionally -- no circular wait), publishes its
 //            own inclusive prefix and hands the exclusive one to the workgroup;
@@ -25,10 +25,18 @@
 
 namespace kmers {
 
-constexpr uint32_t UTILE_MAX = 32768;    // candidate starts per tile (a multiple of 1024), at most
-constexpr uint32_t UROUND = 1024;        // starts per wavefront round (16 per lane)
+#ifndef KMERS_UTILE_MAX
+#define KMERS_UTILE_MAX 32768
+#endif
+constexpr uint32_t UTILE_MAX = KMERS_UTILE_MAX;  // candidate starts per tile (a multiple of 1024), at most
+#ifndef KMERS_UROUND
+#define KMERS_UROUND 1024
+#endif
+constexpr uint32_t UROUND = KMERS_UROUND;  // starts per wavefront round (16 or 8 per lane)
+constexpr uint32_t USLICE = UROUND / 64;  // consecutive starts per lane
 constexpr uint64_t DESC_VALUE = (1ull << 62) - 1ull;
 constexpr uint64_t DESC_AGGREGATE = 1ull << 62, DESC_PREFIX = 2ull << 62;
+constexpr int LOOKBACK = 4;               // descriptors per lane and look-back step (256 tiles per step)
         // descriptors per lane and look-back step (256 per step)
 
 enum UMode { UMODE_EMIT = 0, UMODE_COUNT = 1, UMODE_XOR = 2 };
@@ -53,6 +61,7 @@ struct UnambArgs {
     uint32_t ascii_table;          // SRC_BITS == 8: ASCII_TABLE_SKIPPING = the reference's ASCII_SKIPPING_LUT (common.jl:22-32)
     uint32_t tuples;               // 1: out_kmers receives Tuple{Kmer,Int} elements (N + 1 words each), out_starts unused
     uint32_t vec16;                // out_kmers / out_starts are 16-byte aligned (16-byte stores allowed)
+    uint64_t *stamps;              // diagnostic builds (-DKMERS_STAMPS) only: 8 s_memrealtime stamps per tile
 };
 
 __device__ __forceinline__ unsigned long long desc_load(const unsigned long long *p) {
@@ -94,6 +103,28 @@ __device__ __forceinline__ uint64_t keep_qword(const uint64_t *amb, uint32_t bit
     return lo;
 }
 
+// This kernel only ever needs FORWARD kmers, so it stages the 2-bit codes of a tile in KMER order: symbol i of the staged
+// words sits at bits [B - 2 - 2i, B - 2i) of the LDS stream (B = its length in bits), i.e. later symbols in LOWER bits,
+// exactly like Kmer's big-endian layout (src/kmer.jl:32-44).  The kmer of the window whose first symbol is i is then the
+// 2K bits at bit B - 2(i + K): one funnel shift and the head mask -- the same value as K applications of shift_encoding
+// (construction_utils.jl:129-134), with no per-kmer symbol reversal.
+__device__ __forceinline__ uint32_t rev2_32(uint32_t x) {  // reverse the order of the 16 two-bit symbols of a dword
+    const uint32_t r = __brev(x);
+    return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+template <int N>
+__device__ __forceinline__ void cut_fw(const uint64_t *rs, uint32_t o, uint64_t mask, uint64_t (&fw)[N]) {
+    const uint32_t q = o >> 6, sh = o & 63u;
+    uint64_t lo = rs[q];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {  // word N-1-j of the kmer = stream bits [o + 64j, o + 64j + 64)
+        const uint64_t hi = rs[q + j + 1];
+        fw[N - 1 - j] = funnel64(lo, hi, sh);
+        lo = hi;
+    }
+    fw[0] &= mask;
+}
+
 template <int SRC_BITS, int N, int UMODE>
 __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a) {
     constexpr uint32_t STREAM_QWORDS = (UTILE_MAX + 128 + 64) / 32 + 4;   // 2-bit codes of the tile + its K-1 overlap
@@ -103,7 +134,11 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
     __shared__ uint64_t amb[AMB_QWORDS];
     __shared__ uint64_t keepm[MAXQ];                                     // bit j of keepm[q]: start 64q + j is kept
     __shared__ uint32_t pre[MAXQ + 1];                                   // kept starts of the tile before qword q
-    __shared__ uint16_t kept[UMODE == UMODE_COUNT ? 1 : WAVES * UROUND]; // per wavefront: the kept starts of a round
+    // per wavefront: the kept starts of a round.  512-start rounds fit the flag stream's space, which is dead once the tile is
+    // resolved (8 workgroups per CU instead of 5)
+    constexpr bool LIST_IN_AMB = WAVES * UROUND * 2 <= AMB_QWORDS * 8;
+    __shared__ uint16_t kept_own[(UMODE == UMODE_COUNT || LIST_IN_AMB) ? 1 : WAVES * UROUND];
+    uint16_t *const kept = LIST_IN_AMB ? reinterpret_cast<uint16_t *>(amb) : kept_own;
     __shared__ uint64_t s_tile, s_base;
     __shared__ uint32_t s_wave_total[WAVES];
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
@@ -119,15 +154,19 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
     // EMIT: one tile per workgroup, drawn from the ticket counter; COUNT / XOR: a persistent grid strides over the tiles
     for (uint64_t it = blockIdx.x; it < a.n_tiles; it += gridDim.x) {
         uint64_t tile = it;
-        if constexpr (UMODE == UMODE_EMIT) {
-#ifdef KMERS_UNAMB_NO_TICKET  // timing experiment only: relies on in-order dispatch
-            if (tid == 0) s_tile = it;
+#ifdef KMERS_STAMPS
+        uint64_t ts[8];
+        ts[0] = __builtin_amdgcn_s_memrealtime();
+#define USTAMP(i) ts[i] = __builtin_amdgcn_s_memrealtime()
 #else
-            if (tid == 0) s_tile = atomicAdd(a.ticket, 1ull);
+#define USTAMP(i)
 #endif
+        if constexpr (UMODE == UMODE_EMIT) {
+            if (tid == 0) s_tile = atomicAdd(a.ticket, 1ull);
         }
         block_sync();  // also: the previous tile's readers are done with the LDS arrays
         if constexpr (UMODE == UMODE_EMIT) tile = s_tile;
+        USTAMP(1);  // ticket drawn
         const uint64_t m0 = tile * T;
         const uint64_t left = a.n_cand - m0;
         const uint32_t mt = left < T ? (uint32_t)left : T;
@@ -137,10 +176,12 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
         const uint64_t end_bit = bit0 + ((uint64_t)(mt - 1) + k) * SRC_BITS;
         const uint32_t nw = (uint32_t)(((end_bit + 63) >> 6) - w0);
         const uint32_t nq = (mt + 63u) >> 6;
+        const uint32_t kbit0 = nw * (128u / SRC_BITS) - 2u * (b0 + k);  // the kmer of tile start r sits at stream bit kbit0 - 2r
 
         // ---- stage: source words -> 2-bit codes + one ambiguity flag per symbol ------------------------------------
-        // (four loads per lane are in flight before the first is used: a 32768-start tile of a 4-bit source is 2050 words)
-        constexpr uint32_t PRE = 4;
+        // (all of a lane's loads are in flight before the first is used -- a 32768-start tile of a 4-bit source is 2050
+        // words, nine per lane -- so that a tile pays one memory latency; byte sources take two such batches)
+        constexpr uint32_t PRE = 9;
         for (uint32_t wbase = 0; wbase < nw; wbase += PRE * BLOCK) {
             uint64_t xs[PRE];
 #pragma unroll
@@ -163,23 +204,25 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
                             flags |= (v >= 0xf0u ? 1u : 0u) << b;             // 0xf0: ambiguous -> skip the window
                             f |= (uint64_t)(v == 0xffu ? 1u : 0u) << (8 * b);  // 0xff: not a nucleotide -> throw
                         }
-                        reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)codes;
+                        reinterpret_cast<uint16_t *>(lds)[nw - 1u - wi] = (uint16_t)(rev2_32(codes) >> 16);
                         reinterpret_cast<uint8_t *>(amb)[wi] = (uint8_t)flags;
                         if (f) report_bad_symbols<8, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, w0 + wi, f, x, a.index_origin);
                     } else if constexpr (SRC_BITS == 4) {
                         uint64_t bad;
                         uint32_t c = pack_4to2(x, bad);
-                        reinterpret_cast<uint32_t *>(lds)[wi] = c;
+                        reinterpret_cast<uint32_t *>(lds)[nw - 1u - wi] = rev2_32(c);
                         reinterpret_cast<uint16_t *>(amb)[wi] = (uint16_t)bad_bits16(bad);
                     } else {
-                        lds[wi] = x;
+                        lds[nw - 1u - wi] = rev2(x);
                         reinterpret_cast<uint32_t *>(amb)[wi] = 0u;  // 32 symbols per 2-bit word, none ambiguous
                     }
                 }
             }
         }
         // (flag and code bits past the staged words only ever reach starts >= mt, which are masked out below)
+        USTAMP(2);  // this wavefront's source words staged
         block_sync();
+        USTAMP(3);  // everybody's
 
         // ---- resolve: keep mask of every candidate start, kept starts before every qword ------------------------------
         // thread t owns qwords 2t and 2t + 1 of the keep mask (64 starts each)
@@ -226,39 +269,47 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
         if constexpr (UMODE == UMODE_COUNT) {
             if (tid == 0) acc += tile_total;
         }
+        USTAMP(4);  // keep mask and prefix of the tile resolved
         if (wave == 0) {
             if constexpr (UMODE == UMODE_EMIT) {
                 // ---- publish the aggregate, look back for the exclusive prefix, publish the inclusive prefix -------
                 uint64_t excl = 0;
-#ifdef KMERS_UNAMB_NO_LOOKBACK  // timing experiment only: positions are wrong
-                if (true) {
-                    excl = (m0 / 4) % (a.capacity > 2 * UTILE_MAX ? a.capacity - 2 * UTILE_MAX : 1);
-                    if (lane == 0) desc_store(a.desc + tile, DESC_PREFIX | (uint64_t)tile_total);
-                } else
-#endif
                 if (tile == 0) {
                     if (lane == 0) desc_store(a.desc, DESC_PREFIX | (uint64_t)tile_total);
                 } else {
                     if (lane == 0) desc_store(a.desc + tile, DESC_AGGREGATE | (uint64_t)tile_total);
+                    // Every step reads LOOKBACK descriptors per lane, all loads in flight together: the step must cover the
+                    // tiles that started within one look-back time (about 20 tiles per microsecond here, and a descriptor read
+                    // takes 2-3 us under load), or the distance to the nearest published prefix grows without bound.
                     long long pos = (long long)tile - 1;  // the nearest predecessor not yet accounted for
                     uint64_t part = 0;                    // this lane's share of the sum
-                    for (;;) {
-                        // 64 descriptors per step, lane l the l-th nearest; before tile 0: prefix 0
-                        const long long idx = pos - (long long)lane;
-                        uint64_t e = idx >= 0 ? desc_load(a.desc + idx) : DESC_PREFIX;
-                        uint32_t fp;
-                        for (;;) {
-                            const uint32_t st = (uint32_t)(e >> 62);
-                            const uint64_t bp = __ballot(st == 2u);
-                            fp = bp ? (uint32_t)__builtin_ctzll(bp) : 64u;               // the nearest prefix of this step
-                            const bool wait = st == 0u && lane < fp;                      // a nearer tile has not published yet
-                            if (__ballot(wait) == 0) break;
-                            __builtin_amdgcn_s_sleep(8);
-                            if (wait) e = desc_load(a.desc + idx);                        // only the missing ones are read again
+                    bool found = false;
+                    while (!found) {
+                        uint64_t e[LOOKBACK];
+#pragma unroll
+                        for (int j = 0; j < LOOKBACK; ++j) {  // chunk j: the 64 tiles pos - 64j - lane; before tile 0: prefix 0
+                            const long long idx = pos - (long long)(lane + 64u * (uint32_t)j);
+                            e[j] = idx >= 0 ? desc_load(a.desc + idx) : DESC_PREFIX;
                         }
-                        if (lane <= fp) part += e & DESC_VALUE;  // aggregates up to and including the prefix
-                        if (fp < 64u) break;
-                        pos -= 64;
+#pragma unroll
+                        for (int j = 0; j < LOOKBACK; ++j) {
+                            if (!found) {
+                                const long long idx = pos - (long long)(lane + 64u * (uint32_t)j);
+                                uint32_t fp;
+                                for (;;) {
+                                    const uint32_t st = (uint32_t)(e[j] >> 62);
+                                    const uint64_t bp = __ballot(st == 2u);
+                                    fp = bp ? (uint32_t)__builtin_ctzll(bp) : 64u;      // the nearest prefix of this chunk
+                                    const bool wait = st == 0u && lane < fp;             // a nearer tile has not published yet
+                                    if (__ballot(wait) == 0) break;
+                                    __builtin_amdgcn_s_sleep(8);
+                                    if (wait) e[j] = desc_load(a.desc + idx);            // only the missing ones are read again
+                                }
+                                if (lane <= fp) part += e[j] & DESC_VALUE;  // aggregates up to and including the prefix
+                                found = fp < 64u;
+                            }
+                        }
+                        pos -= 64 * LOOKBACK;
                     }
                     excl = wave_sum64(part);
                     if (lane == 0) desc_store(a.desc + tile, DESC_PREFIX | ((excl + (uint64_t)tile_total) & DESC_VALUE));
@@ -267,19 +318,25 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
             }
         }
         if constexpr (UMODE == UMODE_COUNT) continue;  // (the loop's first barrier protects the LDS arrays)
+        USTAMP(5);  // (wavefront 0) look-back done
         block_sync();
+        USTAMP(6);  // base known to everybody
         const uint64_t base = UMODE == UMODE_EMIT ? s_base : 0;
 
         // ---- emit: wavefront w takes rounds w, w + WAVES, ... of 1024 candidate starts -------------------------------
         uint16_t *mine = kept + wave * UROUND;
-        for (uint32_t r_begin = wave * UROUND; r_begin < mt; r_begin += WAVES * UROUND) {
+        // every wavefront takes a CONTIGUOUS quarter of the tile's rounds, so that its stores sweep one contiguous region
+        // of each output array (partial first / last lines only where two wavefronts' regions meet)
+        const uint32_t rounds_per_wave = ((mt + UROUND - 1u) / UROUND + WAVES - 1u) / WAVES;
+        const uint32_t wave_end = (wave + 1u) * rounds_per_wave * UROUND < mt ? (wave + 1u) * rounds_per_wave * UROUND : mt;
+        for (uint32_t r_begin = wave * rounds_per_wave * UROUND; r_begin < wave_end; r_begin += UROUND) {
             const uint32_t n_round = mt - r_begin < UROUND ? mt - r_begin : UROUND;
             const uint32_t q0 = r_begin >> 6;
-            const uint32_t q = q0 + (lane >> 2), sl = 16u * (lane & 3u);
+            const uint32_t q = q0 + lane / (64u / USLICE), sl = USLICE * (lane % (64u / USLICE));
             const uint64_t km = q < nq ? keepm[q] : 0;
-            uint32_t keep16 = (uint32_t)(km >> sl) & 0xffffu;
+            uint32_t keep16 = (uint32_t)(km >> sl) & ((1u << USLICE) - 1u);
             const uint32_t round_off = pre[q0];
-            const uint32_t q1 = q0 + 16u;
+            const uint32_t q1 = q0 + UROUND / 64u;
             const uint32_t cnt = (q1 < nq ? pre[q1] : pre[MAXQ]) - round_off;  // kept starts of this round
             uint64_t pos = base + round_off;                                    // output index of the round's first
             if (cnt == 0) continue;
@@ -291,8 +348,8 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
                 if (cnt == n_round && a.vec16 && !a.tuples && pos + cnt <= a.capacity) {
                     const uint32_t head = (uint32_t)(pos & 1u);
                     auto single = [&](uint32_t e) {
-                        uint64_t fw[1], rc[1];
-                        window<1, 2>(lds, 2u * (r_begin + e + b0), k, mask, fw, rc);
+                        uint64_t fw[1];
+                        cut_fw<1>(lds, kbit0 - 2u * (r_begin + e), mask, fw);
                         if (a.out_kmers) a.out_kmers[pos + e] = fw[0];
                         if (a.out_starts) a.out_starts[pos + e] = (long long)(origin + r_begin + e);
                     };
@@ -300,9 +357,10 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
                     const uint32_t pairs = (cnt - head) >> 1;
                     for (uint32_t i = lane; i < pairs; i += 64u) {
                         const uint32_t e = head + 2u * i;
-                        uint64_t f0, r0, sym;
-                        window1_and_next<2>(lds, 2u * (r_begin + e + b0), k, mask, f0, r0, sym);
-                        const uint64_t f1 = ((f0 << 2) | sym) & mask;
+                        uint64_t fa[1], fb[1];
+                        cut_fw<1>(lds, kbit0 - 2u * (r_begin + e), mask, fa);
+                        cut_fw<1>(lds, kbit0 - 2u * (r_begin + e + 1u), mask, fb);
+                        const uint64_t f0 = fa[0], f1 = fb[0];
                         if (a.out_kmers) *reinterpret_cast<ulonglong2 *>(a.out_kmers + pos + e) = make_ulonglong2(f0, f1);
                         if (a.out_starts)
                             *reinterpret_cast<ulonglong2 *>(a.out_starts + pos + e) =
@@ -314,17 +372,18 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
             }
             // list the kept starts of the round in LDS, in order: this lane's slice of 16 starts begins at list index o
             uint32_t o = pre[q] - round_off + (uint32_t)__popcll(km & ((1ull << sl) - 1ull));
-            const uint32_t s0 = (lane << 4);  // round-relative index of the slice's first start
+            const uint32_t s0 = lane * USLICE;  // round-relative index of the slice's first start
             while (keep16) {
                 mine[o++] = (uint16_t)(s0 + (uint32_t)__builtin_ctz(keep16));
                 keep16 &= keep16 - 1u;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = lane; i < cnt; i += 64u) {
+            // one listed element: window cut + stores (also the generic path: tuples, unaligned outputs, the XOR reducer)
+            auto emit_one = [&](uint32_t i) {
                 const uint32_t r = r_begin + (uint32_t)mine[i];
-                uint64_t fw[N], rc[N];
-                window<N, 2>(lds, 2u * (r + b0), k, mask, fw, rc);
+                uint64_t fw[N];
+                cut_fw<N>(lds, kbit0 - 2u * r, mask, fw);
                 if constexpr (UMODE == UMODE_XOR) {
                     acc ^= fw[0];
                 } else {
@@ -343,10 +402,53 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
                         }
                     }
                 }
+            };
+            bool paired = false;
+            if constexpr (UMODE == UMODE_EMIT) {
+                // Two listed elements per lane and 16-byte stores (8-byte stores per lane cap this device near 4 TB/s,
+                // 16-byte ones reach 6.4; MI355X_MICROARCH.md, profiles/r02_tuning.md): the pair starts at an even output
+                // index, an odd first / last element goes alone.
+                paired = a.vec16 && !a.tuples && pos + cnt <= a.capacity;
+                if (paired) {
+                    const uint32_t head = (uint32_t)(pos & 1u);
+                    if (head && lane == 0) emit_one(0);
+                    const uint32_t pairs = (cnt - head) >> 1;
+                    for (uint32_t i = lane; i < pairs; i += 64u) {
+                        const uint32_t e = head + 2u * i;
+                        const uint32_t ra = r_begin + (uint32_t)mine[e], rb = r_begin + (uint32_t)mine[e + 1u];
+                        uint64_t fa[N], fb[N];
+                        cut_fw<N>(lds, kbit0 - 2u * ra, mask, fa);
+                        cut_fw<N>(lds, kbit0 - 2u * rb, mask, fb);
+                        const uint64_t o2 = pos + e;  // even
+                        if (a.out_kmers) {
+                            if constexpr (N == 1) {
+                                *reinterpret_cast<ulonglong2 *>(a.out_kmers + o2) = make_ulonglong2(fa[0], fb[0]);
+                            } else {
+                                store_kmer<N>(a.out_kmers, o2, fa);
+                                store_kmer<N>(a.out_kmers, o2 + 1, fb);
+                            }
+                        }
+                        if (a.out_starts) *reinterpret_cast<ulonglong2 *>(a.out_starts + o2) = make_ulonglong2(origin + ra, origin + rb);
+                    }
+                    if (((cnt - head) & 1u) && lane == 0) emit_one(cnt - 1u);
+                }
+            }
+            if (!paired) {
+                for (uint32_t i = lane; i < cnt; i += 64u) emit_one(i);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next round
         }
+#ifdef KMERS_STAMPS
+        USTAMP(7);  // this wavefront's stores issued
+        if (a.stamps && (tile & 15u) == 0 && lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint64_t *o = a.stamps + ((tile >> 4) * WAVES + wave) * 10;
+            for (int i = 0; i < 8; ++i) o[i] = ts[i];
+            o[8] = __builtin_amdgcn_s_memrealtime();  // ... and drained
+            o[9] = tile;
+        }
+#endif
     }
     if constexpr (UMODE == UMODE_COUNT) {
         if (tid == 0 && acc) atomicAdd(a.total, (unsigned long long)acc);

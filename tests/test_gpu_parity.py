@@ -429,7 +429,7 @@ def test_unambiguous_device_outputs_any_alignment(km, ctx, orc):
 def test_unambiguous_parity(km, ctx, orc):
     """UnambiguousKmers (UnambiguousKmers.jl:64-77, :134-148): windows and 1-based starts."""
     rng = np.random.default_rng(31)
-    for K in (1, 3, 21, 31, 32, 33, 64):
+    for K in (1, 3, 21, 31, 32, 33, 64, 65, 96, 97, 128):
         for L in (K - 1, K, 300, 5000, 33000):
             if L < 0:
                 continue
@@ -445,6 +445,53 @@ def test_unambiguous_parity(km, ctx, orc):
             kmers, starts = run_unambiguous(km, ctx, words, L, 2, K)
             ek, es, _ = orc.unambiguous(words, L, 2, K)
             assert np.array_equal(kmers, ek) and np.array_equal(starts, es)
+
+
+def test_unambiguous_single_pass_device_path(km, ctx, orc):
+    """The one-pass kernel proper (device outputs: no count pass): tile descriptors + look-back across many tiles, every
+    tile size, workgroups that draw several tickets (capped grid), kmers of one to four words, stride lattices, and the
+    capacity contract: nothing is written at or beyond `capacity`, KMERS_E_CAPACITY reports the count needed."""
+    cap = km._capi
+    rng = np.random.default_rng(131)
+    L = 300_017
+    guard = np.uint64(0xDEADBEEFDEADBEEF)
+    for p_amb in (0.04, 0.0005, 0.5):
+        text = naive.random_text(rng, L, p_amb=p_amb)
+        words = naive.longseq_words(text, 4)
+        d_src = ctx.alloc(words.nbytes + 16)
+        ctx.h2d(d_src, words)
+        for K, stride in ((21, 1), (31, 1), (33, 1), (65, 1), (97, 1), (128, 1), (21, 3), (70, 5)):
+            ek, es, _ = orc.unambiguous(words, L, 4, K)
+            keep = (es - 1) % stride == 0
+            ek, es = ek[keep], es[keep]
+            n, N = len(ek), (2 * K + 63) // 64
+            seq = cap.Seq(d_src, L, 0, 1000, 4, 0)   # index_origin: starts come out global
+            for tile, grid in ((0, 0), (1024, 0), (4096, 7), (32768, 2), (2048, 300)):
+                ctx.set_param(cap.PARAM_TILE_KMERS, tile)
+                ctx.set_param(cap.PARAM_MAX_GRID, grid)
+                for capacity in (n, n + 1000, max(n - 1, 0) if n else 0, n // 2):
+                    room = max(n, 1) + 1000 + 8
+                    hk = np.full((room, N), guard, np.uint64)
+                    hs = np.full(room, guard.view(np.int64), np.int64)
+                    dk, ds = ctx.alloc(hk.nbytes), ctx.alloc(hs.nbytes)
+                    ctx.h2d(dk, hk)
+                    ctx.h2d(ds, hs)
+                    res = cap.Result()
+                    rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, stride, dk, ds, capacity, cap.MEM_DEVICE, C.byref(res))
+                    ctx.d2h(hk, dk)
+                    ctx.d2h(hs, ds)
+                    ctx.free(dk)
+                    ctx.free(ds)
+                    assert res.n_out == n, (K, stride, tile, grid, capacity, res.n_out, n)
+                    assert np.all(hk[capacity:] == guard) and np.all(hs[capacity:] == guard.view(np.int64))   # never beyond the capacity
+                    if capacity >= n:
+                        assert rc == 0
+                        assert np.array_equal(hk[:n], ek) and np.array_equal(hs[:n], es + 1000), (K, stride, tile, grid, p_amb)
+                    else:
+                        assert rc == cap.E_CAPACITY and res.status == cap.E_CAPACITY
+            ctx.set_param(cap.PARAM_TILE_KMERS, 0)
+            ctx.set_param(cap.PARAM_MAX_GRID, 0)
+        ctx.free(d_src)
 
 
 def test_spaced_skip_variant(km, ctx, orc):

@@ -14,6 +14,7 @@ ap.add_argument("--libs", default=cap.library_path())
 ap.add_argument("--tiles", default="0")
 ap.add_argument("--cases", default="k31,c5,clean")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--grids", default="0")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 L = 1_000_000_000
@@ -48,8 +49,9 @@ for case in a.cases.split(","):
     buf, K, J = cases[case]
     seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
     for (name, lib), h in zip(libs, ctxs):
-        for t in a.tiles.split(","):
+        for t, g in [(t, g) for t in a.tiles.split(",") for g in a.grids.split(",")]:
             lib.kmers_ctx_set_param(h, cap.PARAM_TILE_KMERS, int(t))
+            lib.kmers_ctx_set_param(h, cap.PARAM_MAX_GRID, int(g))
             stream = torch.cuda.ExternalStream(lib.kmers_ctx_stream(h), device=dev)
             ts = []
             for r in range(a.reps + 1):
@@ -65,4 +67,4 @@ for case in a.cases.split(","):
             m = int(res.n_out)
             med = float(np.median(ts))
             alg = 0.5 * L + 16.0 * m
-            print(f"{case:6s} {name:24s} tile {int(t):5d}  {med:7.3f} ms (min {min(ts):.3f})  kept {m}  {alg / med / 1e6:7.1f} GB/s = {alg / med / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
+            print(f"{case:6s} {name:24s} tile {int(t):5d} grid {int(g):5d}  {med:7.3f} ms (min {min(ts):.3f})  kept {m}  {alg / med / 1e6:7.1f} GB/s = {alg / med / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
