@@ -13,8 +13,9 @@
  * Data formats (bit-identical to the reference):
  *   input  = LongSequence.data :: Vector{UInt64}, symbol i (1-based) at bits
  *            [((i-1)*bps) mod 64, +bps) of word ((i-1)*bps) div 64   (bps = 2 or 4),
- *            or ASCII bytes (src_bits = 8: String / Vector{UInt8} sources, one byte per symbol,
- *            `words` then points at the bytes; AsciiEncode, src/construction.jl:94-95)
+ *            or bytes (src_bits = 8, `words` then points at the bytes, one per symbol): ASCII text (String /
+ *            Vector{UInt8} sources; AsciiEncode, src/construction.jl:94-95) or symbol values (Vector{DNA} and the
+ *            like; GenericRecoding, :90-98) -- see kmers_seq.alphabet
  *   output = Vector{Kmer{A,K,N}} memory: N = cld(K*bps_dst, 64) UInt64 per element,
  *            data[1] first, first symbol in the most significant used bits, unused
  *            bits = top bits of data[1] = 0                        (src/kmer.jl:32-44)
@@ -80,8 +81,16 @@ typedef struct {
     uint64_t first_base;   /* 0-based symbol offset of the view inside words[] */
     uint64_t index_origin; /* 0 for a whole sequence */
     int32_t src_bits;      /* 2 (DNA/RNAAlphabet{2}), 4 (DNA/RNAAlphabet{4}) or 8 (ASCII bytes: String, Vector{UInt8}) */
-    int32_t alphabet;      /* ASCII sources only: 0 = the kmer alphabet is DNA (T valid), 1 = RNA (U valid) */
+    int32_t alphabet;      /* byte sources only (src_bits = 8): KMERS_ALPHABET_DNA / _RNA = ASCII text for a DNA (T valid) / RNA
+                            * (U valid) kmer alphabet; KMERS_ALPHABET_SYMBOLS = not text: one BioSymbols value per byte, the
+                            * memory of a Vector{DNA} / Vector{RNA} -- the reference's GenericRecoding sources
+                            * (src/construction.jl:90-98, FwKmers.jl:80-86, CanonicalKmers.jl:81-91): each symbol goes
+                            * through BioSequences.encode of the kmer alphabet (2-bit: one-hot values only, anything else is
+                            * the reference's EncodeError; 4-bit: every value below 16) */
 } kmers_seq;
+#define KMERS_ALPHABET_DNA 0
+#define KMERS_ALPHABET_RNA 1
+#define KMERS_ALPHABET_SYMBOLS 2
 
 /* ---- library / context ------------------------------------------------------- */
 int kmers_abi_version(void);
@@ -115,7 +124,11 @@ int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t
 /* ---- geometry (src/kmer.jl:117-137; iterator length()) ----------------------- */
 int kmers_words_per_kmer(int k, int dst_bits);                      /* n_coding_elements, kmer.jl:123-125 */
 uint64_t kmers_count(uint64_t n_bases, int k, int stride);          /* FwKmers.jl:40-43; SpacedKmers.jl:38-42 */
-int kmers_supported(int src_bits, int dst_bits, int k, int stride); /* 1 if the kernels cover it */
+/* 1 if kmers_fw / kmers_canonical / kmers_spaced cover the geometry: every K >= 1 (Kmer{A,K,N} has no bound on N,
+ * src/kmer.jl:97-111; kmers of one to four words run on the tile kernels, wider ones on a run-time-width kernel).
+ * kmers_unambiguous, the fused consumers, the element-wise operations and the batch entry points take kmers of at most
+ * four words (K <= 128 two-bit, K <= 64 four-bit) and return KMERS_E_UNSUPPORTED beyond. */
+int kmers_supported(int src_bits, int dst_bits, int k, int stride);
 
 /* ---- iterators --------------------------------------------------------------- */
 /* FwKmers{A,K}(seq) collected (FwKmers.jl:57-115); with out_rc != NULL also
@@ -215,7 +228,7 @@ int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bi
  * returns KMERS_E_CAPACITY with res->n_out = the number required (capacity 0 + NULL outputs = a size
  * query).  KMERS_MEM_DEVICE applies to pool->words, out_a and out_b; out_offsets is always host memory;
  * spans is host memory unless KMERS_SPANS_DEVICE is set (tens of millions of reads: keep them
- * resident).  Kmers of up to four words (K <= 128 two-bit, K <= 64 four-bit), as everywhere in this library.
+ * resident).  Kmers of up to four words (K <= 128 two-bit, K <= 64 four-bit).
  * EncodeError: the first failing record in batch order wins, res->err_pos = 1-based position inside
  * THAT record, res->err_enc = the raw symbol, res->n_out = the record's index in spans[]. */
 typedef struct {

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libkmers_hip.so")
 SOURCES = ["kmers_api.hip", "comm_api.hip"]  # iterators + consumers; RCCL communication
-HEADERS = ["context.hpp", "device_bits.hpp", "stream_kernel.hpp", "unambiguous_kernel.hpp", "composition_kernel.hpp", "run_kernel.hpp", "ragged_kernels.hpp", "record_sketch_kernel.hpp", "batch_kernels.hpp", "ascii_tables.hpp",
+HEADERS = ["context.hpp", "device_bits.hpp", "stream_kernel.hpp", "unambiguous_kernel.hpp", "wide_kernel.hpp", "composition_kernel.hpp", "run_kernel.hpp", "ragged_kernels.hpp", "record_sketch_kernel.hpp", "batch_kernels.hpp", "ascii_tables.hpp",
            os.path.join("..", "..", "include", "kmers_hip.h")]
 
 

@@ -45,13 +45,23 @@ inline void build_ascii_skipping_table(uint8_t *t) {
 // used to add a whole global-load latency to every short-lived workgroup of the byte-source kernels).
 //   table 0 / 1: ascii_encode of the 2-bit DNA / RNA alphabet   2 / 3: of the 4-bit DNA / RNA alphabet
 //   table 4    : ASCII_SKIPPING_LUT
+//   table 5 / 6: NOT text -- one BioSymbols value per byte (Vector{DNA} / Vector{RNA} and other collections of
+//                nucleotide symbols: the reference's GenericRecoding, src/construction.jl:90-98): BioSequences.encode of
+//                the 2-bit alphabets (one-hot values only -> trailing_zeros) / of the 4-bit alphabets (every value < 16)
 #ifdef __HIPCC__
 #define KMERS_HD __host__ __device__
 #else
 #define KMERS_HD
 #endif
 constexpr int ASCII_TABLE_SKIPPING = 4;
+constexpr int SYMBOL_TABLE_2BIT = 5, SYMBOL_TABLE_4BIT = 6;
 KMERS_HD inline uint8_t ascii_entry(uint32_t table, uint32_t c) {
+    if (table >= (uint32_t)SYMBOL_TABLE_2BIT) {  // symbol values, not letters
+        if (c > 15u) return 0x80;
+        if (table == (uint32_t)SYMBOL_TABLE_4BIT) return (uint8_t)c;
+        if (c == 0 || (c & (c - 1u))) return 0x80;  // gap or ambiguous: EncodeError (count_ones != 1)
+        return (uint8_t)(c == 1u ? 0u : c == 2u ? 1u : c == 4u ? 2u : 3u);
+    }
     // IUPAC value ("-ACMGRSVTWYHKDBN" index) of the letters a..p and q..z, one nibble each; t and u hold 8
     //                  p o n m l k j i h g f e d c b a                      z y x w v u t s r q
     const uint64_t LO = 0x00F30C00B400D2E1ull, HI = 0x0000000A09788650ull >> 0;

@@ -17,6 +17,7 @@
 #include "context.hpp"
 #include "batch_kernels.hpp"
 #include "unambiguous_kernel.hpp"
+#include "wide_kernel.hpp"
 #include "composition_kernel.hpp"
 #include "ragged_kernels.hpp"
 #include "record_sketch_kernel.hpp"
@@ -38,20 +39,24 @@ void clear(kmers_result *res) {
 
 // Common argument checks.  K, J errors mirror the constructors (FwKmers.jl:31-35,
 // SpacedKmers.jl:26-32); geometry limits are this library's.
-int check_common(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_bits, int flags) {
+int check_common(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_bits, int flags, bool any_width = false) {
     if (!ctx) return KMERS_E_BADARG;
     if (!seq) return fail(ctx, KMERS_E_BADARG, "seq is NULL");
     if (k < 1) return fail(ctx, KMERS_E_BADARG, "K must be at least 1");
     if (stride < 1) return fail(ctx, KMERS_E_BADARG, "J must be at least 1");
     if (seq->src_bits != 2 && seq->src_bits != 4 && seq->src_bits != 8)
         return fail(ctx, KMERS_E_BADARG, "src_bits must be 2, 4 or 8 (ASCII bytes)");
+    if (seq->src_bits == 8 && (seq->alphabet < 0 || seq->alphabet > KMERS_ALPHABET_SYMBOLS))
+        return fail(ctx, KMERS_E_BADARG, "alphabet of a byte source must be 0 (DNA text), 1 (RNA text) or 2 (symbol values)");
     if (seq->src_bits == 8 && (flags & KMERS_MEM_DEVICE) && (reinterpret_cast<uintptr_t>(seq->words) & 7u))
         return fail(ctx, KMERS_E_BADARG, "device ASCII buffers must be 8-byte aligned");
     if (seq->n_bases && !seq->words) return fail(ctx, KMERS_E_BADARG, "seq.words is NULL");
     if ((flags & KMERS_ASYNC) && !(flags & KMERS_MEM_DEVICE))
         return fail(ctx, KMERS_E_BADARG, "KMERS_ASYNC requires KMERS_MEM_DEVICE");
-    if (!kmers_supported(seq->src_bits, dst_bits, k, stride))
-        return fail(ctx, KMERS_E_UNSUPPORTED, "unsupported (src_bits, dst_bits, K) geometry");
+    if (dst_bits != 2 && dst_bits != 4) return fail(ctx, KMERS_E_BADARG, "dst_bits must be 2 or 4");
+    // the iterators take kmers of any width (wide_kernel.hpp); the other entry points kmers of one to four words
+    if (!any_width && n_coding_elements(k, dst_bits) > 4)
+        return fail(ctx, KMERS_E_UNSUPPORTED, "this entry point takes kmers of at most four words (K <= 128 two-bit, K <= 64 four-bit)");
     return KMERS_OK;
 }
 
@@ -126,7 +131,11 @@ int collect(kmers_ctx *ctx, kmers_result *res, uint64_t n_out, uint64_t *value_o
 }
 
 // table id of ascii_entry(): BioSequences.ascii_encode of the kmer alphabet (ascii_tables.hpp)
-uint32_t ascii_table(kmers_ctx *, int dst_bits, bool rna) { return (dst_bits == 4 ? 2u : 0u) + (rna ? 1u : 0u); }
+// (kmers_seq.alphabet: 0 = DNA text, 1 = RNA text, 2 = one BioSymbols value per byte -- GenericRecoding sources)
+uint32_t ascii_table(kmers_ctx *, int dst_bits, int alphabet) {
+    if (alphabet == KMERS_ALPHABET_SYMBOLS) return dst_bits == 4 ? (uint32_t)SYMBOL_TABLE_4BIT : (uint32_t)SYMBOL_TABLE_2BIT;
+    return (dst_bits == 4 ? 2u : 0u) + (alphabet != 0 ? 1u : 0u);
+}
 
 // Default tile: about 16 KiB of output per workgroup (four 16-byte stores per lane), one tile
 // per workgroup.  Measured on MI355X (profiles/r01_tuning.md): shorter workgroups are bound by
@@ -184,6 +193,9 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     uint32_t max_tile_symbols = (uint32_t)MAX_TILE_BITS / (uint32_t)dst_bits;
     if (MODE == MODE_MINIMIZER) max_tile_symbols -= std::min<uint32_t>(max_tile_symbols / 2, a.window_kmers);  // room for the longer overlap
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
+    // strided tiles read `stride` times the source per element: twice the output per workgroup amortises the longer load
+    // phase (SpacedDNAMers{21,3} over 1 Gbase: 0.64-0.68 -> 0.71-0.74 of 8 TB/s, profiles/r02_tuning.md)
+    if (ctx->tile_kmers <= 0 && J > 1 && MODE == MODE_FW) tile *= 2;
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);
     tile = std::max<uint32_t>(pass, tile / pass * pass);
     if ((uint64_t)(tile - 1) * J + 1 > (uint64_t)max_tile_symbols) return fail(ctx, KMERS_E_UNSUPPORTED, "stride too large for the tile kernel");
@@ -220,12 +232,13 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_bits, int mode,
                uint64_t *out_a, uint64_t *out_b, bool b_is_hash, uint64_t seed, int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags)) {
+    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags, true)) {
         if (res) res->status = rc;
         return rc;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int nw = kmers_words_per_kmer(k, dst_bits);
+    if (nw > 4 && (flags & KMERS_OUT_TUPLES)) return fail(ctx, KMERS_E_UNSUPPORTED, "KMERS_OUT_TUPLES: kmers of at most four words");
     const uint64_t n = kmers_count(seq->n_bases, k, stride);
     if (n == 0) {  // length(seq) < K: empty iteration, nothing inspected (FwKmers.jl:63)
         if (res) res->status = KMERS_OK;
@@ -264,11 +277,29 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     a.err_origin = seq->index_origin;
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
-    a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+    a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet);
     a.tuples = tuples ? 1u : 0u;
 
     int rc;
-    if ((uint64_t)stride * (uint64_t)dst_bits > 64) {
+    if (nw > 4) {
+        // kmers of more than four words: the run-time-width kernel (wide_kernel.hpp), one lane per kmer
+        dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+        const uint32_t nwu = (uint32_t)nw;
+#define WIDE(SB, DB)                                                                                         \
+    do {                                                                                                     \
+        if (mode == MODE_FW) hipLaunchKernelGGL((wide_kernel<SB, DB, MODE_FW>), grid, block, 0, ctx->stream, a, nwu);   \
+        else hipLaunchKernelGGL((wide_kernel<SB, DB, MODE_CANON>), grid, block, 0, ctx->stream, a, nwu);                \
+    } while (0)
+        if (seq->src_bits == 8 && dst_bits == 2) WIDE(8, 2);
+        else if (seq->src_bits == 8) WIDE(8, 4);
+        else if (seq->src_bits == 4 && dst_bits == 2) WIDE(4, 2);
+        else if (seq->src_bits == 2 && dst_bits == 2) WIDE(2, 2);
+        else if (seq->src_bits == 4 && dst_bits == 4) WIDE(4, 4);
+        else WIDE(2, 4);
+#undef WIDE
+        HIP_TRY(ctx, hipGetLastError());
+        rc = KMERS_OK;
+    } else if ((uint64_t)stride * (uint64_t)dst_bits > 64) {
         // gather path (forward kmers only: kmers_spaced); a tile would stage mostly unused symbols
         dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
         if (seq->src_bits == 8 && dst_bits == 2) launch_gather<8, 2>(nw, grid, block, ctx->stream, a);
@@ -322,7 +353,7 @@ int emit_all_kept(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k,
     a.err_origin = seq->index_origin;
     a.k = (uint32_t)k;
     a.stride = 1;
-    a.ascii_table = ascii_table(ctx, 2, seq->alphabet != 0);
+    a.ascii_table = ascii_table(ctx, 2, seq->alphabet);
     const bool vec_ok = (!d_k || aligned16(d_k)) && (!d_s || aligned16(d_s));
     return launch_stream<MODE_FW>(ctx, a, seq->src_bits, 2, kmers_words_per_kmer(k, 2), vec_ok);
 }
@@ -475,7 +506,7 @@ int launch_fused(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, 
     a.err_origin = seq->index_origin;
     a.k = (uint32_t)k;
     a.stride = 1;
-    a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+    a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet);
     int64_t saved = ctx->max_grid;
     if (ctx->max_grid <= 0) ctx->max_grid = 256 * 8;  // persistent grid: no output stream to pace
     int rc = launch_stream<MODE>(ctx, a, seq->src_bits, dst_bits, kmers_words_per_kmer(k, dst_bits), true, dyn_lds);
@@ -497,7 +528,7 @@ int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int 
     a.err_origin = seq->index_origin;
     a.k = (uint32_t)k;
     a.stride = 1;
-    a.ascii_table = ascii_table(ctx, 2, seq->alphabet != 0);
+    a.ascii_table = ascii_table(ctx, 2, seq->alphabet);
     a.n_tiles = (a.n_kmers + RTILE - 1) / RTILE;
     const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)ctx->n_cus * 8;  // persistent grid
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, resident)), block(RBLOCK);
@@ -583,7 +614,7 @@ int kmers_supported(int src_bits, int dst_bits, int k, int stride) {
     if (src_bits != 2 && src_bits != 4 && src_bits != 8) return 0;
     if (dst_bits != 2 && dst_bits != 4) return 0;
     if (k < 1 || stride < 1) return 0;
-    return n_coding_elements(k, dst_bits) <= 4;  // K <= 128 (2-bit kmers) / K <= 64 (4-bit kmers)
+    return 1;  // FwKmers / FwRvIterator / CanonicalKmers / SpacedKmers take kmers of any width (wide_kernel.hpp)
 }
 
 int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out) {
@@ -750,7 +781,7 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
         a.k = (uint32_t)k;
         a.stride = (uint32_t)stride;
         a.xor_canonical = 0;
-        a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+        a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet);
         int64_t saved = ctx->max_grid;
         if (ctx->max_grid <= 0) ctx->max_grid = (int64_t)ctx->n_cus * 8;  // persistent grid: nothing is streamed out
         const int rc = launch_stream<MODE_XOR>(ctx, a, seq->src_bits, dst_bits, nw, true);
@@ -1058,7 +1089,7 @@ int kmers_minimizers(kmers_ctx *ctx, const kmers_seq *seq, int k, int w, int str
     a.stride = (uint32_t)stride;
     a.window_kmers = (uint32_t)w;
     a.minimizer_mode = (uint32_t)mode;
-    a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet != 0);
+    a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet);
     // strides >= span leave gaps the reference's loop never reads: restrict the validation to the windows
     if (int rc = launch_stream<MODE_MINIMIZER>(ctx, a, seq->src_bits, dst_bits, nw, false)) return rc;
     if (flags & KMERS_ASYNC) {
@@ -1102,7 +1133,7 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
             a.counts = d_counts;
             a.err_slot = ctx->d_err;
             a.err_origin = seq->index_origin;
-            a.ascii_table = ascii_table(ctx, 2, seq->alphabet != 0);
+            a.ascii_table = ascii_table(ctx, 2, seq->alphabet);
             a.k = (uint32_t)k;
             a.hist_words = (uint32_t)std::min<size_t>(bins, (size_t)1 << CBINS_LOG2) / 2;
             const uint32_t passes = (uint32_t)std::max<size_t>(1, bins >> CBINS_LOG2);
@@ -1149,7 +1180,7 @@ static int pool_stream(kmers_ctx *ctx, const kmers_seq *pool, const uint64_t *sr
     r.src = src0;
     r.n_words = n_src_words;
     r.stream = static_cast<uint64_t *>(ctx->stage[4]);
-    r.ascii_table = ascii_table(ctx, dst_bits, pool->alphabet != 0);
+    r.ascii_table = ascii_table(ctx, dst_bits, pool->alphabet);
     if (sb != 2) {
         if (int rc = ensure_stage(ctx, 5, flag_bytes + 16)) return rc;
         r.flags = static_cast<uint64_t *>(ctx->stage[5]);
@@ -1183,7 +1214,10 @@ static int report_window_error(kmers_ctx *ctx, const kmers_seq *pool, const uint
     HIP_TRY(ctx, hipMemcpyAsync(w.data(), src0 + wlo, w.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     uint8_t table[256];
-    if (sb == 8) build_ascii_encode_table(dst_bits, pool->alphabet != 0, table);
+    if (sb == 8) {
+        const uint32_t tb = ascii_table(ctx, dst_bits, pool->alphabet);
+        for (uint32_t b = 0; b < 256u; ++b) table[b] = ascii_entry(tb, b);
+    }
     for (uint64_t t = 0; t < (uint64_t)k; ++t) {
         const uint64_t bit = (p0 + t) * sb - wlo * 64;
         const uint32_t enc = (uint32_t)((w[bit >> 6] >> (bit & 63u)) & ((1ull << sb) - 1ull));
@@ -1525,6 +1559,8 @@ int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, u
         return rc;
     }
     if (flags & KMERS_ASYNC) return fail(ctx, KMERS_E_BADARG, "kmers_unambiguous is synchronous (data-dependent count)");
+    if (seq->src_bits == 8 && seq->alphabet == KMERS_ALPHABET_SYMBOLS)  // the reference has no such method (UnambiguousKmers.jl:64-132)
+        return fail(ctx, KMERS_E_UNSUPPORTED, "UnambiguousKmers takes 2-bit / 4-bit sequences and text, not collections of symbols");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return run_unambiguous(ctx, seq, k, stride, out_kmers, out_starts, capacity, flags, res);
 }

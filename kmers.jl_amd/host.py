@@ -264,8 +264,39 @@ class AsciiSource:
     __del__ = LongSequence.__del__
 
 
+class SymbolVector:
+    """A `Vector{DNA}` / `Vector{RNA}` -- any collection of nucleotide symbols that is neither a BioSequence nor text:
+    the reference iterates it through GenericRecoding (src/construction.jl:90-98, FwKmers.jl:80-86), symbol by symbol
+    through `BioSequences.encode` of the kmer alphabet.  One byte per symbol holding its BioSymbols value."""
+    src_bits = 8
+    symbols = True
+
+    def __init__(self, kind, source):
+        self.alphabet = _Alphabet(kind, 4)
+        if isinstance(source, str):
+            try:
+                raw = bytes(_ENC4[c] for c in source.upper().replace("U", "T"))
+            except KeyError as e:
+                raise EncodeError(self.alphabet, e.args[0], None, None)
+        else:
+            raw = bytes(int(v) for v in source)
+        self.len = len(raw)
+        self.data = np.frombuffer(raw + b"\0" * ((-self.len) % 8 + 8), dtype=np.uint8)
+        self._dev = None
+
+    def __len__(self):
+        return self.len
+
+    def __str__(self):
+        inv = _decode_table(self.alphabet)
+        return "".join(inv[int(v)] for v in self.data[:self.len])
+
+    device_words = LongSequence.device_words
+    __del__ = LongSequence.__del__
+
+
 def _as_sequence(s):
-    if isinstance(s, (LongSequence, AsciiSource)):
+    if isinstance(s, (LongSequence, AsciiSource, SymbolVector)):
         return s
     if isinstance(s, (str, bytes, bytearray, np.ndarray)):
         return AsciiSource(s)
@@ -388,7 +419,9 @@ class KmerArray:
 # --------------------------------------------------------------------------------------------
 # iterators
 def _raise_encode(alphabet, seq, res):
-    if seq.src_bits == 8:  # EncodeError(A, repr(byte)), FwKmers.jl:124-126
+    if getattr(seq, "symbols", False):  # EncodeError(A, symbol) from BioSequences.encode (kmer.jl:445-448)
+        sym = _decode_table(seq.alphabet)[res.err_enc] if res.err_enc < 16 else f"0x{res.err_enc:02x}"
+    elif seq.src_bits == 8:  # EncodeError(A, repr(byte)), FwKmers.jl:124-126
         sym = f"0x{res.err_enc:02x} (Char {chr(res.err_enc)!r})"
     else:
         sym = _decode_table(seq.alphabet)[res.err_enc] if seq.src_bits == 4 else "?"
@@ -430,8 +463,7 @@ class AbstractKmerIterator(metaclass=_Parametric):
         self.N = n_coding_elements(K, alphabet.bits)
         if not self.ctx.lib.kmers_supported(self.seq.src_bits, alphabet.bits, K, stride):
             raise UnsupportedError(
-                f"Kmer{{{alphabet},{K}}} from {self.seq.alphabet or 'ASCII bytes'} is outside the kernels' coverage "
-                "(kmers of at most 4 words: K <= 128 for 2-bit, K <= 64 for 4-bit alphabets)")
+                f"Kmer{{{alphabet},{K}}} from {self.seq.alphabet or 'ASCII bytes'} is outside the kernels' coverage")
 
     # Base.eltype (src/iterators/common.jl:13-15)
     @property
@@ -443,7 +475,7 @@ class AbstractKmerIterator(metaclass=_Parametric):
 
     def _view(self, first_base, n_bases):
         return _capi.Seq(self.seq.device_words(self.ctx), n_bases, first_base, first_base,
-                         self.seq.src_bits, 1 if self.alphabet.kind == "RNA" else 0)
+                         self.seq.src_bits, 2 if getattr(self.seq, "symbols", False) else (1 if self.alphabet.kind == "RNA" else 0))
 
     def _wrap(self, arrays, lo, hi):
         raise NotImplementedError

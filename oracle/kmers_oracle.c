@@ -195,12 +195,28 @@ void orc_ascii_tables(int dst_bps, int rna, uint8_t *encode_lut, uint8_t *skippi
 }
 
 #define IS_ASCII(src_bps) ((src_bps) == ORC_SRC_ASCII_DNA || (src_bps) == ORC_SRC_ASCII_RNA)
+#define IS_BYTES(src_bps) (IS_ASCII(src_bps) || (src_bps) == ORC_SRC_SYMBOLS)
 
 /* One checked/recoded symbol fetch, per RecodingScheme (src/construction.jl:75-100):
  * same width -> Copyable, 4->2 FourToTwo, 2->4 TwoToFour.
  * Returns 0 and the encoding to shift in, or ORC_E_ENCODE. */
 INL int fetch_recoded(const uint64_t *seq, uint64_t i, const int src_bps, const int dst_bps,
                       uint64_t *enc_out, orc_result *res) {
+    if (src_bps == ORC_SRC_SYMBOLS) {
+        /* GenericRecoding: symbol = convert(eltype(kmer), seq[i]) keeps the 4-bit value (DNA <-> RNA share encodings);
+         * BioSequences.encode(A, symbol): a 2-bit alphabet takes only the four one-hot values (trailing_zeros), anything
+         * else is EncodeError(A, symbol); a 4-bit alphabet takes every nucleotide value, gap included
+         * (construction_utils.jl:98-100, kmer.jl:445-448) */
+        uint8_t byte = ((const uint8_t *)seq)[i - 1];
+        if (byte > 0x0f) return throw_uncertain(res, i, byte); /* not a nucleotide value at all */
+        if (dst_bps == 4) {
+            *enc_out = byte;
+            return 0;
+        }
+        if (count_ones64(byte) != 1) return throw_uncertain(res, i, byte);
+        *enc_out = (uint64_t)trailing_zeros64(byte);
+        return 0;
+    }
     if (IS_ASCII(src_bps)) { /* AsciiEncode: FwKmers.jl:117-129, construction_utils.jl:71-88, :220-236 */
         uint8_t byte = ((const uint8_t *)seq)[i - 1];
         uint8_t encoding = ascii_encode(dst_bps, src_bps == ORC_SRC_ASCII_RNA, byte);
@@ -439,7 +455,7 @@ INL int fwrv_impl(const uint64_t *seq, uint64_t len, const int src_bps, const in
         res->n_out++;
         if (i > len) return 0;                                              /* :100,:113,:124,:137 */
         uint64_t fenc, renc;
-        if (IS_ASCII(src_bps)) {                     /* AsciiEncode: :146-174 */
+        if (IS_BYTES(src_bps)) {                     /* AsciiEncode: :146-174; GenericRecoding: :81-91 (complement(symbol)) */
             if (fetch_recoded(seq, i, src_bps, dst_bps, &fenc, res)) return ORC_E_ENCODE;
             renc = dst_bps == 4 ? complement_nibble(fenc) : (fenc ^ 0x03); /* :161-165 */
             shift_encoding(fw, N, K, dst_bps, fenc);
@@ -601,7 +617,7 @@ int orc_minimizers(const uint64_t *seq, uint64_t len, int src_bps, int dst_bps, 
  * timing is of specialised code (Julia specialises on A, K, N at compile time). */
 static int check_args(int src_bps, int dst_bps, int K, orc_result *res) {
     memset(res, 0, sizeof *res);
-    if ((src_bps != 2 && src_bps != 4 && !IS_ASCII(src_bps)) || (dst_bps != 2 && dst_bps != 4) || K < 1 ||
+    if ((src_bps != 2 && src_bps != 4 && !IS_BYTES(src_bps)) || (dst_bps != 2 && dst_bps != 4) || K < 1 ||
         n_coding_elements(K, dst_bps) > ORC_MAX_N) {
         res->status = ORC_E_BADARG; /* FwKmers.jl:31-35 "K must be at least 1" */
         return ORC_E_BADARG;
@@ -658,6 +674,10 @@ uint64_t orc_reduce_xor_canonical(const uint64_t *seq, uint64_t len, int src_bps
 int orc_unambiguous(const uint64_t *seq, uint64_t len, int src_bps, int K,
                     uint64_t *out_kmers, int64_t *out_starts, orc_result *res) {
     if (check_args(src_bps, 2, K, res)) return ORC_E_BADARG;
+    if (src_bps == ORC_SRC_SYMBOLS) { /* UnambiguousKmers has no GenericRecoding method (UnambiguousKmers.jl:64-132) */
+        res->status = ORC_E_BADARG;
+        return ORC_E_BADARG;
+    }
     int N = n_coding_elements(K, 2);
     if (src_bps == 4 && N == 1) return unambiguous_impl(seq, len, 4, 1, K, out_kmers, out_starts, res);
     return unambiguous_impl(seq, len, src_bps, N, K, out_kmers, out_starts, res);

@@ -33,6 +33,11 @@ extern "C" {
  * validity table is the one of the KMER's alphabet (DNA: T, RNA: U). */
 #define ORC_SRC_ASCII_DNA 8
 #define ORC_SRC_ASCII_RNA 9
+/* GenericRecoding source (src/construction.jl:90-98): any other collection of nucleotide symbols, e.g. Vector{DNA} /
+ * Vector{RNA}: `seq` is a byte string, one BioSymbols value per byte (its 4-bit encoding, BioSymbols 5.1.3).  Every
+ * symbol goes through convert(eltype(kmer), symbol) + BioSequences.encode(A, symbol) (FwKmers.jl:80-86,
+ * CanonicalKmers.jl:81-91, construction_utils.jl:90-103, :161-172, kmer.jl:445-448, :506-509). */
+#define ORC_SRC_SYMBOLS 10
 
 #define ORC_OK 0
 #define ORC_E_ENCODE 1 /* BioSequences.EncodeError: src/construction.jl:108-110 */

@@ -45,7 +45,9 @@ def test_geometry_helpers(km):
     assert lib.kmers_count(8, 3, 2) == 3 and lib.kmers_count(11, 3, 3) == 3
     assert lib.kmers_count(10**10, 31, 1) == 10**10 - 30
     assert lib.kmers_supported(4, 2, 31, 1) == 1 and lib.kmers_supported(4, 2, 128, 1) == 1
-    assert lib.kmers_supported(4, 2, 129, 1) == 0 and lib.kmers_supported(2, 4, 64, 1) == 1 and lib.kmers_supported(2, 4, 65, 1) == 0
+    # the iterators take kmers of any width (src/kmer.jl:97-111 has no bound on N)
+    assert lib.kmers_supported(4, 2, 129, 1) == 1 and lib.kmers_supported(2, 4, 64, 1) == 1 and lib.kmers_supported(2, 4, 65, 1) == 1
+    assert lib.kmers_supported(3, 2, 5, 1) == 0 and lib.kmers_supported(4, 3, 5, 1) == 0 and lib.kmers_supported(4, 2, 0, 1) == 0
 
 
 def test_no_cpu_fallback(km):

@@ -179,6 +179,30 @@ def test_string_sources(km, kats):
     assert texts(km.collect(km.each_codon(km.RNA, b"UAUGCUGAA"))) == ["UAU", "GCU", "GAA"]
 
 
+def test_symbol_vector_sources(km):
+    """A Vector{DNA} / Vector{RNA} source goes through GenericRecoding in the reference (src/construction.jl:90-98,
+    FwKmers.jl:80-86): the same elements as the BioSequence of the same symbols, the same EncodeError."""
+    text = "TAGCTGACCGTTAGGCATCGATCGGATCCGATAGCTAGCTAGGA"
+    v = km.SymbolVector("DNA", text)
+    assert str(v) == text and len(v) == len(text)
+    for K in (3, 21, 33):
+        assert km.collect(km.FwDNAMers[K](v)) == km.collect(km.FwDNAMers[K](km.LongDNA[4](text)))
+        assert km.collect(km.CanonicalDNAMers[K](v)) == km.collect(km.CanonicalDNAMers[K](km.LongDNA[4](text)))
+        assert km.collect(km.FwRNAMers[K](v)) == km.collect(km.FwRNAMers[K](km.LongDNA[4](text)))       # convert(RNA, ::DNA)
+        assert km.collect(km.SpacedDNAMers[K, 2](v)) == km.collect(km.SpacedDNAMers[K, 2](km.LongDNA[4](text)))
+    amb = km.SymbolVector("DNA", "TAGWC-GA")
+    assert km.collect(km.FwKmers[km.DNAAlphabet[4], 3](amb)) == km.collect(km.FwKmers[km.DNAAlphabet[4], 3](km.LongDNA[4]("TAGWC-GA")))
+    with pytest.raises(km.EncodeError, match=re.escape("cannot encode W in DNAAlphabet{2}")):
+        km.collect(km.FwDNAMers[3](amb))
+    got = []
+    with pytest.raises(km.EncodeError):
+        for x in km.FwDNAMers[3](amb):      # TAG is yielded, then AGW throws
+            got.append(str(x))
+    assert got == ["TAG"]
+    with pytest.raises(km.UnsupportedError):    # no such method in the reference (UnambiguousKmers.jl:64-132)
+        km.collect(km.UnambiguousDNAMers[3](v))
+
+
 def test_fx_hash_known_answers(km, kats):
     # test/runtests.jl:903-910 (nucleotide cases)
     assert km.fx_hash(km.mer("TAGCTAG")) == 0xA76409341339D05A

@@ -148,6 +148,67 @@ def test_all_recoding_schemes_and_wide_kmers(km, ctx, orc, src, dst):
             assert np.array_equal(out, ek), (K, J)
 
 
+def test_kmers_wider_than_four_words(km, ctx, orc):
+    """Kmer{A,K,N} has no upper bound on N (src/kmer.jl:97-111): K > 128 (2-bit) / K > 64 (4-bit) run on the run-time-width
+    kernel.  FwKmers + reverse complements, CanonicalKmers + fx_hash and SpacedKmers against the oracle (N <= 8), every
+    recoding scheme incl. text, and the EncodeError position; beyond the oracle's widths against the independent naive
+    slicer (big-integer packing from the layout rule only)."""
+    cap = km._capi
+    rng = np.random.default_rng(4242)
+    for src, dst, ks in ((2, 2, (129, 160, 256)), (4, 2, (129, 193, 255)), (4, 4, (65, 100, 128)), (2, 4, (65, 127)), (8, 2, (130,)), (8, 4, (70,))):
+        for K in ks:
+            N = (K * dst + 63) // 64
+            assert N > 4
+            for L in (K, K + 3, 1500):
+                text = naive.random_text(rng, L, p_amb=0.05 if (src == 4 and dst == 4) or (src == 8 and dst == 4) else 0.0)
+                words = naive.ascii_words(text) if src == 8 else naive.longseq_words(text, src)
+                osrc = 8 if src == 8 else src
+                seq = cap.Seq(words.ctypes.data, L, 0, 0, src, 0)
+                n = L - K + 1
+                res = cap.Result()
+                fw, rv = np.zeros((n, N), np.uint64), np.zeros((n, N), np.uint64)
+                assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, dst, vp(fw), vp(rv), cap.MEM_HOST, C.byref(res)) == 0
+                efw, erv, _ = orc.fwrv(words, L, osrc, dst, K)
+                assert np.array_equal(fw, efw) and np.array_equal(rv, erv), (src, dst, K, L)
+                ck, hs = np.zeros((n, N), np.uint64), np.zeros(n, np.uint64)
+                assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, vp(ck), vp(hs), 77, cap.MEM_HOST, C.byref(res)) == 0
+                ek, eh, _ = orc.canonical(words, L, osrc, dst, K, seed=77)
+                assert np.array_equal(ck, ek) and np.array_equal(hs, eh), (src, dst, K, L)
+                for J in (7, K + 5):
+                    m = (L - K) // J + 1
+                    out = np.zeros((m, N), np.uint64)
+                    assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, dst, vp(out), cap.MEM_HOST, C.byref(res)) == 0
+                    es, _ = orc.spaced(words, L, osrc, dst, K, J)
+                    assert np.array_equal(out, es), (src, dst, K, L, J)
+            if dst == 2 and src in (4, 8):   # the first symbol the 2-bit alphabet cannot hold, in sequence order
+                L = 1200
+                t = list(naive.random_text(rng, L))
+                t[700], t[333], t[1100] = "N", "W", "-"
+                text = "".join(t)
+                words = naive.ascii_words(text) if src == 8 else naive.longseq_words(text, src)
+                seq = cap.Seq(words.ctypes.data, L, 0, 0, src, 0)
+                out = np.zeros((L - K + 1, N), np.uint64)
+                res = cap.Result()
+                rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, vp(out), None, 0, cap.MEM_HOST, C.byref(res))
+                _, _, eres = orc.canonical(words, L, 8 if src == 8 else src, dst, K)
+                assert (rc, res.err_pos, res.err_enc) == (1, eres.err_pos, eres.err_enc) == (1, 334, res.err_enc)
+    # wider than the oracle goes: K = 700 two-bit (22 words), against the naive slicer
+    K, L = 700, 1000
+    text = naive.random_text(rng, L)
+    words = naive.longseq_words(text, 4)
+    seq = cap.Seq(words.ctypes.data, L, 0, 0, 4, 0)
+    N = (2 * K + 63) // 64
+    fw, rv = np.zeros((L - K + 1, N), np.uint64), np.zeros((L - K + 1, N), np.uint64)
+    res = cap.Result()
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, vp(fw), vp(rv), cap.MEM_HOST, C.byref(res)) == 0
+    assert [tuple(int(x) for x in r) for r in fw] == naive.fw_kmers(text, K, 2)
+    assert [tuple(int(x) for x in r) for r in rv] == [b for _, b in naive.fwrv(text, K, 2)]
+    # the other entry points say so instead of computing something else
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), 129, 1, None, None, 0, 0, C.byref(res)) == cap.E_UNSUPPORTED
+    val = C.c_uint64()
+    assert ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), 129, 2, 1, C.byref(val), 0, C.byref(res)) == cap.E_UNSUPPORTED
+
+
 def ascii_seq(km, text_or_bytes, L, alphabet=0, first_base=0):
     words = naive.ascii_words(text_or_bytes)
     return km._capi.Seq(words.ctypes.data, L, first_base, 0, 8, alphabet), words
@@ -285,6 +346,54 @@ def test_ascii_unambiguous_clean_text_of_the_other_alphabet(km, ctx, orc):
                 seq2, keep2 = ascii_seq(km, ok_text, len(ok_text), alphabet=0)
                 out = np.zeros((len(ok_text) - 3, 1), np.uint64)
                 assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq2), 4, 2, vp(out), None, 0, C.byref(res)) == 0, (res.status, res.err_pos)
+
+
+def test_symbol_vector_sources(km, ctx, orc):
+    """GenericRecoding sources (src/construction.jl:90-98; FwKmers.jl:80-86, CanonicalKmers.jl:81-91,
+    construction_utils.jl:90-103, :161-172): a Vector{DNA} / Vector{RNA} -- one BioSymbols value per byte
+    (kmers_seq.alphabet = KMERS_ALPHABET_SYMBOLS).  Same kmers and the same EncodeError (position, symbol) as the oracle;
+    UnambiguousKmers has no method for such a source."""
+    cap = km._capi
+    rng = np.random.default_rng(2027)
+    enc4 = {c: i for i, c in enumerate("-ACMGRSVTWYHKDBN")}
+    for dst in (2, 4):
+        for K in (1, 5, 31, 33, 64, 70 if dst == 2 else 40):
+            N = (K * dst + 63) // 64
+            for L in (K, K + 13, 5000, 40013):
+                for p_amb in (0.0, 0.001):
+                    text = naive.random_text(rng, L, p_amb=p_amb)
+                    raw = bytes(enc4[c] for c in text)
+                    if p_amb and L > 100 and dst == 4:
+                        raw = raw[:77] + bytes([0x41]) + raw[78:]   # not a nucleotide value: an error for both widths
+                    words = naive.ascii_words(raw)
+                    seq = cap.Seq(words.ctypes.data, L, 0, 0, 8, 2)
+                    n = L - K + 1
+                    res = cap.Result()
+                    fw, rv = np.zeros((n, N), np.uint64), np.zeros((n, N), np.uint64)
+                    rc = ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, dst, vp(fw), vp(rv), cap.MEM_HOST, C.byref(res))
+                    efw, erv, eres = orc.fwrv(words, L, 10, dst, K)
+                    assert (rc, res.err_pos, res.err_enc) == (eres.status, eres.err_pos, eres.err_enc), (dst, K, L)
+                    if rc == 0:
+                        assert np.array_equal(fw, efw) and np.array_equal(rv, erv), (dst, K, L)
+                    ck, hs = np.zeros((n, N), np.uint64), np.zeros(n, np.uint64)
+                    rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, vp(ck), vp(hs), 9, cap.MEM_HOST, C.byref(res))
+                    ek, eh, eres = orc.canonical(words, L, 10, dst, K, seed=9)
+                    assert (rc, res.err_pos, res.err_enc) == (eres.status, eres.err_pos, eres.err_enc)
+                    if rc == 0:
+                        assert np.array_equal(ck, ek) and np.array_equal(hs, eh)
+                    for J in (3, K + 3):
+                        m = (L - K) // J + 1
+                        out = np.zeros((m, N), np.uint64)
+                        rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, dst, vp(out), cap.MEM_HOST, C.byref(res))
+                        es, eres = orc.spaced(words, L, 10, dst, K, J)
+                        assert (rc, res.err_pos, res.err_enc) == (eres.status, eres.err_pos, eres.err_enc), (dst, K, L, J)
+                        if rc == 0:
+                            assert np.array_equal(out, es)
+    seq = cap.Seq(naive.ascii_words(bytes([1, 2, 4, 8])).ctypes.data, 4, 0, 0, 8, 2)
+    res = cap.Result()
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), 2, 1, None, None, 0, 0, C.byref(res)) == cap.E_UNSUPPORTED
+    seq = cap.Seq(naive.ascii_words(b"ACGT").ctypes.data, 4, 0, 0, 8, 3)
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 2, 2, None, None, 0, C.byref(res)) == cap.E_BADARG
 
 
 def test_offset_views(km, ctx, orc):
@@ -607,9 +716,10 @@ def test_bad_arguments(km, ctx):
     res = cap.Result()
     assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 0, 2, vp(out), None, 0, C.byref(res)) == cap.E_BADARG
     assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), 3, 0, 2, vp(out), 0, C.byref(res)) == cap.E_BADARG
-    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 129, 2, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
-    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 65, 4, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
-    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 8, vp(out), None, 0, C.byref(res)) == cap.E_UNSUPPORTED
+    # kmers longer than the sequence: an empty iteration whatever their width (FwKmers.jl:63)
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 129, 2, vp(out), None, 0, C.byref(res)) == 0 and res.n_out == 0
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 65, 4, vp(out), None, 0, C.byref(res)) == 0 and res.n_out == 0
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 8, vp(out), None, 0, C.byref(res)) == cap.E_BADARG   # no 8-bit kmer alphabet here
     assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 3, 2, vp(out), None, cap.ASYNC, C.byref(res)) == cap.E_BADARG
 
 
