@@ -205,10 +205,11 @@ def verify_canonical(ctx, cap, stream, dev, buf, n_bases, first_kmer, first_word
     return ok
 
 
-def other_configs(ctx, cap, stream, dev, reps=5):
+def other_configs(ctx, cap, stream, dev, reps=7):
     """Kernel rates of the other BASELINE.json configs (parity-test cases, not the headline): C3 shape
     per GPU, C4, C5 strict and skip, and the north-star size (10 Gbase LongDNA{4}).  Resident data, HIP events on
-    the library's stream, median of reps."""
+    the library's stream, median of reps.  The 10 Gbase leg comes last: 165 GB of output per launch leave the device in a
+    lower power state for a while (the 1.6 ms C3 launch measured 1.84 ms right behind it, profiles/r02_tuning.md)."""
     import numpy as np
     import torch
     res = cap.Result()
@@ -246,23 +247,6 @@ def other_configs(ctx, cap, stream, dev, reps=5):
                      "GB_per_s": round(alg_bytes / ms / 1e6, 1), "frac_of_8TBps": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBPS, 4), **extra}
 
     with torch.cuda.stream(stream):
-        # N1 (north star): CanonicalDNAMers{31} + fx_hash over 10 Gbase LongDNA{4} on ONE GPU: 5 GB in, 160 GB out
-        free_b, _ = torch.cuda.mem_get_info(dev)
-        L, K = 10_000_000_000, 31
-        if free_b > 175e9:
-            seed10 = GOLDEN ^ 10
-            buf = synth(seed10, L, 4)
-            n = L - K + 1
-            a = torch.empty(n, dtype=torch.int64, device=dev)
-            h = torch.empty(n, dtype=torch.int64, device=dev)
-            seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
-            ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), h.data_ptr(), 0, ASYNC, C.byref(res)))
-            ok = verify_canonical(ctx, cap, stream, dev, buf, L, 0, 0, 4, K, 1, seed10, a, h, n)
-            entry("N1 north star: CanonicalDNAMers{31} + fx_hash, 10 Gbase LongDNA{4}, one GPU, 16.5 B/kmer", ms, L, 16.5 * n, verified=ok)
-            del buf, a, h
-            torch.cuda.empty_cache()
-        else:
-            out["N1 north star: 10 Gbase LongDNA{4}"] = {"skipped": f"needs 165 GB of HBM, {free_b / 1e9:.0f} GB free"}
         # C3: CanonicalDNAMers{31} over 10 Gbase LongDNA{2} sharded 8 ways -> 1.25 Gbase per GPU, kmers only
         L, K = 1_250_000_000, 31
         buf = synth(GOLDEN ^ 3, L, 2)
@@ -326,6 +310,24 @@ def other_configs(ctx, cap, stream, dev, reps=5):
         out[f"kmers_batch: {n_reads} reads x {rl} bases, CanonicalDNAMers{{31}} + fx_hash per read"] = {
             "ms": round(ms, 4), "G_elements_per_s": round(total / ms / 1e6, 1), "Gbases_per_s": round(n_reads * rl / ms / 1e6, 1),
             "GB_per_s": round((16.0 * total + 0.5 * n_reads * rl) / ms / 1e6, 1)}
+        del a, b, buf, spans, counts
+        torch.cuda.empty_cache()
+        # N1 (north star): CanonicalDNAMers{31} + fx_hash over 10 Gbase LongDNA{4} on ONE GPU: 5 GB in, 160 GB out
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        L, K = 10_000_000_000, 31
+        if free_b > 175e9:
+            seed10 = GOLDEN ^ 10
+            buf = synth(seed10, L, 4)
+            n = L - K + 1
+            a = torch.empty(n, dtype=torch.int64, device=dev)
+            h = torch.empty(n, dtype=torch.int64, device=dev)
+            seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
+            ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), h.data_ptr(), 0, ASYNC, C.byref(res)))
+            ok = verify_canonical(ctx, cap, stream, dev, buf, L, 0, 0, 4, K, 1, seed10, a, h, n)
+            entry("N1 north star: CanonicalDNAMers{31} + fx_hash, 10 Gbase LongDNA{4}, one GPU, 16.5 B/kmer", ms, L, 16.5 * n, verified=ok)
+            del buf, a, h
+        else:
+            out["N1 north star: 10 Gbase LongDNA{4}"] = {"skipped": f"needs 165 GB of HBM, {free_b / 1e9:.0f} GB free"}
     return out
 
 

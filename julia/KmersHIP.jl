@@ -2,7 +2,8 @@
 # include/kmers_hip.h plus the methods that route Kmers.jl's own iterator API to them.
 #
 # NOT EXECUTED IN THIS REPOSITORY'S CI: neither `julia` nor BioSequences.jl exist in the build
-# image (see DESIGN.md).  It is the binding a Kmers.jl maintainer would add (INTEGRATION.md); the
+# image (see DESIGN.md).  It overloads `Base.collect` for Kmers.jl's iterator types over the sources this library reads;
+# every geometry the library does not take falls back to Kmers.jl's own method (`invoke(collect, Tuple{Any}, it)`).  It is the binding a Kmers.jl maintainer would add (INTEGRATION.md); the
 # same mapping is exercised through ctypes by kmers.jl_amd/host.py and tests/.
 #
 # Usage:
@@ -37,7 +38,8 @@ mutable struct CResult
     CResult() = new(0, 0, 0, 0)
 end
 
-const OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY = Int32.(0:6)
+const OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY, E_NCCL = Int32.(0:7)
+const ALPHABET_DNA, ALPHABET_RNA, ALPHABET_SYMBOLS = Int32(0), Int32(1), Int32(2)
 const MEM_HOST, MEM_DEVICE, ASYNC, OUT_TUPLES = Int32(0), Int32(1), Int32(2), Int32(4)
 
 # ---- context (one per Julia thread) --------------------------------------------------------
@@ -53,15 +55,18 @@ mutable struct Context
     end
 end
 
-const CONTEXTS = Dict{Int, Context}()
-context() = get!(() -> Context(0), CONTEXTS, Threads.threadid())
+# One context (= one HIP stream) per TASK: tasks migrate between threads, so a table keyed by threadid() would hand one
+# context to two running tasks; task-local storage cannot.  (A kmers_ctx is not thread-safe; any number of them may run
+# concurrently.)
+context() = get!(() -> Context(0), task_local_storage(), :kmers_hip_context)::Context
 last_error(ctx::Context) = unsafe_string(@ccall LIB.kmers_last_error(ctx.handle::Ptr{Cvoid})::Cstring)
 
 # ---- helpers -------------------------------------------------------------------------------
 const NucAlphabet24 = Union{DNAAlphabet{2}, DNAAlphabet{4}, RNAAlphabet{2}, RNAAlphabet{4}}
 const NucSeq24 = LongSequence{<:NucAlphabet24}
 const ByteSource = Union{String, SubString{String}, Vector{UInt8}, Base.CodeUnits{UInt8, String}}
-const Source = Union{NucSeq24, ByteSource}          # every source a RecodingScheme other than Generic covers
+const SymbolVector = Union{Vector{DNA}, Vector{RNA}}   # GenericRecoding sources whose memory is one BioSymbols value per byte
+const Source = Union{NucSeq24, ByteSource, SymbolVector}
 const TwoBitAlphabet = Union{DNAAlphabet{2}, RNAAlphabet{2}}
 
 dst_bits(::Type{A}) where {A} = Int32(BioSequences.bits_per_symbol(A()))
@@ -72,6 +77,10 @@ cseq(s::LongSequence, ::Type{A}) where {A} =
     CSeq(pointer(s.data), length(s) % UInt64, 0, 0, Int32(BioSequences.bits_per_symbol(Alphabet(s))), 0)
 cseq(s::ByteSource, ::Type{A}) where {A} =
     CSeq(Ptr{UInt64}(pointer(s)), ncodeunits_or_length(s) % UInt64, 0, 0, Int32(8), isrna(A))
+# a Vector{DNA} / Vector{RNA}: GenericRecoding in the reference (src/construction.jl:90-98); its memory is what
+# KMERS_ALPHABET_SYMBOLS reads.  (Other generic sources keep Kmers.jl's own path: they are not `Source`s here.)
+cseq(s::SymbolVector, ::Type{A}) where {A} =
+    CSeq(Ptr{UInt64}(pointer(s)), length(s) % UInt64, 0, 0, Int32(8), ALPHABET_SYMBOLS)
 ncodeunits_or_length(s::AbstractString) = ncodeunits(s)
 ncodeunits_or_length(s) = length(s)
 
@@ -80,7 +89,7 @@ function check(ctx::Context, rc::Integer, res::CResult, ::Type{A}, s) where {A}
     rc == OK && return nothing
     if rc == E_ENCODE
         # LongSequence sources: the offending symbol; byte sources: repr(byte) (FwKmers.jl:124-126)
-        sym = s isa LongSequence ? reinterpret(eltype(s), res.err_enc % UInt8) : repr(res.err_enc % UInt8)
+        sym = (s isa LongSequence || s isa SymbolVector) ? reinterpret(eltype(s), res.err_enc % UInt8) : repr(res.err_enc % UInt8)
         throw(BioSequences.EncodeError(A(), sym))
     end
     error("libkmers_hip: status $rc: $(last_error(ctx))")
@@ -155,6 +164,9 @@ end
 
 "collect(UnambiguousKmers{A,K}(seq)): (kmer, start) tuples (UnambiguousKmers.jl:59-148)"
 function Base.collect(it::UnambiguousKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: Source}
+    # geometries this entry point does not take keep Kmers.jl's own path (kmers of more than four words; a Vector{DNA}
+    # source has no UnambiguousKmers method in the reference either and fails there exactly as it always did)
+    (cld(2K, 64) > 4 || it.it.seq isa SymbolVector) && return invoke(collect, Tuple{Any}, it)
     ctx, s = context(), it.it.seq
     T = Kmers.derive_type(Kmer{A, K})
     res = CResult()
@@ -422,6 +434,65 @@ function shard_plan(len::Integer, K::Integer, n_shards::Integer, shard_id::Integ
                                      shard_id::Cint, out::Ptr{CShard})::Cint
     rc == OK || error("kmers_shard_plan: bad arguments")
     return out[]
+end
+
+# ---- the sharded path: one Julia process per GPU, RCCL behind the C ABI ---------------------------
+# (include/kmers_hip.h, "the communication of the sharded path").  The 128-byte id made by ONE rank travels over whatever
+# the host program has (MPI.jl `MPI.bcast`, Distributed.jl `remotecall`, a shared file).
+"ncclGetUniqueId through the library: call on one rank, hand the bytes to all."
+function comm_id()
+    id = Vector{UInt8}(undef, 128)
+    rc = @ccall LIB.kmers_comm_id(pointer(id)::Ptr{UInt8})::Cint
+    rc == OK || error("kmers_comm_id: status $rc")
+    return id
+end
+
+mutable struct Comm
+    ctx::Context
+    handle::Ptr{Cvoid}
+    rank::Int
+    n_ranks::Int
+end
+
+"ncclCommInitRank on the context's device; collective over all `n_ranks` callers."
+function Comm(id::Vector{UInt8}, n_ranks::Integer, rank::Integer; ctx::Context = context())
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = GC.@preserve id @ccall LIB.kmers_comm_create(ctx.handle::Ptr{Cvoid}, pointer(id)::Ptr{UInt8}, n_ranks::Cint, rank::Cint,
+                                                      h::Ptr{Ptr{Cvoid}})::Cint
+    rc == OK || error("kmers_comm_create: status $rc: $(last_error(ctx))")
+    c = Comm(ctx, h[], rank, n_ranks)
+    finalizer(x -> (@ccall LIB.kmers_comm_destroy(x.ctx.handle::Ptr{Cvoid}, x.handle::Ptr{Cvoid})::Cint), c)
+    return c
+end
+
+"""
+    halo_exchange!(comm, shard, words_dev)
+
+The one neighbour step of the path (grouped ncclSend/ncclRecv on the context's stream, enqueue only): `words_dev` (HBM:
+the shard's own words followed by room for `shard.halo_words`) receives the first words of shard `rank + 1` behind its own
+and sends its first `shard.send_words` words to `rank - 1`.
+"""
+function halo_exchange!(c::Comm, shard::CShard, words_dev::Ptr{UInt64})
+    rc = @ccall LIB.kmers_halo_exchange(c.ctx.handle::Ptr{Cvoid}, c.handle::Ptr{Cvoid}, Ref(shard)::Ptr{CShard},
+                                        words_dev::Ptr{UInt64})::Cint
+    rc == OK || error("kmers_halo_exchange: status $rc: $(last_error(c.ctx))")
+    return nothing
+end
+
+"The first EncodeError of the whole sequence (`res` holds this shard's, positions global): ncclAllReduce(min)."
+function first_error!(c::Comm, res::CResult)
+    rc = @ccall LIB.kmers_first_error_allreduce(c.ctx.handle::Ptr{Cvoid}, c.handle::Ptr{Cvoid}, res::Ref{CResult})::Cint
+    (rc == OK || rc == E_ENCODE) || error("kmers_first_error_allreduce: status $rc: $(last_error(c.ctx))")
+    return res
+end
+
+"(offset of this shard's elements in the global output, total) for SizeUnknown iterators: ncclAllGather + scan."
+function output_offsets(c::Comm, n_local::Integer)
+    off, tot = Ref{UInt64}(0), Ref{UInt64}(0)
+    rc = @ccall LIB.kmers_offsets_allgather(c.ctx.handle::Ptr{Cvoid}, c.handle::Ptr{Cvoid}, n_local::UInt64,
+                                            off::Ptr{UInt64}, tot::Ptr{UInt64})::Cint
+    rc == OK || error("kmers_offsets_allgather: status $rc: $(last_error(c.ctx))")
+    return Int(off[]), Int(tot[])
 end
 
 # ---- chunk-buffered iterate(): `for kmer in gpu(it)` -----------------------------------------

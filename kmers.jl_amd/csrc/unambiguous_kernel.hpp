@@ -390,9 +390,13 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
                     const uint64_t o2 = pos + i;
                     if (o2 < a.capacity) {
                         if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
+                            if (N == 1 && a.vec16) {  // one 16-byte store per element
+                                *reinterpret_cast<ulonglong2 *>(a.out_kmers + 2u * o2) = make_ulonglong2(fw[0], origin + r);
+                            } else {
 #pragma unroll
-                            for (int wd = 0; wd < N; ++wd) a.out_kmers[o2 * (N + 1) + wd] = fw[wd];
-                            a.out_kmers[o2 * (N + 1) + N] = origin + r;
+                                for (int wd = 0; wd < N; ++wd) a.out_kmers[o2 * (N + 1) + wd] = fw[wd];
+                                a.out_kmers[o2 * (N + 1) + N] = origin + r;
+                            }
                         } else {
                             if (a.out_kmers) {
 #pragma unroll

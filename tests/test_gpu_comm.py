@@ -138,3 +138,18 @@ def test_async_launches_share_one_error_slot(km, ctx):
     assert rc == 0
     for p in (d_clean, d_bad, out):
         ctx.free(p)
+
+
+def test_plain_c_sharded_client(tmp_path):
+    """examples/sharded_canonical.c: the sharded path from plain C -- no torch in the process, so the RCCL the library was
+    linked with (/opt/rocm) is the one that runs: shard plan, halo words through kmers_comm_sendrecv on a communicator,
+    index_origin, the two reductions; 8 and 3 shards must reproduce the unsharded checksum."""
+    csrc = os.path.join(ROOT, "kmers.jl_amd", "csrc")
+    exe = tmp_path / "sharded_canonical"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "sharded_canonical.c"),
+                    "-L", csrc, "-lkmers_hip", f"-Wl,-rpath,{csrc}", "-o", str(exe)], check=True)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    for shards, bases in (("8", "10000003"), ("3", "999"), ("5", "64")):
+        out = subprocess.run([str(exe), shards, bases], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, (out.stdout, out.stderr)
+        assert "communicator: rank 0 of 1" in out.stdout and ": equal" in out.stdout, out.stdout

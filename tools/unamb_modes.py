@@ -36,4 +36,7 @@ for K, J in ((31, 1), (21, 3)):
     t_xor = timed(lambda: ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), K, 2, cap.ITER_UNAMBIGUOUS, J, C.byref(val), cap.MEM_DEVICE, C.byref(res)))
     t_emit = timed(lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, J, kk.data_ptr(), ss.data_ptr(), L // 2, cap.MEM_DEVICE, C.byref(res)))
     t_k = timed(lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, J, kk.data_ptr(), None, L // 2, cap.MEM_DEVICE, C.byref(res)))
+    OUT_TUPLES = 4
+    t_t = timed(lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, J, kk.data_ptr(), None, L // 4, cap.MEM_DEVICE | OUT_TUPLES, C.byref(res)))
+    print(f"K={K} J={J} tuples {t_t:.3f} ms", end="  ")
     print(f"K={K} J={J} kept {m}: COUNT {t_count:.3f} ms  XOR {t_xor:.3f} ms  EMIT kmers+starts {t_emit:.3f} ms  EMIT kmers only {t_k:.3f} ms")
