@@ -464,22 +464,26 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         HIP_TRY(ctx, hipMemsetAsync(scratch, 0, ((size_t)a.n_tiles + 2) * 8, ctx->stream));
         a.desc = scratch;
         a.ticket = scratch + a.n_tiles;
+        a.abort_flag = scratch + a.n_tiles + 1;
         a.out_kmers = d_k;
         a.out_starts = d_s;
         a.capacity = dev ? capacity : total;
         a.vec16 = ((!d_k || aligned16(d_k)) && (!d_s || aligned16(d_s))) ? 1u : 0u;
-        dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap_grid));
+        // a persistent grid: every workgroup draws tickets until none is left (three workgroups per CU: the kernel keeps
+        // two tiles' state in LDS, 41 KiB; its throughput is flat from two workgroups per CU on, profiles/r02_tuning.md)
+        dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, std::min<uint64_t>(cap_grid, (uint64_t)ctx->n_cus * UNAMB_EMIT_WGS)));
         launch_unambiguous<UMODE_EMIT>(ctx, seq->src_bits, nw, grid, a);
         HIP_TRY(ctx, hipGetLastError());
         // the last tile's inclusive prefix is the element count
-        uint64_t *h = ctx->h_result + 2;  // pinned
-        HIP_TRY(ctx, hipMemcpyAsync(h, a.desc + (a.n_tiles - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+        uint64_t *h = ctx->h_result + 2;  // pinned: [last descriptor, ticket counter, abort flag]
+        HIP_TRY(ctx, hipMemcpyAsync(h, a.desc + (a.n_tiles - 1), 24, hipMemcpyDeviceToHost, ctx->stream));
         if (ascii) {  // an invalid byte anywhere in the source is an EncodeError
             if (int erc = collect(ctx, res, 0)) return erc;
         } else {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
-        total = *h & DESC_VALUE;
+        if (h[2]) return fail(ctx, KMERS_E_HIP, "UnambiguousKmers: a tile never published its count (look-back gave up)");
+        total = h[0] & DESC_VALUE;
         if (res) res->n_out = total;
         if (total > capacity) {  // the kernel stored nothing at or beyond the capacity
             if (res) res->status = KMERS_E_CAPACITY;

@@ -34,9 +34,18 @@ constexpr uint32_t UTILE_MAX = KMERS_UTILE_MAX;  // candidate starts per tile (a
 #endif
 constexpr uint32_t UROUND = KMERS_UROUND;  // starts per wavefront round (16 or 8 per lane)
 constexpr uint32_t USLICE = UROUND / 64;  // consecutive starts per lane
+#ifndef KMERS_UNAMB_WGS
+#define KMERS_UNAMB_WGS 3
+#endif
+constexpr int UNAMB_EMIT_WGS = KMERS_UNAMB_WGS;  // workgroups per CU of the emitting mode (its LDS: two tiles' state)
 constexpr uint64_t DESC_VALUE = (1ull << 62) - 1ull;
 constexpr uint64_t DESC_AGGREGATE = 1ull << 62, DESC_PREFIX = 2ull << 62;
 constexpr int LOOKBACK = 4;               // descriptors per lane and look-back step (256 tiles per step)
+// Every spin is bounded (MI355X_MICROARCH.md, correctness boundaries): a look-back polls a missing aggregate at most
+// SPIN_LIMIT times (well over a second; a tile publishes its aggregate microseconds after its ticket), then raises the abort
+// flag, which every other look-back checks every SPIN_CHECK polls: the kernel drains and the host reports KMERS_E_HIP
+// instead of hanging the device.
+constexpr uint32_t SPIN_CHECK = 1024, SPIN_LIMIT = 1u << 22;
         // descriptors per lane and look-back step (256 per step)
 
 enum UMode { UMODE_EMIT = 0, UMODE_COUNT = 1, UMODE_XOR = 2 };
@@ -49,6 +58,7 @@ struct UnambArgs {
     uint64_t n_tiles;
     unsigned long long *desc;      // EMIT: [n_tiles] tile descriptors, zeroed before the launch
     unsigned long long *ticket;    // EMIT: zeroed; tile ids are drawn in the order workgroups start
+    unsigned long long *abort_flag;  // EMIT: zeroed; set if a look-back ever waits longer than it possibly can (see SPIN_LIMIT)
     unsigned long long *total;     // COUNT: += kept starts;  XOR: ^= head words of the kept kmers
     uint64_t *out_kmers;           // nullable
     long long *out_starts;         // nullable
@@ -126,16 +136,18 @@ __device__ __forceinline__ void cut_fw(const uint64_t *rs, uint32_t o, uint64_t 
 }
 
 template <int SRC_BITS, int N, int UMODE>
-__global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a) {
+__global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 8) void unambiguous_kernel(const UnambArgs a) {
+    constexpr bool EMIT = UMODE == UMODE_EMIT;
+    constexpr uint32_t NBUF = EMIT ? 2u : 1u;  // EMIT resolves tile n+1 before it emits tile n: two sets of tile state
     constexpr uint32_t STREAM_QWORDS = (UTILE_MAX + 128 + 64) / 32 + 4;   // 2-bit codes of the tile + its K-1 overlap
     constexpr uint32_t AMB_QWORDS = (UTILE_MAX + 128 + 64) / 64 + 6;
     constexpr uint32_t MAXQ = UTILE_MAX / 64;
-    __shared__ uint64_t lds[STREAM_QWORDS];
-    __shared__ uint64_t amb[AMB_QWORDS];
-    __shared__ uint64_t keepm[MAXQ];                                     // bit j of keepm[q]: start 64q + j is kept
-    __shared__ uint32_t pre[MAXQ + 1];                                   // kept starts of the tile before qword q
-    // per wavefront: the kept starts of a round.  512-start rounds fit the flag stream's space, which is dead once the tile is
-    // resolved (8 workgroups per CU instead of 5)
+    __shared__ uint64_t lds2[NBUF][STREAM_QWORDS];
+    __shared__ uint64_t keepm2[NBUF][MAXQ];                              // bit j of keepm[q]: start 64q + j is kept
+    __shared__ uint32_t pre2[NBUF][MAXQ + 1];                            // kept starts of the tile before qword q; [MAXQ] = all
+    __shared__ uint64_t amb[AMB_QWORDS];                                 // flag stream: only between stage and resolve
+    // per wavefront: the kept starts of a round.  512-start rounds fit the flag stream's space, which is dead while a tile is
+    // emitted (four workgroups per CU instead of three)
     constexpr bool LIST_IN_AMB = WAVES * UROUND * 2 <= AMB_QWORDS * 8;
     __shared__ uint16_t kept_own[(UMODE == UMODE_COUNT || LIST_IN_AMB) ? 1 : WAVES * UROUND];
     uint16_t *const kept = LIST_IN_AMB ? reinterpret_cast<uint16_t *>(amb) : kept_own;
@@ -150,37 +162,51 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
     const uint64_t mask = head_mask((int)k, 2);
     const uint32_t T = a.tile_starts;
     uint64_t acc = 0;  // COUNT: kept starts; XOR: fold of the head words
+    uint64_t lattice = ~0ull;  // bit j set iff j % stride == 0 (stride < 64; a larger stride has one lattice start per qword at most)
+    if (a.stride > 1) {
+        lattice = 0;
+        for (uint32_t j = 0; j < 64u; j += a.stride) lattice |= 1ull << j;
+    }
 
-    // EMIT: one tile per workgroup, drawn from the ticket counter; COUNT / XOR: a persistent grid strides over the tiles
-    for (uint64_t it = blockIdx.x; it < a.n_tiles; it += gridDim.x) {
-        uint64_t tile = it;
+    struct Geom {
+        uint64_t m0, w0;
+        uint32_t mt, b0, nw, nq, kbit0;
+    };
+    auto geometry = [&](uint64_t tile) {
+        Geom g;
+        g.m0 = tile * T;
+        const uint64_t left = a.n_cand - g.m0;
+        g.mt = left < T ? (uint32_t)left : T;
+        const uint64_t bit0 = a.first_bit + g.m0 * SRC_BITS;
+        g.w0 = bit0 >> 6;
+        g.b0 = (uint32_t)(bit0 & 63u) / SRC_BITS;
+        const uint64_t end_bit = bit0 + ((uint64_t)(g.mt - 1) + k) * SRC_BITS;
+        g.nw = (uint32_t)(((end_bit + 63) >> 6) - g.w0);
+        g.nq = (g.mt + 63u) >> 6;
+        g.kbit0 = g.nw * (128u / SRC_BITS) - 2u * (g.b0 + k);  // the kmer of tile start r sits at stream bit kbit0 - 2r
+        return g;
+    };
 #ifdef KMERS_STAMPS
-        uint64_t ts[8];
-        ts[0] = __builtin_amdgcn_s_memrealtime();
+    uint64_t ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define USTAMP(i) ts[i] = __builtin_amdgcn_s_memrealtime()
 #else
 #define USTAMP(i)
 #endif
-        if constexpr (UMODE == UMODE_EMIT) {
-            if (tid == 0) s_tile = atomicAdd(a.ticket, 1ull);
-        }
-        block_sync();  // also: the previous tile's readers are done with the LDS arrays
-        if constexpr (UMODE == UMODE_EMIT) tile = s_tile;
-        USTAMP(1);  // ticket drawn
-        const uint64_t m0 = tile * T;
-        const uint64_t left = a.n_cand - m0;
-        const uint32_t mt = left < T ? (uint32_t)left : T;
-        const uint64_t bit0 = a.first_bit + m0 * SRC_BITS;
-        const uint64_t w0 = bit0 >> 6;
-        const uint32_t b0 = (uint32_t)(bit0 & 63u) / SRC_BITS;
-        const uint64_t end_bit = bit0 + ((uint64_t)(mt - 1) + k) * SRC_BITS;
-        const uint32_t nw = (uint32_t)(((end_bit + 63) >> 6) - w0);
-        const uint32_t nq = (mt + 63u) >> 6;
-        const uint32_t kbit0 = nw * (128u / SRC_BITS) - 2u * (b0 + k);  // the kmer of tile start r sits at stream bit kbit0 - 2r
 
-        // ---- stage: source words -> 2-bit codes + one ambiguity flag per symbol ------------------------------------
-        // (all of a lane's loads are in flight before the first is used -- a 32768-start tile of a 4-bit source is 2050
-        // words, nine per lane -- so that a tile pays one memory latency; byte sources take two such batches)
+    // ---- front of a tile: stage its source words once, resolve every candidate start, publish the AGGREGATE -----------
+    auto front = [&](uint64_t tile, uint32_t buf) {
+        uint64_t *const lds = lds2[buf];
+        uint64_t *const keepm = keepm2[buf];
+        uint32_t *const pre = pre2[buf];
+        const Geom g = geometry(tile);
+        const uint32_t nw = g.nw, b0 = g.b0, mt = g.mt, nq = g.nq;
+        const uint64_t w0 = g.w0, m0 = g.m0;
+        const uint32_t tile_rem = a.stride > 1 ? (uint32_t)(m0 % a.stride) : 0u;  // wave-uniform
+        block_sync();  // the readers of this buffer (the tile before last), of the flag stream and of the list are done
+        USTAMP(1);
+        // stage: source words -> 2-bit codes (in kmer order) + one ambiguity flag per symbol
+        // (all of a lane's loads of a batch are in flight before the first is used -- a 32768-start tile of a 4-bit source is
+        // 2050 words, nine per lane -- so that a tile pays one memory latency; byte sources take two such batches)
         constexpr uint32_t PRE = 9;
         for (uint32_t wbase = 0; wbase < nw; wbase += PRE * BLOCK) {
             uint64_t xs[PRE];
@@ -220,67 +246,70 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
             }
         }
         // (flag and code bits past the staged words only ever reach starts >= mt, which are masked out below)
-        USTAMP(2);  // this wavefront's source words staged
+        USTAMP(2);
         block_sync();
-        USTAMP(3);  // everybody's
-
-        // ---- resolve: keep mask of every candidate start, kept starts before every qword ------------------------------
-        // thread t owns qwords 2t and 2t + 1 of the keep mask (64 starts each)
-        uint32_t tile_total = 0;
-        {
-            uint32_t c2[2];
+        USTAMP(3);
+        // resolve: thread t owns qwords 2t and 2t + 1 of the keep mask (64 starts each)
+        uint32_t c2[2];
 #pragma unroll
-            for (uint32_t h = 0; h < 2; ++h) {
-                const uint32_t q = 2u * tid + h;
-                uint64_t keep = 0;
-                if (q < nq) {
-                    keep = keep_qword(amb, 64u * q + b0, k);
-                    const uint32_t valid = mt - 64u * q;  // starts of this qword that exist
-                    if (valid < 64u) keep &= (1ull << valid) - 1ull;
-                    if (a.stride > 1) {                   // keep only starts with (m0 + 64q + j) % stride == 0
-                        const uint64_t rem = (m0 + 64ull * q) % a.stride;
-                        uint64_t lat = 0;
-                        for (uint64_t pbit = rem ? a.stride - rem : 0; pbit < 64; pbit += a.stride) lat |= 1ull << pbit;
-                        keep &= lat;
-                    }
+        for (uint32_t h = 0; h < 2; ++h) {
+            const uint32_t q = 2u * tid + h;
+            uint64_t keep = 0;
+            if (q < nq) {
+                keep = keep_qword(amb, 64u * q + b0, k);
+                const uint32_t valid = mt - 64u * q;  // starts of this qword that exist
+                if (valid < 64u) keep &= (1ull << valid) - 1ull;
+                if (a.stride > 1) {                   // keep only starts with (m0 + 64q + j) % stride == 0
+                    const uint32_t rem = (tile_rem + (64u * q) % a.stride) % a.stride;   // (m0 + 64q) % stride
+                    const uint32_t first = rem ? a.stride - rem : 0u;                    // first lattice start of the qword, then every stride-th
+                    keep = first < 64u ? keep & (lattice << first) : 0;
                 }
-                keepm[q] = keep;
-                c2[h] = (uint32_t)__popcll(keep);
             }
-            const uint32_t c = c2[0] + c2[1];
-            uint32_t incl = c;
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(incl, d, 64);
-                if ((int)lane >= d) incl += y;
-            }
-            if (lane == 63) s_wave_total[wave] = incl;
-            block_sync();
-            uint32_t before = 0;
+            keepm[q] = keep;
+            c2[h] = (uint32_t)__popcll(keep);
+        }
+        const uint32_t c = c2[0] + c2[1];
+        uint32_t incl = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += y;
+        }
+        if (lane == 63) s_wave_total[wave] = incl;
+        block_sync();
+        uint32_t before = 0, tile_total = 0;
 #pragma unroll
-            for (uint32_t w = 0; w < (uint32_t)WAVES; ++w) {
-                const uint32_t wt = s_wave_total[w];
-                if (w < wave) before += wt;
-                tile_total += wt;
-            }
-            pre[2u * tid] = before + incl - c;
-            pre[2u * tid + 1u] = before + incl - c + c2[0];
-            if (tid == 0) pre[MAXQ] = tile_total;
+        for (uint32_t w = 0; w < (uint32_t)WAVES; ++w) {
+            const uint32_t wt = s_wave_total[w];
+            if (w < wave) before += wt;
+            tile_total += wt;
         }
-        if constexpr (UMODE == UMODE_COUNT) {
-            if (tid == 0) acc += tile_total;
+        pre[2u * tid] = before + incl - c;
+        pre[2u * tid + 1u] = before + incl - c + c2[0];
+        if (tid == 0) {
+            pre[MAXQ] = tile_total;
+            if constexpr (UMODE == UMODE_COUNT) acc += tile_total;
+            // the aggregate is out as early as it can be: the tiles behind this one wait for nothing else of it
+            if constexpr (EMIT) desc_store(a.desc + tile, (tile == 0 ? DESC_PREFIX : DESC_AGGREGATE) | (uint64_t)tile_total);
         }
-        USTAMP(4);  // keep mask and prefix of the tile resolved
-        if (wave == 0) {
-            if constexpr (UMODE == UMODE_EMIT) {
-                // ---- publish the aggregate, look back for the exclusive prefix, publish the inclusive prefix -------
+        USTAMP(4);
+    };
+
+    // ---- back of a tile: its exclusive prefix (look-back), then list and emit its kept starts --------------------------
+    auto back = [&](uint64_t tile, uint32_t buf) {
+        const uint64_t *const lds = lds2[buf];
+        const uint64_t *const keepm = keepm2[buf];
+        const uint32_t *const pre = pre2[buf];
+        const Geom g = geometry(tile);
+        const uint32_t mt = g.mt, nq = g.nq, kbit0 = g.kbit0;
+        const uint64_t m0 = g.m0;
+        if constexpr (EMIT) {
+            if (wave == 0) {
+                // Sum the descriptors of the preceding tiles, nearest first, until one holds an inclusive PREFIX.  Every step
+                // reads LOOKBACK x 64 descriptors with all loads in flight together; a tile that has not published yet is
+                // polled alone (re-reading whole windows made 1280 wavefronts hammer the same few cache lines).
                 uint64_t excl = 0;
-                if (tile == 0) {
-                    if (lane == 0) desc_store(a.desc, DESC_PREFIX | (uint64_t)tile_total);
-                } else {
-                    if (lane == 0) desc_store(a.desc + tile, DESC_AGGREGATE | (uint64_t)tile_total);
-                    // Every step reads LOOKBACK descriptors per lane, all loads in flight together: the step must cover the
-                    // tiles that started within one look-back time (about 20 tiles per microsecond here, and a descriptor read
-                    // takes 2-3 us under load), or the distance to the nearest published prefix grows without bound.
+                if (tile != 0) {
+                    const uint32_t tile_total = pre[MAXQ];
                     long long pos = (long long)tile - 1;  // the nearest predecessor not yet accounted for
                     uint64_t part = 0;                    // this lane's share of the sum
                     bool found = false;
@@ -295,7 +324,7 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
                         for (int j = 0; j < LOOKBACK; ++j) {
                             if (!found) {
                                 const long long idx = pos - (long long)(lane + 64u * (uint32_t)j);
-                                uint32_t fp;
+                                uint32_t fp, spins = 0;
                                 for (;;) {
                                     const uint32_t st = (uint32_t)(e[j] >> 62);
                                     const uint64_t bp = __ballot(st == 2u);
@@ -303,6 +332,14 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
                                     const bool wait = st == 0u && lane < fp;             // a nearer tile has not published yet
                                     if (__ballot(wait) == 0) break;
                                     __builtin_amdgcn_s_sleep(8);
+                                    if ((++spins % SPIN_CHECK) == 0) {                   // bounded: see SPIN_LIMIT
+                                        const bool raised = desc_load(a.abort_flag) != 0;
+                                        if (raised || spins >= SPIN_LIMIT) {
+                                            if (!raised && lane == 0) desc_store(a.abort_flag, 1ull);
+                                            fp = 0;  // give up: the result of this call is discarded by the host
+                                            break;
+                                        }
+                                    }
                                     if (wait) e[j] = desc_load(a.desc + idx);            // only the missing ones are read again
                                 }
                                 if (lane <= fp) part += e[j] & DESC_VALUE;  // aggregates up to and including the prefix
@@ -316,17 +353,15 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
                 }
                 if (lane == 0) s_base = excl;
             }
+            USTAMP(5);
+            block_sync();
+            USTAMP(6);
         }
-        if constexpr (UMODE == UMODE_COUNT) continue;  // (the loop's first barrier protects the LDS arrays)
-        USTAMP(5);  // (wavefront 0) look-back done
-        block_sync();
-        USTAMP(6);  // base known to everybody
-        const uint64_t base = UMODE == UMODE_EMIT ? s_base : 0;
+        const uint64_t base = EMIT ? s_base : 0;
 
-        // ---- emit: wavefront w takes rounds w, w + WAVES, ... of 1024 candidate starts -------------------------------
+        // every wavefront takes a CONTIGUOUS quarter of the tile's rounds of 1024 candidate starts, so that its stores sweep
+        // one contiguous region of each output array
         uint16_t *mine = kept + wave * UROUND;
-        // every wavefront takes a CONTIGUOUS quarter of the tile's rounds, so that its stores sweep one contiguous region
-        // of each output array (partial first / last lines only where two wavefronts' regions meet)
         const uint32_t rounds_per_wave = ((mt + UROUND - 1u) / UROUND + WAVES - 1u) / WAVES;
         const uint32_t wave_end = (wave + 1u) * rounds_per_wave * UROUND < mt ? (wave + 1u) * rounds_per_wave * UROUND : mt;
         for (uint32_t r_begin = wave * rounds_per_wave * UROUND; r_begin < wave_end; r_begin += UROUND) {
@@ -341,10 +376,10 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
             uint64_t pos = base + round_off;                                    // output index of the round's first
             if (cnt == 0) continue;
             const uint64_t origin = m0 + 1 + a.index_origin;                     // start of candidate r is origin + r
-            if constexpr (N == 1 && UMODE == UMODE_EMIT) {
+            if constexpr (N == 1 && EMIT) {
                 // Dense round (every one of its starts is kept -- the normal state of real sequence outside its N
-                // blocks): no list; two consecutive kmers per lane (the second by the reference's rolling step,
-                // construction_utils.jl:129-134) and 16-byte stores aligned to the parity of the output position.
+                // blocks): no list; two consecutive kmers per lane and 16-byte stores aligned to the parity of the
+                // output position.
                 if (cnt == n_round && a.vec16 && !a.tuples && pos + cnt <= a.capacity) {
                     const uint32_t head = (uint32_t)(pos & 1u);
                     auto single = [&](uint32_t e) {
@@ -360,8 +395,7 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
                         uint64_t fa[1], fb[1];
                         cut_fw<1>(lds, kbit0 - 2u * (r_begin + e), mask, fa);
                         cut_fw<1>(lds, kbit0 - 2u * (r_begin + e + 1u), mask, fb);
-                        const uint64_t f0 = fa[0], f1 = fb[0];
-                        if (a.out_kmers) *reinterpret_cast<ulonglong2 *>(a.out_kmers + pos + e) = make_ulonglong2(f0, f1);
+                        if (a.out_kmers) *reinterpret_cast<ulonglong2 *>(a.out_kmers + pos + e) = make_ulonglong2(fa[0], fb[0]);
                         if (a.out_starts)
                             *reinterpret_cast<ulonglong2 *>(a.out_starts + pos + e) =
                                 make_ulonglong2(origin + r_begin + e, origin + r_begin + e + 1);
@@ -370,7 +404,7 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
                     continue;
                 }
             }
-            // list the kept starts of the round in LDS, in order: this lane's slice of 16 starts begins at list index o
+            // list the kept starts of the round in LDS, in order: this lane's slice of consecutive starts begins at list index o
             uint32_t o = pre[q] - round_off + (uint32_t)__popcll(km & ((1ull << sl) - 1ull));
             const uint32_t s0 = lane * USLICE;  // round-relative index of the slice's first start
             while (keep16) {
@@ -408,10 +442,9 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
                 }
             };
             bool paired = false;
-            if constexpr (UMODE == UMODE_EMIT) {
-                // Two listed elements per lane and 16-byte stores (8-byte stores per lane cap this device near 4 TB/s,
-                // 16-byte ones reach 6.4; MI355X_MICROARCH.md, profiles/r02_tuning.md): the pair starts at an even output
-                // index, an odd first / last element goes alone.
+            if constexpr (EMIT) {
+                // Two listed elements per lane and 16-byte stores: the pair starts at an even output index, an odd first /
+                // last element goes alone.
                 paired = a.vec16 && !a.tuples && pos + cnt <= a.capacity;
                 if (paired) {
                     const uint32_t head = (uint32_t)(pos & 1u);
@@ -453,6 +486,44 @@ __global__ __launch_bounds__(BLOCK, 8) void unambiguous_kernel(const UnambArgs a
             o[9] = tile;
         }
 #endif
+    };
+
+    if constexpr (!EMIT) {
+        // COUNT / XOR: a persistent grid strides over the tiles; nothing is placed, so no descriptors
+        for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+            front(tile, 0);
+            if constexpr (UMODE == UMODE_XOR) {
+                block_sync();
+                back(tile, 0);
+            }
+        }
+    } else {
+        // EMIT: a persistent grid draws tiles from the ticket counter (tile ids in the order workgroups reach for them: a tile
+        // only ever waits for lower ids, all held by running workgroups) and works one tile AHEAD on the front: tile n+1 is
+        // staged, resolved and its aggregate published before tile n looks back and emits.  An aggregate is thus out a few
+        // microseconds after its ticket was drawn, and by the time a tile looks back -- one whole front later -- its
+        // predecessors have published theirs: the look-back finds what it needs at once (it waited 14 us per tile, with
+        // three of the four wavefronts idle, when it ran right behind the tile's own resolve).
+        auto draw = [&]() {
+            block_sync();  // (everybody has read the previous s_tile)
+            if (tid == 0) s_tile = atomicAdd(a.ticket, 1ull);
+            block_sync();
+            return (uint64_t)s_tile;
+        };
+        uint64_t cur = draw();
+        uint32_t buf = 0;
+        if (cur < a.n_tiles) front(cur, buf);
+        while (cur < a.n_tiles) {
+#ifdef KMERS_STAMPS
+            ts[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+            const uint64_t nxt = draw();
+            if (nxt < a.n_tiles) front(nxt, buf ^ 1u);
+            block_sync();  // the tile's own state (keep mask, prefix) is complete for every wavefront
+            back(cur, buf);
+            cur = nxt;
+            buf ^= 1u;
+        }
     }
     if constexpr (UMODE == UMODE_COUNT) {
         if (tid == 0 && acc) atomicAdd(a.total, (unsigned long long)acc);
