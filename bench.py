@@ -219,20 +219,28 @@ def other_configs(ctx, cap, stream, dev, reps=7):
         """HIP events on the library's stream around one call, median of reps.  Entry points with an asynchronous form
         (KMERS_ASYNC: kmers_canonical / kmers_fw / kmers_spaced) are timed in it, like the headline step: the events then
         bracket the kernel alone; around a synchronous call they would also bracket the host's wake-up after its stream
-        wait and its next launch (measured: +0.25 ms on a 1.6 ms kernel, tools/diag_c3.py, profiles/r02_tuning.md)."""
+        wait and its next launch (measured: +0.25 ms on a 1.6 ms kernel, tools/diag_c3.py, profiles/r02_tuning.md).
+        The device is kept busy with the same call for 50 ms first and the reps follow back to back: after an idle gap of
+        0.2 s or more this device runs its next ~10 ms slower (the 1.59 ms C3 launch: 1.65, 1.87, 2.04, 1.95, 1.89, 1.79 ms
+        in a row from a rested device, 1.59-1.61 right behind load; tools/diag_cooldown.py) -- a leg of a few launches
+        would otherwise measure that transient, not the kernel."""
         fn()
-        ts = []
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.05:
+            fn()
+            fn()
+            torch.cuda.synchronize()
+        evs = []
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
             e0.record(stream)
             fn()
             e1.record(stream)
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
         rc, _ = ctx.sync()
         assert rc == 0, ctx.last_error()
-        return float(np.median(ts))
+        return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
     ASYNC = cap.MEM_DEVICE | cap.ASYNC
 

@@ -87,7 +87,7 @@ struct RecodeArgs {
 };
 
 // ---- the ragged layout, computed on the device (a batch may hold tens of millions of records) ------
-// elements per record (FwKmers.jl:40-43) for the scan kernels of compact_kernels.hpp; bad[0] != 0 if a
+// elements per record (FwKmers.jl:40-43) for the scan kernels of unambiguous_kernel.hpp; bad[0] != 0 if a
 // span reaches outside the pool or a record is too long for the 32-bit count
 __global__ __launch_bounds__(256) void ragged_count_kernel(const RaggedSpan *__restrict__ spans, uint64_t n, uint32_t k,
                                                             uint32_t step, uint64_t pool_bases, uint32_t *__restrict__ counts,
