@@ -34,6 +34,9 @@ constexpr uint32_t UTILE_MAX = KMERS_UTILE_MAX;  // candidate starts per tile (a
 #endif
 constexpr uint32_t UROUND = KMERS_UROUND;  // starts per wavefront round (16 or 8 per lane)
 constexpr uint32_t USLICE = UROUND / 64;  // consecutive starts per lane
+// A round whose kept starts fit the wavefront's list takes 4096 candidate starts at once (64 per lane): with 14-28 % of the
+// starts kept, a 1024-start round lists 140-290 elements and fills its last 128-element store pass badly
+constexpr uint32_t ULONG = 4096, ULIST = 2048;
 #ifndef KMERS_UNAMB_WGS
 #define KMERS_UNAMB_WGS 3
 #endif
@@ -136,7 +139,7 @@ __device__ __forceinline__ void cut_fw(const uint64_t *rs, uint32_t o, uint64_t 
 }
 
 template <int SRC_BITS, int N, int UMODE>
-__global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 8) void unambiguous_kernel(const UnambArgs a) {
+__global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 5) void unambiguous_kernel(const UnambArgs a) {
     constexpr bool EMIT = UMODE == UMODE_EMIT;
     constexpr uint32_t NBUF = EMIT ? 2u : 1u;  // EMIT resolves tile n+1 before it emits tile n: two sets of tile state
     constexpr uint32_t STREAM_QWORDS = (UTILE_MAX + 128 + 64) / 32 + 4;   // 2-bit codes of the tile + its K-1 overlap
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 8) vo
     __shared__ uint64_t amb[AMB_QWORDS];                                 // flag stream: only between stage and resolve
     // per wavefront: the kept starts of a round.  512-start rounds fit the flag stream's space, which is dead while a tile is
     // emitted (four workgroups per CU instead of three)
-    constexpr bool LIST_IN_AMB = WAVES * UROUND * 2 <= AMB_QWORDS * 8;
-    __shared__ uint16_t kept_own[(UMODE == UMODE_COUNT || LIST_IN_AMB) ? 1 : WAVES * UROUND];
+    constexpr bool LIST_IN_AMB = WAVES * ULIST * 2 <= AMB_QWORDS * 8;
+    __shared__ uint16_t kept_own[(UMODE == UMODE_COUNT || LIST_IN_AMB) ? 1 : WAVES * ULIST];
     uint16_t *const kept = LIST_IN_AMB ? reinterpret_cast<uint16_t *>(amb) : kept_own;
     __shared__ uint64_t s_tile, s_base;
     __shared__ uint32_t s_wave_total[WAVES];
@@ -361,19 +364,35 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 8) vo
 
         // every wavefront takes a CONTIGUOUS quarter of the tile's rounds of 1024 candidate starts, so that its stores sweep
         // one contiguous region of each output array
-        uint16_t *mine = kept + wave * UROUND;
+        uint16_t *mine = kept + wave * ULIST;
         const uint32_t rounds_per_wave = ((mt + UROUND - 1u) / UROUND + WAVES - 1u) / WAVES;
         const uint32_t wave_end = (wave + 1u) * rounds_per_wave * UROUND < mt ? (wave + 1u) * rounds_per_wave * UROUND : mt;
-        for (uint32_t r_begin = wave * rounds_per_wave * UROUND; r_begin < wave_end; r_begin += UROUND) {
-            const uint32_t n_round = mt - r_begin < UROUND ? mt - r_begin : UROUND;
+        uint32_t n_round = 0;
+        for (uint32_t r_begin = wave * rounds_per_wave * UROUND; r_begin < wave_end; r_begin += n_round) {
             const uint32_t q0 = r_begin >> 6;
-            const uint32_t q = q0 + lane / (64u / USLICE), sl = USLICE * (lane % (64u / USLICE));
-            const uint64_t km = q < nq ? keepm[q] : 0;
-            uint32_t keep16 = (uint32_t)(km >> sl) & ((1u << USLICE) - 1u);
             const uint32_t round_off = pre[q0];
-            const uint32_t q1 = q0 + UROUND / 64u;
-            const uint32_t cnt = (q1 < nq ? pre[q1] : pre[MAXQ]) - round_off;  // kept starts of this round
-            uint64_t pos = base + round_off;                                    // output index of the round's first
+            // a long round if its kept starts fit the list (or nothing at all is dropped), else 1024 starts
+            n_round = wave_end - r_begin < ULONG ? wave_end - r_begin : ULONG;
+            uint32_t q1 = (r_begin + n_round + 63u) >> 6;
+            uint32_t cnt = (q1 < nq ? pre[q1] : pre[MAXQ]) - round_off;  // kept starts of this round
+            uint32_t usl = ULONG / 64u;                                    // consecutive starts per lane
+            uint64_t pos = base + round_off;                               // output index of the round's first
+            // (a round with nothing dropped needs no list when it can take the two-kmers-per-lane path below)
+            const bool dense_long = N == 1 && EMIT && cnt == n_round && a.vec16 && !a.tuples && pos + cnt <= a.capacity;
+            if (n_round > UROUND && cnt > ULIST && !dense_long) {
+                n_round = UROUND;
+                q1 = q0 + UROUND / 64u;
+                cnt = (q1 < nq ? pre[q1] : pre[MAXQ]) - round_off;
+                usl = USLICE;
+            } else if (n_round <= UROUND) {
+                usl = USLICE;
+            }
+            const uint32_t q = q0 + ((lane * usl) >> 6), sl = (lane * usl) & 63u;
+            const uint64_t km = q < nq ? keepm[q] : 0;
+            // this lane's slice of the keep mask: `usl` consecutive starts, cut at the end of the round (the starts behind it
+            // belong to the next wavefront's chunk)
+            const uint32_t mine_n = lane * usl < n_round ? (n_round - lane * usl < usl ? n_round - lane * usl : usl) : 0u;
+            uint64_t keep16 = (km >> sl) & (mine_n >= 64u ? ~0ull : ((1ull << mine_n) - 1ull));
             if (cnt == 0) continue;
             const uint64_t origin = m0 + 1 + a.index_origin;                     // start of candidate r is origin + r
             if constexpr (N == 1 && EMIT) {
@@ -406,10 +425,10 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 8) vo
             }
             // list the kept starts of the round in LDS, in order: this lane's slice of consecutive starts begins at list index o
             uint32_t o = pre[q] - round_off + (uint32_t)__popcll(km & ((1ull << sl) - 1ull));
-            const uint32_t s0 = lane * USLICE;  // round-relative index of the slice's first start
+            const uint32_t s0 = lane * usl;  // round-relative index of the slice's first start
             while (keep16) {
-                mine[o++] = (uint16_t)(s0 + (uint32_t)__builtin_ctz(keep16));
-                keep16 &= keep16 - 1u;
+                mine[o++] = (uint16_t)(s0 + (uint32_t)__builtin_ctzll(keep16));
+                keep16 &= keep16 - 1ull;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
