@@ -9,7 +9,7 @@ import naive
 
 pytestmark = pytest.mark.gpu
 
-KS = [1, 2, 5, 16, 21, 31, 32, 33, 47, 63, 64]
+KS = [1, 2, 5, 16, 21, 31, 32, 33, 47, 63, 64, 65, 96, 128, 129, 200]  # 129, 200: more than four words (run-time-width kernel)
 
 
 @pytest.fixture(scope="module")
