@@ -147,7 +147,28 @@ static uint32_t default_tile(uint32_t out_bytes_per_kmer, uint32_t pass) {
 }
 
 template <int MODE, int SB, int DB>
-void launch_widths(int n_words, bool s1, bool pair, dim3 grid, dim3 block, hipStream_t st, const StreamArgs &a, size_t dyn_lds) {
+void launch_widths(int n_words, bool s1, bool pair, bool fwd, dim3 grid, dim3 block, hipStream_t st, const StreamArgs &a, size_t dyn_lds) {
+    if constexpr (MODE == MODE_FW && DB == 2) {
+        if (fwd) {  // forward kmers only: kmer-order staging (stream_kernel.hpp, FWD)
+            if (pair) {
+                hipLaunchKernelGGL((stream_kernel<SB, DB, 1, MODE, false, false, true, true>), grid, block, dyn_lds, st, a);
+                return;
+            }
+#define LAUNCH_FWD(NN)                                                                                                    \
+    do {                                                                                                                  \
+        if (s1) hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, true, false, false, true>), grid, block, dyn_lds, st, a);  \
+        else hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, false, false, false, true>), grid, block, dyn_lds, st, a);    \
+    } while (0)
+            switch (n_words) {
+                case 1: LAUNCH_FWD(1); break;
+                case 2: LAUNCH_FWD(2); break;
+                case 3: LAUNCH_FWD(3); break;
+                default: LAUNCH_FWD(4); break;
+            }
+#undef LAUNCH_FWD
+            return;
+        }
+    }
     if constexpr (MODE == MODE_FW || MODE == MODE_CANON) {
         if (a.tuples) {  // array-of-structs outputs: one kmer per lane per pass
             switch (n_words) {
@@ -184,6 +205,11 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     const uint32_t J = a.stride;
     const bool stride1 = (J == 1) && vec_ok && !a.tuples;
     const bool pair = (MODE == MODE_FW || MODE == MODE_XOR) && J > 1 && vec_ok && !a.tuples && n_words == 1;
+#ifdef KMERS_NO_FWD  // A/B builds only
+    const bool fwd = false;
+#else
+    const bool fwd = MODE == MODE_FW && dst_bits == 2 && !a.out_b && !a.tuples;  // no reverse complements wanted
+#endif
     const uint32_t pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * BLOCK;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
                          (MODE == MODE_CANON && a.out_b ? 8u : 0u) + (MODE == MODE_FW && a.out_starts ? 8u : 0u);
@@ -205,12 +231,12 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, cap));
     dim3 block(BLOCK);
-    if (src_bits == 8 && dst_bits == 2) launch_widths<MODE, 8, 2>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
-    else if (src_bits == 8) launch_widths<MODE, 8, 4>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
-    else if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
-    else if (src_bits == 2 && dst_bits == 2) launch_widths<MODE, 2, 2>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
-    else if (src_bits == 4 && dst_bits == 4) launch_widths<MODE, 4, 4>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
-    else launch_widths<MODE, 2, 4>(n_words, stride1, pair, grid, block, ctx->stream, a, dyn_lds);
+    if (src_bits == 8 && dst_bits == 2) launch_widths<MODE, 8, 2>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 8) launch_widths<MODE, 8, 4>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 2 && dst_bits == 2) launch_widths<MODE, 2, 2>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 4 && dst_bits == 4) launch_widths<MODE, 4, 4>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
+    else launch_widths<MODE, 2, 4>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
     HIP_TRY(ctx, hipGetLastError());
     return KMERS_OK;
 }

@@ -180,6 +180,28 @@ __device__ __forceinline__ void window1_and_next(const uint64_t *lds, uint32_t b
     next_sym = (W1 >> ((uint32_t)DST * (k - 1u))) & ((1u << DST) - 1u);  // last symbol of the next window
 }
 
+// Kernels that only ever need FORWARD kmers of a 2-bit alphabet stage the codes of a tile in KMER order: symbol i of the staged
+// words sits at bits [B - 2 - 2i, B - 2i) of the LDS stream (B = its length in bits), i.e. later symbols in LOWER bits,
+// exactly like Kmer's big-endian layout (src/kmer.jl:32-44).  The kmer of the window whose first symbol is i is then the
+// 2K bits at bit B - 2(i + K): one funnel shift and the head mask -- the same value as K applications of shift_encoding
+// (construction_utils.jl:129-134), with no per-kmer symbol reversal.
+__device__ __forceinline__ uint32_t rev2_32(uint32_t x) {  // reverse the order of the 16 two-bit symbols of a dword
+    const uint32_t r = __brev(x);
+    return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+template <int N>
+__device__ __forceinline__ void cut_fw(const uint64_t *rs, uint32_t o, uint64_t mask, uint64_t (&fw)[N]) {
+    const uint32_t q = o >> 6, sh = o & 63u;
+    uint64_t lo = rs[q];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {  // word N-1-j of the kmer = stream bits [o + 64j, o + 64j + 64)
+        const uint64_t hi = rs[q + j + 1];
+        fw[N - 1 - j] = funnel64(lo, hi, sh);
+        lo = hi;
+    }
+    fw[0] &= mask;
+}
+
 template <int N>
 __device__ __forceinline__ bool kmer_less(const uint64_t (&x)[N], const uint64_t (&y)[N]) {
     // cmp(x.data, y.data) == -1: lexicographic, head word first (kmer.jl:176-178)
@@ -223,8 +245,11 @@ __device__ __forceinline__ void store_kmer(uint64_t *out, uint64_t g, const uint
 // src/construction.jl:75-100).  Returns one flag per offending symbol at bit SRC*j (FourToTwo:
 // count_ones != 1; AsciiEncode: byte outside the alphabet), 0 otherwise.
 //   stream word index: SRC == DST: qword wi;  4->2: dword wi;  2->4: qwords 2wi, 2wi+1
-template <int SRC, int DST>
+//   REV (2-bit kmers, forward only): the stream is kept in KMER order -- `wi` is then the word's index counted from the END of
+//   the staged words and its symbols are reversed (cut_fw above)
+template <int SRC, int DST, bool REV = false>
 __device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint64_t x, const uint8_t *lut) {
+    static_assert(!REV || DST == 2, "kmer-order staging: 2-bit kmer alphabets");
     if constexpr (SRC == 8) {  // AsciiEncode: 8 bytes -> 8 symbols through the alphabet's table
         uint32_t codes = 0;
         uint64_t f = 0;
@@ -234,15 +259,17 @@ __device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint6
             codes |= (v & 0xfu) << (DST * j);
             f |= (uint64_t)(v >> 7) << (8 * j);  // 0x80: not a symbol of the alphabet
         }
-        if constexpr (DST == 2) reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)codes;
+        if constexpr (REV) reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)(rev2_32(codes) >> 16);
+        else if constexpr (DST == 2) reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)codes;
         else reinterpret_cast<uint32_t *>(lds)[wi] = codes;
         return f;
     } else if constexpr (SRC == DST) {  // Copyable
-        lds[wi] = x;
+        lds[wi] = REV ? rev2(x) : x;
         return 0;
     } else if constexpr (SRC == 4) {  // FourToTwo: trailing_zeros of a one-hot nibble, validated
         uint64_t bad;
-        reinterpret_cast<uint32_t *>(lds)[wi] = pack_4to2(x, bad);
+        const uint32_t c = pack_4to2(x, bad);
+        reinterpret_cast<uint32_t *>(lds)[wi] = REV ? rev2_32(c) : c;
         return bad ? flags_from_bad4(bad) : 0;
     } else {  // TwoToFour
         lds[2 * wi] = expand_2to4((uint32_t)x);
@@ -277,8 +304,13 @@ __device__ __forceinline__ void sketch_candidate(const StreamArgs &a, uint64_t h
 // PAIR (strided kernels, one-word kmers): a lane takes two neighbouring lattice kmers, each cut from its own window, so
 // that SpacedKmers output is stored 16 bytes per lane like the stride-1 kernels' (SpacedKmers.jl:121-139 yields the same
 // elements whichever lane cuts them).
-template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1, bool TUPLES = false, bool PAIR = false>
+// FWD (MODE_FW over a 2-bit kmer alphabet with no reverse complements wanted: FwKmers, SpacedKmers, UnambiguousKmers over
+// a sequence in which nothing is dropped): the codes are staged in kmer order, a kmer is one funnel shift + the head mask
+// (cut_fw) -- no symbol reversal per kmer.  The strided kernel is bound by its integer work (one SIMD-cycle in four per
+// instruction at 5.9 TB/s), so this is where it counts.
+template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1, bool TUPLES = false, bool PAIR = false, bool FWD = false>
 __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
+    static_assert(!FWD || (MODE == MODE_FW && DST == 2 && !TUPLES), "FWD: forward kmers of a 2-bit alphabet, separate arrays");
     __shared__ uint64_t lds[LDS_QWORDS];
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     const uint32_t tid = threadIdx.x;
@@ -329,7 +361,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
             for (uint32_t j = 0; j < PRE; ++j) {
                 const uint32_t wi = base + j * BLOCK + tid;
                 if (wi < nw) {
-                    uint64_t f = stage_word<SRC_BITS, DST>(lds, wi, x[j], lut);
+                    uint64_t f = stage_word<SRC_BITS, DST, FWD>(lds, FWD ? nw - 1u - wi : wi, x[j], lut);
                     if constexpr ((SRC_BITS == 4 && DST == 2) || SRC_BITS == 8) {
                         // `span` symbols per element are read (K, or K + W - 1 for minimizer windows): gaps start after them
                         if (f) report_bad_symbols<SRC_BITS, STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, span, w0 + wi, f, x[j], a.err_origin);
@@ -349,7 +381,19 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
         for (uint32_t r = tid * KPL; r < mt; r += BLOCK * KPL) {
             const uint64_t g = m0 + r;
             uint64_t fw[KPL][N], rc[KPL][N];
-            if constexpr (PAIR) {
+            if constexpr (FWD) {
+                // the kmer of tile element r sits at bit kbit0 - 2 J r of the kmer-order stream (rc stays unused)
+                const uint32_t o = nw * (128u / SRC_BITS) - 2u * (b0 + k) - 2u * J * r;
+#pragma unroll
+                for (uint32_t e = 0; e < KPL; ++e)
+#pragma unroll
+                    for (int w = 0; w < N; ++w) rc[e][w] = 0;
+                cut_fw<N>(lds, o, mask, fw[0]);
+                if constexpr (KPL == 2) {
+                    if (r + 1 < mt) cut_fw<N>(lds, o - 2u * J, mask, fw[1]);
+                    else fw[1][0] = 0;
+                }
+            } else if constexpr (PAIR) {
                 window<N, DST>(lds, (uint32_t)DST * (r * J + b0), k, mask, fw[0], rc[0]);
                 if (r + 1 < mt) window<N, DST>(lds, (uint32_t)DST * ((r + 1) * J + b0), k, mask, fw[1], rc[1]);
                 else fw[1][0] = rc[1][0] = 0;

@@ -116,30 +116,10 @@ __device__ __forceinline__ uint64_t keep_qword(const uint64_t *amb, uint32_t bit
     return lo;
 }
 
-// This kernel only ever needs FORWARD kmers, so it stages the 2-bit codes of a tile in KMER order: symbol i of the staged
-// words sits at bits [B - 2 - 2i, B - 2i) of the LDS stream (B = its length in bits), i.e. later symbols in LOWER bits,
-// exactly like Kmer's big-endian layout (src/kmer.jl:32-44).  The kmer of the window whose first symbol is i is then the
-// 2K bits at bit B - 2(i + K): one funnel shift and the head mask -- the same value as K applications of shift_encoding
-// (construction_utils.jl:129-134), with no per-kmer symbol reversal.
-__device__ __forceinline__ uint32_t rev2_32(uint32_t x) {  // reverse the order of the 16 two-bit symbols of a dword
-    const uint32_t r = __brev(x);
-    return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
-}
-template <int N>
-__device__ __forceinline__ void cut_fw(const uint64_t *rs, uint32_t o, uint64_t mask, uint64_t (&fw)[N]) {
-    const uint32_t q = o >> 6, sh = o & 63u;
-    uint64_t lo = rs[q];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {  // word N-1-j of the kmer = stream bits [o + 64j, o + 64j + 64)
-        const uint64_t hi = rs[q + j + 1];
-        fw[N - 1 - j] = funnel64(lo, hi, sh);
-        lo = hi;
-    }
-    fw[0] &= mask;
-}
+// This kernel only ever needs FORWARD kmers, so it stages the 2-bit codes of a tile in KMER order (cut_fw, stream_kernel.hpp).
 
 template <int SRC_BITS, int N, int UMODE>
-__global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 5) void unambiguous_kernel(const UnambArgs a) {
+__global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) void unambiguous_kernel(const UnambArgs a) {
     constexpr bool EMIT = UMODE == UMODE_EMIT;
     constexpr uint32_t NBUF = EMIT ? 2u : 1u;  // EMIT resolves tile n+1 before it emits tile n: two sets of tile state
     constexpr uint32_t STREAM_QWORDS = (UTILE_MAX + 128 + 64) / 32 + 4;   // 2-bit codes of the tile + its K-1 overlap
