@@ -439,7 +439,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the k-mer kernels have no CPU fallback")
     ndev = torch.cuda.device_count()
     backend = "none"
-    if env_world > 1:
+    # KMERS_BENCH_FORCE_GROUP=1 (tests): also a 1-rank run goes through the N > 1 code path -- process group, ncclUniqueId
+    # hand-over, kmers_comm_create, kmers_halo_exchange every step, the two reductions -- which is all of it that a 1-GPU
+    # box can run on RCCL
+    grouped = env_world > 1 or (os.environ.get("KMERS_BENCH_FORCE_GROUP") == "1" and "RANK" in os.environ)
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm.  KMERS_BENCH_BACKEND=gloo exists only to exercise the multi-rank
         # logic on a 1-GPU box (ranks share the device; not a measurement).
@@ -449,13 +453,13 @@ def main():
     dev_index = local_rank % ndev  # one rank per GPU; wraps only in the shared-device gloo mode
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if env_world > 1:
+    if grouped:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
         backend = dist.get_backend()
-    world = dist.get_world_size() if env_world > 1 else 1
+    world = dist.get_world_size() if grouped else 1
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: the process group has {world} ranks")
 
@@ -464,7 +468,7 @@ def main():
     from oracle import pyoracle
     if rank == 0:
         pyoracle.build()  # the checker used after the timed region; one builder, the others wait
-    if world > 1:
+    if grouped:
         dist.barrier()
     cap = km._capi
     ctx = km.Context(dev_index)
@@ -492,9 +496,9 @@ def main():
         out_k = torch.empty(sh.n_kmers * N, dtype=torch.int64, device=dev)
         out_h = None if args.no_hash else torch.empty(sh.n_kmers, dtype=torch.int64, device=dev)
         halo = None
-        if world > 1 and transport != "native":
+        if grouped and transport != "native":
             halo = HaloExchanger(buf, sh, plan, transport=transport)  # its workspace is filled on this stream too
-    if world > 1 and transport == "native":
+    if grouped and transport == "native":
         if backend != "nccl":
             raise SystemExit("KMERS_HALO_TRANSPORT=native needs one GPU per rank (RCCL); the gloo mode shares a device")
         comm = NativeComm.bootstrap(ctx)
@@ -521,7 +525,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -552,7 +556,7 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
     t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms_max = float(t[0]), float(t[1])
 
@@ -565,7 +569,7 @@ def main():
         off, tot = comm.output_offsets(sh.n_kmers)
         verified &= off == sh.first_kmer and tot == sum(s.n_kmers for s in plan)
     v = torch.tensor([1 if verified else 0], device=dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
     verified = bool(v.item())
 
@@ -573,7 +577,7 @@ def main():
         n_kmers_rank = sh.n_kmers
         bytes_per_kmer = bits / 8 + 8 * N + (0 if args.no_hash else 8)
         achieved = bytes_per_kmer * n_kmers_rank / (kern_ms * 1e-3) / 1e9
-        if world == 1:
+        if not grouped:
             sharding = "single shard"
         else:
             how = {"native": "kmers_halo_exchange of the C ABI: grouped ncclSend/ncclRecv on the kernel's stream (RCCL; torch carried only the ncclUniqueId)",
@@ -590,7 +594,7 @@ def main():
                                    if not args.no_hash else
                                    f"CanonicalDNAMers{{{K}}} over {args.bases / 1e9:g} Gbase LongDNA{{{bits}}} per GPU",
                        "k": K, "src_bits": bits, "bases_per_gpu": args.bases,
-                       "sharding": sharding, "backend": backend, "halo_transport": transport if world > 1 else None,
+                       "sharding": sharding, "backend": backend, "halo_transport": transport if grouped else None,
                        "seed": hex(seed)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": "not measured",
@@ -638,7 +642,7 @@ def main():
         print(json.dumps(line), flush=True)
     if comm is not None:
         comm.close()
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     if not verified:

@@ -153,3 +153,25 @@ def test_plain_c_sharded_client(tmp_path):
         out = subprocess.run([str(exe), shards, bases], capture_output=True, text=True, timeout=300, env=env)
         assert out.returncode == 0, (out.stdout, out.stderr)
         assert "communicator: rank 0 of 1" in out.stdout and ": equal" in out.stdout, out.stdout
+
+
+def test_bench_rccl_code_path_on_one_rank():
+    """Exactly the code a rank of `bench.py --gpus N` runs under RCCL -- process group on `nccl`, the ncclUniqueId handed over
+    torch.distributed, kmers_comm_create, kmers_halo_exchange in every step, kmers_first_error_allreduce,
+    kmers_offsets_allgather -- with the one rank a 1-GPU box admits (KMERS_BENCH_FORCE_GROUP=1 under torch.distributed.run)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, KMERS_BENCH_FORCE_GROUP="1", KMERS_BENCH_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--bases", "8000000", "--no-other-configs", "--no-cpu-baseline", "--no-pmc"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["verified"] is True
+    assert d["config"]["backend"] == "nccl" and d["config"]["halo_transport"] == "native"
+    assert "kmers_halo_exchange" in d["config"]["sharding"]
