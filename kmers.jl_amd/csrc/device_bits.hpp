@@ -60,7 +60,11 @@ __device__ __forceinline__ uint32_t bad_bits16(uint64_t bad) {
 // release relies on the LDS queue being in order, and under heavy same-address contention that was observed to be
 // false (a histogram word read after the barrier missed a whole tile of increments: the 16-bit composition counters
 // overflowed in 1-2 % of cold runs).  The explicit wait makes every wavefront's own LDS operations complete first.
+#ifdef KMERS_NO_SETTLE  // ISA comparison builds only (tools/check_lds_barrier.sh): the barriers as hipcc emits them
+__device__ __forceinline__ void lds_atomics_settle() {}
+#else
 __device__ __forceinline__ void lds_atomics_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
 // Every workgroup barrier of these kernels: the wavefront's own LDS operations first, then the barrier (the wait
 // is what hipcc emits in most places anyway; making it unconditional removes the class of hazards above).
 __device__ __forceinline__ void block_sync() {
