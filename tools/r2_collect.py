@@ -46,20 +46,20 @@ L1 = 999_999_970
 import glob
 traces = sorted(glob.glob(os.path.join(E, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(traces[-1]))
-        if "stream_kernel<4, 2, 1, 1, true, false, false>" in r["Kernel_Name"]]
+        if "stream_kernel<4, 2, 1, 1, true, false, false" in r["Kernel_Name"]]
 c2 = [d for d in durs if d < 8.0]
 n1 = [d for d in durs if d >= 8.0]
 hk_ms = under["roofline"]["kernel_ms"]
-rows.append(f"| C2 headline: CanonicalDNAMers{{31}} + fx_hash, 1 Gbase LongDNA{{4}} (2 warm-up + 10 timed launches) | `stream_kernel<4, 2, 1, 1, true, false, false>` | {len(c2)} | "
+rows.append(f"| C2 headline: CanonicalDNAMers{{31}} + fx_hash, 1 Gbase LongDNA{{4}} (2 warm-up + 10 timed launches) | `stream_kernel<4, 2, 1, 1, true, …>` | {len(c2)} | "
             f"{sum(c2) / len(c2):.4f} | {min(c2):.4f} | {hk_ms} | {16.5 * L1 / (sum(c2) / len(c2)) / 1e6 / 8000:.3f} |")
 if n1:
     n1_ms = [v.get("kernel_ms") for k, v in oc.items() if k.startswith("N1")]
     rows.append(f"| N1 north star: the same kernel over 10 Gbase LongDNA{{4}} (warm phase + 7 timed launches) | same | {len(n1)} | {sum(n1) / len(n1):.4f} | {min(n1):.4f} | "
                 f"{n1_ms[0] if n1_ms else ''} | {16.5 * 9_999_999_970 / (sum(n1) / len(n1)) / 1e6 / 8000:.3f} |")
 for label, sub, key, alg in (
-        ("C3 shard: CanonicalDNAMers{31}, 1.25 Gbase LongDNA{2}", "stream_kernel<2, 2, 1, 1, true, false, false>", "C3", 8.25 * (1_250_000_000 - 30)),
-        ("C4: FwDNAMers{63} + reverse_complement, 1 Gbase LongDNA{4}", "stream_kernel<4, 2, 2, 0, true, false, false>", "C4", 32.5 * (1_000_000_000 - 62)),
-        ("C5 strict: SpacedDNAMers{21,3}, 1 Gbase LongDNA{4}", "stream_kernel<4, 2, 1, 0, false, false, true>", "C5 SpacedDNAMers", 0.5e9 + 8.0 * ((1_000_000_000 - 21) // 3 + 1)),
+        ("C3 shard: CanonicalDNAMers{31}, 1.25 Gbase LongDNA{2}", "stream_kernel<2, 2, 1, 1, true, false, false", "C3", 8.25 * (1_250_000_000 - 30)),
+        ("C4: FwDNAMers{63} + reverse_complement, 1 Gbase LongDNA{4}", "stream_kernel<4, 2, 2, 0, true, false, false", "C4", 32.5 * (1_000_000_000 - 62)),
+        ("C5 strict: SpacedDNAMers{21,3}, 1 Gbase LongDNA{4}", "stream_kernel<4, 2, 1, 0, false, false, true", "C5 SpacedDNAMers", 0.5e9 + 8.0 * ((1_000_000_000 - 21) // 3 + 1)),
         ("UnambiguousKmers, one pass (both legs: C5 lattice and K = 31)", "unambiguous_kernel<4, 1, 0>", None, None)):
     try:
         ms, calls, mn = avg_ms(sub)
