@@ -126,8 +126,9 @@ int kmers_words_per_kmer(int k, int dst_bits);                      /* n_coding_
 uint64_t kmers_count(uint64_t n_bases, int k, int stride);          /* FwKmers.jl:40-43; SpacedKmers.jl:38-42 */
 /* 1 if kmers_fw / kmers_canonical / kmers_spaced cover the geometry: every K >= 1 (Kmer{A,K,N} has no bound on N,
  * src/kmer.jl:97-111; kmers of one to four words run on the tile kernels, wider ones on a run-time-width kernel).
- * kmers_unambiguous, the fused consumers, the element-wise operations and the batch entry points take kmers of at most
- * four words (K <= 128 two-bit, K <= 64 four-bit) and return KMERS_E_UNSUPPORTED beyond. */
+ * kmers_unambiguous takes K <= 30720 (its one-pass kernel stages a tile together with its K-1 symbols of overlap); the
+ * fused consumers, the element-wise operations and the batch entry points take kmers of at most four words (K <= 128
+ * two-bit, K <= 64 four-bit) and return KMERS_E_UNSUPPORTED beyond. */
 int kmers_supported(int src_bits, int dst_bits, int k, int stride);
 
 /* ---- iterators --------------------------------------------------------------- */

@@ -394,7 +394,8 @@ void launch_unambiguous(kmers_ctx *ctx, int src_bits, int nw, dim3 grid, const U
             case 1: hipLaunchKernelGGL((unambiguous_kernel<SB, 1, UMODE>), grid, block, 0, ctx->stream, a); break; \
             case 2: hipLaunchKernelGGL((unambiguous_kernel<SB, 2, UMODE>), grid, block, 0, ctx->stream, a); break; \
             case 3: hipLaunchKernelGGL((unambiguous_kernel<SB, 3, UMODE>), grid, block, 0, ctx->stream, a); break; \
-            default: hipLaunchKernelGGL((unambiguous_kernel<SB, 4, UMODE>), grid, block, 0, ctx->stream, a); break; \
+            case 4: hipLaunchKernelGGL((unambiguous_kernel<SB, 4, UMODE>), grid, block, 0, ctx->stream, a); break; \
+            default: hipLaunchKernelGGL((unambiguous_kernel<SB, 0, UMODE>), grid, block, 0, ctx->stream, a); break; /* run-time width */ \
         }                                                                                                       \
     } while (0)
     if constexpr (UMODE == UMODE_COUNT) nw = 1;  // counting does not depend on the kmer width
@@ -404,10 +405,13 @@ void launch_unambiguous(kmers_ctx *ctx, int src_bits, int nw, dim3 grid, const U
 #undef UW
 }
 
-uint32_t unambiguous_tile(kmers_ctx *ctx) {
+// longest kmer the single-pass kernel stages (a tile and its K-1 symbols of overlap must fit the LDS stream)
+constexpr int UNAMB_MAX_K = (int)UTILE_MAX - 2048;
+uint32_t unambiguous_tile(kmers_ctx *ctx, int k) {
     // candidate starts per tile: a multiple of 1024 (one wavefront round), at most UTILE_MAX.  Long tiles keep the rate of
-    // tile descriptors low enough for the look-back.
+    // tile descriptors low enough for the look-back; very long kmers leave room for their overlap.
     uint32_t t = ctx->tile_kmers > 0 ? (uint32_t)std::min<int64_t>(ctx->tile_kmers, UTILE_MAX) : UTILE_MAX;
+    if (k > 128) t = std::min<uint32_t>(t, (UTILE_MAX - (uint32_t)k) / UROUND * UROUND);
     return std::max<uint32_t>(UROUND, t / UROUND * UROUND);
 }
 
@@ -443,7 +447,8 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
     a.index_origin = seq->index_origin;
-    a.tile_starts = unambiguous_tile(ctx);
+    a.tile_starts = unambiguous_tile(ctx, k);
+    a.n_words = (uint32_t)nw;
     a.n_tiles = (n + a.tile_starts - 1) / a.tile_starts;
     a.tuples = tuples ? 1u : 0u;
     a.stamps = reinterpret_cast<uint64_t *>(ctx->stamps_ptr);
@@ -842,7 +847,8 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
     a.k = (uint32_t)kk;
     a.stride = (uint32_t)stride;
     a.index_origin = seq->index_origin;
-    a.tile_starts = UTILE_MAX;    // nothing is streamed out: long tiles on a persistent grid
+    a.tile_starts = kk > 128 ? (UTILE_MAX - (uint32_t)kk) / UROUND * UROUND : UTILE_MAX;  // nothing is streamed out: long tiles
+    a.n_words = (uint32_t)kmers_words_per_kmer(kk, 2);
     a.n_tiles = (n + a.tile_starts - 1) / a.tile_starts;
     a.total = reinterpret_cast<unsigned long long *>(ctx->d_scratch);
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, (uint64_t)ctx->n_cus * 8));
@@ -1584,11 +1590,12 @@ int kmers_minhash_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span 
 int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uint64_t *out_kmers,
                       int64_t *out_starts, uint64_t capacity, int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, seq, k, stride, 2, flags & ~KMERS_ASYNC)) {
+    if (int rc = check_common(ctx, seq, k, stride, 2, flags & ~KMERS_ASYNC, true)) {
         if (res) res->status = rc;
         return rc;
     }
     if (flags & KMERS_ASYNC) return fail(ctx, KMERS_E_BADARG, "kmers_unambiguous is synchronous (data-dependent count)");
+    if (k > UNAMB_MAX_K) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_unambiguous: K above 30720");
     if (seq->src_bits == 8 && seq->alphabet == KMERS_ALPHABET_SYMBOLS)  // the reference has no such method (UnambiguousKmers.jl:64-132)
         return fail(ctx, KMERS_E_UNSUPPORTED, "UnambiguousKmers takes 2-bit / 4-bit sequences and text, not collections of symbols");
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -74,6 +74,7 @@ struct UnambArgs {
     uint32_t ascii_table;          // SRC_BITS == 8: ASCII_TABLE_SKIPPING = the reference's ASCII_SKIPPING_LUT (common.jl:22-32)
     uint32_t tuples;               // 1: out_kmers receives Tuple{Kmer,Int} elements (N + 1 words each), out_starts unused
     uint32_t vec16;                // out_kmers / out_starts are 16-byte aligned (16-byte stores allowed)
+    uint32_t n_words;              // words per kmer (the N = 0 instantiation takes it at run time: kmers of more than four words)
     uint64_t *stamps;              // diagnostic builds (-DKMERS_STAMPS) only: 8 s_memrealtime stamps per tile
 };
 
@@ -102,6 +103,18 @@ __device__ __forceinline__ uint64_t keep_qword(const uint64_t *amb, uint32_t bit
             have += step;
         }
         return lo;
+    }
+    if (k > 129) {
+        // kmers of more than four words (an edge path): start j is kept iff the flag bits [j, j + K) are all zero, tested word
+        // by word; every lane walks the 64 + K bits behind its 64 starts once, keeping the distance to the next flag
+        uint64_t keep = 0;
+        uint32_t clear = 0;  // unflagged symbols directly behind the position being visited (walking downwards)
+        for (int p = (int)(63u + k) - 1; p >= 0; --p) {  // symbol bit + p, from the far end of the last window down to start 0
+            const uint32_t b = bit + (uint32_t)p;
+            clear = ((amb[b >> 6] >> (b & 63u)) & 1ull) ? 0u : clear + 1u;
+            if (p < 64 && clear >= k) keep |= 1ull << p;
+        }
+        return keep;
     }
     uint64_t hi = ~funnel64(amb[Q + 2], amb[Q + 3], sft);
     uint32_t have = 1;
@@ -144,6 +157,9 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     const uint32_t k = a.k;
     const uint64_t mask = head_mask((int)k, 2);
     const uint32_t T = a.tile_starts;
+    constexpr bool WIDE = N == 0;                        // kmers of more than four words: their width is a.n_words
+    constexpr int NW = WIDE ? 1 : N;                     // (register arrays of the fixed-width paths)
+    const uint32_t n_words = WIDE ? a.n_words : (uint32_t)N;
     uint64_t acc = 0;  // COUNT: kept starts; XOR: fold of the head words
     uint64_t lattice = ~0ull;  // bit j set iff j % stride == 0 (stride < 64; a larger stride has one lattice start per qword at most)
     if (a.stride > 1) {
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             uint64_t keep16 = (km >> sl) & (mine_n >= 64u ? ~0ull : ((1ull << mine_n) - 1ull));
             if (cnt == 0) continue;
             const uint64_t origin = m0 + 1 + a.index_origin;                     // start of candidate r is origin + r
-            if constexpr (N == 1 && EMIT) {
+            if constexpr (N == 1 && EMIT) {  // (one-word kmers only)
                 // Dense round (every one of its starts is kept -- the normal state of real sequence outside its N
                 // blocks): no list; two consecutive kmers per lane and 16-byte stores aligned to the parity of the
                 // output position.
@@ -415,8 +431,30 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             // one listed element: window cut + stores (also the generic path: tuples, unaligned outputs, the XOR reducer)
             auto emit_one = [&](uint32_t i) {
                 const uint32_t r = r_begin + (uint32_t)mine[i];
-                uint64_t fw[N];
-                cut_fw<N>(lds, kbit0 - 2u * r, mask, fw);
+                if constexpr (WIDE) {
+                    // run-time width: word n_words-1-j of the kmer = stream bits [o + 64j, +64), straight to memory
+                    const uint32_t o = kbit0 - 2u * r, q = o >> 6, sh = o & 63u;
+                    const uint64_t o2 = pos + i;
+                    uint64_t lo = lds[q], head = 0;
+                    for (uint32_t j = 0; j < n_words; ++j) {
+                        const uint64_t hi = lds[q + j + 1u];
+                        uint64_t w = funnel64(lo, hi, sh);
+                        lo = hi;
+                        if (j + 1u == n_words) head = w &= mask;
+                        if constexpr (UMODE != UMODE_XOR) {
+                            if (o2 < a.capacity && a.out_kmers) a.out_kmers[o2 * (n_words + (a.tuples ? 1u : 0u)) + (n_words - 1u - j)] = w;
+                        }
+                    }
+                    if constexpr (UMODE == UMODE_XOR) {
+                        acc ^= head;
+                    } else if (o2 < a.capacity) {
+                        if (a.tuples) a.out_kmers[o2 * (n_words + 1u) + n_words] = origin + r;
+                        else if (a.out_starts) a.out_starts[o2] = (long long)(origin + r);
+                    }
+                    return;
+                }
+                uint64_t fw[NW];
+                cut_fw<NW>(lds, kbit0 - 2u * r, mask, fw);
                 if constexpr (UMODE == UMODE_XOR) {
                     acc ^= fw[0];
                 } else {
@@ -427,13 +465,13 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                                 *reinterpret_cast<ulonglong2 *>(a.out_kmers + 2u * o2) = make_ulonglong2(fw[0], origin + r);
                             } else {
 #pragma unroll
-                                for (int wd = 0; wd < N; ++wd) a.out_kmers[o2 * (N + 1) + wd] = fw[wd];
-                                a.out_kmers[o2 * (N + 1) + N] = origin + r;
+                                for (int wd = 0; wd < NW; ++wd) a.out_kmers[o2 * (NW + 1) + wd] = fw[wd];
+                                a.out_kmers[o2 * (NW + 1) + NW] = origin + r;
                             }
                         } else {
                             if (a.out_kmers) {
 #pragma unroll
-                                for (int wd = 0; wd < N; ++wd) a.out_kmers[o2 * N + wd] = fw[wd];
+                                for (int wd = 0; wd < NW; ++wd) a.out_kmers[o2 * NW + wd] = fw[wd];
                             }
                             if (a.out_starts) a.out_starts[o2] = (long long)(origin + r);
                         }
@@ -444,7 +482,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             if constexpr (EMIT) {
                 // Two listed elements per lane and 16-byte stores: the pair starts at an even output index, an odd first /
                 // last element goes alone.
-                paired = a.vec16 && !a.tuples && pos + cnt <= a.capacity;
+                paired = !WIDE && a.vec16 && !a.tuples && pos + cnt <= a.capacity;
                 if (paired) {
                     const uint32_t head = (uint32_t)(pos & 1u);
                     if (head && lane == 0) emit_one(0);
@@ -452,16 +490,16 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                     for (uint32_t i = lane; i < pairs; i += 64u) {
                         const uint32_t e = head + 2u * i;
                         const uint32_t ra = r_begin + (uint32_t)mine[e], rb = r_begin + (uint32_t)mine[e + 1u];
-                        uint64_t fa[N], fb[N];
-                        cut_fw<N>(lds, kbit0 - 2u * ra, mask, fa);
-                        cut_fw<N>(lds, kbit0 - 2u * rb, mask, fb);
+                        uint64_t fa[NW], fb[NW];
+                        cut_fw<NW>(lds, kbit0 - 2u * ra, mask, fa);
+                        cut_fw<NW>(lds, kbit0 - 2u * rb, mask, fb);
                         const uint64_t o2 = pos + e;  // even
                         if (a.out_kmers) {
                             if constexpr (N == 1) {
                                 *reinterpret_cast<ulonglong2 *>(a.out_kmers + o2) = make_ulonglong2(fa[0], fb[0]);
                             } else {
-                                store_kmer<N>(a.out_kmers, o2, fa);
-                                store_kmer<N>(a.out_kmers, o2 + 1, fb);
+                                store_kmer<NW>(a.out_kmers, o2, fa);
+                                store_kmer<NW>(a.out_kmers, o2 + 1, fb);
                             }
                         }
                         if (a.out_starts) *reinterpret_cast<ulonglong2 *>(a.out_starts + o2) = make_ulonglong2(origin + ra, origin + rb);

@@ -204,7 +204,6 @@ def test_kmers_wider_than_four_words(km, ctx, orc):
     assert [tuple(int(x) for x in r) for r in fw] == naive.fw_kmers(text, K, 2)
     assert [tuple(int(x) for x in r) for r in rv] == [b for _, b in naive.fwrv(text, K, 2)]
     # the other entry points say so instead of computing something else
-    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), 129, 1, None, None, 0, 0, C.byref(res)) == cap.E_UNSUPPORTED
     val = C.c_uint64()
     assert ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), 129, 2, 1, C.byref(val), 0, C.byref(res)) == cap.E_UNSUPPORTED
 
@@ -601,6 +600,54 @@ def test_unambiguous_single_pass_device_path(km, ctx, orc):
             ctx.set_param(cap.PARAM_TILE_KMERS, 0)
             ctx.set_param(cap.PARAM_MAX_GRID, 0)
         ctx.free(d_src)
+
+
+def test_unambiguous_kmers_wider_than_four_words(km, ctx, orc):
+    """UnambiguousKmers{A,K} with K > 128 (src/kmer.jl:97-111 puts no bound on N): the single-pass kernel's run-time-width
+    instantiation.  Against the oracle up to its 8 words, against the naive slicer beyond; host and device paths, a stride
+    lattice, several tiles."""
+    cap = km._capi
+    rng = np.random.default_rng(777)
+    for K, L, p_amb in ((129, 40_000, 0.002), (200, 70_001, 0.003), (256, 9_000, 0.0), (130, 300, 0.0), (256, 255, 0.0)):
+        text = naive.random_text(rng, L, p_amb=p_amb)
+        words = naive.longseq_words(text, 4)
+        ek, es, _ = orc.unambiguous(words, L, 4, K)
+        kmers, starts = run_unambiguous(km, ctx, words, L, 4, K)                 # host path (count, then emit)
+        assert np.array_equal(kmers, ek) and np.array_equal(starts, es), (K, L)
+        kmers, starts = run_unambiguous(km, ctx, words, L, 4, K, stride=5)
+        keep = (es - 1) % 5 == 0
+        assert np.array_equal(kmers, ek[keep]) and np.array_equal(starts, es[keep]), (K, L)
+        # device path (one pass), small tiles
+        n, N = len(ek), (2 * K + 63) // 64
+        d_src = ctx.alloc(words.nbytes + 16)
+        ctx.h2d(d_src, words)
+        for tile in (0, 1024):
+            ctx.set_param(cap.PARAM_TILE_KMERS, tile)
+            hk, hs = np.zeros((n + 8, N), np.uint64), np.zeros(n + 8, np.int64)
+            dk, ds = ctx.alloc(hk.nbytes), ctx.alloc(hs.nbytes)
+            res = cap.Result()
+            seq = cap.Seq(d_src, L, 0, 0, 4, 0)
+            assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, dk, ds, n + 8, cap.MEM_DEVICE, C.byref(res)) == 0
+            assert res.n_out == n
+            ctx.d2h(hk, dk)
+            ctx.d2h(hs, ds)
+            ctx.free(dk)
+            ctx.free(ds)
+            assert np.array_equal(hk[:n], ek) and np.array_equal(hs[:n], es), (K, L, tile)
+        ctx.set_param(cap.PARAM_TILE_KMERS, 0)
+        ctx.free(d_src)
+    # beyond the oracle's widths: K = 700 (22 words) and K = 3000 over text with a few ambiguity codes, against the naive slicer
+    for K, L in ((700, 4000), (3000, 12_000)):
+        text = list(naive.random_text(rng, L))
+        for pos in rng.integers(0, L, 3):
+            text[int(pos)] = "N"
+        text = "".join(text)
+        kmers, starts = run_unambiguous(km, ctx, naive.longseq_words(text, 4), L, 4, K)
+        exp = naive.unambiguous(text, K)
+        assert [tuple(int(x) for x in r) for r in kmers] == [k_ for k_, _ in exp] and list(starts) == [i for _, i in exp], K
+    res = cap.Result()
+    seq, keep = make_seq(km, naive.longseq_words("ACGT" * 10, 4), 40, 4)
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), 31000, 1, None, None, 0, 0, C.byref(res)) == cap.E_UNSUPPORTED
 
 
 def test_spaced_skip_variant(km, ctx, orc):
