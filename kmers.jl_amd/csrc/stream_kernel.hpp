@@ -248,8 +248,36 @@ __device__ __forceinline__ void store_kmer(uint64_t *out, uint64_t g, const uint
 //   REV (2-bit kmers, forward only): the stream is kept in KMER order -- `wi` is then the word's index counted from the END of
 //   the staged words and its symbols are reversed (cut_fw above)
 template <int SRC, int DST, bool REV = false>
-__device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint64_t x, const uint8_t *lut) {
+__device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint64_t x, const uint8_t *lut, uint32_t text = 0) {
     static_assert(!REV || DST == 2, "kmer-order staging: 2-bit kmer alphabets");
+    if constexpr (SRC == 8 && DST == 2) {
+        // AsciiEncode of DNA / RNA text into a 2-bit alphabet without the table (text = 1: DNA, T valid; 2: RNA, U valid): all
+        // 8 bytes at once.  In either case of ACGT / ACGU, code = ((c >> 1) & 3) ^ (that >> 1) is A 0, C 1, G 2, T/U 3, and a
+        // byte is a symbol iff its upper-cased value is the letter its code stands for (BioSequences.ascii_encode restated;
+        // ascii_tables.hpp holds the table this replaces, tests/c/ascii_entry_check.cpp compares the two over all 256 bytes).
+        if (text) {
+            const uint64_t B1 = 0x0101010101010101ull;
+            const uint64_t U = x & 0xDFDFDFDFDFDFDFDFull;                 // upper case
+            const uint64_t c2 = (U >> 1) & (3ull * B1);
+            const uint64_t code = c2 ^ ((c2 >> 1) & B1);
+            const uint64_t b0 = code & B1, b1 = (code >> 1) & B1;
+            const uint64_t is1 = b0 & ~b1, is2 = b1 & ~b0, is3 = b0 & b1;
+            // the letter each code stands for: 'A' + {0, 2, 6, 0x13 ('T') or 0x14 ('U')}
+            uint64_t E = 0x41ull * B1 + (is1 << 1) + (is2 << 1) + (is2 << 2) + (is3 << 4) + (is3 << 1) + is3;
+            if (text == 2u) E += is3;
+            const uint64_t bad = U ^ E;
+            const uint64_t nz = ((bad | ((bad & (0x7Full * B1)) + (0x7Full * B1))) >> 7) & B1;  // bit 8j: byte j is not a symbol
+            uint64_t t = code | (code >> 6);
+            t &= 0x000F000F000F000Full;
+            t |= t >> 12;
+            t &= 0x000000FF000000FFull;
+            t |= t >> 24;
+            const uint32_t codes = (uint32_t)t & 0xFFFFu;
+            if constexpr (REV) reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)(rev2_32(codes) >> 16);
+            else reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)codes;
+            return nz;
+        }
+    }
     if constexpr (SRC == 8) {  // AsciiEncode: 8 bytes -> 8 symbols through the alphabet's table
         uint32_t codes = 0;
         uint64_t f = 0;
@@ -317,8 +345,12 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     const uint32_t k = a.k;
     const uint32_t J = STRIDE1 ? 1u : a.stride;
     const uint64_t mask = head_mask((int)k, DST);  // mask of the kmer's head word
+    // byte sources: DNA / RNA text into a 2-bit alphabet is recoded arithmetically (stage_word), everything else through the
+    // alphabet's 256-entry table in LDS
+    const uint32_t text = (SRC_BITS == 8 && DST == 2 && a.ascii_table <= 1u) ? 1u + a.ascii_table : 0u;
     if constexpr (SRC_BITS == 8) {
-        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);  // computed, not loaded; visible after the tile loop's first barrier
+        if (!text)
+            for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);  // computed, not loaded; visible after the tile loop's first barrier
     }
     static_assert(!PAIR || (!STRIDE1 && N == 1 && !TUPLES && (MODE == MODE_FW || MODE == MODE_XOR)), "PAIR: strided one-word kmers");
     constexpr uint32_t KPL = ((STRIDE1 || PAIR) && N == 1 && !TUPLES) ? 2u : 1u;  // kmers per lane per pass -> 16 B stores
@@ -361,7 +393,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
             for (uint32_t j = 0; j < PRE; ++j) {
                 const uint32_t wi = base + j * BLOCK + tid;
                 if (wi < nw) {
-                    uint64_t f = stage_word<SRC_BITS, DST, FWD>(lds, FWD ? nw - 1u - wi : wi, x[j], lut);
+                    uint64_t f = stage_word<SRC_BITS, DST, FWD>(lds, FWD ? nw - 1u - wi : wi, x[j], lut, text);
                     if constexpr ((SRC_BITS == 4 && DST == 2) || SRC_BITS == 8) {
                         // `span` symbols per element are read (K, or K + W - 1 for minimizer windows): gaps start after them
                         if (f) report_bad_symbols<SRC_BITS, STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, span, w0 + wi, f, x[j], a.err_origin);

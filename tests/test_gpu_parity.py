@@ -347,6 +347,45 @@ def test_ascii_unambiguous_clean_text_of_the_other_alphabet(km, ctx, orc):
                 assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq2), 4, 2, vp(out), None, 0, C.byref(res)) == 0, (res.status, res.err_pos)
 
 
+def test_ascii_every_byte_value(km, ctx, orc):
+    """Text into a 2-bit alphabet is recoded arithmetically, eight bytes at a time (stage_word): every one of the 256 byte values,
+    at every position of a source word, must give what BioSequences.ascii_encode gives -- the symbol, or the EncodeError with that
+    byte -- for DNA and for RNA kmers, through the stride-1, the strided and the forward-only kernels."""
+    cap = km._capi
+    base = b"ACGTTGCAAGGCTTACGATCGATTAGC"
+    for alphabet in (0, 1):
+        b0 = base.replace(b"T", b"U") if alphabet else base
+        for value in range(256):
+            slot = value % 8 + 8                       # walk the byte through the positions of a word
+            raw = b0[:slot] + bytes([value]) + b0[slot + 1:]
+            L = len(raw)
+            words = naive.ascii_words(raw)
+            seq = cap.Seq(words.ctypes.data, L, 0, 0, 8, alphabet)
+            osrc = 9 if alphabet else 8
+            for K in (3, 5):
+                n = L - K + 1
+                res = cap.Result()
+                ck, hs = np.zeros((n, 1), np.uint64), np.zeros(n, np.uint64)
+                rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, vp(ck), vp(hs), 0, cap.MEM_HOST, C.byref(res))
+                ek, eh, eres = orc.canonical(words, L, osrc, 2, K)
+                assert (rc, res.err_pos, res.err_enc) == (eres.status, eres.err_pos, eres.err_enc), (alphabet, value, K)
+                if rc == 0:
+                    assert np.array_equal(ck, ek) and np.array_equal(hs, eh), (alphabet, value)
+                fw = np.zeros((n, 1), np.uint64)
+                rc = ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, vp(fw), None, cap.MEM_HOST, C.byref(res))   # forward-only kernel
+                efw, eres = orc.fw_kmers(words, L, osrc, 2, K)
+                assert (rc, res.err_pos, res.err_enc) == (eres.status, eres.err_pos, eres.err_enc), (alphabet, value, K)
+                if rc == 0:
+                    assert np.array_equal(fw, efw)
+                m = (L - K) // 2 + 1
+                sp = np.zeros((m, 1), np.uint64)
+                rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, 2, 2, vp(sp), cap.MEM_HOST, C.byref(res))
+                es, eres = orc.spaced(words, L, osrc, 2, K, 2)
+                assert (rc, res.err_pos, res.err_enc) == (eres.status, eres.err_pos, eres.err_enc), (alphabet, value, K)
+                if rc == 0:
+                    assert np.array_equal(sp, es)
+
+
 def test_symbol_vector_sources(km, ctx, orc):
     """GenericRecoding sources (src/construction.jl:90-98; FwKmers.jl:80-86, CanonicalKmers.jl:81-91,
     construction_utils.jl:90-103, :161-172): a Vector{DNA} / Vector{RNA} -- one BioSymbols value per byte
