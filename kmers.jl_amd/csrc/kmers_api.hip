@@ -398,10 +398,16 @@ void launch_unambiguous(kmers_ctx *ctx, int src_bits, int nw, dim3 grid, const U
             default: hipLaunchKernelGGL((unambiguous_kernel<SB, 0, UMODE>), grid, block, 0, ctx->stream, a); break; /* run-time width */ \
         }                                                                                                       \
     } while (0)
-    if constexpr (UMODE == UMODE_COUNT) nw = 1;  // counting does not depend on the kmer width
-    if (src_bits == 8) UW(8);
-    else if (src_bits == 4) UW(4);
-    else UW(2);
+    if constexpr (UMODE == UMODE_COUNT) {  // counting does not depend on the kmer width: one instantiation per source
+        (void)nw;
+        if (src_bits == 8) hipLaunchKernelGGL((unambiguous_kernel<8, 1, UMODE_COUNT>), grid, block, 0, ctx->stream, a);
+        else if (src_bits == 4) hipLaunchKernelGGL((unambiguous_kernel<4, 1, UMODE_COUNT>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((unambiguous_kernel<2, 1, UMODE_COUNT>), grid, block, 0, ctx->stream, a);
+    } else {
+        if (src_bits == 8) UW(8);
+        else if (src_bits == 4) UW(4);
+        else UW(2);
+    }
 #undef UW
 }
 
