@@ -460,8 +460,9 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.stamps = reinterpret_cast<uint64_t *>(ctx->stamps_ptr);
     const uint64_t cap_grid = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
 
-    // a 2-bit source has no ambiguous symbols: every start survives, nothing to resolve
-    const bool known_all = seq->src_bits == 2 && stride == 1 && !validate_only;
+    // a 2-bit source has no ambiguous symbols: every start survives, nothing to resolve (kmers of more than four
+    // words take the run-time-width instantiation of the one-pass kernel like every other source)
+    const bool known_all = seq->src_bits == 2 && stride == 1 && !validate_only && nw <= 4;
     uint64_t total = n;
     // Host-memory outputs are staged through HBM buffers of exactly `total` elements, so the host path counts first
     // (it is PCIe-bound anyway); device outputs and their capacity are used as they are: one pass.

@@ -1,5 +1,5 @@
-"""Seeded fuzz of the C ABI against the oracle: random source kind (2-bit, 4-bit, ASCII), kmer
-alphabet (2-/4-bit), K, length, offset view (first_base), stride, ambiguity rate and entry point.
+"""Seeded fuzz of the C ABI against the oracle: random source kind (2-bit, 4-bit, ASCII text, symbol vector), kmer
+alphabet (2-/4-bit), K (kmers of one to eight words), length, offset view (first_base), stride, ambiguity rate and entry point.
 Results must be bit-identical and EncodeErrors must carry the oracle's position and symbol."""
 import ctypes as C
 
@@ -37,7 +37,13 @@ def make_source(rng, src, L, first, p_amb, rna):
         if rna:
             text = text.replace("T", "U").replace("t", "u")
         return naive.ascii_words(text), naive.ascii_words(text[first:]), 8 + rna
+    if src == 10:  # a Vector{DNA}: one BioSymbols value per byte (GenericRecoding)
+        raw = bytes(ENC4[c] for c in text)
+        return naive.ascii_words(raw), naive.ascii_words(raw[first:]), 10
     return naive.longseq_words(text, src), naive.longseq_words(text[first:], src), src
+
+
+ENC4 = {c: i for i, c in enumerate("-ACMGRSVTWYHKDBN")}
 
 
 def same_error(rc, res, eres, first_origin=0):
@@ -51,10 +57,10 @@ def test_fuzz_iterators(km, ctx, orc, seed):
     cap = km._capi
     rng = np.random.default_rng(1000 + seed)
     for case in range(120):
-        src = int(rng.choice([2, 4, 8]))
+        src = int(rng.choice([2, 4, 8, 10]))
         dst = int(rng.choice([2, 4]))
-        kmax = 128 if dst == 2 else 64
-        K = int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 96, kmax]))
+        kmax = 256 if dst == 2 else 128          # the oracle's eight words; more than four run on the run-time-width kernels
+        K = int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 96, 128, 129, 200, kmax]))
         K = min(K, kmax)
         L = int(rng.choice([0, K - 1, K, K + 1, 100, 777, 4096, 5003, 20000]))
         L = max(L, 0)
@@ -63,7 +69,7 @@ def test_fuzz_iterators(km, ctx, orc, seed):
         rna = int(rng.integers(0, 2))
         N = (K * dst + 63) // 64
         words, view_words, osrc = make_source(rng, src, L, first, p_amb, rna)
-        seq = cap.Seq(words.ctypes.data, L, first, 0, src, rna)
+        seq = cap.Seq(words.ctypes.data, L, first, 0, 8 if src == 10 else src, 2 if src == 10 else rna)
         res = cap.Result()
         tag = (seed, case, src, dst, K, L, first, p_amb)
         n = max(0, L - K + 1)
@@ -94,19 +100,29 @@ def test_fuzz_iterators(km, ctx, orc, seed):
             assert same_error(rc, res, eres), tag + (J,)
             if rc == 0:
                 assert res.n_out == m and np.array_equal(out[:m], ek), tag + (J,)
-        else:  # unambiguous (2-bit kmers, K <= 64)
-            K2 = min(K, 64)
+        else:  # unambiguous (2-bit kmers of any width; no method for symbol vectors), with a stride lattice now and then
+            if src == 10:
+                assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), 3, 1, None, None, 0, 0, C.byref(res)) == cap.E_UNSUPPORTED
+                continue
+            K2 = min(K, 256)
             N2 = (2 * K2 + 63) // 64
-            rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K2, 1, None, None, 0, 0, C.byref(res))
+            J = int(rng.choice([1, 1, 1, 2, 3, 11, 64, 1000]))
+            ctx.set_param(cap.PARAM_TILE_KMERS, int(rng.choice([0, 0, 1024, 2048, 8192])))
+            ctx.set_param(cap.PARAM_MAX_GRID, int(rng.choice([0, 0, 1, 5])))
+            rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K2, J, None, None, 0, 0, C.byref(res))
             ek, es, eres = orc.unambiguous(view_words, L, osrc, K2)
             assert same_error(rc, res, eres), tag
             if rc == 0:
+                keep = (es - 1) % J == 0
+                ek, es = ek[keep], es[keep]
                 m = int(res.n_out)
-                assert m == len(ek), tag
+                assert m == len(ek), tag + (J,)
                 kmers = np.zeros((max(m, 1), N2), np.uint64)
                 starts = np.zeros(max(m, 1), np.int64)
-                rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K2, 1, vp(kmers), vp(starts), m, 0, C.byref(res))
-                assert rc == 0 and np.array_equal(kmers[:m], ek) and np.array_equal(starts[:m], es), tag
+                rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K2, J, vp(kmers), vp(starts), m, 0, C.byref(res))
+                assert rc == 0 and np.array_equal(kmers[:m], ek) and np.array_equal(starts[:m], es), tag + (J,)
+            ctx.set_param(cap.PARAM_TILE_KMERS, 0)
+            ctx.set_param(cap.PARAM_MAX_GRID, 0)
 
 
 @pytest.mark.parametrize("seed", range(2))

@@ -675,6 +675,16 @@ def test_unambiguous_kmers_wider_than_four_words(km, ctx, orc):
             assert np.array_equal(hk[:n], ek) and np.array_equal(hs[:n], es), (K, L, tile)
         ctx.set_param(cap.PARAM_TILE_KMERS, 0)
         ctx.free(d_src)
+    # a LongDNA{2} or text source with K > 128 (nothing ambiguous in a 2-bit source: still the run-time-width kernel, not the
+    # four-word stream kernel -- the round-2 fuzz found that dispatch returning unwritten kmers)
+    for src, K, L in ((2, 129, 129), (2, 200, 5003), (2, 256, 257), (8, 150, 2000)):
+        text = naive.random_text(rng, L, p_amb=0.0 if src == 2 else 0.004)
+        words = naive.longseq_words(text, 2) if src == 2 else naive.ascii_words(text)
+        ek, es, _ = orc.unambiguous(words, L, src, K)
+        for stride in (1, 3):
+            kmers, starts = run_unambiguous(km, ctx, words, L, src, K, stride=stride)
+            keep = (es - 1) % stride == 0
+            assert np.array_equal(kmers, ek[keep]) and np.array_equal(starts, es[keep]), (src, K, L, stride)
     # beyond the oracle's widths: K = 700 (22 words) and K = 3000 over text with a few ambiguity codes, against the naive slicer
     for K, L in ((700, 4000), (3000, 12_000)):
         text = list(naive.random_text(rng, L))
