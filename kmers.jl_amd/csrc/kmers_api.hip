@@ -202,6 +202,9 @@ void launch_widths(int n_words, bool s1, bool pair, bool fwd, dim3 grid, dim3 bl
 
 template <int MODE>
 int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int n_words, bool vec_ok, size_t dyn_lds = 0) {
+    // the tile kernel is instantiated for one to four words; wider kmers belong to wide_kernel.hpp / the run-time-width
+    // single-pass kernel and a caller that comes here with them must hear about it
+    if (n_words < 1 || n_words > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "internal: the tile kernel takes kmers of one to four words");
     const uint32_t J = a.stride;
     const bool stride1 = (J == 1) && vec_ok && !a.tuples;
     const bool pair = (MODE == MODE_FW || MODE == MODE_XOR) && J > 1 && vec_ok && !a.tuples && n_words == 1;
