@@ -191,13 +191,18 @@ __device__ __forceinline__ uint32_t rev2_32(uint32_t x) {  // reverse the order 
 }
 template <int N>
 __device__ __forceinline__ void cut_fw(const uint64_t *rs, uint32_t o, uint64_t mask, uint64_t (&fw)[N]) {
-    const uint32_t q = o >> 6, sh = o & 63u;
-    uint64_t lo = rs[q];
+    // the 64N stream bits from bit o on, read as 2N + 1 dwords from the dword that holds bit o: every output dword is one
+    // v_alignbit_b32 of two neighbours (a 64-bit funnel shift is three 64-bit shifts and two ORs)
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(rs) + (o >> 5);
+    const uint32_t b = o & 31u;
+    uint32_t w[2 * N + 1];
+#pragma unroll
+    for (int i = 0; i < 2 * N + 1; ++i) w[i] = d[i];
 #pragma unroll
     for (int j = 0; j < N; ++j) {  // word N-1-j of the kmer = stream bits [o + 64j, o + 64j + 64)
-        const uint64_t hi = rs[q + j + 1];
-        fw[N - 1 - j] = funnel64(lo, hi, sh);
-        lo = hi;
+        const uint32_t lo = __builtin_amdgcn_alignbit(w[2 * j + 1], w[2 * j], b);
+        const uint32_t hi = __builtin_amdgcn_alignbit(w[2 * j + 2], w[2 * j + 1], b);
+        fw[N - 1 - j] = ((uint64_t)hi << 32) | lo;
     }
     fw[0] &= mask;
 }

@@ -36,7 +36,13 @@ constexpr uint32_t UROUND = KMERS_UROUND;  // starts per wavefront round (16 or 
 constexpr uint32_t USLICE = UROUND / 64;  // consecutive starts per lane
 // A round whose kept starts fit the wavefront's list takes 4096 candidate starts at once (64 per lane): with 14-28 % of the
 // starts kept, a 1024-start round lists 140-290 elements and fills its last 128-element store pass badly
-constexpr uint32_t ULONG = 4096, ULIST = 2048;
+#ifndef KMERS_ULONG
+#define KMERS_ULONG 4096
+#endif
+#ifndef KMERS_ULIST
+#define KMERS_ULIST 2048
+#endif
+constexpr uint32_t ULONG = KMERS_ULONG, ULIST = KMERS_ULIST;
 #ifndef KMERS_UNAMB_WGS
 #define KMERS_UNAMB_WGS 3
 #endif
@@ -248,11 +254,13 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         USTAMP(2);
         block_sync();
         USTAMP(3);
-        // resolve: thread t owns qwords 2t and 2t + 1 of the keep mask (64 starts each)
-        uint32_t c2[2];
+        // resolve: thread t owns QPT consecutive qwords of the keep mask (64 starts each; two with 32768-start tiles)
+        constexpr uint32_t QPT = MAXQ >= (uint32_t)BLOCK ? MAXQ / (uint32_t)BLOCK : 1u;
+        uint32_t c2[QPT];
+        uint32_t c = 0;
 #pragma unroll
-        for (uint32_t h = 0; h < 2; ++h) {
-            const uint32_t q = 2u * tid + h;
+        for (uint32_t h = 0; h < QPT; ++h) {
+            const uint32_t q = QPT * tid + h;
             uint64_t keep = 0;
             if (q < nq) {
                 keep = keep_qword(amb, 64u * q + b0, k);
@@ -264,10 +272,10 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                     keep = first < 64u ? keep & (lattice << first) : 0;
                 }
             }
-            keepm[q] = keep;
+            if (q < MAXQ) keepm[q] = keep;
             c2[h] = (uint32_t)__popcll(keep);
+            c += c2[h];
         }
-        const uint32_t c = c2[0] + c2[1];
         uint32_t incl = c;
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t y = __shfl_up(incl, d, 64);
@@ -282,8 +290,12 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             if (w < wave) before += wt;
             tile_total += wt;
         }
-        pre[2u * tid] = before + incl - c;
-        pre[2u * tid + 1u] = before + incl - c + c2[0];
+        uint32_t running = before + incl - c;
+#pragma unroll
+        for (uint32_t h = 0; h < QPT; ++h) {
+            if (QPT * tid + h < MAXQ) pre[QPT * tid + h] = running;
+            running += c2[h];
+        }
         if (tid == 0) {
             pre[MAXQ] = tile_total;
             if constexpr (UMODE == UMODE_COUNT) acc += tile_total;
@@ -422,9 +434,15 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             // list the kept starts of the round in LDS, in order: this lane's slice of consecutive starts begins at list index o
             uint32_t o = pre[q] - round_off + (uint32_t)__popcll(km & ((1ull << sl) - 1ull));
             const uint32_t s0 = lane * usl;  // round-relative index of the slice's first start
-            while (keep16) {
-                mine[o++] = (uint16_t)(s0 + (uint32_t)__builtin_ctzll(keep16));
-                keep16 &= keep16 - 1ull;
+            // (half by half: the 64-bit form of this loop is twelve instructions per listed start, a 32-bit half seven)
+            uint32_t half_lo = (uint32_t)keep16, half_hi = (uint32_t)(keep16 >> 32);
+            while (half_lo) {
+                mine[o++] = (uint16_t)(s0 + (uint32_t)__builtin_ctz(half_lo));
+                half_lo &= half_lo - 1u;
+            }
+            while (half_hi) {
+                mine[o++] = (uint16_t)(s0 + 32u + (uint32_t)__builtin_ctz(half_hi));
+                half_hi &= half_hi - 1u;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
