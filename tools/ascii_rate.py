@@ -8,7 +8,8 @@ import numpy as np
 import torch
 import kmers_jl_amd as km
 cap = km._capi
-libs = sys.argv[1].split(",") if len(sys.argv) > 1 else [cap.library_path()]
+libs = sys.argv[1].split(",") if len(sys.argv) > 1 and sys.argv[1] else [cap.library_path()]
+tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 dev = torch.device("cuda", 0)
 L, K = 1_000_000_000, 31
 
@@ -34,7 +35,10 @@ seqs = {"ASCII": cap.Seq(text.data_ptr(), L, 0, 0, 8, 0), "4-bit": cap.Seq(w4.da
 times = {}
 F = cap.MEM_DEVICE | cap.ASYNC
 for rnd in range(12):
+  for tile in tiles:
     for name, lib, h in variants:
+        lib.kmers_ctx_set_param(h, cap.PARAM_TILE_KMERS, tile)
+        name = f"{name} tile {tile}"
         stream = torch.cuda.ExternalStream(lib.kmers_ctx_stream(h), device=dev)
         for label, seq in seqs.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
