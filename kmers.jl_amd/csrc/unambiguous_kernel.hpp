@@ -34,17 +34,19 @@ constexpr uint32_t UTILE_MAX = KMERS_UTILE_MAX;  // candidate starts per tile (a
 #endif
 constexpr uint32_t UROUND = KMERS_UROUND;  // starts per wavefront round (16 or 8 per lane)
 constexpr uint32_t USLICE = UROUND / 64;  // consecutive starts per lane
-// A round whose kept starts fit the wavefront's list takes 4096 candidate starts at once (64 per lane): with 14-28 % of the
-// starts kept, a 1024-start round lists 140-290 elements and fills its last 128-element store pass badly
+// A round whose kept starts fit the wavefront's list takes 2048 candidate starts at once (32 per lane): with 14-28 % of the
+// starts kept, a 1024-start round lists 140-290 elements and fills its last 128-element store pass badly.  (4096-start rounds
+// with 2048-entry lists ran the same; the 8 KiB they cost are the fourth workgroup of a CU: 38.3 KiB of LDS per workgroup,
+// +7 % on the sparse cases, profiles/r02_tuning.md section 6)
 #ifndef KMERS_ULONG
-#define KMERS_ULONG 4096
+#define KMERS_ULONG 2048
 #endif
 #ifndef KMERS_ULIST
-#define KMERS_ULIST 2048
+#define KMERS_ULIST 1024
 #endif
 constexpr uint32_t ULONG = KMERS_ULONG, ULIST = KMERS_ULIST;
 #ifndef KMERS_UNAMB_WGS
-#define KMERS_UNAMB_WGS 3
+#define KMERS_UNAMB_WGS 4
 #endif
 constexpr int UNAMB_EMIT_WGS = KMERS_UNAMB_WGS;  // workgroups per CU of the emitting mode (its LDS: two tiles' state)
 constexpr uint64_t DESC_VALUE = (1ull << 62) - 1ull;
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     constexpr uint32_t MAXQ = UTILE_MAX / 64;
     __shared__ uint64_t lds2[NBUF][STREAM_QWORDS];
     __shared__ uint64_t keepm2[NBUF][MAXQ];                              // bit j of keepm[q]: start 64q + j is kept
-    __shared__ uint32_t pre2[NBUF][MAXQ + 1];                            // kept starts of the tile before qword q; [MAXQ] = all
+    static_assert(UTILE_MAX <= 65535u, "the per-qword prefix counts are 16-bit");
+    __shared__ uint16_t pre2[NBUF][MAXQ + 2];                            // kept starts of the tile before qword q; [MAXQ] = all
     __shared__ uint64_t amb[AMB_QWORDS];                                 // flag stream: only between stage and resolve
     // per wavefront: the kept starts of a round.  512-start rounds fit the flag stream's space, which is dead while a tile is
     // emitted (four workgroups per CU instead of three)
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     auto front = [&](uint64_t tile, uint32_t buf) {
         uint64_t *const lds = lds2[buf];
         uint64_t *const keepm = keepm2[buf];
-        uint32_t *const pre = pre2[buf];
+        uint16_t *const pre = pre2[buf];
         const Geom g = geometry(tile);
         const uint32_t nw = g.nw, b0 = g.b0, mt = g.mt, nq = g.nq;
         const uint64_t w0 = g.w0, m0 = g.m0;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         block_sync();
         USTAMP(3);
         // resolve: thread t owns QPT consecutive qwords of the keep mask (64 starts each; two with 32768-start tiles)
-        constexpr uint32_t QPT = MAXQ >= (uint32_t)BLOCK ? MAXQ / (uint32_t)BLOCK : 1u;
+        constexpr uint32_t QPT = (MAXQ + (uint32_t)BLOCK - 1u) / (uint32_t)BLOCK;
         uint32_t c2[QPT];
         uint32_t c = 0;
 #pragma unroll
@@ -293,11 +296,11 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         uint32_t running = before + incl - c;
 #pragma unroll
         for (uint32_t h = 0; h < QPT; ++h) {
-            if (QPT * tid + h < MAXQ) pre[QPT * tid + h] = running;
+            if (QPT * tid + h < MAXQ) pre[QPT * tid + h] = (uint16_t)running;
             running += c2[h];
         }
         if (tid == 0) {
-            pre[MAXQ] = tile_total;
+            pre[MAXQ] = (uint16_t)tile_total;
             if constexpr (UMODE == UMODE_COUNT) acc += tile_total;
             // the aggregate is out as early as it can be: the tiles behind this one wait for nothing else of it
             if constexpr (EMIT) desc_store(a.desc + tile, (tile == 0 ? DESC_PREFIX : DESC_AGGREGATE) | (uint64_t)tile_total);
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     auto back = [&](uint64_t tile, uint32_t buf) {
         const uint64_t *const lds = lds2[buf];
         const uint64_t *const keepm = keepm2[buf];
-        const uint32_t *const pre = pre2[buf];
+        const uint16_t *const pre = pre2[buf];
         const Geom g = geometry(tile);
         const uint32_t mt = g.mt, nq = g.nq, kbit0 = g.kbit0;
         const uint64_t m0 = g.m0;

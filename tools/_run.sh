@@ -1,3 +1,4 @@
-timeout 300 python tools/ascii_rate.py '' 1024,1536,2048 2>&1 | grep 4-bit
-timeout 300 python tools/sweep.py --tiles 1024,1536,2048 --rounds 7 2>&1 | tail -n 3
-timeout 300 python tools/ascii_rate.py '' 1024,1536,2048 2>&1 | grep 4-bit
+L=kmers.jl_amd/csrc/libkmers_hip.so
+timeout 300 python tools/unamb_rate.py --libs tools/libkmers_old.so,$L,tools/libkmers_w4c.so --cases k31,c5,clean --reps 7 2>&1 | tail -n 9
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed" | tail -n 2
+timeout 600 python tools/stress_unamb.py 2>&1 | tail -n 1
