@@ -45,6 +45,8 @@ constexpr uint32_t USLICE = UROUND / 64;  // consecutive starts per lane
 #define KMERS_ULIST 1024
 #endif
 constexpr uint32_t ULONG = KMERS_ULONG, ULIST = KMERS_ULIST;
+static_assert(ULIST >= UROUND, "a short round may keep every one of its starts");
+static_assert(ULONG % UROUND == 0 && (ULONG == 1024 || ULONG == 2048 || ULONG == 4096) && 64 % USLICE == 0, "a lane's slice of a round lies in one keep-mask qword");
 #ifndef KMERS_UNAMB_WGS
 #define KMERS_UNAMB_WGS 4
 #endif
@@ -150,12 +152,13 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     __shared__ uint64_t keepm2[NBUF][MAXQ];                              // bit j of keepm[q]: start 64q + j is kept
     static_assert(UTILE_MAX <= 65535u, "the per-qword prefix counts are 16-bit");
     __shared__ uint16_t pre2[NBUF][MAXQ + 2];                            // kept starts of the tile before qword q; [MAXQ] = all
-    __shared__ uint64_t amb[AMB_QWORDS];                                 // flag stream: only between stage and resolve
-    // per wavefront: the kept starts of a round.  512-start rounds fit the flag stream's space, which is dead while a tile is
-    // emitted (four workgroups per CU instead of three)
-    constexpr bool LIST_IN_AMB = WAVES * ULIST * 2 <= AMB_QWORDS * 8;
-    __shared__ uint16_t kept_own[(UMODE == UMODE_COUNT || LIST_IN_AMB) ? 1 : WAVES * ULIST];
-    uint16_t *const kept = LIST_IN_AMB ? reinterpret_cast<uint16_t *>(amb) : kept_own;
+    // flag stream (between stage and resolve of the tile ahead) and, in the same space, the per-wavefront lists of kept starts
+    // of the tile being emitted: the flag stream is dead by then (the scan's barrier lies between its last reader and the first
+    // list entry, the barrier that opens the next front between the last list reader and the next flag)
+    constexpr uint32_t LIST_BYTES = UMODE == UMODE_COUNT ? 0u : (uint32_t)WAVES * ULIST * 2u;
+    constexpr uint32_t AMB_ALLOC = AMB_QWORDS * 8u > LIST_BYTES ? AMB_QWORDS : (LIST_BYTES + 7u) / 8u;
+    __shared__ uint64_t amb[AMB_ALLOC];
+    uint16_t *const kept = reinterpret_cast<uint16_t *>(amb);
     __shared__ uint64_t s_tile, s_base;
     __shared__ uint32_t s_wave_total[WAVES];
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
