@@ -48,7 +48,7 @@ constexpr uint32_t ULONG = KMERS_ULONG, ULIST = KMERS_ULIST;
 static_assert(ULIST >= UROUND, "a short round may keep every one of its starts");
 static_assert(ULONG % UROUND == 0 && (ULONG == 1024 || ULONG == 2048 || ULONG == 4096) && 64 % USLICE == 0, "a lane's slice of a round lies in one keep-mask qword");
 #ifndef KMERS_UNAMB_WGS
-#define KMERS_UNAMB_WGS 4
+#define KMERS_UNAMB_WGS 6
 #endif
 constexpr int UNAMB_EMIT_WGS = KMERS_UNAMB_WGS;  // workgroups per CU of the emitting mode (its LDS: two tiles' state)
 constexpr uint64_t DESC_VALUE = (1ull << 62) - 1ull;
@@ -149,9 +149,17 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     constexpr uint32_t AMB_QWORDS = (UTILE_MAX + 128 + 64) / 64 + 6;
     constexpr uint32_t MAXQ = UTILE_MAX / 64;
     __shared__ uint64_t lds2[NBUF][STREAM_QWORDS];
-    __shared__ uint64_t keepm2[NBUF][MAXQ];                              // bit j of keepm[q]: start 64q + j is kept
-    static_assert(UTILE_MAX <= 65535u, "the per-qword prefix counts are 16-bit");
-    __shared__ uint16_t pre2[NBUF][MAXQ + 2];                            // kept starts of the tile before qword q; [MAXQ] = all
+    // The keep mask of a tile and the kept starts before each of its 64-start qwords never go to LDS: thread t resolves
+    // qwords QPT*t .. QPT*t + QPT-1 and keeps them in registers until the tile is emitted (one whole front later); wavefront
+    // w then works on exactly the qwords its own lanes hold, and fetches what a lane needs with a lane shuffle.
+    constexpr uint32_t QPT = (MAXQ + (uint32_t)BLOCK - 1u) / (uint32_t)BLOCK;  // qwords per thread (two with 32768-start tiles)
+    constexpr uint32_t WQ = 64u * QPT;                                          // qwords per wavefront
+    struct TileRegs {
+        uint64_t k[QPT];   // bit j of k[h]: start 64 (QPT t + h) + j is kept
+        uint32_t p[QPT];   // kept starts of the tile before that qword
+        uint32_t wave_end; // ... before the first qword of the next wavefront
+        uint32_t total;    // kept starts of the tile
+    };
     // flag stream (between stage and resolve of the tile ahead) and, in the same space, the per-wavefront lists of kept starts
     // of the tile being emitted: the flag stream is dead by then (the scan's barrier lies between its last reader and the first
     // list entry, the barrier that opens the next front between the last list reader and the next flag)
@@ -207,8 +215,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     // ---- front of a tile: stage its source words once, resolve every candidate start, publish the AGGREGATE -----------
     auto front = [&](uint64_t tile, uint32_t buf) {
         uint64_t *const lds = lds2[buf];
-        uint64_t *const keepm = keepm2[buf];
-        uint16_t *const pre = pre2[buf];
+        TileRegs tr;
         const Geom g = geometry(tile);
         const uint32_t nw = g.nw, b0 = g.b0, mt = g.mt, nq = g.nq;
         const uint64_t w0 = g.w0, m0 = g.m0;
@@ -260,8 +267,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         USTAMP(2);
         block_sync();
         USTAMP(3);
-        // resolve: thread t owns QPT consecutive qwords of the keep mask (64 starts each; two with 32768-start tiles)
-        constexpr uint32_t QPT = (MAXQ + (uint32_t)BLOCK - 1u) / (uint32_t)BLOCK;
+        // resolve: thread t owns QPT consecutive qwords of the keep mask (64 starts each)
         uint32_t c2[QPT];
         uint32_t c = 0;
 #pragma unroll
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                     keep = first < 64u ? keep & (lattice << first) : 0;
                 }
             }
-            if (q < MAXQ) keepm[q] = keep;
+            tr.k[h] = keep;
             c2[h] = (uint32_t)__popcll(keep);
             c += c2[h];
         }
@@ -299,25 +305,25 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         uint32_t running = before + incl - c;
 #pragma unroll
         for (uint32_t h = 0; h < QPT; ++h) {
-            if (QPT * tid + h < MAXQ) pre[QPT * tid + h] = (uint16_t)running;
+            tr.p[h] = running;
             running += c2[h];
         }
+        tr.wave_end = before + (uint32_t)__shfl(incl, 63, 64);
+        tr.total = tile_total;
         if (tid == 0) {
-            pre[MAXQ] = (uint16_t)tile_total;
             if constexpr (UMODE == UMODE_COUNT) acc += tile_total;
             // the aggregate is out as early as it can be: the tiles behind this one wait for nothing else of it
             if constexpr (EMIT) desc_store(a.desc + tile, (tile == 0 ? DESC_PREFIX : DESC_AGGREGATE) | (uint64_t)tile_total);
         }
         USTAMP(4);
+        return tr;
     };
 
     // ---- back of a tile: its exclusive prefix (look-back), then list and emit its kept starts --------------------------
-    auto back = [&](uint64_t tile, uint32_t buf) {
+    auto back = [&](uint64_t tile, uint32_t buf, const TileRegs &tr) {
         const uint64_t *const lds = lds2[buf];
-        const uint64_t *const keepm = keepm2[buf];
-        const uint16_t *const pre = pre2[buf];
         const Geom g = geometry(tile);
-        const uint32_t mt = g.mt, nq = g.nq, kbit0 = g.kbit0;
+        const uint32_t mt = g.mt, kbit0 = g.kbit0;
         const uint64_t m0 = g.m0;
         if constexpr (EMIT) {
             if (wave == 0) {
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                 // polled alone (re-reading whole windows made 1280 wavefronts hammer the same few cache lines).
                 uint64_t excl = 0;
                 if (tile != 0) {
-                    const uint32_t tile_total = pre[MAXQ];
+                    const uint32_t tile_total = tr.total;
                     long long pos = (long long)tile - 1;  // the nearest predecessor not yet accounted for
                     uint64_t part = 0;                    // this lane's share of the sum
                     bool found = false;
@@ -376,19 +382,30 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         }
         const uint64_t base = EMIT ? s_base : 0;
 
-        // every wavefront takes a CONTIGUOUS quarter of the tile's rounds of 1024 candidate starts, so that its stores sweep
-        // one contiguous region of each output array
+        // every wavefront takes the CONTIGUOUS quarter of the tile whose keep mask its own lanes resolved, so that its stores
+        // sweep one contiguous region of each output array and the mask never leaves the registers
         uint16_t *mine = kept + wave * ULIST;
-        const uint32_t rounds_per_wave = ((mt + UROUND - 1u) / UROUND + WAVES - 1u) / WAVES;
-        const uint32_t wave_end = (wave + 1u) * rounds_per_wave * UROUND < mt ? (wave + 1u) * rounds_per_wave * UROUND : mt;
+        const uint32_t qw0 = wave * WQ;                                       // the wavefront's first qword
+        const uint32_t wave_end = (qw0 + WQ) * 64u < mt ? (qw0 + WQ) * 64u : mt;
+        // kept starts of the tile before qword qw0 + qrel (qrel <= WQ, the same in every lane)
+        auto prefix_at = [&](uint32_t qrel) -> uint32_t {
+            if (qrel >= WQ) return tr.wave_end;
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t h = 0; h < QPT; ++h) {
+                const uint32_t x = (uint32_t)__shfl(tr.p[h], (int)(qrel / QPT), 64);
+                if (qrel % QPT == h) v = x;
+            }
+            return v;
+        };
         uint32_t n_round = 0;
-        for (uint32_t r_begin = wave * rounds_per_wave * UROUND; r_begin < wave_end; r_begin += n_round) {
+        for (uint32_t r_begin = qw0 * 64u; r_begin < wave_end; r_begin += n_round) {
             const uint32_t q0 = r_begin >> 6;
-            const uint32_t round_off = pre[q0];
+            const uint32_t round_off = prefix_at(q0 - qw0);
             // a long round if its kept starts fit the list (or nothing at all is dropped), else 1024 starts
             n_round = wave_end - r_begin < ULONG ? wave_end - r_begin : ULONG;
             uint32_t q1 = (r_begin + n_round + 63u) >> 6;
-            uint32_t cnt = (q1 < nq ? pre[q1] : pre[MAXQ]) - round_off;  // kept starts of this round
+            uint32_t cnt = prefix_at(q1 - qw0) - round_off;                // kept starts of this round
             uint32_t usl = ULONG / 64u;                                    // consecutive starts per lane
             uint64_t pos = base + round_off;                               // output index of the round's first
             // (a round with nothing dropped needs no list when it can take the two-kmers-per-lane path below)
@@ -396,13 +413,26 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             if (n_round > UROUND && cnt > ULIST && !dense_long) {
                 n_round = UROUND;
                 q1 = q0 + UROUND / 64u;
-                cnt = (q1 < nq ? pre[q1] : pre[MAXQ]) - round_off;
+                cnt = prefix_at(q1 - qw0) - round_off;
                 usl = USLICE;
             } else if (n_round <= UROUND) {
                 usl = USLICE;
             }
-            const uint32_t q = q0 + ((lane * usl) >> 6), sl = (lane * usl) & 63u;
-            const uint64_t km = q < nq ? keepm[q] : 0;
+            // this lane's qword of the mask and the kept starts before it, from the lane that holds them
+            const uint32_t sl = (lane * usl) & 63u;
+            uint32_t qrel = q0 - qw0 + ((lane * usl) >> 6);
+            if (qrel >= WQ) qrel = WQ - 1u;  // (a lane past the end of the round: its slice is empty, any qword will do)
+            uint64_t km = 0;
+            uint32_t km_before = 0;
+#pragma unroll
+            for (uint32_t h = 0; h < QPT; ++h) {
+                const uint64_t xk = __shfl(tr.k[h], (int)(qrel / QPT), 64);
+                const uint32_t xp = (uint32_t)__shfl(tr.p[h], (int)(qrel / QPT), 64);
+                if (qrel % QPT == h) {
+                    km = xk;
+                    km_before = xp;
+                }
+            }
             // this lane's slice of the keep mask: `usl` consecutive starts, cut at the end of the round (the starts behind it
             // belong to the next wavefront's chunk)
             const uint32_t mine_n = lane * usl < n_round ? (n_round - lane * usl < usl ? n_round - lane * usl : usl) : 0u;
@@ -438,7 +468,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                 }
             }
             // list the kept starts of the round in LDS, in order: this lane's slice of consecutive starts begins at list index o
-            uint32_t o = pre[q] - round_off + (uint32_t)__popcll(km & ((1ull << sl) - 1ull));
+            uint32_t o = km_before - round_off + (uint32_t)__popcll(km & ((1ull << sl) - 1ull));
             const uint32_t s0 = lane * usl;  // round-relative index of the slice's first start
             // (half by half: the 64-bit form of this loop is twelve instructions per listed start, a 32-bit half seven)
             uint32_t half_lo = (uint32_t)keep16, half_hi = (uint32_t)(keep16 >> 32);
@@ -552,10 +582,12 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     if constexpr (!EMIT) {
         // COUNT / XOR: a persistent grid strides over the tiles; nothing is placed, so no descriptors
         for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-            front(tile, 0);
+            const TileRegs tr = front(tile, 0);
             if constexpr (UMODE == UMODE_XOR) {
                 block_sync();
-                back(tile, 0);
+                back(tile, 0, tr);
+            } else {
+                (void)tr;
             }
         }
     } else {
@@ -573,15 +605,17 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         };
         uint64_t cur = draw();
         uint32_t buf = 0;
-        if (cur < a.n_tiles) front(cur, buf);
+        TileRegs tr_cur{}, tr_nxt{};
+        if (cur < a.n_tiles) tr_cur = front(cur, buf);
         while (cur < a.n_tiles) {
 #ifdef KMERS_STAMPS
             ts[0] = __builtin_amdgcn_s_memrealtime();
 #endif
             const uint64_t nxt = draw();
-            if (nxt < a.n_tiles) front(nxt, buf ^ 1u);
-            block_sync();  // the tile's own state (keep mask, prefix) is complete for every wavefront
-            back(cur, buf);
+            if (nxt < a.n_tiles) tr_nxt = front(nxt, buf ^ 1u);
+            block_sync();  // the codes of the tile are staged for every wavefront
+            back(cur, buf, tr_cur);
+            tr_cur = tr_nxt;
             cur = nxt;
             buf ^= 1u;
         }
