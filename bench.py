@@ -59,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra C3/C4/C5/10 Gbase rates (N = 1 only)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child runs")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--wake-s", type=float, default=1.0, help="seconds of plain fills before the W warm-up steps (a fresh or idle device is slower at first)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: the profiled child of the traffic leg
     return ap.parse_args(argv)
 
@@ -530,12 +531,13 @@ def main():
         torch.cuda.synchronize()
 
     # Wake the device: after an idle gap (allocation, data generation, process start) this device runs its next ~10 ms
-    # 10-25 % slower (tools/diag_cooldown.py, profiles/r02_tuning.md section 1), which is longer than the W warm-up steps of the
-    # contract.  50 ms of plain torch fills of the output arrays -- not steps of the hot path -- come first; the W warm-up
-    # steps and the K timed steps below are exactly the contract's.
+    # 10-25 % slower (tools/diag_cooldown.py, profiles/r02_tuning.md section 1) and the first second of a fresh process 2 %
+    # slower than the ninety that follow (tools/diag_warmup.py: 2.49 ms per launch, then 2.435), which is longer than the W
+    # warm-up steps of the contract.  --wake-s seconds (default 1) of plain torch fills of the output arrays -- not steps of
+    # the hot path -- come first; the W warm-up steps and the K timed steps below are exactly the contract's.
     with torch.cuda.stream(stream):
         t_wake = time.perf_counter()
-        while time.perf_counter() - t_wake < 0.05:
+        while time.perf_counter() - t_wake < args.wake_s:
             out_k.fill_(0)
             if out_h is not None:
                 out_h.fill_(0)
@@ -595,7 +597,7 @@ def main():
                                    f"CanonicalDNAMers{{{K}}} over {args.bases / 1e9:g} Gbase LongDNA{{{bits}}} per GPU",
                        "k": K, "src_bits": bits, "bases_per_gpu": args.bases,
                        "sharding": sharding, "backend": backend, "halo_transport": transport if grouped else None,
-                       "seed": hex(seed)},
+                       "seed": hex(seed), "wake_s": args.wake_s},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": "not measured",
                          "kernel": "stream_kernel<src_bits,N,CANON,stride1>", "kernel_ms": round(kern_ms, 4),
