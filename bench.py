@@ -59,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra C3/C4/C5/10 Gbase rates (N = 1 only)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child runs")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--no-defrag", action="store_true", help="skip the one large allocate-and-release before the working buffers")
     ap.add_argument("--wake-s", type=float, default=1.0, help="seconds of plain fills before the W warm-up steps (a fresh or idle device is slower at first)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: the profiled child of the traffic leg
     return ap.parse_args(argv)
@@ -490,6 +491,19 @@ def main():
     # hands the 128-byte ncclUniqueId around); under gloo (shared-device debugging, CPU tests) torch.distributed's
     transport = os.environ.get("KMERS_HALO_TRANSPORT", "native" if backend == "nccl" else "allgather")
     comm = None
+    # A fresh box hands out fragmented VRAM: the same launch over two freshly allocated 8 GB output arrays runs at 0.794 of
+    # 8 TB/s in the first process of a box and at 0.83-0.84 in any process after one that has allocated and released a large
+    # block (tools/diag_alloc2.py, profiles/r02_tuning.md section 7: the driver then has large contiguous ranges to give, and
+    # the address translation reaches further).  One allocation of 60 % of the free memory, released at once and never
+    # touched, puts every run in the second state; INTEGRATION.md gives the same advice to host applications.
+    defrag_gb = 0.0
+    if not args.no_defrag:
+        free_b, _total_b = torch.cuda.mem_get_info(dev)
+        n_defrag = int(free_b * 0.6) // 8
+        tmp = torch.empty(n_defrag, dtype=torch.int64, device=dev)
+        del tmp
+        torch.cuda.empty_cache()
+        defrag_gb = round(n_defrag * 8 / 1e9, 1)
     with torch.cuda.stream(stream):
         buf = torch.zeros(sh.n_own_words + sh.halo_words + 2, dtype=torch.int64, device=dev)
         ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, sh.first_word, sh.n_own_words, bits, 0, buf.data_ptr()),
@@ -597,7 +611,8 @@ def main():
                                    f"CanonicalDNAMers{{{K}}} over {args.bases / 1e9:g} Gbase LongDNA{{{bits}}} per GPU",
                        "k": K, "src_bits": bits, "bases_per_gpu": args.bases,
                        "sharding": sharding, "backend": backend, "halo_transport": transport if grouped else None,
-                       "seed": hex(seed), "wake_s": args.wake_s},
+                       "seed": hex(seed), "wake_s": args.wake_s,
+                       "vram_defrag_GB": defrag_gb},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": "not measured",
                          "kernel": "stream_kernel<src_bits,N,CANON,stride1>", "kernel_ms": round(kern_ms, 4),
