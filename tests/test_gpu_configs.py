@@ -298,6 +298,69 @@ def test_c5_spaced21_3_one_gbase_strict_and_skip(km, ctx, orc):
     assert np.array_equal(starts[:cnt].cpu().numpy(), es[keep])
 
 
+def test_unambiguous31_one_gbase_every_element(km, ctx, orc):
+    """UnambiguousDNAMers{31} over 1 Gbase LongDNA{4} with N at p = 0.04 (the reference's own skipping iterator at the headline
+    K and size), device outputs, checked over EVERY element without the oracle: the starts are exactly the positions whose
+    31 symbols hold no N (N flags decoded from the source words and window-summed with torch), in order, and every kmer is
+    the forward kmer of the clean copy at that start.  The oracle then confirms the first 4 Mbase bit for bit, and the tuple
+    layout gives the same elements."""
+    cap = km._capi
+    L, K, bits = 1_000_000_000, 31, 4
+    seed = GOLDEN ^ 6
+    nw = (L * bits + 63) // 64
+    amb = synth(ctx, seed, 0, nw, bits, 2621)
+    seq_a = cap.Seq(amb.data_ptr(), L, 0, 0, bits, 0)
+    res = cap.Result()
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq_a), K, 1, None, None, 0, cap.MEM_DEVICE, C.byref(res)) == 0
+    m = int(res.n_out)
+    assert 0.27 * L < m < 0.30 * L                                    # (1 - 0.04)^31 = 0.282
+    kmers, starts = dev_empty(m), dev_empty(m)
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq_a), K, 1, kmers.data_ptr(), starts.data_ptr(), m,
+                                     cap.MEM_DEVICE, C.byref(res)) == 0 and res.n_out == m
+    # the expected starts, from the source words alone: symbol j of word w is N iff its nibble is 0b1111
+    n_cand = L - K + 1
+    expected = []
+    carry = torch.zeros(K - 1, dtype=torch.int32, device="cuda:0")      # N flags of the K-1 symbols before the chunk
+    step = 1 << 26                                                      # symbols per chunk (a multiple of 16)
+    found = 0
+    for lo in range(0, L, step):
+        hi = min(L, lo + step)
+        words = amb[lo // 16:(hi + 15) // 16]
+        nib = (words.unsqueeze(1) >> (4 * torch.arange(16, device="cuda:0", dtype=torch.int64))) & 0xF
+        is_n = (nib == 0xF).reshape(-1)[:hi - lo].to(torch.int32)
+        flags = torch.cat([carry, is_n])                                # symbols lo-(K-1) .. hi-1
+        cs = torch.cumsum(flags, 0, dtype=torch.int32)
+        cs = torch.cat([torch.zeros(1, dtype=torch.int32, device="cuda:0"), cs])
+        win = cs[K:] - cs[:-K]                                          # window sums of the starts lo-(K-1) .. hi-K
+        first_start = lo - (K - 1)                                      # 0-based start of win[0]
+        ok = torch.nonzero(win == 0).reshape(-1) + first_start
+        ok = ok[(ok >= 0) & (ok < n_cand)]
+        got = starts[found:found + ok.numel()]
+        assert got.numel() == ok.numel() and bool(torch.equal(got, ok + 1)), lo
+        found += ok.numel()
+        carry = flags[-(K - 1):].clone()
+        del nib, is_n, flags, cs, win, ok
+    assert found == m
+    # every kmer = the forward kmer of the clean copy (same seed, no N) at its start
+    clean = synth(ctx, seed, 0, nw, bits)
+    seq_c = cap.Seq(clean.data_ptr(), L, 0, 0, bits, 0)
+    fw = dev_empty(n_cand)
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq_c), K, 2, fw.data_ptr(), None, cap.MEM_DEVICE, C.byref(res)) == 0
+    for lo, hi in chunks(m):
+        assert bool(torch.equal(kmers[lo:hi], fw[starts[lo:hi] - 1])), lo
+    del fw, clean
+    # Tuple{Kmer,Int} elements: the same pairs interleaved
+    tup = dev_empty(2 * m)
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq_a), K, 1, tup.data_ptr(), None, m,
+                                     cap.MEM_DEVICE | cap.OUT_TUPLES, C.byref(res)) == 0 and res.n_out == m
+    assert bool(torch.equal(tup[0::2], kmers)) and bool(torch.equal(tup[1::2], starts))
+    # and the oracle on the first 4 Mbase
+    Lp = 4_000_000
+    w = orc.synth_words(seed, 0, Lp * bits // 64 + 1, bits, 2621)
+    ek, es, _ = orc.unambiguous(w, Lp, bits, K)
+    assert np.array_equal(host_u64(kmers[:len(ek)]), ek[:, 0]) and np.array_equal(starts[:len(es)].cpu().numpy(), es)
+
+
 def test_synth_10k_fixture_on_device(km, ctx):
     """tests/golden/synth_10k.json: device generator + HIP iterators against the committed values
     (no oracle at run time)."""
