@@ -510,8 +510,8 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         a.out_starts = d_s;
         a.capacity = dev ? capacity : total;
         a.vec16 = ((!d_k || aligned16(d_k)) && (!d_s || aligned16(d_s))) ? 1u : 0u;
-        // a persistent grid: every workgroup draws tickets until none is left (four workgroups per CU: the kernel keeps
-        // two tiles' state in LDS, 38.3 KiB; its time falls with every resident workgroup up to that, profiles/r02_tuning.md)
+        // a persistent grid: every workgroup draws tickets until none is left (UNAMB_EMIT_WGS = six workgroups per CU, 24.2 KiB
+        // of LDS and 80 VGPRs each; the kernel's time falls with every resident workgroup, profiles/r02_tuning.md section 6)
         dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, std::min<uint64_t>(cap_grid, (uint64_t)ctx->n_cus * UNAMB_EMIT_WGS)));
         launch_unambiguous<UMODE_EMIT>(ctx, seq->src_bits, nw, grid, a);
         HIP_TRY(ctx, hipGetLastError());

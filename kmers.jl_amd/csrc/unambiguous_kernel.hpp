@@ -13,9 +13,12 @@
 //            one that already holds an inclusive PREFIX (decoupled look-back: it never waits for a predecessor's prefix,
 //            only for aggregates, which every started tile publishes unconditionally -- no circular wait), publishes its
 //            own inclusive prefix and hands the exclusive one to the workgroup;
-//   emit     every wavefront lists the kept starts of 1024 candidates at a time in LDS (their order is the reference's) and
-//            works the list off with every lane busy: window cut + contiguous stores.  A stretch with nothing dropped
+//   emit     every wavefront lists the kept starts of 1024-2048 candidates at a time in LDS (their order is the reference's)
+//            and works the list off with every lane busy: window cut + contiguous stores.  A stretch with nothing dropped
 //            (real sequence outside its N blocks) skips the list: two kmers per lane, 16-byte stores.
+//   pipeline the grid is persistent (six workgroups per CU) and a workgroup runs the first step of its NEXT tile before the
+//            last two of the current one, so that an aggregate is out microseconds after its ticket.  Between the two a
+//            tile's keep mask and prefix counts stay in the registers of the lanes that resolved them; its codes in LDS.
 //
 // A descriptor is ONE 64-bit word (status in the top two bits, count below) moved with relaxed agent-scope atomics, so
 // no fence is needed: the word is the whole hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, "8-B agent atomics
@@ -36,8 +39,8 @@ constexpr uint32_t UROUND = KMERS_UROUND;  // starts per wavefront round (16 or 
 constexpr uint32_t USLICE = UROUND / 64;  // consecutive starts per lane
 // A round whose kept starts fit the wavefront's list takes 2048 candidate starts at once (32 per lane): with 14-28 % of the
 // starts kept, a 1024-start round lists 140-290 elements and fills its last 128-element store pass badly.  (4096-start rounds
-// with 2048-entry lists ran the same; the 8 KiB they cost are the fourth workgroup of a CU: 38.3 KiB of LDS per workgroup,
-// +7 % on the sparse cases, profiles/r02_tuning.md section 6)
+// with 2048-entry lists ran the same and cost 8 KiB of LDS more; the kernel's time falls with every resident workgroup,
+// profiles/r02_tuning.md section 6)
 #ifndef KMERS_ULONG
 #define KMERS_ULONG 2048
 #endif
@@ -50,7 +53,7 @@ static_assert(ULONG % UROUND == 0 && (ULONG == 1024 || ULONG == 2048 || ULONG ==
 #ifndef KMERS_UNAMB_WGS
 #define KMERS_UNAMB_WGS 6
 #endif
-constexpr int UNAMB_EMIT_WGS = KMERS_UNAMB_WGS;  // workgroups per CU of the emitting mode (its LDS: two tiles' state)
+constexpr int UNAMB_EMIT_WGS = KMERS_UNAMB_WGS;  // workgroups per CU of the emitting mode (24.2 KiB of LDS each, 80 VGPRs)
 constexpr uint64_t DESC_VALUE = (1ull << 62) - 1ull;
 constexpr uint64_t DESC_AGGREGATE = 1ull << 62, DESC_PREFIX = 2ull << 62;
 constexpr int LOOKBACK = 4;               // descriptors per lane and look-back step (256 tiles per step)
