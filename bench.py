@@ -497,13 +497,17 @@ def main():
     # the address translation reaches further).  One allocation of 60 % of the free memory, released at once and never
     # touched, puts every run in the second state; INTEGRATION.md gives the same advice to host applications.
     defrag_gb = 0.0
-    if not args.no_defrag:
+    shared_device = grouped and backend != "nccl"  # (gloo debugging mode: the ranks share one device and its memory)
+    if not args.no_defrag and not shared_device:
         free_b, _total_b = torch.cuda.mem_get_info(dev)
         n_defrag = int(free_b * 0.6) // 8
-        tmp = torch.empty(n_defrag, dtype=torch.int64, device=dev)
-        del tmp
+        try:
+            tmp = torch.empty(n_defrag, dtype=torch.int64, device=dev)
+            del tmp
+            defrag_gb = round(n_defrag * 8 / 1e9, 1)
+        except torch.OutOfMemoryError:
+            pass  # somebody else holds the memory: measure in whatever state the allocator is
         torch.cuda.empty_cache()
-        defrag_gb = round(n_defrag * 8 / 1e9, 1)
     with torch.cuda.stream(stream):
         buf = torch.zeros(sh.n_own_words + sh.halo_words + 2, dtype=torch.int64, device=dev)
         ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, sh.first_word, sh.n_own_words, bits, 0, buf.data_ptr()),
