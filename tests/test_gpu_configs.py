@@ -361,6 +361,76 @@ def test_unambiguous31_one_gbase_every_element(km, ctx, orc):
     assert np.array_equal(host_u64(kmers[:len(ek)]), ek[:, 0]) and np.array_equal(starts[:len(es)].cpu().numpy(), es)
 
 
+@pytest.mark.parametrize("world", [3, 8])
+def test_spaced_and_unambiguous_over_logical_shards(km, ctx, orc, world):
+    """SURVEY.md 8(e) for the two iterators whose shards are not plain kmer ranges: SpacedDNAMers{21,3} (shard boundaries on
+    the stride lattice AND on source words) and UnambiguousDNAMers{21} (per-shard compaction + exclusive scan of the counts;
+    global 1-based starts through index_origin).  The shards run one after another on this device exactly as `world` ranks
+    would (own words + the halo words of the next shard, index_origin = first_base); their concatenation must equal one call
+    over the whole sequence, and the strict iterator's first EncodeError is the minimum over the shards."""
+    from kmers_jl_amd.shard import plan_shards
+    cap = km._capi
+    L, K, J, bits = 48_000_017, 21, 3, 4
+    seed = GOLDEN ^ 8
+    nw = (L * bits + 63) // 64
+    res = cap.Result()
+
+    def shard_buffer(sh, amb):
+        buf = dev_empty(sh.n_own_words + sh.halo_words + 2)
+        ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, sh.first_word, sh.n_own_words + sh.halo_words, bits, amb, buf.data_ptr()), "synth")
+        return buf
+
+    for amb in (0, 2621):
+        whole = synth(ctx, seed, 0, nw, bits, amb)
+        wseq = cap.Seq(whole.data_ptr(), L, 0, 0, bits, 0)
+        # ---- SpacedDNAMers{21,3}
+        n = (L - K) // J + 1
+        ref = dev_empty(n)
+        rc_whole = ctx.lib.kmers_spaced(ctx.handle, C.byref(wseq), K, J, 2, ref.data_ptr(), cap.MEM_DEVICE, C.byref(res))
+        whole_err = (res.err_pos, res.err_enc)
+        plan = plan_shards(L, K, world, bits, J)
+        assert sum(sh.n_kmers for sh in plan) == n
+        parts, errs = [], []
+        for sh in plan:
+            assert sh.first_base % J == 0 and (sh.first_base * bits) % 64 == 0
+            buf = shard_buffer(sh, amb)
+            out = dev_empty(max(sh.n_kmers, 1))
+            seq = cap.Seq(buf.data_ptr(), sh.n_bases, 0, sh.first_base, bits, 0)
+            rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, 2, out.data_ptr(), cap.MEM_DEVICE, C.byref(res))
+            if rc == 0:
+                assert res.n_out == sh.n_kmers
+                parts.append(out[:sh.n_kmers])
+            else:
+                assert rc == cap.E_ENCODE
+                errs.append((res.err_pos, res.err_enc))
+        if amb == 0:
+            assert rc_whole == 0 and not errs and bool(torch.equal(torch.cat(parts), ref))
+        else:
+            assert rc_whole == cap.E_ENCODE and min(errs) == whole_err   # the reduction kmers_first_error_allreduce does
+        # ---- UnambiguousDNAMers{21}: counts scanned over the shards, starts global
+        assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(wseq), K, 1, None, None, 0, cap.MEM_DEVICE, C.byref(res)) == 0
+        m = int(res.n_out)
+        rk, rs = dev_empty(m), dev_empty(m)
+        assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(wseq), K, 1, rk.data_ptr(), rs.data_ptr(), m, cap.MEM_DEVICE, C.byref(res)) == 0
+        plan = plan_shards(L, K, world, bits, 1)
+        gk, gs = dev_empty(m), dev_empty(m)
+        offset = 0
+        for sh in plan:
+            buf = shard_buffer(sh, amb)
+            seq = cap.Seq(buf.data_ptr(), sh.n_bases, 0, sh.first_base, bits, 0)
+            # the shard writes straight into its slice of the global arrays (offset = exclusive scan of the counts)
+            rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, gk.data_ptr() + 8 * offset, gs.data_ptr() + 8 * offset,
+                                           m - offset, cap.MEM_DEVICE, C.byref(res))
+            assert rc == 0
+            offset += int(res.n_out)
+        assert offset == m and bool(torch.equal(gk, rk)) and bool(torch.equal(gs, rs))
+    # and the oracle on the head of the whole-sequence result (amb = 2621 is the last state of rk / rs)
+    Lp = 2_000_000
+    w = orc.synth_words(seed, 0, Lp * bits // 64 + 1, bits, 2621)
+    ek, es, _ = orc.unambiguous(w, Lp, bits, K)
+    assert np.array_equal(host_u64(rk[:len(ek)]), ek[:, 0]) and np.array_equal(rs[:len(es)].cpu().numpy(), es)
+
+
 def test_synth_10k_fixture_on_device(km, ctx):
     """tests/golden/synth_10k.json: device generator + HIP iterators against the committed values
     (no oracle at run time)."""
