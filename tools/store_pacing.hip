@@ -54,6 +54,27 @@ __global__ __launch_bounds__(256) void persistent_work(ulonglong2* __restrict__ 
         a[i] = make_ulonglong2(x, v ^ i); b[i] = make_ulonglong2(v * i, x - i);
     }
 }
+// the same with the stores made conditional on something that never happens: the arithmetic alone
+template <int W>
+__global__ __launch_bounds__(256) void persistent_work_only(ulonglong2* __restrict__ a, ulonglong2* __restrict__ b, size_t n, unsigned long long v) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        unsigned long long x = v + i;
+#pragma unroll 16
+        for (int w = 0; w < W; ++w) x = x * 0x9E3779B97F4A7C15ull + w;
+        if (x == 0x1234567ull) { a[i] = make_ulonglong2(x, v ^ i); b[i] = make_ulonglong2(v * i, x - i); }
+    }
+}
+template <int W>
+__global__ __launch_bounds__(256) void persistent_work_heavy(ulonglong2* __restrict__ a, ulonglong2* __restrict__ b, size_t n, unsigned long long v) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        unsigned long long x = v + i;
+#pragma unroll 16
+        for (int w = 0; w < W; ++w) x = x * 0x9E3779B97F4A7C15ull + w;
+        a[i] = make_ulonglong2(x, v ^ i); b[i] = make_ulonglong2(v * i, x - i);
+    }
+}
 template <int W>
 __global__ __launch_bounds__(256) void one_pass_work(ulonglong2* __restrict__ a, ulonglong2* __restrict__ b, size_t n, unsigned long long v, int per_tile) {
     size_t base = (size_t)blockIdx.x * per_tile;
@@ -96,6 +117,12 @@ int main() {
         snprintf(l, 128, "persistent, s_sleep 32 every 4th pair, grid %d", grid); RUN(l, P(5, 32, grid));
         snprintf(l, 128, "persistent + 16 mul-adds per pair, grid %d", grid); RUN(l, hipLaunchKernelGGL(persistent_work<16>, dim3(grid), dim3(256), 0, 0, a, b, n, 1ull));
         snprintf(l, 128, "persistent + 64 mul-adds per pair, grid %d", grid); RUN(l, hipLaunchKernelGGL(persistent_work<64>, dim3(grid), dim3(256), 0, 0, a, b, n, 1ull));
+    }
+    for (int grid : {768, 1536}) {
+        char l[128];
+#define HW(W) snprintf(l, 128, "persistent, %d mul-adds per pair, NO stores, grid %d", W, grid); RUN(l, hipLaunchKernelGGL(persistent_work_only<W>, dim3(grid), dim3(256), 0, 0, a, b, n, 1ull)); \
+              snprintf(l, 128, "persistent, %d mul-adds per pair + stores, grid %d", W, grid); RUN(l, hipLaunchKernelGGL(persistent_work_heavy<W>, dim3(grid), dim3(256), 0, 0, a, b, n, 1ull));
+        HW(128) HW(192) HW(256) HW(384)
     }
     RUN("one pass + 16 mul-adds per pair", hipLaunchKernelGGL(one_pass_work<16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a, b, n, 1ull, 256));
     RUN("one pass + 64 mul-adds per pair", hipLaunchKernelGGL(one_pass_work<64>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a, b, n, 1ull, 256));
