@@ -121,6 +121,13 @@ def test_fuzz_iterators(km, ctx, orc, seed):
                 starts = np.zeros(max(m, 1), np.int64)
                 rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K2, J, vp(kmers), vp(starts), m, 0, C.byref(res))
                 assert rc == 0 and np.array_equal(kmers[:m], ek) and np.array_equal(starts[:m], es), tag + (J,)
+                if case % 3 == 0:  # Tuple{Kmer,Int} elements (any width), and only the kmers / only the starts
+                    tup = np.zeros((max(m, 1), N2 + 1), np.uint64)
+                    rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K2, J, vp(tup), None, m, cap.OUT_TUPLES, C.byref(res))
+                    assert rc == 0 and np.array_equal(tup[:m, :N2], ek) and np.array_equal(tup[:m, N2].astype(np.int64), es), tag + (J, "tuples")
+                    only = np.zeros(max(m, 1), np.int64)
+                    rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K2, J, None, vp(only), m, 0, C.byref(res))
+                    assert rc == 0 and np.array_equal(only[:m], es), tag + (J, "starts only")
             ctx.set_param(cap.PARAM_TILE_KMERS, 0)
             ctx.set_param(cap.PARAM_MAX_GRID, 0)
 
