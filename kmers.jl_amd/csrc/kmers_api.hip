@@ -579,8 +579,11 @@ int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int 
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, resident)), block(RBLOCK);
 #define RUNK(SB)                                                                                             \
     do {                                                                                                     \
-        if (k <= 32) hipLaunchKernelGGL((run_kernel<SB, RMODE, 1>), grid, block, best_bytes, ctx->stream, a); \
-        else hipLaunchKernelGGL((run_kernel<SB, RMODE, 2>), grid, block, best_bytes, ctx->stream, a);        \
+        if (RMODE == RMODE_XOR && !a.xor_canonical) {                                                        \
+            if (k <= 32) hipLaunchKernelGGL((run_kernel<SB, RMODE_XOR, 1, false>), grid, block, best_bytes, ctx->stream, a); \
+            else hipLaunchKernelGGL((run_kernel<SB, RMODE_XOR, 2, false>), grid, block, best_bytes, ctx->stream, a);         \
+        } else if (k <= 32) hipLaunchKernelGGL((run_kernel<SB, RMODE, 1, true>), grid, block, best_bytes, ctx->stream, a);   \
+        else hipLaunchKernelGGL((run_kernel<SB, RMODE, 2, true>), grid, block, best_bytes, ctx->stream, a);  \
     } while (0)
     if (seq->src_bits == 8) RUNK(8);
     else if (seq->src_bits == 4) RUNK(4);

@@ -4,11 +4,11 @@
 //   RMODE_SKETCH MinHash candidates: fx_hash(canonical kmer) below the running threshold
 //                (docs/src/minhash.md:31-35).
 // These are ALU-bound (0.25-0.5 B of source per kmer), so the kernel spends as few instructions
-// per kmer as the reference's own recurrence allows: a lane builds the first kmer of a RUN of 16
+// per kmer as the reference's own recurrence allows: a lane builds the first kmer of a RUN of 32
 // from the LDS window (symbol reversal, complement) and then ROLLS the forward and
 // reverse-complement kmers one symbol at a time -- shift_encoding / shift_first_encoding, exactly
-// the step of CanonicalKmers.jl:131-144 -- taking the entering symbols from the same 128 stream
-// bits it already holds.  The next tile's source words travel from HBM while the current tile
+// the step of CanonicalKmers.jl:131-144 -- taking the 31 entering symbols from the same stream bits
+// it already holds (K + 31 <= 64 N + 31 symbols: the N + 1 window words).  The next tile's source words travel from HBM while the current tile
 // is consumed (register prefetch).
 #pragma once
 #include "stream_kernel.hpp"
@@ -16,12 +16,14 @@
 namespace kmers {
 
 constexpr int RBLOCK = 256;
-constexpr int RRUN = 16;                   // consecutive kmers per lane
+constexpr int RRUN = 32;                   // consecutive kmers per lane (16 until late in round 2: the window cut is 45 instructions a run)
 constexpr int RTILE = RBLOCK * RRUN;       // kmers per tile
 enum RunMode { RMODE_XOR = 0, RMODE_SKETCH = 1 };
 
-template <int SRC_BITS, int RMODE, int N = 1>
+// CANON: canonical kmers (always for the sketch); false = the forward kmers (kmers_reduce_xor with canonical = 0)
+template <int SRC_BITS, int RMODE, int N = 1, bool CANON = true>
 __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
+    static_assert(RMODE != RMODE_SKETCH || CANON, "the sketch is over canonical kmers");
     __shared__ uint64_t lds[RTILE * 2 / 64 + 16];  // + K - 1 <= 63 symbols of overlap + 32 of misalignment + the (N+1)-th window word
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     const uint32_t tid = threadIdx.x;
@@ -43,7 +45,6 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
             for (uint32_t i = tid; i < nb; i += RBLOCK) sbest[i] = a.best[i];  // visible after the tile loop's first barrier
         }
     }
-    const bool canonical = RMODE == RMODE_SKETCH || a.xor_canonical != 0;
     uint64_t xacc = 0;
 
     struct Geo { uint64_t w0; uint32_t b0, nw, mt; };
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
     };
     // one kmer (N words, head first) and its reverse complement -> the consumer
     auto consume = [&](const uint64_t (&fw)[N], const uint64_t (&rc)[N]) {
-        const bool lt = !canonical || kmer_less<N>(fw, rc);  // fw < rv ? fw : rv, CanonicalKmers.jl:220-225
+        const bool lt = !CANON || kmer_less<N>(fw, rc);  // fw < rv ? fw : rv, CanonicalKmers.jl:220-225
         uint64_t c[N];
 #pragma unroll
         for (int w = 0; w < N; ++w) c[w] = lt ? fw[w] : rc[w];
@@ -170,13 +171,13 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
 #pragma unroll
                 for (int i = 1; i < N; ++i) fw[i] = (R[i] >> sh) | ((R[i - 1] << 1) << (63u - sh));
             }
-            // the 15 symbols that enter afterwards: stream symbols K, K+1, ... of the run
+            // the 31 symbols that enter afterwards: stream symbols K, K+1, ... of the run
             const uint32_t kb = 2u * k - 64u * (N - 1);  // bit offset of symbol K inside W[N-1] : W[N] (1..64)
-            const uint32_t S = (uint32_t)(kb == 64u ? W[N] : funnel64(W[N - 1], W[N], kb));
+            const uint64_t S = kb == 64u ? W[N] : funnel64(W[N - 1], W[N], kb);
             const uint32_t top = 2u * (k - 1u) - 64u * (N - 1);  // bit of the first symbol inside the head word
             consume(fw, rc);
             auto roll = [&](uint32_t j) {
-                const uint64_t sym = (S >> (2u * (j - 1u))) & 3u;
+                const uint64_t sym = (uint32_t)(S >> (2u * (j - 1u))) & 3u;
                 // shift_encoding (construction_utils.jl:129-134) / shift_first_encoding of the complement (kmer.jl:511-518)
 #pragma unroll
                 for (int w = 0; w < N - 1; ++w) fw[w] = (fw[w] << 2) | (fw[w + 1] >> 62);
