@@ -37,12 +37,16 @@ __device__ __forceinline__ uint32_t pack_4to2(uint64_t x, uint64_t &bad) {
     uint64_t x1 = x >> 1, x2 = x >> 2, x3 = x >> 3;
     uint64_t pop = (x & M1) + (x1 & M1) + (x2 & M1) + (x3 & M1);
     bad = pop ^ M1;
-    uint64_t c = ((x1 | x3) & M1) | (((x2 | x3) & M1) << 1);  // 2-bit code in the low bits of each nibble
-    c = (c | (c >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-    c = (c | (c >> 4)) & 0x00FF00FF00FF00FFull;
-    c = (c | (c >> 8)) & 0x0000FFFF0000FFFFull;
-    c = (c | (c >> 16));
-    return (uint32_t)c;
+    const uint64_t c = ((x1 | x3) & M1) | (((x2 | x3) & M1) << 1);  // 2-bit code in the low bits of each nibble
+    // 16 nibbles -> 16 2-bit fields, on the 32-bit halves: pairs of nibbles into the low nibble of every byte, pairs of
+    // bytes into bytes 0 and 2, and one byte permute gathers the four bytes of the two halves (11 instructions; the
+    // 64-bit shift-or-mask ladder was twice that, and these paths are bound by their instruction count)
+    uint32_t lo = (uint32_t)c, hi = (uint32_t)(c >> 32);
+    lo = (lo | (lo >> 2)) & 0x0F0F0F0Fu;
+    hi = (hi | (hi >> 2)) & 0x0F0F0F0Fu;
+    lo |= lo >> 4;
+    hi |= hi >> 4;
+    return __builtin_amdgcn_perm(hi, lo, 0x06040200u);  // bytes: lo.0, lo.2, hi.0, hi.2
 }
 
 // one bit per symbol (bit j set = symbol j of the word is ambiguous) from pack_4to2's `bad`
