@@ -1348,16 +1348,17 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     if (total == 0) return KMERS_OK;
     // tile = 1..8 passes of 1024 elements: long tiles amortise the two rounds of loads every tile starts with
     // (each about 5 us under the store load), short ones keep a small batch spread over the device
-    uint64_t passes = total / ((uint64_t)RG_PASS * (uint64_t)ctx->n_cus * 32u);
+    uint64_t passes = total / ((uint64_t)RG_UNIT * (uint64_t)ctx->n_cus * 32u);
     passes = std::min<uint64_t>(std::max<uint64_t>(passes, 1), (uint64_t)RG_MAX_PASSES);
     // ... but not longer than the record slots staged in LDS allow (very short reads: many records per pass)
-    const uint64_t per_pass = (n * (uint64_t)RG_PASS + total - 1) / total;  // records per pass, on average
+    const uint64_t per_pass = (n * (uint64_t)RG_UNIT + total - 1) / total;  // records per 1024 elements, on average
     passes = std::min<uint64_t>(passes, std::max<uint64_t>(1, (uint64_t)(RG_SLOTS * 7 / 8) / std::max<uint64_t>(per_pass, 1)));
     // ... nor than the stretch of the stream a tile can stage (records lying far apart in the pool: a FASTQ buffer)
-    const uint64_t words_per_pass = (uint64_t)(1.1 * (double)pool->n_bases / (double)total * RG_PASS * dst_bits / 64.0) + 1;
+    const uint64_t words_per_pass = (uint64_t)(1.1 * (double)pool->n_bases / (double)total * RG_UNIT * dst_bits / 64.0) + 1;
     passes = std::min<uint64_t>(passes, std::max<uint64_t>(1, (uint64_t)(RG_STAGE * 7 / 8) / words_per_pass));
     if (ctx->batch_passes > 0) passes = std::min<uint64_t>((uint64_t)ctx->batch_passes, (uint64_t)RG_MAX_PASSES);  // tests, tuning
-    const uint32_t tile_elems = (uint32_t)(passes * RG_PASS);
+    // (the run path of the element kernel takes RG_PASS elements per workgroup pass: whole passes)
+    const uint32_t tile_elems = (uint32_t)((passes * RG_UNIT + RG_PASS - 1) / RG_PASS * RG_PASS);
     const uint64_t n_tiles = (total + tile_elems - 1) / tile_elems;
     if (int rc = ensure_stage(ctx, 6, (size_t)n_tiles * sizeof(RaggedTile))) return rc;
     RaggedTile *d_tiles = static_cast<RaggedTile *>(ctx->stage[6]);

@@ -23,8 +23,12 @@
 
 namespace kmers {
 
-constexpr int RG_RUN = 4;                // consecutive elements per lane and pass (one-word kmers)
-constexpr int RG_PASS = 256 * RG_RUN;    // elements per workgroup and pass; a tile is 1..RG_MAX_PASSES passes (chosen per call)
+#ifndef KMERS_RG_RUN
+#define KMERS_RG_RUN 4
+#endif
+constexpr int RG_RUN = KMERS_RG_RUN;     // consecutive elements per lane and pass (one-word kmers: 32 contiguous bytes per lane and array; 64 write at 60 % of that rate, profiles/r01_tuning.md)
+constexpr int RG_UNIT = 1024;            // tile lengths are given in units of this many elements (KMERS_PARAM_BATCH_PASSES)
+constexpr int RG_PASS = 256 * RG_RUN;    // elements per workgroup and pass of the run path; a tile is a multiple of it, 1..RG_MAX_PASSES units
 constexpr int RG_MAX_PASSES = 8;
 constexpr int RG_SLOTS = 448;            // records of a tile staged in LDS (more: the global-search path)
 constexpr int RG_STAGE = 1024;           // stream words of a tile staged in LDS (records in pool order: the usual case)
@@ -411,75 +415,105 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
             for (uint32_t e = RUN * tid; e < a.tile; e += (uint32_t)RG_PASS) {
                 const uint64_t g = e0 + e;
                 if (g > e_last) break;
-                uint64_t X[RUN] = {0, 0, 0, 0}, Y[RUN] = {0, 0, 0, 0};
+                uint64_t X[RUN] = {}, Y[RUN] = {};
                 const uint32_t cnt = e_last - g + 1 < (uint64_t)RUN ? (uint32_t)(e_last - g + 1) : RUN;
                 r = slot_of(g, r);
                 uint64_t fw[1], rc[1], x[1], y[1];
-                if (g + cnt - 1u < off_l[r + 1u]) {               // the whole run lies in record slot r
-                    const uint64_t p = delta_l[r] + g;
-                    const uint32_t span = k + cnt - 1u;            // symbols the run reads
-                    uint64_t fbits = 0;                            // flagged symbols of the run (skip mode)
-                    const uint64_t bit = p * (uint64_t)DST;
-                    const uint64_t q = bit >> 6;
-                    const uint32_t sh = (uint32_t)(bit & 63u);
-                    const uint32_t need = (sh + (uint32_t)DST * span + 63u) >> 6;  // 1..3 stream words
-                    const uint64_t rel = q - d.q_lo;                               // (wraps for a window before the stretch)
-                    const bool staged = rel < (uint64_t)d.n_words && rel + need <= (uint64_t)d.n_words;
-                    if (flags) {
-                        const uint64_t fq = p >> 6;
-                        const uint32_t fs = (uint32_t)(p & 63u);
-                        uint64_t f0, f1 = 0;
+                // The run lies in record slot r (sub-run A, lenA elements) and, when it crosses a boundary, goes on in the next
+                // record that owns something (sub-run B).  Each sub-run is ONE window cut and rolling steps.  A wavefront of 64
+                // runs over 95-kmer reads almost always has a lane that crosses (1 - 0.968^64 = 87 %): sending that lane through
+                // the element-by-element path made every wavefront pay for it (120 instructions per element, measured; this
+                // kernel is bound by them).  Only a run that touches three records (records shorter than RUN kmers) still does.
+                const uint64_t offA = off_l[r + 1u];
+                const uint32_t lenA = offA - g < (uint64_t)cnt ? (uint32_t)(offA - g) : cnt;
+                const bool two = lenA < cnt;
+                uint32_t rB = r + 1u;
+                bool three = false;
+                if (two) {
+                    while (off_l[rB + 1u] <= g + lenA) ++rB;       // (records that own nothing are stepped over)
+                    three = g + cnt - 1u >= off_l[rB + 1u];
+                }
+                if (!three) {
+                    // window cut of the sub-run of `len` elements that starts at element gg of record slot rr
+                    auto cut = [&](uint64_t gg, uint32_t rr, uint32_t len, uint64_t &f_out, uint64_t &r_out, uint32_t &s_out, uint64_t &fb_out) {
+                        const uint64_t p = delta_l[rr] + gg;
+                        const uint32_t span = k + len - 1u;        // symbols the sub-run reads
+                        fb_out = 0;                                // flagged symbols of the sub-run (skip mode)
+                        const uint64_t bit = p * (uint64_t)DST;
+                        const uint64_t q = bit >> 6;
+                        const uint32_t sh = (uint32_t)(bit & 63u);
+                        const uint32_t need = (sh + (uint32_t)DST * span + 63u) >> 6;  // 1..3 stream words
+                        const uint64_t rel = q - d.q_lo;                               // (wraps for a window before the stretch)
+                        const bool staged = rel < (uint64_t)d.n_words && rel + need <= (uint64_t)d.n_words;
+                        if (flags) {
+                            const uint64_t fq = p >> 6;
+                            const uint32_t fs = (uint32_t)(p & 63u);
+                            uint64_t f0, f1 = 0;
+                            if (staged) {
+                                const uint32_t fr = (uint32_t)(fq - d.f_lo);
+                                f0 = flg_l[fr];
+                                if (fs + span > 64u) f1 = flg_l[fr + 1u];
+                            } else {
+                                f0 = flags[fq];
+                                if (fs + span > 64u) f1 = flags[fq + 1];
+                            }
+                            uint64_t f = (f0 >> fs) | ((f1 << 1) << (63u - fs));
+                            f &= (1ull << span) - 1ull;               // span <= 32 + RUN - 1
+                            if (f && !a.skip) {                        // the first element whose window holds a flagged symbol
+                                const uint32_t first = (uint32_t)__builtin_ctzll(f);
+                                atomicMin(a.err_slot, (unsigned long long)(gg + (first >= k ? first - k + 1u : 0u)));
+                            }
+                            if (a.skip) fb_out = f;
+                        }
+                        uint64_t l0, l1 = 0, l2 = 0;
                         if (staged) {
-                            const uint32_t fr = (uint32_t)(fq - d.f_lo);
-                            f0 = flg_l[fr];
-                            if (fs + span > 64u) f1 = flg_l[fr + 1u];
+                            l0 = src_l[(uint32_t)rel];
+                            if (need > 1u) l1 = src_l[(uint32_t)rel + 1u];
+                            if (need > 2u) l2 = src_l[(uint32_t)rel + 2u];
                         } else {
-                            f0 = flags[fq];
-                            if (fs + span > 64u) f1 = flags[fq + 1];
+                            l0 = a.stream[q];
+                            if (need > 1u) l1 = a.stream[q + 1];
+                            if (need > 2u) l2 = a.stream[q + 2];
                         }
-                        uint64_t f = (f0 >> fs) | ((f1 << 1) << (63u - fs));
-                        f &= (1ull << span) - 1ull;               // span <= 32 + 3
-                        if (f && !a.skip) {                        // the first element whose window holds a flagged symbol
-                            const uint32_t first = (uint32_t)__builtin_ctzll(f);
-                            atomicMin(a.err_slot, (unsigned long long)(g + (first >= k ? first - k + 1u : 0u)));
-                        }
-                        if (a.skip) fbits = f;
-                    }
-                    uint64_t l0, l1 = 0, l2 = 0;
-                    if (staged) {
-                        l0 = src_l[(uint32_t)rel];
-                        if (need > 1u) l1 = src_l[(uint32_t)rel + 1u];
-                        if (need > 2u) l2 = src_l[(uint32_t)rel + 2u];
-                    } else {
-                        l0 = a.stream[q];
-                        if (need > 1u) l1 = a.stream[q + 1];
-                        if (need > 2u) l2 = a.stream[q + 2];
-                    }
-                    const uint64_t W0 = funnel64(l0, l1, sh), W1 = funnel64(l1, l2, sh);
-                    fw[0] = rev_symbols<DST>(W0 & mask) >> (64u - (uint32_t)DST * k);
-                    rc[0] = comp_symbols<DST>(W0 & mask);
-                    if constexpr (DST == 2) rc[0] &= mask;
-                    // symbols K, K+1, K+2 of the run
-                    const uint32_t S = (uint32_t)((uint32_t)DST * k == 64u ? W1 : funnel64(W0, W1, (uint32_t)DST * k));
+                        const uint64_t W0 = funnel64(l0, l1, sh), W1 = funnel64(l1, l2, sh);
+                        f_out = rev_symbols<DST>(W0 & mask) >> (64u - (uint32_t)DST * k);
+                        r_out = comp_symbols<DST>(W0 & mask);
+                        if constexpr (DST == 2) r_out &= mask;
+                        // symbols K, K+1, ... of the sub-run
+                        s_out = (uint32_t)((uint32_t)DST * k == 64u ? W1 : funnel64(W0, W1, (uint32_t)DST * k));
+                    };
+                    uint64_t fwB = 0, rcB = 0, fbits, fbB = 0;
+                    uint32_t S, SB = 0;
+                    cut(g, r, lenA, fw[0], rc[0], S, fbits);
+                    if (two) cut(g + lenA, rB, cnt - lenA, fwB, rcB, SB, fbB);
+                    uint32_t base = 0;                             // run index of the current sub-run's first element
                     finish(fw, rc, x, y);
                     X[0] = (fbits & kbits) ? ~0ull : x[0];
                     Y[0] = (fbits & kbits) ? ~0ull : y[0];
 #pragma unroll
                     for (uint32_t j = 1; j < RUN; ++j) {
                         if (j < cnt) {
-                            const uint64_t sym = (S >> ((uint32_t)DST * (j - 1u))) & ((1u << DST) - 1u);
-                            uint64_t csym;
-                            if constexpr (DST == 2) csym = sym ^ 3u;
-                            else csym = ((sym & 1u) << 3) | ((sym & 2u) << 1) | ((sym & 4u) >> 1) | ((sym & 8u) >> 3);
-                            fw[0] = ((fw[0] << DST) | sym) & mask;
-                            rc[0] = (rc[0] >> DST) | (csym << top);
+                            if (two && j == lenA) {                // the next record's first element: its own cut
+                                fw[0] = fwB;
+                                rc[0] = rcB;
+                                S = SB;
+                                fbits = fbB;
+                                base = lenA;
+                            } else {
+                                const uint64_t sym = (S >> ((uint32_t)DST * (j - base - 1u))) & ((1u << DST) - 1u);
+                                uint64_t csym;
+                                if constexpr (DST == 2) csym = sym ^ 3u;
+                                else csym = ((sym & 1u) << 3) | ((sym & 2u) << 1) | ((sym & 4u) >> 1) | ((sym & 8u) >> 3);
+                                fw[0] = ((fw[0] << DST) | sym) & mask;
+                                rc[0] = (rc[0] >> DST) | (csym << top);
+                            }
                             finish(fw, rc, x, y);
-                            const bool masked = ((fbits >> j) & kbits) != 0;
+                            const bool masked = ((fbits >> (j - base)) & kbits) != 0;
                             X[j] = masked ? ~0ull : x[0];
                             Y[j] = masked ? ~0ull : y[0];
                         }
                     }
-                } else {                                           // the run crosses into the next record(s)
+                } else {                                           // the run touches three or more records
                     uint32_t rj = r;
 #pragma unroll
                     for (uint32_t j = 0; j < RUN; ++j) {
@@ -494,12 +528,12 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
                 }
                 if (g + RUN - 1 <= e_last) {
                     if (a.out_a) {
-                        *reinterpret_cast<ulonglong2 *>(a.out_a + g) = make_ulonglong2(X[0], X[1]);
-                        *reinterpret_cast<ulonglong2 *>(a.out_a + g + 2) = make_ulonglong2(X[2], X[3]);
+#pragma unroll
+                        for (uint32_t j = 0; j < RUN; j += 2) *reinterpret_cast<ulonglong2 *>(a.out_a + g + j) = make_ulonglong2(X[j], X[j + 1]);
                     }
                     if (a.out_b) {
-                        *reinterpret_cast<ulonglong2 *>(a.out_b + g) = make_ulonglong2(Y[0], Y[1]);
-                        *reinterpret_cast<ulonglong2 *>(a.out_b + g + 2) = make_ulonglong2(Y[2], Y[3]);
+#pragma unroll
+                        for (uint32_t j = 0; j < RUN; j += 2) *reinterpret_cast<ulonglong2 *>(a.out_b + g + j) = make_ulonglong2(Y[j], Y[j + 1]);
                     }
                 } else {
                     for (uint32_t j = 0; j < RUN && g + j <= e_last; ++j) {
