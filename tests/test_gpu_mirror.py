@@ -163,6 +163,9 @@ def test_string_sources(km, kats):
         km.collect(km.FwDNAMers[3]("TAGTCGTAGPATGC"))
     with pytest.raises(km.EncodeError, match=re.escape("cannot encode 0x4e (Char 'N') in DNAAlphabet{2}")):
         km.collect(km.FwRvDNAIterator[3]("AGNGT"))                       # CanonicalKmers.jl:20-22
+    with pytest.raises(km.EncodeError, match=re.escape("cannot encode 0x55 (Char 'U') in DNAAlphabet{2}")):
+        km.collect(km.FwDNAMers[3]("UGU"))                               # docs/src/iteration.md:23-25: text is not converted between DNA and RNA
+    assert km.collect(km.FwRNAMers[3]("UGU"))[0] == km.mer("UGU", "r")
     for text in kats["G14_property_seqs"]["canonical"]:
         got = km.collect(km.CanonicalDNAMers[5](text))
         assert [k.data for k in got] == naive.canonical(text, 5, 2)
