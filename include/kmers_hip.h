@@ -156,7 +156,11 @@ int kmers_spaced(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int ds
  * (SizeUnknown, :33): capacity = elements the buffers can hold; res->n_out = count.
  * stride > 1 keeps only windows whose 0-based start is a multiple of stride (the
  * "Spaced with ambiguous-base skip" composition of BASELINE.json config 5,
- * docs/src/faq.md:28-33); stride = 1 is the reference iterator. */
+ * docs/src/faq.md:28-33); stride = 1 is the reference iterator.  Sources: 2-bit and
+ * 4-bit sequences (in a 4-bit sequence the gap is skipped like an ambiguity code,
+ * :134-148), text (ASCII_SKIPPING_LUT: ambiguity letters are skipped, any other byte
+ * is E_ENCODE, :109-132) and collections of symbols (KMERS_ALPHABET_SYMBOLS, the
+ * generic method :88-106: ambiguous symbols are skipped, the gap is E_ENCODE). */
 int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride,
                       uint64_t *out_kmers, int64_t *out_starts, uint64_t capacity, int flags,
                       kmers_result *res);

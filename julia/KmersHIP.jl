@@ -164,9 +164,9 @@ end
 
 "collect(UnambiguousKmers{A,K}(seq)): (kmer, start) tuples (UnambiguousKmers.jl:59-148)"
 function Base.collect(it::UnambiguousKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: Source}
-    # geometries this entry point does not take keep Kmers.jl's own path (K above 30720; a Vector{DNA} source has no
-    # UnambiguousKmers method in the reference either and fails there exactly as it always did)
-    (K > 30720 || it.it.seq isa SymbolVector) && return invoke(collect, Tuple{Any}, it)
+    # a geometry this entry point does not take keeps Kmers.jl's own path (K above 30720).  A Vector{DNA} source is the
+    # reference's generic method (UnambiguousKmers.jl:88-106): ambiguous symbols skipped, the gap an EncodeError.
+    K > 30720 && return invoke(collect, Tuple{Any}, it)
     ctx, s = context(), it.it.seq
     T = Kmers.derive_type(Kmer{A, K})
     res = CResult()

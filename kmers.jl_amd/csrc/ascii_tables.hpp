@@ -55,8 +55,16 @@ inline void build_ascii_skipping_table(uint8_t *t) {
 #endif
 constexpr int ASCII_TABLE_SKIPPING = 4;
 constexpr int SYMBOL_TABLE_2BIT = 5, SYMBOL_TABLE_4BIT = 6;
+// UnambiguousKmers over a collection of symbols (the generic method, UnambiguousKmers.jl:88-106): an ambiguous symbol
+// (count_ones > 1) is skipped (0xf0), a certain one shifted in, and the gap fails in `shift` -> encode (0xff: EncodeError)
+constexpr int SYMBOL_TABLE_SKIPPING = 7;
 KMERS_HD inline uint8_t ascii_entry(uint32_t table, uint32_t c) {
     if (table >= (uint32_t)SYMBOL_TABLE_2BIT) {  // symbol values, not letters
+        if (table == (uint32_t)SYMBOL_TABLE_SKIPPING) {
+            if (c == 0u || c > 15u) return 0xff;
+            if (c & (c - 1u)) return 0xf0;
+            return (uint8_t)(c == 1u ? 0u : c == 2u ? 1u : c == 4u ? 2u : 3u);
+        }
         if (c > 15u) return 0x80;
         if (table == (uint32_t)SYMBOL_TABLE_4BIT) return (uint8_t)c;
         if (c == 0 || (c & (c - 1u))) return 0x80;  // gap or ambiguous: EncodeError (count_ones != 1)

@@ -451,7 +451,8 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.first_bit = st.first_bit;
     a.n_cand = n;
     a.n_bases = seq->n_bases;
-    a.ascii_table = (uint32_t)ASCII_TABLE_SKIPPING;
+    // text: the reference's ASCII_SKIPPING_LUT; a collection of symbols: its generic method (UnambiguousKmers.jl:88-106)
+    a.ascii_table = seq->alphabet == KMERS_ALPHABET_SYMBOLS ? (uint32_t)SYMBOL_TABLE_SKIPPING : (uint32_t)ASCII_TABLE_SKIPPING;
     a.err_slot = ctx->d_err;
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
@@ -855,7 +856,8 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
     a.first_bit = st.first_bit;
     a.n_cand = n;
     a.n_bases = seq->n_bases;
-    a.ascii_table = (uint32_t)ASCII_TABLE_SKIPPING;
+    // text: the reference's ASCII_SKIPPING_LUT; a collection of symbols: its generic method (UnambiguousKmers.jl:88-106)
+    a.ascii_table = seq->alphabet == KMERS_ALPHABET_SYMBOLS ? (uint32_t)SYMBOL_TABLE_SKIPPING : (uint32_t)ASCII_TABLE_SKIPPING;
     a.err_slot = ctx->d_err;
     a.k = (uint32_t)kk;
     a.stride = (uint32_t)stride;
@@ -1610,8 +1612,6 @@ int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, u
     }
     if (flags & KMERS_ASYNC) return fail(ctx, KMERS_E_BADARG, "kmers_unambiguous is synchronous (data-dependent count)");
     if (k > UNAMB_MAX_K) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_unambiguous: K above 30720");
-    if (seq->src_bits == 8 && seq->alphabet == KMERS_ALPHABET_SYMBOLS)  // the reference has no such method (UnambiguousKmers.jl:64-132)
-        return fail(ctx, KMERS_E_UNSUPPORTED, "UnambiguousKmers takes 2-bit / 4-bit sequences and text, not collections of symbols");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return run_unambiguous(ctx, seq, k, stride, out_kmers, out_starts, capacity, flags, res);
 }

@@ -485,7 +485,8 @@ INL int fwrv_impl(const uint64_t *seq, uint64_t len, const int src_bps, const in
 }
 
 /* UnambiguousKmers: src/iterators/UnambiguousKmers.jl:64-77 (Copyable -> FwKmers with
- * index i-K+1), :79-86 (initial state), :134-148 (FourToTwo loop). dst is TwoBit. */
+ * index i-K+1), :79-86 (initial state), :88-106 (any other scheme: symbol by symbol), :109-132 (text),
+ * :134-148 (FourToTwo loop). dst is TwoBit. */
 INL int unambiguous_impl(const uint64_t *seq, uint64_t len, const int src_bps, const int N,
                          const int K, uint64_t *out_kmers, int64_t *out_starts, orc_result *res) {
     uint64_t kmer[ORC_MAX_N];
@@ -509,6 +510,28 @@ INL int unambiguous_impl(const uint64_t *seq, uint64_t len, const int src_bps, c
     for (int w = 0; w < N; ++w) kmer[w] = 0;
     int64_t remaining = K;
     uint64_t index = 1;
+    if (src_bps == ORC_SRC_SYMBOLS) { /* :88-106, the method of every other RecodingScheme (GenericRecoding: one symbol per byte) */
+        for (;;) {
+            while (remaining != 0) {
+                if (index > len) return 0;
+                uint8_t symbol = ((const uint8_t *)seq)[index - 1]; /* convert(eltype(kmer), seq[index]): DNA <-> RNA keeps the value */
+                index += 1;
+                if (symbol < 16 && count_ones64(symbol) > 1) { /* isambiguous(symbol) */
+                    remaining = K;
+                } else {
+                    /* shift(kmer, symbol) encodes the symbol in the 2-bit alphabet: the gap (and a byte that is no symbol) throws */
+                    if (symbol == 0 || symbol > 15) return throw_uncertain(res, index - 1, symbol);
+                    remaining -= 1;
+                    shift_encoding(kmer, N, K, 2, (uint64_t)trailing_zeros64(symbol));
+                }
+            }
+            if (out_kmers)
+                for (int w = 0; w < N; ++w) out_kmers[res->n_out * N + w] = kmer[w];
+            if (out_starts) out_starts[res->n_out] = (int64_t)index - K;
+            res->n_out++;
+            remaining = 1;
+        }
+    }
     if (IS_ASCII(src_bps)) { /* :109-132 with ASCII_SKIPPING_LUT */
         for (;;) {
             while (remaining != 0) {
@@ -674,10 +697,6 @@ uint64_t orc_reduce_xor_canonical(const uint64_t *seq, uint64_t len, int src_bps
 int orc_unambiguous(const uint64_t *seq, uint64_t len, int src_bps, int K,
                     uint64_t *out_kmers, int64_t *out_starts, orc_result *res) {
     if (check_args(src_bps, 2, K, res)) return ORC_E_BADARG;
-    if (src_bps == ORC_SRC_SYMBOLS) { /* UnambiguousKmers has no GenericRecoding method (UnambiguousKmers.jl:64-132) */
-        res->status = ORC_E_BADARG;
-        return ORC_E_BADARG;
-    }
     int N = n_coding_elements(K, 2);
     if (src_bps == 4 && N == 1) return unambiguous_impl(seq, len, 4, 1, K, out_kmers, out_starts, res);
     return unambiguous_impl(seq, len, src_bps, N, K, out_kmers, out_starts, res);

@@ -100,10 +100,7 @@ def test_fuzz_iterators(km, ctx, orc, seed):
             assert same_error(rc, res, eres), tag + (J,)
             if rc == 0:
                 assert res.n_out == m and np.array_equal(out[:m], ek), tag + (J,)
-        else:  # unambiguous (2-bit kmers of any width; no method for symbol vectors), with a stride lattice now and then
-            if src == 10:
-                assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), 3, 1, None, None, 0, 0, C.byref(res)) == cap.E_UNSUPPORTED
-                continue
+        else:  # unambiguous (2-bit kmers of any width, every kind of source), with a stride lattice now and then
             K2 = min(K, 256)
             N2 = (2 * K2 + 63) // 64
             J = int(rng.choice([1, 1, 1, 2, 3, 11, 64, 1000]))

@@ -202,8 +202,15 @@ def test_symbol_vector_sources(km):
         for x in km.FwDNAMers[3](amb):      # TAG is yielded, then AGW throws
             got.append(str(x))
     assert got == ["TAG"]
-    with pytest.raises(km.UnsupportedError):    # no such method in the reference (UnambiguousKmers.jl:64-132)
-        km.collect(km.UnambiguousDNAMers[3](v))
+    # UnambiguousKmers over such a source is the reference's generic method (UnambiguousKmers.jl:88-106, runtests.jl:834-840:
+    # LongSequence{GenericNucAlphabet}(dna"TGATCGTAGATGwATGTC")): the elements of the four-bit sequence of the same symbols ...
+    for t in (text, "TGATCGTAGATGWATGTC", "TAGCTKAGAGGAGAACWSGCGAGA"):
+        for K in (4, 7):
+            assert km.collect(km.UnambiguousDNAMers[K](km.SymbolVector("DNA", t))) == km.collect(km.UnambiguousDNAMers[K](km.LongDNA[4](t)))
+    # ... except for the gap: a four-bit sequence skips it, `shift` of a symbol cannot encode it
+    assert [i for _, i in km.collect(km.UnambiguousDNAMers[3](km.LongDNA[4]("TAGWC-GAT")))] == [1, 7]
+    with pytest.raises(km.EncodeError, match=re.escape("cannot encode - in DNAAlphabet{2}")):
+        km.collect(km.UnambiguousDNAMers[3](km.SymbolVector("DNA", "TAGWC-GAT")))
 
 
 def test_fx_hash_known_answers(km, kats):

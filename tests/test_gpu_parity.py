@@ -427,9 +427,29 @@ def test_symbol_vector_sources(km, ctx, orc):
                         assert (rc, res.err_pos, res.err_enc) == (eres.status, eres.err_pos, eres.err_enc), (dst, K, L, J)
                         if rc == 0:
                             assert np.array_equal(out, es)
-    seq = cap.Seq(naive.ascii_words(bytes([1, 2, 4, 8])).ctypes.data, 4, 0, 0, 8, 2)
+    # UnambiguousKmers over a collection of symbols: the reference's generic method (UnambiguousKmers.jl:88-106; its test
+    # runtests.jl:834-840).  Ambiguous symbols are skipped; the gap is an EncodeError (a four-bit sequence skips it).
+    enc4 = {c: i for i, c in enumerate("-ACMGRSVTWYHKDBN")}
+    for L in (1, 30, 1000, 70_001):
+        for p_amb, gaps in ((0.0, 0), (0.03, 0), (0.03, 2)):
+            text = list(naive.random_text(rng, L, p_amb=p_amb).replace("-", "N"))
+            for pos in rng.integers(0, L, gaps):
+                text[int(pos)] = "-"
+            words = naive.ascii_words(bytes(enc4[c] for c in text))
+            seq = cap.Seq(words.ctypes.data, L, 0, 0, 8, 2)
+            for K, J in ((1, 1), (4, 1), (31, 1), (33, 1), (140, 1), (21, 3)):
+                res = cap.Result()
+                ek, es, eres = orc.unambiguous(words, L, 10, K)
+                rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, J, None, None, 0, cap.MEM_HOST, C.byref(res))
+                assert (rc, res.err_pos, res.err_enc) == (eres.status, eres.err_pos, eres.err_enc), (L, K, J, gaps)
+                if rc == 0:
+                    keep = (es - 1) % J == 0
+                    m = int(keep.sum())
+                    assert res.n_out == m
+                    kmers, starts = np.zeros((max(m, 1), (2 * K + 63) // 64), np.uint64), np.zeros(max(m, 1), np.int64)
+                    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, J, vp(kmers), vp(starts), m, cap.MEM_HOST, C.byref(res)) == 0
+                    assert np.array_equal(kmers[:m], ek[keep]) and np.array_equal(starts[:m], es[keep]), (L, K, J)
     res = cap.Result()
-    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), 2, 1, None, None, 0, 0, C.byref(res)) == cap.E_UNSUPPORTED
     seq = cap.Seq(naive.ascii_words(b"ACGT").ctypes.data, 4, 0, 0, 8, 3)
     assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 2, 2, None, None, 0, C.byref(res)) == cap.E_BADARG
 

@@ -3,6 +3,9 @@ BioSequence nor text, e.g. Vector{DNA}; FwKmers.jl:80-86, CanonicalKmers.jl:81-9
 :161-172): one BioSymbols value per byte.  The reference's own tests hold such sources equal to the BioSequence of the same
 symbols (test/runtests.jl:674-690 iterate `collect(seq)`-like generic sources), which is the differential used here: a
 symbol vector must give exactly what the LongSequence{DNAAlphabet{4}} of the same symbols gives -- kmers and EncodeErrors."""
+import json
+import os
+
 import numpy as np
 
 import naive
@@ -59,6 +62,30 @@ def test_known_cases(orc):
     # a byte that is no nucleotide value at all
     _, res = orc.fw_kmers(naive.ascii_words(bytes([1, 2, 0x41, 4])), 4, SYMBOLS, 4, 2)
     assert (res.status, res.err_pos, res.err_enc) == (1, 3, 0x41)
-    # UnambiguousKmers has no method for such sources (UnambiguousKmers.jl:64-132)
-    _, _, res = orc.unambiguous(symbol_words("ACGT"), 4, SYMBOLS, 2)
-    assert res.status == 2
+
+
+def test_unambiguous_over_symbols_is_the_generic_method(orc):
+    """UnambiguousKmers over a collection of symbols takes the method of `::RecodingScheme` (UnambiguousKmers.jl:88-106): an
+    ambiguous symbol is skipped, a certain one shifted in -- the elements of the four-bit sequence of the same symbols, as the
+    reference's own test compares them (test/runtests.jl:826-840: LongSequence{GenericNucAlphabet} against the naive filter)
+    -- and the gap, which is neither, fails in `shift`'s encode where the four-bit method skips it."""
+    rng = np.random.default_rng(17)
+    kats = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kats.json")))
+    texts = [t.replace("-", "N") for t in kats["G14_property_seqs"]["unambiguous"]] + ["TGATCGTAGATGWATGTC"]  # (runtests.jl:836)
+    texts += ["".join(rng.choice(list("ACGTACGTACGTNWSK"), int(L))) for L in (1, 5, 40, 333, 2000)]
+    for text in texts:
+        for K in (1, 3, 4, 7, 31, 33):
+            ka, sa, ra = orc.unambiguous(symbol_words(text), len(text), SYMBOLS, K)
+            kb, sb, rb = orc.unambiguous(naive.longseq_words(text, 4), len(text), 4, K)
+            assert ra.status == rb.status == 0 and np.array_equal(ka, kb) and np.array_equal(sa, sb), (text[:20], K)
+            exp = naive.unambiguous(text, K)
+            assert [tuple(int(x) for x in r) for r in ka] == [k_ for k_, _ in exp] and list(sa) == [i for _, i in exp]
+    # the gap: skipped in a four-bit sequence (count_ones != 1, :140-146), an EncodeError here -- also in a sequence shorter than K
+    k4, s4, r4 = orc.unambiguous(naive.longseq_words("ACG-TACGT", 4), 9, 4, 3)
+    assert r4.status == 0 and list(s4) == [1, 5, 6, 7]
+    _, _, res = orc.unambiguous(symbol_words("ACG-TACGT"), 9, SYMBOLS, 3)
+    assert (res.status, res.err_pos, res.err_enc) == (1, 4, 0)
+    _, _, res = orc.unambiguous(symbol_words("A-"), 2, SYMBOLS, 5)
+    assert (res.status, res.err_pos, res.err_enc) == (1, 2, 0)
+    _, _, res = orc.unambiguous(naive.ascii_words(bytes([1, 2, 0x41, 4])), 4, SYMBOLS, 2)
+    assert (res.status, res.err_pos, res.err_enc) == (1, 3, 0x41)
