@@ -449,6 +449,10 @@ def test_symbol_vector_sources(km, ctx, orc):
                     kmers, starts = np.zeros((max(m, 1), (2 * K + 63) // 64), np.uint64), np.zeros(max(m, 1), np.int64)
                     assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, J, vp(kmers), vp(starts), m, cap.MEM_HOST, C.byref(res)) == 0
                     assert np.array_equal(kmers[:m], ek[keep]) and np.array_equal(starts[:m], es[keep]), (L, K, J)
+                    if K <= 64 and J == 1:  # the fused XOR reducer over the same iterator
+                        val = C.c_uint64()
+                        assert ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), K, 2, cap.ITER_UNAMBIGUOUS, 1, C.byref(val), 0, C.byref(res)) == 0
+                        assert val.value == (int(np.bitwise_xor.reduce(ek[:, 0])) if len(ek) else 0), (L, K)
     res = cap.Result()
     seq = cap.Seq(naive.ascii_words(b"ACGT").ctypes.data, 4, 0, 0, 8, 3)
     assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 2, 2, None, None, 0, C.byref(res)) == cap.E_BADARG
