@@ -75,6 +75,60 @@ __global__ __launch_bounds__(256) void persistent_work_heavy(ulonglong2* __restr
         a[i] = make_ulonglong2(x, v ^ i); b[i] = make_ulonglong2(v * i, x - i);
     }
 }
+// The same arithmetic and the same stores with the two decoupled: wavefronts 0-2 of a workgroup compute into an LDS ring (two
+// slots each), wavefront 3 does nothing but move full slots to HBM.  A full store queue then stalls the mover only.
+template <int W>
+__global__ __launch_bounds__(256) void persistent_split(ulonglong2* __restrict__ a, ulonglong2* __restrict__ b, size_t n, unsigned long long v) {
+    __shared__ ulonglong2 ring_a[3][2][64], ring_b[3][2][64];
+    __shared__ unsigned long long ring_i[3][2];   // first element index of the slot, ~0 = stop
+    __shared__ volatile unsigned int full[3][2];
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (threadIdx.x < 6) full[threadIdx.x / 2][threadIdx.x % 2] = 0u;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * 192;
+    if (wave < 3) {
+        unsigned slot = 0;
+        for (size_t i0 = (size_t)blockIdx.x * 192 + wave * 64; ; i0 += stride) {
+            const bool last = i0 >= n;
+            const size_t i = i0 + lane;
+            unsigned long long x = v + i;
+            if (!last) {
+#pragma unroll 16
+                for (int w = 0; w < W; ++w) x = x * 0x9E3779B97F4A7C15ull + w;
+            }
+            while (full[wave][slot]) __builtin_amdgcn_s_sleep(1);
+            ring_a[wave][slot][lane] = make_ulonglong2(x, v ^ i);
+            ring_b[wave][slot][lane] = make_ulonglong2(v * i, x - i);
+            if (lane == 0) ring_i[wave][slot] = last ? ~0ull : (unsigned long long)i0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) full[wave][slot] = 1u;
+            slot ^= 1u;
+            if (last) break;
+        }
+    } else {
+        unsigned slot[3] = {0, 0, 0};
+        unsigned live = 7u;
+        while (live) {
+#pragma unroll
+            for (unsigned p = 0; p < 3; ++p) {
+                if (!(live & (1u << p))) continue;
+                if (!full[p][slot[p]]) continue;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const unsigned long long i0 = ring_i[p][slot[p]];
+                if (i0 == ~0ull) {
+                    live &= ~(1u << p);
+                } else {
+                    const size_t i = (size_t)i0 + lane;
+                    const ulonglong2 xa = ring_a[p][slot[p]][lane], xb = ring_b[p][slot[p]][lane];
+                    if (i < n) { a[i] = xa; b[i] = xb; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) full[p][slot[p]] = 0u;
+                slot[p] ^= 1u;
+            }
+        }
+    }
+}
 template <int W>
 __global__ __launch_bounds__(256) void one_pass_work(ulonglong2* __restrict__ a, ulonglong2* __restrict__ b, size_t n, unsigned long long v, int per_tile) {
     size_t base = (size_t)blockIdx.x * per_tile;
@@ -123,6 +177,8 @@ int main() {
 #define HW(W) snprintf(l, 128, "persistent, %d mul-adds per pair, NO stores, grid %d", W, grid); RUN(l, hipLaunchKernelGGL(persistent_work_only<W>, dim3(grid), dim3(256), 0, 0, a, b, n, 1ull)); \
               snprintf(l, 128, "persistent, %d mul-adds per pair + stores, grid %d", W, grid); RUN(l, hipLaunchKernelGGL(persistent_work_heavy<W>, dim3(grid), dim3(256), 0, 0, a, b, n, 1ull));
         HW(128) HW(192) HW(256) HW(384)
+#define SP(W) snprintf(l, 128, "persistent, %d mul-adds per pair, 3 compute + 1 store wavefront, grid %d", W, grid); RUN(l, hipLaunchKernelGGL(persistent_split<W>, dim3(grid), dim3(256), 0, 0, a, b, n, 1ull));
+        SP(128) SP(192) SP(256)
     }
     RUN("one pass + 16 mul-adds per pair", hipLaunchKernelGGL(one_pass_work<16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a, b, n, 1ull, 256));
     RUN("one pass + 64 mul-adds per pair", hipLaunchKernelGGL(one_pass_work<64>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a, b, n, 1ull, 256));
