@@ -8,18 +8,29 @@ path over the rank's shard: the (K-1)-base halo exchange with the next rank (N >
 ABI's kmers_halo_exchange on RCCL) followed by the canonical+hash kernel, inputs and outputs
 resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--total-bases T]
 
 With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: before any HIP call
 it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
 ...  bench.py <same arguments>` as a child, relays rank 0's JSON line and exits with the child's
 status.  Started under torch.distributed.run (WORLD_SIZE set) it is one rank of the job.
 
-Rank 0 prints ONE JSON line.  Weak scaling: every rank owns `--bases` symbols of one long
-sequence of N * bases symbols; value = all symbols processed / max-over-ranks time.
+Rank 0 prints ONE JSON line.  Two scaling modes:
+  weak   (default)            every rank owns `--bases` symbols of one long sequence of N * bases symbols
+  strong (--total-bases T)    ONE sequence of T symbols (the north star: 10 Gbase LongDNA{4}) is split over the N ranks
+                              by kmers_shard_plan; `"scaling": "strong"`
+value = all symbols processed / max-over-ranks time either way.  A weak run on N > 1 GPUs ALSO measures the strong split of
+the north-star input (`strong_scaling` in the line: K steps of 10 Gbase over the N ranks under the same barrier and
+max-over-ranks rule, then the same 10 Gbase on rank 0 alone, and the ratio of the two) so that the contract's plain
+`--gpus N` command yields the fixed-input speedup as well.
+
+Memory: the buffers come from the product's arena (kmers_arena_reserve + kmers_dev_alloc, include/kmers_hip.h) -- what a Julia
+or C host gets from the library -- not from an allocate-and-release trick of the bench (round 2); `--alloc plain` uses torch
+allocations instead, and `roofline.plain_alloc` reports the same launch into plain allocations made BEFORE the arena.
 """
 import argparse
 import ctypes as C
+import datetime
 import glob
 import json
 import os
@@ -38,6 +49,8 @@ METRIC = "canonical k-mers/sec (Gbases/s input) + % HBM roofline, K=31 DNA{4}"
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured float4 copy
 FX_CONSTANT = 0x517CC1B727220A95
 GOLDEN = 0x9E3779B97F4A7C15
+NORTH_STAR_BASES = 10_000_000_000
+N_SIMDS = 1024  # 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its SIMD for 4 cycles
 
 
 def log(*a):
@@ -49,7 +62,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bases", type=int, default=1_000_000_000, help="symbols per GPU (weak scaling)")
+    ap.add_argument("--bases", type=int, default=1_000_000_000, help="symbols per GPU (weak scaling, the default)")
+    ap.add_argument("--total-bases", type=int, default=0, help="strong scaling: ONE sequence of this many symbols split over the --gpus ranks")
+    ap.add_argument("--strong-bases", type=int, default=-1,
+                    help="weak runs on N > 1 GPUs also time this fixed input split over the N ranks (default: the north star's 10 Gbase; 0 = skip)")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--src-bits", type=int, default=4)
     ap.add_argument("--tile", type=int, default=0)
@@ -57,11 +73,13 @@ def parse_args(argv=None):
     ap.add_argument("--no-hash", action="store_true", help="materialise canonical kmers only (8.5 / 8.25 B per kmer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra C3/C4/C5/10 Gbase rates (N = 1 only)")
-    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child runs")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic / VALU issue shares with rocprofv3 --pmc child runs")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
-    ap.add_argument("--no-defrag", action="store_true", help="skip the one large allocate-and-release before the working buffers")
+    ap.add_argument("--alloc", choices=("arena", "plain"), default="arena",
+                    help="arena: buffers from kmers_arena_reserve + kmers_dev_alloc (the product's allocator); plain: torch allocations")
+    ap.add_argument("--arena-gb", type=float, default=0.0, help="size of the arena (0 = three quarters of the free memory)")
     ap.add_argument("--wake-s", type=float, default=1.0, help="seconds of plain fills before the W warm-up steps (a fresh or idle device is slower at first)")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: the profiled child of the traffic leg
+    ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)  # internal: the profiled child ("headline" or "legs")
     return ap.parse_args(argv)
 
 
@@ -106,6 +124,41 @@ def launch_ranks(args):
 
 
 # --------------------------------------------------------------------------------------------
+# device memory: the product's arena, viewed as torch tensors for the checks
+class _RawDeviceArray:
+    def __init__(self, ptr, n_words):
+        self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i8", "data": (ptr, False), "version": 2, "strides": None}
+
+
+class Memory:
+    """Where the bench's buffers come from.  arena: ctx.alloc (kmers_dev_alloc, served by the context's arena) wrapped as
+    int64 torch tensors through __cuda_array_interface__; plain: torch.empty."""
+
+    def __init__(self, ctx, dev, use_arena):
+        self.ctx, self.dev, self.use_arena, self.live = ctx, dev, use_arena, {}
+
+    def empty(self, n_words):
+        import torch
+        n_words = max(int(n_words), 1)
+        if not self.use_arena:
+            return torch.empty(n_words, dtype=torch.int64, device=self.dev)
+        ptr = self.ctx.alloc(8 * n_words)
+        t = torch.as_tensor(_RawDeviceArray(ptr, n_words), device=self.dev)
+        assert t.data_ptr() == ptr and t.numel() == n_words
+        self.live[ptr] = t
+        return t
+
+    def free(self, *tensors):
+        """Give the blocks back to the arena (the tensors must not be used afterwards)."""
+        for t in tensors:
+            if t is None:
+                continue
+            if self.use_arena and t.data_ptr() in self.live:
+                ptr = t.data_ptr()
+                del self.live[ptr]
+                self.ctx.free(ptr)
+
+
 def xor_fold(t):
     """XOR of all elements of an int64 CUDA tensor."""
     import torch
@@ -168,8 +221,12 @@ def cpu_baseline(k, bits, seed, total_bases, budget_s=12.0, chunk_bases=1 << 24)
 
 
 def verify_canonical(ctx, cap, stream, dev, buf, n_bases, first_kmer, first_word, bits, K, N, seed, out_k, out_h, n_kmers):
-    """Integrity of what a canonical(+hash) launch wrote, over ALL elements: hashes == kmers * FX_CONSTANT (one-word kmers),
-    XOR fold of the kmers == the fused reducer over the same sequence, and the first and last 2 Mbase against the oracle.
+    """Integrity of what a canonical(+hash) launch wrote, over ALL elements.  Two kinds of check:
+      * against the ORACLE: the first and the last 2 Mbase of the shard, kmers and hashes, bit for bit (the independent part);
+      * SELF-CONSISTENCY of the HIP path over everything in between: hashes == kmers * FX_CONSTANT (one-word kmers; torch
+        arithmetic against the kernel's), and the XOR fold of the kmers == kmers_reduce_xor over the same sequence -- a
+        different kernel of the same library (run_kernel.hpp), so HIP against HIP: it catches a launch that skipped or
+        misplaced elements, not an error both kernels share.
     Chunked so that the 10 Gbase size (165 GB of output) needs no large temporaries."""
     import numpy as np
     import torch
@@ -177,9 +234,11 @@ def verify_canonical(ctx, cap, stream, dev, buf, n_bases, first_kmer, first_word
     from oracle import pyoracle
     ok = True
     res = cap.Result()
+    if n_kmers == 0:
+        return True
     with torch.cuda.stream(stream):
         CH = 1 << 28
-        col0 = out_k.view(-1, N)[:, 0]
+        col0 = out_k.view(-1, N)[:n_kmers, 0]
         cmul = torch.tensor(FX_CONSTANT, dtype=torch.int64, device=dev)
         folded = 0
         for lo in range(0, n_kmers, CH):
@@ -207,48 +266,55 @@ def verify_canonical(ctx, cap, stream, dev, buf, n_bases, first_kmer, first_word
     return ok
 
 
-def other_configs(ctx, cap, stream, dev, reps=7):
+def busy_timed(ctx, stream, fn, reps=7, busy_s=0.05):
+    """HIP events on the library's stream around one call, median of reps.  Entry points with an asynchronous form
+    (KMERS_ASYNC: kmers_canonical / kmers_fw / kmers_spaced) are timed in it, like the headline step: the events then
+    bracket the kernel alone; around a synchronous call they would also bracket the host's wake-up after its stream
+    wait and its next launch (measured: +0.25 ms on a 1.6 ms kernel, profiles/r02_tuning.md section 1).
+    The device is kept busy with the same call for 50 ms first and the reps follow back to back: after an idle gap of
+    0.2 s or more this device runs its next ~10 ms slower -- a leg of a few launches would otherwise measure that
+    transient, not the kernel."""
+    import numpy as np
+    import torch
+    fn()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < busy_s:
+        fn()
+        fn()
+        torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        fn()
+        e1.record(stream)
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    rc, _ = ctx.sync()
+    assert rc == 0, ctx.last_error()
+    return float(np.median([a.elapsed_time(b) for a, b in evs]))
+
+
+def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7):
     """Kernel rates of the other BASELINE.json configs (parity-test cases, not the headline): C3 shape
     per GPU, C4, C5 strict and skip, and the north-star size (10 Gbase LongDNA{4}).  Resident data, HIP events on
     the library's stream, median of reps.  The 10 Gbase leg comes last: 165 GB of output per launch leave the device in a
-    lower power state for a while (the 1.6 ms C3 launch measured 1.84 ms right behind it, profiles/r02_tuning.md)."""
+    lower power state for a while (the 1.6 ms C3 launch measured 1.84 ms right behind it, profiles/r02_tuning.md).
+    `valu`: per-leg VALU issue shares from the PMC child (measure_legs), merged into the entries they belong to."""
     import numpy as np
     import torch
     res = cap.Result()
     out = {}
+    valu = valu or {}
 
     def timed(fn):
-        """HIP events on the library's stream around one call, median of reps.  Entry points with an asynchronous form
-        (KMERS_ASYNC: kmers_canonical / kmers_fw / kmers_spaced) are timed in it, like the headline step: the events then
-        bracket the kernel alone; around a synchronous call they would also bracket the host's wake-up after its stream
-        wait and its next launch (measured: +0.25 ms on a 1.6 ms kernel, tools/diag_c3.py, profiles/r02_tuning.md).
-        The device is kept busy with the same call for 50 ms first and the reps follow back to back: after an idle gap of
-        0.2 s or more this device runs its next ~10 ms slower (the 1.59 ms C3 launch: 1.65, 1.87, 2.04, 1.95, 1.89, 1.79 ms
-        in a row from a rested device, 1.59-1.61 right behind load; tools/diag_cooldown.py) -- a leg of a few launches
-        would otherwise measure that transient, not the kernel."""
-        fn()
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < 0.05:
-            fn()
-            fn()
-            torch.cuda.synchronize()
-        evs = []
-        for _ in range(reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            fn()
-            e1.record(stream)
-            evs.append((e0, e1))
-        torch.cuda.synchronize()
-        rc, _ = ctx.sync()
-        assert rc == 0, ctx.last_error()
-        return float(np.median([a.elapsed_time(b) for a, b in evs]))
+        return busy_timed(ctx, stream, fn, reps)
 
     ASYNC = cap.MEM_DEVICE | cap.ASYNC
 
     def synth(seed, n_bases, bits, amb=0):
         nw = (n_bases * bits + 63) // 64
-        b = torch.empty(nw + 2, dtype=torch.int64, device=dev)
+        b = mem.empty(nw + 2)
         ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, 0, nw, bits, amb, b.data_ptr()), "kmers_synth_dna")
         return b
 
@@ -256,23 +322,36 @@ def other_configs(ctx, cap, stream, dev, reps=7):
         out[name] = {"kernel_ms": round(ms, 4), "Gbases_per_s": round(n_bases / ms / 1e6, 1),
                      "GB_per_s": round(alg_bytes / ms / 1e6, 1), "frac_of_8TBps": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBPS, 4), **extra}
 
+    def ceilings(leg, ms, alg_bytes):
+        """What bounds a leg that is not purely a store stream: its HBM floor (algorithmic bytes at the device's measured
+        two-array store rate of 6.3 TB/s), its VALU floor (instructions x 4 cycles / 1024 SIMDs at the measured clock) and
+        the fraction of the larger of the two that the measured time reaches."""
+        v = valu.get(leg)
+        if not v:
+            return {"valu_issue": "not measured (no PMC pass)"}
+        hbm_floor = alg_bytes / 6.3e12 * 1e3 if alg_bytes else 0.0
+        floor = max(hbm_floor, v["valu_floor_ms"] or 0.0)
+        return {"valu_issue_frac": v["valu_issue_frac"], "valu_insts_per_launch": v["valu_insts"], "valu_floor_ms": v["valu_floor_ms"],
+                "hbm_floor_ms_at_6.3TBps": round(hbm_floor, 4), "frac_of_max_floor": round(floor / ms, 4) if ms else None,
+                "valu_source": v["source"]}
+
     with torch.cuda.stream(stream):
         # C3: CanonicalDNAMers{31} over 10 Gbase LongDNA{2} sharded 8 ways -> 1.25 Gbase per GPU, kmers only
         L, K = 1_250_000_000, 31
         buf = synth(GOLDEN ^ 3, L, 2)
-        a = torch.empty(L, dtype=torch.int64, device=dev)
+        a = mem.empty(2 * 1_000_000_000)
+        b = mem.empty(2 * 1_000_000_000)
         seq = cap.Seq(buf.data_ptr(), L, 0, 0, 2, 0)
         ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), None, 0, ASYNC, C.byref(res)))
         entry("C3 CanonicalDNAMers{31}, 1.25 Gbase LongDNA{2} (one of 8 shards), 8.25 B/kmer", ms, L, 8.25 * (L - K + 1))
+        mem.free(buf)
         # C4: FwDNAMers{63} + reverse_complement over 1 Gbase LongDNA{4}
         L, K = 1_000_000_000, 63
         buf = synth(GOLDEN ^ 4, L, 4)
-        a = torch.empty(2 * L, dtype=torch.int64, device=dev)
-        b = torch.empty(2 * L, dtype=torch.int64, device=dev)
         seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
         ms = timed(lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), b.data_ptr(), ASYNC, C.byref(res)))
         entry("C4 FwDNAMers{63} + reverse_complement, 1 Gbase LongDNA{4}, 32.5 B/kmer", ms, L, 32.5 * (L - K + 1))
-        del b
+        mem.free(buf)
         # C5: SpacedDNAMers{21,3} over 1 Gbase LongDNA{4}: strict, and the skip variant with N at p = 0.04
         K, J = 21, 3
         n = (L - K) // J + 1
@@ -284,68 +363,88 @@ def other_configs(ctx, cap, stream, dev, reps=7):
         seqa = cap.Seq(amb.data_ptr(), L, 0, 0, 4, 0)
         ctx.check(ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seqa), K, J, None, None, 0, cap.MEM_DEVICE, C.byref(res)), "count")
         m = int(res.n_out)
-        st = torch.empty(m, dtype=torch.int64, device=dev)
-        ms = timed(lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seqa), K, J, a.data_ptr(), st.data_ptr(), m, cap.MEM_DEVICE, C.byref(res)))
+        ms = timed(lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seqa), K, J, a.data_ptr(), b.data_ptr(), m, cap.MEM_DEVICE, C.byref(res)))
         # algorithmic bytes: the source once (0.5 B/base) + (kmer, start) per kept element
-        entry(f"C5 skip variant (UnambiguousDNAMers{{21}} on the stride-3 lattice, p(N)=0.04, {m} kept), 0.5 B/base + 16 B/kept", ms, L, 0.5 * L + 16.0 * m)
+        alg = 0.5 * L + 16.0 * m
+        entry(f"C5 skip variant (UnambiguousDNAMers{{21}} on the stride-3 lattice, p(N)=0.04, {m} kept), 0.5 B/base + 16 B/kept", ms, L, alg,
+              **ceilings("u21", ms, alg))
         # the reference's own skipping iterator at the headline K: UnambiguousDNAMers{31}, same source
         K = 31
         ctx.check(ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seqa), K, 1, None, None, 0, cap.MEM_DEVICE, C.byref(res)), "count")
         m = int(res.n_out)
-        st = torch.empty(m, dtype=torch.int64, device=dev)
-        ms = timed(lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seqa), K, 1, a.data_ptr(), st.data_ptr(), m, cap.MEM_DEVICE, C.byref(res)))
-        entry(f"UnambiguousDNAMers{{31}}, 1 Gbase LongDNA{{4}}, p(N)=0.04, {m} kept, 0.5 B/base + 16 B/kept", ms, L, 0.5 * L + 16.0 * m)
-        del amb, st
-        # fused consumers over the clean 1 Gbase LongDNA{4} (nothing materialised per kmer: no HBM roofline,
-        # reported as kernel time and Gbases/s)
+        ms = timed(lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seqa), K, 1, a.data_ptr(), b.data_ptr(), m, cap.MEM_DEVICE, C.byref(res)))
+        alg = 0.5 * L + 16.0 * m
+        entry(f"UnambiguousDNAMers{{31}}, 1 Gbase LongDNA{{4}}, p(N)=0.04, {m} kept, 0.5 B/base + 16 B/kept", ms, L, alg, **ceilings("u31", ms, alg))
+        mem.free(amb)
+        # fused consumers over the clean 1 Gbase LongDNA{4} (nothing materialised per kmer: their roofline is the integer
+        # issue rate, SURVEY.md 8d -- kmers/s and the VALU issue share, not HBM bytes)
+        def fused(name, leg, ms, n_kmers):
+            out[name] = {"ms": round(ms, 4), "Gbases_per_s": round(L / ms / 1e6, 1), "G_kmers_per_s": round(n_kmers / ms / 1e6, 1),
+                         "bound": "VALU issue", **ceilings(leg, ms, 0.0)}
         val = C.c_uint64()
         ms = timed(lambda: ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), 31, 2, 1, C.byref(val), cap.MEM_DEVICE, C.byref(res)))
-        out["fused XOR-reduce of CanonicalDNAMers{31} (test/benchmark.jl:9-15)"] = {"ms": round(ms, 4), "Gbases_per_s": round(L / ms / 1e6, 1)}
+        fused("fused XOR-reduce of CanonicalDNAMers{31} (test/benchmark.jl:9-15)", "xor", ms, L - 30)
         sk = np.zeros(1000, dtype=np.uint64)
         ms = timed(lambda: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), 16, 2, 0, 1000, sk.ctypes.data_as(C.c_void_p), cap.MEM_DEVICE, C.byref(res)))
-        out["fused MinHash sketch(fx_hash, CanonicalDNAMers{16}, 1000) (docs/src/minhash.md:34)"] = {"ms": round(ms, 4), "Gbases_per_s": round(L / ms / 1e6, 1)}
-        counts = torch.empty(4 ** 8 // 2, dtype=torch.int64, device=dev)
+        fused("fused MinHash sketch(fx_hash, CanonicalDNAMers{16}, 1000) (docs/src/minhash.md:34)", "minhash", ms, L - 15)
         for Kc in (4, 8):
-            ms = timed(lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), Kc, counts.data_ptr(), cap.MEM_DEVICE, C.byref(res)))
-            out[f"fused composition counts of FwDNAMers{{{Kc}}} (docs/src/composition.md:28-39)"] = {"ms": round(ms, 4), "Gbases_per_s": round(L / ms / 1e6, 1)}
+            ms = timed(lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), Kc, b.data_ptr(), cap.MEM_DEVICE, C.byref(res)))
+            fused(f"fused composition counts of FwDNAMers{{{Kc}}} (docs/src/composition.md:28-39)", f"comp{Kc}", ms, L - Kc + 1)
         # ragged batch: 8 M reads x 125 bases = the same 1 Gbase pool, CanonicalDNAMers{31} + fx_hash per read
         n_reads, rl, Kb = 8_000_000, 125, 31
         spans = torch.stack([torch.arange(n_reads, dtype=torch.int64, device=dev) * rl,
                              torch.full((n_reads,), rl, dtype=torch.int64, device=dev)], dim=1).contiguous()
         total = n_reads * (rl - Kb + 1)
-        b = torch.empty(total, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
         ms = timed(lambda: ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans.data_ptr(), n_reads, cap.BATCH_CANONICAL, Kb, 2, a.data_ptr(),
                                                b.data_ptr(), 0, None, total, cap.MEM_DEVICE | cap.SPANS_DEVICE, C.byref(res)))
         out[f"kmers_batch: {n_reads} reads x {rl} bases, CanonicalDNAMers{{31}} + fx_hash per read"] = {
             "ms": round(ms, 4), "G_elements_per_s": round(total / ms / 1e6, 1), "Gbases_per_s": round(n_reads * rl / ms / 1e6, 1),
             "GB_per_s": round((16.0 * total + 0.5 * n_reads * rl) / ms / 1e6, 1)}
-        del a, b, buf, spans, counts
+        mem.free(a, b, buf)
+        del a, b, buf, spans
         torch.cuda.empty_cache()
         # N1 (north star): CanonicalDNAMers{31} + fx_hash over 10 Gbase LongDNA{4} on ONE GPU: 5 GB in, 160 GB out
-        free_b, _ = torch.cuda.mem_get_info(dev)
-        L, K = 10_000_000_000, 31
-        if free_b > 175e9:
-            seed10 = GOLDEN ^ 10
-            buf = synth(seed10, L, 4)
-            n = L - K + 1
-            a = torch.empty(n, dtype=torch.int64, device=dev)
-            h = torch.empty(n, dtype=torch.int64, device=dev)
-            seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
-            ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), h.data_ptr(), 0, ASYNC, C.byref(res)))
-            ok = verify_canonical(ctx, cap, stream, dev, buf, L, 0, 0, 4, K, 1, seed10, a, h, n)
-            entry("N1 north star: CanonicalDNAMers{31} + fx_hash, 10 Gbase LongDNA{4}, one GPU, 16.5 B/kmer", ms, L, 16.5 * n, verified=ok)
-            del buf, a, h
-        else:
-            out["N1 north star: 10 Gbase LongDNA{4}"] = {"skipped": f"needs 165 GB of HBM, {free_b / 1e9:.0f} GB free"}
+        out.update(north_star_one_gpu(ctx, cap, stream, dev, mem, reps))
     return out
 
 
+def north_star_one_gpu(ctx, cap, stream, dev, mem, reps=7, L=NORTH_STAR_BASES):
+    import torch
+    res = cap.Result()
+    K = 31
+    n = L - K + 1
+    need = 8 * (2 * n + L // 16 + 2)
+    if mem.use_arena:
+        room = ctx.arena_info()[2]
+    else:
+        room = torch.cuda.mem_get_info(dev)[0]
+    name = f"N1 north star: CanonicalDNAMers{{31}} + fx_hash, {L / 1e9:g} Gbase LongDNA{{4}}, one GPU, 16.5 B/kmer"
+    if room < need + (2 << 30):
+        return {name: {"skipped": f"needs {need / 1e9:.0f} GB of HBM, {room / 1e9:.0f} GB available"}}
+    seed10 = GOLDEN ^ 10
+    nw = (L * 4 + 63) // 64
+    buf = mem.empty(nw + 2)
+    ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed10, 0, nw, 4, 0, buf.data_ptr()), "kmers_synth_dna")
+    a, h = mem.empty(n), mem.empty(n)
+    seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
+    ASYNC = cap.MEM_DEVICE | cap.ASYNC
+    ms = busy_timed(ctx, stream, lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), h.data_ptr(), 0, ASYNC, C.byref(res)), reps)
+    ok = verify_canonical(ctx, cap, stream, dev, buf, L, 0, 0, 4, K, 1, seed10, a, h, n)
+    mem.free(buf, a, h)
+    alg = 16.5 * n
+    return {name: {"kernel_ms": round(ms, 4), "Gbases_per_s": round(L / ms / 1e6, 1), "GB_per_s": round(alg / ms / 1e6, 1),
+                   "frac_of_8TBps": round(alg / ms / 1e6 / HBM_PEAK_GBPS, 4), "verified": ok}}
+
+
 # --------------------------------------------------------------------------------------------
-# roofline.traffic: HBM bytes of the headline kernel from the PMC counters, measured in THIS run by two profiled child
-# processes (FETCH_SIZE and WRITE_SIZE need separate passes: TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots")
+# PMC: HBM bytes of the headline kernel (roofline.traffic) and VALU issue shares of the legs that are not pure store
+# streams, measured in THIS run by profiled child processes (FETCH_SIZE and WRITE_SIZE need separate passes: TCC slots,
+# MI355X_MICROARCH.md "rocprofv3 PMC slots")
 def pmc_child(args):
-    """The profiled program: the headline launch three times, nothing else (run under rocprofv3 --pmc)."""
+    """The profiled program (run under rocprofv3 --pmc): "headline" = the headline launch three times, nothing else;
+    "legs" = UnambiguousKmers on the C5 lattice and at K = 31, then the fused consumers, twice each, in this order."""
+    import numpy as np
     import torch
 
     import kmers_jl_amd as km
@@ -354,59 +453,157 @@ def pmc_child(args):
     dev = torch.device("cuda", 0)
     stream = torch.cuda.ExternalStream(ctx.lib.kmers_ctx_stream(ctx.handle), device=dev)
     K, bits, L = args.k, args.src_bits, args.bases
-    nw = (L * bits + 63) // 64
-    with torch.cuda.stream(stream):
-        buf = torch.zeros(nw + 2, dtype=torch.int64, device=dev)
-        ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, GOLDEN ^ 2, 0, nw, bits, 0, buf.data_ptr()), "kmers_synth_dna")
+    res = cap.Result()
+
+    def synth(seed, amb=0):
+        nw = (L * bits + 63) // 64
+        with torch.cuda.stream(stream):
+            buf = torch.zeros(nw + 2, dtype=torch.int64, device=dev)
+            ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, 0, nw, bits, amb, buf.data_ptr()), "kmers_synth_dna")
+        return buf
+    if args.pmc_child == "headline":
+        buf = synth(GOLDEN ^ 2)
         n = L - K + 1
         N = cap.load().kmers_words_per_kmer(K, 2)
         out_k = torch.empty(n * N, dtype=torch.int64, device=dev)
         out_h = None if args.no_hash else torch.empty(n, dtype=torch.int64, device=dev)
-    seq = cap.Seq(buf.data_ptr(), L, 0, 0, bits, 0)
-    res = cap.Result()
-    for _ in range(3):
-        rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, out_k.data_ptr(), out_h.data_ptr() if out_h is not None else None,
-                                     0, cap.MEM_DEVICE, C.byref(res))
-        assert rc == 0, ctx.last_error()
+        seq = cap.Seq(buf.data_ptr(), L, 0, 0, bits, 0)
+        for _ in range(3):
+            rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, out_k.data_ptr(), out_h.data_ptr() if out_h is not None else None,
+                                         0, cap.MEM_DEVICE, C.byref(res))
+            assert rc == 0, ctx.last_error()
+        torch.cuda.synchronize()
+        return
+    a = torch.empty(L, dtype=torch.int64, device=dev)
+    b = torch.empty(L, dtype=torch.int64, device=dev)
+    amb = synth(GOLDEN ^ 5, 2621)
+    seqa = cap.Seq(amb.data_ptr(), L, 0, 0, bits, 0)
+    for Ku, Ju in ((21, 3), (31, 1)):
+        for _ in range(2):
+            rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seqa), Ku, Ju, a.data_ptr(), b.data_ptr(), L, cap.MEM_DEVICE, C.byref(res))
+            assert rc == 0, ctx.last_error()
+    del amb
+    clean = synth(GOLDEN ^ 5)
+    seq = cap.Seq(clean.data_ptr(), L, 0, 0, bits, 0)
+    val = C.c_uint64()
+    sk = np.zeros(1000, dtype=np.uint64)
+    for _ in range(2):
+        assert ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), 31, 2, 1, C.byref(val), cap.MEM_DEVICE, C.byref(res)) == 0
+    for _ in range(2):
+        assert ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), 16, 2, 0, 1000, sk.ctypes.data_as(C.c_void_p), cap.MEM_DEVICE, C.byref(res)) == 0
+    for Kc in (4, 8):
+        for _ in range(2):
+            assert ctx.lib.kmers_composition(ctx.handle, C.byref(seq), Kc, b.data_ptr(), cap.MEM_DEVICE, C.byref(res)) == 0
     torch.cuda.synchronize()
 
 
-def measure_traffic(args):
-    """Returns (bytes per launch or None, description of where the number comes from)."""
+def profiler_in_environment():
+    """True when this process itself runs under a profiler (rocprofv3 preloads its tool library through these variables).
+    A nested rocprofv3 would inherit them, and its launcher -- with the GPU already initialised by the preloaded tool --
+    would exec the child program: on this pool a process that has touched the GPU must never replace itself."""
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER_")) for k in os.environ):
+        return True
+    return any(s in os.environ.get("LD_PRELOAD", "") for s in ("rocprof", "roctracer", "rocprofiler"))
+
+
+def run_pmc_pass(args, which, counters, device_index, timeout):
+    """One `rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --pmc-child <which>` child.  Returns
+    ([(kernel name, dispatch id, counter, value)], [(kernel name, dispatch id, duration in ns)]) or raises."""
     import csv
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
-    vals = {}
+        raise RuntimeError("rocprofv3 not found")
     tmp = tempfile.mkdtemp(prefix="kmers_pmc_")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-                   os.path.abspath(__file__), "--pmc-child", "--bases", str(args.bases), "--k", str(args.k), "--src-bits", str(args.src_bits)]
-            if args.no_hash:
-                cmd.append("--no-hash")
-            env = dict(os.environ, TMPDIR=tmp)
-            p = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-            if p.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} child failed ({p.returncode}): {p.stderr[-300:]}"
-            rows = []
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    if "stream_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
-                        rows.append(float(r["Counter_Value"]))
-            if not rows:
-                return None, f"no {counter} rows for stream_kernel in the rocprofv3 output"
-            vals[counter] = sum(rows) / len(rows)
-    except Exception as e:
-        return None, f"PMC pass failed: {e!r}"
+        cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable,
+               os.path.abspath(__file__), "--pmc-child", which, "--bases", str(args.bases), "--k", str(args.k), "--src-bits", str(args.src_bits)]
+        if args.no_hash:
+            cmd.append("--no-hash")
+        # a clean environment for the child: no profiler variables of an outer run, one visible device (the rank's own)
+        env = {k: v for k, v in os.environ.items()
+               if not k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER_")) and k not in ("LD_PRELOAD", "RANK", "LOCAL_RANK", "WORLD_SIZE",
+                                                                                        "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+        visible = os.environ.get("HIP_VISIBLE_DEVICES")
+        env["HIP_VISIBLE_DEVICES"] = visible.split(",")[device_index] if visible else str(device_index)
+        env["TMPDIR"] = tmp
+        p = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        if p.returncode != 0:
+            raise RuntimeError(f"rocprofv3 --pmc {' '.join(counters)} child failed ({p.returncode}): {p.stderr[-300:]}")
+        rows, durs = [], []
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                rows.append((r.get("Kernel_Name", ""), int(r.get("Dispatch_Id", 0)), r.get("Counter_Name"), float(r["Counter_Value"])))
+        for f in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                durs.append((r.get("Kernel_Name", ""), int(r.get("Dispatch_Id", 0)), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        return rows, durs
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_traffic(args, device_index=0, timeout=600):
+    """Returns (bytes per launch or None, description of where the number comes from)."""
+    if profiler_in_environment():
+        return None, "this run is itself under a profiler (LD_PRELOAD / ROCP_* set): no nested rocprofv3"
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            rows, _ = run_pmc_pass(args, "headline", [counter], device_index, timeout)
+            v = [x for (name, _, cn, x) in rows if "stream_kernel" in name and cn == counter]
+            if not v:
+                return None, f"no {counter} rows for stream_kernel in the rocprofv3 output"
+            vals[counter] = sum(v) / len(v)
+    except Exception as e:
+        return None, f"PMC pass failed: {e!r}"
     # units and gfx950 corrections exactly as MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KiB;
     # FETCH_SIZE reports half of a coalesced streaming read on gfx950 -> doubled; WRITE_SIZE is exact for 16 B/lane stores
     traffic = int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)
     return traffic, (f"measured in this run: two rocprofv3 --pmc child passes over the same launch (FETCH_SIZE {vals['FETCH_SIZE']:.1f} KiB "
                      f"x 2 [gfx950 correction], WRITE_SIZE {vals['WRITE_SIZE']:.1f} KiB)")
+
+
+def measure_legs(args, device_index=0, timeout=600):
+    """VALU issue share of the legs whose roofline is not (only) HBM: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs against the
+    cycles the XCDs were active (GRBM_GUI_ACTIVE / 8), one rocprofv3 --pmc child over the `legs` program.  Returns
+    {leg: {...}} (empty when the pass could not run).  The legs are told apart by kernel name and dispatch order."""
+    if profiler_in_environment():
+        return {}
+    try:
+        rows, durs = run_pmc_pass(args, "legs", ["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], device_index, timeout)
+    except Exception as e:
+        log(f"VALU pass failed: {e!r}")
+        return {}
+    per = {}
+    for name, did, cn, x in rows:
+        per.setdefault(did, {"name": name})[cn] = per.get(did, {}).get(cn, 0.0) + x
+    for name, did, ns in durs:
+        if did in per:
+            per[did]["ns"] = ns
+    order = [per[d] for d in sorted(per)]
+
+    def pick(sub, excl=()):
+        return [d for d in order if sub in d["name"] and not any(e in d["name"] for e in excl) and "SQ_INSTS_VALU" in d]
+    # kmers_unambiguous launches its one-pass kernel once per call here (capacity given): u21 twice, then u31 twice
+    un = pick("unambiguous_kernel")
+    groups = {"u21": un[0:2], "u31": un[2:4]}
+    rk = pick("run_kernel")
+    groups["xor"], groups["minhash"] = rk[0:2], rk[2:4]
+    comp = pick("composition_kernel")
+    groups["comp4"], groups["comp8"] = comp[0:2], comp[2:4]
+    res = {}
+    for leg, ds in groups.items():
+        if not ds:
+            continue
+        d = ds[-1]
+        valu, act = d["SQ_INSTS_VALU"], d.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        cyc = valu * 4.0 / N_SIMDS
+        ns = d.get("ns", 0)
+        clock_ghz = act / ns if ns else 0.0
+        res[leg] = {"valu_insts": int(valu), "valu_issue_frac": round(cyc / act, 4) if act else None,
+                    "valu_floor_ms": round(cyc / (clock_ghz * 1e6), 4) if clock_ghz else None,
+                    "source": f"measured in this run: rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE child pass, kernel {d['name'][:60]}, "
+                              f"{ns / 1e6:.3f} ms under the profiler at {clock_ghz:.2f} GHz"}
+    return res
 
 
 def replayed_traffic(args):
@@ -421,6 +618,105 @@ def replayed_traffic(args):
 
 
 # --------------------------------------------------------------------------------------------
+class Leg:
+    """One sharded canonical(+hash) workload resident on this rank: its shard of `total_bases`, the halo step and the launch."""
+
+    def __init__(self, env, total_bases, seed):
+        import torch
+        self.env = env
+        ctx, cap, mem, args = env.ctx, env.cap, env.mem, env.args
+        from kmers_jl_amd.shard import HaloExchanger, plan_shards
+        self.total_bases, self.seed = total_bases, seed
+        self.plan = plan_shards(total_bases, args.k, env.world, args.src_bits)
+        sh = self.sh = self.plan[env.rank]
+        self.N = cap.load().kmers_words_per_kmer(args.k, 2)
+        with torch.cuda.stream(env.stream):
+            self.buf = mem.empty(sh.n_own_words + sh.halo_words + 2)
+            self.buf.zero_()
+            ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, sh.first_word, sh.n_own_words, args.src_bits, 0, self.buf.data_ptr()),
+                      "kmers_synth_dna")
+            self.out_k = mem.empty(sh.n_kmers * self.N)
+            self.out_h = None if args.no_hash else mem.empty(sh.n_kmers)
+            self.halo = None
+            if env.grouped and env.transport != "native":
+                self.halo = HaloExchanger(self.buf, sh, self.plan, transport=env.transport)  # its workspace is filled on this stream too
+        self.shard_c = env.comm._shard_struct(sh) if env.comm is not None else None
+        torch.cuda.synchronize()
+        self.seq = cap.Seq(self.buf.data_ptr(), sh.n_bases, 0, sh.first_kmer, args.src_bits, 0)
+        self.res = cap.Result()
+        self.ph = self.out_h.data_ptr() if self.out_h is not None else None
+
+    def step(self, ev=None):
+        import torch
+        env = self.env
+        ctx, cap = env.ctx, env.cap
+        with torch.cuda.stream(env.stream):
+            if ev:
+                ev[0].record(env.stream)
+            if env.comm is not None:
+                env.comm.halo_exchange(self.shard_c, self.buf.data_ptr())
+            elif self.halo is not None:
+                self.halo.exchange()
+            if ev:
+                ev[1].record(env.stream)
+            rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(self.seq), env.args.k, 2, self.out_k.data_ptr(), self.ph, 0,
+                                         cap.MEM_DEVICE | cap.ASYNC, C.byref(self.res))
+            if ev:
+                ev[2].record(env.stream)
+        if rc != 0:
+            raise RuntimeError(f"kmers_canonical failed: {ctx.last_error()}")
+
+    def timed(self, warmup, steps, solo=False):
+        """W untimed steps, then exactly `steps` steps between two fences (device sync + barrier + device sync); returns
+        (elapsed seconds, mean kernel ms, mean halo-step ms) of THIS rank.  solo: this rank runs alone (no barrier)."""
+        import numpy as np
+        import torch
+        env = self.env
+        for _ in range(warmup):
+            self.step()
+        rc, _ = env.ctx.sync()
+        assert rc == 0, env.ctx.last_error()
+        events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(steps)]
+        env.fence(solo)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(events[i])
+        env.fence(solo)
+        elapsed = time.perf_counter() - t0
+        rc, _ = env.ctx.sync()
+        assert rc == 0, env.ctx.last_error()
+        kern = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if steps else 0.0
+        halo = float(np.mean([e[0].elapsed_time(e[1]) for e in events])) if steps else 0.0
+        return elapsed, kern, halo
+
+    def verify(self):
+        env, sh, args = self.env, self.sh, self.env.args
+        return verify_canonical(env.ctx, env.cap, env.stream, env.dev, self.buf, sh.n_bases, sh.first_kmer, sh.first_word, args.src_bits,
+                                args.k, self.N, self.seed, self.out_k, self.out_h, sh.n_kmers)
+
+    def release(self):
+        import torch
+        self.env.mem.free(self.buf, self.out_k, self.out_h)
+        self.buf = self.out_k = self.out_h = self.halo = None
+        torch.cuda.empty_cache()
+
+
+class Env:
+    pass
+
+
+def gather_floats(env, values):
+    """[values of rank 0, values of rank 1, ...] (each a list of floats) on every rank."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor(values, dtype=torch.float64, device=env.dev)
+    if not env.grouped:
+        return [list(map(float, t.tolist()))]
+    parts = [torch.zeros_like(t) for _ in range(env.world)]
+    dist.all_gather(parts, t)
+    return [list(map(float, p.tolist())) for p in parts]
+
+
 def main():
     args = parse_args()
     if args.pmc_child:
@@ -456,17 +752,20 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if grouped:
+        # rank 0 works alone for a while after the timed region (PMC child passes, the CPU baseline, the 1-GPU leg of the
+        # strong-scaling pair) while the others wait in a barrier: give the collectives' watchdog room for that
+        long_wait = datetime.timedelta(minutes=45)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=long_wait)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=long_wait)
         backend = dist.get_backend()
     world = dist.get_world_size() if grouped else 1
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: the process group has {world} ranks")
 
     import kmers_jl_amd as km
-    from kmers_jl_amd.shard import HaloExchanger, NativeComm, plan_shards
+    from kmers_jl_amd.shard import NativeComm
     from oracle import pyoracle
     if rank == 0:
         pyoracle.build()  # the checker used after the timed region; one builder, the others wait
@@ -481,122 +780,153 @@ def main():
         ctx.set_param(cap.PARAM_MAX_GRID, args.max_grid)
 
     K, bits = args.k, args.src_bits
-    total_bases = args.bases * world
-    plan = plan_shards(total_bases, K, world, bits)
-    sh = plan[rank]
+    strong = args.total_bases > 0
+    total_bases = args.total_bases if strong else args.bases * world
     seed = GOLDEN ^ 2  # golden ^ config id (C2)
     N = cap.load().kmers_words_per_kmer(K, 2)
+    bytes_per_kmer = bits / 8 + 8 * N + (0 if args.no_hash else 8)
 
     # the halo transport: under RCCL the C ABI's own exchange (grouped ncclSend/ncclRecv on the context's stream; torch only
     # hands the 128-byte ncclUniqueId around); under gloo (shared-device debugging, CPU tests) torch.distributed's
     transport = os.environ.get("KMERS_HALO_TRANSPORT", "native" if backend == "nccl" else "allgather")
-    comm = None
-    # A fresh box hands out fragmented VRAM: the same launch over two freshly allocated 8 GB output arrays runs at 0.794 of
-    # 8 TB/s in the first process of a box and at 0.83-0.84 in any process after one that has allocated and released a large
-    # block (tools/diag_alloc2.py, profiles/r02_tuning.md section 7: the driver then has large contiguous ranges to give, and
-    # the address translation reaches further).  One allocation of 60 % of the free memory, released at once and never
-    # touched, puts every run in the second state; INTEGRATION.md gives the same advice to host applications.
-    defrag_gb = 0.0
     shared_device = grouped and backend != "nccl"  # (gloo debugging mode: the ranks share one device and its memory)
-    if not args.no_defrag and not shared_device:
-        free_b, _total_b = torch.cuda.mem_get_info(dev)
-        n_defrag = int(free_b * 0.6) // 8
+    use_arena = args.alloc == "arena" and not shared_device
+
+    env = Env()
+    env.args, env.ctx, env.cap, env.dev, env.stream = args, ctx, cap, dev, stream
+    env.rank, env.world, env.grouped, env.transport, env.comm = rank, world, grouped, transport, None
+
+    def fence(solo=False):
+        torch.cuda.synchronize()
+        if grouped and not solo:
+            dist.barrier()
+        torch.cuda.synchronize()
+    env.fence = fence
+
+    # ---- the same launch into PLAIN allocations, before the arena exists (rank 0, N = 1; not the headline) -----------
+    # Where the outputs live is worth 3-5 % on this device (profiles/r03_alloc.md): this is what a host gets that allocates
+    # its outputs one hipMalloc each on a fresh machine, kept in the line next to the arena's figure.
+    plain_alloc = None
+    if use_arena and world == 1 and not strong and not args.no_other_configs:
         try:
-            tmp = torch.empty(n_defrag, dtype=torch.int64, device=dev)
-            del tmp
-            defrag_gb = round(n_defrag * 8 / 1e9, 1)
-        except torch.OutOfMemoryError:
-            pass  # somebody else holds the memory: measure in whatever state the allocator is
-        torch.cuda.empty_cache()
-    with torch.cuda.stream(stream):
-        buf = torch.zeros(sh.n_own_words + sh.halo_words + 2, dtype=torch.int64, device=dev)
-        ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, sh.first_word, sh.n_own_words, bits, 0, buf.data_ptr()),
-                  "kmers_synth_dna")
-        out_k = torch.empty(sh.n_kmers * N, dtype=torch.int64, device=dev)
-        out_h = None if args.no_hash else torch.empty(sh.n_kmers, dtype=torch.int64, device=dev)
-        halo = None
-        if grouped and transport != "native":
-            halo = HaloExchanger(buf, sh, plan, transport=transport)  # its workspace is filled on this stream too
+            env.mem = Memory(ctx, dev, False)
+            leg0 = Leg(env, total_bases, seed)
+            ms0 = busy_timed(ctx, stream, leg0.step, reps=7, busy_s=0.3)
+            plain_alloc = {"kernel_ms": round(ms0, 4), "frac": round(bytes_per_kmer * leg0.sh.n_kmers / ms0 / 1e6 / HBM_PEAK_GBPS, 4),
+                           "what": "the headline launch into two torch (hipMalloc) allocations made before the arena was reserved; "
+                                   "7 launches behind 0.3 s of the same launch, outside the timed region"}
+            del leg0
+            torch.cuda.empty_cache()
+        except Exception as e:
+            plain_alloc = {"error": repr(e)}
+    arena_gb = 0.0
+    if use_arena:
+        arena_gb = round(ctx.arena_reserve(int(args.arena_gb * 1e9)) / 1e9, 1)
+    mem = env.mem = Memory(ctx, dev, use_arena)
     if grouped and transport == "native":
         if backend != "nccl":
             raise SystemExit("KMERS_HALO_TRANSPORT=native needs one GPU per rank (RCCL); the gloo mode shares a device")
-        comm = NativeComm.bootstrap(ctx)
-        shard_c = comm._shard_struct(sh)
-    torch.cuda.synchronize()
-    seq = cap.Seq(buf.data_ptr(), sh.n_bases, 0, sh.first_kmer, bits, 0)
-    res = cap.Result()
-    flags = cap.MEM_DEVICE | cap.ASYNC
-    ph = out_h.data_ptr() if out_h is not None else None
+        env.comm = NativeComm.bootstrap(ctx)
+    comm = env.comm
 
-    def step(ev=None):
-        with torch.cuda.stream(stream):
-            if comm is not None:
-                comm.halo_exchange(shard_c, buf.data_ptr())
-            elif halo is not None:
-                halo.exchange()
-            if ev:
-                ev[0].record(stream)
-            rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, out_k.data_ptr(), ph, 0, flags, C.byref(res))
-            if ev:
-                ev[1].record(stream)
-        if rc != 0:
-            raise RuntimeError(f"kmers_canonical failed: {ctx.last_error()}")
-
-    def fence():
-        torch.cuda.synchronize()
-        if grouped:
-            dist.barrier()
-        torch.cuda.synchronize()
+    leg = Leg(env, total_bases, seed)
+    sh, plan = leg.sh, leg.plan
 
     # Wake the device: after an idle gap (allocation, data generation, process start) this device runs its next ~10 ms
-    # 10-25 % slower (tools/diag_cooldown.py, profiles/r02_tuning.md section 1) and the first second of a fresh process 2 %
-    # slower than the ninety that follow (tools/diag_warmup.py: 2.49 ms per launch, then 2.435), which is longer than the W
-    # warm-up steps of the contract.  --wake-s seconds (default 1) of plain torch fills of the output arrays -- not steps of
-    # the hot path -- come first; the W warm-up steps and the K timed steps below are exactly the contract's.
+    # 10-25 % slower (profiles/r02_tuning.md section 1) and the first second of a fresh process 2 % slower than the ninety
+    # that follow, which is longer than the W warm-up steps of the contract.  --wake-s seconds (default 1) of plain torch
+    # fills of the output arrays -- not steps of the hot path -- come first; the W warm-up steps and the K timed steps
+    # are exactly the contract's.
     with torch.cuda.stream(stream):
         t_wake = time.perf_counter()
         while time.perf_counter() - t_wake < args.wake_s:
-            out_k.fill_(0)
-            if out_h is not None:
-                out_h.fill_(0)
+            leg.out_k.fill_(0)
+            if leg.out_h is not None:
+                leg.out_h.fill_(0)
             torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    rc, sres = ctx.sync()
-    assert rc == 0, ctx.last_error()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(events[i])
-    fence()
-    elapsed = time.perf_counter() - t0
-    rc, sres = ctx.sync()
-    assert rc == 0, ctx.last_error()
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
-
-    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
-    if grouped:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms_max = float(t[0]), float(t[1])
+    elapsed, kern_ms, halo_ms = leg.timed(args.warmup, args.steps)
+    per_rank = gather_floats(env, [elapsed, kern_ms, halo_ms, float(sh.n_kmers)])
+    elapsed = max(p[0] for p in per_rank)
 
     # ---- integrity of what the timed kernel wrote (outside the timed region) --------------
-    verified = verify_canonical(ctx, cap, stream, dev, buf, sh.n_bases, sh.first_kmer, sh.first_word, bits, K, N, seed, out_k, out_h, sh.n_kmers)
+    verified = leg.verify()
     # the two tiny cross-shard reductions of the path, through the same communicator (results known in closed form)
     if comm is not None:
         st, pos, enc = comm.first_error(1 if rank == world - 1 else 0, err_pos=sh.first_base + 5, err_enc=0xF)
         verified &= (st, pos, enc) == (1, plan[-1].first_base + 5, 0xF)
         off, tot = comm.output_offsets(sh.n_kmers)
         verified &= off == sh.first_kmer and tot == sum(s.n_kmers for s in plan)
+
+    fill_gbps = None
+    if rank == 0:
+        try:  # what this device writes when it does nothing else: torch fills of the two output arrays
+            with torch.cuda.stream(stream):
+                fills = []
+                for _ in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    leg.out_k.fill_(1)
+                    if leg.out_h is not None:
+                        leg.out_h.fill_(2)
+                    e1.record(stream)
+                    torch.cuda.synchronize()
+                    fills.append(e0.elapsed_time(e1))
+                fill_bytes = leg.out_k.numel() * 8 + (leg.out_h.numel() * 8 if leg.out_h is not None else 0)
+                fill_gbps = fill_bytes / (float(np.median(fills[1:])) * 1e-3) / 1e9
+        except Exception as e:
+            log(f"fill measurement failed: {e!r}")
+    leg.release()
+
+    # ---- weak runs on N > 1 GPUs: the strong split of the north-star input, in the same run -------------------
+    strong_extra = None
+    strong_bases = args.strong_bases if args.strong_bases >= 0 else (0 if shared_device else NORTH_STAR_BASES)
+    if grouped and world > 1 and not strong and strong_bases:
+        sleg = Leg(env, strong_bases, GOLDEN ^ 10)
+        s_elapsed, s_kern, s_halo = sleg.timed(args.warmup, args.steps)
+        s_per_rank = gather_floats(env, [s_elapsed, s_kern, s_halo, float(sleg.sh.n_kmers)])
+        s_ok = sleg.verify()
+        sleg.release()
+        solo = [0.0, 0.0]
+        if rank == 0:  # the same input on ONE GPU (rank 0 alone; the others wait at the barrier below)
+            env.world, env.grouped, env.comm = 1, False, None
+            try:
+                one = Leg(env, strong_bases, GOLDEN ^ 10)
+                o_elapsed, o_kern, _ = one.timed(args.warmup, args.steps, solo=True)
+                s_ok &= one.verify()
+                one.release()
+                solo = [o_elapsed, o_kern]
+            except Exception as e:
+                log(f"1-GPU leg of the strong-scaling pair failed: {e!r}")
+            env.world, env.grouped, env.comm = world, grouped, comm
+        sv = torch.tensor([1 if s_ok else 0], device=dev)
+        dist.all_reduce(sv, op=dist.ReduceOp.MIN)
+        tN = max(p[0] for p in s_per_rank) / args.steps
+        strong_extra = {
+            "workload": f"CanonicalDNAMers{{{K}}} + fx_hash over ONE sequence of {strong_bases / 1e9:g} Gbase LongDNA{{{bits}}} split over {world} GPUs "
+                        f"(kmers_shard_plan: contiguous kmer ranges, (K-1)-base halo), same steps / warm-up / fences as the headline",
+            "scaling": "strong", "total_bases": strong_bases, "n_gpus": world,
+            "ms_per_step": round(tN * 1e3, 4), "value": round(strong_bases / tN / 1e9, 3), "unit": "Gbases/s",
+            "kernel_ms_per_rank": [round(p[1], 4) for p in s_per_rank], "halo_ms_per_rank": [round(p[2], 4) for p in s_per_rank],
+            "frac_per_rank": [round(bytes_per_kmer * p[3] / p[1] / 1e6 / HBM_PEAK_GBPS, 4) if p[1] else None for p in s_per_rank],
+            "verified": bool(sv.item()),
+        }
+        if rank == 0 and solo[0]:
+            t1 = solo[0] / args.steps
+            strong_extra["one_gpu"] = {"ms_per_step": round(t1 * 1e3, 4), "value": round(strong_bases / t1 / 1e9, 3), "kernel_ms": round(solo[1], 4),
+                                       "what": "the same input on rank 0's GPU alone, same run, same steps"}
+            strong_extra["speedup_vs_one_gpu"] = round(t1 / tN, 3)
+        verified &= bool(sv.item())
     v = torch.tensor([1 if verified else 0], device=dev)
     if grouped:
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
     verified = bool(v.item())
 
     if rank == 0:
-        n_kmers_rank = sh.n_kmers
-        bytes_per_kmer = bits / 8 + 8 * N + (0 if args.no_hash else 8)
-        achieved = bytes_per_kmer * n_kmers_rank / (kern_ms * 1e-3) / 1e9
+        kern_list = [p[1] for p in per_rank]
+        halo_list = [p[2] for p in per_rank]
+        fracs = [bytes_per_kmer * p[3] / p[1] / 1e6 / HBM_PEAK_GBPS if p[1] else 0.0 for p in per_rank]
+        worst = int(np.argmin(fracs))  # the slowest GPU bounds the job
+        achieved = fracs[worst] * HBM_PEAK_GBPS
         if not grouped:
             sharding = "single shard"
         else:
@@ -604,61 +934,66 @@ def main():
                    "allgather": f"torch.distributed all_gather of <= 32 B per rank ({backend})",
                    "p2p": f"torch.distributed batch_isend_irecv between neighbours ({backend})"}[transport]
             sharding = f"contiguous kmer-start ranges, (K-1)-base halo from rank+1 each step; backend {backend}; transport {transport}: {how}"
+        what = f"CanonicalDNAMers{{{K}}}" + ("" if args.no_hash else " + fx_hash")
+        if strong:
+            workload = (f"{what} over ONE sequence of {total_bases / 1e9:g} Gbase LongDNA{{{bits}}} split over {world} GPU(s) "
+                        f"(north star: 10 Gbase LongDNA{{4}}), kmers and hashes materialised in HBM")
+        else:
+            workload = (f"{what} over {args.bases / 1e9:g} Gbase LongDNA{{{bits}}} per GPU (BASELINE.json configs[1]), "
+                        f"kmers and hashes materialised in HBM")
         line = {
             "metric": METRIC, "value": round(total_bases * args.steps / elapsed / 1e9, 3), "unit": "Gbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"CanonicalDNAMers{{{K}}} + fx_hash over {args.bases / 1e9:g} Gbase LongDNA{{{bits}}} "
-                                   f"per GPU (BASELINE.json configs[1]), kmers and hashes materialised in HBM"
-                                   if not args.no_hash else
-                                   f"CanonicalDNAMers{{{K}}} over {args.bases / 1e9:g} Gbase LongDNA{{{bits}}} per GPU",
-                       "k": K, "src_bits": bits, "bases_per_gpu": args.bases,
+            "config": {"workload": workload, "k": K, "src_bits": bits, "total_bases": total_bases,
+                       "bases_per_gpu": [s.n_bases for s in plan] if strong else args.bases,
                        "sharding": sharding, "backend": backend, "halo_transport": transport if grouped else None,
                        "seed": hex(seed), "wake_s": args.wake_s,
-                       "vram_defrag_GB": defrag_gb},
+                       "alloc": (f"kmers_arena_reserve ({arena_gb} GB, one block) + kmers_dev_alloc" if use_arena else "torch.empty (hipMalloc)")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": "not measured",
-                         "kernel": "stream_kernel<src_bits,N,CANON,stride1>", "kernel_ms": round(kern_ms, 4),
-                         "bytes_per_kmer": bytes_per_kmer, "kmers_per_launch": n_kmers_rank},
+                         "kernel": "stream_kernel<src_bits,N,CANON,stride1>", "kernel_ms": round(kern_list[worst], 4),
+                         "bytes_per_kmer": bytes_per_kmer, "kmers_per_launch": int(per_rank[worst][3])},
             "verified": verified,
         }
-        if world == 1:
-            try:  # what this device writes when it does nothing else: torch fills of the two output arrays
-                with torch.cuda.stream(stream):
-                    fills = []
-                    for _ in range(5):
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record(stream)
-                        out_k.fill_(1)
-                        if out_h is not None:
-                            out_h.fill_(2)
-                        e1.record(stream)
-                        torch.cuda.synchronize()
-                        fills.append(e0.elapsed_time(e1))
-                    fill_bytes = out_k.numel() * 8 + (out_h.numel() * 8 if out_h is not None else 0)
-                    fill_gbps = fill_bytes / (float(np.median(fills[1:])) * 1e-3) / 1e9
-                line["roofline"]["torch_fill_GBps"] = round(fill_gbps, 1)  # torch.Tensor.fill_ over the same two arrays, same run
-                line["roofline"]["vs_torch_fill"] = round(achieved / fill_gbps, 4)
-            except Exception as e:
-                line["roofline"]["torch_fill_GBps"] = None
-                log(f"fill measurement failed: {e!r}")
-        if world == 1:
-            del out_k, out_h, buf
-            torch.cuda.empty_cache()
-            traffic, source = (None, "not measured (--no-pmc)") if args.no_pmc else measure_traffic(args)
-            if traffic is None:
-                log(f"roofline.traffic: {source}")
-                traffic, source2 = replayed_traffic(args)
-                source = f"{source2}; live measurement: {source}"
-            line["roofline"]["traffic"] = traffic
-            line["roofline"]["traffic_source"] = source
+        rf = line["roofline"]
+        if grouped:
+            rf["per_gpu"] = "achieved / frac / kernel_ms are those of the slowest GPU; the lists are in rank order"
+            rf["kernel_ms_per_rank"] = [round(x, 4) for x in kern_list]
+            rf["kernel_ms_min"], rf["kernel_ms_max"] = round(min(kern_list), 4), round(max(kern_list), 4)
+            rf["frac_per_rank"] = [round(x, 4) for x in fracs]
+            rf["halo_step_ms_per_rank"] = [round(x, 4) for x in halo_list]
+            rf["halo_step_share"] = round(max(halo_list) / max(1e-9, max(halo_list) + max(kern_list)), 5)
+        if plain_alloc is not None:
+            rf["plain_alloc"] = plain_alloc
+        if fill_gbps:
+            rf["torch_fill_GBps"] = round(fill_gbps, 1)  # torch.Tensor.fill_ over the same two arrays, same run
+            rf["vs_torch_fill"] = round(achieved / fill_gbps, 4)
+        if strong_extra is not None:
+            line["strong_scaling"] = strong_extra
+        # the PMC child passes, rank 0's device (the other ranks wait in the barrier at the end)
+        pmc_args = argparse.Namespace(**vars(args))
+        if strong:  # the child profiles a launch of the rank's shard size, capped at what fits beside this process's arena
+            pmc_args.bases = max(K, min(sh.n_bases, 2_000_000_000))
+        child_timeout = 600 if world == 1 else 200
+        traffic, source = (None, "not measured (--no-pmc)") if args.no_pmc else measure_traffic(pmc_args, dev_index, child_timeout)
+        if traffic is None:
+            log(f"roofline.traffic: {source}")
+            traffic, source2 = replayed_traffic(args)
+            source = f"{source2}; live measurement: {source}"
+        rf["traffic"] = traffic
+        rf["traffic_source"] = source
+        if traffic is not None and pmc_args.bases - K + 1 != rf["kmers_per_launch"]:
+            rf["traffic_kmers_per_launch"] = pmc_args.bases - K + 1  # the profiled launch is shorter than the timed one
+            rf["traffic_over_algorithmic"] = round(traffic / (bytes_per_kmer * (pmc_args.bases - K + 1)), 4)
         if world == 1 and not args.no_other_configs:
+            valu = {} if args.no_pmc else measure_legs(pmc_args, dev_index, child_timeout)
             try:  # informative extras; never allowed to break the headline line
-                line["other_configs"] = other_configs(ctx, cap, stream, dev)
+                line["other_configs"] = other_configs(ctx, cap, stream, dev, mem, valu)
             except Exception as e:
                 line["other_configs"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(K, bits, seed, args.bases, args.cpu_budget)
         print(json.dumps(line), flush=True)
     if comm is not None:

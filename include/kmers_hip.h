@@ -113,13 +113,30 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 #define KMERS_PARAM_SKETCH_HOST_ONLY 4 /* kmers_minhash: 1 = use the host-feedback path even for small sketches (tests) */
 #define KMERS_PARAM_BATCH_PASSES 5     /* kmers_batch: elements per workgroup tile = 1024 * value (1..8); 0 = chosen from the batch size */
 #define KMERS_PARAM_SKETCH_BATCH_LDS 6 /* kmers_minhash_batch: candidate values per workgroup (2048 / 4096 / 8192); 0 = chosen per call */
+#define KMERS_PARAM_SUBTILES 7         /* strided tile kernels (kmers_spaced, kmers_minimizers): consecutive tiles per workgroup, the next one's source words in flight */
 int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
 
-/* device memory for hosts without their own HIP binding */
+/* ---- device memory ---------------------------------------------------------------------------
+ * For hosts without a HIP binding of their own (the reference allocates its outputs itself: `collect` makes one Vector per
+ * call).  kmers_dev_free first waits for the context's stream. */
 int kmers_dev_alloc(kmers_ctx *ctx, size_t bytes, void **out);
 int kmers_dev_free(kmers_ctx *ctx, void *p);
 int kmers_memcpy_h2d(kmers_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* The context's ARENA: one large block of HBM reserved once, out of which kmers_dev_alloc then serves every request that fits
+ * (best fit, KMERS_ARENA_GRANULE-aligned ranges; a request that does not fit falls through to a plain allocation;
+ * kmers_dev_free returns a range to the arena and merges it with its free neighbours).  Two reasons to use it: (1) a collect
+ * per sequence allocates and releases tens of gigabytes, and a plain allocation of that size costs the driver milliseconds; (2)
+ * on MI355X the write rate of the kernels depends on where their outputs were placed: into two freshly allocated 8 GB arrays
+ * the canonical + hash launch runs at 0.79 of 8 TB/s on a fresh machine, into ranges of one block of 64 GB or more at 0.82-0.84
+ * (profiles/r03_alloc.md).  bytes = 0 reserves three quarters of the memory that is free at the time of the call.  One arena per
+ * context; kmers_arena_release fails with KMERS_E_BADARG while blocks of it are allocated; kmers_ctx_destroy releases it. */
+#define KMERS_ARENA_GRANULE ((size_t)2 << 20)
+int kmers_arena_reserve(kmers_ctx *ctx, size_t bytes);
+int kmers_arena_release(kmers_ctx *ctx);
+/* any of the three outputs may be NULL; all zero when no arena is reserved */
+int kmers_arena_info(kmers_ctx *ctx, size_t *reserved, size_t *in_use, size_t *largest_free);
 
 /* ---- geometry (src/kmer.jl:117-137; iterator length()) ----------------------- */
 int kmers_words_per_kmer(int k, int dst_bits);                      /* n_coding_elements, kmer.jl:123-125 */

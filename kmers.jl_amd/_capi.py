@@ -11,6 +11,7 @@ from . import build as _build
 
 OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY, E_NCCL = range(8)
 COMM_ID_BYTES = 128
+ARENA_GRANULE = 2 << 20
 MEM_HOST, MEM_DEVICE, ASYNC, OUT_TUPLES = 0, 1, 2, 4
 BATCH_FW, BATCH_CANONICAL = 0, 1
 ITER_FW, ITER_CANONICAL, ITER_SPACED, ITER_UNAMBIGUOUS = 0, 1, 2, 3
@@ -18,7 +19,7 @@ SPANS_DEVICE = 8
 BATCH_SKIP = 16
 (OP_REVERSE, OP_COMPLEMENT, OP_REVCOMP, OP_CANONICAL, OP_ISCANONICAL, OP_TO_LONGSEQ, OP_COUNT_GC, OP_AS_INTEGER,
  OP_FROM_INTEGER) = range(9)
-PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY, PARAM_BATCH_PASSES, PARAM_SKETCH_BATCH_LDS = 1, 2, 3, 4, 5, 6
+PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY, PARAM_BATCH_PASSES, PARAM_SKETCH_BATCH_LDS, PARAM_SUBTILES = 1, 2, 3, 4, 5, 6, 7
 
 STATUS_NAMES = {OK: "KMERS_OK", E_ENCODE: "KMERS_E_ENCODE", E_BADARG: "KMERS_E_BADARG",
                 E_HIP: "KMERS_E_HIP", E_NOMEM: "KMERS_E_NOMEM",
@@ -59,6 +60,9 @@ SYMBOLS = {
     "kmers_ctx_set_param": (C.c_int, [_P, C.c_int, C.c_int64]),
     "kmers_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "kmers_dev_free": (C.c_int, [_P, _P]),
+    "kmers_arena_reserve": (C.c_int, [_P, C.c_size_t]),
+    "kmers_arena_release": (C.c_int, [_P]),
+    "kmers_arena_info": (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "kmers_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "kmers_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "kmers_words_per_kmer": (C.c_int, [C.c_int, C.c_int]),

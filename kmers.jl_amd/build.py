@@ -1,14 +1,26 @@
-"""Builds libkmers_hip.so (gfx950) in-tree with hipcc.  No other backend exists."""
+"""Builds libkmers_hip.so (gfx950) in-tree with hipcc.  No other backend exists.
+
+One translation unit per entry-point family of include/kmers_hip.h (csrc/api_common.hpp says which is which), compiled in
+parallel and incrementally: an object is rebuilt when its source or any header it includes (transitively) is newer.
+`build_variant` links the same objects with some units recompiled under extra -D flags: tuning / diagnostic builds, and the
+test build whose one-pass UnambiguousKmers kernel withholds a tile's aggregate (tests/test_gpu_parity.py).
+"""
 import os
+import re
 import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libkmers_hip.so")
-SOURCES = ["kmers_api.hip", "comm_api.hip"]  # iterators + consumers; RCCL communication
-HEADERS = ["context.hpp", "device_bits.hpp", "stream_kernel.hpp", "unambiguous_kernel.hpp", "wide_kernel.hpp", "composition_kernel.hpp", "run_kernel.hpp", "ragged_kernels.hpp", "record_sketch_kernel.hpp", "batch_kernels.hpp", "ascii_tables.hpp",
-           os.path.join("..", "..", "include", "kmers_hip.h")]
+SOURCES = ["iterators_api.hip", "consumers_api.hip", "unambiguous_api.hip", "batch_api.hip", "elementwise_api.hip", "context_api.hip",
+           "memory_api.hip", "comm_api.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-array-bounds"]
+# the look-back of unambiguous_kernel.hpp gives up instead of hanging the device; this build provokes it (one tile never
+# publishes its count) so that the abort / drain path and the host's KMERS_E_HIP are exercised once on hardware
+TEST_ABORT_LIB = os.path.join(CSRC, "libkmers_hip_testabort.so")
+TEST_ABORT = ("testabort", ["-DKMERS_TEST_ABORT"], ["unambiguous_api.hip"])
 
 
 def hipcc():
@@ -18,44 +30,110 @@ def hipcc():
     raise RuntimeError("hipcc not found: libkmers_hip.so cannot be built")
 
 
-def stale():
-    if not os.path.exists(LIB):
+_INCLUDE = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def dependencies(source):
+    """The source file and every quoted header it includes, transitively (absolute paths)."""
+    seen, todo = set(), [os.path.join(CSRC, source)]
+    while todo:
+        f = os.path.normpath(todo.pop())
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.add(f)
+        with open(f) as fh:
+            for inc in _INCLUDE.findall(fh.read()):
+                todo.append(os.path.join(os.path.dirname(f), inc))
+    return seen
+
+
+def _object(source, tag=""):
+    return os.path.join(OBJ, os.path.splitext(source)[0] + (f".{tag}" if tag else "") + ".o")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def stale(lib=LIB):
+    return _newer(lib, set().union(*(dependencies(s) for s in SOURCES)))
+
+
+def _compile(jobs, verbose):
+    """jobs: [(source, object, extra flags)] -- the stale ones, in parallel."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ, exist_ok=True)
+
+    def one(job):
+        src, obj, extra = job
+        tmp = f"{obj}.{os.getpid()}.tmp"
+        cmd = [hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.run(cmd, check=True, cwd=CSRC)
+            os.replace(tmp, obj)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    if jobs:
+        with ThreadPoolExecutor(min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(one, jobs))
+
+
+def _link(objs, lib, verbose):
+    # RCCL is NOT linked: comm_api.hip binds librccl.so.1 with dlopen at the first kmers_comm_* call; the RUNPATH hipcc
+    # writes (the ROCm lib directory) lets that dlopen find /opt/rocm's copy in a process that does not already hold one
+    tmp = f"{lib}.{os.getpid()}.tmp"  # atomic replace: concurrent builders / loaders never see a partial file
+    cmd = [hipcc()] + FLAGS + ["-shared", "-o", tmp] + objs + ["-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    try:
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        os.replace(tmp, lib)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
 
 
 def build(force=False, verbose=False):
-    """Compile the HIP kernels + C ABI for gfx950 and link them with the HIP runtime and RCCL.
+    """Compile the HIP kernels + C ABI for gfx950 and link them with the HIP runtime (RCCL is bound lazily, comm_api.hip).
     Returns the path of the shared library."""
-    if not force and not stale():
-        return LIB
-    from concurrent.futures import ThreadPoolExecutor
-    tag = f"{os.getpid()}.tmp"
-    common = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-array-bounds"]
-    objs = [os.path.join(CSRC, f"{os.path.splitext(s)[0]}.{tag}.o") for s in SOURCES]
-
-    def compile_one(i):
-        cmd = common + ["-c", os.path.join(CSRC, SOURCES[i]), "-o", objs[i]]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True, cwd=CSRC)
-    tmp = f"{LIB}.{tag}"  # atomic replace: concurrent builders / loaders never see a partial file
-    try:
-        with ThreadPoolExecutor(len(SOURCES)) as ex:
-            list(ex.map(compile_one, range(len(SOURCES))))
-        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), "lib")
-        cmd = common + ["-shared", "-o", tmp] + objs + [f"-L{rocm_lib}", "-lrccl"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True, cwd=CSRC)
-        os.replace(tmp, LIB)
-    finally:
-        for o in objs + [tmp]:
-            if os.path.exists(o):
-                os.remove(o)
+    jobs = [(s, _object(s), []) for s in SOURCES if force or _newer(_object(s), dependencies(s))]
+    _compile(jobs, verbose)
+    objs = [_object(s) for s in SOURCES]
+    if force or jobs or _newer(LIB, objs):
+        _link(objs, LIB, verbose)
     return LIB
 
 
+def build_variant(name, defines, units=None, out=None, force=False, verbose=False):
+    """libkmers_hip_<name>.so: the product's objects with `units` (default: all) recompiled under the extra flags `defines`."""
+    build(verbose=verbose)
+    units = list(units or SOURCES)
+    out = out or os.path.join(CSRC, f"libkmers_hip_{name}.so")
+    jobs = [(s, _object(s, name), list(defines)) for s in units if force or _newer(_object(s, name), dependencies(s))]
+    _compile(jobs, verbose)
+    objs = [_object(s, name) if s in units else _object(s) for s in SOURCES]
+    if force or jobs or _newer(out, objs):
+        _link(objs, out, verbose)
+    return out
+
+
+def build_test_abort(force=False, verbose=False):
+    name, defines, units = TEST_ABORT
+    return build_variant(name, defines, units, TEST_ABORT_LIB, force, verbose)
+
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "variant":  # python -m kmers_jl_amd.build variant <name> -DX ... [unit.hip ...]
+        nm = sys.argv[2]
+        print(build_variant(nm, [a for a in sys.argv[3:] if a.startswith("-")], [a for a in sys.argv[3:] if a.endswith(".hip")] or None,
+                            verbose=True))
+    else:
+        print(build(force=True, verbose=True))
+        print(build_test_abort(verbose=True))

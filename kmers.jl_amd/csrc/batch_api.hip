@@ -1,0 +1,405 @@
+// batch_api.hip -- batches of records (include/kmers_hip.h): kmers_batch / kmers_batch_spaced / kmers_minhash_batch, what the
+// per-record iterators would yield for every LongSubSeq view of a pool, in one launch sequence (ragged_kernels.hpp,
+// record_sketch_kernel.hpp).
+#include "../../include/kmers_hip.h"
+
+#include "api_common.hpp"
+#include "ragged_kernels.hpp"
+#include "record_sketch_kernel.hpp"
+#include "scan_kernels.hpp"
+
+using namespace kmers;
+
+// The pool as a DST-bit symbol stream: the pool itself when the kmer alphabet has the source's width (Copyable,
+// nothing can fail), else the output of the recode pass (stream in stage 4, flag bits in stage 5).
+struct PoolStream {
+    const uint64_t *stream = nullptr, *flags = nullptr, *any_flag = nullptr;
+};
+static int pool_stream(kmers_ctx *ctx, const kmers_seq *pool, const uint64_t *src0, uint64_t origin, uint64_t n_src_words, int dst_bits,
+                       PoolStream *out) {
+    (void)origin;
+    const int sb = pool->src_bits;
+    if (sb == dst_bits) {
+        out->stream = src0;
+        return KMERS_OK;
+    }
+    const size_t stream_bytes = (size_t)n_src_words * 8 * dst_bits / sb + 16, flag_bytes = (size_t)n_src_words * 8 / sb + 16;
+    if (int rc = ensure_stage(ctx, 4, stream_bytes)) return rc;
+    RecodeArgs r{};
+    r.src = src0;
+    r.n_words = n_src_words;
+    r.stream = static_cast<uint64_t *>(ctx->stage[4]);
+    r.ascii_table = ascii_table(ctx, dst_bits, pool->alphabet);
+    if (sb != 2) {
+        if (int rc = ensure_stage(ctx, 5, flag_bytes + 16)) return rc;
+        r.flags = static_cast<uint64_t *>(ctx->stage[5]);
+        r.any_flag = reinterpret_cast<uint64_t *>(static_cast<char *>(ctx->stage[5]) + ((flag_bytes + 7) & ~(size_t)7));
+        HIP_TRY(ctx, hipMemsetAsync(r.any_flag, 0, 8, ctx->stream));
+    }
+    if (n_src_words) {
+        dim3 rgrid((unsigned)std::min<uint64_t>((n_src_words + 255) / 256, (uint64_t)ctx->n_cus * 16)), rblock(256);
+        if (sb == 4) hipLaunchKernelGGL((recode_kernel<4, 2>), rgrid, rblock, 0, ctx->stream, r);
+        else if (sb == 2) hipLaunchKernelGGL((recode_kernel<2, 4>), rgrid, rblock, 0, ctx->stream, r);
+        else if (dst_bits == 2) hipLaunchKernelGGL((recode_kernel<8, 2>), rgrid, rblock, 0, ctx->stream, r);
+        else hipLaunchKernelGGL((recode_kernel<8, 4>), rgrid, rblock, 0, ctx->stream, r);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    out->stream = r.stream;
+    out->flags = r.flags;
+    out->any_flag = r.any_flag;
+    return KMERS_OK;
+}
+
+// EncodeError of a batch: the window that starts at symbol j (0-based) of record r holds the record's first symbol
+// that the kmer alphabet cannot encode (all earlier windows of the record were clean); find it on the host.
+static int report_window_error(kmers_ctx *ctx, const kmers_seq *pool, const uint64_t *src0, uint64_t origin, const RaggedSpan *d_spans,
+                               uint64_t r, uint64_t j, int k, int dst_bits, kmers_result *res) {
+    const int sb = pool->src_bits;
+    kmers_span bad_span;
+    HIP_TRY(ctx, hipMemcpy(&bad_span, d_spans + r, sizeof bad_span, hipMemcpyDeviceToHost));
+    const uint64_t p0 = bad_span.first_base + j + origin;     // symbol index from src0
+    const uint64_t wlo = p0 * sb / 64, whi = ((p0 + k) * sb + 63) / 64;
+    std::vector<uint64_t> w(whi - wlo);
+    HIP_TRY(ctx, hipMemcpyAsync(w.data(), src0 + wlo, w.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint8_t table[256];
+    if (sb == 8) {
+        const uint32_t tb = ascii_table(ctx, dst_bits, pool->alphabet);
+        for (uint32_t b = 0; b < 256u; ++b) table[b] = ascii_entry(tb, b);
+    }
+    for (uint64_t t = 0; t < (uint64_t)k; ++t) {
+        const uint64_t bit = (p0 + t) * sb - wlo * 64;
+        const uint32_t enc = (uint32_t)((w[bit >> 6] >> (bit & 63u)) & ((1ull << sb) - 1ull));
+        const bool bad = sb == 8 ? table[enc] == 0x80 : (sb == 4 && dst_bits == 2 && __builtin_popcount(enc) != 1);
+        if (bad) {
+            if (res) {
+                res->status = KMERS_E_ENCODE;
+                res->err_pos = j + t + 1;
+                res->err_enc = enc;
+                res->n_out = r;
+            }
+            ctx->last_error = "EncodeError: symbol cannot be encoded in the kmer alphabet";
+            return KMERS_E_ENCODE;
+        }
+    }
+    return fail(ctx, KMERS_E_HIP, "kmers_batch: a flagged window holds no offending symbol");
+}
+
+static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int mode, int k,
+                      int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
+                      uint64_t capacity, int flags, kmers_result *res, uint64_t stride = 1) {
+    clear(res);
+    if (stride == 0 || stride >= 0xFFFFFFFFull) return fail(ctx, KMERS_E_BADARG, "J must be at least 1 (and below 2^32)");
+    if (stride != 1 && mode != KMERS_BATCH_FW) return fail(ctx, KMERS_E_BADARG, "strided batches yield forward kmers (SpacedKmers)");
+    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP | INTERNAL_OUT_DEVICE))) {
+        if (res) res->status = rc;
+        return rc;
+    }
+    if (flags & (KMERS_ASYNC | KMERS_OUT_TUPLES)) return fail(ctx, KMERS_E_BADARG, "kmers_batch is synchronous and writes separate arrays");
+    if (mode != KMERS_BATCH_FW && mode != KMERS_BATCH_CANONICAL) return fail(ctx, KMERS_E_BADARG, "unknown batch mode");
+    if (n_spans && !spans) return fail(ctx, KMERS_E_BADARG, "spans is NULL");
+    const int nw = kmers_words_per_kmer(k, dst_bits);
+    if (nw > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_batch supports kmers of at most four words");
+    if (n_spans >= 0xFFFFFFFFull) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_batch supports fewer than 2^32 records per call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // ---- the ragged layout, on the device: spans -> HBM, elements per record, exclusive scan
+    const uint64_t n = n_spans;
+    if (n == 0) {
+        if (out_offsets) out_offsets[0] = 0;
+        return KMERS_OK;
+    }
+    const uint64_t n_seg = (n + SCAN_SEG - 1) / SCAN_SEG;
+    const size_t span_bytes = (size_t)n * 16, cnt_bytes = ((size_t)n * 4 + 15) & ~(size_t)15, off_bytes = ((size_t)n + 1) * 8,
+                 seg_bytes = ((size_t)n_seg + 2) * 8;
+    const bool spans_dev = (flags & KMERS_SPANS_DEVICE) != 0;
+    if (int rc = ensure_stage(ctx, 3, span_bytes + cnt_bytes + off_bytes + seg_bytes)) return rc;
+    char *meta = static_cast<char *>(ctx->stage[3]);
+    const RaggedSpan *d_spans = spans_dev ? reinterpret_cast<const RaggedSpan *>(spans) : reinterpret_cast<const RaggedSpan *>(meta);
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(meta + span_bytes);
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(meta + span_bytes + cnt_bytes);
+    uint64_t *d_seg = reinterpret_cast<uint64_t *>(meta + span_bytes + cnt_bytes + off_bytes);  // [n_seg + 1], then the bad-span flag
+    uint64_t *d_bad = d_seg + n_seg + 1;
+    if (!spans_dev) HIP_TRY(ctx, hipMemcpyAsync(meta, spans, span_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+    {
+        dim3 g((unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->n_cus * 16)), b(256);
+        hipLaunchKernelGGL(ragged_count_kernel, g, b, 0, ctx->stream, d_spans, n, (uint32_t)k, (uint32_t)stride, pool->n_bases, d_cnt, d_bad);
+        hipLaunchKernelGGL(scan_segment_sums_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, d_cnt, n, d_seg);
+        hipLaunchKernelGGL(scan_segments_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_seg, n_seg);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, d_cnt, n, d_seg, n_seg, d_off);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    uint64_t *h = reinterpret_cast<uint64_t *>(ctx->h_bounce);  // pinned: [total, bad]
+    HIP_TRY(ctx, hipMemcpyAsync(h, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + 1, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_offsets) HIP_TRY(ctx, hipMemcpyAsync(out_offsets, d_off, off_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t total = h[0];
+    if (h[1]) return fail(ctx, KMERS_E_BADARG, "a span reaches outside the pool (or holds 2^32 symbols or more)");
+    if (res) res->n_out = total;
+    if (total > capacity || (!out_a && !out_b)) {
+        if (total > capacity && (out_a || out_b)) {
+            if (res) res->status = KMERS_E_CAPACITY;
+            return fail(ctx, KMERS_E_CAPACITY, "output capacity too small");
+        }
+        return KMERS_OK;  // size query
+    }
+    if (total == 0) return KMERS_OK;
+    // tile = 1..8 passes of 1024 elements: long tiles amortise the two rounds of loads every tile starts with
+    // (each about 5 us under the store load), short ones keep a small batch spread over the device
+    uint64_t passes = total / ((uint64_t)RG_UNIT * (uint64_t)ctx->n_cus * 32u);
+    passes = std::min<uint64_t>(std::max<uint64_t>(passes, 1), (uint64_t)RG_MAX_PASSES);
+    // ... but not longer than the record slots staged in LDS allow (very short reads: many records per pass)
+    const uint64_t per_pass = (n * (uint64_t)RG_UNIT + total - 1) / total;  // records per 1024 elements, on average
+    passes = std::min<uint64_t>(passes, std::max<uint64_t>(1, (uint64_t)(RG_SLOTS * 7 / 8) / std::max<uint64_t>(per_pass, 1)));
+    // ... nor than the stretch of the stream a tile can stage (records lying far apart in the pool: a FASTQ buffer)
+    const uint64_t words_per_pass = (uint64_t)(1.1 * (double)pool->n_bases / (double)total * RG_UNIT * dst_bits / 64.0) + 1;
+    passes = std::min<uint64_t>(passes, std::max<uint64_t>(1, (uint64_t)(RG_STAGE * 7 / 8) / words_per_pass));
+    if (ctx->batch_passes > 0) passes = std::min<uint64_t>((uint64_t)ctx->batch_passes, (uint64_t)RG_MAX_PASSES);  // tests, tuning
+    // (the run path of the element kernel takes RG_PASS elements per workgroup pass: whole passes)
+    const uint32_t tile_elems = (uint32_t)((passes * RG_UNIT + RG_PASS - 1) / RG_PASS * RG_PASS);
+    const uint64_t n_tiles = (total + tile_elems - 1) / tile_elems;
+    if (int rc = ensure_stage(ctx, 6, (size_t)n_tiles * sizeof(RaggedTile))) return rc;
+    RaggedTile *d_tiles = static_cast<RaggedTile *>(ctx->stage[6]);
+
+    Staged st;
+    if (int rc = stage_sequence(ctx, pool, flags, &st)) return rc;
+    const bool dev = flags & KMERS_MEM_DEVICE;
+    const int sb = pool->src_bits;
+    const uint64_t *src0 = st.d_words + (st.first_bit >> 6);        // word that holds pool symbol 0
+    const uint64_t origin = (st.first_bit & 63u) / (uint64_t)sb;     // its symbol offset inside that word
+    const uint64_t n_src_words = ((origin + pool->n_bases) * (uint64_t)sb + 63) / 64;
+    hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_spans, n, n_tiles,
+                       total, tile_elems, (uint32_t)k, (uint32_t)stride, (uint32_t)dst_bits, origin, d_tiles);
+    HIP_TRY(ctx, hipGetLastError());
+
+    RaggedArgs a{};
+    a.rec_off = d_off;
+    a.spans = d_spans;
+    a.tiles = d_tiles;
+    a.n_records = n;
+    a.n_elems = total;
+    a.seed = seed;
+    a.err_slot = ctx->d_err;
+    a.k = (uint32_t)k;
+    a.skip = (flags & KMERS_BATCH_SKIP) ? 1u : 0u;
+    a.tile = tile_elems;
+    a.stride = (uint32_t)stride;
+    a.stream_origin = origin;
+    PoolStream ps;
+    if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;
+    a.stream = ps.stream;
+    a.flags = ps.flags;
+    a.any_flag = ps.any_flag;
+
+    uint64_t *d_a = out_a, *d_b = out_b;
+    const bool b_is_hash = mode == KMERS_BATCH_CANONICAL;
+    const size_t bytes_a = (size_t)total * nw * 8, bytes_b = (size_t)total * (b_is_hash ? 1 : nw) * 8;
+    const bool out_dev = dev || (flags & INTERNAL_OUT_DEVICE);
+    if (!out_dev) {
+        if (out_a) { if (int rc = ensure_stage(ctx, 1, bytes_a)) return rc; d_a = (uint64_t *)ctx->stage[1]; }
+        if (out_b) { if (int rc = ensure_stage(ctx, 2, bytes_b)) return rc; d_b = (uint64_t *)ctx->stage[2]; }
+    }
+    if ((nw == 2 || nw == 4) && ((d_a && !aligned16(d_a)) || (d_b && !b_is_hash && !aligned16(d_b))))
+        return fail(ctx, KMERS_E_BADARG, "two- and four-word kmer outputs must be 16-byte aligned");
+    a.out_a = d_a;
+    a.out_b = d_b;
+    const bool vec = (!d_a || aligned16(d_a)) && (!d_b || aligned16(d_b));
+    dim3 grid((unsigned)n_tiles), block(256);
+#define RG(DB, NN, MD)                                                                                         \
+    do {                                                                                                       \
+        if (vec && NN == 1) hipLaunchKernelGGL((ragged_kernel<DB, NN, MD, NN == 1>), grid, block, 0, ctx->stream, a);  \
+        else hipLaunchKernelGGL((ragged_kernel<DB, NN, MD, false>), grid, block, 0, ctx->stream, a);          \
+    } while (0)
+#define RGM(DB, NN) do { if (mode == KMERS_BATCH_FW) RG(DB, NN, MODE_FW); else RG(DB, NN, MODE_CANON); } while (0)
+#define RGN(DB) do { if (nw == 1) RGM(DB, 1); else if (nw == 2) RGM(DB, 2); else if (nw == 3) RGM(DB, 3); else RGM(DB, 4); } while (0)
+    if (dst_bits == 2) RGN(2);
+    else RGN(4);
+#undef RGN
+#undef RGM
+#undef RG
+    HIP_TRY(ctx, hipGetLastError());
+    if (!out_dev) {
+        if (out_a) HIP_TRY(ctx, hipMemcpyAsync(out_a, d_a, bytes_a, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_b) HIP_TRY(ctx, hipMemcpyAsync(out_b, d_b, bytes_b, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_scratch, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t g = ctx->h_result[1];
+    if (g == NO_ERROR_POS) {
+        if (res) res->status = KMERS_OK;
+        return KMERS_OK;
+    }
+    // EncodeError: element g is the first one whose window holds a symbol the kmer alphabet cannot encode;
+    // all earlier windows of its record were clean, so its first bad symbol is the record's first
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream));
+    std::vector<uint64_t> offs(n + 1);  // rare path: find the record on the host
+    HIP_TRY(ctx, hipMemcpyAsync(offs.data(), d_off, off_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t r = (uint64_t)(std::upper_bound(offs.begin(), offs.begin() + n, g) - offs.begin()) - 1;  // last record with off <= g
+    const uint64_t j = (g - offs[r]) * stride;                // 0-based start of the window inside the record
+    return report_window_error(ctx, pool, src0, origin, d_spans, r, j, k, dst_bits, res);
+}
+
+extern "C" {
+
+int kmers_batch_spaced(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, uint64_t stride,
+                       int dst_bits, uint64_t *out_kmers, uint64_t *out_offsets, uint64_t capacity, int flags, kmers_result *res) {
+    try {
+        return batch_impl(ctx, pool, spans, n_spans, KMERS_BATCH_FW, k, dst_bits, out_kmers, nullptr, 0, out_offsets, capacity, flags, res,
+                          stride);
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, KMERS_E_NOMEM, "host allocation failed in kmers_batch_spaced");
+    } catch (...) {
+        return fail(ctx, KMERS_E_HIP, "unexpected exception in kmers_batch_spaced");
+    }
+}
+
+int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int mode, int k,
+                int dst_bits, uint64_t *out_a, uint64_t *out_b, uint64_t seed, uint64_t *out_offsets,
+                uint64_t capacity, int flags, kmers_result *res) {
+    try {
+        return batch_impl(ctx, pool, spans, n_spans, mode, k, dst_bits, out_a, out_b, seed, out_offsets, capacity, flags, res);
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, KMERS_E_NOMEM, "host allocation failed in kmers_batch");
+    } catch (...) {
+        return fail(ctx, KMERS_E_HIP, "unexpected exception in kmers_batch");
+    }
+}
+
+// kmers_minhash_batch, fused: the recode pass (if the pool needs one), then one workgroup per record that derives the
+// record's hashes tile by tile and keeps its bottom-s (record_sketch_kernel.hpp).  No layout pass, no hash array.
+static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, int dst_bits,
+                               uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags, kmers_result *res) {
+    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP))) {
+        if (res) res->status = rc;
+        return rc;
+    }
+    if (flags & (KMERS_ASYNC | KMERS_OUT_TUPLES)) return fail(ctx, KMERS_E_BADARG, "kmers_minhash_batch is synchronous");
+    if (n_spans && !spans) return fail(ctx, KMERS_E_BADARG, "spans is NULL");
+    const int nw = kmers_words_per_kmer(k, dst_bits);
+    if (nw > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minhash_batch supports kmers of at most four words");
+    if (n_spans == 0) return KMERS_OK;
+    if (n_spans >= 0xFFFFFFFFull) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minhash_batch supports fewer than 2^32 records per call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = n_spans;
+    const bool spans_dev = (flags & KMERS_SPANS_DEVICE) != 0;
+    const size_t span_bytes = (size_t)n * 16;
+    if (int rc = ensure_stage(ctx, 3, span_bytes + 16)) return rc;
+    char *meta = static_cast<char *>(ctx->stage[3]);
+    const RaggedSpan *d_spans = spans_dev ? reinterpret_cast<const RaggedSpan *>(spans) : reinterpret_cast<const RaggedSpan *>(meta);
+    uint64_t *d_bad = reinterpret_cast<uint64_t *>(meta + span_bytes);
+    if (!spans_dev) HIP_TRY(ctx, hipMemcpyAsync(meta, spans, span_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+
+    Staged st;
+    if (int rc = stage_sequence(ctx, pool, flags, &st)) return rc;
+    const bool dev = flags & KMERS_MEM_DEVICE;
+    const int sb = pool->src_bits;
+    const uint64_t *src0 = st.d_words + (st.first_bit >> 6);        // word that holds pool symbol 0
+    const uint64_t origin = (st.first_bit & 63u) / (uint64_t)sb;     // its symbol offset inside that word
+    const uint64_t n_src_words = ((origin + pool->n_bases) * (uint64_t)sb + 63) / 64;
+    PoolStream ps;
+    if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;
+
+    const size_t out_bytes = (size_t)n * s * 8, cnt_out_bytes = (size_t)n * 8;
+    uint64_t *d_out = out_hashes, *d_cnt = out_counts;
+    if (!dev) {
+        if (int rc = ensure_stage(ctx, 1, out_bytes)) return rc;
+        if (int rc = ensure_stage(ctx, 2, cnt_out_bytes)) return rc;
+        d_out = static_cast<uint64_t *>(ctx->stage[1]);
+        d_cnt = static_cast<uint64_t *>(ctx->stage[2]);
+    }
+    // LDS per workgroup = the candidate buffer (+ 0.8 KiB of staged stream).  Short records (one tile of windows) need room
+    // for the sketch and that tile: 16 KiB keeps eight workgroups on a CU.  Long records leave about 1.8 s candidates
+    // below the provisional threshold: 32 KiB holds them without a merge half way.
+    const bool long_records = pool->n_bases / n > 1024;
+    const uint32_t run = long_records ? 8u : 4u, rs_tile = 256u * run;
+    uint32_t cap = long_records ? 4096u : 2048u;
+    while (cap < (uint32_t)s + rs_tile) cap <<= 1;
+    if (ctx->sketch_batch_lds == 2048 || ctx->sketch_batch_lds == 4096 || ctx->sketch_batch_lds == 8192)  // tuning (a power of two)
+        cap = std::max<uint32_t>(cap, (uint32_t)ctx->sketch_batch_lds);
+    RecordSketchArgs a{};
+    a.stream = ps.stream;
+    a.flags = ps.flags;
+    a.any_flag = ps.any_flag;
+    a.stream_origin = origin;
+    a.spans = d_spans;
+    a.pool_bases = pool->n_bases;
+    a.seed = seed;
+    a.out = d_out;
+    a.counts = d_cnt;
+    a.err_slot = ctx->d_err;
+    a.bad = d_bad;
+    a.k = (uint32_t)k;
+    a.s = (uint32_t)s;
+    a.skip = (flags & KMERS_BATCH_SKIP) ? 1u : 0u;
+    a.cap = cap;
+    const size_t lds = ((size_t)cap + RS_STAGE + RS_FSTAGE) * 8;
+    dim3 grid((unsigned)n), block(256);
+#define RS(DB, NN, RR)                                                                                                                  \
+    do {                                                                                                                                \
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(record_sketch_kernel<DB, NN, RR>),                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SEG_VALUES + RS_STAGE + RS_FSTAGE) * 8))); \
+        hipLaunchKernelGGL((record_sketch_kernel<DB, NN, RR>), grid, block, lds, ctx->stream, a);                                       \
+    } while (0)
+#define RSR(DB, NN) do { if (run == 8u) RS(DB, NN, 8); else RS(DB, NN, 4); } while (0)
+#define RSN(DB) do { if (nw == 1) RSR(DB, 1); else if (nw == 2) RSR(DB, 2); else if (nw == 3) RSR(DB, 3); else RSR(DB, 4); } while (0)
+    if (dst_bits == 2) RSN(2);
+    else RSN(4);
+#undef RSR
+#undef RSN
+#undef RS
+    HIP_TRY(ctx, hipGetLastError());
+    if (!dev) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_hashes, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(out_counts, d_cnt, cnt_out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_scratch, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result + 2, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t g = ctx->h_result[1];
+    if (g != NO_ERROR_POS) HIP_TRY(ctx, hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream));
+    if (ctx->h_result[2]) return fail(ctx, KMERS_E_BADARG, "a span reaches outside the pool (or holds 2^32 symbols or more)");
+    if (g != NO_ERROR_POS)  // (record << 32 | window): the first failing record in batch order, its first failing window
+        return report_window_error(ctx, pool, src0, origin, d_spans, g >> 32, g & 0xFFFFFFFFull, k, dst_bits, res);
+    if (res) {
+        res->status = KMERS_OK;
+        res->n_out = n_spans;
+    }
+    return KMERS_OK;
+}
+
+static int minhash_batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, int dst_bits,
+                              uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags, kmers_result *res) {
+    clear(res);
+    if (!ctx) return KMERS_E_BADARG;
+    if (s == 0 || s > SEG_VALUES / 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minhash_batch supports sketch sizes 1..2048");
+    if (n_spans && (!out_hashes || !out_counts)) return fail(ctx, KMERS_E_BADARG, "out_hashes / out_counts is NULL");
+    return minhash_batch_fused(ctx, pool, spans, n_spans, k, dst_bits, seed, s, out_hashes, out_counts, flags, res);
+}
+
+int kmers_minhash_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, int dst_bits,
+                        uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags, kmers_result *res) {
+    try {
+        return minhash_batch_impl(ctx, pool, spans, n_spans, k, dst_bits, seed, s, out_hashes, out_counts, flags, res);
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, KMERS_E_NOMEM, "host allocation failed in kmers_minhash_batch");
+    } catch (...) {
+        return fail(ctx, KMERS_E_HIP, "unexpected exception in kmers_minhash_batch");
+    }
+}
+
+}  // extern "C"
+
+#ifdef KMERS_RG_PROBE
+extern "C" int kmers_debug_rg_probe(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(kmers::rg_probe), 128) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(kmers::rg_probe), z, 128) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

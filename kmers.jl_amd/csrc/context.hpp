@@ -4,9 +4,19 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
 #include <string>
 
 #include "../../include/kmers_hip.h"
+
+// The context's device-memory arena (kmers_arena_reserve, include/kmers_hip.h): ONE hipMalloc, sub-allocated in 2 MiB
+// granules by kmers_dev_alloc.  Offsets are relative to `base`; free ranges are kept coalesced.
+struct kmers_arena {
+    char *base = nullptr;
+    size_t bytes = 0;
+    std::map<size_t, size_t> free_ranges;  // offset -> length
+    std::map<size_t, size_t> used;         // offset -> length
+};
 
 struct kmers_ctx {
     int device = 0;
@@ -23,11 +33,13 @@ struct kmers_ctx {
     std::string last_error;
     int64_t tile_kmers = 0;  // 0 = default
     int64_t max_grid = 0;    // 0 = default
+    int64_t subtiles = 0;    // KMERS_PARAM_SUBTILES; 0 = default
     int64_t stamps_ptr = 0;  // diagnostic builds only (KMERS_PARAM_STAMPS_PTR)
     int n_cus = 256;                // multiProcessorCount
     bool sketch_host_only = false;  // KMERS_PARAM_SKETCH_HOST_ONLY: force the host-feedback MinHash path (tests)
     int64_t batch_passes = 0;       // KMERS_PARAM_BATCH_PASSES (tests, tuning); 0 = default
     int64_t sketch_batch_lds = 0;   // KMERS_PARAM_SKETCH_BATCH_LDS (tuning); 0 = default
+    kmers_arena arena;              // memory_api.hip
 };
 
 namespace kmers {

@@ -4,11 +4,11 @@
 // the tile's stretch of the (recoded) stream is staged in LDS, every lane derives four consecutive
 // canonical kmers (first window cut out of the staged words, the others by the reference's rolling step,
 // CanonicalKmers.jl:131-144) and their fx_hash (kmer.jl:255-261), and the values below the record's running
-// threshold are appended to the candidate buffer described in batch_kernels.hpp (segment_merge).
+// threshold are appended to the candidate buffer described in segment_sort.hpp (segment_merge).
 // Nothing but the pool is read and nothing but the sketches is written: 0.25-0.5 B per base instead of the
 // 16 B per kmer of hashes written and read back.
 #pragma once
-#include "batch_kernels.hpp"
+#include "segment_sort.hpp"
 #include "ragged_kernels.hpp"
 
 namespace kmers {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchAr
     const uint64_t *flags = (a.flags && *a.any_flag) ? a.flags : nullptr;
     const uint64_t mask = head_mask((int)k, DST);
     uint32_t nb = 0;
-    for (int pass = 0; pass < 2; ++pass) {     // pass 0: provisional threshold (batch_kernels.hpp); pass 1: without it
+    for (int pass = 0; pass < 2; ++pass) {     // pass 0: provisional threshold (segment_sort.hpp); pass 1: without it
         const double frac = n ? (1.5 * (double)s + 8.0 * sqrt((double)s) + 32.0) / (double)n : 1.0;
         const bool provisional = pass == 0 && frac < 0.5;
         uint64_t threshold = ~0ull;

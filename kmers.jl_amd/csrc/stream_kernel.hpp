@@ -42,6 +42,7 @@ struct StreamArgs {
     uint32_t k;
     uint32_t stride;
     uint32_t tile_kmers;
+    uint32_t subtiles;       // strided kernels: consecutive tiles per workgroup, the next one's source words in flight (0 = 1)
     uint32_t xor_canonical;  // MODE_XOR: 1 = canonical kmers, 0 = forward kmers
     uint64_t *stamps;        // diagnostic builds (-DKMERS_STAMPS) only: per-workgroup s_memrealtime stamps
     uint32_t ascii_table;     // SRC_BITS == 8: which byte -> symbol table (ascii_entry(), ascii_tables.hpp)
@@ -344,7 +345,6 @@ __device__ __forceinline__ void sketch_candidate(const StreamArgs &a, uint64_t h
 template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1, bool TUPLES = false, bool PAIR = false, bool FWD = false>
 __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     static_assert(!FWD || (MODE == MODE_FW && DST == 2 && !TUPLES), "FWD: forward kmers of a 2-bit alphabet, separate arrays");
-    __shared__ uint64_t lds[LDS_QWORDS];
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t k = a.k;
@@ -368,42 +368,79 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     uint32_t *count_base = nullptr;
     if constexpr (MODE == MODE_COUNT) count_base = reinterpret_cast<uint32_t *>(a.out_a);
 
-    for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const uint64_t m0 = tile * a.tile_kmers;
-        const uint64_t left = a.n_kmers - m0;
-        const uint32_t mt = left < a.tile_kmers ? (uint32_t)left : a.tile_kmers;
-        const uint64_t bit0 = a.first_bit + m0 * J * SRC_BITS;
-        const uint64_t w0 = bit0 >> 6;
-        const uint32_t b0 = (uint32_t)(bit0 & 63u) / SRC_BITS;
-        const uint32_t span = MODE == MODE_MINIMIZER ? k + a.window_kmers - 1u : k;  // symbols one element reads
-        const uint64_t end_bit = bit0 + ((uint64_t)(mt - 1) * J + span) * SRC_BITS;
-        const uint32_t nw = (uint32_t)(((end_bit + 63) >> 6) - w0);
-
+    // A strided tile reads `stride` times the source per output byte (769 words in front of the first store of 4096
+    // SpacedDNAMers{21,3} windows), and under the kernel's own store traffic a round of loads takes several microseconds: a
+    // workgroup of such a kernel visits `subtiles` CONSECUTIVE tiles and has the next tile's words in flight (registers) while it
+    // stores the current one; the stream is double-buffered in LDS so that one barrier per tile suffices.  Stride-1 kernels keep
+    // one tile per visit (their load round is a quarter of a load per lane; short-lived workgroups write fastest).
+    constexpr uint32_t NBUF = STRIDE1 ? 1u : 2u;
+    constexpr uint32_t PRE = STRIDE1 ? 1u : (SRC_BITS == 8 ? 8u : 4u);  // words per lane of one load round (in flight together)
+    __shared__ uint64_t lds_all[NBUF][LDS_QWORDS];
+    struct Geom {
+        uint64_t m0, w0;
+        uint32_t mt, b0, nw, span;
+    };
+    auto geometry = [&](uint64_t tile) {
+        Geom g;
+        g.m0 = tile * a.tile_kmers;
+        const uint64_t left = a.n_kmers - g.m0;
+        g.mt = left < a.tile_kmers ? (uint32_t)left : a.tile_kmers;
+        const uint64_t bit0 = a.first_bit + g.m0 * J * SRC_BITS;
+        g.w0 = bit0 >> 6;
+        g.b0 = (uint32_t)(bit0 & 63u) / SRC_BITS;
+        g.span = MODE == MODE_MINIMIZER ? k + a.window_kmers - 1u : k;  // symbols one element reads
+        const uint64_t end_bit = bit0 + ((uint64_t)(g.mt - 1) * J + g.span) * SRC_BITS;
+        g.nw = (uint32_t)(((end_bit + 63) >> 6) - g.w0);
+        return g;
+    };
+    auto load_round = [&](const Geom &g, uint32_t base, uint64_t (&x)[PRE]) {  // all of a lane's loads of a round are issued together
+#pragma unroll
+        for (uint32_t j = 0; j < PRE; ++j) {
+            const uint32_t wi = base + j * BLOCK + tid;
+            x[j] = wi < g.nw ? a.src[g.w0 + wi] : 0;
+        }
+    };
+    auto stage_round = [&](const Geom &g, uint32_t base, const uint64_t (&x)[PRE], uint64_t *lds) {
+#pragma unroll
+        for (uint32_t j = 0; j < PRE; ++j) {
+            const uint32_t wi = base + j * BLOCK + tid;
+            if (wi < g.nw) {
+                uint64_t f = stage_word<SRC_BITS, DST, FWD>(lds, FWD ? g.nw - 1u - wi : wi, x[j], lut, text);
+                if constexpr ((SRC_BITS == 4 && DST == 2) || SRC_BITS == 8) {
+                    // `span` symbols per element are read (K, or K + W - 1 for minimizer windows): gaps start after them
+                    if (f) report_bad_symbols<SRC_BITS, STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, g.span, g.w0 + wi, f, x[j], a.err_origin);
+                }
+            }
+        }
+    };
+    const uint64_t S = STRIDE1 || a.subtiles == 0 ? 1u : a.subtiles;
+    uint32_t buf = 0;
+    for (uint64_t visit = blockIdx.x; visit * S < a.n_tiles; visit += gridDim.x) {
+      const uint64_t t_end = (visit + 1) * S < a.n_tiles ? (visit + 1) * S : a.n_tiles;
+      uint64_t xpre[PRE];
+      Geom gn = geometry(visit * S);
+      if constexpr (!STRIDE1) load_round(gn, 0, xpre);  // the first tile of the visit: nothing to hide behind
+      for (uint64_t tile = visit * S; tile < t_end; ++tile) {
+        const Geom g = gn;
+        const uint64_t m0 = g.m0;
+        const uint32_t mt = g.mt, b0 = g.b0, nw = g.nw;
+        uint64_t *const lds = lds_all[buf];
 #ifdef KMERS_STAMPS
         uint64_t t0 = __builtin_amdgcn_s_memrealtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 #endif
-        block_sync();  // previous tile's readers are done with the LDS stream
         // ---- phase 1: source words -> DST-bit stream in LDS ------------------------------
-        // (strided tiles span several words per lane -- 769 for 4096 SpacedDNAMers{21,3} windows of a 4-bit source: all of a
-        // lane's loads are issued before the first is used, so that the tile pays one memory latency, not one per round)
-        constexpr uint32_t PRE = STRIDE1 ? 1u : 4u;
-        for (uint32_t base = 0; base < nw; base += PRE * BLOCK) {
-            uint64_t x[PRE];
-#pragma unroll
-            for (uint32_t j = 0; j < PRE; ++j) {
-                const uint32_t wi = base + j * BLOCK + tid;
-                x[j] = wi < nw ? a.src[w0 + wi] : 0;
+        if constexpr (STRIDE1) {
+            block_sync();  // previous tile's readers are done with the LDS stream
+            for (uint32_t base = 0; base < nw; base += PRE * BLOCK) {
+                load_round(g, base, xpre);
+                stage_round(g, base, xpre, lds);
             }
-#pragma unroll
-            for (uint32_t j = 0; j < PRE; ++j) {
-                const uint32_t wi = base + j * BLOCK + tid;
-                if (wi < nw) {
-                    uint64_t f = stage_word<SRC_BITS, DST, FWD>(lds, FWD ? nw - 1u - wi : wi, x[j], lut, text);
-                    if constexpr ((SRC_BITS == 4 && DST == 2) || SRC_BITS == 8) {
-                        // `span` symbols per element are read (K, or K + W - 1 for minimizer windows): gaps start after them
-                        if (f) report_bad_symbols<SRC_BITS, STRIDE1>(a.err_slot, a.first_bit, a.inspect_end, a.stride, span, w0 + wi, f, x[j], a.err_origin);
-                    }
-                }
+        } else {
+            // (no barrier in front: this buffer's readers -- the tile before last -- all passed the barrier below since)
+            stage_round(g, 0, xpre, lds);
+            for (uint32_t base = PRE * BLOCK; base < nw; base += PRE * BLOCK) {  // (tiles longer than one round: not prefetched)
+                load_round(g, base, xpre);
+                stage_round(g, base, xpre, lds);
             }
         }
 #ifdef KMERS_STAMPS
@@ -413,6 +450,13 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
 #ifdef KMERS_STAMPS
         t2 = __builtin_amdgcn_s_memrealtime();
 #endif
+        if constexpr (!STRIDE1) {
+            if (tile + 1 < t_end) {  // the next tile's words travel while this one is stored
+                gn = geometry(tile + 1);
+                load_round(gn, 0, xpre);
+            }
+            buf ^= 1u;
+        }
 
         // ---- phase 2: windows -> kmers ---------------------------------------------------
         for (uint32_t r = tid * KPL; r < mt; r += BLOCK * KPL) {
@@ -566,6 +610,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
             o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = tile;
         }
 #endif
+      }
     }
 
     if constexpr (MODE == MODE_XOR) {

@@ -1,0 +1,122 @@
+// stream_launch.hpp -- host-side launcher of stream_kernel (tile choice, template dispatch).  A template over the kernel's MODE:
+// each translation unit instantiates only the modes it launches (iterators_api.hip: FW, CANON; consumers_api.hip: XOR, SKETCH,
+// COUNT, MINIMIZER), so no kernel is compiled twice.
+#pragma once
+#include "api_common.hpp"
+
+namespace kmers {
+
+// Default tile: about 16 KiB of output per workgroup (four 16-byte stores per lane), one tile
+// per workgroup.  Measured on MI355X (profiles/r01_tuning.md): shorter workgroups are bound by
+// workgroup launch + the exposed source-load latency, longer ones and persistent grid-stride
+// loops lose 10-20 % of the HBM write rate.
+constexpr int64_t DEFAULT_SUBTILES = 3;
+
+inline uint32_t default_tile(uint32_t out_bytes_per_kmer, uint32_t pass) {
+    uint32_t t = (16384u / std::max<uint32_t>(out_bytes_per_kmer, 1u)) / pass * pass;
+    return std::max<uint32_t>(pass, t);
+}
+
+template <int MODE, int SB, int DB>
+void launch_widths(int n_words, bool s1, bool pair, bool fwd, dim3 grid, dim3 block, hipStream_t st, const StreamArgs &a, size_t dyn_lds) {
+    if constexpr (MODE == MODE_FW && DB == 2) {
+        if (fwd) {  // forward kmers only: kmer-order staging (stream_kernel.hpp, FWD)
+            if (pair) {
+                hipLaunchKernelGGL((stream_kernel<SB, DB, 1, MODE, false, false, true, true>), grid, block, dyn_lds, st, a);
+                return;
+            }
+#define LAUNCH_FWD(NN)                                                                                                    \
+    do {                                                                                                                  \
+        if (s1) hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, true, false, false, true>), grid, block, dyn_lds, st, a);  \
+        else hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, false, false, false, true>), grid, block, dyn_lds, st, a);    \
+    } while (0)
+            switch (n_words) {
+                case 1: LAUNCH_FWD(1); break;
+                case 2: LAUNCH_FWD(2); break;
+                case 3: LAUNCH_FWD(3); break;
+                default: LAUNCH_FWD(4); break;
+            }
+#undef LAUNCH_FWD
+            return;
+        }
+    }
+    if constexpr (MODE == MODE_FW || MODE == MODE_CANON) {
+        if (a.tuples) {  // array-of-structs outputs: one kmer per lane per pass
+            switch (n_words) {
+                case 1: hipLaunchKernelGGL((stream_kernel<SB, DB, 1, MODE, false, true>), grid, block, dyn_lds, st, a); break;
+                case 2: hipLaunchKernelGGL((stream_kernel<SB, DB, 2, MODE, false, true>), grid, block, dyn_lds, st, a); break;
+                case 3: hipLaunchKernelGGL((stream_kernel<SB, DB, 3, MODE, false, true>), grid, block, dyn_lds, st, a); break;
+                default: hipLaunchKernelGGL((stream_kernel<SB, DB, 4, MODE, false, true>), grid, block, dyn_lds, st, a); break;
+            }
+            return;
+        }
+    }
+    if constexpr (MODE == MODE_FW || MODE == MODE_XOR) {
+        if (pair) {  // strided one-word kmers, two lattice kmers per lane (16-byte stores)
+            hipLaunchKernelGGL((stream_kernel<SB, DB, 1, MODE, false, false, true>), grid, block, dyn_lds, st, a);
+            return;
+        }
+    }
+#define LAUNCH(NN)                                                                                   \
+    do {                                                                                             \
+        if (s1) hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, true>), grid, block, dyn_lds, st, a);  \
+        else hipLaunchKernelGGL((stream_kernel<SB, DB, NN, MODE, false>), grid, block, dyn_lds, st, a);    \
+    } while (0)
+    switch (n_words) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+}
+
+template <int MODE>
+int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int n_words, bool vec_ok, size_t dyn_lds = 0) {
+    // the tile kernel is instantiated for one to four words; wider kmers belong to wide_kernel.hpp / the run-time-width
+    // single-pass kernel and a caller that comes here with them must hear about it
+    if (n_words < 1 || n_words > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "internal: the tile kernel takes kmers of one to four words");
+    const uint32_t J = a.stride;
+    const bool stride1 = (J == 1) && vec_ok && !a.tuples;
+    const bool pair = (MODE == MODE_FW || MODE == MODE_XOR) && J > 1 && vec_ok && !a.tuples && n_words == 1;
+#ifdef KMERS_NO_FWD  // A/B builds only
+    const bool fwd = false;
+#else
+    const bool fwd = MODE == MODE_FW && dst_bits == 2 && !a.out_b && !a.tuples;  // no reverse complements wanted
+#endif
+    const uint32_t pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * BLOCK;  // kmers per workgroup pass
+    uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
+                         (MODE == MODE_CANON && a.out_b ? 8u : 0u) + (MODE == MODE_FW && a.out_starts ? 8u : 0u);
+    if (a.tuples) out_bytes = MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u;
+    if (MODE == MODE_XOR || MODE == MODE_SKETCH || MODE == MODE_COUNT) out_bytes = 4u;  // nothing streamed out: long tiles
+    if (MODE == MODE_MINIMIZER) out_bytes = 8u * n_words;
+    uint32_t max_tile_symbols = (uint32_t)MAX_TILE_BITS / (uint32_t)dst_bits;
+    if (MODE == MODE_MINIMIZER) max_tile_symbols -= std::min<uint32_t>(max_tile_symbols / 2, a.window_kmers);  // room for the longer overlap
+    uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
+    // strided tiles read `stride` times the source per element: twice the output per workgroup amortises the longer load
+    // phase (SpacedDNAMers{21,3} over 1 Gbase: 0.64-0.68 -> 0.71-0.74 of 8 TB/s, profiles/r02_tuning.md)
+    if (ctx->tile_kmers <= 0 && J > 1 && MODE == MODE_FW) tile *= 2;
+    tile = std::min<uint32_t>(tile, max_tile_symbols / J);
+    tile = std::max<uint32_t>(pass, tile / pass * pass);
+    if ((uint64_t)(tile - 1) * J + 1 > (uint64_t)max_tile_symbols) return fail(ctx, KMERS_E_UNSUPPORTED, "stride too large for the tile kernel");
+    a.tile_kmers = tile;
+    a.n_tiles = (a.n_kmers + tile - 1) / tile;
+    // strided kernels: consecutive tiles per workgroup visit, the next tile's source words in flight behind the current tile's
+    // stores (stream_kernel.hpp; profiles/r03_tuning.md)
+    a.subtiles = J > 1 ? (uint32_t)(ctx->subtiles > 0 ? ctx->subtiles : DEFAULT_SUBTILES) : 1u;
+    a.stamps = reinterpret_cast<uint64_t *>(ctx->stamps_ptr);
+    uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
+    const uint64_t visits = (a.n_tiles + a.subtiles - 1) / a.subtiles;
+    dim3 grid((unsigned)std::min<uint64_t>(visits, cap));
+    dim3 block(BLOCK);
+    if (src_bits == 8 && dst_bits == 2) launch_widths<MODE, 8, 2>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 8) launch_widths<MODE, 8, 4>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 2 && dst_bits == 2) launch_widths<MODE, 2, 2>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
+    else if (src_bits == 4 && dst_bits == 4) launch_widths<MODE, 4, 4>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
+    else launch_widths<MODE, 2, 4>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
+    HIP_TRY(ctx, hipGetLastError());
+    return KMERS_OK;
+}
+
+}  // namespace kmers

@@ -48,6 +48,14 @@ constexpr uint32_t USLICE = UROUND / 64;  // consecutive starts per lane
 #define KMERS_ULIST 1024
 #endif
 constexpr uint32_t ULONG = KMERS_ULONG, ULIST = KMERS_ULIST;
+// The emitting path stores in FRAMES: 128 consecutive output elements, aligned to 128 in the OUTPUT index (lane l of a frame owns
+// elements 2l and 2l + 1: one 16-byte store per lane and array, 1 KiB = eight whole 128-byte lines per wave store).  What a
+// round lists beyond its last whole frame stays at the head of the list for the next round (fewer than UFRAME entries), so a
+// wavefront issues partial store instructions only at the two ends of its quarter of the tile, not at the ends of every round
+// (with 14-28 % of the starts kept a 2048-start round used to end in a store pass that was 25-50 % full, plus up to four
+// one-lane stores for odd heads and tails: 45-65 % of the bytes a store instruction can carry, profiles/r03_unamb.md).
+constexpr uint32_t UFRAME = 128;
+constexpr uint32_t ULSTRIDE = ULIST + UFRAME;  // list entries per wavefront: a round's kept starts behind the carried ones
 static_assert(ULIST >= UROUND, "a short round may keep every one of its starts");
 static_assert(ULONG % UROUND == 0 && (ULONG == 1024 || ULONG == 2048 || ULONG == 4096) && 64 % USLICE == 0, "a lane's slice of a round lies in one keep-mask qword");
 #ifndef KMERS_UNAMB_WGS
@@ -61,8 +69,14 @@ constexpr int LOOKBACK = 4;               // descriptors per lane and look-back 
 // SPIN_LIMIT times (well over a second; a tile publishes its aggregate microseconds after its ticket), then raises the abort
 // flag, which every other look-back checks every SPIN_CHECK polls: the kernel drains and the host reports KMERS_E_HIP
 // instead of hanging the device.
+#ifdef KMERS_TEST_ABORT
+// test build (kmers_jl_amd/build.py: build_test_abort): tile 1 never publishes its aggregate, so the look-back of tile 2 runs
+// into the limit, raises the abort flag, every workgroup drains and the host reports KMERS_E_HIP -- the path that cannot be
+// provoked on a healthy device, exercised once (tests/test_gpu_parity.py::test_unambiguous_lookback_gives_up_instead_of_hanging)
+constexpr uint32_t SPIN_CHECK = 64, SPIN_LIMIT = 1u << 12;
+#else
 constexpr uint32_t SPIN_CHECK = 1024, SPIN_LIMIT = 1u << 22;
-        // descriptors per lane and look-back step (256 per step)
+#endif
 
 enum UMode { UMODE_EMIT = 0, UMODE_COUNT = 1, UMODE_XOR = 2 };
 
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     // flag stream (between stage and resolve of the tile ahead) and, in the same space, the per-wavefront lists of kept starts
     // of the tile being emitted: the flag stream is dead by then (the scan's barrier lies between its last reader and the first
     // list entry, the barrier that opens the next front between the last list reader and the next flag)
-    constexpr uint32_t LIST_BYTES = UMODE == UMODE_COUNT ? 0u : (uint32_t)WAVES * ULIST * 2u;
+    constexpr uint32_t LIST_BYTES = UMODE == UMODE_COUNT ? 0u : (uint32_t)WAVES * ULSTRIDE * 2u;
     constexpr uint32_t AMB_ALLOC = AMB_QWORDS * 8u > LIST_BYTES ? AMB_QWORDS : (LIST_BYTES + 7u) / 8u;
     __shared__ uint64_t amb[AMB_ALLOC];
     uint16_t *const kept = reinterpret_cast<uint16_t *>(amb);
@@ -316,6 +330,9 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         if (tid == 0) {
             if constexpr (UMODE == UMODE_COUNT) acc += tile_total;
             // the aggregate is out as early as it can be: the tiles behind this one wait for nothing else of it
+#ifdef KMERS_TEST_ABORT
+            if (tile != 1)
+#endif
             if constexpr (EMIT) desc_store(a.desc + tile, (tile == 0 ? DESC_PREFIX : DESC_AGGREGATE) | (uint64_t)tile_total);
         }
         USTAMP(4);
@@ -375,6 +392,9 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                         pos -= 64 * LOOKBACK;
                     }
                     excl = wave_sum64(part);
+#ifdef KMERS_TEST_ABORT
+                    if (tile != 1)  // (nor its prefix: tile 1 stays silent)
+#endif
                     if (lane == 0) desc_store(a.desc + tile, DESC_PREFIX | ((excl + (uint64_t)tile_total) & DESC_VALUE));
                 }
                 if (lane == 0) s_base = excl;
@@ -387,7 +407,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
 
         // every wavefront takes the CONTIGUOUS quarter of the tile whose keep mask its own lanes resolved, so that its stores
         // sweep one contiguous region of each output array and the mask never leaves the registers
-        uint16_t *mine = kept + wave * ULIST;
+        uint16_t *mine = kept + wave * ULSTRIDE;
         const uint32_t qw0 = wave * WQ;                                       // the wavefront's first qword
         const uint32_t wave_end = (qw0 + WQ) * 64u < mt ? (qw0 + WQ) * 64u : mt;
         // kept starts of the tile before qword qw0 + qrel (qrel <= WQ, the same in every lane)
@@ -401,8 +421,147 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             }
             return v;
         };
+        bool framed = false;
+        if constexpr (EMIT && !WIDE) framed = a.vec16 && !a.tuples;
+        if constexpr (EMIT && !WIDE) {
+            if (framed) {
+                // ---- the framed path (separate 16-byte aligned arrays, kmers of one to four words) -------------------------
+                const uint32_t qbase = qw0 * 64u;                       // tile-relative start of the wavefront's quarter
+                const uint64_t origin = m0 + 1 + a.index_origin;        // start of candidate r is origin + r
+                uint32_t list_n = 0;                                    // listed, not yet emitted (quarter-relative starts)
+                uint64_t list_pos = base + prefix_at(0);                // output index of the first element not yet emitted
+                // elements with output indexes [lo, hi) -> memory, frame by frame; start_of(j) = tile-relative start of element lo + j
+                auto emit_range = [&](uint64_t lo, uint64_t hi, auto start_of) {
+                    for (uint64_t P = lo & ~(uint64_t)(UFRAME - 1u); P < hi; P += UFRAME) {
+                        const uint64_t i0 = P + 2u * lane, i1 = i0 + 1u;
+                        const bool v0 = i0 >= lo && i0 < hi && i0 < a.capacity, v1 = i1 >= lo && i1 < hi && i1 < a.capacity;
+                        if (!(v0 || v1)) continue;
+                        uint32_t ra = 0, rb = 0;
+                        uint64_t fa[NW], fb[NW];
+                        if (v0) {
+                            ra = start_of((uint32_t)(i0 - lo));
+                            cut_fw<NW>(lds, kbit0 - 2u * ra, mask, fa);
+                        }
+                        if (v1) {
+                            rb = start_of((uint32_t)(i1 - lo));
+                            cut_fw<NW>(lds, kbit0 - 2u * rb, mask, fb);
+                        }
+                        if (v0 && v1) {
+                            if (a.out_kmers) {
+                                if constexpr (N == 1) {
+                                    *reinterpret_cast<ulonglong2 *>(a.out_kmers + i0) = make_ulonglong2(fa[0], fb[0]);
+                                } else {
+                                    store_kmer<NW>(a.out_kmers, i0, fa);
+                                    store_kmer<NW>(a.out_kmers, i1, fb);
+                                }
+                            }
+                            if (a.out_starts) *reinterpret_cast<ulonglong2 *>(a.out_starts + i0) = make_ulonglong2(origin + ra, origin + rb);
+                        } else {  // the first element of an odd range / the last of one that ends on an even index
+                            const uint64_t i = v0 ? i0 : i1;
+                            if (a.out_kmers) {
+#pragma unroll
+                                for (int wd = 0; wd < NW; ++wd) a.out_kmers[i * NW + wd] = v0 ? fa[wd] : fb[wd];
+                            }
+                            if (a.out_starts) a.out_starts[i] = (long long)(origin + (v0 ? ra : rb));
+                        }
+                    }
+                };
+                auto listed = [&](uint32_t j) { return qbase + (uint32_t)mine[j]; };
+                uint32_t n_round = 0;
+                for (uint32_t r_begin = qbase; r_begin < wave_end; r_begin += n_round) {
+                    const uint32_t q0 = r_begin >> 6;
+                    const uint32_t round_off = prefix_at(q0 - qw0);
+                    // a long round if its kept starts fit the list (or nothing at all is dropped), else 1024 starts
+                    n_round = wave_end - r_begin < ULONG ? wave_end - r_begin : ULONG;
+                    uint32_t q1 = (r_begin + n_round + 63u) >> 6;
+                    uint32_t cnt = prefix_at(q1 - qw0) - round_off;
+                    uint32_t usl = ULONG / 64u;
+                    if (n_round > UROUND && cnt > ULIST && cnt != n_round) {
+                        n_round = UROUND;
+                        q1 = q0 + UROUND / 64u;
+                        cnt = prefix_at(q1 - qw0) - round_off;
+                        usl = USLICE;
+                    } else if (n_round <= UROUND) {
+                        usl = USLICE;
+                    }
+                    if (cnt == 0) continue;
+                    if (cnt == n_round) {
+                        // a round with nothing dropped (real sequence outside its N blocks) needs no list: element j starts at
+                        // r_begin + j.  Whatever is still listed goes first (output order).
+                        if (list_n) {
+                            emit_range(list_pos, list_pos + list_n, listed);
+                            list_pos += list_n;
+                            list_n = 0;
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        emit_range(list_pos, list_pos + cnt, [&](uint32_t j) { return r_begin + j; });
+                        list_pos += cnt;
+                        continue;
+                    }
+                    // this lane's qword of the mask and the kept starts before it, from the lane that holds them
+                    const uint32_t sl = (lane * usl) & 63u;
+                    uint32_t qrel = q0 - qw0 + ((lane * usl) >> 6);
+                    if (qrel >= WQ) qrel = WQ - 1u;  // (a lane past the end of the round: its slice is empty, any qword will do)
+                    uint64_t km = 0;
+                    uint32_t km_before = 0;
+#pragma unroll
+                    for (uint32_t h = 0; h < QPT; ++h) {
+                        const uint64_t xk = __shfl(tr.k[h], (int)(qrel / QPT), 64);
+                        const uint32_t xp = (uint32_t)__shfl(tr.p[h], (int)(qrel / QPT), 64);
+                        if (qrel % QPT == h) {
+                            km = xk;
+                            km_before = xp;
+                        }
+                    }
+                    const uint32_t mine_n = lane * usl < n_round ? (n_round - lane * usl < usl ? n_round - lane * usl : usl) : 0u;
+                    const uint64_t keep16 = (km >> sl) & (mine_n >= 64u ? ~0ull : ((1ull << mine_n) - 1ull));
+                    // list the round's kept starts behind the carried ones, in order, relative to the quarter
+                    uint32_t o = list_n + km_before - round_off + (uint32_t)__popcll(km & ((1ull << sl) - 1ull));
+                    const uint32_t s0 = r_begin - qbase + lane * usl;
+                    uint32_t half_lo = (uint32_t)keep16, half_hi = (uint32_t)(keep16 >> 32);
+                    while (half_lo) {
+                        mine[o++] = (uint16_t)(s0 + (uint32_t)__builtin_ctz(half_lo));
+                        half_lo &= half_lo - 1u;
+                    }
+                    while (half_hi) {
+                        mine[o++] = (uint16_t)(s0 + 32u + (uint32_t)__builtin_ctz(half_hi));
+                        half_hi &= half_hi - 1u;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t total = list_n + cnt;
+                    const uint64_t end_emit = (list_pos + total) & ~(uint64_t)(UFRAME - 1u);  // the last whole frame's end
+                    if (end_emit > list_pos) {
+                        const uint32_t E = (uint32_t)(end_emit - list_pos), left = total - E;  // left < UFRAME
+                        emit_range(list_pos, end_emit, listed);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        // what is left moves to the head of the list: every lane reads before any lane writes
+                        uint16_t x0 = 0, x1 = 0;
+                        if (lane < left) x0 = mine[E + lane];
+                        if (lane + 64u < left) x1 = mine[E + lane + 64u];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < left) mine[lane] = x0;
+                        if (lane + 64u < left) mine[lane + 64u] = x1;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        list_pos = end_emit;
+                        list_n = left;
+                    } else {
+                        list_n = total;
+                    }
+                }
+                if (list_n) emit_range(list_pos, list_pos + list_n, listed);  // the tail of the quarter: one partial frame
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next tile
+            }
+        }
+        // ---- the generic path: one element per lane (Tuple{Kmer,Int} elements, unaligned outputs, kmers of run-time width, and
+        // the XOR reducer, which stores nothing)
         uint32_t n_round = 0;
-        for (uint32_t r_begin = qw0 * 64u; r_begin < wave_end; r_begin += n_round) {
+        for (uint32_t r_begin = qw0 * 64u; r_begin < wave_end && !framed; r_begin += n_round) {
             const uint32_t q0 = r_begin >> 6;
             const uint32_t round_off = prefix_at(q0 - qw0);
             // a long round if its kept starts fit the list (or nothing at all is dropped), else 1024 starts
@@ -411,9 +570,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             uint32_t cnt = prefix_at(q1 - qw0) - round_off;                // kept starts of this round
             uint32_t usl = ULONG / 64u;                                    // consecutive starts per lane
             uint64_t pos = base + round_off;                               // output index of the round's first
-            // (a round with nothing dropped needs no list when it can take the two-kmers-per-lane path below)
-            const bool dense_long = N == 1 && EMIT && cnt == n_round && a.vec16 && !a.tuples && pos + cnt <= a.capacity;
-            if (n_round > UROUND && cnt > ULIST && !dense_long) {
+            if (n_round > UROUND && cnt > ULIST) {
                 n_round = UROUND;
                 q1 = q0 + UROUND / 64u;
                 cnt = prefix_at(q1 - qw0) - round_off;
@@ -442,34 +599,6 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             uint64_t keep16 = (km >> sl) & (mine_n >= 64u ? ~0ull : ((1ull << mine_n) - 1ull));
             if (cnt == 0) continue;
             const uint64_t origin = m0 + 1 + a.index_origin;                     // start of candidate r is origin + r
-            if constexpr (N == 1 && EMIT) {  // (one-word kmers only)
-                // Dense round (every one of its starts is kept -- the normal state of real sequence outside its N
-                // blocks): no list; two consecutive kmers per lane and 16-byte stores aligned to the parity of the
-                // output position.
-                if (cnt == n_round && a.vec16 && !a.tuples && pos + cnt <= a.capacity) {
-                    const uint32_t head = (uint32_t)(pos & 1u);
-                    auto single = [&](uint32_t e) {
-                        uint64_t fw[1];
-                        cut_fw<1>(lds, kbit0 - 2u * (r_begin + e), mask, fw);
-                        if (a.out_kmers) a.out_kmers[pos + e] = fw[0];
-                        if (a.out_starts) a.out_starts[pos + e] = (long long)(origin + r_begin + e);
-                    };
-                    if (head && lane == 0) single(0);
-                    const uint32_t pairs = (cnt - head) >> 1;
-                    for (uint32_t i = lane; i < pairs; i += 64u) {
-                        const uint32_t e = head + 2u * i;
-                        uint64_t fa[1], fb[1];
-                        cut_fw<1>(lds, kbit0 - 2u * (r_begin + e), mask, fa);
-                        cut_fw<1>(lds, kbit0 - 2u * (r_begin + e + 1u), mask, fb);
-                        if (a.out_kmers) *reinterpret_cast<ulonglong2 *>(a.out_kmers + pos + e) = make_ulonglong2(fa[0], fb[0]);
-                        if (a.out_starts)
-                            *reinterpret_cast<ulonglong2 *>(a.out_starts + pos + e) =
-                                make_ulonglong2(origin + r_begin + e, origin + r_begin + e + 1);
-                    }
-                    if (((cnt - head) & 1u) && lane == 0) single(cnt - 1);
-                    continue;
-                }
-            }
             // list the kept starts of the round in LDS, in order: this lane's slice of consecutive starts begins at list index o
             uint32_t o = km_before - round_off + (uint32_t)__popcll(km & ((1ull << sl) - 1ull));
             const uint32_t s0 = lane * usl;  // round-relative index of the slice's first start
@@ -535,38 +664,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                     }
                 }
             };
-            bool paired = false;
-            if constexpr (EMIT) {
-                // Two listed elements per lane and 16-byte stores: the pair starts at an even output index, an odd first /
-                // last element goes alone.
-                paired = !WIDE && a.vec16 && !a.tuples && pos + cnt <= a.capacity;
-                if (paired) {
-                    const uint32_t head = (uint32_t)(pos & 1u);
-                    if (head && lane == 0) emit_one(0);
-                    const uint32_t pairs = (cnt - head) >> 1;
-                    for (uint32_t i = lane; i < pairs; i += 64u) {
-                        const uint32_t e = head + 2u * i;
-                        const uint32_t ra = r_begin + (uint32_t)mine[e], rb = r_begin + (uint32_t)mine[e + 1u];
-                        uint64_t fa[NW], fb[NW];
-                        cut_fw<NW>(lds, kbit0 - 2u * ra, mask, fa);
-                        cut_fw<NW>(lds, kbit0 - 2u * rb, mask, fb);
-                        const uint64_t o2 = pos + e;  // even
-                        if (a.out_kmers) {
-                            if constexpr (N == 1) {
-                                *reinterpret_cast<ulonglong2 *>(a.out_kmers + o2) = make_ulonglong2(fa[0], fb[0]);
-                            } else {
-                                store_kmer<NW>(a.out_kmers, o2, fa);
-                                store_kmer<NW>(a.out_kmers, o2 + 1, fb);
-                            }
-                        }
-                        if (a.out_starts) *reinterpret_cast<ulonglong2 *>(a.out_starts + o2) = make_ulonglong2(origin + ra, origin + rb);
-                    }
-                    if (((cnt - head) & 1u) && lane == 0) emit_one(cnt - 1u);
-                }
-            }
-            if (!paired) {
-                for (uint32_t i = lane; i < cnt; i += 64u) emit_one(i);
-            }
+            for (uint32_t i = lane; i < cnt; i += 64u) emit_one(i);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next round
         }
@@ -630,100 +728,6 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         for (int off = 32; off > 0; off >>= 1) acc ^= __shfl_xor(acc, off, 64);
         if (lane == 0 && acc) atomicXor(a.total, (unsigned long long)acc);
     }
-}
-
-// ---- exclusive scan of n 32-bit counts into 64-bit offsets (offsets[n] = total): the layout pass of kmers_batch ----
-// Three coalesced kernels: per-segment sums -> scan of the segment sums (one workgroup) ->
-// per-segment rescan with the segment's base.  A segment is SCAN_SEG consecutive counts.
-constexpr uint32_t SCAN_SEG = 2048;  // 256 threads x 8
-
-__device__ __forceinline__ uint64_t block_reduce_sum(uint64_t v, uint64_t *tmp) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63u) == 0) tmp[threadIdx.x >> 6] = v;
-    block_sync();
-    uint64_t total = 0;
-    for (uint32_t w = 0; w < blockDim.x / 64; ++w) total += tmp[w];
-    block_sync();
-    return total;
-}
-
-__global__ __launch_bounds__(256) void scan_segment_sums_kernel(const uint32_t *__restrict__ counts, uint64_t n,
-                                                                 uint64_t *__restrict__ seg_sums) {
-    __shared__ uint64_t tmp[4];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_SEG;
-    uint64_t v = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < SCAN_SEG / 256; ++j) {
-        uint64_t i = base + threadIdx.x + 256u * j;
-        if (i < n) v += counts[i];
-    }
-    uint64_t total = block_reduce_sum(v, tmp);
-    if (threadIdx.x == 0) seg_sums[blockIdx.x] = total;
-}
-
-// in-place exclusive scan of the segment sums; seg_sums[n_seg] = grand total
-__global__ __launch_bounds__(1024) void scan_segments_kernel(uint64_t *__restrict__ seg_sums, uint64_t n_seg) {
-    __shared__ uint64_t part[1024];
-    const uint32_t t = threadIdx.x;
-    const uint64_t chunk = (n_seg + 1023) / 1024;
-    const uint64_t lo = (uint64_t)t * chunk < n_seg ? (uint64_t)t * chunk : n_seg, hi = lo + chunk < n_seg ? lo + chunk : n_seg;
-    uint64_t s = 0;
-    for (uint64_t i = lo; i < hi; ++i) s += seg_sums[i];
-    part[t] = s;
-    block_sync();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan of the partials
-        uint64_t v = t >= d ? part[t - d] : 0;
-        block_sync();
-        part[t] += v;
-        block_sync();
-    }
-    uint64_t run = t ? part[t - 1] : 0;
-    for (uint64_t i = lo; i < hi; ++i) {
-        uint64_t c = seg_sums[i];
-        seg_sums[i] = run;
-        run += c;
-    }
-    if (t == 1023) seg_sums[n_seg] = part[1023];
-}
-
-__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restrict__ counts, uint64_t n,
-                                                          const uint64_t *__restrict__ seg_sums, uint64_t n_seg,
-                                                          uint64_t *__restrict__ offsets) {
-    __shared__ uint32_t c[SCAN_SEG];
-    __shared__ uint64_t wave_tot[4];
-    const uint32_t t = threadIdx.x;
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_SEG;
-#pragma unroll
-    for (uint32_t j = 0; j < SCAN_SEG / 256; ++j) {
-        uint64_t i = base + t + 256u * j;
-        c[t + 256u * j] = i < n ? counts[i] : 0u;
-    }
-    block_sync();
-    // thread t owns 8 consecutive counts: local exclusive prefix, then a scan over the thread totals
-    uint64_t local[SCAN_SEG / 256];  // 64-bit: kmers_batch scans per-record counts of up to 2^32 - 1
-    uint64_t sum = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < SCAN_SEG / 256; ++j) {
-        local[j] = sum;
-        sum += c[t * (SCAN_SEG / 256) + j];
-    }
-    uint64_t incl = sum;
-    const uint32_t lane = t & 63u, wave = t >> 6;
-    for (int off = 1; off < 64; off <<= 1) {
-        uint64_t v = __shfl_up(incl, off, 64);
-        if ((int)lane >= off) incl += v;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    block_sync();
-    uint64_t before = seg_sums[blockIdx.x];
-    for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
-    const uint64_t excl = before + incl - sum;
-#pragma unroll
-    for (uint32_t j = 0; j < SCAN_SEG / 256; ++j) {
-        uint64_t i = base + (uint64_t)t * (SCAN_SEG / 256) + j;
-        if (i < n) offsets[i] = excl + local[j];
-    }
-    if (blockIdx.x == 0 && t == 0) offsets[n] = seg_sums[n_seg];
 }
 
 }  // namespace kmers

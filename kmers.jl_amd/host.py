@@ -143,6 +143,19 @@ class Context:
         if ptr and self.handle:
             self.lib.kmers_dev_free(self.handle, C.c_void_p(ptr))
 
+    # the context's arena (include/kmers_hip.h): one large block, sub-allocated by alloc()
+    def arena_reserve(self, nbytes=0):
+        self.check(self.lib.kmers_arena_reserve(self.handle, nbytes), "kmers_arena_reserve")
+        return self.arena_info()[0]
+
+    def arena_release(self):
+        self.check(self.lib.kmers_arena_release(self.handle), "kmers_arena_release")
+
+    def arena_info(self):
+        r, u, f = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self.check(self.lib.kmers_arena_info(self.handle, C.byref(r), C.byref(u), C.byref(f)), "kmers_arena_info")
+        return r.value, u.value, f.value
+
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)
         self.check(self.lib.kmers_memcpy_h2d(self.handle, C.c_void_p(dptr), arr.ctypes.data_as(C.c_void_p),

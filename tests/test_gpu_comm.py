@@ -81,7 +81,8 @@ def test_bench_launches_two_ranks_by_itself(transport):
     """`python bench.py --gpus 2` exactly as the driver calls it (no torchrun around it): the parent starts the ranks.  Two
     ranks share the one device over gloo here, which exercises the launcher, the shard plan, the halo step and the
     verification of both shards; the line must report what really ran."""
-    r = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--bases", "8000000", "--no-other-configs", "--no-cpu-baseline", "--no-pmc"],
+    r = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--bases", "8000000", "--strong-bases", "12000029", "--no-other-configs",
+                   "--cpu-budget", "0.2", "--no-pmc"],
                   {"KMERS_BENCH_BACKEND": "gloo", "KMERS_HALO_TRANSPORT": transport})
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -91,6 +92,34 @@ def test_bench_launches_two_ranks_by_itself(transport):
     assert d["config"]["backend"] == "gloo" and d["config"]["halo_transport"] == transport
     assert "gloo" in d["config"]["sharding"] and "RCCL" not in d["config"]["sharding"]
     assert d["value"] > 0 and d["roofline"]["kmers_per_launch"] > 0
+    # the N > 1 line carries what the N = 1 line does: per-rank kernel times, the halo step's share, the CPU baseline
+    rf = d["roofline"]
+    assert len(rf["kernel_ms_per_rank"]) == 2 and rf["kernel_ms_min"] <= rf["kernel_ms"] <= rf["kernel_ms_max"] + 1e-9
+    assert len(rf["halo_step_ms_per_rank"]) == 2 and 0 <= rf["halo_step_share"] < 1 and "traffic_source" in rf
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
+    # ... and the strong split of a fixed input measured in the same run, with the same input on one rank beside it
+    st = d["strong_scaling"]
+    assert st["scaling"] == "strong" and st["total_bases"] == 12000029 and st["n_gpus"] == 2 and st["verified"] is True
+    assert len(st["kernel_ms_per_rank"]) == 2 and st["one_gpu"]["ms_per_step"] > 0 and st["speedup_vs_one_gpu"] > 0
+
+
+def test_bench_strong_scaling_eight_ranks_share_the_device():
+    """`python bench.py --gpus 8 --total-bases T`: ONE sequence of T symbols split over 8 ranks by kmers_shard_plan (the north
+    star's split at a small size; the ranks share this box's one device over gloo).  Every rank verifies its shard against the
+    oracle at both ends and by the all-element checks; the line says "strong" and names the split."""
+    total = 40_000_003
+    r = run_bench(["--gpus", "8", "--total-bases", str(total), "--steps", "2", "--warmup", "1", "--no-other-configs", "--no-cpu-baseline", "--no-pmc"],
+                  {"KMERS_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["verified"] is True
+    assert d["config"]["total_bases"] == total and len(d["config"]["bases_per_gpu"]) == 8
+    # the shards tile the sequence: every kmer exactly once, (K-1)-base overlaps between neighbours
+    assert sum(b - 30 for b in d["config"]["bases_per_gpu"]) == total - 30
+    assert "ONE sequence" in d["config"]["workload"] and "8 GPU" in d["config"]["workload"]
+    assert len(d["roofline"]["kernel_ms_per_rank"]) == 8 and abs(d["value"] - total * 2 / (d["ms_per_step"] * 2e-3) / 1e9) < 0.01 * d["value"] + 1e-3
 
 
 def test_bench_refuses_more_rccl_ranks_than_gpus():

@@ -1162,3 +1162,40 @@ def test_reduce_xor_over_spaced_and_unambiguous(km, ctx, orc):
     assert ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), 9, 4, cap.ITER_CANONICAL, 1, C.byref(val), 0, C.byref(res)) == 0
     assert val.value == exp
     assert ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), 9, 2, cap.ITER_SPACED, 40, C.byref(val), 0, C.byref(res)) == cap.E_UNSUPPORTED
+
+
+def test_unambiguous_lookback_gives_up_instead_of_hanging(km):
+    """The give-up path of the one-pass kernel's look-back (unambiguous_kernel.hpp: SPIN_LIMIT, the abort flag) cannot be provoked
+    on a healthy device, so a TEST BUILD of the same library provokes it: libkmers_hip_testabort.so (-DKMERS_TEST_ABORT,
+    kmers_jl_amd/build.py) never publishes the count of tile 1.  The launch must come back -- every look-back sees the flag and
+    drains -- with KMERS_E_HIP and a message, and the device must be usable afterwards.  A fresh process: one library per process."""
+    import os
+    import subprocess
+    import sys
+    from kmers_jl_amd import build
+    lib = build.TEST_ABORT_LIB
+    assert os.path.exists(lib), "run __graft_entry__.build() first: it builds the test library next to the product"
+    code = r'''
+import ctypes as C, sys
+import numpy as np
+import kmers_jl_amd as km
+cap = km._capi
+ctx = km.Context(0)
+L, K = 200_000, 31                      # seven tiles of 32768 candidate starts
+nw = L // 16 + 1
+d_w, d_k, d_s = ctx.alloc(nw * 8 + 8), ctx.alloc(L * 8), ctx.alloc(L * 8)
+ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, 3, 0, nw, 4, 2621, d_w), "synth")
+res = cap.Result()
+seq = cap.Seq(d_w, L, 0, 0, 4, 0)
+rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, d_k, d_s, L, cap.MEM_DEVICE, C.byref(res))
+assert rc == cap.E_HIP, rc
+assert "gave up" in ctx.last_error(), ctx.last_error()
+# one tile: nothing to look back at -- the same build, the same context, right behind the aborted launch
+seq1 = cap.Seq(d_w, 20_000, 0, 0, 4, 0)
+rc = ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq1), K, 1, d_k, d_s, L, cap.MEM_DEVICE, C.byref(res))
+assert rc == 0 and res.n_out > 0, (rc, ctx.last_error())
+print("ok", res.n_out)
+'''
+    env = dict(os.environ, KMERS_HIP_LIB=lib, PYTHONPATH=os.pathsep.join(sys.path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout, r.stderr[-2000:])

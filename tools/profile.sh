@@ -9,7 +9,7 @@ OUT="$ROOT/gpurun_out/prof"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="$ROOT/bench.py"
-ARGS="--no-cpu-baseline --no-other-configs $*"
+ARGS="--no-cpu-baseline --no-other-configs --no-pmc $*"  # --no-pmc: never a nested rocprofv3 under this one
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$BENCH" --steps 10 --warmup 2 $ARGS > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 "$BENCH" --steps 3 --warmup 1 $ARGS > "$OUT/pmc_fetch_bench.json" 2> "$OUT/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 "$BENCH" --steps 3 --warmup 1 $ARGS > "$OUT/pmc_write_bench.json" 2> "$OUT/pmc_write.err"
