@@ -819,9 +819,17 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             plain_alloc = {"error": repr(e)}
-    arena_gb = 0.0
+    arena_gb, arena_map = 0.0, None
     if use_arena:
         arena_gb = round(ctx.arena_reserve(int(args.arena_gb * 1e9)) / 1e9, 1)
+        _base, gran, classes = ctx.arena_regions()
+        if gran:  # run-length form of the measured map: "A16 B16 C4 ..." = 16 granules of class A, 16 of class B, ...
+            runs, start = [], 0
+            for i in range(1, len(classes) + 1):
+                if i == len(classes) or classes[i] != classes[start]:
+                    runs.append(f"{chr(65 + classes[start])}{i - start}")
+                    start = i
+            arena_map = f"{gran >> 30} GiB granules: " + " ".join(runs)
     mem = env.mem = Memory(ctx, dev, use_arena)
     if grouped and transport == "native":
         if backend != "nccl":
@@ -950,7 +958,8 @@ def main():
                        "bases_per_gpu": [s.n_bases for s in plan] if strong else args.bases,
                        "sharding": sharding, "backend": backend, "halo_transport": transport if grouped else None,
                        "seed": hex(seed), "wake_s": args.wake_s,
-                       "alloc": (f"kmers_arena_reserve ({arena_gb} GB, one block) + kmers_dev_alloc" if use_arena else "torch.empty (hipMalloc)")},
+                       "alloc": (f"kmers_arena_reserve ({arena_gb} GB, one block) + kmers_dev_alloc" if use_arena else "torch.empty (hipMalloc)"),
+                       "arena_region_map": arena_map},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": "not measured",
                          "kernel": "stream_kernel<src_bits,N,CANON,stride1>", "kernel_ms": round(kern_list[worst], 4),

@@ -113,6 +113,10 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 #define KMERS_PARAM_SKETCH_HOST_ONLY 4 /* kmers_minhash: 1 = use the host-feedback path even for small sketches (tests) */
 #define KMERS_PARAM_BATCH_PASSES 5     /* kmers_batch: elements per workgroup tile = 1024 * value (1..8); 0 = chosen from the batch size */
 #define KMERS_PARAM_SKETCH_BATCH_LDS 6 /* kmers_minhash_batch: candidate values per workgroup (2048 / 4096 / 8192); 0 = chosen per call */
+#define KMERS_PARAM_SPLIT_ORDER 9      /* 1: the tile kernels visit the two halves of their tile range alternately (two write windows per output
+                                         * array; +1 % for one output array that straddles two region classes of HBM, -1..4 % for two
+                                         * arrays; results are identical either way) */
+#define KMERS_PARAM_ARENA_NO_PROBE 8   /* 1: kmers_arena_reserve does not measure the region map of its block (best-fit placement only) */
 #define KMERS_PARAM_SUBTILES 7         /* strided tile kernels (kmers_spaced, kmers_minimizers): consecutive tiles per workgroup, the next one's source words in flight */
 int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
 
@@ -125,18 +129,28 @@ int kmers_memcpy_h2d(kmers_ctx *ctx, void *dst_dev, const void *src_host, size_t
 int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
 /* The context's ARENA: one large block of HBM reserved once, out of which kmers_dev_alloc then serves every request that fits
- * (best fit, KMERS_ARENA_GRANULE-aligned ranges; a request that does not fit falls through to a plain allocation;
- * kmers_dev_free returns a range to the arena and merges it with its free neighbours).  Two reasons to use it: (1) a collect
- * per sequence allocates and releases tens of gigabytes, and a plain allocation of that size costs the driver milliseconds; (2)
- * on MI355X the write rate of the kernels depends on where their outputs were placed: into two freshly allocated 8 GB arrays
- * the canonical + hash launch runs at 0.79 of 8 TB/s on a fresh machine, into ranges of one block of 64 GB or more at 0.82-0.84
- * (profiles/r03_alloc.md).  bytes = 0 reserves three quarters of the memory that is free at the time of the call.  One arena per
- * context; kmers_arena_release fails with KMERS_E_BADARG while blocks of it are allocated; kmers_ctx_destroy releases it. */
+ * (KMERS_ARENA_GRANULE-aligned ranges; a request that does not fit falls through to a plain allocation; kmers_dev_free returns
+ * a range to the arena and merges it with its free neighbours).  Two reasons to use it:
+ * (1) a collect per sequence allocates and releases tens of gigabytes, and a plain allocation of that size costs milliseconds;
+ * (2) PLACEMENT.  On MI355X store streams that run side by side inside one region of HBM (a few classes of tens of gigabytes
+ *     each; tools/xcd_affinity.hip, profiles/r03_alloc.md) share about 6.0 TB/s, streams in different classes reach about 7.1:
+ *     the two output arrays of one launch are two such streams, and where two plain allocations happen to lie decides whether
+ *     FwDNAMers{63} + reverse complements runs at 0.72 or at 0.89 of 8 TB/s (canonical 31-mers + hashes: 0.80 or 0.855).
+ *     kmers_arena_reserve measures the map of its block (about 0.1 s for 200 GB; only blocks of 16 GiB or more;
+ *     KMERS_PARAM_ARENA_NO_PROBE = 1 skips it) and kmers_dev_alloc places CONSECUTIVE allocations in DIFFERENT classes: allocate
+ *     the arrays of one launch one after the other.  kmers_arena_regions reports the map.
+ * bytes = 0 reserves three quarters of the memory that is free at the time of the call.  One arena per context;
+ * kmers_arena_release fails with KMERS_E_BADARG while blocks of it are allocated; kmers_ctx_destroy releases it. */
 #define KMERS_ARENA_GRANULE ((size_t)2 << 20)
 int kmers_arena_reserve(kmers_ctx *ctx, size_t bytes);
 int kmers_arena_release(kmers_ctx *ctx);
 /* any of the three outputs may be NULL; all zero when no arena is reserved */
 int kmers_arena_info(kmers_ctx *ctx, size_t *reserved, size_t *in_use, size_t *largest_free);
+/* The measured map: the block starts at *base and is *n_regions granules of *region_bytes (the tail that is left belongs to the
+ * last one), granule g is in class classes[g] (at most `capacity` entries are written; boundaries are known to the allocator
+ * more finely than a granule).  *region_bytes = 0: no map (block too small, probing switched off, or one class only).  Any
+ * output may be NULL. */
+int kmers_arena_regions(kmers_ctx *ctx, void **base, size_t *region_bytes, unsigned char *classes, size_t capacity, size_t *n_regions);
 
 /* ---- geometry (src/kmer.jl:117-137; iterator length()) ----------------------- */
 int kmers_words_per_kmer(int k, int dst_bits);                      /* n_coding_elements, kmer.jl:123-125 */

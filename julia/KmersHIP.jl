@@ -461,9 +461,41 @@ function Comm(id::Vector{UInt8}, n_ranks::Integer, rank::Integer; ctx::Context =
                                                       h::Ptr{Ptr{Cvoid}})::Cint
     rc == OK || error("kmers_comm_create: status $rc: $(last_error(ctx))")
     c = Comm(ctx, h[], rank, n_ranks)
-    finalizer(x -> (@ccall LIB.kmers_comm_destroy(x.ctx.handle::Ptr{Cvoid}, x.handle::Ptr{Cvoid})::Cint), c)
+    # ncclCommDestroy synchronises the stream and is collective in effect: it must not run from the GC (arbitrary time, arbitrary
+    # order across ranks, and finalizers must not block).  Call close(comm) on every rank; the finalizer only reports a leak.
+    finalizer(x -> (x.handle == C_NULL || @async @warn "KmersHIP.Comm was never closed: call close(comm) on every rank"), c)
     return c
 end
+
+"ncclCommDestroy (after a stream synchronize): call on every rank when the sharded work is done."
+function Base.close(c::Comm)
+    c.handle == C_NULL && return nothing
+    rc = @ccall LIB.kmers_comm_destroy(c.ctx.handle::Ptr{Cvoid}, c.handle::Ptr{Cvoid})::Cint
+    c.handle = C_NULL
+    rc == OK || error("kmers_comm_destroy: status $rc: $(last_error(c.ctx))")
+    return nothing
+end
+
+# ---- device memory: the context's arena (include/kmers_hip.h, "device memory") -------------------------------------------
+"One large block of HBM per context (`bytes = 0`: three quarters of what is free), out of which `device_alloc` serves."
+function arena_reserve!(ctx::Context = context(); bytes::Integer = 0)
+    rc = @ccall LIB.kmers_arena_reserve(ctx.handle::Ptr{Cvoid}, bytes::Csize_t)::Cint
+    rc == OK || error("kmers_arena_reserve: status $rc: $(last_error(ctx))")
+    return nothing
+end
+function arena_release!(ctx::Context = context())
+    rc = @ccall LIB.kmers_arena_release(ctx.handle::Ptr{Cvoid})::Cint
+    rc == OK || error("kmers_arena_release: status $rc: $(last_error(ctx))")
+    return nothing
+end
+"`n` elements of `T` in HBM (a range of the arena when one is reserved and has room, else a plain allocation)."
+function device_alloc(ctx::Context, ::Type{T}, n::Integer) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = @ccall LIB.kmers_dev_alloc(ctx.handle::Ptr{Cvoid}, (n * sizeof(T))::Csize_t, p::Ptr{Ptr{Cvoid}})::Cint
+    rc == OK || error("kmers_dev_alloc: status $rc: $(last_error(ctx))")
+    return Ptr{T}(p[])
+end
+device_free(ctx::Context, p::Ptr) = (@ccall LIB.kmers_dev_free(ctx.handle::Ptr{Cvoid}, p::Ptr{Cvoid})::Cint; nothing)
 
 """
     halo_exchange!(comm, shard, words_dev)

@@ -19,7 +19,7 @@ SPANS_DEVICE = 8
 BATCH_SKIP = 16
 (OP_REVERSE, OP_COMPLEMENT, OP_REVCOMP, OP_CANONICAL, OP_ISCANONICAL, OP_TO_LONGSEQ, OP_COUNT_GC, OP_AS_INTEGER,
  OP_FROM_INTEGER) = range(9)
-PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY, PARAM_BATCH_PASSES, PARAM_SKETCH_BATCH_LDS, PARAM_SUBTILES = 1, 2, 3, 4, 5, 6, 7
+PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY, PARAM_BATCH_PASSES, PARAM_SKETCH_BATCH_LDS, PARAM_SUBTILES, PARAM_ARENA_NO_PROBE, PARAM_SPLIT_ORDER = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 STATUS_NAMES = {OK: "KMERS_OK", E_ENCODE: "KMERS_E_ENCODE", E_BADARG: "KMERS_E_BADARG",
                 E_HIP: "KMERS_E_HIP", E_NOMEM: "KMERS_E_NOMEM",
@@ -63,6 +63,7 @@ SYMBOLS = {
     "kmers_arena_reserve": (C.c_int, [_P, C.c_size_t]),
     "kmers_arena_release": (C.c_int, [_P]),
     "kmers_arena_info": (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "kmers_arena_regions": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "kmers_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "kmers_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "kmers_words_per_kmer": (C.c_int, [C.c_int, C.c_int]),

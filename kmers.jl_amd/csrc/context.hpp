@@ -6,16 +6,26 @@
 #include <cstdint>
 #include <map>
 #include <string>
+#include <vector>
 
 #include "../../include/kmers_hip.h"
 
 // The context's device-memory arena (kmers_arena_reserve, include/kmers_hip.h): ONE hipMalloc, sub-allocated in 2 MiB
-// granules by kmers_dev_alloc.  Offsets are relative to `base`; free ranges are kept coalesced.
+// granules by kmers_dev_alloc.  Offsets are relative to `base`; free ranges are kept coalesced.  `region` is the map of the
+// block that the calibration of memory_api.hip measured: two store streams inside one REGION CLASS of HBM share a write rate of
+// ~6 TB/s on MI355X, streams in different classes reach ~7.1 TB/s, so consecutive allocations go to different classes.
 struct kmers_arena {
     char *base = nullptr;
     size_t bytes = 0;
     std::map<size_t, size_t> free_ranges;  // offset -> length
     std::map<size_t, size_t> used;         // offset -> length
+    size_t region_bytes = 0;               // granule of the region map (0: not calibrated)
+    std::vector<uint8_t> region;           // class of every granule of the block (kmers_arena_regions)
+    std::vector<size_t> run_start;         // the map as runs: run i = [run_start[i], run_start[i + 1]) is in class run_class[i];
+    std::vector<uint8_t> run_class;        //   boundaries refined to about half a gigabyte
+    std::vector<float> pair_rate;          // measured: pair_rate[i * n_runs + j] = GB/s of two store streams, one in run i, one in run j
+    int n_classes = 0;
+    int last_run = -1, last2_run = -1;     // runs of the two most recent allocations
 };
 
 struct kmers_ctx {
@@ -34,6 +44,8 @@ struct kmers_ctx {
     int64_t tile_kmers = 0;  // 0 = default
     int64_t max_grid = 0;    // 0 = default
     int64_t subtiles = 0;    // KMERS_PARAM_SUBTILES; 0 = default
+    int64_t split_order = 0;     // KMERS_PARAM_SPLIT_ORDER: the tile kernels visit the two halves of their tile range alternately
+    int64_t arena_no_probe = 0;  // KMERS_PARAM_ARENA_NO_PROBE: kmers_arena_reserve skips the region calibration
     int64_t stamps_ptr = 0;  // diagnostic builds only (KMERS_PARAM_STAMPS_PTR)
     int n_cus = 256;                // multiProcessorCount
     bool sketch_host_only = false;  // KMERS_PARAM_SKETCH_HOST_ONLY: force the host-feedback MinHash path (tests)

@@ -6,7 +6,18 @@
 // launch into two freshly hipMalloc'ed 8 GB arrays runs at 0.79 of 8 TB/s on a fresh box and at 0.82-0.84 into ranges of one
 // large block (profiles/r02_tuning.md section 7; counters in profiles/r03_alloc.md).  kmers_arena_reserve makes that block a
 // property of the context instead of an accident of the process's allocation history.
+//
+// What the placement effect IS (round 3, tools/xcd_affinity.hip, profiles/r03_alloc.md): HBM on this device behaves as a few
+// REGION CLASSES of tens of gigabytes each.  Store streams that run side by side inside one class share ~6.0 TB/s (75 % of the
+// 8 TB/s peak -- the "achievable" figure of every single-buffer bandwidth test); streams in different classes reach ~7.1 TB/s
+// (89 %).  The two output arrays of one launch are two such streams.  kmers_arena_reserve therefore MEASURES the map of its
+// block (calibrate(): a two-stream fill between every 4 GiB granule and one representative per class found so far; about
+// 0.1 s for 200 GB) and kmers_dev_alloc places consecutive allocations in different classes.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "context.hpp"
 
@@ -18,16 +29,216 @@ constexpr size_t GRANULE = KMERS_ARENA_GRANULE;
 
 size_t round_up(size_t x) { return (x + GRANULE - 1) / GRANULE * GRANULE; }
 
-// smallest free range that fits (best fit keeps the large ranges whole for the large outputs)
+constexpr size_t REGION = (size_t)4 << 30;    // granule of the region map
+constexpr size_t PROBE = (size_t)512 << 20;   // bytes per stream of one probe
+
+// two store streams, 8 KiB of each per workgroup, 16 bytes per lane: the shape of the stream kernels' outputs
+__global__ __launch_bounds__(256) void arena_probe_kernel(ulonglong2 *a, ulonglong2 *b) {
+    const uint64_t w = blockIdx.x;
+    ulonglong2 *p = a + w * 512u, *q = b + w * 512u;
+    for (uint32_t i = threadIdx.x; i < 512u; i += 256u) {
+        p[i] = make_ulonglong2(w, i);
+        q[i] = make_ulonglong2(i, w);
+    }
+}
+
+// milliseconds of one probe (the faster of two): PROBE bytes at offset x and PROBE bytes at offset y of the block
+int probe_ms(kmers_ctx *ctx, hipEvent_t e0, hipEvent_t e1, size_t x, size_t y, float *out) {
+    char *base = ctx->arena.base;
+    float best = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(arena_probe_kernel, dim3((unsigned)(PROBE / 8192)), dim3(256), 0, ctx->stream, reinterpret_cast<ulonglong2 *>(base + x),
+                           reinterpret_cast<ulonglong2 *>(base + y));
+        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    *out = best;
+    return KMERS_OK;
+}
+
+// The region map of a freshly reserved block (nothing allocated yet: the probes write into it).  Granule g is in the class of
+// the first representative r with which it is SLOW (two streams in one class); fast with every representative = a new class.
+// "Slow" is calibrated on the block itself: the two halves of one granule are in one class (the median over all granules
+// discards the few that straddle a boundary).
+int calibrate(kmers_ctx *ctx) {
+    kmers_arena &a = ctx->arena;
+    a.region.clear();
+    a.run_start.clear();
+    a.run_class.clear();
+    a.region_bytes = 0;
+    a.n_classes = 0;
+    a.pair_rate.clear();
+    a.last_run = a.last2_run = -1;
+    const size_t n = a.bytes / REGION;
+    if (n < 4 || ctx->arena_no_probe) return KMERS_OK;
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    int rc = KMERS_OK;
+    std::vector<float> same(n);
+    float warm;
+    rc = probe_ms(ctx, e0, e1, 0, REGION / 2, &warm);  // (first launch of the kernel, clocks)
+    for (size_t g = 0; g < n && rc == KMERS_OK; ++g) rc = probe_ms(ctx, e0, e1, g * REGION, g * REGION + REGION / 2, &same[g]);
+    std::vector<uint8_t> cls(n, 0);
+    std::vector<size_t> refs;
+    if (rc == KMERS_OK) {
+        std::vector<float> sorted = same;
+        std::sort(sorted.begin(), sorted.end());
+        const float slow = sorted[n / 2], threshold = 0.93f * slow;  // different classes run at ~0.85 of the one-class time
+        for (size_t g = 0; g < n && rc == KMERS_OK; ++g) {
+            int c = -1;
+            for (size_t r = 0; r < refs.size() && c < 0 && rc == KMERS_OK; ++r) {
+                if (refs[r] == g) {
+                    c = (int)r;
+                    break;
+                }
+                float t;
+                rc = probe_ms(ctx, e0, e1, g * REGION, refs[r] * REGION + REGION / 2, &t);
+                if (t >= threshold) c = (int)r;
+            }
+            if (c < 0) {
+                if (refs.size() >= 16) {  // noise, not structure: no map
+                    refs.clear();
+                    break;
+                }
+                refs.push_back(g);
+                c = (int)refs.size() - 1;
+            }
+            cls[g] = (uint8_t)c;
+        }
+    }
+    std::vector<size_t> run_start;
+    std::vector<uint8_t> run_class;
+    if (rc == KMERS_OK && refs.size() >= 2) {
+        // runs of granules, then every boundary bisected to the probe's own resolution: x is in class c iff a stream at x is
+        // slow beside a stream at c's representative
+        std::vector<float> sorted = same;
+        std::sort(sorted.begin(), sorted.end());
+        const float threshold = 0.93f * sorted[n / 2];
+        for (size_t g = 0; g < n && rc == KMERS_OK; ++g) {
+            if (g && cls[g] == cls[g - 1]) continue;
+            size_t start = g * REGION;
+            if (g) {  // the class of granule g - 1 ends somewhere in (its start, the start of g]
+                const size_t r = refs[cls[g - 1]];
+                size_t lo = (g - 1) * REGION, hi = g * REGION;
+                while (hi - lo > PROBE && rc == KMERS_OK) {
+                    const size_t mid = lo + (hi - lo) / 2 / GRANULE * GRANULE;
+                    float t;
+                    rc = probe_ms(ctx, e0, e1, mid, r * REGION + (mid >= r * REGION + REGION / 2 && mid < (r + 1) * REGION ? 0 : REGION / 2), &t);
+                    if (t >= threshold) lo = mid;
+                    else hi = mid;
+                }
+                start = hi;
+            }
+            run_start.push_back(start);
+            run_class.push_back(cls[g]);
+        }
+    }
+    // what the placement goes by: the measured rate of every PAIR of runs (a stream at the head of each), not the labels --
+    // the classes are not all alike (a pair of them may share more than another pair), and a mislabelled granule is harmless
+    std::vector<float> pair;
+    const size_t k = run_start.size();
+    if (rc == KMERS_OK && k >= 2) {
+        pair.assign(k * k, 0.f);
+        auto run_len = [&](size_t i) { return (i + 1 < k ? run_start[i + 1] : a.bytes) - run_start[i]; };
+        for (size_t i = 0; i < k && rc == KMERS_OK; ++i) {
+            for (size_t j = i; j < k && rc == KMERS_OK; ++j) {
+                if (run_len(i) < 2 * PROBE || run_len(j) < 2 * PROBE) continue;  // (a sliver: rate 0, never preferred)
+                float t;
+                rc = probe_ms(ctx, e0, e1, run_start[i], run_start[j] + (i == j ? PROBE : 0), &t);
+                pair[i * k + j] = pair[j * k + i] = (float)(2.0 * (double)PROBE / 1e6 / (double)t);  // GB/s
+            }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != KMERS_OK) return rc;
+    if (refs.size() >= 2) {
+        a.region = cls;
+        a.region_bytes = REGION;
+        a.n_classes = (int)refs.size();
+        a.run_start = run_start;
+        a.run_class = run_class;
+        a.pair_rate = pair;
+        if (std::getenv("KMERS_ARENA_DEBUG")) {  // the measured map on stderr
+            for (size_t i = 0; i < k; ++i) {
+                std::fprintf(stderr, "arena run %2zu: class %c at %7.2f GiB:", i, 'A' + run_class[i], (double)run_start[i] / (double)((size_t)1 << 30));
+                for (size_t j = 0; j < k; ++j) std::fprintf(stderr, " %4.0f", (double)pair[i * k + j]);
+                std::fprintf(stderr, "\n");
+            }
+        }
+    }
+    return KMERS_OK;
+}
+
+size_t run_of(const kmers_arena &a, size_t off) {  // index of the run that holds `off`
+    size_t i = std::upper_bound(a.run_start.begin(), a.run_start.end(), off) - a.run_start.begin();
+    return i ? i - 1 : 0;
+}
+int class_at(const kmers_arena &a, size_t off) { return a.run_class.empty() ? 0 : a.run_class[run_of(a, off)]; }
+size_t run_end(const kmers_arena &a, size_t i) { return i + 1 < a.run_start.size() ? a.run_start[i + 1] : a.bytes; }
+
+void arena_commit(kmers_arena &a, std::map<size_t, size_t>::iterator range, size_t off, size_t need) {
+    const size_t fo = range->first, fl = range->second;
+    a.free_ranges.erase(range);
+    if (off > fo) a.free_ranges[fo] = off - fo;
+    if (fo + fl > off + need) a.free_ranges[off + need] = fo + fl - (off + need);
+    a.used[off] = need;
+    a.last2_run = a.last_run;
+    a.last_run = a.run_start.empty() ? -1 : (int)run_of(a, off);
+}
+
+// Placement.  With a region map every stretch of a free range inside ONE run that fits the request is a candidate; the run
+// whose MEASURED two-stream rate beside the run of the previous allocation is highest wins (the arrays of one launch are
+// allocated one after the other), the allocation before that counting half; ties go to the tightest stretch.  Without a map,
+// or when no stretch fits (a request larger than any run): best fit over the free ranges.
+// (Measured and not kept, profiles/r03_alloc.md: centring every large block on a class boundary and letting the tile kernels
+// write each array through two windows half an array apart -- KMERS_PARAM_SPLIT_ORDER -- gains a single-output launch 1 %
+// and costs a two-output launch 1-4 % against the two arrays in two different classes.)
 bool arena_take(kmers_arena &a, size_t need, size_t *off_out) {
+    if (!a.run_start.empty()) {
+        auto best_range = a.free_ranges.end();
+        size_t best_off = 0, best_slack = 0;
+        float best_score = -1.f;
+        const size_t k = a.run_start.size();
+        for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it) {
+            const size_t fo = it->first, fe = fo + it->second;
+            size_t pos = fo;
+            while (pos < fe) {  // the run that holds `pos`, cut to the free range
+                const size_t r = run_of(a, pos);
+                const size_t stretch_end = std::min(fe, run_end(a, r));
+                if (stretch_end - pos >= need) {
+                    // GB/s beside the previous block's run (+ half of that beside the one before); no history: the run's own rate
+                    float score = a.last_run < 0 ? a.pair_rate[r * k + r] : a.pair_rate[(size_t)a.last_run * k + r];
+                    if (a.last2_run >= 0) score += 0.5f * a.pair_rate[(size_t)a.last2_run * k + r];
+                    score = (float)(int)(score / 100.f);  // (rates within 100 GB/s of each other are a tie)
+                    const size_t slack = stretch_end - pos - need;
+                    if (score > best_score || (score == best_score && slack < best_slack)) {
+                        best_range = it;
+                        best_off = pos;
+                        best_slack = slack;
+                        best_score = score;
+                    }
+                }
+                pos = stretch_end;
+            }
+        }
+        if (best_range != a.free_ranges.end()) {
+            arena_commit(a, best_range, best_off, need);
+            *off_out = best_off;
+            return true;
+        }
+    }
     auto best = a.free_ranges.end();
     for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it)
         if (it->second >= need && (best == a.free_ranges.end() || it->second < best->second)) best = it;
     if (best == a.free_ranges.end()) return false;
-    const size_t off = best->first, len = best->second;
-    a.free_ranges.erase(best);
-    if (len > need) a.free_ranges[off + need] = len - need;
-    a.used[off] = need;
+    const size_t off = best->first;
+    arena_commit(a, best, off, need);
     *off_out = off;
     return true;
 }
@@ -70,6 +281,22 @@ int kmers_arena_reserve(kmers_ctx *ctx, size_t bytes) {
     ctx->arena.free_ranges.clear();
     ctx->arena.used.clear();
     ctx->arena.free_ranges[0] = bytes;
+    if (int rc = calibrate(ctx)) {  // (a failed probe is a HIP failure: give the block back)
+        (void)hipFree(ctx->arena.base);
+        ctx->arena = kmers_arena();
+        return rc;
+    }
+    return KMERS_OK;
+}
+
+int kmers_arena_regions(kmers_ctx *ctx, void **base, size_t *region_bytes, unsigned char *classes, size_t capacity, size_t *n_regions) {
+    if (!ctx) return KMERS_E_BADARG;
+    const kmers_arena &a = ctx->arena;
+    if (base) *base = a.base;
+    if (region_bytes) *region_bytes = a.region_bytes;
+    if (n_regions) *n_regions = a.region.size();
+    if (classes)
+        for (size_t i = 0; i < a.region.size() && i < capacity; ++i) classes[i] = a.region[i];
     return KMERS_OK;
 }
 

@@ -43,6 +43,7 @@ struct StreamArgs {
     uint32_t stride;
     uint32_t tile_kmers;
     uint32_t subtiles;       // strided kernels: consecutive tiles per workgroup, the next one's source words in flight (0 = 1)
+    uint32_t split_order;    // 1: workgroups visit the two halves of the tile range alternately (see the kernel)
     uint32_t xor_canonical;  // MODE_XOR: 1 = canonical kmers, 0 = forward kmers
     uint64_t *stamps;        // diagnostic builds (-DKMERS_STAMPS) only: per-workgroup s_memrealtime stamps
     uint32_t ascii_table;     // SRC_BITS == 8: which byte -> symbol table (ascii_entry(), ascii_tables.hpp)
@@ -415,7 +416,20 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     };
     const uint64_t S = STRIDE1 || a.subtiles == 0 ? 1u : a.subtiles;
     uint32_t buf = 0;
-    for (uint64_t visit = blockIdx.x; visit * S < a.n_tiles; visit += gridDim.x) {
+    // SPLIT ORDER (opt-in, KMERS_PARAM_SPLIT_ORDER): even workgroups walk the first half of the tile range, odd ones the second
+    // half, so that every output array is written through TWO moving windows half an array apart.  On MI355X store streams inside
+    // one region class of HBM share ~6 TB/s and streams in different classes reach ~7.2 (memory_api.hip, profiles/r03_alloc.md):
+    // a single output array that straddles two classes is then written 1 % faster (a pure fill of that shape: 6.4 -> 7.2 TB/s,
+    // the kernels: 0.80 -> 0.81), but the two arrays of a two-output launch are better off in two different classes with one
+    // window each (-1..4 % with four windows), which is what the context's arena arranges: off by default.
+    const uint64_t n_visits = (a.n_tiles + S - 1) / S, n_first = (n_visits + 1) >> 1;
+    const uint64_t n_slots = a.split_order ? 2 * n_first : n_visits;
+    for (uint64_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {
+      uint64_t visit = slot;
+      if (a.split_order) {
+          visit = (slot & 1u) ? n_first + (slot >> 1) : (slot >> 1);
+          if (visit >= n_visits) continue;  // (an odd number of visits: the second half is one short)
+      }
       const uint64_t t_end = (visit + 1) * S < a.n_tiles ? (visit + 1) * S : a.n_tiles;
       uint64_t xpre[PRE];
       Geom gn = geometry(visit * S);

@@ -10,7 +10,10 @@ namespace kmers {
 // per workgroup.  Measured on MI355X (profiles/r01_tuning.md): shorter workgroups are bound by
 // workgroup launch + the exposed source-load latency, longer ones and persistent grid-stride
 // loops lose 10-20 % of the HBM write rate.
-constexpr int64_t DEFAULT_SUBTILES = 3;
+// Measured in round 3 (profiles/r03_tuning.md): more than one tile per visit LOSES -- SpacedDNAMers{21,3}, 1 Gbase: 0.757 / 0.746 /
+// 0.733 / 0.728 / 0.698 of 8 TB/s at 1 / 2 / 3 / 4 / 6 tiles of 2048 per visit -- a workgroup that lives longer writes slower, and
+// that costs more than the load round it hides.  The mechanism stays (KMERS_PARAM_SUBTILES) for sources with slower loads.
+constexpr int64_t DEFAULT_SUBTILES = 1;
 
 inline uint32_t default_tile(uint32_t out_bytes_per_kmer, uint32_t pass) {
     uint32_t t = (16384u / std::max<uint32_t>(out_bytes_per_kmer, 1u)) / pass * pass;
@@ -93,9 +96,8 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     uint32_t max_tile_symbols = (uint32_t)MAX_TILE_BITS / (uint32_t)dst_bits;
     if (MODE == MODE_MINIMIZER) max_tile_symbols -= std::min<uint32_t>(max_tile_symbols / 2, a.window_kmers);  // room for the longer overlap
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
-    // strided tiles read `stride` times the source per element: twice the output per workgroup amortises the longer load
-    // phase (SpacedDNAMers{21,3} over 1 Gbase: 0.64-0.68 -> 0.71-0.74 of 8 TB/s, profiles/r02_tuning.md)
-    if (ctx->tile_kmers <= 0 && J > 1 && MODE == MODE_FW) tile *= 2;
+    // (round 2 doubled the tile of strided launches -- 32 KiB of output per workgroup; with two lattice kmers per lane the 16 KiB
+    // tile is as fast or faster on every box measured in round 3: 0.73-0.76 against 0.70-0.74, profiles/r03_tuning.md)
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);
     tile = std::max<uint32_t>(pass, tile / pass * pass);
     if ((uint64_t)(tile - 1) * J + 1 > (uint64_t)max_tile_symbols) return fail(ctx, KMERS_E_UNSUPPORTED, "stride too large for the tile kernel");
@@ -107,7 +109,11 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     a.stamps = reinterpret_cast<uint64_t *>(ctx->stamps_ptr);
     uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
     const uint64_t visits = (a.n_tiles + a.subtiles - 1) / a.subtiles;
-    dim3 grid((unsigned)std::min<uint64_t>(visits, cap));
+    // two write windows per output array (stream_kernel.hpp, SPLIT ORDER): opt-in, see KMERS_PARAM_SPLIT_ORDER
+    const bool materialises = MODE == MODE_FW || MODE == MODE_CANON || MODE == MODE_MINIMIZER;
+    a.split_order = materialises && visits >= 4096 && ctx->split_order != 0 ? 1u : 0u;
+    const uint64_t slots = a.split_order ? 2 * ((visits + 1) / 2) : visits;
+    dim3 grid((unsigned)std::min<uint64_t>(slots, cap));
     dim3 block(BLOCK);
     if (src_bits == 8 && dst_bits == 2) launch_widths<MODE, 8, 2>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
     else if (src_bits == 8) launch_widths<MODE, 8, 4>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);

@@ -432,20 +432,25 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                 uint64_t list_pos = base + prefix_at(0);                // output index of the first element not yet emitted
                 // elements with output indexes [lo, hi) -> memory, frame by frame; start_of(j) = tile-relative start of element lo + j
                 auto emit_range = [&](uint64_t lo, uint64_t hi, auto start_of) {
-                    for (uint64_t P = lo & ~(uint64_t)(UFRAME - 1u); P < hi; P += UFRAME) {
-                        const uint64_t i0 = P + 2u * lane, i1 = i0 + 1u;
-                        const bool v0 = i0 >= lo && i0 < hi && i0 < a.capacity, v1 = i1 >= lo && i1 < hi && i1 < a.capacity;
+                    // (elements at or beyond the capacity are not stored: the host reports KMERS_E_CAPACITY with the count needed)
+                    const uint64_t room = a.capacity > lo ? a.capacity - lo : 0;
+                    const uint32_t n = (uint32_t)(hi - lo < room ? hi - lo : room);
+                    const uint32_t head = (uint32_t)lo & (UFRAME - 1u);  // where `lo` lies in its frame
+                    for (uint32_t f = 0; f < head + n; f += UFRAME) {
+                        const uint32_t j0 = f + 2u * lane - head, j1 = j0 + 1u;  // element numbers relative to lo (wrapped if before it)
+                        const bool v0 = j0 < n, v1 = j1 < n;
                         if (!(v0 || v1)) continue;
                         uint32_t ra = 0, rb = 0;
                         uint64_t fa[NW], fb[NW];
                         if (v0) {
-                            ra = start_of((uint32_t)(i0 - lo));
+                            ra = start_of(j0);
                             cut_fw<NW>(lds, kbit0 - 2u * ra, mask, fa);
                         }
                         if (v1) {
-                            rb = start_of((uint32_t)(i1 - lo));
+                            rb = start_of(j1);
                             cut_fw<NW>(lds, kbit0 - 2u * rb, mask, fb);
                         }
+                        const uint64_t i1 = lo + j1, i0 = i1 - 1u;  // (i1 is the one that always exists: j1 = 0 when `lo` is odd)
                         if (v0 && v1) {
                             if (a.out_kmers) {
                                 if constexpr (N == 1) {

@@ -156,6 +156,13 @@ class Context:
         self.check(self.lib.kmers_arena_info(self.handle, C.byref(r), C.byref(u), C.byref(f)), "kmers_arena_info")
         return r.value, u.value, f.value
 
+    def arena_regions(self):
+        """(base address, granule bytes, [class of every granule]) of the arena's measured region map; granule 0 without one."""
+        g, n, base = C.c_size_t(), C.c_size_t(), C.c_void_p()
+        buf = (C.c_ubyte * 1024)()
+        self.check(self.lib.kmers_arena_regions(self.handle, C.byref(base), C.byref(g), buf, 1024, C.byref(n)), "kmers_arena_regions")
+        return base.value or 0, g.value, list(buf[:min(n.value, 1024)]) if g.value else []
+
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)
         self.check(self.lib.kmers_memcpy_h2d(self.handle, C.c_void_p(dptr), arr.ctypes.data_as(C.c_void_p),

@@ -7,6 +7,9 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+# torch FIRST: it brings its own copy of the HIP / HSA runtime libraries, and a process that has already loaded /opt/rocm's
+# (through libkmers_hip.so) cannot initialise torch's afterwards ("No HIP GPUs are available")
+torch = pytest.importorskip("torch")
 
 
 @pytest.fixture()
@@ -75,4 +78,46 @@ def test_launch_inside_the_arena_matches_the_oracle(km, orc):
     for p in (d_words, d_k, d_h):
         ctx.free(p)
     ctx.arena_release()
+    ctx.close()
+
+
+def test_arena_measures_its_region_map_and_spreads_the_outputs_of_a_launch(km):
+    """A large arena measures the region map of its block (memory_api.hip: store streams inside one region class of HBM share a
+    lower write rate than streams in different classes) and places the arrays of a launch accordingly: a block lies in another
+    class than the block before it.  The map itself is a property of the machine: the test asks for its invariants only."""
+    cap = km._capi
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    if free_b < 100e9:
+        pytest.skip(f"needs 100 GB of free HBM for a map with more than one class, {free_b / 1e9:.0f} GB free")
+    ctx = km.Context(0)
+    reserved = ctx.arena_reserve(int(free_b * 0.7))
+    base, gran, classes = ctx.arena_regions()
+    assert base and gran == 4 << 30 and len(classes) == reserved // gran
+    assert 2 <= len(set(classes)) <= 16, classes
+    # classes come in runs (regions of tens of gigabytes), not as noise
+    runs = 1 + sum(1 for i in range(1, len(classes)) if classes[i] != classes[i - 1])
+    assert runs <= 12, classes
+
+    def covered(ptr, nbytes):
+        off = ptr - base
+        assert 0 <= off and off + nbytes <= reserved
+        return {classes[min(g, len(classes) - 1)] for g in range(off // gran, (off + nbytes - 1) // gran + 1)}
+    small = ctx.alloc(64 << 20)          # (a small block first: the source words of a launch)
+    a = ctx.alloc(8 << 30)
+    b = ctx.alloc(8 << 30)
+    assert ctx.arena_info()[1] == (64 << 20) + (16 << 30)
+    assert all(p % cap.ARENA_GRANULE == 0 for p in (small, a, b))
+    ca, cb = covered(a, 8 << 30), covered(b, 8 << 30)
+    assert ca != cb or len(ca) >= 2, (ca, cb, classes)   # the outputs of one launch never share one single class
+    for p in (small, a, b):
+        ctx.free(p)
+    assert ctx.arena_info() == (reserved, 0, reserved)
+    ctx.arena_release()
+    # probing switched off: no map, best fit from the bottom of the block
+    ctx.set_param(cap.PARAM_ARENA_NO_PROBE, 1)
+    ctx.arena_reserve(reserved // 4)
+    base2, gran2, classes2 = ctx.arena_regions()
+    assert gran2 == 0 and classes2 == []
+    p0, p1 = ctx.alloc(1 << 30), ctx.alloc(1 << 30)
+    assert p0 == base2 and p1 == p0 + (1 << 30)
     ctx.close()

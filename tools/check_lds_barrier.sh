@@ -7,8 +7,11 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="${1:-/tmp/kmers_isa}"
 mkdir -p "$OUT"
 cd "$ROOT/kmers.jl_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only kmers_api.hip -o "$OUT/settle.s" 2>/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -DKMERS_NO_SETTLE kmers_api.hip -o "$OUT/nosettle.s" 2>/dev/null
+: > "$OUT/settle.s"; : > "$OUT/nosettle.s"
+for f in *_api.hip; do   # every translation unit of the library, concatenated
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only "$f" -o "$OUT/one.s" 2>/dev/null && cat "$OUT/one.s" >> "$OUT/settle.s"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -DKMERS_NO_SETTLE "$f" -o "$OUT/one.s" 2>/dev/null && cat "$OUT/one.s" >> "$OUT/nosettle.s"
+done
 python3 - "$OUT" <<'PY'
 import re, sys
 out = sys.argv[1]

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Files what `tools/evidence.sh` measured on the GPU box (gpurun_out/r3ev/) under profiles/r03_*:
+
+  r03_bench.json                 the driver's command, as printed
+  r03_bench_under_rocprof.json   the same program under rocprofv3 --kernel-trace --stats (its line) ...
+  r03_kernel_stats.csv           ... and rocprofv3's per-kernel summary of that run
+  r03_kernel_stats_<leg>.csv     one --kernel-trace --stats pass per leg (tools/leg.py): each leg is a row of its own file
+  r03_legs.md                    per leg: rocprofv3's average kernel duration -> fraction of 8 TB/s on the algorithmic bytes of
+                                 SURVEY.md 8(d), next to the leg's own HIP-event median; HBM bytes per launch from the
+                                 FETCH_SIZE / WRITE_SIZE passes (gfx950 correction as MI355X_MICROARCH.md prescribes)
+  pmc_traffic.json               the headline launch's bytes (bench.py replays it only when its live passes fail, and says so)
+"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+E = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r3ev")
+P = os.path.join(ROOT, "profiles")
+L = 1_000_000_000
+LEGS = {  # leg -> (label, kernel substring, algorithmic bytes per launch given the leg's printed line)
+    "c2": ("C2 CanonicalDNAMers{31} + fx_hash, 1 Gbase LongDNA{4}", "stream_kernel<4, 2, 1, 1", lambda kept: 16.5 * (L - 30)),
+    "c3": ("C3 CanonicalDNAMers{31}, 1.25 Gbase LongDNA{2}", "stream_kernel<2, 2, 1, 1", lambda kept: 8.25 * (1_250_000_000 - 30)),
+    "c4": ("C4 FwDNAMers{63} + reverse complements", "stream_kernel<4, 2, 2, 0", lambda kept: 32.5 * (L - 62)),
+    "c5": ("C5 strict SpacedDNAMers{21,3}", "stream_kernel<4, 2, 1, 0, false", lambda kept: 0.5 * L + 8.0 * ((L - 21) // 3 + 1)),
+    "u31": ("UnambiguousDNAMers{31}, p(N) = 0.04", "unambiguous_kernel<4, 1, 0", lambda kept: 0.5 * L + 16.0 * kept),
+    "u21": ("C5 skip variant: UnambiguousDNAMers{21} on the stride-3 lattice, p(N) = 0.04", "unambiguous_kernel<4, 1, 0", lambda kept: 0.5 * L + 16.0 * kept),
+    "xor": ("fused XOR-reduce of CanonicalDNAMers{31}", "run_kernel<4", lambda kept: 0.0),
+}
+
+
+def copy(src, dst):
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, dst))
+        return True
+    print("missing", src)
+    return False
+
+
+def first_json_line(path):
+    try:
+        for l in open(path):
+            if l.startswith("{"):
+                return json.loads(l)
+    except OSError:
+        pass
+    return None
+
+
+def main():
+    os.makedirs(P, exist_ok=True)
+    for name in ("bench.json", "bench_under_rocprof.json"):
+        d = first_json_line(os.path.join(E, name))
+        if d:
+            json.dump(d, open(os.path.join(P, "r03_" + name), "w"), indent=1)
+    copy(os.path.join(E, "kernel_stats.csv"), "r03_kernel_stats.csv")
+    bench = first_json_line(os.path.join(E, "bench.json")) or {}
+    rows = ["# Round 3: every leg in a rocprofv3 pass of its own (`tools/evidence.sh`, one MI355X, outputs from the context's arena)", "",
+            "`ms (rocprofv3)` = average duration of the leg's kernel in `profiles/r03_kernel_stats_<leg>.csv` (a `--kernel-trace --stats` pass over",
+            "`tools/leg.py --leg <leg>`: warm-up launches + 20 timed ones); `ms (HIP events)` = the median the same process printed; fractions",
+            "are of 8 TB/s on the algorithmic bytes of SURVEY.md 8(d).  HBM bytes: `FETCH_SIZE x 2` (gfx950: the counter reports half of a",
+            "coalesced streaming read) `+ WRITE_SIZE`, separate passes over two bare launches (`leg.py --once`).", "",
+            "| leg | kernel | calls | ms (rocprofv3) | frac | ms (HIP events) | frac | HBM bytes / algorithmic |", "|---|---|---|---|---|---|---|---|"]
+    for leg, (label, sub, alg_of) in LEGS.items():
+        stats = os.path.join(E, f"kernel_stats_{leg}.csv")
+        if not copy(stats, f"r03_kernel_stats_{leg}.csv"):
+            continue
+        kept, ev_ms = 0, None
+        try:
+            last = [l for l in open(os.path.join(E, f"stats_{leg}.txt")) if l.startswith(leg)][-1]
+            m = re.search(r"kept=(\d+)", last)
+            kept = int(m.group(1)) if m else 0
+            m = re.search(r": ([0-9.]+) ms", last)
+            ev_ms = float(m.group(1)) if m else None
+        except (OSError, IndexError):
+            pass
+        alg = alg_of(kept)
+        best = None
+        for r in csv.DictReader(open(stats)):
+            if sub in r["Name"] and (best is None or float(r["TotalDurationNs"]) > float(best["TotalDurationNs"])):
+                best = r
+        if not best:
+            continue
+        ms = float(best["AverageNs"]) / 1e6
+        traffic = ""
+        vals = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            v = []
+            for f in glob.glob(os.path.join(E, f"pmc_{c}_{leg}", "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if sub in r["Kernel_Name"] and r["Counter_Name"] == c:
+                        v.append(float(r["Counter_Value"]))
+            if v:
+                vals[c] = sum(v) / len(v)
+        if len(vals) == 2 and alg:
+            tot = vals["FETCH_SIZE"] * 2048 + vals["WRITE_SIZE"] * 1024
+            traffic = f"{tot / 1e9:.3f} GB / {alg / 1e9:.3f} GB = {tot / alg:.3f}"
+        fr = lambda t: f"{alg / t / 1e6 / 8000:.3f}" if alg and t else "-"
+        rows.append(f"| {label} | `{best['Name'][:70]}` | {best['Calls']} | {ms:.4f} | {fr(ms)} | {ev_ms if ev_ms else '-'} | {fr(ev_ms)} | {traffic} |")
+    open(os.path.join(P, "r03_legs.md"), "w").write("\n".join(rows) + "\n")
+    rf = bench.get("roofline", {})
+    if rf.get("traffic") and "measured in this run" in rf.get("traffic_source", ""):
+        json.dump({"bases": bench["config"].get("bases_per_gpu"), "k": bench["config"]["k"], "src_bits": bench["config"]["src_bits"],
+                   "traffic_bytes_per_launch": rf["traffic"], "source": "profiles/r03_bench.json: " + rf["traffic_source"]},
+                  open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+    print("\n".join(rows))
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,10 @@ import torch
 
 import kmers_jl_amd as km
 
+if os.environ.get("LEG_OLD_ABI"):  # A/B against a library of an earlier round (KMERS_HIP_LIB=tools/libkmers_r02.so): no arena, no sub-tiles
+    for name in [n for n in km._capi.SYMBOLS if "arena" in n]:
+        del km._capi.SYMBOLS[name]
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--leg", default="c2")
 ap.add_argument("--alloc", default="plain")
@@ -37,7 +41,9 @@ ap.add_argument("--busy-ms", type=float, default=300.0)
 ap.add_argument("--tile", type=int, default=0)
 ap.add_argument("--max-grid", type=int, default=0)
 ap.add_argument("--subtiles", type=int, default=0)
+ap.add_argument("--split", action="store_true", help="two write windows per array (KMERS_PARAM_SPLIT_ORDER)")
 ap.add_argument("--once", action="store_true")
+ap.add_argument("--shifts", default="", help="carve mode: comma-separated SA:SB byte shifts of the two output bases inside the block; one timing per pair, same process")
 ap.add_argument("--bases", type=int, default=1_000_000_000)
 args = ap.parse_args()
 
@@ -54,6 +60,8 @@ if args.max_grid:
     ctx.set_param(cap.PARAM_MAX_GRID, args.max_grid)
 if args.subtiles:
     ctx.set_param(cap.PARAM_SUBTILES, args.subtiles)
+if args.split:
+    ctx.set_param(cap.PARAM_SPLIT_ORDER, 1)
 
 leg = args.leg
 L = 1_250_000_000 if leg == "c3" else args.bases
@@ -82,10 +90,21 @@ with torch.cuda.stream(stream):
         keep.append(block)
         pa = block.data_ptr()
         pb = pa + ((8 * words_a + (1 << 21) - 1) >> 21 << 21)
+    elif mode == "arenacarve":  # the arena's block and its measured map, but the two arrays at offsets given by --shifts
+        ctx.check(ctx.lib.kmers_arena_reserve(ctx.handle, size << 30), "kmers_arena_reserve")
+        abase, gran, classes = ctx.arena_regions()
+        print("arena map", "".join(chr(65 + c) for c in classes), flush=True)
+        pa = pb = abase
+        mode = "carve"
     elif mode == "arena":
         ctx.check(ctx.lib.kmers_arena_reserve(ctx.handle, size << 30), "kmers_arena_reserve")
         pa = ctx.alloc(8 * words_a)
         pb = ctx.alloc(8 * max(words_b, 1))
+        abase, gran, classes = ctx.arena_regions()
+        if gran:
+            cls = lambda p, nbytes: "".join(sorted({chr(65 + classes[min(g, len(classes) - 1)]) for g in range((p - abase) // gran, (p - abase + nbytes - 1) // gran + 1)}))
+            print(f"arena map {''.join(chr(65 + c) for c in classes)}; a at {(pa - abase) / 2**30:.2f} GiB in {cls(pa, 8 * words_a)}, "
+                  f"b at {(pb - abase) / 2**30:.2f} GiB in {cls(pb, 8 * max(words_b, 1))}", flush=True)
     else:
         ta = torch.empty(words_a, dtype=torch.int64, device=dev)
         tb = torch.empty(max(words_b, 1), dtype=torch.int64, device=dev)
@@ -122,11 +141,34 @@ def fn():
 
 
 if args.once:
+    if args.shifts:  # the first pair only: the two launches a PMC pass profiles, at a chosen place of the block
+        sa, sb = (int(float(x)) for x in args.shifts.split(",")[0].split(":"))
+        pa, pb = pa + sa, pb + sb
     fn()
     fn()
     torch.cuda.synchronize()
     ctx.sync()
     print(f"{leg} {args.alloc} once kept={m_kept}", flush=True)
+    sys.exit(0)
+
+if args.shifts:
+    assert mode == "carve"
+    pa0, pb0 = pa, pb
+    for pair in args.shifts.split(","):
+        sa, sb = (int(float(x)) for x in pair.split(":"))
+        pa, pb = pa0 + sa, pb0 + sb
+        with torch.cuda.stream(stream):
+            for _ in range(6):
+                fn()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+            ev[0].record(stream)
+            for i in range(5):
+                fn()
+                ev[i + 1].record(stream)
+            torch.cuda.synchronize()
+        ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+        med = float(np.median(ts))
+        print(f"{leg} shift a {sa:10d} b {sb:10d}: {med:.4f} ms frac {alg / med / 1e6 / 8000:.4f}", flush=True)
     sys.exit(0)
 
 with torch.cuda.stream(stream):
@@ -146,4 +188,5 @@ assert rc == 0, ctx.last_error()
 ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.reps)]
 med = float(np.median(ts))
 frac = f"frac {alg / med / 1e6 / 8000:.4f}" if alg else ""
-print(f"{leg:7s} {args.alloc:12s} tile {args.tile:5d} sub {args.subtiles}: {med:.4f} ms (min {min(ts):.4f} max {max(ts):.4f}) {frac} kept={m_kept} a at {pa:#x}", flush=True)
+nosplit = " split" if args.split else ""
+print(f"{leg:7s} {args.alloc:12s} tile {args.tile:5d} sub {args.subtiles}{nosplit}: {med:.4f} ms (min {min(ts):.4f} max {max(ts):.4f}) {frac} kept={m_kept} a at {pa:#x}", flush=True)

@@ -9,14 +9,16 @@ for leg in c2 c4; do python3 tools/leg.py --leg $leg --alloc plain >> $T 2>> $O/
 cd /tmp && export TMPDIR=/tmp
 pmc() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -- python3 $R/tools/leg.py --leg $LEG --alloc $ALLOC --once > $O/$name.txt 2>&1
+  # (timeout: a counter set the hardware cannot collect aborts the child and leaves rocprofv3 waiting forever)
+  timeout 180 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -- python3 $R/tools/leg.py --leg $LEG --alloc $ALLOC --once > $O/$name.txt 2>&1
 }
 passes() {  # state label
   pmc $1_${LEG}_utcl1 TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_PERMISSION_MISS_sum
   pmc $1_${LEG}_utcl1s TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_LFIFO_FULL_sum
   pmc $1_${LEG}_tccw TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_LEVEL_sum
   pmc $1_${LEG}_lat TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum
-  if [ $LEG = c4 ]; then pmc $1_${LEG}_grbm GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE GRBM_EA_BUSY GRBM_TC_BUSY; fi
+  pmc $1_${LEG}_grbm GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE
+  pmc $1_${LEG}_tcc2 TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_BUSY_sum TCC_TAG_STALL_sum
 }
 ALLOC=plain
 for LEG in c2 c4; do passes slow; done
@@ -53,4 +55,3 @@ open(O + "/counters.md", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
 PY
 tail -5 $O/err.txt
-python3 -m pytest tests/test_gpu_arena.py tests/test_gpu_comm.py -x -q -m gpu 2>&1 | tail -5

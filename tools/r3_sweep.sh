@@ -4,7 +4,7 @@
 #   UnambiguousKmers (framed stores): K = 31 and the C5 lattice
 O=$PWD/gpurun_out/r3s; rm -rf $O; mkdir -p $O
 T=$O/times.txt
-python3 -m pytest tests/test_gpu_arena.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -5 | tee $O/pytest.txt
+timeout 900 python3 -m pytest tests/test_gpu_arena.py tests/test_gpu_comm.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -5 | tee $O/pytest.txt
 A="--alloc arena:0"
 for rep in 1 2; do
   for sub in 1 2 3 4 6; do for tile in 2048 4096; do python3 tools/leg.py --leg c5 $A --tile $tile --subtiles $sub >> $T 2>> $O/err.txt; done; done
