@@ -117,6 +117,7 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
                                          * array; +1 % for one output array that straddles two region classes of HBM, -1..4 % for two
                                          * arrays; results are identical either way) */
 #define KMERS_PARAM_ARENA_NO_PROBE 8   /* 1: kmers_arena_reserve does not measure the region map of its block (best-fit placement only) */
+#define KMERS_PARAM_BLOCK_THREADS 10   /* threads per workgroup of the tile kernels: 64, 128 or 256 (0: chosen per output shape) */
 #define KMERS_PARAM_SUBTILES 7         /* strided tile kernels (kmers_spaced, kmers_minimizers): consecutive tiles per workgroup, the next one's source words in flight */
 int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
 

@@ -24,9 +24,30 @@ struct kmers_arena {
     std::vector<size_t> run_start;         // the map as runs: run i = [run_start[i], run_start[i + 1]) is in class run_class[i];
     std::vector<uint8_t> run_class;        //   boundaries refined to about half a gigabyte
     std::vector<float> pair_rate;          // measured: pair_rate[i * n_runs + j] = GB/s of two store streams, one in run i, one in run j
+    float best_pair_rate = 0.f;            // the largest of them
     int n_classes = 0;
     int last_run = -1, last2_run = -1;     // runs of the two most recent allocations
 };
+
+// index of the arena's run that holds offset `off` (the map must exist)
+inline size_t kmers_arena_run_of(const kmers_arena &a, size_t off) {
+    size_t lo = 0, hi = a.run_start.size();
+    while (hi - lo > 1) {
+        const size_t mid = (lo + hi) / 2;
+        if (a.run_start[mid] <= off) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+// true iff p and q both lie in the arena, in runs whose MEASURED two-stream rate is within 5 % of the best pair of the block:
+// the launchers pick the launch shape that is fastest for well-placed outputs only then (stream_launch.hpp)
+inline bool kmers_arena_spread(const kmers_arena &a, const void *p, const void *q) {
+    if (a.run_start.empty() || !p || !q) return false;
+    const char *cp = static_cast<const char *>(p), *cq = static_cast<const char *>(q);
+    if (cp < a.base || cp >= a.base + a.bytes || cq < a.base || cq >= a.base + a.bytes) return false;
+    const size_t k = a.run_start.size(), i = kmers_arena_run_of(a, (size_t)(cp - a.base)), j = kmers_arena_run_of(a, (size_t)(cq - a.base));
+    return a.pair_rate[i * k + j] >= 0.95f * a.best_pair_rate;
+}
 
 struct kmers_ctx {
     int device = 0;
@@ -44,6 +65,7 @@ struct kmers_ctx {
     int64_t tile_kmers = 0;  // 0 = default
     int64_t max_grid = 0;    // 0 = default
     int64_t subtiles = 0;    // KMERS_PARAM_SUBTILES; 0 = default
+    int64_t block_threads = 0;  // KMERS_PARAM_BLOCK_THREADS: 64 / 128 / 256 threads per workgroup of the tile kernel; 0 = per shape
     int64_t split_order = 0;     // KMERS_PARAM_SPLIT_ORDER: the tile kernels visit the two halves of their tile range alternately
     int64_t arena_no_probe = 0;  // KMERS_PARAM_ARENA_NO_PROBE: kmers_arena_reserve skips the region calibration
     int64_t stamps_ptr = 0;  // diagnostic builds only (KMERS_PARAM_STAMPS_PTR)

@@ -30,7 +30,7 @@ constexpr size_t GRANULE = KMERS_ARENA_GRANULE;
 size_t round_up(size_t x) { return (x + GRANULE - 1) / GRANULE * GRANULE; }
 
 constexpr size_t REGION = (size_t)4 << 30;    // granule of the region map
-constexpr size_t PROBE = (size_t)512 << 20;   // bytes per stream of one probe
+constexpr size_t PROBE = (size_t)1 << 30;     // bytes per stream of one probe
 
 // two store streams, 8 KiB of each per workgroup, 16 bytes per lane: the shape of the stream kernels' outputs
 __global__ __launch_bounds__(256) void arena_probe_kernel(ulonglong2 *a, ulonglong2 *b) {
@@ -42,11 +42,11 @@ __global__ __launch_bounds__(256) void arena_probe_kernel(ulonglong2 *a, ulonglo
     }
 }
 
-// milliseconds of one probe (the faster of two): PROBE bytes at offset x and PROBE bytes at offset y of the block
+// milliseconds of one probe (the fastest of three): PROBE bytes at offset x and PROBE bytes at offset y of the block
 int probe_ms(kmers_ctx *ctx, hipEvent_t e0, hipEvent_t e1, size_t x, size_t y, float *out) {
     char *base = ctx->arena.base;
     float best = 1e30f;
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < 3; ++rep) {
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
         hipLaunchKernelGGL(arena_probe_kernel, dim3((unsigned)(PROBE / 8192)), dim3(256), 0, ctx->stream, reinterpret_cast<ulonglong2 *>(base + x),
                            reinterpret_cast<ulonglong2 *>(base + y));
@@ -72,6 +72,7 @@ int calibrate(kmers_ctx *ctx) {
     a.region_bytes = 0;
     a.n_classes = 0;
     a.pair_rate.clear();
+    a.best_pair_rate = 0.f;
     a.last_run = a.last2_run = -1;
     const size_t n = a.bytes / REGION;
     if (n < 4 || ctx->arena_no_probe) return KMERS_OK;
@@ -109,6 +110,20 @@ int calibrate(kmers_ctx *ctx) {
                 c = (int)refs.size() - 1;
             }
             cls[g] = (uint8_t)c;
+        }
+    }
+    // a lone granule between two granules of one class is usually a noisy probe, not a region: asked again, against that class
+    if (rc == KMERS_OK && refs.size() >= 2) {
+        std::vector<float> sorted = same;
+        std::sort(sorted.begin(), sorted.end());
+        const float threshold = 0.93f * sorted[n / 2];
+        for (size_t g = 1; g + 1 < n && rc == KMERS_OK; ++g) {
+            if (cls[g - 1] != cls[g + 1] || cls[g] == cls[g - 1]) continue;
+            const size_t r = refs[cls[g - 1]];
+            float t0, t1;
+            rc = probe_ms(ctx, e0, e1, g * REGION, r * REGION + REGION / 2, &t0);
+            if (rc == KMERS_OK) rc = probe_ms(ctx, e0, e1, g * REGION + REGION / 2, r * REGION + REGION / 2, &t1);
+            if (rc == KMERS_OK && (t0 >= threshold || t1 >= threshold)) cls[g] = cls[g - 1];
         }
     }
     std::vector<size_t> run_start;
@@ -164,6 +179,7 @@ int calibrate(kmers_ctx *ctx) {
         a.run_start = run_start;
         a.run_class = run_class;
         a.pair_rate = pair;
+        a.best_pair_rate = pair.empty() ? 0.f : *std::max_element(pair.begin(), pair.end());
         if (std::getenv("KMERS_ARENA_DEBUG")) {  // the measured map on stderr
             for (size_t i = 0; i < k; ++i) {
                 std::fprintf(stderr, "arena run %2zu: class %c at %7.2f GiB:", i, 'A' + run_class[i], (double)run_start[i] / (double)((size_t)1 << 30));
@@ -175,10 +191,7 @@ int calibrate(kmers_ctx *ctx) {
     return KMERS_OK;
 }
 
-size_t run_of(const kmers_arena &a, size_t off) {  // index of the run that holds `off`
-    size_t i = std::upper_bound(a.run_start.begin(), a.run_start.end(), off) - a.run_start.begin();
-    return i ? i - 1 : 0;
-}
+size_t run_of(const kmers_arena &a, size_t off) { return kmers_arena_run_of(a, off); }
 int class_at(const kmers_arena &a, size_t off) { return a.run_class.empty() ? 0 : a.run_class[run_of(a, off)]; }
 size_t run_end(const kmers_arena &a, size_t i) { return i + 1 < a.run_start.size() ? a.run_start[i + 1] : a.bytes; }
 

@@ -348,6 +348,9 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     static_assert(!FWD || (MODE == MODE_FW && DST == 2 && !TUPLES), "FWD: forward kmers of a 2-bit alphabet, separate arrays");
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     const uint32_t tid = threadIdx.x;
+    // threads per workgroup: a LAUNCH parameter (64, 128 or 256: stream_launch.hpp picks it per output shape); the tile, not
+    // the workgroup, fixes how much a workgroup writes
+    const uint32_t TB = blockDim.x;
     const uint32_t k = a.k;
     const uint32_t J = STRIDE1 ? 1u : a.stride;
     const uint64_t mask = head_mask((int)k, DST);  // mask of the kmer's head word
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     const uint32_t text = (SRC_BITS == 8 && DST == 2 && a.ascii_table <= 1u) ? 1u + a.ascii_table : 0u;
     if constexpr (SRC_BITS == 8) {
         if (!text)
-            for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);  // computed, not loaded; visible after the tile loop's first barrier
+            for (uint32_t i = tid; i < 256u; i += TB) lut[i] = ascii_entry(a.ascii_table, i);  // computed, not loaded; visible after the tile loop's first barrier
     }
     static_assert(!PAIR || (!STRIDE1 && N == 1 && !TUPLES && (MODE == MODE_FW || MODE == MODE_XOR)), "PAIR: strided one-word kmers");
     constexpr uint32_t KPL = ((STRIDE1 || PAIR) && N == 1 && !TUPLES) ? 2u : 1u;  // kmers per lane per pass -> 16 B stores
@@ -397,14 +400,14 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     auto load_round = [&](const Geom &g, uint32_t base, uint64_t (&x)[PRE]) {  // all of a lane's loads of a round are issued together
 #pragma unroll
         for (uint32_t j = 0; j < PRE; ++j) {
-            const uint32_t wi = base + j * BLOCK + tid;
+            const uint32_t wi = base + j * TB + tid;
             x[j] = wi < g.nw ? a.src[g.w0 + wi] : 0;
         }
     };
     auto stage_round = [&](const Geom &g, uint32_t base, const uint64_t (&x)[PRE], uint64_t *lds) {
 #pragma unroll
         for (uint32_t j = 0; j < PRE; ++j) {
-            const uint32_t wi = base + j * BLOCK + tid;
+            const uint32_t wi = base + j * TB + tid;
             if (wi < g.nw) {
                 uint64_t f = stage_word<SRC_BITS, DST, FWD>(lds, FWD ? g.nw - 1u - wi : wi, x[j], lut, text);
                 if constexpr ((SRC_BITS == 4 && DST == 2) || SRC_BITS == 8) {
@@ -445,14 +448,14 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
         // ---- phase 1: source words -> DST-bit stream in LDS ------------------------------
         if constexpr (STRIDE1) {
             block_sync();  // previous tile's readers are done with the LDS stream
-            for (uint32_t base = 0; base < nw; base += PRE * BLOCK) {
+            for (uint32_t base = 0; base < nw; base += PRE * TB) {
                 load_round(g, base, xpre);
                 stage_round(g, base, xpre, lds);
             }
         } else {
             // (no barrier in front: this buffer's readers -- the tile before last -- all passed the barrier below since)
             stage_round(g, 0, xpre, lds);
-            for (uint32_t base = PRE * BLOCK; base < nw; base += PRE * BLOCK) {  // (tiles longer than one round: not prefetched)
+            for (uint32_t base = PRE * TB; base < nw; base += PRE * TB) {  // (tiles longer than one round: not prefetched)
                 load_round(g, base, xpre);
                 stage_round(g, base, xpre, lds);
             }
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
         }
 
         // ---- phase 2: windows -> kmers ---------------------------------------------------
-        for (uint32_t r = tid * KPL; r < mt; r += BLOCK * KPL) {
+        for (uint32_t r = tid * KPL; r < mt; r += TB * KPL) {
             const uint64_t g = m0 + r;
             uint64_t fw[KPL][N], rc[KPL][N];
             if constexpr (FWD) {
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         t4 = __builtin_amdgcn_s_memrealtime();
         if (a.stamps && (tile & 1023u) == 0 && (tid & 63u) == 0) {
-            uint64_t *o = a.stamps + ((tile >> 10) * WAVES + (tid >> 6)) * 8;
+            uint64_t *o = a.stamps + ((tile >> 10) * (TB >> 6) + (tid >> 6)) * 8;
             o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = tile;
         }
 #endif

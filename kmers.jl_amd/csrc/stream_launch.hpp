@@ -87,7 +87,20 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
 #else
     const bool fwd = MODE == MODE_FW && dst_bits == 2 && !a.out_b && !a.tuples;  // no reverse complements wanted
 #endif
-    const uint32_t pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * BLOCK;  // kmers per workgroup pass
+    // Launch shape of the two-output, one-word-element launches (canonical kmers + hashes -- the headline --, forward + reverse
+    // complements, forward kmers + start indices), measured in round 3 (profiles/r03_tuning.md, 1 Gbase, A/B on one box):
+    //   * 24 KiB of output per workgroup (1536 kmers) instead of 16: 0.85-0.87 against 0.81-0.82 of 8 TB/s wherever the arrays lie;
+    //   * workgroups of 128 threads when the two arrays lie in well-separated region classes of HBM, which the launcher knows
+    //     for blocks of the context's arena (kmers_arena_spread): 0.878-0.894 against 0.866-0.872 with 256; arrays in one class
+    //     (or of unknown placement) are faster with 256: 0.85-0.87 against 0.82-0.83.
+    // Every other shape keeps 16 KiB and 256 threads (C3 0.80-0.82 / 0.72-0.77 with 128, C4 0.87 at 512 x 256 in both
+    // placements, C5 0.75-0.76 / 0.72-0.76).
+    const bool two_word_streams = n_words == 1 && stride1 && !a.tuples && a.out_a && (a.out_b || a.out_starts) &&
+                                  (MODE == MODE_FW || MODE == MODE_CANON);
+    const bool spread = two_word_streams && kmers_arena_spread(ctx->arena, a.out_a, a.out_b ? (const void *)a.out_b : (const void *)a.out_starts);
+    uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads : (spread ? 128u : (uint32_t)BLOCK);
+    if (threads != 64u && threads != 128u) threads = (uint32_t)BLOCK;
+    const uint32_t pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * threads;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
                          (MODE == MODE_CANON && a.out_b ? 8u : 0u) + (MODE == MODE_FW && a.out_starts ? 8u : 0u);
     if (a.tuples) out_bytes = MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u;
@@ -96,6 +109,7 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     uint32_t max_tile_symbols = (uint32_t)MAX_TILE_BITS / (uint32_t)dst_bits;
     if (MODE == MODE_MINIMIZER) max_tile_symbols -= std::min<uint32_t>(max_tile_symbols / 2, a.window_kmers);  // room for the longer overlap
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
+    if (ctx->tile_kmers <= 0 && two_word_streams) tile = tile * 3 / 2 / pass * pass;  // 24 KiB per workgroup (see above)
     // (round 2 doubled the tile of strided launches -- 32 KiB of output per workgroup; with two lattice kmers per lane the 16 KiB
     // tile is as fast or faster on every box measured in round 3: 0.73-0.76 against 0.70-0.74, profiles/r03_tuning.md)
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);
@@ -111,10 +125,10 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     const uint64_t visits = (a.n_tiles + a.subtiles - 1) / a.subtiles;
     // two write windows per output array (stream_kernel.hpp, SPLIT ORDER): opt-in, see KMERS_PARAM_SPLIT_ORDER
     const bool materialises = MODE == MODE_FW || MODE == MODE_CANON || MODE == MODE_MINIMIZER;
-    a.split_order = materialises && visits >= 4096 && ctx->split_order != 0 ? 1u : 0u;
+    a.split_order = materialises && visits >= 2 && ctx->split_order != 0 ? 1u : 0u;
     const uint64_t slots = a.split_order ? 2 * ((visits + 1) / 2) : visits;
     dim3 grid((unsigned)std::min<uint64_t>(slots, cap));
-    dim3 block(BLOCK);
+    dim3 block(threads);
     if (src_bits == 8 && dst_bits == 2) launch_widths<MODE, 8, 2>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
     else if (src_bits == 8) launch_widths<MODE, 8, 4>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
     else if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);

@@ -94,9 +94,9 @@ def test_arena_measures_its_region_map_and_spreads_the_outputs_of_a_launch(km):
     base, gran, classes = ctx.arena_regions()
     assert base and gran == 4 << 30 and len(classes) == reserved // gran
     assert 2 <= len(set(classes)) <= 16, classes
-    # classes come in runs (regions of tens of gigabytes), not as noise
-    runs = 1 + sum(1 for i in range(1, len(classes)) if classes[i] != classes[i - 1])
-    assert runs <= 12, classes
+    # classes come in runs (regions of tens of gigabytes), not as noise: most granules have a neighbour of their own class
+    lonely = sum(1 for i in range(1, len(classes) - 1) if classes[i] != classes[i - 1] and classes[i] != classes[i + 1])
+    assert lonely <= len(classes) // 8, classes
 
     def covered(ptr, nbytes):
         off = ptr - base

@@ -68,6 +68,13 @@ def test_fuzz_iterators(km, ctx, orc, seed):
         p_amb = float(rng.choice([0.0, 0.0, 0.002, 0.05]))
         rna = int(rng.integers(0, 2))
         N = (K * dst + 63) // 64
+        # launch shapes of the tile kernels: threads per workgroup, tiles per visit, the order of the visits, small tiles
+        ctx.set_param(cap.PARAM_TILE_KMERS, 0)
+        ctx.set_param(cap.PARAM_BLOCK_THREADS, int(rng.choice([0, 0, 64, 128, 256])))
+        ctx.set_param(cap.PARAM_SUBTILES, int(rng.choice([0, 0, 1, 2, 5])))
+        ctx.set_param(cap.PARAM_SPLIT_ORDER, int(rng.choice([0, 0, 1])))
+        if case % 4 == 0:
+            ctx.set_param(cap.PARAM_TILE_KMERS, int(rng.choice([512, 1024, 1536])))
         words, view_words, osrc = make_source(rng, src, L, first, p_amb, rna)
         seq = cap.Seq(words.ctypes.data, L, first, 0, 8 if src == 10 else src, 2 if src == 10 else rna)
         res = cap.Result()
@@ -127,6 +134,8 @@ def test_fuzz_iterators(km, ctx, orc, seed):
                     assert rc == 0 and np.array_equal(only[:m], es), tag + (J, "starts only")
             ctx.set_param(cap.PARAM_TILE_KMERS, 0)
             ctx.set_param(cap.PARAM_MAX_GRID, 0)
+    for prm in (cap.PARAM_TILE_KMERS, cap.PARAM_BLOCK_THREADS, cap.PARAM_SUBTILES, cap.PARAM_SPLIT_ORDER):
+        ctx.set_param(prm, 0)
 
 
 @pytest.mark.parametrize("seed", range(2))

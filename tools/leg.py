@@ -41,6 +41,7 @@ ap.add_argument("--busy-ms", type=float, default=300.0)
 ap.add_argument("--tile", type=int, default=0)
 ap.add_argument("--max-grid", type=int, default=0)
 ap.add_argument("--subtiles", type=int, default=0)
+ap.add_argument("--threads", type=int, default=0, help="threads per workgroup of the tile kernels (KMERS_PARAM_BLOCK_THREADS)")
 ap.add_argument("--split", action="store_true", help="two write windows per array (KMERS_PARAM_SPLIT_ORDER)")
 ap.add_argument("--once", action="store_true")
 ap.add_argument("--shifts", default="", help="carve mode: comma-separated SA:SB byte shifts of the two output bases inside the block; one timing per pair, same process")
@@ -60,6 +61,8 @@ if args.max_grid:
     ctx.set_param(cap.PARAM_MAX_GRID, args.max_grid)
 if args.subtiles:
     ctx.set_param(cap.PARAM_SUBTILES, args.subtiles)
+if args.threads:
+    ctx.set_param(cap.PARAM_BLOCK_THREADS, args.threads)
 if args.split:
     ctx.set_param(cap.PARAM_SPLIT_ORDER, 1)
 
@@ -189,4 +192,4 @@ ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.reps)]
 med = float(np.median(ts))
 frac = f"frac {alg / med / 1e6 / 8000:.4f}" if alg else ""
 nosplit = " split" if args.split else ""
-print(f"{leg:7s} {args.alloc:12s} tile {args.tile:5d} sub {args.subtiles}{nosplit}: {med:.4f} ms (min {min(ts):.4f} max {max(ts):.4f}) {frac} kept={m_kept} a at {pa:#x}", flush=True)
+print(f"{leg:7s} {args.alloc:12s} tile {args.tile:5d} thr {args.threads:3d} sub {args.subtiles}{nosplit}: {med:.4f} ms (min {min(ts):.4f} max {max(ts):.4f}) {frac} kept={m_kept} a at {pa:#x}", flush=True)
