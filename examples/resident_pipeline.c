@@ -1,0 +1,95 @@
+/* resident_pipeline.c -- a plain-C host that keeps its sequence and its outputs in HBM (no Python, no Julia, no HIP headers):
+ *   CanonicalDNAMers{31}(seq) + fx_hash of every element (src/iterators/CanonicalKmers.jl:199-225, src/kmer.jl:255-261) over a
+ *   synthetic LongDNA{4} sequence, launched asynchronously a few times,
+ *     (a) into two plain device allocations (kmers_dev_alloc without an arena = hipMalloc),
+ *     (b) into two blocks of the context's ARENA (kmers_arena_reserve: the library measures the region map of its block and
+ *         places the arrays of a launch where they are written fastest together, include/kmers_hip.h),
+ *   and prints the time per launch of both and the measured map.  The two runs must produce identical elements.
+ *
+ *   gcc -std=c99 -Iinclude examples/resident_pipeline.c -Lkmers.jl_amd/csrc -lkmers_hip \
+ *       -Wl,-rpath,$PWD/kmers.jl_amd/csrc -o resident_pipeline && ./resident_pipeline [Mbases]
+ */
+#define _POSIX_C_SOURCE 199309L
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "kmers_hip.h"
+
+#define CHECK(call)                                                                       \
+    do {                                                                                  \
+        int rc_ = (call);                                                                 \
+        if (rc_ != KMERS_OK) {                                                            \
+            fprintf(stderr, "%s: status %d: %s\n", #call, rc_, kmers_last_error(ctx));   \
+            return 2;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec / 1e6;
+}
+
+int main(int argc, char **argv) {
+    const uint64_t n_bases = (argc > 1 ? strtoull(argv[1], NULL, 10) : 256) * 1000000ull;
+    const int k = 31, reps = 10;
+    const uint64_t n = kmers_count(n_bases, k, 1), n_words = (n_bases * 4 + 63) / 64;
+    enum { HEAD = 4096 };
+    uint64_t head[2][2][HEAD];
+    kmers_ctx *ctx = NULL;
+    if (kmers_ctx_create(0, NULL, &ctx) != KMERS_OK) {
+        fprintf(stderr, "no usable HIP device (this library has no CPU fallback)\n");
+        return 2;
+    }
+    double ms[2] = {0, 0};
+    for (int with_arena = 0; with_arena < 2; ++with_arena) {
+        if (with_arena) {
+            CHECK(kmers_arena_reserve(ctx, 0));
+            size_t gran = 0, n_regions = 0;
+            unsigned char classes[1024];
+            CHECK(kmers_arena_regions(ctx, NULL, &gran, classes, sizeof classes, &n_regions));
+            printf("arena: %zu granules of %zu GiB, classes ", n_regions, gran >> 30);
+            for (size_t i = 0; i < n_regions && i < sizeof classes; ++i) putchar('A' + classes[i]);
+            putchar('\n');
+        }
+        void *words = NULL, *out_kmers = NULL, *out_hashes = NULL;
+        CHECK(kmers_dev_alloc(ctx, (n_words + 2) * 8, &words));
+        CHECK(kmers_dev_alloc(ctx, n * 8, &out_kmers));   /* the arrays of one launch, one after the other */
+        CHECK(kmers_dev_alloc(ctx, n * 8, &out_hashes));
+        CHECK(kmers_synth_dna(ctx, 42, 0, n_words, 4, 0, (uint64_t *)words));
+        kmers_seq seq = {(const uint64_t *)words, n_bases, 0, 0, 4, 0};
+        kmers_result res;
+        for (int warm = 0; warm < 3; ++warm)
+            CHECK(kmers_canonical(ctx, &seq, k, 2, (uint64_t *)out_kmers, (uint64_t *)out_hashes, 0, KMERS_MEM_DEVICE | KMERS_ASYNC, &res));
+        CHECK(kmers_sync(ctx, &res));
+        const double t0 = now_ms();
+        for (int r = 0; r < reps; ++r)
+            CHECK(kmers_canonical(ctx, &seq, k, 2, (uint64_t *)out_kmers, (uint64_t *)out_hashes, 0, KMERS_MEM_DEVICE | KMERS_ASYNC, &res));
+        CHECK(kmers_sync(ctx, &res));
+        ms[with_arena] = (now_ms() - t0) / reps;
+        const uint64_t m = n < HEAD ? n : HEAD;
+        CHECK(kmers_memcpy_d2h(ctx, head[with_arena][0], out_kmers, m * 8));
+        CHECK(kmers_memcpy_d2h(ctx, head[with_arena][1], out_hashes, m * 8));
+        for (uint64_t i = 0; i < m; ++i)
+            if (head[with_arena][1][i] != head[with_arena][0][i] * 0x517cc1b727220a95ull) {
+                fprintf(stderr, "hash %llu is not fx_hash of its kmer\n", (unsigned long long)i);
+                return 1;
+            }
+        printf("%-24s %8.3f ms per launch = %6.1f Gbases/s = %5.2f TB/s of algorithmic traffic (16.5 B per kmer)\n",
+               with_arena ? "outputs from the arena:" : "plain allocations:", ms[with_arena], n_bases / ms[with_arena] / 1e6,
+               16.5 * n / ms[with_arena] / 1e9);
+        CHECK(kmers_dev_free(ctx, words));
+        CHECK(kmers_dev_free(ctx, out_kmers));
+        CHECK(kmers_dev_free(ctx, out_hashes));
+    }
+    const uint64_t m = n < HEAD ? n : HEAD;
+    if (memcmp(head[0], head[1], sizeof head[0]) != 0 && m == HEAD) {
+        fprintf(stderr, "the two runs differ\n");
+        return 1;
+    }
+    printf("both runs: %llu elements, the first %llu identical: equal\n", (unsigned long long)n, (unsigned long long)m);
+    kmers_ctx_destroy(ctx);
+    return 0;
+}

@@ -86,7 +86,7 @@ def test_header_is_plain_c_and_example_links(km, tmp_path):
     import subprocess
     import torch
     csrc = os.path.join(ROOT, "kmers.jl_amd", "csrc")
-    for name in ("canonical_hashes", "batch_reads", "sharded_canonical"):
+    for name in ("canonical_hashes", "batch_reads", "sharded_canonical", "resident_pipeline"):
         exe = tmp_path / name
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "examples", name + ".c"), "-L", csrc, "-lkmers_hip",

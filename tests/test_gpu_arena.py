@@ -121,3 +121,20 @@ def test_arena_measures_its_region_map_and_spreads_the_outputs_of_a_launch(km):
     p0, p1 = ctx.alloc(1 << 30), ctx.alloc(1 << 30)
     assert p0 == base2 and p1 == p0 + (1 << 30)
     ctx.close()
+
+
+def test_plain_c_resident_pipeline(km, orc, tmp_path):
+    """examples/resident_pipeline.c: a plain-C host with everything resident in HBM, its outputs first from plain device
+    allocations, then from the context's arena; identical elements either way, checked here against the oracle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "kmers.jl_amd", "csrc")
+    exe = tmp_path / "resident_pipeline"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "resident_pipeline.c"),
+                    "-L", csrc, "-lkmers_hip", f"-Wl,-rpath,{csrc}", "-o", str(exe)], check=True)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    out = subprocess.run([str(exe), "64"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert "plain allocations:" in out.stdout and "outputs from the arena:" in out.stdout and ": equal" in out.stdout, out.stdout
+    assert "arena:" in out.stdout and "classes A" in out.stdout
