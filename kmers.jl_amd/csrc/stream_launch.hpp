@@ -88,11 +88,12 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     const bool fwd = MODE == MODE_FW && dst_bits == 2 && !a.out_b && !a.tuples;  // no reverse complements wanted
 #endif
     // Launch shape of the two-output, one-word-element launches (canonical kmers + hashes -- the headline --, forward + reverse
-    // complements, forward kmers + start indices), measured in round 3 (profiles/r03_tuning.md, 1 Gbase, A/B on one box):
-    //   * 24 KiB of output per workgroup (1536 kmers) instead of 16: 0.85-0.87 against 0.81-0.82 of 8 TB/s wherever the arrays lie;
-    //   * workgroups of 128 threads when the two arrays lie in well-separated region classes of HBM, which the launcher knows
-    //     for blocks of the context's arena (kmers_arena_spread): 0.878-0.894 against 0.866-0.872 with 256; arrays in one class
-    //     (or of unknown placement) are faster with 256: 0.85-0.87 against 0.82-0.83.
+    // complements, forward kmers + start indices), measured in round 3 (profiles/r03_tuning.md, 1 Gbase, fresh processes):
+    //   * the two arrays in well-separated region classes of HBM -- which the launcher knows for blocks of the context's arena
+    //     (kmers_arena_spread) --: 24 KiB of output per workgroup (1536 kmers) and workgroups of 128 threads: 0.876-0.895 of
+    //     8 TB/s against 0.819-0.840 with round 2's 16 KiB x 256 and 0.866-0.872 with 24 KiB x 256;
+    //   * anything else (two plain allocations, one region class): 16 KiB x 256 threads stays: 0.788-0.801 in six processes, where
+    //     24 KiB is bimodal (0.727-0.728 in three of them, 0.79-0.81 in the others) and 128 threads lose 3-5 %.
     // Every other shape keeps 16 KiB and 256 threads (C3 0.80-0.82 / 0.72-0.77 with 128, C4 0.87 at 512 x 256 in both
     // placements, C5 0.75-0.76 / 0.72-0.76).
     const bool two_word_streams = n_words == 1 && stride1 && !a.tuples && a.out_a && (a.out_b || a.out_starts) &&
@@ -109,7 +110,7 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     uint32_t max_tile_symbols = (uint32_t)MAX_TILE_BITS / (uint32_t)dst_bits;
     if (MODE == MODE_MINIMIZER) max_tile_symbols -= std::min<uint32_t>(max_tile_symbols / 2, a.window_kmers);  // room for the longer overlap
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
-    if (ctx->tile_kmers <= 0 && two_word_streams) tile = tile * 3 / 2 / pass * pass;  // 24 KiB per workgroup (see above)
+    if (ctx->tile_kmers <= 0 && spread) tile = tile * 3 / 2 / pass * pass;  // 24 KiB per workgroup (see above)
     // (round 2 doubled the tile of strided launches -- 32 KiB of output per workgroup; with two lattice kmers per lane the 16 KiB
     // tile is as fast or faster on every box measured in round 3: 0.73-0.76 against 0.70-0.74, profiles/r03_tuning.md)
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);

@@ -346,6 +346,8 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         const uint32_t mt = g.mt, kbit0 = g.kbit0;
         const uint64_t m0 = g.m0;
         if constexpr (EMIT) {
+            // (one wavefront looks back and the others wait at the barrier behind it: every wavefront looking back for itself --
+            // no barrier, four times the descriptor polls -- measured 7-9 % slower, profiles/r03_tuning.md section 4)
             if (wave == 0) {
                 // Sum the descriptors of the preceding tiles, nearest first, until one holds an inclusive PREFIX.  Every step
                 // reads LOOKBACK x 64 descriptors with all loads in flight together; a tile that has not published yet is
