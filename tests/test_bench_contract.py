@@ -44,3 +44,41 @@ def test_bench_json_line_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == d["unit"]
     assert d["verified"] is True and d["value"] > 0
+
+
+def test_bench_never_nests_a_profiler(monkeypatch):
+    """a bench.py that itself runs under rocprofv3 (its tool library preloaded through LD_PRELOAD / ROCP_*)
+    must not start the nested `rocprofv3 --pmc` child passes -- on the GPU pool that is a GPU-initialised process replacing
+    itself.  The live traffic / VALU measurements then say why they did not run."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in list(os.environ):
+        if k.startswith(("ROCP", "ROCPROF")) or k == "LD_PRELOAD":
+            monkeypatch.delenv(k, raising=False)
+    assert bench.profiler_in_environment() is False
+    args = bench.parse_args(["--steps", "1"])
+    assert args.alloc == "arena" and args.total_bases == 0 and args.strong_bases == -1 and args.gpus == 1
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.profiler_in_environment() is True
+    traffic, why = bench.measure_traffic(args)
+    assert traffic is None and "profiler" in why
+    assert bench.measure_legs(args) == {}
+    monkeypatch.delenv("ROCP_TOOL_LIBRARIES")
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so.0")
+    assert bench.profiler_in_environment() is True
+
+
+def test_bench_strong_scaling_plan_tiles_the_sequence():
+    """`bench.py --total-bases T --gpus N`: the ranks' shards (plan_shards) tile ONE sequence -- every kmer exactly once, in rank
+    order, (K-1)-base overlaps between neighbours, word-aligned starts -- for the north star's own numbers."""
+    sys.path.insert(0, ROOT)
+    import kmers_jl_amd  # noqa: F401
+    from kmers_jl_amd.shard import plan_shards
+    T, K = 10_000_000_000, 31
+    for n in (1, 2, 4, 8):
+        plan = plan_shards(T, K, n, 4)
+        assert sum(s.n_kmers for s in plan) == T - K + 1 and plan[0].first_kmer == 0
+        for a, b in zip(plan, plan[1:]):
+            assert b.first_kmer == a.first_kmer + a.n_kmers and b.first_base % 16 == 0 and a.halo_words == 2 and b.send_words == 2
+            assert a.n_bases == a.n_kmers + K - 1
+        assert plan[-1].halo_words == 0 and max(s.n_kmers for s in plan) - min(s.n_kmers for s in plan) <= 16 * n

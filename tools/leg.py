@@ -44,6 +44,7 @@ ap.add_argument("--subtiles", type=int, default=0)
 ap.add_argument("--threads", type=int, default=0, help="threads per workgroup of the tile kernels (KMERS_PARAM_BLOCK_THREADS)")
 ap.add_argument("--split", action="store_true", help="two write windows per array (KMERS_PARAM_SPLIT_ORDER)")
 ap.add_argument("--once", action="store_true")
+ap.add_argument("--straddle", action="store_true", help="arenacarve mode: the first array centred on the first class boundary of the arena's map")
 ap.add_argument("--shifts", default="", help="carve mode: comma-separated SA:SB byte shifts of the two output bases inside the block; one timing per pair, same process")
 ap.add_argument("--bases", type=int, default=1_000_000_000)
 args = ap.parse_args()
@@ -98,6 +99,11 @@ with torch.cuda.stream(stream):
         abase, gran, classes = ctx.arena_regions()
         print("arena map", "".join(chr(65 + c) for c in classes), flush=True)
         pa = pb = abase
+        if args.straddle:
+            g = next(i for i in range(1, len(classes)) if classes[i] != classes[i - 1])
+            pa = abase + ((g * gran - 4 * words_a) >> 21 << 21)
+            pb = abase + ((g + 6) * gran)   # (a second array, if the leg has one: 24 GiB further on)
+            print(f"straddle: boundary at {g * gran >> 30} GiB, a at {(pa - abase) / 2**30:.2f} GiB", flush=True)
         mode = "carve"
     elif mode == "arena":
         ctx.check(ctx.lib.kmers_arena_reserve(ctx.handle, size << 30), "kmers_arena_reserve")
