@@ -424,9 +424,9 @@ def north_star_one_gpu(ctx, cap, stream, dev, mem, reps=7, L=NORTH_STAR_BASES):
         return {name: {"skipped": f"needs {need / 1e9:.0f} GB of HBM, {room / 1e9:.0f} GB available"}}
     seed10 = GOLDEN ^ 10
     nw = (L * 4 + 63) // 64
+    a, h = mem.empty(n), mem.empty(n)  # (the 80 GB arrays before the 5 GB one: each must find one free range of the arena)
     buf = mem.empty(nw + 2)
     ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed10, 0, nw, 4, 0, buf.data_ptr()), "kmers_synth_dna")
-    a, h = mem.empty(n), mem.empty(n)
     seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
     ASYNC = cap.MEM_DEVICE | cap.ASYNC
     ms = busy_timed(ctx, stream, lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), h.data_ptr(), 0, ASYNC, C.byref(res)), reps)
@@ -631,12 +631,14 @@ class Leg:
         sh = self.sh = self.plan[env.rank]
         self.N = cap.load().kmers_words_per_kmer(args.k, 2)
         with torch.cuda.stream(env.stream):
+            # the two output arrays first and one right after the other: the arena places consecutive blocks where they are
+            # written fastest together (and the 80 GB arrays of the 10 Gbase legs find their room before the small block does)
+            self.out_k = mem.empty(sh.n_kmers * self.N)
+            self.out_h = None if args.no_hash else mem.empty(sh.n_kmers)
             self.buf = mem.empty(sh.n_own_words + sh.halo_words + 2)
             self.buf.zero_()
             ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, sh.first_word, sh.n_own_words, args.src_bits, 0, self.buf.data_ptr()),
                       "kmers_synth_dna")
-            self.out_k = mem.empty(sh.n_kmers * self.N)
-            self.out_h = None if args.no_hash else mem.empty(sh.n_kmers)
             self.halo = None
             if env.grouped and env.transport != "native":
                 self.halo = HaloExchanger(self.buf, sh, self.plan, transport=env.transport)  # its workspace is filled on this stream too

@@ -27,6 +27,7 @@ struct kmers_arena {
     float best_pair_rate = 0.f;            // the largest of them
     int n_classes = 0;
     int last_run = -1, last2_run = -1;     // runs of the two most recent allocations
+    size_t last_off = 0, last_len = 0;     // the most recent allocation itself (placement of blocks longer than a run)
 };
 
 // index of the arena's run that holds offset `off` (the map must exist)
@@ -39,14 +40,20 @@ inline size_t kmers_arena_run_of(const kmers_arena &a, size_t off) {
     }
     return lo;
 }
-// true iff p and q both lie in the arena, in runs whose MEASURED two-stream rate is within 5 % of the best pair of the block:
-// the launchers pick the launch shape that is fastest for well-placed outputs only then (stream_launch.hpp)
-inline bool kmers_arena_spread(const kmers_arena &a, const void *p, const void *q) {
-    if (a.run_start.empty() || !p || !q) return false;
+// true iff two arrays of `bytes` bytes at p and q both lie in the arena and the MEASURED two-stream rate of the runs they pass
+// through side by side (sampled at eight points: an array may be longer than a run) averages within 5 % of the best pair of
+// the block: the launchers pick the launch shape that is fastest for well-placed outputs only then (stream_launch.hpp)
+inline bool kmers_arena_spread(const kmers_arena &a, const void *p, const void *q, size_t bytes) {
+    if (a.run_start.empty() || !p || !q || bytes == 0) return false;
     const char *cp = static_cast<const char *>(p), *cq = static_cast<const char *>(q);
-    if (cp < a.base || cp >= a.base + a.bytes || cq < a.base || cq >= a.base + a.bytes) return false;
-    const size_t k = a.run_start.size(), i = kmers_arena_run_of(a, (size_t)(cp - a.base)), j = kmers_arena_run_of(a, (size_t)(cq - a.base));
-    return a.pair_rate[i * k + j] >= 0.95f * a.best_pair_rate;
+    if (cp < a.base || cp + bytes > a.base + a.bytes || cq < a.base || cq + bytes > a.base + a.bytes) return false;
+    const size_t k = a.run_start.size();
+    float sum = 0.f;
+    for (int i = 0; i < 8; ++i) {
+        const size_t t = (size_t)((2 * i + 1) * (double)bytes / 16.0);
+        sum += a.pair_rate[kmers_arena_run_of(a, (size_t)(cp - a.base) + t) * k + kmers_arena_run_of(a, (size_t)(cq - a.base) + t)];
+    }
+    return sum / 8.f >= 0.95f * a.best_pair_rate;
 }
 
 struct kmers_ctx {

@@ -203,6 +203,8 @@ void arena_commit(kmers_arena &a, std::map<size_t, size_t>::iterator range, size
     a.used[off] = need;
     a.last2_run = a.last_run;
     a.last_run = a.run_start.empty() ? -1 : (int)run_of(a, off);
+    a.last_off = off;
+    a.last_len = need;
 }
 
 // Placement.  With a region map every stretch of a free range inside ONE run that fits the request is a candidate; the run
@@ -238,6 +240,38 @@ bool arena_take(kmers_arena &a, size_t need, size_t *off_out) {
                     }
                 }
                 pos = stretch_end;
+            }
+        }
+        if (best_range != a.free_ranges.end()) {
+            arena_commit(a, best_range, best_off, need);
+            *off_out = best_off;
+            return true;
+        }
+    }
+    if (!a.run_start.empty() && a.last_len) {
+        // a block longer than any run (the 80 GB arrays of a 10 Gbase launch) passes through several runs: at the bottom or at
+        // the top of a free range that fits (nothing is fragmented), wherever its runs -- sampled at eight points -- write
+        // fastest beside the previous block's
+        const size_t k = a.run_start.size();
+        auto best_range = a.free_ranges.end();
+        size_t best_off = 0;
+        float best_score = -1.f;
+        for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it) {
+            if (it->second < need) continue;
+            const size_t ends[2] = {it->first, (it->first + it->second - need) / GRANULE * GRANULE};
+            for (int e = 0; e < 2; ++e) {
+                const size_t off = ends[e];
+                if (off < it->first) continue;
+                float sum = 0.f;
+                for (int i = 0; i < 8; ++i) {
+                    const size_t t = (size_t)((2 * i + 1) * (double)need / 16.0), u = (size_t)((2 * i + 1) * (double)a.last_len / 16.0);
+                    sum += a.pair_rate[run_of(a, a.last_off + u) * k + run_of(a, off + t)];
+                }
+                if (sum > best_score + 400.f) {  // (a later position must be better by 50 GB/s on average to be preferred)
+                    best_score = sum;
+                    best_range = it;
+                    best_off = off;
+                }
             }
         }
         if (best_range != a.free_ranges.end()) {

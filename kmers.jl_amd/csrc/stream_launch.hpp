@@ -98,7 +98,8 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     // placements, C5 0.75-0.76 / 0.72-0.76).
     const bool two_word_streams = n_words == 1 && stride1 && !a.tuples && a.out_a && (a.out_b || a.out_starts) &&
                                   (MODE == MODE_FW || MODE == MODE_CANON);
-    const bool spread = two_word_streams && kmers_arena_spread(ctx->arena, a.out_a, a.out_b ? (const void *)a.out_b : (const void *)a.out_starts);
+    const bool spread = two_word_streams && kmers_arena_spread(ctx->arena, a.out_a, a.out_b ? (const void *)a.out_b : (const void *)a.out_starts,
+                                                                  (size_t)a.n_kmers * 8u);
     uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads : (spread ? 128u : (uint32_t)BLOCK);
     if (threads != 64u && threads != 128u) threads = (uint32_t)BLOCK;
     const uint32_t pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * threads;  // kmers per workgroup pass
