@@ -153,6 +153,11 @@ int kmers_arena_info(kmers_ctx *ctx, size_t *reserved, size_t *in_use, size_t *l
  * more finely than a granule).  *region_bytes = 0: no map (block too small, probing switched off, or one class only).  Any
  * output may be NULL. */
 int kmers_arena_regions(kmers_ctx *ctx, void **base, size_t *region_bytes, unsigned char *classes, size_t capacity, size_t *n_regions);
+/* For hosts that allocate their outputs themselves (no arena): the write rate, in GB/s, of two store streams side by side into
+ * two device buffers the host is about to use as the output arrays of a launch -- the measurement the arena makes of its own
+ * block.  DESTRUCTIVE: the first min(bytes, 2 GiB) of both buffers are overwritten.  About 7000 = the buffers lie in different
+ * region classes, about 6000 = in one; a host with several candidate buffers can pick the pair that writes fastest. */
+int kmers_placement_probe(kmers_ctx *ctx, void *a_dev, void *b_dev, size_t bytes, double *gbps);
 
 /* ---- geometry (src/kmer.jl:117-137; iterator length()) ----------------------- */
 int kmers_words_per_kmer(int k, int dst_bits);                      /* n_coding_elements, kmer.jl:123-125 */

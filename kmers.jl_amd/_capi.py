@@ -64,6 +64,7 @@ SYMBOLS = {
     "kmers_arena_release": (C.c_int, [_P]),
     "kmers_arena_info": (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "kmers_arena_regions": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "kmers_placement_probe": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_double)]),
     "kmers_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "kmers_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "kmers_words_per_kmer": (C.c_int, [C.c_int, C.c_int]),

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 
@@ -366,6 +367,35 @@ int kmers_arena_info(kmers_ctx *ctx, size_t *reserved, size_t *in_use, size_t *l
     if (reserved) *reserved = ctx->arena.bytes;
     if (in_use) *in_use = used;
     if (largest_free) *largest_free = largest;
+    return KMERS_OK;
+}
+
+int kmers_placement_probe(kmers_ctx *ctx, void *a_dev, void *b_dev, size_t bytes, double *gbps) {
+    if (!ctx) return KMERS_E_BADARG;
+    if (!a_dev || !b_dev || !gbps || bytes < 8192 || ((uintptr_t)a_dev & 15u) || ((uintptr_t)b_dev & 15u))
+        return fail(ctx, KMERS_E_BADARG, "kmers_placement_probe: two 16-byte aligned device buffers of at least 8 KiB");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t groups = std::min<size_t>(bytes, (size_t)2 << 30) / 8192;  // at most 2 GiB of each are written
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    float best = 1e30f;
+    int rc = KMERS_OK;
+    for (int rep = 0; rep < 4 && rc == KMERS_OK; ++rep) {  // (the first one warms up)
+        hipError_t e = hipEventRecord(e0, ctx->stream);
+        hipLaunchKernelGGL(arena_probe_kernel, dim3((unsigned)groups), dim3(256), 0, ctx->stream, static_cast<ulonglong2 *>(a_dev),
+                           static_cast<ulonglong2 *>(b_dev));
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = fail(ctx, KMERS_E_HIP, "kmers_placement_probe", e);
+        else if (rep && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != KMERS_OK) return rc;
+    *gbps = 2.0 * (double)groups * 8192.0 / 1e6 / (double)best;
     return KMERS_OK;
 }
 

@@ -163,6 +163,12 @@ class Context:
         self.check(self.lib.kmers_arena_regions(self.handle, C.byref(base), C.byref(g), buf, 1024, C.byref(n)), "kmers_arena_regions")
         return base.value or 0, g.value, list(buf[:min(n.value, 1024)]) if g.value else []
 
+    def placement_probe(self, ptr_a, ptr_b, nbytes):
+        """GB/s of two store streams side by side into two (still empty) device buffers; DESTRUCTIVE (kmers_placement_probe)."""
+        g = C.c_double()
+        self.check(self.lib.kmers_placement_probe(self.handle, C.c_void_p(ptr_a), C.c_void_p(ptr_b), nbytes, C.byref(g)), "kmers_placement_probe")
+        return g.value
+
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)
         self.check(self.lib.kmers_memcpy_h2d(self.handle, C.c_void_p(dptr), arr.ctypes.data_as(C.c_void_p),

@@ -109,6 +109,12 @@ def test_arena_measures_its_region_map_and_spreads_the_outputs_of_a_launch(km):
     assert all(p % cap.ARENA_GRANULE == 0 for p in (small, a, b))
     ca, cb = covered(a, 8 << 30), covered(b, 8 << 30)
     assert ca != cb or len(ca) >= 2, (ca, cb, classes)   # the outputs of one launch never share one single class
+    # kmers_placement_probe (the same measurement, for buffers of the caller's): the pair the arena chose writes at the
+    # two-class rate, the two halves of ONE of its blocks at the one-class rate
+    apart, together = ctx.placement_probe(a, b, 1 << 30), ctx.placement_probe(a, a + (4 << 30), 1 << 30)
+    assert 4000 < together < apart < 9000 and apart > 1.05 * together, (apart, together)
+    res_bad = ctx.lib.kmers_placement_probe(ctx.handle, C.c_void_p(a + 8), C.c_void_p(b), 1 << 30, C.byref(C.c_double()))
+    assert res_bad == cap.E_BADARG
     for p in (small, a, b):
         ctx.free(p)
     assert ctx.arena_info() == (reserved, 0, reserved)
