@@ -56,7 +56,7 @@ extern "C" {
 /* flags */
 #define KMERS_MEM_HOST 0x0   /* sequence/output pointers are host memory (staged through HBM) */
 #define KMERS_MEM_DEVICE 0x1 /* sequence/output pointers are device (HBM) memory              */
-#define KMERS_ASYNC 0x2      /* device memory only: enqueue and return; collect status with kmers_sync */
+#define KMERS_ASYNC 0x2      /* device memory only: enqueue and return; collect status (kmers_unambiguous: and the count) with kmers_sync */
 #define KMERS_OUT_TUPLES 0x4 /* array-of-structs output = the eltype of the tuple-yielding iterators, written to the
                               * FIRST output pointer (second must be NULL): kmers_fw -> Tuple{Kmer,Kmer} (fw, rc; eltype of
                               * FwRvIterator, CanonicalKmers.jl:44-45), kmers_canonical -> Tuple{Kmer,UInt64} (kmer, fx_hash),
@@ -198,7 +198,11 @@ int kmers_spaced(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int ds
  * 4-bit sequences (in a 4-bit sequence the gap is skipped like an ambiguity code,
  * :134-148), text (ASCII_SKIPPING_LUT: ambiguity letters are skipped, any other byte
  * is E_ENCODE, :109-132) and collections of symbols (KMERS_ALPHABET_SYMBOLS, the
- * generic method :88-106: ambiguous symbols are skipped, the gap is E_ENCODE). */
+ * generic method :88-106: ambiguous symbols are skipped, the gap is E_ENCODE).
+ * KMERS_MEM_DEVICE | KMERS_ASYNC enqueues the one pass and returns: the count is not known yet (res->n_out = 0, except for a
+ * 2-bit source, where nothing can be dropped); the next kmers_sync reports it in its res->n_out, with KMERS_E_CAPACITY if it
+ * exceeds `capacity` (nothing was stored at or beyond it).  If several asynchronous calls ran since the last sync, the sync
+ * reports the count of the LAST one. */
 int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride,
                       uint64_t *out_kmers, int64_t *out_starts, uint64_t capacity, int flags,
                       kmers_result *res);

@@ -62,7 +62,8 @@ struct kmers_ctx {
     bool own_stream = false;
     uint64_t *d_scratch = nullptr;        // 64 words of device scratch; word 0: reduction result, word 1: the error slot
     unsigned long long *d_err = nullptr;  // = d_scratch + 1: first offending symbol (0-based), ~0 = none
-    uint64_t *h_result = nullptr;         // pinned host mirror of scratch words 0..1: one small D2H copy per call
+    uint64_t *h_result = nullptr;         // pinned, 16 words: 0..1 mirror of scratch words 0..1 (one small D2H copy per call), 2..7 per-call
+                                          // read-backs of the synchronous entry points, 8..10 the asynchronous kmers_unambiguous
     char *h_bounce = nullptr;             // pinned bounce buffer for short host-pointer calls (FASTA-record sized):
                                           // [0, BOUNCE_IN) source words, [BOUNCE_IN, BOUNCE_IN + BOUNCE_OUT) outputs
     uint64_t *d_recent = nullptr;         // MinHash: table of recently appended candidate hashes (RECENT_SLOTS entries)
@@ -81,9 +82,13 @@ struct kmers_ctx {
     int64_t batch_passes = 0;       // KMERS_PARAM_BATCH_PASSES (tests, tuning); 0 = default
     int64_t sketch_batch_lds = 0;   // KMERS_PARAM_SKETCH_BATCH_LDS (tuning); 0 = default
     kmers_arena arena;              // memory_api.hip
+    bool unamb_pending = false;     // an asynchronous kmers_unambiguous has run since the last kmers_sync: its count is in h_result[8..10]
+    uint64_t unamb_capacity = 0;
 };
 
 namespace kmers {
+
+constexpr uint64_t DESCRIPTOR_COUNT_MASK = (1ull << 62) - 1ull;  // a tile descriptor of unambiguous_kernel.hpp: status in the top two bits
 
 inline int fail(kmers_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
     if (ctx) {

@@ -93,7 +93,7 @@ int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return KMERS_E_HIP; }
         ctx->own_stream = true;
     }
-    if (hipMalloc(&ctx->d_scratch, 64 * 8) != hipSuccess || hipHostMalloc(&ctx->h_result, 64, hipHostMallocDefault) != hipSuccess ||
+    if (hipMalloc(&ctx->d_scratch, 64 * 8) != hipSuccess || hipHostMalloc(&ctx->h_result, 128, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(&ctx->h_bounce, BOUNCE_IN + BOUNCE_OUT, hipHostMallocDefault) != hipSuccess ||
         (ctx->d_err = reinterpret_cast<unsigned long long *>(ctx->d_scratch + 1)) == nullptr ||
         hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream) != hipSuccess ||
@@ -143,7 +143,21 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res) {
     if (!ctx) return KMERS_E_BADARG;
     clear(res);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return collect(ctx, res, 0);
+    const int rc = collect(ctx, res, 0);
+    if (ctx->unamb_pending) {
+        // the asynchronous kmers_unambiguous of this context: its element count travelled to pinned memory behind the kernel
+        ctx->unamb_pending = false;
+        if (rc != KMERS_OK) return rc;  // (an EncodeError of a byte source wins: the outputs are unspecified then)
+        const uint64_t *h = ctx->h_result + 8;  // [last tile's descriptor, ticket counter, abort flag]
+        if (h[2]) return fail(ctx, KMERS_E_HIP, "UnambiguousKmers: a tile never published its count (look-back gave up)");
+        const uint64_t total = h[0] & DESCRIPTOR_COUNT_MASK;
+        if (res) res->n_out = total;
+        if (total > ctx->unamb_capacity) {
+            if (res) res->status = KMERS_E_CAPACITY;
+            return fail(ctx, KMERS_E_CAPACITY, "output capacity too small");
+        }
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -9,6 +9,8 @@ using namespace kmers;
 
 namespace {
 
+static_assert(DESC_VALUE == DESCRIPTOR_COUNT_MASK, "kmers_sync decodes a tile descriptor with context.hpp's mask");
+
 // UnambiguousKmers over a sequence in which every window survives (a 2-bit source, or a count pass that kept
 // everything): its elements are FwKmers plus the start indices 1, 2, ..., so the stream kernel writes them at
 // its two-array rate -- no compaction, no offsets.
@@ -160,6 +162,15 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, std::min<uint64_t>(cap_grid, (uint64_t)ctx->n_cus * UNAMB_EMIT_WGS)));
         launch_unambiguous<UMODE_EMIT>(ctx, seq->src_bits, nw, grid, a);
         HIP_TRY(ctx, hipGetLastError());
+        if (flags & KMERS_ASYNC) {
+            // enqueue only: the count (the last tile's inclusive prefix) follows the kernel into pinned memory and kmers_sync
+            // reports it -- together with KMERS_E_CAPACITY if it exceeds `capacity` (nothing was stored beyond it)
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result + 8, a.desc + (a.n_tiles - 1), 24, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->unamb_pending = true;
+            ctx->unamb_capacity = capacity;
+            if (res) res->n_out = 0;
+            return KMERS_OK;
+        }
         // the last tile's inclusive prefix is the element count
         uint64_t *h = ctx->h_result + 2;  // pinned: [last descriptor, ticket counter, abort flag]
         HIP_TRY(ctx, hipMemcpyAsync(h, a.desc + (a.n_tiles - 1), 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -180,6 +191,7 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         if (out_kmers) HIP_TRY(ctx, hipMemcpyAsync(out_kmers, d_k, kb, hipMemcpyDeviceToHost, ctx->stream));
         if (out_starts) HIP_TRY(ctx, hipMemcpyAsync(out_starts, d_s, sb, hipMemcpyDeviceToHost, ctx->stream));
     }
+    if (flags & KMERS_ASYNC) return KMERS_OK;  // (a 2-bit source: the count is known, res->n_out holds it; the launch is enqueued)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return KMERS_OK;
 }
@@ -230,11 +242,12 @@ extern "C" {
 int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uint64_t *out_kmers,
                       int64_t *out_starts, uint64_t capacity, int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, seq, k, stride, 2, flags & ~KMERS_ASYNC, true)) {
+    if (int rc = check_common(ctx, seq, k, stride, 2, flags, true)) {
         if (res) res->status = rc;
         return rc;
     }
-    if (flags & KMERS_ASYNC) return fail(ctx, KMERS_E_BADARG, "kmers_unambiguous is synchronous (data-dependent count)");
+    if ((flags & KMERS_ASYNC) && !(flags & KMERS_MEM_DEVICE)) return fail(ctx, KMERS_E_BADARG, "KMERS_ASYNC requires KMERS_MEM_DEVICE");
+    if ((flags & KMERS_ASYNC) && !out_kmers && !out_starts) return fail(ctx, KMERS_E_BADARG, "the size query of kmers_unambiguous is synchronous");
     if (k > UNAMB_MAX_K) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_unambiguous: K above 30720");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return run_unambiguous(ctx, seq, k, stride, out_kmers, out_starts, capacity, flags, res);

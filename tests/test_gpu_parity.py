@@ -665,6 +665,80 @@ def test_unambiguous_single_pass_device_path(km, ctx, orc):
         ctx.free(d_src)
 
 
+def test_unambiguous_asynchronous_form(km, ctx, orc):
+    """KMERS_MEM_DEVICE | KMERS_ASYNC: the one pass is only enqueued; kmers_sync reports the count (and KMERS_E_CAPACITY with the
+    count needed when the outputs were too small -- nothing stored beyond them) and an EncodeError of a byte source; of several
+    asynchronous calls before one sync the last one's count is reported.  A 2-bit source knows its count at once."""
+    cap = km._capi
+    rng = np.random.default_rng(77)
+    L, K = 200_003, 31
+    text = naive.random_text(rng, L, p_amb=0.03)
+    words = naive.longseq_words(text, 4)
+    ek, es, _ = orc.unambiguous(words, L, 4, K)
+    n = len(ek)
+    d_src = ctx.alloc(words.nbytes + 16)
+    ctx.h2d(d_src, words)
+    seq = cap.Seq(d_src, L, 0, 0, 4, 0)
+    guard = np.uint64(0xDEADBEEFDEADBEEF)
+    ASYNC = cap.MEM_DEVICE | cap.ASYNC
+    for capacity in (n + 5, n, n - 1):
+        hk = np.full(n + 64, guard, np.uint64)
+        hs = np.full(n + 64, guard.view(np.int64), np.int64)
+        dk, ds = ctx.alloc(hk.nbytes), ctx.alloc(hs.nbytes)
+        ctx.h2d(dk, hk)
+        ctx.h2d(ds, hs)
+        res = cap.Result()
+        assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, dk, ds, capacity, ASYNC, C.byref(res)) == 0 and res.n_out == 0
+        # a second one behind it (same outputs: the sync reports the last one's count), and other asynchronous work
+        assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, dk, ds, capacity, ASYNC, C.byref(res)) == 0
+        d_tmp = ctx.alloc(8 * L)
+        assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), 5, 4, d_tmp, None, 0, ASYNC, C.byref(res)) == 0
+        rc, sres = ctx.sync()
+        ctx.d2h(hk, dk)
+        ctx.d2h(hs, ds)
+        assert sres.n_out == n, (capacity, sres.n_out, n)
+        assert np.all(hs[capacity:] == guard.view(np.int64))
+        if capacity >= n:
+            assert rc == 0 and np.array_equal(hk[:n], ek[:, 0]) and np.array_equal(hs[:n], es)
+        else:
+            assert rc == cap.E_CAPACITY and sres.status == cap.E_CAPACITY
+        rc, sres = ctx.sync()          # nothing pending any more
+        assert rc == 0 and sres.n_out == 0
+        ctx.free(dk)
+        ctx.free(ds)
+        ctx.free(d_tmp)
+    # host pointers and the size query have no asynchronous form
+    res = cap.Result()
+    out = np.zeros(n + 1, np.uint64)
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, vp(out), None, n, cap.ASYNC, C.byref(res)) == cap.E_BADARG
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, 1, None, None, 0, ASYNC, C.byref(res)) == cap.E_BADARG
+    # text with a byte that is no nucleotide: the sync reports the EncodeError
+    raw = bytearray(naive.random_text(rng, 5000).encode())
+    raw[3210] = ord("!")
+    wb = naive.ascii_words(bytes(raw))
+    d_txt = ctx.alloc(wb.nbytes + 16)
+    ctx.h2d(d_txt, wb)
+    seqt = cap.Seq(d_txt, len(raw), 0, 0, 8, 0)
+    dk, ds = ctx.alloc(10_000 * 8), ctx.alloc(10_000 * 8)
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seqt), 21, 1, dk, ds, 5000, ASYNC, C.byref(res)) == 0
+    rc, sres = ctx.sync()
+    assert rc == cap.E_ENCODE and sres.err_pos == 3211 and sres.err_enc == ord("!")
+    # a 2-bit source: nothing can be dropped, the count is known at the call
+    w2 = naive.longseq_words(naive.random_text(rng, 10_000), 2)
+    d2 = ctx.alloc(w2.nbytes + 16)
+    ctx.h2d(d2, w2)
+    seq2 = cap.Seq(d2, 10_000, 0, 0, 2, 0)
+    assert ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq2), 21, 1, dk, ds, 10_000, ASYNC, C.byref(res)) == 0 and res.n_out == 9980
+    rc, sres = ctx.sync()
+    assert rc == 0
+    e2, s2, _ = orc.unambiguous(w2, 10_000, 2, 21)
+    hk = np.zeros(9980, np.uint64)
+    ctx.d2h(hk, dk)
+    assert np.array_equal(hk, e2[:, 0])
+    for p in (d_src, d_txt, d2, dk, ds):
+        ctx.free(p)
+
+
 def test_unambiguous_kmers_wider_than_four_words(km, ctx, orc):
     """UnambiguousKmers{A,K} with K > 128 (src/kmer.jl:97-111 puts no bound on N): the single-pass kernel's run-time-width
     instantiation.  Against the oracle up to its 8 words, against the naive slicer beyond; host and device paths, a stride

@@ -134,8 +134,8 @@ calls = {
     "c4": lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, pa, pb, ASYNC, C.byref(res)),
     "c4t": lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, pa, None, ASYNC | cap.OUT_TUPLES, C.byref(res)),
     "c5": lambda: ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, 2, pa, ASYNC, C.byref(res)),
-    "u31": lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, J, pa, pb, m_kept, cap.MEM_DEVICE, C.byref(res)),
-    "u21": lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, J, pa, pb, m_kept, cap.MEM_DEVICE, C.byref(res)),
+    "u31": lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, J, pa, pb, m_kept, ASYNC, C.byref(res)),
+    "u21": lambda: ctx.lib.kmers_unambiguous(ctx.handle, C.byref(seq), K, J, pa, pb, m_kept, ASYNC, C.byref(res)),
     "xor": lambda: ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, 2, 1, C.byref(val), cap.MEM_DEVICE, C.byref(res)),
     "minhash": lambda: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, 2, 0, 1000, sk.ctypes.data_as(C.c_void_p), cap.MEM_DEVICE, C.byref(res)),
     "comp8": lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), K, pa, cap.MEM_DEVICE, C.byref(res)),
