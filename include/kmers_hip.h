@@ -138,8 +138,9 @@ int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t
  *     the two output arrays of one launch are two such streams, and where two plain allocations happen to lie decides whether
  *     FwDNAMers{63} + reverse complements runs at 0.72 or at 0.89 of 8 TB/s (canonical 31-mers + hashes: 0.80 or 0.855).
  *     kmers_arena_reserve measures the map of its block (about 0.1 s for 200 GB; only blocks of 16 GiB or more;
- *     KMERS_PARAM_ARENA_NO_PROBE = 1 skips it) and kmers_dev_alloc places CONSECUTIVE allocations in DIFFERENT classes: allocate
- *     the arrays of one launch one after the other.  kmers_arena_regions reports the map.  The launchers consult it too: two
+ *     KMERS_PARAM_ARENA_NO_PROBE = 1 skips it) and kmers_dev_alloc places a block where the MEASURED two-stream rate beside the
+ *     blocks that are live is highest (the previous allocation counting double): allocate the arrays of one launch one after
+ *     the other and they end up in different classes.  kmers_arena_regions reports the map.  The launchers consult it too: two
  *     output arrays that they can see are well placed get the launch shape that is fastest for such arrays.
  * bytes = 0 reserves three quarters of the memory that is free at the time of the call.  One arena per context;
  * kmers_arena_release fails with KMERS_E_BADARG while blocks of it are allocated; kmers_ctx_destroy releases it. */

@@ -1,0 +1,190 @@
+// arena_placement.hpp -- the pure host logic of the context's device-memory arena (memory_api.hip): the block's measured region
+// map and where a new block goes.  No HIP in here: tests/c/arena_placement_check.cpp exercises it on the CPU with made-up maps.
+#pragma once
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <vector>
+
+constexpr size_t KMERS_ARENA_GRANULE_BYTES = (size_t)2 << 20;   // == KMERS_ARENA_GRANULE of include/kmers_hip.h
+constexpr size_t KMERS_ARENA_REGION_BYTES = (size_t)4 << 30;    // granule of the region map
+
+// The context's device-memory arena (kmers_arena_reserve, include/kmers_hip.h): ONE hipMalloc, sub-allocated in 2 MiB
+// granules by kmers_dev_alloc.  Offsets are relative to `base`; free ranges are kept coalesced.  `region` is the map of the
+// block that the calibration of memory_api.hip measured: two store streams inside one REGION CLASS of HBM share a write rate of
+// ~6 TB/s on MI355X, streams in different classes reach ~7.1 TB/s, so a new block goes where it writes fastest beside the live ones.
+struct kmers_arena {
+    char *base = nullptr;
+    size_t bytes = 0;
+    std::map<size_t, size_t> free_ranges;  // offset -> length
+    std::map<size_t, size_t> used;         // offset -> length
+    size_t region_bytes = 0;               // granule of the region map (0: not calibrated)
+    std::vector<uint8_t> region;           // class of every granule of the block (kmers_arena_regions)
+    std::vector<size_t> run_start;         // the map as runs: run i = [run_start[i], run_start[i + 1]) is in class run_class[i];
+    std::vector<uint8_t> run_class;        //   boundaries refined to about half a gigabyte
+    std::vector<float> pair_rate;          // measured: pair_rate[i * n_runs + j] = GB/s of two store streams, one in run i, one in run j
+    float best_pair_rate = 0.f;            // the largest of them
+    int n_classes = 0;
+    int last_run = -1, last2_run = -1;     // runs of the two most recent allocations
+    size_t last_off = 0, last_len = 0;     // the most recent allocation itself (placement of blocks longer than a run)
+};
+
+// index of the arena's run that holds offset `off` (the map must exist)
+inline size_t kmers_arena_run_of(const kmers_arena &a, size_t off) {
+    size_t lo = 0, hi = a.run_start.size();
+    while (hi - lo > 1) {
+        const size_t mid = (lo + hi) / 2;
+        if (a.run_start[mid] <= off) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+// true iff two arrays of `bytes` bytes at p and q both lie in the arena and the MEASURED two-stream rate of the runs they pass
+// through side by side (sampled at eight points: an array may be longer than a run) averages within 5 % of the best pair of
+// the block: the launchers pick the launch shape that is fastest for well-placed outputs only then (stream_launch.hpp)
+inline bool kmers_arena_spread(const kmers_arena &a, const void *p, const void *q, size_t bytes) {
+    if (a.run_start.empty() || !p || !q || bytes == 0) return false;
+    const char *cp = static_cast<const char *>(p), *cq = static_cast<const char *>(q);
+    if (cp < a.base || cp + bytes > a.base + a.bytes || cq < a.base || cq + bytes > a.base + a.bytes) return false;
+    const size_t k = a.run_start.size();
+    float sum = 0.f;
+    for (int i = 0; i < 8; ++i) {
+        const size_t t = (size_t)((2 * i + 1) * (double)bytes / 16.0);
+        sum += a.pair_rate[kmers_arena_run_of(a, (size_t)(cp - a.base) + t) * k + kmers_arena_run_of(a, (size_t)(cq - a.base) + t)];
+    }
+    return sum / 8.f >= 0.95f * a.best_pair_rate;
+}
+
+namespace kmers {
+namespace arena {
+
+constexpr size_t GRANULE = KMERS_ARENA_GRANULE_BYTES;
+constexpr size_t REGION = KMERS_ARENA_REGION_BYTES;
+inline size_t round_up(size_t x) { return (x + GRANULE - 1) / GRANULE * GRANULE; }
+
+inline size_t run_of(const kmers_arena &a, size_t off) { return kmers_arena_run_of(a, off); }
+inline int class_at(const kmers_arena &a, size_t off) { return a.run_class.empty() ? 0 : a.run_class[run_of(a, off)]; }
+inline size_t run_end(const kmers_arena &a, size_t i) { return i + 1 < a.run_start.size() ? a.run_start[i + 1] : a.bytes; }
+
+inline void arena_commit(kmers_arena &a, std::map<size_t, size_t>::iterator range, size_t off, size_t need) {
+    const size_t fo = range->first, fl = range->second;
+    a.free_ranges.erase(range);
+    if (off > fo) a.free_ranges[fo] = off - fo;
+    if (fo + fl > off + need) a.free_ranges[off + need] = fo + fl - (off + need);
+    a.used[off] = need;
+    a.last2_run = a.last_run;
+    a.last_run = a.run_start.empty() ? -1 : (int)run_of(a, off);
+    a.last_off = off;
+    a.last_len = need;
+}
+
+// Placement.  With a region map every stretch of a free range inside ONE run that fits the request is a candidate; the run
+// whose MEASURED two-stream rate beside the runs of the live blocks is highest on average wins (the previous allocation counts
+// double); ties go to the tightest stretch.  Without a map,
+// or when no stretch fits (a request larger than any run): best fit over the free ranges.
+// (Measured and not kept, profiles/r03_alloc.md: centring every large block on a class boundary and letting the tile kernels
+// write each array through two windows half an array apart -- KMERS_PARAM_SPLIT_ORDER -- gains a single-output launch 1 %
+// and costs a two-output launch 1-4 % against the two arrays in two different classes.)
+inline bool arena_take(kmers_arena &a, size_t need, size_t *off_out) {
+    if (!a.run_start.empty()) {
+        auto best_range = a.free_ranges.end();
+        size_t best_off = 0, best_slack = 0;
+        float best_score = -1.f;
+        const size_t k = a.run_start.size();
+        for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it) {
+            const size_t fo = it->first, fe = fo + it->second;
+            size_t pos = fo;
+            while (pos < fe) {  // the run that holds `pos`, cut to the free range
+                const size_t r = run_of(a, pos);
+                const size_t stretch_end = std::min(fe, run_end(a, r));
+                if (stretch_end - pos >= need) {
+                    // mean GB/s beside the LIVE blocks of the arena (those of 64 MiB or more: the arrays and sequences launches
+                    // stream through; the previous allocation counts double -- the arrays of one launch are allocated one after
+                    // the other); nothing live: the run's own rate
+                    float sum = 0.f, weight = 0.f;
+                    for (const auto &u : a.used) {
+                        if (u.second < ((size_t)64 << 20)) continue;
+                        const float w = u.first == a.last_off ? 2.f : 1.f;
+                        sum += w * a.pair_rate[run_of(a, u.first) * k + r];
+                        weight += w;
+                    }
+                    float score = weight > 0.f ? sum / weight : a.pair_rate[r * k + r];
+                    score = (float)(int)(score / 100.f);  // (rates within 100 GB/s of each other are a tie)
+                    const size_t slack = stretch_end - pos - need;
+                    if (score > best_score || (score == best_score && slack < best_slack)) {
+                        best_range = it;
+                        best_off = pos;
+                        best_slack = slack;
+                        best_score = score;
+                    }
+                }
+                pos = stretch_end;
+            }
+        }
+        if (best_range != a.free_ranges.end()) {
+            arena_commit(a, best_range, best_off, need);
+            *off_out = best_off;
+            return true;
+        }
+    }
+    if (!a.run_start.empty() && a.last_len) {
+        // a block longer than any run (the 80 GB arrays of a 10 Gbase launch) passes through several runs: at the bottom or at
+        // the top of a free range that fits (nothing is fragmented), wherever its runs -- sampled at eight points -- write
+        // fastest beside the previous block's
+        const size_t k = a.run_start.size();
+        auto best_range = a.free_ranges.end();
+        size_t best_off = 0;
+        float best_score = -1.f;
+        for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it) {
+            if (it->second < need) continue;
+            const size_t ends[2] = {it->first, (it->first + it->second - need) / GRANULE * GRANULE};
+            for (int e = 0; e < 2; ++e) {
+                const size_t off = ends[e];
+                if (off < it->first) continue;
+                float sum = 0.f;
+                for (int i = 0; i < 8; ++i) {
+                    const size_t t = (size_t)((2 * i + 1) * (double)need / 16.0), u = (size_t)((2 * i + 1) * (double)a.last_len / 16.0);
+                    sum += a.pair_rate[run_of(a, a.last_off + u) * k + run_of(a, off + t)];
+                }
+                if (sum > best_score + 400.f) {  // (a later position must be better by 50 GB/s on average to be preferred)
+                    best_score = sum;
+                    best_range = it;
+                    best_off = off;
+                }
+            }
+        }
+        if (best_range != a.free_ranges.end()) {
+            arena_commit(a, best_range, best_off, need);
+            *off_out = best_off;
+            return true;
+        }
+    }
+    auto best = a.free_ranges.end();
+    for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it)
+        if (it->second >= need && (best == a.free_ranges.end() || it->second < best->second)) best = it;
+    if (best == a.free_ranges.end()) return false;
+    const size_t off = best->first;
+    arena_commit(a, best, off, need);
+    *off_out = off;
+    return true;
+}
+
+inline void arena_give(kmers_arena &a, size_t off, size_t len) {
+    auto next = a.free_ranges.lower_bound(off);
+    if (next != a.free_ranges.end() && off + len == next->first) {  // merge with the range behind
+        len += next->second;
+        next = a.free_ranges.erase(next);
+    }
+    if (next != a.free_ranges.begin()) {
+        auto prev = std::prev(next);
+        if (prev->first + prev->second == off) {  // merge with the range in front
+            prev->second += len;
+            return;
+        }
+    }
+    a.free_ranges[off] = len;
+}
+
+}  // namespace arena
+}  // namespace kmers

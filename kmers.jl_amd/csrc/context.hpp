@@ -9,52 +9,7 @@
 #include <vector>
 
 #include "../../include/kmers_hip.h"
-
-// The context's device-memory arena (kmers_arena_reserve, include/kmers_hip.h): ONE hipMalloc, sub-allocated in 2 MiB
-// granules by kmers_dev_alloc.  Offsets are relative to `base`; free ranges are kept coalesced.  `region` is the map of the
-// block that the calibration of memory_api.hip measured: two store streams inside one REGION CLASS of HBM share a write rate of
-// ~6 TB/s on MI355X, streams in different classes reach ~7.1 TB/s, so consecutive allocations go to different classes.
-struct kmers_arena {
-    char *base = nullptr;
-    size_t bytes = 0;
-    std::map<size_t, size_t> free_ranges;  // offset -> length
-    std::map<size_t, size_t> used;         // offset -> length
-    size_t region_bytes = 0;               // granule of the region map (0: not calibrated)
-    std::vector<uint8_t> region;           // class of every granule of the block (kmers_arena_regions)
-    std::vector<size_t> run_start;         // the map as runs: run i = [run_start[i], run_start[i + 1]) is in class run_class[i];
-    std::vector<uint8_t> run_class;        //   boundaries refined to about half a gigabyte
-    std::vector<float> pair_rate;          // measured: pair_rate[i * n_runs + j] = GB/s of two store streams, one in run i, one in run j
-    float best_pair_rate = 0.f;            // the largest of them
-    int n_classes = 0;
-    int last_run = -1, last2_run = -1;     // runs of the two most recent allocations
-    size_t last_off = 0, last_len = 0;     // the most recent allocation itself (placement of blocks longer than a run)
-};
-
-// index of the arena's run that holds offset `off` (the map must exist)
-inline size_t kmers_arena_run_of(const kmers_arena &a, size_t off) {
-    size_t lo = 0, hi = a.run_start.size();
-    while (hi - lo > 1) {
-        const size_t mid = (lo + hi) / 2;
-        if (a.run_start[mid] <= off) lo = mid;
-        else hi = mid;
-    }
-    return lo;
-}
-// true iff two arrays of `bytes` bytes at p and q both lie in the arena and the MEASURED two-stream rate of the runs they pass
-// through side by side (sampled at eight points: an array may be longer than a run) averages within 5 % of the best pair of
-// the block: the launchers pick the launch shape that is fastest for well-placed outputs only then (stream_launch.hpp)
-inline bool kmers_arena_spread(const kmers_arena &a, const void *p, const void *q, size_t bytes) {
-    if (a.run_start.empty() || !p || !q || bytes == 0) return false;
-    const char *cp = static_cast<const char *>(p), *cq = static_cast<const char *>(q);
-    if (cp < a.base || cp + bytes > a.base + a.bytes || cq < a.base || cq + bytes > a.base + a.bytes) return false;
-    const size_t k = a.run_start.size();
-    float sum = 0.f;
-    for (int i = 0; i < 8; ++i) {
-        const size_t t = (size_t)((2 * i + 1) * (double)bytes / 16.0);
-        sum += a.pair_rate[kmers_arena_run_of(a, (size_t)(cp - a.base) + t) * k + kmers_arena_run_of(a, (size_t)(cq - a.base) + t)];
-    }
-    return sum / 8.f >= 0.95f * a.best_pair_rate;
-}
+#include "arena_placement.hpp"
 
 struct kmers_ctx {
     int device = 0;

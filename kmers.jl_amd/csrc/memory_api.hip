@@ -12,7 +12,7 @@
 // 8 TB/s peak -- the "achievable" figure of every single-buffer bandwidth test); streams in different classes reach ~7.1 TB/s
 // (89 %).  The two output arrays of one launch are two such streams.  kmers_arena_reserve therefore MEASURES the map of its
 // block (calibrate(): a two-stream fill between every 4 GiB granule and one representative per class found so far; about
-// 0.1 s for 200 GB) and kmers_dev_alloc places consecutive allocations in different classes.
+// 0.3 s for 200 GB) and kmers_dev_alloc places a block where the measured two-stream rate beside the live blocks is highest.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -26,11 +26,8 @@ using namespace kmers;
 
 namespace {
 
-constexpr size_t GRANULE = KMERS_ARENA_GRANULE;
-
-size_t round_up(size_t x) { return (x + GRANULE - 1) / GRANULE * GRANULE; }
-
-constexpr size_t REGION = (size_t)4 << 30;    // granule of the region map
+using namespace kmers::arena;  // GRANULE, REGION, round_up, run_of, arena_take / arena_give: arena_placement.hpp (pure host logic)
+static_assert(GRANULE == KMERS_ARENA_GRANULE, "arena_placement.hpp and include/kmers_hip.h disagree about the granule");
 constexpr size_t PROBE = (size_t)1 << 30;     // bytes per stream of one probe
 
 // two store streams, 8 KiB of each per workgroup, 16 bytes per lane: the shape of the stream kernels' outputs
@@ -190,121 +187,6 @@ int calibrate(kmers_ctx *ctx) {
         }
     }
     return KMERS_OK;
-}
-
-size_t run_of(const kmers_arena &a, size_t off) { return kmers_arena_run_of(a, off); }
-int class_at(const kmers_arena &a, size_t off) { return a.run_class.empty() ? 0 : a.run_class[run_of(a, off)]; }
-size_t run_end(const kmers_arena &a, size_t i) { return i + 1 < a.run_start.size() ? a.run_start[i + 1] : a.bytes; }
-
-void arena_commit(kmers_arena &a, std::map<size_t, size_t>::iterator range, size_t off, size_t need) {
-    const size_t fo = range->first, fl = range->second;
-    a.free_ranges.erase(range);
-    if (off > fo) a.free_ranges[fo] = off - fo;
-    if (fo + fl > off + need) a.free_ranges[off + need] = fo + fl - (off + need);
-    a.used[off] = need;
-    a.last2_run = a.last_run;
-    a.last_run = a.run_start.empty() ? -1 : (int)run_of(a, off);
-    a.last_off = off;
-    a.last_len = need;
-}
-
-// Placement.  With a region map every stretch of a free range inside ONE run that fits the request is a candidate; the run
-// whose MEASURED two-stream rate beside the run of the previous allocation is highest wins (the arrays of one launch are
-// allocated one after the other), the allocation before that counting half; ties go to the tightest stretch.  Without a map,
-// or when no stretch fits (a request larger than any run): best fit over the free ranges.
-// (Measured and not kept, profiles/r03_alloc.md: centring every large block on a class boundary and letting the tile kernels
-// write each array through two windows half an array apart -- KMERS_PARAM_SPLIT_ORDER -- gains a single-output launch 1 %
-// and costs a two-output launch 1-4 % against the two arrays in two different classes.)
-bool arena_take(kmers_arena &a, size_t need, size_t *off_out) {
-    if (!a.run_start.empty()) {
-        auto best_range = a.free_ranges.end();
-        size_t best_off = 0, best_slack = 0;
-        float best_score = -1.f;
-        const size_t k = a.run_start.size();
-        for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it) {
-            const size_t fo = it->first, fe = fo + it->second;
-            size_t pos = fo;
-            while (pos < fe) {  // the run that holds `pos`, cut to the free range
-                const size_t r = run_of(a, pos);
-                const size_t stretch_end = std::min(fe, run_end(a, r));
-                if (stretch_end - pos >= need) {
-                    // GB/s beside the previous block's run (+ half of that beside the one before); no history: the run's own rate
-                    float score = a.last_run < 0 ? a.pair_rate[r * k + r] : a.pair_rate[(size_t)a.last_run * k + r];
-                    if (a.last2_run >= 0) score += 0.5f * a.pair_rate[(size_t)a.last2_run * k + r];
-                    score = (float)(int)(score / 100.f);  // (rates within 100 GB/s of each other are a tie)
-                    const size_t slack = stretch_end - pos - need;
-                    if (score > best_score || (score == best_score && slack < best_slack)) {
-                        best_range = it;
-                        best_off = pos;
-                        best_slack = slack;
-                        best_score = score;
-                    }
-                }
-                pos = stretch_end;
-            }
-        }
-        if (best_range != a.free_ranges.end()) {
-            arena_commit(a, best_range, best_off, need);
-            *off_out = best_off;
-            return true;
-        }
-    }
-    if (!a.run_start.empty() && a.last_len) {
-        // a block longer than any run (the 80 GB arrays of a 10 Gbase launch) passes through several runs: at the bottom or at
-        // the top of a free range that fits (nothing is fragmented), wherever its runs -- sampled at eight points -- write
-        // fastest beside the previous block's
-        const size_t k = a.run_start.size();
-        auto best_range = a.free_ranges.end();
-        size_t best_off = 0;
-        float best_score = -1.f;
-        for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it) {
-            if (it->second < need) continue;
-            const size_t ends[2] = {it->first, (it->first + it->second - need) / GRANULE * GRANULE};
-            for (int e = 0; e < 2; ++e) {
-                const size_t off = ends[e];
-                if (off < it->first) continue;
-                float sum = 0.f;
-                for (int i = 0; i < 8; ++i) {
-                    const size_t t = (size_t)((2 * i + 1) * (double)need / 16.0), u = (size_t)((2 * i + 1) * (double)a.last_len / 16.0);
-                    sum += a.pair_rate[run_of(a, a.last_off + u) * k + run_of(a, off + t)];
-                }
-                if (sum > best_score + 400.f) {  // (a later position must be better by 50 GB/s on average to be preferred)
-                    best_score = sum;
-                    best_range = it;
-                    best_off = off;
-                }
-            }
-        }
-        if (best_range != a.free_ranges.end()) {
-            arena_commit(a, best_range, best_off, need);
-            *off_out = best_off;
-            return true;
-        }
-    }
-    auto best = a.free_ranges.end();
-    for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it)
-        if (it->second >= need && (best == a.free_ranges.end() || it->second < best->second)) best = it;
-    if (best == a.free_ranges.end()) return false;
-    const size_t off = best->first;
-    arena_commit(a, best, off, need);
-    *off_out = off;
-    return true;
-}
-
-void arena_give(kmers_arena &a, size_t off, size_t len) {
-    auto next = a.free_ranges.lower_bound(off);
-    if (next != a.free_ranges.end() && off + len == next->first) {  // merge with the range behind
-        len += next->second;
-        next = a.free_ranges.erase(next);
-    }
-    if (next != a.free_ranges.begin()) {
-        auto prev = std::prev(next);
-        if (prev->first + prev->second == off) {  // merge with the range in front
-            prev->second += len;
-            return;
-        }
-    }
-    a.free_ranges[off] = len;
 }
 
 }  // namespace

@@ -94,3 +94,15 @@ def test_header_is_plain_c_and_example_links(km, tmp_path):
         if not torch.cuda.is_available():
             out = subprocess.run([str(exe)], capture_output=True, text=True)
             assert out.returncode == 2 and "no usable HIP device" in out.stderr  # fails loudly, no fallback
+
+
+def test_arena_placement_logic_on_the_cpu(tmp_path):
+    """csrc/arena_placement.hpp -- the allocator of the context's arena and its placement policy, pure host code -- on made-up
+    region maps, under AddressSanitizer + UBSan: best fit and merging, the outputs of a launch in different classes, the sequence
+    in a third one, blocks longer than a run, kmers_arena_spread, and the allocator's invariants under 20 000 random requests."""
+    import subprocess
+    exe = tmp_path / "arena_placement_check"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-o", str(exe), os.path.join(ROOT, "tests", "c", "arena_placement_check.cpp")], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "arena placement ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
