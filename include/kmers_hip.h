@@ -165,9 +165,10 @@ int kmers_words_per_kmer(int k, int dst_bits);                      /* n_coding_
 uint64_t kmers_count(uint64_t n_bases, int k, int stride);          /* FwKmers.jl:40-43; SpacedKmers.jl:38-42 */
 /* 1 if kmers_fw / kmers_canonical / kmers_spaced cover the geometry: every K >= 1 (Kmer{A,K,N} has no bound on N,
  * src/kmer.jl:97-111; kmers of one to four words run on the tile kernels, wider ones on a run-time-width kernel).
- * kmers_unambiguous takes K <= 30720 (its one-pass kernel stages a tile together with its K-1 symbols of overlap); the
- * fused consumers, the element-wise operations and the batch entry points take kmers of at most four words (K <= 128
- * two-bit, K <= 64 four-bit) and return KMERS_E_UNSUPPORTED beyond. */
+ * kmers_unambiguous (and the fused reducer over it) takes K <= 30720 (its one-pass kernel stages a tile together with its
+ * K-1 symbols of overlap).  The fused consumers, the element-wise operations and the batch entry points take every width
+ * as well (run-time-width kernels beyond four words); what stays refused (KMERS_E_UNSUPPORTED) is a resource bound, not a
+ * width: kmers_composition above K = 12 (4^K counters), sketches per record above 2048 values, 2^32 records per batch. */
 int kmers_supported(int src_bits, int dst_bits, int k, int stride);
 
 /* ---- iterators --------------------------------------------------------------- */
@@ -276,7 +277,7 @@ int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bi
  * returns KMERS_E_CAPACITY with res->n_out = the number required (capacity 0 + NULL outputs = a size
  * query).  KMERS_MEM_DEVICE applies to pool->words, out_a and out_b; out_offsets is always host memory;
  * spans is host memory unless KMERS_SPANS_DEVICE is set (tens of millions of reads: keep them
- * resident).  Kmers of up to four words (K <= 128 two-bit, K <= 64 four-bit).
+ * resident).  Kmers of any width (more than four words: one lane per element, not tuned).
  * EncodeError: the first failing record in batch order wins, res->err_pos = 1-based position inside
  * THAT record, res->err_enc = the raw symbol, res->n_out = the record's index in spans[]. */
 typedef struct {

@@ -91,7 +91,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     clear(res);
     if (stride == 0 || stride >= 0xFFFFFFFFull) return fail(ctx, KMERS_E_BADARG, "J must be at least 1 (and below 2^32)");
     if (stride != 1 && mode != KMERS_BATCH_FW) return fail(ctx, KMERS_E_BADARG, "strided batches yield forward kmers (SpacedKmers)");
-    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP | INTERNAL_OUT_DEVICE))) {
+    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP | INTERNAL_OUT_DEVICE), true)) {
         if (res) res->status = rc;
         return rc;
     }
@@ -99,7 +99,6 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     if (mode != KMERS_BATCH_FW && mode != KMERS_BATCH_CANONICAL) return fail(ctx, KMERS_E_BADARG, "unknown batch mode");
     if (n_spans && !spans) return fail(ctx, KMERS_E_BADARG, "spans is NULL");
     const int nw = kmers_words_per_kmer(k, dst_bits);
-    if (nw > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_batch supports kmers of at most four words");
     if (n_spans >= 0xFFFFFFFFull) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_batch supports fewer than 2^32 records per call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
@@ -160,7 +159,8 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     // (the run path of the element kernel takes RG_PASS elements per workgroup pass: whole passes)
     const uint32_t tile_elems = (uint32_t)((passes * RG_UNIT + RG_PASS - 1) / RG_PASS * RG_PASS);
     const uint64_t n_tiles = (total + tile_elems - 1) / tile_elems;
-    if (int rc = ensure_stage(ctx, 6, (size_t)n_tiles * sizeof(RaggedTile))) return rc;
+    const bool wide = nw > 4;  // kmers of more than four words: ragged_wide_kernel, one lane per element, no tiles
+    if (int rc = ensure_stage(ctx, 6, wide ? 16 : (size_t)n_tiles * sizeof(RaggedTile))) return rc;
     RaggedTile *d_tiles = static_cast<RaggedTile *>(ctx->stage[6]);
 
     Staged st;
@@ -170,8 +170,9 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     const uint64_t *src0 = st.d_words + (st.first_bit >> 6);        // word that holds pool symbol 0
     const uint64_t origin = (st.first_bit & 63u) / (uint64_t)sb;     // its symbol offset inside that word
     const uint64_t n_src_words = ((origin + pool->n_bases) * (uint64_t)sb + 63) / 64;
-    hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_spans, n, n_tiles,
-                       total, tile_elems, (uint32_t)k, (uint32_t)stride, (uint32_t)dst_bits, origin, d_tiles);
+    if (!wide)
+        hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_spans, n, n_tiles,
+                           total, tile_elems, (uint32_t)k, (uint32_t)stride, (uint32_t)dst_bits, origin, d_tiles);
     HIP_TRY(ctx, hipGetLastError());
 
     RaggedArgs a{};
@@ -214,7 +215,17 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     } while (0)
 #define RGM(DB, NN) do { if (mode == KMERS_BATCH_FW) RG(DB, NN, MODE_FW); else RG(DB, NN, MODE_CANON); } while (0)
 #define RGN(DB) do { if (nw == 1) RGM(DB, 1); else if (nw == 2) RGM(DB, 2); else if (nw == 3) RGM(DB, 3); else RGM(DB, 4); } while (0)
-    if (dst_bits == 2) RGN(2);
+    if (wide) {
+        grid = dim3((unsigned)((total + 255) / 256));
+        const uint32_t nwu = (uint32_t)nw;
+        if (dst_bits == 2) {
+            if (mode == KMERS_BATCH_FW) hipLaunchKernelGGL((ragged_wide_kernel<2, MODE_FW>), grid, block, 0, ctx->stream, a, nwu);
+            else hipLaunchKernelGGL((ragged_wide_kernel<2, MODE_CANON>), grid, block, 0, ctx->stream, a, nwu);
+        } else {
+            if (mode == KMERS_BATCH_FW) hipLaunchKernelGGL((ragged_wide_kernel<4, MODE_FW>), grid, block, 0, ctx->stream, a, nwu);
+            else hipLaunchKernelGGL((ragged_wide_kernel<4, MODE_CANON>), grid, block, 0, ctx->stream, a, nwu);
+        }
+    } else if (dst_bits == 2) RGN(2);
     else RGN(4);
 #undef RGN
 #undef RGM
@@ -272,14 +283,13 @@ int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, 
 // record's hashes tile by tile and keeps its bottom-s (record_sketch_kernel.hpp).  No layout pass, no hash array.
 static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, int dst_bits,
                                uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags, kmers_result *res) {
-    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP))) {
+    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP), true)) {
         if (res) res->status = rc;
         return rc;
     }
     if (flags & (KMERS_ASYNC | KMERS_OUT_TUPLES)) return fail(ctx, KMERS_E_BADARG, "kmers_minhash_batch is synchronous");
     if (n_spans && !spans) return fail(ctx, KMERS_E_BADARG, "spans is NULL");
     const int nw = kmers_words_per_kmer(k, dst_bits);
-    if (nw > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minhash_batch supports kmers of at most four words");
     if (n_spans == 0) return KMERS_OK;
     if (n_spans >= 0xFFFFFFFFull) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minhash_batch supports fewer than 2^32 records per call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -336,6 +346,7 @@ static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmer
     a.s = (uint32_t)s;
     a.skip = (flags & KMERS_BATCH_SKIP) ? 1u : 0u;
     a.cap = cap;
+    a.n_words = (uint32_t)nw;
     const size_t lds = ((size_t)cap + RS_STAGE + RS_FSTAGE) * 8;
     dim3 grid((unsigned)n), block(256);
 #define RS(DB, NN, RR)                                                                                                                  \
@@ -345,7 +356,7 @@ static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmer
         hipLaunchKernelGGL((record_sketch_kernel<DB, NN, RR>), grid, block, lds, ctx->stream, a);                                       \
     } while (0)
 #define RSR(DB, NN) do { if (run == 8u) RS(DB, NN, 8); else RS(DB, NN, 4); } while (0)
-#define RSN(DB) do { if (nw == 1) RSR(DB, 1); else if (nw == 2) RSR(DB, 2); else if (nw == 3) RSR(DB, 3); else RSR(DB, 4); } while (0)
+#define RSN(DB) do { if (nw == 1) RSR(DB, 1); else if (nw == 2) RSR(DB, 2); else if (nw == 3) RSR(DB, 3); else if (nw == 4) RSR(DB, 4); else RSR(DB, 0); } while (0)
     if (dst_bits == 2) RSN(2);
     else RSN(4);
 #undef RSR

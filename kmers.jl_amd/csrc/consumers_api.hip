@@ -4,6 +4,7 @@
 #include "../../include/kmers_hip.h"
 
 #include "stream_launch.hpp"
+#include "wide_kernel.hpp"
 #include "composition_kernel.hpp"
 #include "run_kernel.hpp"
 #include "sketch_prune_kernel.hpp"
@@ -32,10 +33,35 @@ int launch_fused(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, 
     return rc;
 }
 
+// Kmers of more than four words (and strides no tile can stage): one lane per kmer, the width a run-time argument
+// (wide_kernel.hpp).  `a` carries the consumer's own fields; the sequence fields are filled here.
+template <int CMODE>
+int launch_wide_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, int stride, int dst_bits, StreamArgs &a) {
+    a.src = st.d_words;
+    a.first_bit = st.first_bit;
+    a.n_bases = seq->n_bases;
+    a.n_kmers = kmers_count(seq->n_bases, k, stride);
+    a.inspect_end = seq->n_bases;
+    a.err_slot = ctx->d_err;
+    a.err_origin = seq->index_origin;
+    a.k = (uint32_t)k;
+    a.stride = (uint32_t)stride;
+    a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet);
+    const uint32_t nwu = (uint32_t)kmers_words_per_kmer(k, dst_bits);
+    dim3 grid((unsigned)((a.n_kmers + BLOCK - 1) / BLOCK)), block(BLOCK);
+#define WIDEC(SB, DB) hipLaunchKernelGGL((wide_consumer_kernel<SB, DB, CMODE>), grid, block, 0, ctx->stream, a, nwu)
+    KMERS_WIDE_DISPATCH(WIDEC, seq->src_bits, dst_bits);
+#undef WIDEC
+    HIP_TRY(ctx, hipGetLastError());
+    return KMERS_OK;
+}
+
 // Fused consumers of one- and two-word 2-bit kmers (K <= 64): the rolling run kernel (run_kernel.hpp);
 // everything else (three- and four-word kmers, 4-bit kmer alphabets) goes through the stream kernel's fused modes.
 template <int RMODE, int SMODE>
 int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int k, int dst_bits, StreamArgs &a, size_t best_bytes = 0) {
+    if (kmers_words_per_kmer(k, dst_bits) > 4)
+        return launch_wide_consumer<RMODE == RMODE_XOR ? WIDE_XOR : WIDE_SKETCH>(ctx, seq, st, k, 1, dst_bits, a);
     if (dst_bits != 2 || k > 64) return launch_fused<SMODE>(ctx, seq, st, k, dst_bits, a);
     a.src = st.d_words;
     a.first_bit = st.first_bit;
@@ -73,7 +99,7 @@ extern "C" {
 int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, int canonical, uint64_t *out_value,
                      int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, seq, k, 1, dst_bits, flags & ~KMERS_ASYNC)) {
+    if (int rc = check_common(ctx, seq, k, 1, dst_bits, flags & ~KMERS_ASYNC, true)) {
         if (res) res->status = rc;
         return rc;
     }
@@ -99,7 +125,7 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
     clear(res);
     if (iter != KMERS_ITER_SPACED && iter != KMERS_ITER_UNAMBIGUOUS) return ctx ? fail(ctx, KMERS_E_BADARG, "unknown iterator") : KMERS_E_BADARG;
     if (iter == KMERS_ITER_UNAMBIGUOUS) dst_bits = 2;
-    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags & ~KMERS_ASYNC)) {
+    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags & ~KMERS_ASYNC, true)) {
         if (res) res->status = rc;
         return rc;
     }
@@ -108,13 +134,20 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
     *out_value = 0;
     const int nw = kmers_words_per_kmer(k, dst_bits);
     if (iter == KMERS_ITER_SPACED) {
-        if ((uint64_t)stride * (uint64_t)dst_bits > 64) return fail(ctx, KMERS_E_UNSUPPORTED, "fused SpacedKmers reducer: stride * bits per symbol must be <= 64");
         const uint64_t n = kmers_count(seq->n_bases, k, stride);
         if (n == 0) return KMERS_OK;
         Staged st;
         if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
         StreamArgs a{};
+        if (nw > 4 || (uint64_t)stride * (uint64_t)dst_bits > 64) {
+            // kmers of more than four words, or windows so far apart that a tile would stage mostly unread symbols
+            // (SpacedKmers.jl:121-139 with J >= K never inspects the gaps): one lane per kmer
+            a.out_a = ctx->d_scratch;
+            a.xor_canonical = 0;
+            if (int rc = launch_wide_consumer<WIDE_XOR>(ctx, seq, st, k, stride, dst_bits, a)) return rc;
+            return collect(ctx, res, n, out_value);
+        }
         a.src = st.d_words;
         a.first_bit = st.first_bit;
         a.n_bases = seq->n_bases;
@@ -140,7 +173,7 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
 static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t seed, uint64_t s,
                         uint64_t *out_hashes, int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, seq, k, 1, dst_bits, flags & ~KMERS_ASYNC)) {
+    if (int rc = check_common(ctx, seq, k, 1, dst_bits, flags & ~KMERS_ASYNC, true)) {
         if (res) res->status = rc;
         return rc;
     }
@@ -367,7 +400,7 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
 int kmers_minimizers(kmers_ctx *ctx, const kmers_seq *seq, int k, int w, int stride, int dst_bits, int mode,
                      uint64_t *out_kmers, int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags)) {
+    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags, true)) {
         if (res) res->status = rc;
         return rc;
     }
@@ -378,7 +411,6 @@ int kmers_minimizers(kmers_ctx *ctx, const kmers_seq *seq, int k, int w, int str
     const uint64_t n = seq->n_bases < span ? 0 : (seq->n_bases - span) / (uint64_t)stride + 1;
     if (n == 0) return KMERS_OK;
     if (!out_kmers) return fail(ctx, KMERS_E_BADARG, "out_kmers is NULL");
-    if ((uint64_t)stride * (uint64_t)dst_bits > 64 * 8) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_minimizers supports window strides up to 512 / dst_bits symbols");
     Staged st;
     if (int rc = stage_sequence(ctx, seq, flags, &st)) return rc;
     const bool dev = flags & KMERS_MEM_DEVICE;
@@ -403,8 +435,18 @@ int kmers_minimizers(kmers_ctx *ctx, const kmers_seq *seq, int k, int w, int str
     a.window_kmers = (uint32_t)w;
     a.minimizer_mode = (uint32_t)mode;
     a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet);
-    // strides >= span leave gaps the reference's loop never reads: restrict the validation to the windows
-    if (int rc = launch_stream<MODE_MINIMIZER>(ctx, a, seq->src_bits, dst_bits, nw, false)) return rc;
+    if (nw > 4 || (uint64_t)stride * (uint64_t)dst_bits > 64 * 8) {
+        // kmers of more than four words / windows further apart than a tile stages: one lane per window (wide_kernel.hpp)
+        const uint32_t nwu = (uint32_t)nw;
+        dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+#define WIDEM(SB, DB) hipLaunchKernelGGL((wide_minimizer_kernel<SB, DB>), grid, block, 0, ctx->stream, a, nwu)
+        KMERS_WIDE_DISPATCH(WIDEM, seq->src_bits, dst_bits);
+#undef WIDEM
+        HIP_TRY(ctx, hipGetLastError());
+    } else if (int rc = launch_stream<MODE_MINIMIZER>(ctx, a, seq->src_bits, dst_bits, nw, false)) {
+        // strides >= span leave gaps the reference's loop never reads: the validation is restricted to the windows
+        return rc;
+    }
     if (flags & KMERS_ASYNC) {
         if (res) { res->status = KMERS_OK; res->n_out = n; }
         return KMERS_OK;

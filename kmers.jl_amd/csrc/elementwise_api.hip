@@ -52,7 +52,6 @@ int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bi
     if (op < 0 || op > 8 || k < 1 || (bits != 2 && bits != 4)) return fail(ctx, KMERS_E_BADARG, "bad transform arguments");
     if (op == KMERS_OP_COUNT_GC && bits != 2) return fail(ctx, KMERS_E_UNSUPPORTED, "count(isGC) is defined for 2-bit kmers (src/counting.jl:1)");
     const int nw = n_coding_elements(k, bits);
-    if (nw > 4) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_transform supports up to 4 words per kmer");
     if ((op == KMERS_OP_AS_INTEGER || op == KMERS_OP_FROM_INTEGER) && nw > 2)
         return fail(ctx, KMERS_E_BADARG, "Must have at most 128 bits in encoding (src/kmer.jl:324)");
     if (n == 0) return KMERS_OK;
@@ -69,6 +68,15 @@ int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bi
         d_in = (const uint64_t *)ctx->stage[0];
         d_out = (uint64_t *)ctx->stage[1];
     }
+    if (nw > 4 && dev) {
+        // the any-width kernel computes a result word from two input words: overlapping arrays go through a copy
+        const char *ib = reinterpret_cast<const char *>(d_in), *ob = reinterpret_cast<const char *>(d_out);
+        if (ib < ob + out_bytes && ob < ib + in_bytes) {
+            if (int rc = ensure_stage(ctx, 0, in_bytes + 8)) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], kmers, in_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            d_in = (const uint64_t *)ctx->stage[0];
+        }
+    }
     const bool vec = aligned16(d_in) && aligned16(d_out) && nw != 3;
     const uint64_t items = (vec && nw == 1) ? (n + 1) / 2 : n;
     dim3 block(256), grid((unsigned)std::min<uint64_t>((items + 255) / 256, (uint64_t)1 << 30));  // one pass per workgroup
@@ -77,7 +85,11 @@ int kmers_transform(kmers_ctx *ctx, int op, const uint64_t *kmers, int k, int bi
         if (vec) hipLaunchKernelGGL((transform_kernel<NW_, B_, true>), grid, block, 0, ctx->stream, op, d_in, n, k, d_out);  \
         else hipLaunchKernelGGL((transform_kernel<NW_, B_, false>), grid, block, 0, ctx->stream, op, d_in, n, k, d_out);     \
     } while (0)
-    if (bits == 2) { if (nw == 1) TL(1, 2); else if (nw == 2) TL(2, 2); else if (nw == 3) TL(3, 2); else TL(4, 2); }
+    if (nw > 4) {  // any width: transform_kernel_any (in and out must not alias: a result word reads two input words)
+        grid = dim3((unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)1 << 30));
+        if (bits == 2) hipLaunchKernelGGL(transform_kernel_any<2>, grid, block, 0, ctx->stream, op, d_in, n, k, nw, d_out);
+        else hipLaunchKernelGGL(transform_kernel_any<4>, grid, block, 0, ctx->stream, op, d_in, n, k, nw, d_out);
+    } else if (bits == 2) { if (nw == 1) TL(1, 2); else if (nw == 2) TL(2, 2); else if (nw == 3) TL(3, 2); else TL(4, 2); }
     else           { if (nw == 1) TL(1, 4); else if (nw == 2) TL(2, 4); else if (nw == 3) TL(3, 4); else TL(4, 4); }
 #undef TL
     HIP_TRY(ctx, hipGetLastError());

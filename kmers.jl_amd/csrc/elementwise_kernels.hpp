@@ -197,6 +197,69 @@ __global__ __launch_bounds__(256) void transform_kernel(int op, const uint64_t *
     }
 }
 
+// Kmers of more than four words (Kmer{A,K,N} has no bound on N, src/kmer.jl:97-111): the width is a run-time argument, a
+// word of the result is computed from the one or two input words it depends on, nothing is held in a register array.
+// One lane per kmer, 8-byte accesses `nw` words apart: an edge path (2 KiB kmers are not a throughput workload).
+template <int BITS>
+__global__ __launch_bounds__(256) void transform_kernel_any(int op, const uint64_t *__restrict__ in, uint64_t n, int k, int nw,
+                                                             uint64_t *__restrict__ out) {
+    const uint64_t mask = head_mask(k, BITS);
+    const uint32_t bu = (uint32_t)bits_unused(k, BITS);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t *x = in + i * (uint64_t)nw;
+        // word w of complement(x): transformations.jl:14-25
+        auto comp = [&](int w) -> uint64_t {
+            const uint64_t c = complement_word<BITS>(x[w]);
+            return (BITS == 2 && w == 0) ? (c & mask) : c;
+        };
+        // word w of reverse(v), v given word by word: reversebits of every word, tuple reversed, right shift by bits_unused
+        // (transformations.jl:1-10)
+        auto rev = [&](auto &&v, int w) -> uint64_t {
+            const uint64_t t = reverse_symbols<BITS>(v(nw - 1 - w));
+            const uint64_t above = w > 0 ? ((reverse_symbols<BITS>(v(nw - w)) << 1) << (63u - bu)) : 0ull;
+            return (t >> bu) | above;
+        };
+        auto plain = [&](int w) -> uint64_t { return x[w]; };
+        if (op == 6) {  // count(isGC, kmer), src/counting.jl:1-8
+            uint64_t n_gc = 0;
+            for (int w = 0; w < nw; ++w) n_gc += (uint64_t)__popcll((x[w] ^ (x[w] >> 1)) & 0x5555555555555555ull);
+            out[i] = n_gc;
+            continue;
+        }
+        if (op == 3 || op == 4) {  // canonical / iscanonical: lexicographic compare with the reverse complement, head first
+            int c = 0;
+            for (int w = 0; w < nw && c == 0; ++w) {
+                const uint64_t r = rev(comp, w);
+                c = x[w] < r ? -1 : (x[w] > r ? 1 : 0);
+            }
+            if (op == 4) {
+                out[i] = c <= 0 ? 1ull : 0ull;
+                continue;
+            }
+            uint64_t *y = out + i * (uint64_t)nw;
+            for (int w = 0; w < nw; ++w) y[w] = c == -1 ? x[w] : rev(comp, w);
+            continue;
+        }
+        uint64_t *y = out + i * (uint64_t)nw;
+        for (int w = 0; w < nw; ++w) {
+            uint64_t v;
+            if (op == 0) v = rev(plain, w);
+            else if (op == 1) v = comp(w);
+            else if (op == 2) v = rev(comp, w);
+            else {  // 5: LongSequence{A}(kmer).data, src/construction.jl:289-324
+                uint64_t chunk = x[w];
+                if (bu != 0) {
+                    chunk = x[w] << bu;
+                    if (w + 1 < nw) chunk |= x[w + 1] >> (64u - bu);
+                }
+                v = reverse_symbols<BITS>(chunk);
+            }
+            y[w] = v;
+        }
+    }
+}
+
 // ---- synthetic input (the CPU checker restates the same generator) ------
 __global__ __launch_bounds__(256) void synth_kernel(uint64_t seed, uint64_t first_word, uint64_t n_words, int bits,
                                                      uint32_t ambig, uint64_t *__restrict__ out) {

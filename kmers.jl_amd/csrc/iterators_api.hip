@@ -30,7 +30,6 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int nw = kmers_words_per_kmer(k, dst_bits);
-    if (nw > 4 && (flags & KMERS_OUT_TUPLES)) return fail(ctx, KMERS_E_UNSUPPORTED, "KMERS_OUT_TUPLES: kmers of at most four words");
     const uint64_t n = kmers_count(seq->n_bases, k, stride);
     if (n == 0) {  // length(seq) < K: empty iteration, nothing inspected (FwKmers.jl:63)
         if (res) res->status = KMERS_OK;
@@ -82,12 +81,7 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
         if (mode == MODE_FW) hipLaunchKernelGGL((wide_kernel<SB, DB, MODE_FW>), grid, block, 0, ctx->stream, a, nwu);   \
         else hipLaunchKernelGGL((wide_kernel<SB, DB, MODE_CANON>), grid, block, 0, ctx->stream, a, nwu);                \
     } while (0)
-        if (seq->src_bits == 8 && dst_bits == 2) WIDE(8, 2);
-        else if (seq->src_bits == 8) WIDE(8, 4);
-        else if (seq->src_bits == 4 && dst_bits == 2) WIDE(4, 2);
-        else if (seq->src_bits == 2 && dst_bits == 2) WIDE(2, 2);
-        else if (seq->src_bits == 4 && dst_bits == 4) WIDE(4, 4);
-        else WIDE(2, 4);
+        KMERS_WIDE_DISPATCH(WIDE, seq->src_bits, dst_bits);
 #undef WIDE
         HIP_TRY(ctx, hipGetLastError());
         rc = KMERS_OK;

@@ -19,7 +19,7 @@
 #pragma once
 #include <type_traits>
 
-#include "stream_kernel.hpp"
+#include "wide_kernel.hpp"
 
 namespace kmers {
 
@@ -554,6 +554,48 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the stores have left
     RG_PROBE(6);
 #endif
+}
+
+// Kmers of more than four words (Kmer{A,K,N} has no bound on N): one lane per element, the width a run-time argument
+// (wide_kernel.hpp), the record found by a search of the global offsets, every symbol read from the stream in HBM.
+// Same results and the same error rule as ragged_kernel; an edge path, not tuned.
+template <int DST, int MODE>
+__global__ __launch_bounds__(256) void ragged_wide_kernel(const RaggedArgs a, const uint32_t n_words) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= a.n_elems) return;
+    uint64_t lo = 0, hi = a.n_records;  // the LAST record with off <= g (records that own nothing share their offset with the next)
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a.rec_off[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t p = a.spans[lo].first_base + (g - a.rec_off[lo]) * a.stride + a.stream_origin;
+    bool bad = false;
+    if (a.flags && *a.any_flag) {
+        const uint64_t fq = p >> 6;
+        bad = any_flag_in([&](uint32_t i) { return a.flags[fq + i]; }, (uint32_t)(p & 63u), a.k);
+        if (bad && !a.skip) atomicMin(a.err_slot, (unsigned long long)g);
+    }
+    const bool masked = bad && a.skip;  // the all-ones sentinel
+    auto sym = [&](uint64_t i) -> uint64_t {
+        const uint64_t bit = (p + i) * (uint64_t)DST;
+        return (a.stream[bit >> 6] >> (bit & 63u)) & ((1ull << DST) - 1ull);
+    };
+    if constexpr (MODE == MODE_FW) {
+        for (uint32_t w = 0; w < n_words; ++w) {
+            if (a.out_a) a.out_a[g * n_words + w] = masked ? ~0ull : wide_word_of<DST>(sym, a.k, n_words, w, false);
+            if (a.out_b) a.out_b[g * n_words + w] = masked ? ~0ull : wide_word_of<DST>(sym, a.k, n_words, w, true);
+        }
+    } else {
+        const bool take_fw = wide_forward_is_canonical_of<DST>(sym, a.k, n_words);
+        uint64_t h = a.seed;
+        for (uint32_t w = 0; w < n_words; ++w) {
+            const uint64_t c = wide_word_of<DST>(sym, a.k, n_words, w, !take_fw);
+            if (a.out_a) a.out_a[g * n_words + w] = masked ? ~0ull : c;
+            h = fx_step(h, c);
+        }
+        if (a.out_b) a.out_b[g] = masked ? ~0ull : h;
+    }
 }
 
 }  // namespace kmers

@@ -31,8 +31,10 @@ struct RecordSketchArgs {
     unsigned long long *err_slot;  // atomicMin of (record << 32 | window) of a window over a flagged symbol (strict mode)
     uint64_t *bad;               // becomes non-zero if a span reaches outside the pool (or holds 2^32 symbols or more)
     uint32_t k, s, skip, cap;
+    uint32_t n_words;            // N == 0 (kmers of more than four words): the run-time width
 };
 
+// N == 0: kmers of any width (a.n_words); nothing is staged, every window is read from the stream in HBM (an edge path).
 template <int DST, int N, int RUN>
 __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchArgs a) {
     constexpr uint32_t RS_TILE = 256u * RUN;
@@ -72,13 +74,15 @@ __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchAr
                 const uint64_t ps = p0 + base;                    // first symbol of the tile
                 const uint64_t q0 = (ps * (uint64_t)DST) >> 6;
                 const uint32_t nwords = (uint32_t)((((ps + nel + k - 1u) * (uint64_t)DST + 63u) >> 6) - q0);
-                for (uint32_t i = t; i < nwords; i += 256u) src_t[i] = a.stream[q0 + i];
                 const uint64_t f0 = ps >> 6;
-                if (flags) {
-                    const uint32_t nf = (uint32_t)(((ps + nel + k - 1u + 63u) >> 6) - f0);
-                    for (uint32_t i = t; i < nf; i += 256u) flg_t[i] = flags[f0 + i];
+                if constexpr (N != 0) {
+                    for (uint32_t i = t; i < nwords; i += 256u) src_t[i] = a.stream[q0 + i];
+                    if (flags) {
+                        const uint32_t nf = (uint32_t)(((ps + nel + k - 1u + 63u) >> 6) - f0);
+                        for (uint32_t i = t; i < nf; i += 256u) flg_t[i] = flags[f0 + i];
+                    }
                 }
-                block_sync();
+                block_sync();  // (also: every lane has read `fill` of the previous tile before anyone appends again)
                 const uint32_t e = (uint32_t)RUN * t;                // this lane's first window of the tile
                 if (e < nel) {
                     const uint32_t cnt = nel - e < (uint32_t)RUN ? nel - e : (uint32_t)RUN;
@@ -88,7 +92,31 @@ __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchAr
                     const uint64_t bit = p * (uint64_t)DST;
                     const uint32_t rel = (uint32_t)((bit >> 6) - q0);
                     const uint32_t sh = (uint32_t)(bit & 63u);
-                    if constexpr (N == 1) {
+                    if constexpr (N == 0) {
+#pragma unroll 1
+                        for (uint32_t j = 0; j < (uint32_t)RUN; ++j) {
+                            keep[j] = false;
+                            hv[j] = 0;
+                            if (j < cnt) {
+                                const uint64_t pj = p + j;
+                                bool flagged = false;
+                                if (flags) {
+                                    const uint64_t fq = pj >> 6;
+                                    flagged = any_flag_in([&](uint32_t i) { return flags[fq + i]; }, (uint32_t)(pj & 63u), k);
+                                }
+                                if (flagged && !a.skip) atomicMin(a.err_slot, (unsigned long long)((r << 32) | (base + e + j)));
+                                auto sym = [&](uint64_t i) -> uint64_t {
+                                    const uint64_t b = (pj + i) * (uint64_t)DST;
+                                    return (a.stream[b >> 6] >> (b & 63u)) & ((1ull << DST) - 1ull);
+                                };
+                                const bool take_fw = wide_forward_is_canonical_of<DST>(sym, k, a.n_words);  // CanonicalKmers.jl:220-225
+                                uint64_t h = a.seed;
+                                for (uint32_t w = 0; w < a.n_words; ++w) h = fx_step(h, wide_word_of<DST>(sym, k, a.n_words, w, !take_fw));
+                                hv[j] = h;
+                                keep[j] = !flagged;
+                            }
+                        }
+                    } else if constexpr (N == 1) {
                         const uint32_t span = k + cnt - 1u;       // symbols the run reads
                         uint64_t fbits = 0;                       // flagged symbols of the run
                         if (flags) {

@@ -201,6 +201,7 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
 // UnambiguousKmers under the fused XOR reducer (kmers_reduce_xor_iter): the single-pass kernel's XOR mode (no descriptors, no
 // look-back: nothing is placed).  Arguments already checked by the caller.
 int kmers::unambiguous_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uint64_t *out_value, int flags, kmers_result *res) {
+    if (k > UNAMB_MAX_K) return fail(ctx, KMERS_E_UNSUPPORTED, "fused UnambiguousKmers reducer: K above 30720");
     uint64_t n = kmers_count(seq->n_bases, k, 1);
     const bool ascii = seq->src_bits == 8;
     const bool validate_only = ascii && n == 0 && seq->n_bases > 0;  // invalid bytes still throw (UnambiguousKmers.jl:117-123)

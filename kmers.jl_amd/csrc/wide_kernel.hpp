@@ -42,56 +42,167 @@ __device__ __forceinline__ uint64_t comp_one(uint64_t s) {
     return ((s & 1u) << 3) | ((s & 2u) << 1) | ((s & 4u) >> 1) | ((s & 8u) >> 3);
 }
 
-// Word w (0 = head, data[1] in Julia) of the forward kmer of the window starting at symbol `start`, or of its reverse
-// complement.  Slot p of a kmer (p = 0 its first symbol) sits at bit DST * (K - 1 - p) of the N-word integer; word w holds
-// the slots whose bits fall into [64 (N-1-w), 64 (N-w)).  Slot p of the reverse complement is the complement of the
-// window's symbol K - 1 - p (transformations.jl:1-34).
-template <int SRC_BITS, int DST>
-__device__ __forceinline__ uint64_t wide_word(const StreamArgs &a, uint64_t start, uint32_t n_words, uint32_t w, bool rc) {
-    const long long K = (long long)a.k;
+// Word w (0 = head, data[1] in Julia) of the forward kmer of a window, or of its reverse complement; sym(p) = the
+// recoded symbol p (0-based) of the window.  Slot p of a kmer (p = 0 its first symbol) sits at bit DST * (K - 1 - p) of the
+// N-word integer; word w holds the slots whose bits fall into [64 (N-1-w), 64 (N-w)).  Slot p of the reverse complement is
+// the complement of the window's symbol K - 1 - p (transformations.jl:1-34).
+template <int DST, class Sym>
+__device__ __forceinline__ uint64_t wide_word_of(Sym sym, uint32_t k, uint32_t n_words, uint32_t w, bool rc) {
+    const long long K = (long long)k;
     const long long top = 64ll * (long long)(n_words - w);         // exclusive upper bit of the word
     long long p_lo = K - 1 - (top - DST) / DST;                     // slot in the word's highest symbol position ...
     if (p_lo < 0) p_lo = 0;                                         // ... (the head word holds fewer: bits_unused, kmer.jl:128)
     const long long p_hi = K - 1 - (top - 64) / DST;                // slot in its lowest
     uint64_t word = 0;
     for (long long p = p_lo; p <= p_hi; ++p) {
-        const uint64_t s = rc ? comp_one<DST>(wide_symbol<SRC_BITS, DST>(a, start + (uint64_t)(K - 1 - p)))
-                              : wide_symbol<SRC_BITS, DST>(a, start + (uint64_t)p);
+        const uint64_t s = rc ? comp_one<DST>(sym((uint64_t)(K - 1 - p))) : sym((uint64_t)p);
         word = (word << DST) | s;
     }
     return word;
 }
 
+// fw < rv ? fw : rv (CanonicalKmers.jl:224): lexicographic on the word tuples, head first (kmer.jl:176-178)
+template <int DST, class Sym>
+__device__ __forceinline__ bool wide_forward_is_canonical_of(Sym sym, uint32_t k, uint32_t n_words) {
+    for (uint32_t w = 0; w < n_words; ++w) {
+        const uint64_t f = wide_word_of<DST>(sym, k, n_words, w, false), r = wide_word_of<DST>(sym, k, n_words, w, true);
+        if (f != r) return f < r;
+    }
+    return false;
+}
+
+// the same over a sequence view: the window that starts at symbol `start`
+template <int SRC_BITS, int DST>
+__device__ __forceinline__ uint64_t wide_word(const StreamArgs &a, uint64_t start, uint32_t n_words, uint32_t w, bool rc) {
+    return wide_word_of<DST>([&](uint64_t p) { return wide_symbol<SRC_BITS, DST>(a, start + p); }, a.k, n_words, w, rc);
+}
+
+template <int SRC_BITS, int DST>
+__device__ __forceinline__ bool wide_forward_is_canonical(const StreamArgs &a, uint64_t start, uint32_t n_words) {
+    return wide_forward_is_canonical_of<DST>([&](uint64_t p) { return wide_symbol<SRC_BITS, DST>(a, start + p); }, a.k, n_words);
+}
+
 // MODE_FW: out_a = forward kmers, out_b = reverse complements (nullable).  MODE_CANON: out_a = canonical kmers
-// (nullable), out_b = fx_hash(canonical kmer, seed) (nullable).
+// (nullable), out_b = fx_hash(canonical kmer, seed) (nullable).  a.tuples: one array of Tuple{Kmer,Kmer} /
+// Tuple{Kmer,UInt64} elements in out_a (CanonicalKmers.jl:44-45).
 template <int SRC_BITS, int DST, int MODE>
 __global__ __launch_bounds__(BLOCK) void wide_kernel(const StreamArgs a, const uint32_t n_words) {
     const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (g >= a.n_kmers) return;
     const uint64_t start = g * a.stride;
     if constexpr (MODE == MODE_FW) {
+        uint64_t *fw = a.tuples ? a.out_a + g * 2u * n_words : a.out_a + g * n_words;
+        uint64_t *rc = a.tuples ? fw + n_words : (a.out_b ? a.out_b + g * n_words : nullptr);
         for (uint32_t w = 0; w < n_words; ++w) {
-            a.out_a[g * n_words + w] = wide_word<SRC_BITS, DST>(a, start, n_words, w, false);
-            if (a.out_b) a.out_b[g * n_words + w] = wide_word<SRC_BITS, DST>(a, start, n_words, w, true);
+            fw[w] = wide_word<SRC_BITS, DST>(a, start, n_words, w, false);
+            if (rc) rc[w] = wide_word<SRC_BITS, DST>(a, start, n_words, w, true);
         }
     } else {
-        // fw < rv ? fw : rv (CanonicalKmers.jl:224): lexicographic on the word tuples, head first (kmer.jl:176-178)
-        bool take_fw = false;
-        for (uint32_t w = 0; w < n_words; ++w) {
-            const uint64_t f = wide_word<SRC_BITS, DST>(a, start, n_words, w, false), r = wide_word<SRC_BITS, DST>(a, start, n_words, w, true);
-            if (f != r) {
-                take_fw = f < r;
-                break;
-            }
-        }
+        const bool take_fw = wide_forward_is_canonical<SRC_BITS, DST>(a, start, n_words);
+        uint64_t *kmer = a.tuples ? a.out_a + g * (n_words + 1u) : (a.out_a ? a.out_a + g * n_words : nullptr);
         uint64_t h = a.seed;
         for (uint32_t w = 0; w < n_words; ++w) {
             const uint64_t c = wide_word<SRC_BITS, DST>(a, start, n_words, w, !take_fw);
-            if (a.out_a) a.out_a[g * n_words + w] = c;
+            if (kmer) kmer[w] = c;
             h = fx_step(h, c);  // kmer.jl:255-260
         }
-        if (a.out_b) a.out_b[g] = h;
+        if (a.tuples) kmer[n_words] = h;
+        else if (a.out_b) a.out_b[g] = h;
     }
 }
+
+// ---- the fused consumers over kmers of any width (consumers_api.hip) ---------------------------------------------
+// WIDE_XOR: the reducer of test/benchmark.jl:9-15 (XOR of data[1]) over FwKmers / CanonicalKmers / SpacedKmers;
+// WIDE_SKETCH: bottom-s MinHash candidates, fx_hash(canonical kmer) below the running threshold (docs/src/minhash.md:17-41).
+// A lane reads every symbol of its window (all words are computed), so every symbol the reference's loop would have
+// inspected is validated.
+enum WideConsumer { WIDE_XOR = 0, WIDE_SKETCH = 1 };
+template <int SRC_BITS, int DST, int CMODE>
+__global__ __launch_bounds__(BLOCK) void wide_consumer_kernel(const StreamArgs a, const uint32_t n_words) {
+    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    uint64_t xacc = 0;
+    if (g < a.n_kmers) {
+        const uint64_t start = g * a.stride;
+        const bool canonical = CMODE == WIDE_SKETCH || a.xor_canonical != 0;
+        const bool take_fw = canonical ? wide_forward_is_canonical<SRC_BITS, DST>(a, start, n_words) : true;
+        uint64_t h = a.seed, head = 0;
+        for (uint32_t w = 0; w < n_words; ++w) {
+            const uint64_t c = wide_word<SRC_BITS, DST>(a, start, n_words, w, !take_fw);
+            if (w == 0) head = c;
+            h = fx_step(h, c);
+        }
+        if constexpr (CMODE == WIDE_XOR) {
+            xacc = head;
+        } else {
+            const uint64_t threshold = a.threshold_ptr ? __hip_atomic_load(a.threshold_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.threshold;
+            if (h < threshold) sketch_candidate(a, h);
+        }
+    }
+    if constexpr (CMODE == WIDE_XOR) {
+        for (int off = 32; off > 0; off >>= 1) xacc ^= __shfl_xor(xacc, off, 64);
+        if ((threadIdx.x & 63u) == 0 && xacc) atomicXor(reinterpret_cast<unsigned long long *>(a.out_a), (unsigned long long)xacc);
+    }
+}
+
+// Minimizers (docs/src/replacements.md:33-51, test/benchmark.jl:96-110) of windows of `window_kmers` kmers, `stride` apart.
+// The element's slot of out_a holds the current minimum while the window is walked, so no register array depends on the width.
+// mode 0 (the published example, literally): each next symbol is shifted into the CURRENT MINIMUM; mode 1: the true
+// sliding-window minimum of fx_hash over the window's kmers (first of equal hashes).
+template <int SRC_BITS, int DST>
+__global__ __launch_bounds__(BLOCK) void wide_minimizer_kernel(const StreamArgs a, const uint32_t n_words) {
+    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= a.n_kmers) return;
+    const uint64_t start = g * a.stride;
+    const uint64_t mask = head_mask((int)a.k, DST);
+    uint64_t *best = a.out_a + g * n_words;
+    uint64_t hash = 0;
+    for (uint32_t w = 0; w < n_words; ++w) {
+        best[w] = wide_word<SRC_BITS, DST>(a, start, n_words, w, false);
+        hash = fx_step(hash, best[w]);
+    }
+    if (a.minimizer_mode == 0) {
+        for (uint32_t off = 0; off + 1 < a.window_kmers; ++off) {
+            const uint64_t sym = wide_symbol<SRC_BITS, DST>(a, start + a.k + off);
+            // fx_hash of shift_encoding(best, sym) (construction_utils.jl:129-134), word by word
+            uint64_t nh = 0;
+            for (uint32_t w = 0; w < n_words; ++w) {
+                uint64_t v = (best[w] << DST) | (w + 1 < n_words ? best[w + 1] >> (64 - DST) : sym);
+                if (w == 0) v &= mask;
+                nh = fx_step(nh, v);
+            }
+            if (nh < hash) {
+                hash = nh;
+                for (uint32_t w = 0; w < n_words; ++w) {  // in place, head first: word w + 1 is read before it is rewritten
+                    uint64_t v = (best[w] << DST) | (w + 1 < n_words ? best[w + 1] >> (64 - DST) : sym);
+                    if (w == 0) v &= mask;
+                    best[w] = v;
+                }
+            }
+        }
+    } else {
+        uint32_t best_off = 0;
+        for (uint32_t off = 1; off < a.window_kmers; ++off) {
+            uint64_t nh = 0;
+            for (uint32_t w = 0; w < n_words; ++w) nh = fx_step(nh, wide_word<SRC_BITS, DST>(a, start + off, n_words, w, false));
+            if (nh < hash) {
+                hash = nh;
+                best_off = off;
+            }
+        }
+        if (best_off)
+            for (uint32_t w = 0; w < n_words; ++w) best[w] = wide_word<SRC_BITS, DST>(a, start + best_off, n_words, w, false);
+    }
+}
+
+// the six (source, kmer alphabet) pairs of RecodingScheme (construction.jl:75-100)
+#define KMERS_WIDE_DISPATCH(CALL, src_bits, dst_bits) \
+    do {                                              \
+        if ((src_bits) == 8 && (dst_bits) == 2) CALL(8, 2);      \
+        else if ((src_bits) == 8) CALL(8, 4);                     \
+        else if ((src_bits) == 4 && (dst_bits) == 2) CALL(4, 2);  \
+        else if ((src_bits) == 2 && (dst_bits) == 2) CALL(2, 2);  \
+        else if ((src_bits) == 4 && (dst_bits) == 4) CALL(4, 4);  \
+        else CALL(2, 4);                                          \
+    } while (0)
 
 }  // namespace kmers

@@ -203,9 +203,7 @@ def test_kmers_wider_than_four_words(km, ctx, orc):
     assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, vp(fw), vp(rv), cap.MEM_HOST, C.byref(res)) == 0
     assert [tuple(int(x) for x in r) for r in fw] == naive.fw_kmers(text, K, 2)
     assert [tuple(int(x) for x in r) for r in rv] == [b for _, b in naive.fwrv(text, K, 2)]
-    # the other entry points say so instead of computing something else
-    val = C.c_uint64()
-    assert ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), 129, 2, 1, C.byref(val), 0, C.byref(res)) == cap.E_UNSUPPORTED
+    # (the other entry points take these widths too: tests/test_gpu_wide.py)
 
 
 def ascii_seq(km, text_or_bytes, L, alphabet=0, first_base=0):
@@ -1235,7 +1233,11 @@ def test_reduce_xor_over_spaced_and_unambiguous(km, ctx, orc):
     exp, _ = orc.reduce_xor_canonical(words, len(t), 4, 4, 9)
     assert ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), 9, 4, cap.ITER_CANONICAL, 1, C.byref(val), 0, C.byref(res)) == 0
     assert val.value == exp
-    assert ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), 9, 2, cap.ITER_SPACED, 40, C.byref(val), 0, C.byref(res)) == cap.E_UNSUPPORTED
+    # strides no tile can stage (J * bits > 64) run one lane per kmer (tests/test_gpu_wide.py); an ambiguous symbol inside a
+    # window is still the iterator's EncodeError
+    rc = ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), 9, 2, cap.ITER_SPACED, 40, C.byref(val), 0, C.byref(res))
+    _, eres = orc.spaced(words, len(t), 4, 2, 9, 40)
+    assert rc == cap.E_ENCODE and (res.err_pos, res.err_enc) == (eres.err_pos, eres.err_enc)
 
 
 def test_unambiguous_lookback_gives_up_instead_of_hanging(km):
