@@ -168,7 +168,7 @@ uint64_t kmers_count(uint64_t n_bases, int k, int stride);          /* FwKmers.j
  * kmers_unambiguous (and the fused reducer over it) takes K <= 30720 (its one-pass kernel stages a tile together with its
  * K-1 symbols of overlap).  The fused consumers, the element-wise operations and the batch entry points take every width
  * as well (run-time-width kernels beyond four words); what stays refused (KMERS_E_UNSUPPORTED) is a resource bound, not a
- * width: kmers_composition above K = 12 (4^K counters), sketches per record above 2048 values, 2^32 records per batch. */
+ * width: kmers_composition above K = 16 (4^K counters), sketches per record above 2048 values, 2^32 records per batch. */
 int kmers_supported(int src_bits, int dst_bits, int k, int stride);
 
 /* ---- iterators --------------------------------------------------------------- */
@@ -242,7 +242,8 @@ int kmers_minimizers(kmers_ctx *ctx, const kmers_seq *seq, int k, int w, int str
                      uint64_t *out_kmers, int flags, kmers_result *res);
 
 /* Fused consumer of docs/src/composition.md:28-39: out_counts[as_integer(kmer)] += 1 for every
- * kmer of FwKmers{DNA/RNAAlphabet{2},K}(seq); out_counts has 4^K uint32 entries (K <= 12). */
+ * kmer of FwKmers{DNA/RNAAlphabet{2},K}(seq); out_counts has 4^K uint32 entries (K <= 16: 16 GiB of counters,
+ * which a host array stages through HBM; K <= 10 counts in LDS, above that with memory-side atomics). */
 int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out_counts, int flags,
                       kmers_result *res);
 

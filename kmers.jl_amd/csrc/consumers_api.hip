@@ -461,7 +461,7 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
         if (res) res->status = rc;
         return rc;
     }
-    if (k > 12) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_composition supports K <= 12 (4^K counters)");
+    if (k > 16) return fail(ctx, KMERS_E_UNSUPPORTED, "kmers_composition supports K <= 16 (4^K uint32 counters: 17 GB at K = 16)");
     if (!out_counts) return fail(ctx, KMERS_E_BADARG, "out_counts is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bins = (size_t)1 << (2 * k);
@@ -506,7 +506,8 @@ int kmers_composition(kmers_ctx *ctx, const kmers_seq *seq, int k, uint32_t *out
             }
             HIP_TRY(ctx, hipGetLastError());
         } else {
-            // 4^11 and 4^12 counters: 64+ passes would cost more than memory-side global atomics (37 ms per Gbase)
+            // 4^11 .. 4^16 counters (16 MiB .. 16 GiB of HBM): 64+ passes would cost more than memory-side global atomics
+            // (37 ms per Gbase at K = 12)
             StreamArgs a{};
             a.out_a = reinterpret_cast<uint64_t *>(d_counts);
             if (int rc = launch_fused<MODE_COUNT>(ctx, seq, st, k, 2, a, 0)) return rc;

@@ -1022,6 +1022,31 @@ def test_composition(km, ctx, orc):
     assert ctx.lib.kmers_composition(ctx.handle, C.byref(seq), 12, vp(counts), cap.MEM_HOST, C.byref(res)) == 0
     fw, _ = orc.fw_kmers(words, L, 4, 2, 12)
     assert np.array_equal(counts, np.bincount(fw[:, 0].astype(np.int64), minlength=4 ** 12).astype(np.uint32))
+    # K = 13 into a host array; K = 16 (2^32 counters, 16 GiB, the widest index the kernel forms) resident in HBM, read back in pieces
+    L = 2_000_000
+    words = orc.synth_words(1316, 0, L // 16 + 1, 4)
+    seq, keep = make_seq(km, words, L, 4)
+    counts = np.zeros(4 ** 13, dtype=np.uint32)
+    assert ctx.lib.kmers_composition(ctx.handle, C.byref(seq), 13, vp(counts), cap.MEM_HOST, C.byref(res)) == 0
+    fw, _ = orc.fw_kmers(words, L, 4, 2, 13)
+    assert np.array_equal(counts, np.bincount(fw[:, 0].astype(np.int64), minlength=4 ** 13).astype(np.uint32))
+    d_w, d_c = ctx.alloc(words.nbytes), ctx.alloc(4 ** 16 * 4)
+    ctx.h2d(d_w, words)
+    dseq = cap.Seq(d_w, L, 0, 0, 4, 0)
+    assert ctx.lib.kmers_composition(ctx.handle, C.byref(dseq), 16, d_c, cap.MEM_DEVICE, C.byref(res)) == 0, ctx.last_error()
+    fw, _ = orc.fw_kmers(words, L, 4, 2, 16)
+    want_idx, want_cnt = np.unique(fw[:, 0], return_counts=True)
+    piece = np.zeros(1 << 26, dtype=np.uint32)          # 256 MiB at a time
+    got_idx, got_cnt = [], []
+    for i in range(4 ** 16 // len(piece)):
+        ctx.d2h(piece, d_c + i * piece.nbytes)
+        nz = np.flatnonzero(piece)
+        got_idx.append(nz.astype(np.uint64) + np.uint64(i * len(piece)))
+        got_cnt.append(piece[nz].astype(np.int64))
+    ctx.free(d_w)
+    ctx.free(d_c)
+    assert np.array_equal(np.concatenate(got_idx), want_idx) and np.array_equal(np.concatenate(got_cnt), want_cnt)
+    assert ctx.lib.kmers_composition(ctx.handle, C.byref(seq), 17, vp(counts), cap.MEM_HOST, C.byref(res)) == cap.E_UNSUPPORTED
     text = naive.random_text(np.random.default_rng(3), 70_001)
     aw = naive.ascii_words(text)
     seq = cap.Seq(aw.ctypes.data, len(text), 0, 0, 8, 0)
