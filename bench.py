@@ -401,8 +401,29 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7):
         out[f"kmers_batch: {n_reads} reads x {rl} bases, CanonicalDNAMers{{31}} + fx_hash per read"] = {
             "ms": round(ms, 4), "G_elements_per_s": round(total / ms / 1e6, 1), "Gbases_per_s": round(n_reads * rl / ms / 1e6, 1),
             "GB_per_s": round((16.0 * total + 0.5 * n_reads * rl) / ms / 1e6, 1)}
+        del spans
+        # SURVEY.md 8(f) rows, the same 1 Gbase: f1 the headline launch from TEXT (1 B/base in: String / Vector{UInt8} sources,
+        # FwKmers.jl:117-129), f3 a 4-bit kmer alphabet (Copyable 4 -> 4, two-word kmers), f4 element-wise fx_hash and
+        # reverse_complement over an array of kmers (kmer.jl:255-261, transformations.jl:32-34)
+        Kf = 31
+        idx = torch.randint(0, 4, (L,), dtype=torch.uint8, device=dev)
+        text = torch.full((L + 8,), 65, dtype=torch.uint8, device=dev)                   # "A"
+        for code, add in ((1, 2), (2, 6), (3, 19)):                                        # "C", "G", "T"
+            text[:L] += idx.eq(code).to(torch.uint8) * add
+        del idx
+        tseq = cap.Seq(text.data_ptr(), L, 0, 0, 8, 0)
+        torch.cuda.synchronize()
+        ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(tseq), Kf, 2, a.data_ptr(), b.data_ptr(), 0, ASYNC, C.byref(res)))
+        entry("f1 CanonicalDNAMers{31} + fx_hash from 1 Gbase of ASCII text (String source), 17 B/kmer", ms, L, 17.0 * (L - Kf + 1))
+        del text
+        ms = timed(lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), Kf, 4, a.data_ptr(), None, ASYNC, C.byref(res)))
+        entry("f3 FwKmers{DNAAlphabet{4},31} (4-bit kmer alphabet, two-word kmers), 1 Gbase LongDNA{4}, 16.5 B/kmer", ms, L, 16.5 * (L - Kf + 1))
+        ms = timed(lambda: ctx.lib.kmers_fx_hash(ctx.handle, a.data_ptr(), 1, L, 0, b.data_ptr(), ASYNC))
+        entry("f4 fx_hash over an array of 1 G one-word kmers, 16 B/kmer", ms, L, 16.0 * L)
+        ms = timed(lambda: ctx.lib.kmers_transform(ctx.handle, cap.OP_REVCOMP, a.data_ptr(), Kf, 2, L, b.data_ptr(), ASYNC))
+        entry("f4 reverse_complement over an array of 1 G DNAKmer{31}, 16 B/kmer", ms, L, 16.0 * L)
         mem.free(a, b, buf)
-        del a, b, buf, spans
+        del a, b, buf
         torch.cuda.empty_cache()
         # N1 (north star): CanonicalDNAMers{31} + fx_hash over 10 Gbase LongDNA{4} on ONE GPU: 5 GB in, 160 GB out
         out.update(north_star_one_gpu(ctx, cap, stream, dev, mem, reps))

@@ -369,3 +369,33 @@ def test_reducer_of_the_reference_benchmark(km, orc):
     assert km.reducer(km.CanonicalDNAMers[7](clean)) == fold(km.collect(km.CanonicalDNAMers[7](clean)))   # String source
     with pytest.raises(km.EncodeError):
         km.reducer(km.SpacedDNAMers[7, 5](s4))
+
+
+def test_wide_kmers_through_the_mirror(km, orc):
+    """Kmers of more than four words (K = 150: five words) through the host mirror's consumers and element-wise functions:
+    the same calls as with short kmers (Kmer{A,K,N} has no bound on N, src/kmer.jl:97-111)."""
+    rng = np.random.default_rng(15)
+    K, L = 150, 20_000
+    text = naive.random_text(rng, L)
+    words = naive.longseq_words(text, 4)
+    seq = km.LongDNA[4](text)
+    ek, eh, _ = orc.canonical(words, L, 4, 2, K)
+    efw, _ = orc.fw_kmers(words, L, 4, 2, K)
+    assert km.reducer(km.CanonicalDNAMers[K](seq)) == int(np.bitwise_xor.reduce(ek[:, 0]))
+    assert km.reducer(km.FwDNAMers[K](seq)) == int(np.bitwise_xor.reduce(efw[:, 0]))
+    assert km.reducer(km.SpacedDNAMers[K, 40](seq)) == int(np.bitwise_xor.reduce(efw[::40, 0]))
+    assert np.array_equal(km.sketch(km.fx_hash, km.CanonicalDNAMers[K](seq), 200), np.unique(eh)[:200])
+    mins = km.minimizers(km.FwDNAMers[K](seq), 9, stride=50, mode=1)
+    exp, _ = orc.minimizers(words, L, 4, 2, K, 9, 50, 1)
+    assert np.array_equal(mins.words, exp)
+    arr = km.collect(km.FwDNAMers[K](seq))
+    assert np.array_equal(arr.words, efw)
+    rc = km.reverse_complement(arr)
+    assert [str(x) for x in rc[:3]] == [naive.revcomp_text(text[i:i + K]) for i in range(3)]
+    assert np.array_equal(km.canonical(arr).words, ek)
+    assert np.array_equal(km.fx_hash(km.canonical(arr)), eh)
+    recs = [text[:100], text[100:700], text[700:5000]]
+    sk = km.sketch_batch(km.fx_hash, km.CanonicalDNAMers[K], recs, 50)
+    for r, got in zip(recs, sk):
+        want = np.unique(orc.canonical(naive.ascii_words(r), len(r), 8, 2, K)[1])[:50] if len(r) >= K else np.zeros(0, np.uint64)
+        assert np.array_equal(got, want)
