@@ -857,7 +857,24 @@ def main():
     if grouped and transport == "native":
         if backend != "nccl":
             raise SystemExit("KMERS_HALO_TRANSPORT=native needs one GPU per rank (RCCL); the gloo mode shares a device")
-        env.comm = NativeComm.bootstrap(ctx)
+        # If the library's own communicator cannot be built on this machine (no RCCL the library can load, an
+        # ncclCommInitRank that fails) the run goes on with torch.distributed's RCCL for the halo -- said in the line
+        # (halo_transport) and on stderr -- rather than losing the measurement.  All ranks take the same decision.
+        try:
+            env.comm = NativeComm.bootstrap(ctx)
+            made = 1
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"[bench rank {rank}] kmers_comm_create failed ({e!r})\n")
+            made = 0
+        agreed = torch.tensor([made], dtype=torch.int32, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            if env.comm is not None:
+                env.comm.close()
+                env.comm = None
+            transport = env.transport = "allgather"
+            if rank == 0:
+                sys.stderr.write("[bench] halo transport falls back to torch.distributed all_gather over RCCL\n")
     comm = env.comm
 
     leg = Leg(env, total_bases, seed)

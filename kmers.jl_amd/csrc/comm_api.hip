@@ -40,7 +40,13 @@ struct Rccl {
 Rccl load_rccl() {
     Rccl r;
     std::vector<std::string> names;
-    if (const char *env = std::getenv("KMERS_RCCL_LIB")) names.push_back(env);
+    if (const char *env = std::getenv("KMERS_RCCL_LIB")) {
+        if (std::string(env) == "none") {  // a host that wants this library never to load RCCL: the kmers_comm_* entry points answer KMERS_E_UNSUPPORTED
+            r.error = "RCCL disabled by KMERS_RCCL_LIB=none: the kmers_comm_* entry points need RCCL";
+            return r;
+        }
+        names.push_back(env);
+    }
     names.push_back("librccl.so.1");  // the soname: an RCCL the process already holds, else the loader's search path + our RUNPATH
     if (const char *rocm = std::getenv("ROCM_PATH")) names.push_back(std::string(rocm) + "/lib/librccl.so.1");
     names.push_back("/opt/rocm/lib/librccl.so.1");

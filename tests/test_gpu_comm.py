@@ -204,3 +204,26 @@ def test_bench_rccl_code_path_on_one_rank():
     assert d["n_gpus"] == 1 and d["verified"] is True
     assert d["config"]["backend"] == "nccl" and d["config"]["halo_transport"] == "native"
     assert "kmers_halo_exchange" in d["config"]["sharding"]
+
+
+def test_bench_falls_back_to_torch_rccl_when_the_library_has_no_communicator():
+    """`bench.py --gpus N` must not lose its measurement to the library's OWN communicator: if kmers_comm_create cannot be had
+    (here: KMERS_RCCL_LIB=none, so the C ABI's communication answers KMERS_E_UNSUPPORTED), every rank agrees to move
+    the halo with torch.distributed's all_gather over RCCL instead, and the line says so."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, KMERS_BENCH_FORCE_GROUP="1", KMERS_BENCH_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               KMERS_RCCL_LIB="none")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--bases", "8000000", "--no-other-configs", "--no-cpu-baseline", "--no-pmc"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["verified"] is True
+    assert d["config"]["backend"] == "nccl" and d["config"]["halo_transport"] == "allgather"
+    assert "kmers_comm_create failed" in r.stderr and "falls back" in r.stderr
