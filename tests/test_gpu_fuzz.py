@@ -144,7 +144,7 @@ def test_fuzz_fused_consumers(km, ctx, orc, seed):
     rng = np.random.default_rng(2000 + seed)
     for case in range(60):
         src = int(rng.choice([2, 4, 8]))
-        K = int(rng.choice([1, 4, 5, 8, 11, 16, 21, 31, 32, 33, 63]))
+        K = int(rng.choice([1, 4, 5, 8, 11, 16, 21, 31, 32, 33, 63, 64, 65, 128, 129, 200, 256]))   # 129 ..: more than four words
         L = int(rng.choice([K - 1, K, 300, 4099, 30000]))
         L = max(L, 0)
         first = int(rng.choice([0, 1, 16, 33, 64]))
@@ -171,7 +171,7 @@ def test_fuzz_fused_consumers(km, ctx, orc, seed):
             fw, _ = orc.fw_kmers(view_words, L, osrc, 2, K)
             assert np.array_equal(counts, np.bincount(fw[:, 0].astype(np.int64), minlength=4 ** K).astype(np.uint32)), tag
         # minimizers
-        W, stride, mode = int(rng.choice([1, 2, 9, 20])), int(rng.choice([1, 3, 20, 50])), int(rng.integers(0, 2))
+        W, stride, mode = int(rng.choice([1, 2, 9, 20])), int(rng.choice([1, 3, 20, 50, 257, 1000])), int(rng.integers(0, 2))
         span = K + W - 1
         m = 0 if L < span else (L - span) // stride + 1
         N = (2 * K + 63) // 64
@@ -190,7 +190,8 @@ def test_fuzz_batches(km, ctx, orc, seed):
     for case in range(40):
         src = int(rng.choice([2, 4, 8]))
         dst = int(rng.choice([2, 4]))
-        K = int(rng.choice([1, 3, 15, 16, 17, 31, 32, 33, 64, 65, 100, 128])) if dst == 2 else int(rng.choice([1, 5, 16, 17, 32, 33, 64]))
+        K = int(rng.choice([1, 3, 15, 16, 17, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256])) if dst == 2 else \
+            int(rng.choice([1, 5, 16, 17, 32, 33, 64, 65, 100, 128]))   # beyond 128 / 64: more than four words
         ctx.set_param(cap.PARAM_BATCH_PASSES, int(rng.choice([0, 0, 1, 3, 8])))   # tile length: per-call choice, or forced
         n_pool = int(rng.choice([0, 10, 500, 20_000]))
         lead = int(rng.choice([0, 1, 17, 64]))
@@ -245,15 +246,15 @@ def test_fuzz_batches(km, ctx, orc, seed):
         assert rc == 0 and res.n_out == offs_s[-1] and [int(x) for x in got_off] == offs_s, tag + (J, ctx.last_error())
         if offs_s[-1]:
             assert np.array_equal(out_s[:offs_s[-1]], np.concatenate(exp_s)), tag + (J,)
-        if dst == 2 and n_rec:
+        if n_rec:
             s = int(rng.choice([1, 7, 300]))
             sk = np.zeros((n_rec, s), np.uint64)
             cnt = np.zeros(n_rec, np.uint64)
-            assert ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq), arr, n_rec, K, 2, case, s, vp(sk), vp(cnt), 0, C.byref(res)) == 0, tag
+            assert ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq), arr, n_rec, K, dst, case, s, vp(sk), vp(cnt), 0, C.byref(res)) == 0, tag
             for i, t in enumerate(recs):
                 if len(t) >= K:
                     w = naive.ascii_words(t) if src == 8 else naive.longseq_words(t, src)
-                    _, eh, _ = orc.canonical(w, len(t), src, 2, K, seed=case)
+                    _, eh, _ = orc.canonical(w, len(t), src, dst, K, seed=case)
                     e = np.unique(eh)[:s]
                 else:
                     e = np.zeros(0, np.uint64)
