@@ -5,6 +5,7 @@
 
 #include "stream_launch.hpp"
 #include "wide_kernel.hpp"
+#include "wide_tile_kernel.hpp"
 #include "composition_kernel.hpp"
 #include "run_kernel.hpp"
 #include "sketch_prune_kernel.hpp"
@@ -48,6 +49,10 @@ int launch_wide_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st,
     a.stride = (uint32_t)stride;
     a.ascii_table = ascii_table(ctx, dst_bits, seq->alphabet);
     const uint32_t nwu = (uint32_t)kmers_words_per_kmer(k, dst_bits);
+    if (!ctx->wide_no_tiles) {  // stride 1: the tile form (wide_tile_kernel.hpp)
+        const int tiled = launch_wide_tile<CMODE == WIDE_XOR ? WMODE_XOR : WMODE_SKETCH>(ctx, a, seq->src_bits, dst_bits, nwu);
+        if (tiled >= 0) return tiled;
+    }
     dim3 grid((unsigned)((a.n_kmers + BLOCK - 1) / BLOCK)), block(BLOCK);
 #define WIDEC(SB, DB) hipLaunchKernelGGL((wide_consumer_kernel<SB, DB, CMODE>), grid, block, 0, ctx->stream, a, nwu)
     KMERS_WIDE_DISPATCH(WIDEC, seq->src_bits, dst_bits);

@@ -30,6 +30,7 @@ struct kmers_ctx {
     int64_t subtiles = 0;    // KMERS_PARAM_SUBTILES; 0 = default
     int64_t block_threads = 0;  // KMERS_PARAM_BLOCK_THREADS: 64 / 128 / 256 threads per workgroup of the tile kernel; 0 = per shape
     int64_t split_order = 0;     // KMERS_PARAM_SPLIT_ORDER: the tile kernels visit the two halves of their tile range alternately
+    int64_t wide_no_tiles = 0;  // KMERS_PARAM_WIDE_NO_TILES: kmers of more than four words skip wide_tile_kernel.hpp
     int64_t arena_no_probe = 0;  // KMERS_PARAM_ARENA_NO_PROBE: kmers_arena_reserve skips the region calibration
     int64_t stamps_ptr = 0;  // diagnostic builds only (KMERS_PARAM_STAMPS_PTR)
     int n_cus = 256;                // multiProcessorCount

@@ -129,6 +129,7 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value) {
     else if (param == KMERS_PARAM_MAX_GRID) ctx->max_grid = value;
     else if (param == KMERS_PARAM_SUBTILES) ctx->subtiles = value;
     else if (param == KMERS_PARAM_BLOCK_THREADS) ctx->block_threads = value;
+    else if (param == KMERS_PARAM_WIDE_NO_TILES) ctx->wide_no_tiles = value;
     else if (param == KMERS_PARAM_ARENA_NO_PROBE) ctx->arena_no_probe = value;
     else if (param == KMERS_PARAM_SPLIT_ORDER) ctx->split_order = value;
     else if (param == KMERS_PARAM_STAMPS_PTR) ctx->stamps_ptr = value;

@@ -4,6 +4,7 @@
 
 #include "stream_launch.hpp"
 #include "wide_kernel.hpp"
+#include "wide_tile_kernel.hpp"
 
 using namespace kmers;
 
@@ -73,9 +74,14 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
 
     int rc;
     if (nw > 4) {
-        // kmers of more than four words: the run-time-width kernel (wide_kernel.hpp), one lane per kmer
-        dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+        // kmers of more than four words: at stride 1 the tile form (wide_tile_kernel.hpp: the symbols staged once in LDS, one
+        // lane per output word), else the run-time-width kernel that reads single symbols (wide_kernel.hpp), one lane per kmer
         const uint32_t nwu = (uint32_t)nw;
+        int tiled = ctx->wide_no_tiles ? -1 : (mode == MODE_FW ? launch_wide_tile<WMODE_FW>(ctx, a, seq->src_bits, dst_bits, nwu)
+                                                                : launch_wide_tile<WMODE_CANON>(ctx, a, seq->src_bits, dst_bits, nwu));
+        if (tiled > 0) return tiled;
+        dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+        if (tiled < 0) {
 #define WIDE(SB, DB)                                                                                         \
     do {                                                                                                     \
         if (mode == MODE_FW) hipLaunchKernelGGL((wide_kernel<SB, DB, MODE_FW>), grid, block, 0, ctx->stream, a, nwu);   \
@@ -83,6 +89,7 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     } while (0)
         KMERS_WIDE_DISPATCH(WIDE, seq->src_bits, dst_bits);
 #undef WIDE
+        }
         HIP_TRY(ctx, hipGetLastError());
         rc = KMERS_OK;
     } else if ((uint64_t)stride * (uint64_t)dst_bits > 64) {

@@ -20,9 +20,12 @@ def km():
     return kmers_jl_amd
 
 
-@pytest.fixture(scope="module")
-def ctx(km):
+@pytest.fixture(scope="module", params=[0, 1], ids=["tile-form", "lane-per-kmer"])
+def ctx(km, request):
+    """Both kernels behind every wide launch at stride 1: the tile form (wide_tile_kernel.hpp, the default) and the
+    one-lane-per-kmer kernel it falls back to (wide_kernel.hpp; KMERS_PARAM_WIDE_NO_TILES)."""
     c = km.Context(0)
+    c.set_param(km._capi.PARAM_WIDE_NO_TILES, request.param)
     yield c
     c.close()
 
@@ -387,3 +390,63 @@ def test_widths_beyond_the_oracle(km, ctx):
     assert ctx.lib.kmers_minimizers(ctx.handle, C.byref(seq), K, W, stride, 2, 1, vp(mz), cap.MEM_HOST, C.byref(res)) == 0
     want = [min(fw[i * stride:i * stride + W], key=lambda kmer: naive.fx_hash(list(kmer), 0)) for i in range(n)]
     assert [tuple(int(v) for v in r) for r in mz] == want
+
+
+def test_tile_form_at_every_tile_length(km, orc):
+    """wide_tile_kernel.hpp with tiles of 1, 7, 64, 333 and 5000 windows (KMERS_PARAM_TILE_KMERS), views that start anywhere
+    in a source word, every RecodingScheme: FwKmers + reverse complements, CanonicalKmers + fx_hash, both tuple layouts, the
+    XOR reducer and the MinHash sketch against the oracle; the first offending symbol in sequence order whichever tile sees it."""
+    cap = km._capi
+    ctx = km.Context(0)
+    rng = np.random.default_rng(16)
+    try:
+        for src, dst, K in WIDE:
+            N = (K * dst + 63) // 64
+            for tile in (1, 7, 64, 333, 5000):
+                ctx.set_param(cap.PARAM_TILE_KMERS, tile)
+                first = int(rng.choice([0, 1, 5, 15, 16, 31, 32, 33, 63, 64, 100]))
+                L = int(rng.choice([K, K + 1, K + 63, 1500, 4000])) if tile > 1 else int(rng.choice([K, K + 40]))
+                text = naive.random_text(rng, first + L, p_amb=0.05 if dst == 4 and src != 2 else 0.0)
+                words = source_words(text, src)
+                view = source_words(text[first:], src)
+                seq = cap.Seq(words.ctypes.data, L, first, 0, src, 0)
+                n = L - K + 1
+                res = cap.Result()
+                tag = (src, dst, K, tile, first, L)
+                efw, erv, _ = orc.fwrv(view, L, src, dst, K)
+                ek, eh, _ = orc.canonical(view, L, src, dst, K, seed=5)
+                fw, rv = np.zeros((n, N), np.uint64), np.zeros((n, N), np.uint64)
+                assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, dst, vp(fw), vp(rv), cap.MEM_HOST, C.byref(res)) == 0, ctx.last_error()
+                assert np.array_equal(fw, efw) and np.array_equal(rv, erv), tag
+                ck, hs = np.zeros((n, N), np.uint64), np.zeros(n, np.uint64)
+                assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, vp(ck), vp(hs), 5, cap.MEM_HOST, C.byref(res)) == 0
+                assert np.array_equal(ck, ek) and np.array_equal(hs, eh), tag
+                assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, None, vp(hs), 5, cap.MEM_HOST, C.byref(res)) == 0   # hashes only
+                assert np.array_equal(hs, eh), tag
+                t = np.zeros((n, 2 * N), np.uint64)
+                assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, dst, vp(t), None, cap.OUT_TUPLES, C.byref(res)) == 0
+                assert np.array_equal(t, np.concatenate([efw, erv], axis=1)), tag
+                t = np.zeros((n, N + 1), np.uint64)
+                assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, vp(t), None, 5, cap.OUT_TUPLES, C.byref(res)) == 0
+                assert np.array_equal(t, np.concatenate([ek, eh[:, None]], axis=1)), tag
+                val = C.c_uint64()
+                for canonical, e in ((0, efw), (1, ek)):
+                    assert ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, dst, canonical, C.byref(val), 0, C.byref(res)) == 0
+                    assert val.value == int(np.bitwise_xor.reduce(e[:, 0])), tag
+                out = np.zeros(40, np.uint64)
+                assert ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, dst, 5, 40, vp(out), cap.MEM_HOST, C.byref(res)) == 0
+                e = np.unique(eh)[:40]
+                assert res.n_out == len(e) and np.array_equal(out[:len(e)], e), tag
+            if dst == 2 and src in (4, 8):
+                ctx.set_param(cap.PARAM_TILE_KMERS, 64)
+                L = 3000
+                t = list(naive.random_text(rng, L))
+                t[2900], t[1234], t[1300] = "N", "R", "-"
+                words = source_words("".join(t), src)
+                seq = cap.Seq(words.ctypes.data, L, 0, 9, src, 0)    # index_origin 9: positions are reported behind it
+                out = np.zeros((L - K + 1, N), np.uint64)
+                res = cap.Result()
+                rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, vp(out), None, 0, cap.MEM_HOST, C.byref(res))
+                assert (rc, res.err_pos, res.err_enc) == (cap.E_ENCODE, 1235 + 9, ord("R") if src == 8 else 0b0101)
+    finally:
+        ctx.close()
