@@ -34,7 +34,7 @@ inline void clear(kmers_result *res) {
 
 // Common argument checks.  K, J errors mirror the constructors (FwKmers.jl:31-35,
 // SpacedKmers.jl:26-32); geometry limits are this library's.
-inline int check_common(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_bits, int flags, bool any_width = false) {
+inline int check_common(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_bits, int flags) {
     if (!ctx) return KMERS_E_BADARG;
     if (!seq) return fail(ctx, KMERS_E_BADARG, "seq is NULL");
     if (k < 1) return fail(ctx, KMERS_E_BADARG, "K must be at least 1");
@@ -49,9 +49,7 @@ inline int check_common(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride,
     if ((flags & KMERS_ASYNC) && !(flags & KMERS_MEM_DEVICE))
         return fail(ctx, KMERS_E_BADARG, "KMERS_ASYNC requires KMERS_MEM_DEVICE");
     if (dst_bits != 2 && dst_bits != 4) return fail(ctx, KMERS_E_BADARG, "dst_bits must be 2 or 4");
-    // the iterators take kmers of any width (wide_kernel.hpp); the other entry points kmers of one to four words
-    if (!any_width && n_coding_elements(k, dst_bits) > 4)
-        return fail(ctx, KMERS_E_UNSUPPORTED, "this entry point takes kmers of at most four words (K <= 128 two-bit, K <= 64 four-bit)");
+    // (kmers of any width: Kmer{A,K,N} has no bound on N, src/kmer.jl:97-111; what an entry point cannot hold it says itself)
     return KMERS_OK;
 }
 

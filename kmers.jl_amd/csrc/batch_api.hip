@@ -91,7 +91,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     clear(res);
     if (stride == 0 || stride >= 0xFFFFFFFFull) return fail(ctx, KMERS_E_BADARG, "J must be at least 1 (and below 2^32)");
     if (stride != 1 && mode != KMERS_BATCH_FW) return fail(ctx, KMERS_E_BADARG, "strided batches yield forward kmers (SpacedKmers)");
-    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP | INTERNAL_OUT_DEVICE), true)) {
+    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP | INTERNAL_OUT_DEVICE))) {
         if (res) res->status = rc;
         return rc;
     }
@@ -283,7 +283,7 @@ int kmers_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, 
 // record's hashes tile by tile and keeps its bottom-s (record_sketch_kernel.hpp).  No layout pass, no hash array.
 static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k, int dst_bits,
                                uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags, kmers_result *res) {
-    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP), true)) {
+    if (int rc = check_common(ctx, pool, k, 1, dst_bits, flags & ~(KMERS_ASYNC | KMERS_SPANS_DEVICE | KMERS_BATCH_SKIP))) {
         if (res) res->status = rc;
         return rc;
     }

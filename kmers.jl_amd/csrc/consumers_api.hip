@@ -104,7 +104,7 @@ extern "C" {
 int kmers_reduce_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, int canonical, uint64_t *out_value,
                      int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, seq, k, 1, dst_bits, flags & ~KMERS_ASYNC, true)) {
+    if (int rc = check_common(ctx, seq, k, 1, dst_bits, flags & ~KMERS_ASYNC)) {
         if (res) res->status = rc;
         return rc;
     }
@@ -130,7 +130,7 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
     clear(res);
     if (iter != KMERS_ITER_SPACED && iter != KMERS_ITER_UNAMBIGUOUS) return ctx ? fail(ctx, KMERS_E_BADARG, "unknown iterator") : KMERS_E_BADARG;
     if (iter == KMERS_ITER_UNAMBIGUOUS) dst_bits = 2;
-    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags & ~KMERS_ASYNC, true)) {
+    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags & ~KMERS_ASYNC)) {
         if (res) res->status = rc;
         return rc;
     }
@@ -178,7 +178,7 @@ int kmers_reduce_xor_iter(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_b
 static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bits, uint64_t seed, uint64_t s,
                         uint64_t *out_hashes, int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, seq, k, 1, dst_bits, flags & ~KMERS_ASYNC, true)) {
+    if (int rc = check_common(ctx, seq, k, 1, dst_bits, flags & ~KMERS_ASYNC)) {
         if (res) res->status = rc;
         return rc;
     }
@@ -405,7 +405,7 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
 int kmers_minimizers(kmers_ctx *ctx, const kmers_seq *seq, int k, int w, int stride, int dst_bits, int mode,
                      uint64_t *out_kmers, int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags, true)) {
+    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags)) {
         if (res) res->status = rc;
         return rc;
     }

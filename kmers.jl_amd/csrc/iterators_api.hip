@@ -25,7 +25,7 @@ void launch_gather(int n_words, dim3 grid, dim3 block, hipStream_t st, const Str
 int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_bits, int mode,
                uint64_t *out_a, uint64_t *out_b, bool b_is_hash, uint64_t seed, int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags, true)) {
+    if (int rc = check_common(ctx, seq, k, stride, dst_bits, flags)) {
         if (res) res->status = rc;
         return rc;
     }

@@ -243,7 +243,7 @@ extern "C" {
 int kmers_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uint64_t *out_kmers,
                       int64_t *out_starts, uint64_t capacity, int flags, kmers_result *res) {
     clear(res);
-    if (int rc = check_common(ctx, seq, k, stride, 2, flags, true)) {
+    if (int rc = check_common(ctx, seq, k, stride, 2, flags)) {
         if (res) res->status = rc;
         return rc;
     }
