@@ -1,4 +1,4 @@
-// wide_tile_kernel.hpp -- kmers of more than four words at stride 1 (FwKmers, FwRvIterator, CanonicalKmers + fx_hash and the
+// wide_tile_kernel.hpp -- kmers of more than four words (FwKmers, FwRvIterator, CanonicalKmers + fx_hash, SpacedKmers and the
 // fused XOR / MinHash consumers over them): the tile form of wide_kernel.hpp.  Kmer{A,K,N} has no bound on N
 // (src/kmer.jl:97-111); wide_kernel.hpp computes every word of every kmer from single symbols read from HBM (about 0.3 TB/s
 // of output: profiles/r03_wide.md), this kernel stages a tile's symbols ONCE in LDS, recoded into the kmer alphabet
@@ -12,7 +12,8 @@
 //   * canonical kmers: one lane per KMER first decides fw < rv (kmer.jl:176-178: the first differing word from the head,
 //     almost always the head itself), folds fx_hash over the chosen strand's words (kmer.jl:255-260) and leaves the decision
 //     in LDS for the word pass.
-// Strided iteration (SpacedKmers), minimizers and tiles that do not fit the LDS (K beyond ~200 000) stay on wide_kernel.hpp.
+// SpacedKmers are the same with windows J symbols apart.  Minimizers and kmers of which not even one fits the LDS (K beyond
+// ~240 000) stay on wide_kernel.hpp.
 #pragma once
 #include <algorithm>
 
@@ -27,8 +28,8 @@ constexpr uint32_t WIDE_TILE_LDS_BYTES = 60u * 1024u;  // budget of the staged s
 
 // 64-bit words of LDS stream a tile of `tile` windows needs (the stream starts at the source word that holds the tile's
 // first symbol; two spare words behind it: a chunk read may touch the word after its last symbol)
-inline uint32_t wide_tile_stream_words(uint32_t tile, uint32_t k, int src_bits, int dst_bits) {
-    const uint64_t symbols = (uint64_t)tile + k - 1u + (uint64_t)(64 / src_bits - 1);
+inline uint32_t wide_tile_stream_words(uint32_t tile, uint32_t k, uint32_t stride, int src_bits, int dst_bits) {
+    const uint64_t symbols = (uint64_t)(tile - 1u) * stride + k + (uint64_t)(64 / src_bits - 1);
     const uint64_t src_words = (symbols * (uint64_t)src_bits + 63u) / 64u + 1u;
     return (uint32_t)((src_words * (uint64_t)dst_bits + (uint64_t)src_bits - 1u) / (uint64_t)src_bits + 2u);
 }
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, co
     uint8_t *const take = reinterpret_cast<uint8_t *>(wl + stream_words);  // per window of the tile: 1 = the forward strand is the canonical one
     constexpr uint32_t SPW = 64u / (uint32_t)DST;                          // symbols per kmer word
     const uint32_t tid = threadIdx.x;
-    const uint32_t k = a.k, T = a.tile_kmers;
+    const uint32_t k = a.k, T = a.tile_kmers, J = a.stride;  // window gl of a tile starts J * gl symbols behind the tile's first
     const uint32_t text = (SRC_BITS == 8 && DST == 2 && a.ascii_table <= 1u) ? 1u + a.ascii_table : 0u;
     if constexpr (SRC_BITS == 8) {
         if (!text) {
@@ -55,14 +56,15 @@ __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, co
     const uint64_t g0 = tile_id * T;
     const uint32_t nk = a.n_kmers - g0 < (uint64_t)T ? (uint32_t)(a.n_kmers - g0) : T;
     // ---- stage: every source word the tile's windows touch, recoded, at its own word-aligned place in the stream
-    const uint64_t bit0 = a.first_bit + g0 * (uint64_t)SRC_BITS;
+    const uint64_t bit0 = a.first_bit + g0 * (uint64_t)J * (uint64_t)SRC_BITS;
     const uint64_t ws = bit0 >> 6;
     const uint32_t off0 = (uint32_t)(bit0 & 63u) / (uint32_t)SRC_BITS;  // symbols of the first staged word in front of the tile
-    const uint32_t n_src = (uint32_t)(((bit0 + (uint64_t)(nk + k - 1u) * SRC_BITS + 63u) >> 6) - ws);
+    const uint32_t n_src = (uint32_t)(((bit0 + ((uint64_t)(nk - 1u) * J + k) * SRC_BITS + 63u) >> 6) - ws);
     for (uint32_t j = tid; j < n_src; j += BLOCK) {
         const uint64_t x = a.src[ws + j];
         const uint64_t f = stage_word<SRC_BITS, DST>(wl, j, x, lut, text);
-        if (f) report_bad_symbols<SRC_BITS, true>(a.err_slot, a.first_bit, a.inspect_end, 1u, k, ws + j, f, x, a.err_origin);
+        // (SpacedKmers with J >= K never inspects the symbols between two windows, SpacedKmers.jl:133-134: report_bad_symbols drops them)
+        if (f) report_bad_symbols<SRC_BITS, false>(a.err_slot, a.first_bit, a.inspect_end, J, k, ws + j, f, x, a.err_origin);
     }
     block_sync();
 
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, co
     };
     const uint32_t c_head = k - (n_words - 1u) * SPW;  // symbols in the head word (kmer.jl:128: the unused bits are its top bits)
     // word w (0 = head) of window gl's forward kmer, or of its reverse complement
-    auto word = [&](uint32_t gl, uint32_t w, bool rc) -> uint64_t {
+    auto word = [&](uint32_t window, uint32_t w, bool rc) -> uint64_t {
+        const uint32_t gl = window * J;  // the window's first symbol
         const uint32_t c = w == 0u ? c_head : SPW;
         const uint32_t p_lo = w == 0u ? 0u : k - (n_words - w) * SPW;  // the window's symbol in the word's top position
         if (!rc) return rev_symbols<DST>(chunk(gl + p_lo, c)) >> (64u - c * (uint32_t)DST);
@@ -157,11 +160,13 @@ __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, co
     }
 }
 
-// Launch of the tile form; returns -1 (nothing launched) where it does not apply -- strided iteration, or a kmer so long that
-// not even one window fits the LDS budget -- and the caller goes on to wide_kernel.hpp.
+// Launch of the tile form; returns -1 (nothing launched) where it does not apply -- a kmer so long that not even one window
+// fits the LDS budget -- and the caller goes on to wide_kernel.hpp.  Strided iteration (SpacedKmers) stages the symbols between
+// its windows too: with J far above K the tiles shrink to the windows that fit (down to one), which is still one coalesced read
+// of the stretch instead of K single-symbol reads per window.
 template <int WMODE>
 int launch_wide_tile(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, uint32_t n_words) {
-    if (a.stride != 1u || a.n_kmers == 0) return -1;
+    if (a.n_kmers == 0) return -1;
     // FW / CANON stream N words per window: 16 KiB per output array and workgroup, like the stream kernels; the consumers
     // store nothing: long tiles
     const bool streams = WMODE == WMODE_FW || WMODE == WMODE_CANON;
@@ -171,14 +176,14 @@ int launch_wide_tile(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, 
                   : WMODE == WMODE_CANON ? std::max<uint32_t>((uint32_t)BLOCK, (2048u / n_words + BLOCK - 1u) / BLOCK * BLOCK) : 2048u;
     if (ctx->tile_kmers > 0) tile = (uint32_t)std::min<int64_t>(ctx->tile_kmers, 1 << 16);  // tests, tuning
     tile = (uint32_t)std::min<uint64_t>(tile, a.n_kmers);
-    auto lds_bytes = [&](uint32_t t) { return (size_t)wide_tile_stream_words(t, a.k, src_bits, dst_bits) * 8u + ((t + 7u) & ~7u); };
+    auto lds_bytes = [&](uint32_t t) { return (size_t)wide_tile_stream_words(t, a.k, a.stride, src_bits, dst_bits) * 8u + ((t + 7u) & ~7u); };
     while (tile > 1u && lds_bytes(tile) > WIDE_TILE_LDS_BYTES) tile /= 2u;
     if (lds_bytes(tile) > WIDE_TILE_LDS_BYTES) return -1;
     const uint64_t n_tiles = (a.n_kmers + tile - 1u) / tile;
     if (n_tiles >= (1ull << 31)) return -1;
     a.tile_kmers = tile;
     a.n_tiles = n_tiles;
-    const uint32_t sw = wide_tile_stream_words(tile, a.k, src_bits, dst_bits);
+    const uint32_t sw = wide_tile_stream_words(tile, a.k, a.stride, src_bits, dst_bits);
     const size_t dyn = lds_bytes(tile);
     const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (streams ? n_tiles : (uint64_t)ctx->n_cus * 8u);
     dim3 grid((unsigned)std::min<uint64_t>(n_tiles, resident)), block(BLOCK);

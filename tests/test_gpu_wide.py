@@ -437,6 +437,13 @@ def test_tile_form_at_every_tile_length(km, orc):
                 assert ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, dst, 5, 40, vp(out), cap.MEM_HOST, C.byref(res)) == 0
                 e = np.unique(eh)[:40]
                 assert res.n_out == len(e) and np.array_equal(out[:len(e)], e), tag
+                for J in (2, 33, K + 7):       # SpacedKmers: windows J symbols apart in the same staged stretch
+                    es, _ = orc.spaced(view, L, src, dst, K, J)
+                    sp = np.zeros((len(es), N), np.uint64)
+                    assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, dst, vp(sp), cap.MEM_HOST, C.byref(res)) == 0, ctx.last_error()
+                    assert res.n_out == len(es) and np.array_equal(sp, es), tag + (J,)
+                    assert ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), K, dst, cap.ITER_SPACED, J, C.byref(val), 0, C.byref(res)) == 0
+                    assert val.value == int(np.bitwise_xor.reduce(es[:, 0])), tag + (J,)
             if dst == 2 and src in (4, 8):
                 ctx.set_param(cap.PARAM_TILE_KMERS, 64)
                 L = 3000
@@ -448,5 +455,23 @@ def test_tile_form_at_every_tile_length(km, orc):
                 res = cap.Result()
                 rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, vp(out), None, 0, cap.MEM_HOST, C.byref(res))
                 assert (rc, res.err_pos, res.err_enc) == (cap.E_ENCODE, 1235 + 9, ord("R") if src == 8 else 0b0101)
+                # SpacedKmers{K, K + 100}: windows [1, K], [K + 101, 2K + 100], ...; a symbol between two windows is never
+                # inspected (SpacedKmers.jl:133-134), the first one inside a window is the error
+                J = K + 100
+                t = list(naive.random_text(rng, L))
+                t[K + 49], t[J + 5], t[J + 2] = "N", "N", "S"       # 1-based K + 50: in the gap; J + 6 and J + 3: in the second window
+                words = source_words("".join(t), src)
+                seq = cap.Seq(words.ctypes.data, L, 0, 0, src, 0)
+                m = (L - K) // J + 1
+                rc = ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, dst, vp(out), cap.MEM_HOST, C.byref(res))
+                _, eres = orc.spaced(words, L, src, dst, K, J)
+                assert (rc, res.err_pos, res.err_enc) == (cap.E_ENCODE, J + 3, ord("S") if src == 8 else 0b0110) == (cap.E_ENCODE, eres.err_pos, eres.err_enc)
+                t[J + 5], t[J + 2] = "A", "C"
+                words = source_words("".join(t), src)
+                seq = cap.Seq(words.ctypes.data, L, 0, 0, src, 0)
+                es, eres = orc.spaced(words, L, src, dst, K, J)
+                assert eres.status == 0
+                assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, dst, vp(out), cap.MEM_HOST, C.byref(res)) == 0
+                assert res.n_out == m and np.array_equal(out[:m], es)
     finally:
         ctx.close()
