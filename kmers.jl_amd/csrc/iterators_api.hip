@@ -92,8 +92,13 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
         }
         HIP_TRY(ctx, hipGetLastError());
         rc = KMERS_OK;
+    } else if ((uint64_t)stride * (uint64_t)dst_bits > 64 && !ctx->wide_no_tiles && mode == MODE_FW &&
+               (rc = launch_wide_tile<WMODE_FW>(ctx, a, seq->src_bits, dst_bits, (uint32_t)nw)) >= 0) {
+        // windows further apart than a tile of the stream kernel stages (SpacedKmers{A,K,K} with K > 32 ...): the tile form of
+        // the run-time-width kernel, which stages whole stretches and cuts the windows out of LDS (wide_tile_kernel.hpp)
+        if (rc) return rc;
     } else if ((uint64_t)stride * (uint64_t)dst_bits > 64) {
-        // gather path (forward kmers only: kmers_spaced); a tile would stage mostly unused symbols
+        // gather path (forward kmers only: kmers_spaced): one lane per kmer, symbol by symbol
         dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
         if (seq->src_bits == 8 && dst_bits == 2) launch_gather<8, 2>(nw, grid, block, ctx->stream, a);
         else if (seq->src_bits == 8) launch_gather<8, 4>(nw, grid, block, ctx->stream, a);

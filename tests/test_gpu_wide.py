@@ -161,6 +161,10 @@ def test_fused_reducers_over_wide_kmers(km, ctx, orc):
         es, _ = orc.spaced(words, L, src, dst, K, J)
         assert ctx.lib.kmers_reduce_xor_iter(ctx.handle, C.byref(seq), K, dst, cap.ITER_SPACED, J, C.byref(val), 0, C.byref(res)) == 0
         assert val.value == int(np.bitwise_xor.reduce(es[:, 0])), (src, dst, K, J)
+        # ... and materialised: kmers_spaced (the tile form of the run-time-width kernel, or the symbol-by-symbol gather kernel)
+        sp = np.zeros(es.shape, np.uint64)
+        assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, dst, vp(sp), cap.MEM_HOST, C.byref(res)) == 0, ctx.last_error()
+        assert res.n_out == len(es) and np.array_equal(sp, es), (src, dst, K, J)
     # strictness is the iterator's: the first symbol the 2-bit alphabet cannot hold, in sequence order; with J >= K a symbol
     # between two windows is never inspected (SpacedKmers.jl:133-134)
     K, L = 130, 3000
