@@ -35,10 +35,14 @@ inline uint32_t wide_tile_stream_words(uint32_t tile, uint32_t k, uint32_t strid
 }
 
 template <int SRC_BITS, int DST, int WMODE>
-__global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, const uint32_t n_words, const uint32_t stream_words) {
+__global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, const uint32_t n_words, const uint32_t stream_words,
+                                                           const uint32_t cw_pitch) {
     extern __shared__ uint64_t wl[];
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     uint8_t *const take = reinterpret_cast<uint8_t *>(wl + stream_words);  // per window of the tile: 1 = the forward strand is the canonical one
+    // CANON with hashes, tiles whose words fit the LDS (cw_pitch != 0: words per window, odd): the word pass leaves the canonical
+    // kmers' words here and the fx_hash fold reads them back, instead of the fold computing every word a second time
+    uint64_t *const cw = reinterpret_cast<uint64_t *>(take + ((a.tile_kmers + 7u) & ~7u));
     constexpr uint32_t SPW = 64u / (uint32_t)DST;                          // symbols per kmer word
     const uint32_t tid = threadIdx.x;
     const uint32_t k = a.k, T = a.tile_kmers, J = a.stride;  // window gl of a tile starts J * gl symbols behind the tile's first
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, co
     if constexpr (WMODE != WMODE_FW) {
         // ---- one lane per kmer: the canonical strand, its hash, the consumers
         const bool canonical = WMODE != WMODE_XOR || a.xor_canonical != 0;
-        const bool want_hash = WMODE == WMODE_SKETCH || (WMODE == WMODE_CANON && (a.out_b || a.tuples));
+        const bool want_hash = WMODE == WMODE_SKETCH || (WMODE == WMODE_CANON && (a.out_b || a.tuples) && cw_pitch == 0u);
         uint64_t threshold = 0;
         if constexpr (WMODE == WMODE_SKETCH)
             threshold = a.threshold_ptr ? __hip_atomic_load(a.threshold_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.threshold;
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, co
         }
         block_sync();  // the decisions are in LDS / every lane is done with the staged stream
         if constexpr (WMODE != WMODE_CANON) continue;
-        if (!a.out_a) continue;
+        if (!a.out_a && cw_pitch == 0u) continue;
     }
 
     // ---- one lane per OUTPUT WORD: consecutive lanes write consecutive words of the array
@@ -142,13 +146,27 @@ __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, co
                 if (a.out_b) a.out_b[at] = word(gl, w, true);
             }
         } else {
-            a.out_a[at] = word(gl, w, take[gl] == 0u);
+            const uint64_t v = word(gl, w, take[gl] == 0u);
+            if (a.out_a) a.out_a[at] = v;
+            if (cw_pitch) cw[gl * cw_pitch + w] = v;
         }
         gl += step_g;
         w += step_w;
         if (w >= per) {
             w -= per;
             ++gl;
+        }
+    }
+    if constexpr (WMODE == WMODE_CANON) {
+        if (cw_pitch) {
+            // ---- fx_hash(canonical kmer, seed): the fold over the words the word pass left in LDS (kmer.jl:255-260), one lane per kmer
+            block_sync();
+            for (uint32_t g = tid; g < nk; g += BLOCK) {
+                uint64_t h = a.seed;
+                for (uint32_t j = 0; j < n_words; ++j) h = fx_step(h, cw[g * cw_pitch + j]);
+                if (a.tuples) a.out_a[(g0 + g) * (n_words + 1u) + n_words] = h;
+                else a.out_b[g0 + g] = h;
+            }
         }
     }
     if (tile_id + gridDim.x < a.n_tiles) block_sync();  // the next tile restages the stream
@@ -177,6 +195,7 @@ int launch_wide_tile(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, 
     if (ctx->tile_kmers > 0) tile = (uint32_t)std::min<int64_t>(ctx->tile_kmers, 1 << 16);  // tests, tuning
     tile = (uint32_t)std::min<uint64_t>(tile, a.n_kmers);
     auto lds_bytes = [&](uint32_t t) { return (size_t)wide_tile_stream_words(t, a.k, a.stride, src_bits, dst_bits) * 8u + ((t + 7u) & ~7u); };
+    const uint32_t word_pitch = n_words | 1u;  // (odd: the fold's lanes read LDS words `pitch` apart)
     while (tile > 1u && lds_bytes(tile) > WIDE_TILE_LDS_BYTES) tile /= 2u;
     if (lds_bytes(tile) > WIDE_TILE_LDS_BYTES) return -1;
     const uint64_t n_tiles = (a.n_kmers + tile - 1u) / tile;
@@ -184,7 +203,12 @@ int launch_wide_tile(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, 
     a.tile_kmers = tile;
     a.n_tiles = n_tiles;
     const uint32_t sw = wide_tile_stream_words(tile, a.k, a.stride, src_bits, dst_bits);
-    const size_t dyn = lds_bytes(tile);
+    size_t dyn = lds_bytes(tile);
+    uint32_t cw_pitch = 0;  // CANON with hashes: the tile's canonical words staged in LDS for the fold, if they fit
+    if (WMODE == WMODE_CANON && (a.out_b || a.tuples) && dyn + (size_t)tile * word_pitch * 8u <= WIDE_TILE_LDS_BYTES) {
+        cw_pitch = word_pitch;
+        dyn += (size_t)tile * word_pitch * 8u;
+    }
     const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (streams ? n_tiles : (uint64_t)ctx->n_cus * 8u);
     dim3 grid((unsigned)std::min<uint64_t>(n_tiles, resident)), block(BLOCK);
 #define WIDET(SB, DB)                                                                                                              \
@@ -192,7 +216,7 @@ int launch_wide_tile(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, 
         if (dyn > 48u * 1024u)                                                                                                     \
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(wide_tile_kernel<SB, DB, WMODE>),                      \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_TILE_LDS_BYTES));               \
-        hipLaunchKernelGGL((wide_tile_kernel<SB, DB, WMODE>), grid, block, dyn, ctx->stream, a, n_words, sw);                     \
+        hipLaunchKernelGGL((wide_tile_kernel<SB, DB, WMODE>), grid, block, dyn, ctx->stream, a, n_words, sw, cw_pitch);           \
     } while (0)
     if (src_bits == 8 && dst_bits == 2) WIDET(8, 2);
     else if (src_bits == 8) WIDET(8, 4);
