@@ -118,7 +118,8 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
                                          * arrays; results are identical either way) */
 #define KMERS_PARAM_ARENA_NO_PROBE 8   /* 1: kmers_arena_reserve does not measure the region map of its block (best-fit placement only) */
 #define KMERS_PARAM_BLOCK_THREADS 10   /* threads per workgroup of the tile kernels: 64, 128 or 256 (0: chosen per output shape) */
-#define KMERS_PARAM_WIDE_NO_TILES 11   /* 1: kmers of more than four words always on the one-lane-per-kmer kernel (A/B, tests) */
+#define KMERS_PARAM_WIDE_NO_TILES 11   /* A/B, tests.  1: kmers of more than four words always on the one-lane-per-kmer kernel; 2: the
+                                        * run-time-width tile form also for kmers of one to four words (it loses there: profiles/r03_wide.md) */
 #define KMERS_PARAM_SUBTILES 7         /* strided tile kernels (kmers_spaced, kmers_minimizers): consecutive tiles per workgroup, the next one's source words in flight */
 int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
 

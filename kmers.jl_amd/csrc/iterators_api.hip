@@ -73,7 +73,12 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
     a.tuples = tuples ? 1u : 0u;
 
     int rc;
-    if (nw > 4) {
+    if (nw <= 4 && ctx->wide_no_tiles == 2 && !(flags & KMERS_OUT_TUPLES) &&
+        (rc = mode == MODE_FW ? launch_wide_tile<WMODE_FW>(ctx, a, seq->src_bits, dst_bits, (uint32_t)nw)
+                              : launch_wide_tile<WMODE_CANON>(ctx, a, seq->src_bits, dst_bits, (uint32_t)nw)) >= 0) {
+        // A/B only (KMERS_PARAM_WIDE_NO_TILES = 2): kmers of one to four words through the run-time-width tile form
+        if (rc) return rc;
+    } else if (nw > 4) {
         // kmers of more than four words: at stride 1 the tile form (wide_tile_kernel.hpp: the symbols staged once in LDS, one
         // lane per output word), else the run-time-width kernel that reads single symbols (wide_kernel.hpp), one lane per kmer
         const uint32_t nwu = (uint32_t)nw;

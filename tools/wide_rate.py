@@ -15,9 +15,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--bases", type=int, default=100_000_000)
 ap.add_argument("--ks", default="128,129,150,256,1000")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--force-tiles", type=int, default=0, help="KMERS_PARAM_WIDE_NO_TILES value (2: the tile form for kmers of one to four words too)")
 args = ap.parse_args()
 cap = km._capi
 ctx = km.Context(0)
+ctx.set_param(11, args.force_tiles)
 dev = torch.device("cuda", 0)
 stream = torch.cuda.ExternalStream(ctx.lib.kmers_ctx_stream(ctx.handle), device=dev)
 L = args.bases
