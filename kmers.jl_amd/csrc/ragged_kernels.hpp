@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
 }
 
 // Kmers of more than four words (Kmer{A,K,N} has no bound on N): one lane per element, the width a run-time argument
-// (wide_kernel.hpp), the record found by a search of the global offsets, every symbol read from the stream in HBM.
+// (wide_kernel.hpp), the record found by a search of the global offsets, every word cut out of the stream in HBM.
 // Same results and the same error rule as ragged_kernel; an edge path, not tuned.
 template <int DST, int MODE>
 __global__ __launch_bounds__(256) void ragged_wide_kernel(const RaggedArgs a, const uint32_t n_words) {
@@ -577,20 +577,17 @@ __global__ __launch_bounds__(256) void ragged_wide_kernel(const RaggedArgs a, co
         if (bad && !a.skip) atomicMin(a.err_slot, (unsigned long long)g);
     }
     const bool masked = bad && a.skip;  // the all-ones sentinel
-    auto sym = [&](uint64_t i) -> uint64_t {
-        const uint64_t bit = (p + i) * (uint64_t)DST;
-        return (a.stream[bit >> 6] >> (bit & 63u)) & ((1ull << DST) - 1ull);
-    };
+    auto load = [&](uint64_t q) -> uint64_t { return a.stream[q]; };  // (the stream is the kmer alphabet's symbols already)
     if constexpr (MODE == MODE_FW) {
         for (uint32_t w = 0; w < n_words; ++w) {
-            if (a.out_a) a.out_a[g * n_words + w] = masked ? ~0ull : wide_word_of<DST>(sym, a.k, n_words, w, false);
-            if (a.out_b) a.out_b[g * n_words + w] = masked ? ~0ull : wide_word_of<DST>(sym, a.k, n_words, w, true);
+            if (a.out_a) a.out_a[g * n_words + w] = masked ? ~0ull : wide_word_from_stream<DST>(load, p, a.k, n_words, w, false);
+            if (a.out_b) a.out_b[g * n_words + w] = masked ? ~0ull : wide_word_from_stream<DST>(load, p, a.k, n_words, w, true);
         }
     } else {
-        const bool take_fw = wide_forward_is_canonical_of<DST>(sym, a.k, n_words);
+        const bool take_fw = wide_forward_is_canonical_from_stream<DST>(load, p, a.k, n_words);
         uint64_t h = a.seed;
         for (uint32_t w = 0; w < n_words; ++w) {
-            const uint64_t c = wide_word_of<DST>(sym, a.k, n_words, w, !take_fw);
+            const uint64_t c = wide_word_from_stream<DST>(load, p, a.k, n_words, w, !take_fw);
             if (a.out_a) a.out_a[g * n_words + w] = masked ? ~0ull : c;
             h = fx_step(h, c);
         }

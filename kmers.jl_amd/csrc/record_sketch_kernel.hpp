@@ -105,13 +105,10 @@ __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchAr
                                     flagged = any_flag_in([&](uint32_t i) { return flags[fq + i]; }, (uint32_t)(pj & 63u), k);
                                 }
                                 if (flagged && !a.skip) atomicMin(a.err_slot, (unsigned long long)((r << 32) | (base + e + j)));
-                                auto sym = [&](uint64_t i) -> uint64_t {
-                                    const uint64_t b = (pj + i) * (uint64_t)DST;
-                                    return (a.stream[b >> 6] >> (b & 63u)) & ((1ull << DST) - 1ull);
-                                };
-                                const bool take_fw = wide_forward_is_canonical_of<DST>(sym, k, a.n_words);  // CanonicalKmers.jl:220-225
+                                auto load = [&](uint64_t q) -> uint64_t { return a.stream[q]; };
+                                const bool take_fw = wide_forward_is_canonical_from_stream<DST>(load, pj, k, a.n_words);  // CanonicalKmers.jl:220-225
                                 uint64_t h = a.seed;
-                                for (uint32_t w = 0; w < a.n_words; ++w) h = fx_step(h, wide_word_of<DST>(sym, k, a.n_words, w, !take_fw));
+                                for (uint32_t w = 0; w < a.n_words; ++w) h = fx_step(h, wide_word_from_stream<DST>(load, pj, k, a.n_words, w, !take_fw));
                                 hv[j] = h;
                                 keep[j] = !flagged;
                             }

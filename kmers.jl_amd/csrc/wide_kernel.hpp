@@ -71,6 +71,34 @@ __device__ __forceinline__ bool wide_forward_is_canonical_of(Sym sym, uint32_t k
     return false;
 }
 
+// The same two words cut out of a stream that already holds the kmer alphabet's symbols, DST bits each, little-endian
+// (symbol j at bits DST * j: a recoded pool in HBM, a staged tile in LDS): word w of the forward kmer of the window that
+// starts at stream symbol p is 64 / DST consecutive symbols reversed, of its reverse complement the complement of the mirrored
+// stretch -- two stream words and a funnel shift instead of 64 / DST single symbols.  load(q) = stream word q; the word behind
+// a chunk's last symbol is never read.
+template <int DST, class Load>
+__device__ __forceinline__ uint64_t wide_word_from_stream(Load load, uint64_t p, uint32_t k, uint32_t n_words, uint32_t w, bool rc) {
+    constexpr uint32_t SPW = 64u / (uint32_t)DST;
+    const uint32_t c = w == 0u ? k - (n_words - 1u) * SPW : SPW;    // symbols in the word (the head word holds fewer, kmer.jl:128)
+    const uint32_t p_lo = w == 0u ? 0u : k - (n_words - w) * SPW;   // the window's symbol in the word's top position
+    const uint64_t b = (p + (rc ? k - p_lo - c : p_lo)) * (uint64_t)DST, q = b >> 6;
+    const uint32_t sh = (uint32_t)(b & 63u);
+    uint64_t v = funnel64(load(q), sh + c * (uint32_t)DST > 64u ? load(q + 1u) : 0ull, sh);
+    const uint64_t keep = c < SPW ? (1ull << (c * (uint32_t)DST)) - 1ull : ~0ull;
+    v &= keep;
+    if (!rc) return rev_symbols<DST>(v) >> (64u - c * (uint32_t)DST);
+    return comp_symbols<DST>(v) & keep;
+}
+
+template <int DST, class Load>
+__device__ __forceinline__ bool wide_forward_is_canonical_from_stream(Load load, uint64_t p, uint32_t k, uint32_t n_words) {
+    for (uint32_t w = 0; w < n_words; ++w) {
+        const uint64_t f = wide_word_from_stream<DST>(load, p, k, n_words, w, false), r = wide_word_from_stream<DST>(load, p, k, n_words, w, true);
+        if (f != r) return f < r;
+    }
+    return false;
+}
+
 // the same over a sequence view: the window that starts at symbol `start`
 template <int SRC_BITS, int DST>
 __device__ __forceinline__ uint64_t wide_word(const StreamArgs &a, uint64_t start, uint32_t n_words, uint32_t w, bool rc) {
