@@ -113,9 +113,10 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 #define KMERS_PARAM_SKETCH_HOST_ONLY 4 /* kmers_minhash: 1 = use the host-feedback path even for small sketches (tests) */
 #define KMERS_PARAM_BATCH_PASSES 5     /* kmers_batch: elements per workgroup tile = 1024 * value (1..8); 0 = chosen from the batch size */
 #define KMERS_PARAM_SKETCH_BATCH_LDS 6 /* kmers_minhash_batch: candidate values per workgroup (2048 / 4096 / 8192); 0 = chosen per call */
-#define KMERS_PARAM_SPLIT_ORDER 9      /* 1: the tile kernels visit the two halves of their tile range alternately (two write windows per output
-                                         * array; +1 % for one output array that straddles two region classes of HBM, -1..4 % for two
-                                         * arrays; results are identical either way) */
+#define KMERS_PARAM_SPLIT_ORDER 9      /* the tile kernels visit the two halves of their tile range alternately (two write windows per output
+                                         * array).  0: when the launch has ONE output array and the arena's map says it lies across a class
+                                         * boundary (kmers_dev_alloc_role(KMERS_ALLOC_LONE_OUTPUT)): +6 % there; 1: always; -1: never.
+                                         * Results are identical either way. */
 #define KMERS_PARAM_ARENA_NO_PROBE 8   /* 1: kmers_arena_reserve does not measure the region map of its block (best-fit placement only) */
 #define KMERS_PARAM_BLOCK_THREADS 10   /* threads per workgroup of the tile kernels: 64, 128 or 256 (0: chosen per output shape) */
 #define KMERS_PARAM_WIDE_NO_TILES 11   /* A/B, tests.  1: kmers of more than four words always on the one-lane-per-kmer kernel; 2: the
@@ -127,6 +128,15 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
  * For hosts without a HIP binding of their own (the reference allocates its outputs itself: `collect` makes one Vector per
  * call).  kmers_dev_free first waits for the context's stream. */
 int kmers_dev_alloc(kmers_ctx *ctx, size_t bytes, void **out);
+/* The same with a word about what the block is for, which the arena (below) uses for its placement; without an arena, or when
+ * the preferred place is taken, exactly kmers_dev_alloc.
+ *   KMERS_ALLOC_DEFAULT      anything: inputs, the arrays of a launch with two outputs (placed in different region classes)
+ *   KMERS_ALLOC_LONE_OUTPUT  the ONLY output array of the launches that fill it (collect(CanonicalKmers) without hashes,
+ *                            FwKmers, SpacedKmers, a tuple array): placed ACROSS a class boundary, and a launch that finds its
+ *                            one output there writes it through two windows, one per class (C3: 0.81 -> 0.87 of 8 TB/s). */
+#define KMERS_ALLOC_DEFAULT 0
+#define KMERS_ALLOC_LONE_OUTPUT 1
+int kmers_dev_alloc_role(kmers_ctx *ctx, size_t bytes, int role, void **out);
 int kmers_dev_free(kmers_ctx *ctx, void *p);
 int kmers_memcpy_h2d(kmers_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);

@@ -488,11 +488,16 @@ function arena_release!(ctx::Context = context())
     rc == OK || error("kmers_arena_release: status $rc: $(last_error(ctx))")
     return nothing
 end
-"`n` elements of `T` in HBM (a range of the arena when one is reserved and has room, else a plain allocation)."
-function device_alloc(ctx::Context, ::Type{T}, n::Integer) where {T}
+"""
+`n` elements of `T` in HBM (a range of the arena when one is reserved and has room, else a plain allocation).
+`lone_output = true`: the ONLY output array of the launches that fill it (`collect` of an iterator without hashes / reverse
+complements): the arena places it across a class boundary of HBM and such a launch writes it through two windows
+(`kmers_dev_alloc_role`, `KMERS_ALLOC_LONE_OUTPUT`).
+"""
+function device_alloc(ctx::Context, ::Type{T}, n::Integer; lone_output::Bool = false) where {T}
     p = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = @ccall LIB.kmers_dev_alloc(ctx.handle::Ptr{Cvoid}, (n * sizeof(T))::Csize_t, p::Ptr{Ptr{Cvoid}})::Cint
-    rc == OK || error("kmers_dev_alloc: status $rc: $(last_error(ctx))")
+    rc = @ccall LIB.kmers_dev_alloc_role(ctx.handle::Ptr{Cvoid}, (n * sizeof(T))::Csize_t, Cint(lone_output)::Cint, p::Ptr{Ptr{Cvoid}})::Cint
+    rc == OK || error("kmers_dev_alloc_role: status $rc: $(last_error(ctx))")
     return Ptr{T}(p[])
 end
 device_free(ctx::Context, p::Ptr) = (@ccall LIB.kmers_dev_free(ctx.handle::Ptr{Cvoid}, p::Ptr{Cvoid})::Cint; nothing)

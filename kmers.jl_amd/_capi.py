@@ -21,6 +21,7 @@ BATCH_SKIP = 16
  OP_FROM_INTEGER) = range(9)
 PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY, PARAM_BATCH_PASSES, PARAM_SKETCH_BATCH_LDS, PARAM_SUBTILES, PARAM_ARENA_NO_PROBE, PARAM_SPLIT_ORDER, PARAM_BLOCK_THREADS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 PARAM_WIDE_NO_TILES = 11
+ALLOC_DEFAULT, ALLOC_LONE_OUTPUT = 0, 1
 
 STATUS_NAMES = {OK: "KMERS_OK", E_ENCODE: "KMERS_E_ENCODE", E_BADARG: "KMERS_E_BADARG",
                 E_HIP: "KMERS_E_HIP", E_NOMEM: "KMERS_E_NOMEM",
@@ -60,6 +61,7 @@ SYMBOLS = {
     "kmers_sync": (C.c_int, [_P, _R]),
     "kmers_ctx_set_param": (C.c_int, [_P, C.c_int, C.c_int64]),
     "kmers_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "kmers_dev_alloc_role": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(_P)]),
     "kmers_dev_free": (C.c_int, [_P, _P]),
     "kmers_arena_reserve": (C.c_int, [_P, C.c_size_t]),
     "kmers_arena_release": (C.c_int, [_P]),

@@ -56,6 +56,23 @@ inline bool kmers_arena_spread(const kmers_arena &a, const void *p, const void *
     return sum / 8.f >= 0.95f * a.best_pair_rate;
 }
 
+// true iff the array of `bytes` bytes at p lies in the arena ACROSS a class boundary, so that its two halves -- the two write
+// windows of a split-order launch (stream_kernel.hpp: even workgroups walk the first half of the tiles, odd ones the second)
+// -- are written side by side at a measured rate within 5 % of the block's best pair (four sample points per half).  A launch
+// with ONE output array is then worth writing through two windows (profiles/r03_tuning.md section 5).
+inline bool kmers_arena_straddles(const kmers_arena &a, const void *p, size_t bytes) {
+    if (a.run_start.size() < 2 || !p || bytes < 16) return false;
+    const char *cp = static_cast<const char *>(p);
+    if (cp < a.base || cp + bytes > a.base + a.bytes) return false;
+    const size_t k = a.run_start.size(), off = (size_t)(cp - a.base), half = bytes / 2;
+    float sum = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        const size_t t = (size_t)((2 * i + 1) * (double)half / 8.0);
+        sum += a.pair_rate[kmers_arena_run_of(a, off + t) * k + kmers_arena_run_of(a, off + half + t)];
+    }
+    return sum / 4.f >= 0.95f * a.best_pair_rate;
+}
+
 namespace kmers {
 namespace arena {
 
@@ -83,9 +100,9 @@ inline void arena_commit(kmers_arena &a, std::map<size_t, size_t>::iterator rang
 // whose MEASURED two-stream rate beside the runs of the live blocks is highest on average wins (the previous allocation counts
 // double); ties go to the tightest stretch.  Without a map,
 // or when no stretch fits (a request larger than any run): best fit over the free ranges.
-// (Measured and not kept, profiles/r03_alloc.md: centring every large block on a class boundary and letting the tile kernels
-// write each array through two windows half an array apart -- KMERS_PARAM_SPLIT_ORDER -- gains a single-output launch 1 %
-// and costs a two-output launch 1-4 % against the two arrays in two different classes.)
+// (Centring EVERY large block on a class boundary and writing every array through two windows costs a two-output launch 1-4 %
+// against its two arrays in two different classes, profiles/r03_alloc.md; the array that is the ONLY output of its launches is
+// the one that gains -- arena_take_straddling below, asked for by role.)
 inline bool arena_take(kmers_arena &a, size_t need, size_t *off_out) {
     if (!a.run_start.empty()) {
         auto best_range = a.free_ranges.end();
@@ -167,6 +184,39 @@ inline bool arena_take(kmers_arena &a, size_t need, size_t *off_out) {
     const size_t off = best->first;
     arena_commit(a, best, off, need);
     *off_out = off;
+    return true;
+}
+
+// Placement of a LONE output (KMERS_ALLOC_LONE_OUTPUT: the only array the launches that fill it write): centred on the
+// boundary between two runs of different classes, so that a split-order launch writes its two halves into two classes at once
+// (C3 0.81 -> 0.87 of 8 TB/s, profiles/r03_tuning.md section 5).  The boundary whose two runs write fastest side by side wins;
+// one whose runs are shorter than half the block only if no other fits.  false: no boundary with room around it (or no map).
+inline bool arena_take_straddling(kmers_arena &a, size_t need, size_t *off_out) {
+    const size_t k = a.run_start.size();
+    if (k < 2) return false;
+    auto best_range = a.free_ranges.end();
+    size_t best_off = 0;
+    float best_score = -1.f;
+    for (size_t r = 0; r + 1 < k; ++r) {
+        const size_t b = a.run_start[r + 1];
+        if (b < need / 2) continue;
+        const size_t off = (b - need / 2) / GRANULE * GRANULE;
+        if (off + need > a.bytes) continue;
+        auto it = a.free_ranges.upper_bound(off);
+        if (it == a.free_ranges.begin()) continue;
+        --it;
+        if (it->first > off || it->first + it->second < off + need) continue;  // not free
+        float score = a.pair_rate[r * k + (r + 1)];
+        if (need / 2 > b - a.run_start[r] || need / 2 > run_end(a, r + 1) - b) score -= 1000.f;  // a half reaches into a third run
+        if (score > best_score) {
+            best_score = score;
+            best_range = it;
+            best_off = off;
+        }
+    }
+    if (best_range == a.free_ranges.end()) return false;
+    arena_commit(a, best_range, best_off, need);
+    *off_out = best_off;
     return true;
 }
 

@@ -281,12 +281,18 @@ int kmers_placement_probe(kmers_ctx *ctx, void *a_dev, void *b_dev, size_t bytes
     return KMERS_OK;
 }
 
-int kmers_dev_alloc(kmers_ctx *ctx, size_t bytes, void **out) {
+int kmers_dev_alloc(kmers_ctx *ctx, size_t bytes, void **out) { return kmers_dev_alloc_role(ctx, bytes, KMERS_ALLOC_DEFAULT, out); }
+
+int kmers_dev_alloc_role(kmers_ctx *ctx, size_t bytes, int role, void **out) {
     if (!ctx || !out) return KMERS_E_BADARG;
     *out = nullptr;
+    if (role != KMERS_ALLOC_DEFAULT && role != KMERS_ALLOC_LONE_OUTPUT) return fail(ctx, KMERS_E_BADARG, "unknown allocation role");
     if (ctx->arena.base) {
         size_t off = 0;
-        if (arena_take(ctx->arena, round_up(bytes ? bytes : 8), &off)) {
+        const size_t need = round_up(bytes ? bytes : 8);
+        // the only output array of its launches: across a class boundary if one has room (else like any other block)
+        if ((role == KMERS_ALLOC_LONE_OUTPUT && need >= ((size_t)64 << 20) && arena_take_straddling(ctx->arena, need, &off)) ||
+            arena_take(ctx->arena, need, &off)) {
             *out = ctx->arena.base + off;
             return KMERS_OK;
         }

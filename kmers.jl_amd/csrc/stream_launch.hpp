@@ -100,7 +100,15 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
                                   (MODE == MODE_FW || MODE == MODE_CANON);
     const bool spread = two_word_streams && kmers_arena_spread(ctx->arena, a.out_a, a.out_b ? (const void *)a.out_b : (const void *)a.out_starts,
                                                                   (size_t)a.n_kmers * 8u);
-    uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads : (spread ? 128u : (uint32_t)BLOCK);
+    // ONE output array that lies across a class boundary of the arena (kmers_dev_alloc_role(KMERS_ALLOC_LONE_OUTPUT)): written
+    // through two windows, one per class (split order), by workgroups of 128 threads -- C3 0.80-0.82 -> 0.867-0.870, a two-word
+    // kmer array 0.80 -> 0.856, C5 0.75 -> 0.77; a tuple array (32-byte elements) 0.61 -> 0.82-0.83 with 256 threads and six times
+    // the tile (profiles/r03_tuning.md section 5; three fresh processes each)
+    const bool materialises = MODE == MODE_FW || MODE == MODE_CANON;
+    const uint32_t lone_bytes = a.tuples ? (MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u) : 8u * n_words;
+    const bool lone = materialises && ctx->split_order >= 0 && a.out_a && !a.out_b && !a.out_starts &&
+                      kmers_arena_straddles(ctx->arena, a.out_a, (size_t)a.n_kmers * lone_bytes);
+    uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads : ((spread || (lone && !a.tuples)) ? 128u : (uint32_t)BLOCK);
     if (threads != 64u && threads != 128u) threads = (uint32_t)BLOCK;
     const uint32_t pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * threads;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
@@ -112,6 +120,7 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     if (MODE == MODE_MINIMIZER) max_tile_symbols -= std::min<uint32_t>(max_tile_symbols / 2, a.window_kmers);  // room for the longer overlap
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
     if (ctx->tile_kmers <= 0 && spread) tile = tile * 3 / 2 / pass * pass;  // 24 KiB per workgroup (see above)
+    if (ctx->tile_kmers <= 0 && lone && a.tuples) tile *= 6u;                // tuple arrays through two windows (see above)
     // (round 2 doubled the tile of strided launches -- 32 KiB of output per workgroup; with two lattice kmers per lane the 16 KiB
     // tile is as fast or faster on every box measured in round 3: 0.73-0.76 against 0.70-0.74, profiles/r03_tuning.md)
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);
@@ -126,8 +135,7 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
     const uint64_t visits = (a.n_tiles + a.subtiles - 1) / a.subtiles;
     // two write windows per output array (stream_kernel.hpp, SPLIT ORDER): opt-in, see KMERS_PARAM_SPLIT_ORDER
-    const bool materialises = MODE == MODE_FW || MODE == MODE_CANON || MODE == MODE_MINIMIZER;
-    a.split_order = materialises && visits >= 2 && ctx->split_order != 0 ? 1u : 0u;
+    a.split_order = visits >= 2 && ((materialises || MODE == MODE_MINIMIZER) && ctx->split_order > 0 || lone) ? 1u : 0u;
     const uint64_t slots = a.split_order ? 2 * ((visits + 1) / 2) : visits;
     dim3 grid((unsigned)std::min<uint64_t>(slots, cap));
     dim3 block(threads);

@@ -134,9 +134,12 @@ class Context:
         self.check(self.lib.kmers_ctx_set_param(self.handle, param, value), "kmers_ctx_set_param")
 
     # device memory
-    def alloc(self, nbytes):
+    def alloc(self, nbytes, lone_output=False):
+        """kmers_dev_alloc_role: `lone_output` = the only output array of the launches that fill it (the arena places it across
+        a class boundary of HBM and such a launch writes it through two windows, include/kmers_hip.h)."""
         p = C.c_void_p()
-        self.check(self.lib.kmers_dev_alloc(self.handle, nbytes, C.byref(p)), "kmers_dev_alloc")
+        role = _capi.ALLOC_LONE_OUTPUT if lone_output else _capi.ALLOC_DEFAULT
+        self.check(self.lib.kmers_dev_alloc_role(self.handle, nbytes, role, C.byref(p)), "kmers_dev_alloc_role")
         return p.value
 
     def free(self, ptr):

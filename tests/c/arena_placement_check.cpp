@@ -97,6 +97,35 @@ int main() {
         give(a, b1); give(a, b2); give(a, s2);
         EXPECT(a.free_ranges.size() == 1);
     }
+    {  // ---- the lone output of a launch: across a class boundary, halves inside the two runs; detection by the launcher's query
+        kmers_arena a = fresh(200 * GiB);
+        set_map(a, {{0, 0}, {64, 1}, {128, 2}, {160, 0}});
+        size_t c3, other, second;
+        EXPECT(arena_take_straddling(a, round_up(10 * GiB), &c3));
+        EXPECT(class_at(a, c3) != class_at(a, c3 + 10 * GiB - 1));                       // it crosses ...
+        EXPECT(class_at(a, c3 + 5 * GiB - 3 * MiB) != class_at(a, c3 + 5 * GiB + 3 * MiB));  // ... at its middle
+        EXPECT(kmers_arena_straddles(a, a.base + c3, 10 * GiB));
+        EXPECT(!kmers_arena_straddles(a, a.base + c3, 4 * GiB));                         // only its first 4 GiB written: one class
+        EXPECT(!kmers_arena_straddles(a, a.base + c3 + 300 * GiB, GiB) && !kmers_arena_straddles(a, nullptr, GiB));
+        EXPECT(take(a, 8 * GiB, &other));
+        EXPECT(!kmers_arena_straddles(a, a.base + other, 8 * GiB));                      // an ordinary block lies inside one run
+        EXPECT(arena_take_straddling(a, round_up(10 * GiB), &second) && second != c3);   // the next boundary
+        EXPECT(kmers_arena_straddles(a, a.base + second, 10 * GiB));
+        // 90 GiB: no boundary has 45 GiB of one run on either side, but [19, 109) across the first one is free and is taken
+        // (its halves reach into a third run: the penalised candidate, the only one)
+        size_t big;
+        give(a, c3); give(a, other); give(a, second);
+        EXPECT(arena_take_straddling(a, round_up(90 * GiB), &big) && big + 45 * GiB <= 64 * GiB + 2 * MiB && big + 45 * GiB + 2 * MiB >= 64 * GiB);
+        give(a, big);
+        // nothing free around any boundary: refused (the caller falls back to arena_take)
+        size_t f0, f1, f2, none;
+        EXPECT(take(a, 60 * GiB, &f0) && take(a, 60 * GiB, &f1) && take(a, 60 * GiB, &f2));
+        EXPECT(!arena_take_straddling(a, round_up(30 * GiB), &none));
+        kmers_arena flat = fresh(64 * GiB);                                              // no map / one run: refused
+        EXPECT(!arena_take_straddling(flat, round_up(GiB), &none));
+        set_map(flat, {{0, 0}});
+        EXPECT(!arena_take_straddling(flat, round_up(GiB), &none) && !kmers_arena_straddles(flat, flat.base, GiB));
+    }
     {  // ---- invariants under a random sequence of requests (with a fragmented map)
         kmers_arena a = fresh(96 * GiB + 6 * MiB);
         set_map(a, {{0, 0}, {16, 1}, {20, 0}, {40, 2}, {72, 1}, {80, 0}});

@@ -129,6 +129,62 @@ def test_arena_measures_its_region_map_and_spreads_the_outputs_of_a_launch(km):
     ctx.close()
 
 
+def test_lone_output_lies_across_a_class_boundary_and_is_written_through_two_windows(km, orc):
+    """kmers_dev_alloc_role(KMERS_ALLOC_LONE_OUTPUT): the only output array of a launch is placed ACROSS a class boundary of the
+    arena's map -- its two halves write at the two-class rate (kmers_placement_probe) -- and the launch that finds its one
+    output there writes it in split order with its own launch shape: the results are those of the oracle, and of the same launch
+    into an ordinary block, bit for bit (CanonicalKmers without hashes, SpacedKmers, a two-word kmer array, a tuple array)."""
+    cap = km._capi
+    free_b, _ = torch.cuda.mem_get_info(0)
+    if free_b < 100e9:
+        pytest.skip(f"needs 100 GB of free HBM for a map with more than one class, {free_b / 1e9:.0f} GB free")
+    ctx = km.Context(0)
+    reserved = ctx.arena_reserve(int(free_b * 0.7))
+    base, gran, classes = ctx.arena_regions()
+    lone = ctx.alloc(4 << 30, lone_output=True)
+    plain = ctx.alloc(4 << 30)
+    assert base <= lone < base + reserved and lone % cap.ARENA_GRANULE == 0
+    halves, inside = ctx.placement_probe(lone, lone + (2 << 30), 1 << 30), ctx.placement_probe(plain, plain + (2 << 30), 1 << 30)
+    assert halves > 1.05 * inside, (halves, inside, classes)
+    ctx.free(lone)
+    ctx.free(plain)
+    res = cap.Result()
+    ASYNC = cap.MEM_DEVICE | cap.ASYNC
+    for bits, what in ((2, "canonical"), (4, "spaced"), (4, "fw4"), (4, "tuples")):
+        L = 30_000_001 if what == "spaced" else 12_000_003     # (outputs of 64 MiB and more are placed by role)
+        words = orc.synth_words(31 + bits, 0, (L * bits + 63) // 64 + 1, bits)
+        d_w = ctx.alloc(words.nbytes)
+        ctx.h2d(d_w, words)
+        seq = cap.Seq(d_w, L, 0, 0, bits, 0)
+        if what == "canonical":      # C3's shape
+            exp = orc.canonical(words, L, bits, 2, 31)[0]
+            call = lambda out: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), 31, 2, out, None, 0, ASYNC, C.byref(res))
+        elif what == "spaced":       # C5's
+            exp = orc.spaced(words, L, bits, 2, 21, 3)[0]
+            call = lambda out: ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), 21, 3, 2, out, ASYNC, C.byref(res))
+        elif what == "fw4":          # two-word kmers of a 4-bit alphabet
+            exp = orc.fw_kmers(words, L, bits, 4, 31)[0]
+            call = lambda out: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 31, 4, out, None, ASYNC, C.byref(res))
+        else:                        # Tuple{Kmer,Kmer} elements of FwRvIterator{63}
+            f, r, _ = orc.fwrv(words, L, bits, 2, 63)
+            exp = np.concatenate([f, r], axis=1)
+            call = lambda out: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), 63, 2, out, None, ASYNC | cap.OUT_TUPLES, C.byref(res))
+        nbytes = exp.nbytes
+        assert nbytes >= 64 << 20
+        got = {}
+        for role in (True, False):
+            out = ctx.alloc(nbytes, lone_output=role)
+            assert call(out) == 0, ctx.last_error()
+            assert ctx.sync()[0] == 0
+            host = np.zeros(exp.shape, np.uint64)
+            ctx.d2h(host, out)
+            got[role] = host
+            ctx.free(out)
+        assert np.array_equal(got[True], exp) and np.array_equal(got[False], exp), what
+        ctx.free(d_w)
+    ctx.close()
+
+
 def test_plain_c_resident_pipeline(km, orc, tmp_path):
     """examples/resident_pipeline.c: a plain-C host with everything resident in HBM, its outputs first from plain device
     allocations, then from the context's arena; identical elements either way, checked here against the oracle."""
