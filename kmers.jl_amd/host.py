@@ -564,7 +564,9 @@ class AbstractKmerIterator(metaclass=_Parametric):
 def _call_with_device_outputs(it, n, widths, call):
     """Allocate device outputs, run `call(ptrs)`, copy back; returns (host arrays, Result)."""
     ctx = it.ctx
-    ptrs = [ctx.alloc(max(8, n * w * 8)) for w in widths]
+    # the ONLY output array of a launch is allocated by that role (kmers_dev_alloc_role: with an arena reserved it lies across a
+    # class boundary of HBM and the launch writes it through two windows, DESIGN.md section 3.8)
+    ptrs = [ctx.alloc(max(8, n * w * 8), lone_output=len(widths) == 1) for w in widths]
     res = _capi.Result()
     try:
         rc = call(ptrs, res)
