@@ -27,6 +27,7 @@ LEGS = {  # leg -> (label, kernel substring, algorithmic bytes per launch given 
     "c3": ("C3 CanonicalDNAMers{31}, 1.25 Gbase LongDNA{2}", "stream_kernel<2, 2, 1, 1", lambda kept: 8.25 * (1_250_000_000 - 30)),
     "c4": ("C4 FwDNAMers{63} + reverse complements", "stream_kernel<4, 2, 2, 0", lambda kept: 32.5 * (L - 62)),
     "c5": ("C5 strict SpacedDNAMers{21,3}", "stream_kernel<4, 2, 1, 0, false", lambda kept: 0.5 * L + 8.0 * ((L - 21) // 3 + 1)),
+    "f3": ("f3 FwKmers{DNAAlphabet{4},31}: two-word kmers of a 4-bit alphabet, one array", "stream_kernel<4, 4, 2, 0", lambda kept: 16.5 * (L - 30)),
     "u31": ("UnambiguousDNAMers{31}, p(N) = 0.04", "unambiguous_kernel<4, 1, 0", lambda kept: 0.5 * L + 16.0 * kept),
     "u21": ("C5 skip variant: UnambiguousDNAMers{21} on the stride-3 lattice, p(N) = 0.04", "unambiguous_kernel<4, 1, 0", lambda kept: 0.5 * L + 16.0 * kept),
     "xor": ("fused XOR-reduce of CanonicalDNAMers{31}", "run_kernel<4", lambda kept: 0.0),

@@ -44,6 +44,8 @@ ap.add_argument("--subtiles", type=int, default=0)
 ap.add_argument("--threads", type=int, default=0, help="threads per workgroup of the tile kernels (KMERS_PARAM_BLOCK_THREADS)")
 ap.add_argument("--split", action="store_true", help="two write windows per array (KMERS_PARAM_SPLIT_ORDER)")
 ap.add_argument("--once", action="store_true")
+ap.add_argument("--no-role", action="store_true", help="arena mode: a single output array is allocated like any other block (not by KMERS_ALLOC_LONE_OUTPUT)")
+ap.add_argument("--straddle-b", type=int, default=0, help="with --straddle: the second array centred on the n-th class boundary after the first")
 ap.add_argument("--straddle", action="store_true", help="arenacarve mode: the first array centred on the first class boundary of the arena's map")
 ap.add_argument("--shifts", default="", help="carve mode: comma-separated SA:SB byte shifts of the two output bases inside the block; one timing per pair, same process")
 ap.add_argument("--bases", type=int, default=1_000_000_000)
@@ -103,11 +105,16 @@ with torch.cuda.stream(stream):
             g = next(i for i in range(1, len(classes)) if classes[i] != classes[i - 1])
             pa = abase + ((g * gran - 4 * words_a) >> 21 << 21)
             pb = abase + ((g + 6) * gran)   # (a second array, if the leg has one: 24 GiB further on)
+            if args.straddle_b:                # ... or centred on a later boundary (the n-th after the first)
+                bs = [i for i in range(1, len(classes)) if classes[i] != classes[i - 1]]
+                g2 = bs[min(args.straddle_b, len(bs) - 1)]
+                pb = abase + ((g2 * gran - 4 * max(words_b, 1)) >> 21 << 21)
+                print(f"straddle: b across the boundary at {g2 * gran >> 30} GiB", flush=True)
             print(f"straddle: boundary at {g * gran >> 30} GiB, a at {(pa - abase) / 2**30:.2f} GiB", flush=True)
         mode = "carve"
     elif mode == "arena":
         ctx.check(ctx.lib.kmers_arena_reserve(ctx.handle, size << 30), "kmers_arena_reserve")
-        pa = ctx.alloc(8 * words_a)
+        pa = ctx.alloc(8 * words_a, lone_output=(words_b == 0 and not args.no_role))  # the only output of its launch: by role
         pb = ctx.alloc(8 * max(words_b, 1))
         abase, gran, classes = ctx.arena_regions()
         if gran:
