@@ -123,7 +123,8 @@ inline bool arena_take(kmers_arena &a, size_t need, size_t *off_out) {
                     for (const auto &u : a.used) {
                         if (u.second < ((size_t)64 << 20)) continue;
                         const float w = u.first == a.last_off ? 2.f : 1.f;
-                        sum += w * a.pair_rate[run_of(a, u.first) * k + r];
+                        // (a block that lies across a boundary -- a lone output -- counts with the runs of both its ends)
+                        sum += w * 0.5f * (a.pair_rate[run_of(a, u.first) * k + r] + a.pair_rate[run_of(a, u.first + u.second - 1) * k + r]);
                         weight += w;
                     }
                     float score = weight > 0.f ? sum / weight : a.pair_rate[r * k + r];

@@ -16,6 +16,9 @@ dev = torch.device("cuda", 0)
 K = int(os.environ.get("BATCH_K", "31"))   # BATCH_K=63: two-word kmers
 NW = (2 * K + 63) // 64
 res = cap.Result()
+ARENA = "--arena" in sys.argv
+if ARENA:
+    ctx.arena_reserve(int(150e9))
 if "--passes" in sys.argv:   # force the tile length (1..8 passes of 1024 elements) instead of the per-call choice
     ctx.set_param(cap.PARAM_BATCH_PASSES, int(sys.argv[sys.argv.index("--passes") + 1]))
 CASES = (("10 M reads x 150", 10_000_000, 150, 151, 4), ("10 M reads x 150", 10_000_000, 150, 151, 2),
@@ -46,21 +49,29 @@ for label, n_reads, lo, hi, src in CASES:
     spans_h = np.stack([starts, lens], axis=1).copy()
     spans_d = torch.from_numpy(spans_h.view(np.int64)).to(dev)
     total = int(np.maximum(lens.astype(np.int64) - K + 1, 0).sum())
-    out_k = torch.empty(total * NW, dtype=torch.int64, device=dev)
-    out_h = torch.empty(total, dtype=torch.int64, device=dev)
+    if ARENA:   # outputs from the context's arena (two region classes), like bench.py's
+        pk, ph = ctx.alloc(total * NW * 8), ctx.alloc(total * 8)
+        out_k = out_h = None
+    else:
+        out_k = torch.empty(total * NW, dtype=torch.int64, device=dev)
+        out_h = torch.empty(total, dtype=torch.int64, device=dev)
+        pk, ph = out_k.data_ptr(), out_h.data_ptr()
     torch.cuda.synchronize()
     seq = cap.Seq(pool_ptr, n_pool, 0, 0, src, 0)
     for spans_ptr, flag, what in ((spans_h.ctypes.data, 0, "host spans"), (spans_d.data_ptr(), cap.SPANS_DEVICE, "resident spans")):
         best = 1e9
         for _ in range(4):
             t0 = time.perf_counter()
-            rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans_ptr, n_reads, cap.BATCH_CANONICAL, K, 2, out_k.data_ptr(), out_h.data_ptr(),
+            rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans_ptr, n_reads, cap.BATCH_CANONICAL, K, 2, pk, ph,
                                      0, None, total, cap.MEM_DEVICE | flag, C.byref(res))
             best = min(best, time.perf_counter() - t0)
             assert rc == 0 and res.n_out == total, ctx.last_error()
         by = total * (8 * NW + 8) + int(lens.sum()) * src / 8
         print(f"src={src} {label:28s} {what:15s} {best * 1e3:8.3f} ms  {total / best / 1e9:7.1f} G elements/s  {int(lens.sum()) / best / 1e9:7.1f} Gbases/s  "
               f"{by / best / 1e9:7.0f} GB/s", flush=True)
+    if ARENA:
+        ctx.free(pk)
+        ctx.free(ph)
     del pool, out_k, out_h, spans_d
 
 # each_codon over the coding sequences of many genomes: SpacedDNAMers{3,3} per record (kmers_batch_spaced)
