@@ -119,10 +119,11 @@ __global__ __launch_bounds__(BLOCK) void wide_kernel(const StreamArgs a, const u
     if (g >= a.n_kmers) return;
     const uint64_t start = g * a.stride;
     if constexpr (MODE == MODE_FW) {
-        uint64_t *fw = a.tuples ? a.out_a + g * 2u * n_words : a.out_a + g * n_words;
+        uint64_t *fw = a.tuples ? a.out_a + g * 2u * n_words : (a.out_a ? a.out_a + g * n_words : nullptr);
         uint64_t *rc = a.tuples ? fw + n_words : (a.out_b ? a.out_b + g * n_words : nullptr);
         for (uint32_t w = 0; w < n_words; ++w) {
-            fw[w] = wide_word<SRC_BITS, DST>(a, start, n_words, w, false);
+            const uint64_t f = wide_word<SRC_BITS, DST>(a, start, n_words, w, false);  // (computed even if not stored: it validates the symbols)
+            if (fw) fw[w] = f;
             if (rc) rc[w] = wide_word<SRC_BITS, DST>(a, start, n_words, w, true);
         }
     } else {
