@@ -21,7 +21,10 @@ namespace kmers {
 #endif
 constexpr int BLOCK = KMERS_BLOCK;             // threads per workgroup (multiple of 64)
 constexpr int WAVES = BLOCK / 64;
-constexpr int MAX_TILE_BITS = 32768;           // LDS stream bits a tile may span (excl. overlap): 16384 2-bit symbols
+#ifndef KMERS_MAX_TILE_BITS
+#define KMERS_MAX_TILE_BITS 32768
+#endif
+constexpr int MAX_TILE_BITS = KMERS_MAX_TILE_BITS;           // LDS stream bits a tile may span (excl. overlap): 16384 2-bit symbols
 constexpr int MAX_TILE_BASES = MAX_TILE_BITS / 2;
 constexpr int LDS_QWORDS = MAX_TILE_BITS / 64 + 16;
 
