@@ -185,6 +185,67 @@ def test_lone_output_lies_across_a_class_boundary_and_is_written_through_two_win
     ctx.close()
 
 
+def test_lone_output_launches_fuzzed(km, orc):
+    """Random geometries through the lone-output path (array across a class boundary, split order, its own launch shapes):
+    kmer widths of one to four words, both kmer alphabets, strides, views that start anywhere in a word, odd lengths -- every
+    element against the oracle."""
+    cap = km._capi
+    free_b, _ = torch.cuda.mem_get_info(0)
+    if free_b < 100e9:
+        pytest.skip(f"needs 100 GB of free HBM for a map with more than one class, {free_b / 1e9:.0f} GB free")
+    ctx = km.Context(0)
+    ctx.arena_reserve(int(free_b * 0.7))
+    rng = np.random.default_rng(2024)
+    res = cap.Result()
+    ASYNC = cap.MEM_DEVICE | cap.ASYNC
+    for case in range(14):
+        bits = int(rng.choice([2, 4]))
+        dst = int(rng.choice([2, 2, 4]))
+        K = int(rng.choice([1, 5, 21, 31, 32, 33, 63, 64])) if dst == 2 else int(rng.choice([3, 16, 17, 31, 32]))
+        what = str(rng.choice(["canonical", "fw", "spaced", "tuples"]))
+        J = int(rng.choice([2, 3, 5, 16])) if what == "spaced" else 1
+        N = (K * dst + 63) // 64
+        per = 2 * N if what == "tuples" else N
+        n_min = (64 << 20) // (8 * per) + 1000                     # outputs of 64 MiB and more are placed by role
+        L = (n_min + int(rng.integers(0, 300_000))) * J + K
+        first = int(rng.choice([0, 1, 7, 15, 16, 31, 33]))
+        words = orc.synth_words(case, 0, ((first + L) * bits + 63) // 64 + 1, bits)
+        d_w = ctx.alloc(words.nbytes)
+        ctx.h2d(d_w, words)
+        seq = cap.Seq(d_w, L, first, 0, bits, 0)
+        # the oracle takes a view that starts at symbol 0: shift the words
+        shifted = np.zeros(len(words), np.uint64)
+        sh = first * bits
+        w0, b0 = sh // 64, sh % 64
+        src64 = words[w0:]
+        shifted[:len(src64)] = src64 >> np.uint64(b0)
+        if b0:
+            shifted[:len(src64) - 1] |= src64[1:] << np.uint64(64 - b0)
+        if what == "canonical":
+            exp = orc.canonical(shifted, L, bits, dst, K)[0]
+            call = lambda out: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, dst, out, None, 0, ASYNC, C.byref(res))
+        elif what == "fw":
+            exp = orc.fw_kmers(shifted, L, bits, dst, K)[0]
+            call = lambda out: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, dst, out, None, ASYNC, C.byref(res))
+        elif what == "spaced":
+            exp = orc.spaced(shifted, L, bits, dst, K, J)[0]
+            call = lambda out: ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, dst, out, ASYNC, C.byref(res))
+        else:
+            f, r, _ = orc.fwrv(shifted, L, bits, dst, K)
+            exp = np.concatenate([f, r], axis=1)
+            call = lambda out: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, dst, out, None, ASYNC | cap.OUT_TUPLES, C.byref(res))
+        assert exp.nbytes >= 64 << 20
+        out = ctx.alloc(exp.nbytes, lone_output=True)
+        assert call(out) == 0, ctx.last_error()
+        assert ctx.sync()[0] == 0
+        host = np.zeros(exp.shape, np.uint64)
+        ctx.d2h(host, out)
+        ctx.free(out)
+        ctx.free(d_w)
+        assert np.array_equal(host, exp), (case, bits, dst, K, what, J, L, first)
+    ctx.close()
+
+
 def test_plain_c_resident_pipeline(km, orc, tmp_path):
     """examples/resident_pipeline.c: a plain-C host with everything resident in HBM, its outputs first from plain device
     allocations, then from the context's arena; identical elements either way, checked here against the oracle."""
