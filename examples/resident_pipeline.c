@@ -90,6 +90,33 @@ int main(int argc, char **argv) {
         return 1;
     }
     printf("both runs: %llu elements, the first %llu identical: equal\n", (unsigned long long)n, (unsigned long long)m);
+    /* A launch with ONE output array (the kmers without their hashes): an ordinary block of the arena against a block taken by
+     * role, which lies across a class boundary of HBM and is written through two windows (include/kmers_hip.h). */
+    for (int role = KMERS_ALLOC_DEFAULT; role <= KMERS_ALLOC_LONE_OUTPUT; ++role) {
+        void *words = NULL, *only_out = NULL;
+        CHECK(kmers_dev_alloc_role(ctx, n * 8, role, &only_out));
+        CHECK(kmers_dev_alloc(ctx, (n_words + 2) * 8, &words));
+        CHECK(kmers_synth_dna(ctx, 42, 0, n_words, 4, 0, (uint64_t *)words));
+        kmers_seq seq = {(const uint64_t *)words, n_bases, 0, 0, 4, 0};
+        kmers_result res;
+        for (int warm = 0; warm < 3; ++warm)
+            CHECK(kmers_canonical(ctx, &seq, k, 2, (uint64_t *)only_out, NULL, 0, KMERS_MEM_DEVICE | KMERS_ASYNC, &res));
+        CHECK(kmers_sync(ctx, &res));
+        const double t0 = now_ms();
+        for (int r = 0; r < reps; ++r)
+            CHECK(kmers_canonical(ctx, &seq, k, 2, (uint64_t *)only_out, NULL, 0, KMERS_MEM_DEVICE | KMERS_ASYNC, &res));
+        CHECK(kmers_sync(ctx, &res));
+        const double t = (now_ms() - t0) / reps;
+        CHECK(kmers_memcpy_d2h(ctx, head[1][1], only_out, m * 8));
+        if (memcmp(head[1][1], head[1][0], m * 8) != 0) {
+            fprintf(stderr, "the kmers-only launch differs from the kmers of the two-output launch\n");
+            return 1;
+        }
+        printf("%-24s %8.3f ms per launch = %5.2f TB/s (8.5 B per kmer)\n", role ? "kmers only, by role:" : "kmers only, plain block:", t,
+               8.5 * n / t / 1e9);
+        CHECK(kmers_dev_free(ctx, words));
+        CHECK(kmers_dev_free(ctx, only_out));
+    }
     kmers_ctx_destroy(ctx);
     return 0;
 }

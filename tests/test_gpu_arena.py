@@ -261,3 +261,4 @@ def test_plain_c_resident_pipeline(km, orc, tmp_path):
     assert out.returncode == 0, (out.stdout, out.stderr)
     assert "plain allocations:" in out.stdout and "outputs from the arena:" in out.stdout and ": equal" in out.stdout, out.stdout
     assert "arena:" in out.stdout and "classes A" in out.stdout
+    assert "kmers only, plain block:" in out.stdout and "kmers only, by role:" in out.stdout
