@@ -56,7 +56,12 @@ __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, co
     uint64_t xacc = 0;  // WMODE_XOR: this lane's fold over all of its tiles
     // FW / CANON: one tile per workgroup (short-lived workgroups write fastest, profiles/r01_tuning.md); the consumers run a
     // persistent grid (launch_wide_tile) and walk the tiles
-    for (uint64_t tile_id = blockIdx.x; tile_id < a.n_tiles; tile_id += gridDim.x) {
+    // split order (a.split_order, one tile per workgroup): even workgroups walk the first half of the tiles, odd ones the second
+    // -- two write windows half an array apart, for an output array that lies across a class boundary of HBM (stream_launch.hpp)
+    const uint64_t n_first = (a.n_tiles + 1u) / 2u;
+    for (uint64_t slot = blockIdx.x; slot < (a.split_order ? 2u * n_first : a.n_tiles); slot += gridDim.x) {
+    const uint64_t tile_id = a.split_order ? ((slot & 1u) ? n_first + (slot >> 1) : (slot >> 1)) : slot;
+    if (tile_id >= a.n_tiles) break;  // (the odd half is the shorter one: only the last slot can fall off, in a one-tile-per-workgroup grid)
     const uint64_t g0 = tile_id * T;
     const uint32_t nk = a.n_kmers - g0 < (uint64_t)T ? (uint32_t)(a.n_kmers - g0) : T;
     // ---- stage: every source word the tile's windows touch, recoded, at its own word-aligned place in the stream
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, co
             }
         }
     }
-    if (tile_id + gridDim.x < a.n_tiles) block_sync();  // the next tile restages the stream
+    if (slot + gridDim.x < (a.split_order ? 2u * n_first : a.n_tiles)) block_sync();  // the next tile restages the stream
     }
     if constexpr (WMODE == WMODE_XOR) {
         // wavefront XOR-reduce (64 lanes), then one atomic per wave and workgroup
@@ -209,8 +214,15 @@ int launch_wide_tile(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, 
         cw_pitch = word_pitch;
         dyn += (size_t)tile * word_pitch * 8u;
     }
-    const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (streams ? n_tiles : (uint64_t)ctx->n_cus * 8u);
-    dim3 grid((unsigned)std::min<uint64_t>(n_tiles, resident)), block(BLOCK);
+    // ONE output array (FwKmers, SpacedKmers; CanonicalKmers, whose hashes are a small second stream) that lies across a class
+    // boundary of the arena (kmers_dev_alloc_role): two write windows, like the stream kernels' lone outputs
+    const size_t element_bytes = (size_t)8 * (a.tuples ? (WMODE == WMODE_FW ? 2u * n_words : n_words + 1u) : n_words);
+    const bool lone = streams && ctx->max_grid <= 0 && ctx->split_order >= 0 && a.out_a && (WMODE == WMODE_CANON || !a.out_b) &&
+                      kmers_arena_straddles(ctx->arena, a.out_a, (size_t)a.n_kmers * element_bytes);
+    a.split_order = (lone || (streams && ctx->max_grid <= 0 && ctx->split_order > 0)) && n_tiles >= 2 ? 1u : 0u;
+    const uint64_t slots = a.split_order ? 2u * ((n_tiles + 1u) / 2u) : n_tiles;
+    const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (streams ? slots : (uint64_t)ctx->n_cus * 8u);
+    dim3 grid((unsigned)std::min<uint64_t>(slots, resident)), block(BLOCK);
 #define WIDET(SB, DB)                                                                                                              \
     do {                                                                                                                           \
         if (dyn > 48u * 1024u)                                                                                                     \

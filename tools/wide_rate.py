@@ -15,11 +15,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--bases", type=int, default=100_000_000)
 ap.add_argument("--ks", default="128,129,150,256,1000")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--arena", action="store_true", help="outputs from the context's arena; the single-output launch also into a block taken by role")
 ap.add_argument("--force-tiles", type=int, default=0, help="KMERS_PARAM_WIDE_NO_TILES value (2: the tile form for kmers of one to four words too)")
 args = ap.parse_args()
 cap = km._capi
 ctx = km.Context(0)
 ctx.set_param(11, args.force_tiles)
+if args.arena:
+    ctx.arena_reserve(int(120e9))
 dev = torch.device("cuda", 0)
 stream = torch.cuda.ExternalStream(ctx.lib.kmers_ctx_stream(ctx.handle), device=dev)
 L = args.bases
@@ -60,14 +63,33 @@ with torch.cuda.stream(stream):
         for K in [int(x) for x in args.ks.split(",")]:
             N = (2 * K + 63) // 64
             n = L - K + 1
-            a = torch.empty(n * N, dtype=torch.int64, device=dev)
-            b = torch.empty(n * N, dtype=torch.int64, device=dev)
+            if args.arena:
+                pa, pb = ctx.alloc(n * N * 8), ctx.alloc(n * N * 8)
+
+                class _P:
+                    def __init__(self, p): self.p = p
+                    def data_ptr(self): return self.p
+                a, b = _P(pa), _P(pb)
+            else:
+                a = torch.empty(n * N, dtype=torch.int64, device=dev)
+                b = torch.empty(n * N, dtype=torch.int64, device=dev)
             val = C.c_uint64()
             t_c = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), b.data_ptr(), 0, ASYNC, C.byref(res)))
             t_f = timed(lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), b.data_ptr(), ASYNC, C.byref(res)))
             t_x = timed(lambda: ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, 2, 1, C.byref(val), cap.MEM_DEVICE, C.byref(res)))
+            t_1 = timed(lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), None, ASYNC, C.byref(res)))
+            t_r = float("nan")
+            if args.arena:
+                ctx.free(pa)
+                ctx.free(pb)
+                pl = ctx.alloc(n * N * 8, lone_output=True)
+                t_r = timed(lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, pl, None, ASYNC, C.byref(res)))
+                t_cr = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, pl, None, 0, ASYNC, C.byref(res)))
+                ctx.free(pl)
+                print(f"   fw only {t_1:8.3f} ms ({8 * N * n / t_1 / 1e6:7.1f} GB/s), by role {t_r:8.3f} ms ({8 * N * n / t_r / 1e6:7.1f} GB/s); canonical kmers only by role {t_cr:8.3f} ms ({8 * N * n / t_cr / 1e6:7.1f} GB/s)")
             gb_c, gb_f = (8 * N + 8) * n / 1e9, 16 * N * n / 1e9
             print(f"src {src} K {K:5d} N {N:3d}: canonical+hash {t_c:9.3f} ms ({gb_c / t_c * 1e3:7.1f} GB/s)  fw+rc {t_f:9.3f} ms ({gb_f / t_f * 1e3:7.1f} GB/s)"
                   f"  xor-reduce {t_x:9.3f} ms ({n / t_x / 1e6:8.2f} G kmers/s)", flush=True)
-            del a, b
+            if not args.arena:
+                del a, b
         del buf
