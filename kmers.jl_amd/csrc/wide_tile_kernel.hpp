@@ -36,7 +36,7 @@ inline uint32_t wide_tile_stream_words(uint32_t tile, uint32_t k, uint32_t strid
 
 template <int SRC_BITS, int DST, int WMODE>
 __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, const uint32_t n_words, const uint32_t stream_words,
-                                                           const uint32_t cw_pitch) {
+                                                           const uint32_t cw_pitch, const uint32_t vec16) {
     extern __shared__ uint64_t wl[];
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     uint8_t *const take = reinterpret_cast<uint8_t *>(wl + stream_words);  // per window of the tile: 1 = the forward strand is the canonical one
@@ -139,6 +139,60 @@ __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, co
     // 2N (Tuple{Kmer,Kmer}: forward words, then reverse complement), N of N + 1 (Tuple{Kmer,UInt64}: the hash was stored above)
     const uint32_t per = (WMODE == WMODE_FW && a.tuples) ? 2u * n_words : n_words;
     const uint32_t pitch = (WMODE == WMODE_CANON && a.tuples) ? n_words + 1u : per;  // words between two elements in out_a
+    // Where the tile's words are one contiguous, 16-byte aligned stretch of the array (separate arrays / Tuple{Kmer,Kmer}, an even
+    // first word, aligned bases: vec16) a lane takes TWO consecutive words and stores them at once -- the second may be the first
+    // word of the next kmer -- like the 16-byte stores of the compile-time-width kernels.
+    const uint64_t first_word = g0 * per;
+    if (vec16 && pitch == per && (first_word & 1u) == 0u) {
+        const uint32_t total = nk * per;
+        const uint32_t step2_g = (2u * (uint32_t)BLOCK) / per, step2_w = (2u * (uint32_t)BLOCK) % per;
+        uint32_t g2 = (2u * tid) / per, w2 = (2u * tid) % per;
+        for (uint32_t i = 2u * tid; i < total; i += 2u * (uint32_t)BLOCK) {
+            uint32_t g3 = g2, w3 = w2 + 1u;  // the second word of the pair
+            if (w3 == per) {
+                w3 = 0;
+                ++g3;
+            }
+            const bool two = i + 1u < total;
+            uint64_t va = 0, vb = 0, ra = 0, rb = 0;
+            if constexpr (WMODE == WMODE_FW) {
+                if (a.tuples) {
+                    va = w2 < n_words ? word(g2, w2, false) : word(g2, w2 - n_words, true);
+                    if (two) vb = w3 < n_words ? word(g3, w3, false) : word(g3, w3 - n_words, true);
+                } else {
+                    if (a.out_a) {
+                        va = word(g2, w2, false);
+                        if (two) vb = word(g3, w3, false);
+                    }
+                    if (a.out_b) {
+                        ra = word(g2, w2, true);
+                        if (two) rb = word(g3, w3, true);
+                    }
+                }
+            } else {
+                va = word(g2, w2, take[g2] == 0u);
+                if (two) vb = word(g3, w3, take[g3] == 0u);
+                if (cw_pitch) {
+                    cw[g2 * cw_pitch + w2] = va;
+                    if (two) cw[g3 * cw_pitch + w3] = vb;
+                }
+            }
+            const uint64_t at = first_word + i;
+            if (two) {
+                if (a.out_a) *reinterpret_cast<ulonglong2 *>(a.out_a + at) = make_ulonglong2(va, vb);
+                if (WMODE == WMODE_FW && !a.tuples && a.out_b) *reinterpret_cast<ulonglong2 *>(a.out_b + at) = make_ulonglong2(ra, rb);
+            } else {
+                if (a.out_a) a.out_a[at] = va;
+                if (WMODE == WMODE_FW && !a.tuples && a.out_b) a.out_b[at] = ra;
+            }
+            g2 += step2_g;
+            w2 += step2_w;
+            if (w2 >= per) {
+                w2 -= per;
+                ++g2;
+            }
+        }
+    } else {
     const uint32_t step_g = (uint32_t)BLOCK / per, step_w = (uint32_t)BLOCK % per;
     uint32_t gl = tid / per, w = tid % per;
     while (gl < nk) {
@@ -161,6 +215,7 @@ __global__ __launch_bounds__(BLOCK) void wide_tile_kernel(const StreamArgs a, co
             w -= per;
             ++gl;
         }
+    }
     }
     if constexpr (WMODE == WMODE_CANON) {
         if (cw_pitch) {
@@ -195,7 +250,7 @@ int launch_wide_tile(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, 
     const bool streams = WMODE == WMODE_FW || WMODE == WMODE_CANON;
     // (CANON first walks its tile one lane per KMER -- the strand decision and the fx_hash fold: whole multiples of the
     // workgroup, however few windows 16 KiB are)
-    uint32_t tile = WMODE == WMODE_FW ? std::max<uint32_t>(1u, 2048u / n_words)
+    uint32_t tile = WMODE == WMODE_FW ? std::max<uint32_t>(1u, (2048u / n_words) & ~1u)  // (even: a tile's first output word is)
                   : WMODE == WMODE_CANON ? std::max<uint32_t>((uint32_t)BLOCK, (2048u / n_words + BLOCK - 1u) / BLOCK * BLOCK) : 2048u;
     if (ctx->tile_kmers > 0) tile = (uint32_t)std::min<int64_t>(ctx->tile_kmers, 1 << 16);  // tests, tuning
     tile = (uint32_t)std::min<uint64_t>(tile, a.n_kmers);
@@ -223,12 +278,15 @@ int launch_wide_tile(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, 
     const uint64_t slots = a.split_order ? 2u * ((n_tiles + 1u) / 2u) : n_tiles;
     const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (streams ? slots : (uint64_t)ctx->n_cus * 8u);
     dim3 grid((unsigned)std::min<uint64_t>(slots, resident)), block(BLOCK);
+    // 16-byte stores where the output bases allow them (the kernel checks the tile's first word)
+    const uint32_t vec16 = ((!a.out_a || (reinterpret_cast<uintptr_t>(a.out_a) & 15u) == 0) &&
+                            (a.tuples || WMODE != WMODE_FW || !a.out_b || (reinterpret_cast<uintptr_t>(a.out_b) & 15u) == 0)) ? 1u : 0u;
 #define WIDET(SB, DB)                                                                                                              \
     do {                                                                                                                           \
         if (dyn > 48u * 1024u)                                                                                                     \
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(wide_tile_kernel<SB, DB, WMODE>),                      \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_TILE_LDS_BYTES));               \
-        hipLaunchKernelGGL((wide_tile_kernel<SB, DB, WMODE>), grid, block, dyn, ctx->stream, a, n_words, sw, cw_pitch);           \
+        hipLaunchKernelGGL((wide_tile_kernel<SB, DB, WMODE>), grid, block, dyn, ctx->stream, a, n_words, sw, cw_pitch, vec16);    \
     } while (0)
     if (src_bits == 8 && dst_bits == 2) WIDET(8, 2);
     else if (src_bits == 8) WIDET(8, 4);
