@@ -147,26 +147,45 @@ inline bool arena_take(kmers_arena &a, size_t need, size_t *off_out) {
         }
     }
     if (!a.run_start.empty() && a.last_len) {
-        // a block longer than any run (the 80 GB arrays of a 10 Gbase launch) passes through several runs: at the bottom or at
-        // the top of a free range that fits (nothing is fragmented), wherever its runs -- sampled at eight points -- write
-        // fastest beside the previous block's
+        // a block longer than any run (the 80 GB arrays of a 10 Gbase launch) passes through several runs: wherever in a free
+        // range that fits its runs -- sampled at sixteen points -- write fastest beside the previous block's.  The two ends of
+        // the range come first (nothing is fragmented); a position inside it, tried every 2 GiB, must be better than the better
+        // end by 100 GB/s on average (a fine-grained map -- runs of 16-32 GiB -- leaves the ends a matter of luck: the 10 Gbase
+        // launch ran at 0.82 on such a box and at 0.88-0.89 on boxes with runs of 64 GiB).
         const size_t k = a.run_start.size();
         auto best_range = a.free_ranges.end();
         size_t best_off = 0;
         float best_score = -1.f;
+        auto score_at = [&](size_t off) {
+            float sum = 0.f;
+            for (int i = 0; i < 16; ++i) {
+                const size_t t = (size_t)((2 * i + 1) * (double)need / 32.0), u = (size_t)((2 * i + 1) * (double)a.last_len / 32.0);
+                sum += a.pair_rate[run_of(a, a.last_off + u) * k + run_of(a, off + t)];
+            }
+            return sum / 16.f;
+        };
         for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it) {
             if (it->second < need) continue;
-            const size_t ends[2] = {it->first, (it->first + it->second - need) / GRANULE * GRANULE};
-            for (int e = 0; e < 2; ++e) {
-                const size_t off = ends[e];
-                if (off < it->first) continue;
-                float sum = 0.f;
-                for (int i = 0; i < 8; ++i) {
-                    const size_t t = (size_t)((2 * i + 1) * (double)need / 16.0), u = (size_t)((2 * i + 1) * (double)a.last_len / 16.0);
-                    sum += a.pair_rate[run_of(a, a.last_off + u) * k + run_of(a, off + t)];
+            const size_t lo = it->first, hi = (it->first + it->second - need) / GRANULE * GRANULE;
+            for (int e = 0; e < 2; ++e) {  // the ends: a later one must be better by 50 GB/s
+                const size_t off = e ? hi : lo;
+                if (off < lo) continue;
+                const float sc = score_at(off);
+                if (sc > best_score + 50.f) {
+                    best_score = sc;
+                    best_range = it;
+                    best_off = off;
                 }
-                if (sum > best_score + 400.f) {  // (a later position must be better by 50 GB/s on average to be preferred)
-                    best_score = sum;
+            }
+        }
+        const float end_score = best_score;
+        for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it) {
+            if (it->second < need) continue;
+            const size_t lo = it->first, hi = (it->first + it->second - need) / GRANULE * GRANULE;
+            for (size_t off = lo + REGION / 2; off < hi; off += REGION / 2) {
+                const float sc = score_at(off);
+                if (sc > end_score + 100.f && sc > best_score) {
+                    best_score = sc;
                     best_range = it;
                     best_off = off;
                 }

@@ -126,6 +126,30 @@ int main() {
         set_map(flat, {{0, 0}});
         EXPECT(!arena_take_straddling(flat, round_up(GiB), &none) && !kmers_arena_straddles(flat, flat.base, GiB));
     }
+    {  // ---- two blocks longer than any run on a FINE-GRAINED map (a box of round 3: runs of 4-32 GiB): the second block goes where
+       //      its runs pair best with the first block's, inside the free range if that beats both of its ends
+        kmers_arena a = fresh(212 * GiB);
+        set_map(a, {{0, 0}, {32, 1}, {48, 2}, {64, 0}, {96, 2}, {104, 1}, {120, 2}, {136, 0}, {152, 2}, {160, 0}, {164, 1}, {188, 2}, {200, 0}, {204, 1}});
+        const size_t need = round_up((size_t)80 * 1000 * 1000 * 1000);
+        size_t first, second;
+        EXPECT(take(a, need, &first) && first == 0);
+        EXPECT(take(a, need, &second) && second >= need);
+        auto differ = [&](size_t off) {  // fraction of the block whose class differs from the first block's at the same relative place
+            int d = 0;
+            for (int i = 0; i < 64; ++i) {
+                const size_t t = (size_t)((2 * i + 1) * (double)need / 128.0);
+                d += class_at(a, first + t) != class_at(a, off + t);
+            }
+            return d / 64.0;
+        };
+        const size_t top = (212 * GiB - need) / GRANULE * GRANULE;
+        EXPECT(differ(second) >= differ(need) && differ(second) >= differ(top));
+        EXPECT(differ(second) >= 0.8);
+        std::printf("fine-grained map: second block at %.1f GiB, classes differ over %.0f %% of it (bottom end %.0f %%, top end %.0f %%)\n",
+                    second / (double)GiB, 100 * differ(second), 100 * differ(need), 100 * differ(top));
+        size_t src;
+        EXPECT(take(a, 5 * GiB, &src));   // the sequence still fits
+    }
     {  // ---- invariants under a random sequence of requests (with a fragmented map)
         kmers_arena a = fresh(96 * GiB + 6 * MiB);
         set_map(a, {{0, 0}, {16, 1}, {20, 0}, {40, 2}, {72, 1}, {80, 0}});
