@@ -422,12 +422,13 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     };
     const uint64_t S = STRIDE1 || a.subtiles == 0 ? 1u : a.subtiles;
     uint32_t buf = 0;
-    // SPLIT ORDER (opt-in, KMERS_PARAM_SPLIT_ORDER): even workgroups walk the first half of the tile range, odd ones the second
-    // half, so that every output array is written through TWO moving windows half an array apart.  On MI355X store streams inside
-    // one region class of HBM share ~6 TB/s and streams in different classes reach ~7.2 (memory_api.hip, profiles/r03_alloc.md):
-    // a single output array that straddles two classes is then written 1 % faster (a pure fill of that shape: 6.4 -> 7.2 TB/s,
-    // the kernels: 0.80 -> 0.81), but the two arrays of a two-output launch are better off in two different classes with one
-    // window each (-1..4 % with four windows), which is what the context's arena arranges: off by default.
+    // SPLIT ORDER (a.split_order; stream_launch.hpp decides): even workgroups walk the first half of the tile range, odd ones the
+    // second half, so that every output array is written through TWO moving windows half an array apart.  On MI355X store streams
+    // inside one region class of HBM share ~6 TB/s and streams in different classes reach ~7.2 (memory_api.hip,
+    // profiles/r03_alloc.md): the ONE output array of a launch that lies across a class boundary (kmers_dev_alloc_role) is then
+    // written 6-7 % faster at the launch shape that suits two windows (C3 0.81 -> 0.87, profiles/r03_tuning.md section 5; at the
+    // one-window shape: nothing).  The two arrays of a two-output launch are better off in two different classes with one window
+    // each (-1..4 % with four windows), which is what the context's arena arranges.
     const uint64_t n_visits = (a.n_tiles + S - 1) / S, n_first = (n_visits + 1) >> 1;
     const uint64_t n_slots = a.split_order ? 2 * n_first : n_visits;
     for (uint64_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {

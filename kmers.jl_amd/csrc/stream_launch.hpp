@@ -137,7 +137,8 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     a.stamps = reinterpret_cast<uint64_t *>(ctx->stamps_ptr);
     uint64_t cap = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)1 << 30;
     const uint64_t visits = (a.n_tiles + a.subtiles - 1) / a.subtiles;
-    // two write windows per output array (stream_kernel.hpp, SPLIT ORDER): opt-in, see KMERS_PARAM_SPLIT_ORDER
+    // two write windows per output array (stream_kernel.hpp, SPLIT ORDER): for a lone output across a class boundary, or when
+    // KMERS_PARAM_SPLIT_ORDER asks for it everywhere
     a.split_order = visits >= 2 && ((materialises || MODE == MODE_MINIMIZER) && ctx->split_order > 0 || lone) ? 1u : 0u;
     const uint64_t slots = a.split_order ? 2 * ((visits + 1) / 2) : visits;
     dim3 grid((unsigned)std::min<uint64_t>(slots, cap));
