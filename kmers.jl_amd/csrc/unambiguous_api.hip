@@ -61,7 +61,8 @@ void launch_unambiguous(kmers_ctx *ctx, int src_bits, int nw, dim3 grid, const U
 }
 
 // longest kmer the single-pass kernel stages (a tile and its K-1 symbols of overlap must fit the LDS stream)
-constexpr int UNAMB_MAX_K = (int)UTILE_MAX - 2048;
+constexpr int UNAMB_MAX_K = 30720;
+static_assert(UNAMB_MAX_K <= (int)UTILE_MAX - 2048, "a tile and its K - 1 symbols of overlap must fit the LDS stream");
 uint32_t unambiguous_tile(kmers_ctx *ctx, int k) {
     // candidate starts per tile: a multiple of 1024 (one wavefront round), at most UTILE_MAX.  Long tiles keep the rate of
     // tile descriptors low enough for the look-back; very long kmers leave room for their overlap.
@@ -157,7 +158,7 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         a.out_starts = d_s;
         a.capacity = dev ? capacity : total;
         a.vec16 = ((!d_k || aligned16(d_k)) && (!d_s || aligned16(d_s))) ? 1u : 0u;
-        // a persistent grid: every workgroup draws tickets until none is left (UNAMB_EMIT_WGS = six workgroups per CU, 24.2 KiB
+        // a persistent grid: every workgroup draws tickets until none is left (UNAMB_EMIT_WGS = four workgroups per CU, 36 KiB
         // of LDS and 80 VGPRs each; the kernel's time falls with every resident workgroup, profiles/r02_tuning.md section 6)
         dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, std::min<uint64_t>(cap_grid, (uint64_t)ctx->n_cus * UNAMB_EMIT_WGS)));
         launch_unambiguous<UMODE_EMIT>(ctx, seq->src_bits, nw, grid, a);

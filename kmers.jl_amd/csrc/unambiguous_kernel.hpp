@@ -16,7 +16,7 @@
 //   emit     every wavefront lists the kept starts of 1024-2048 candidates at a time in LDS (their order is the reference's)
 //            and works the list off with every lane busy: window cut + contiguous stores.  A stretch with nothing dropped
 //            (real sequence outside its N blocks) skips the list: two kmers per lane, 16-byte stores.
-//   pipeline the grid is persistent (six workgroups per CU) and a workgroup runs the first step of its NEXT tile before the
+//   pipeline the grid is persistent (four workgroups per CU) and a workgroup runs the first step of its NEXT tile before the
 //            last two of the current one, so that an aggregate is out microseconds after its ticket.  Between the two a
 //            tile's keep mask and prefix counts stay in the registers of the lanes that resolved them; its codes in LDS.
 //
@@ -28,8 +28,11 @@
 
 namespace kmers {
 
+// 49152-start tiles, four workgroups per CU (36 KiB of LDS each): late in round 3, with the outputs in two region classes, fewer
+// and longer tiles win -- K = 31 0.71 -> 0.73, the stride-3 lattice 0.58 -> 0.61 of 8 TB/s; 6 x 32768 (rounds 2-3), 5 x 40960 and
+// 3 x 65536 run the same, 7 x 28672, 8 x 24576 and 2 x 98304 lose (profiles/r03_tuning.md, tools/r3_unamb_occupancy.sh)
 #ifndef KMERS_UTILE_MAX
-#define KMERS_UTILE_MAX 32768
+#define KMERS_UTILE_MAX 49152
 #endif
 constexpr uint32_t UTILE_MAX = KMERS_UTILE_MAX;  // candidate starts per tile (a multiple of 1024), at most
 #ifndef KMERS_UROUND
@@ -59,9 +62,9 @@ constexpr uint32_t ULSTRIDE = ULIST + UFRAME;  // list entries per wavefront: a 
 static_assert(ULIST >= UROUND, "a short round may keep every one of its starts");
 static_assert(ULONG % UROUND == 0 && (ULONG == 1024 || ULONG == 2048 || ULONG == 4096) && 64 % USLICE == 0, "a lane's slice of a round lies in one keep-mask qword");
 #ifndef KMERS_UNAMB_WGS
-#define KMERS_UNAMB_WGS 6
+#define KMERS_UNAMB_WGS 4
 #endif
-constexpr int UNAMB_EMIT_WGS = KMERS_UNAMB_WGS;  // workgroups per CU of the emitting mode (24.2 KiB of LDS each, 80 VGPRs)
+constexpr int UNAMB_EMIT_WGS = KMERS_UNAMB_WGS;  // workgroups per CU of the emitting mode (36 KiB of LDS each)
 constexpr uint64_t DESC_VALUE = (1ull << 62) - 1ull;
 constexpr uint64_t DESC_AGGREGATE = 1ull << 62, DESC_PREFIX = 2ull << 62;
 constexpr int LOOKBACK = 4;               // descriptors per lane and look-back step (256 tiles per step)
