@@ -122,6 +122,12 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     if (MODE == MODE_MINIMIZER) max_tile_symbols -= std::min<uint32_t>(max_tile_symbols / 2, a.window_kmers);  // room for the longer overlap
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
     if (ctx->tile_kmers <= 0 && spread) tile = tile * 3 / 2 / pass * pass;  // 24 KiB per workgroup (see above)
+    // two-word kmers + their reverse complements (C4) in two well-placed arrays: 12 KiB of each per workgroup instead of 8 --
+    // 0.886-0.901 in four fresh processes against 0.867-0.873 (64 threads x 4 KiB run the same; 128 threads lose;
+    // tools/r3_c4_shapes.sh); in one class the shorter tile stays (0.86 against 0.81-0.84, profiles/r03_tuning.md section 2)
+    if (ctx->tile_kmers <= 0 && n_words == 2 && stride1 && !a.tuples && MODE == MODE_FW && a.out_a && a.out_b &&
+        kmers_arena_spread(ctx->arena, a.out_a, a.out_b, (size_t)a.n_kmers * 16u))
+        tile = tile * 3u / 2u / pass * pass;
     if (ctx->tile_kmers <= 0 && lone && a.tuples) tile *= 6u;                // tuple arrays through two windows (see above)
     if (ctx->tile_kmers <= 0 && lone && J > 1 && !a.tuples) tile = tile * 5u / 2u;  // strided: 40 KiB per workgroup (clamped below)
     // (round 2 doubled the tile of strided launches -- 32 KiB of output per workgroup; with two lattice kmers per lane the 16 KiB
