@@ -43,17 +43,22 @@ inline size_t kmers_arena_run_of(const kmers_arena &a, size_t off) {
 // true iff two arrays of `bytes` bytes at p and q both lie in the arena and the MEASURED two-stream rate of the runs they pass
 // through side by side (sampled at eight points: an array may be longer than a run) averages within 5 % of the best pair of
 // the block: the launchers pick the launch shape that is fastest for well-placed outputs only then (stream_launch.hpp)
-inline bool kmers_arena_spread(const kmers_arena &a, const void *p, const void *q, size_t bytes) {
-    if (a.run_start.empty() || !p || !q || bytes == 0) return false;
+// (arrays of different lengths -- two-word kmers and their one-word hashes -- are compared at the same RELATIVE places: that is
+// where a launch writes them at the same time)
+inline bool kmers_arena_spread(const kmers_arena &a, const void *p, size_t bytes_p, const void *q, size_t bytes_q) {
+    if (a.run_start.empty() || !p || !q || bytes_p == 0 || bytes_q == 0) return false;
     const char *cp = static_cast<const char *>(p), *cq = static_cast<const char *>(q);
-    if (cp < a.base || cp + bytes > a.base + a.bytes || cq < a.base || cq + bytes > a.base + a.bytes) return false;
+    if (cp < a.base || cp + bytes_p > a.base + a.bytes || cq < a.base || cq + bytes_q > a.base + a.bytes) return false;
     const size_t k = a.run_start.size();
     float sum = 0.f;
     for (int i = 0; i < 8; ++i) {
-        const size_t t = (size_t)((2 * i + 1) * (double)bytes / 16.0);
-        sum += a.pair_rate[kmers_arena_run_of(a, (size_t)(cp - a.base) + t) * k + kmers_arena_run_of(a, (size_t)(cq - a.base) + t)];
+        const size_t tp = (size_t)((2 * i + 1) * (double)bytes_p / 16.0), tq = (size_t)((2 * i + 1) * (double)bytes_q / 16.0);
+        sum += a.pair_rate[kmers_arena_run_of(a, (size_t)(cp - a.base) + tp) * k + kmers_arena_run_of(a, (size_t)(cq - a.base) + tq)];
     }
     return sum / 8.f >= 0.95f * a.best_pair_rate;
+}
+inline bool kmers_arena_spread(const kmers_arena &a, const void *p, const void *q, size_t bytes) {
+    return kmers_arena_spread(a, p, bytes, q, bytes);
 }
 
 // true iff the array of `bytes` bytes at p lies in the arena ACROSS a class boundary, so that its two halves -- the two write

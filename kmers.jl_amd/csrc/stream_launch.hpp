@@ -110,7 +110,14 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
                       kmers_arena_straddles(ctx->arena, a.out_a, (size_t)a.n_kmers * lone_bytes);
     // (strided lone outputs -- C5's SpacedKmers -- want the opposite shape: 256 threads and the longest tile the LDS stream holds,
     // 40 KiB of output per workgroup at J = 3: 0.788-0.804 against 0.765-0.772 at 128 x 16 KiB, tools/r3_c5_fine.sh)
-    uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads : ((spread || (lone && !a.tuples && J == 1)) ? 128u : (uint32_t)BLOCK);
+    // Two-word canonical kmers + their hashes (CanonicalDNAMers{33..64} + fx_hash: 24 bytes per kmer in two arrays).  The 16 KiB
+    // rule rounds to 256 x 512 = 12 KiB per workgroup here and that is the worst shape measured: 0.69-0.72 in every placement
+    // (tools/r3_c2_shapes.sh with LEG=c63h, tools/r3_c63h_plain.sh).  128 threads x 512 kmers: 0.80-0.82 with both arrays in one
+    // class, 0.82-0.85 elsewhere; 128 x 768 with the arrays well placed: 0.87-0.88 (and 0.65 in one class: only when the map says so).
+    const bool canon2 = MODE == MODE_CANON && n_words == 2 && stride1 && !a.tuples && a.out_a && a.out_b;
+    const bool canon2_spread = canon2 && kmers_arena_spread(ctx->arena, a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u);
+    uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads
+                                              : ((spread || canon2 || (lone && !a.tuples && J == 1)) ? 128u : (uint32_t)BLOCK);
     if (threads != 64u && threads != 128u) threads = (uint32_t)BLOCK;
     const uint32_t pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * threads;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
@@ -128,6 +135,7 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     if (ctx->tile_kmers <= 0 && n_words == 2 && stride1 && !a.tuples && MODE == MODE_FW && a.out_a && a.out_b &&
         kmers_arena_spread(ctx->arena, a.out_a, a.out_b, (size_t)a.n_kmers * 16u))
         tile = tile * 3u / 2u / pass * pass;
+    if (ctx->tile_kmers <= 0 && canon2) tile = canon2_spread ? 768u : 512u;      // (see above)
     if (ctx->tile_kmers <= 0 && lone && a.tuples) tile *= 6u;                // tuple arrays through two windows (see above)
     if (ctx->tile_kmers <= 0 && lone && J > 1 && !a.tuples) tile = tile * 5u / 2u;  // strided: 40 KiB per workgroup (clamped below)
     // (round 2 doubled the tile of strided launches -- 32 KiB of output per workgroup; with two lattice kmers per lane the 16 KiB
