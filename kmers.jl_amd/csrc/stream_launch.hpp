@@ -114,8 +114,12 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     // rule rounds to 256 x 512 = 12 KiB per workgroup here and that is the worst shape measured: 0.69-0.72 in every placement
     // (tools/r3_c2_shapes.sh with LEG=c63h, tools/r3_c63h_plain.sh).  128 threads x 512 kmers: 0.80-0.82 with both arrays in one
     // class, 0.82-0.85 elsewhere; 128 x 768 with the arrays well placed: 0.87-0.88 (and 0.65 in one class: only when the map says so).
-    const bool canon2 = MODE == MODE_CANON && n_words == 2 && stride1 && !a.tuples && a.out_a && a.out_b;
-    const bool canon2_spread = canon2 && kmers_arena_spread(ctx->arena, a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u);
+    // Four-word kmers + hashes (40 bytes per kmer; the rule gives 256 x 256): 0.58 -> 0.69 at 128 x 512 (0.65 at 256 x 512, 0.68 at
+    // 64 x 256; three fresh processes each), where the canonical comparison of four-word kmers is most of what is left; three-word
+    // kmers take the same shape unmeasured.
+    const bool canon2 = MODE == MODE_CANON && n_words >= 2 && stride1 && !a.tuples && a.out_a && a.out_b;
+    const bool canon2_spread = canon2 && n_words == 2 &&
+                               kmers_arena_spread(ctx->arena, a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u);
     uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads
                                               : ((spread || canon2 || (lone && !a.tuples && J == 1)) ? 128u : (uint32_t)BLOCK);
     if (threads != 64u && threads != 128u) threads = (uint32_t)BLOCK;
