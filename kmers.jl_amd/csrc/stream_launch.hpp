@@ -136,9 +136,11 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     // two-word kmers + their reverse complements (C4) in two well-placed arrays: 12 KiB of each per workgroup instead of 8 --
     // 0.886-0.901 in four fresh processes against 0.867-0.873 (64 threads x 4 KiB run the same; 128 threads lose;
     // tools/r3_c4_shapes.sh); in one class the shorter tile stays (0.86 against 0.81-0.84, profiles/r03_tuning.md section 2)
-    if (ctx->tile_kmers <= 0 && n_words == 2 && stride1 && !a.tuples && MODE == MODE_FW && a.out_a && a.out_b &&
-        kmers_arena_spread(ctx->arena, a.out_a, a.out_b, (size_t)a.n_kmers * 16u))
-        tile = tile * 3u / 2u / pass * pass;
+    // (four-word kmers + reverse complements, 64 bytes per kmer: 256 x 512 = 16 KiB of each array 0.798-0.802 against 0.751-0.756
+    // at the rule's 256 x 256; 128 x 512 0.771-0.778; three-word kmers take 512 too, unmeasured)
+    if (ctx->tile_kmers <= 0 && n_words >= 2 && stride1 && !a.tuples && MODE == MODE_FW && a.out_a && a.out_b &&
+        kmers_arena_spread(ctx->arena, a.out_a, a.out_b, (size_t)a.n_kmers * 8u * (size_t)n_words))
+        tile = n_words == 2 ? tile * 3u / 2u / pass * pass : 512u;
     if (ctx->tile_kmers <= 0 && canon2) tile = canon2_spread ? 768u : 512u;      // (see above)
     if (ctx->tile_kmers <= 0 && lone && a.tuples) tile *= 6u;                // tuple arrays through two windows (see above)
     if (ctx->tile_kmers <= 0 && lone && J > 1 && !a.tuples) tile = tile * 5u / 2u;  // strided: 40 KiB per workgroup (clamped below)

@@ -74,11 +74,11 @@ L = 1_250_000_000 if leg == "c3" else args.bases
 bits = 2 if leg == "c3" else 4
 amb = 2621 if leg in ("u31", "u21") else 0
 seed = {"c2": 2, "c3": 3, "c4": 4, "c4t": 4, "c5": 5, "u31": 5, "u21": 5}.get(leg, 5)
-K = {"c63": 63, "c127h": 127, "c63h": 63, "f3": 31, "c2": 31, "c3": 31, "c4": 63, "c4t": 63, "c5": 21, "u31": 31, "u21": 21, "xor": 31, "minhash": 16, "comp8": 8}[leg]
+K = {"f127": 127, "c63": 63, "c127h": 127, "c63h": 63, "f3": 31, "c2": 31, "c3": 31, "c4": 63, "c4t": 63, "c5": 21, "u31": 31, "u21": 21, "xor": 31, "minhash": 16, "comp8": 8}[leg]
 J = 3 if leg in ("c5", "u21") else 1
 n = (L - K) // J + 1
-words_a = {"c63": 2 * n, "c127h": 4 * n, "c63h": 2 * n, "f3": 2 * n, "c2": n, "c3": n, "c4": 2 * n, "c4t": 4 * n, "c5": n, "u31": n, "u21": n}.get(leg, 1 << 16)
-words_b = {"c127h": n, "c63h": n, "c2": n, "c4": 2 * n, "u31": n, "u21": n}.get(leg, 0)
+words_a = {"f127": 4 * n, "c63": 2 * n, "c127h": 4 * n, "c63h": 2 * n, "f3": 2 * n, "c2": n, "c3": n, "c4": 2 * n, "c4t": 4 * n, "c5": n, "u31": n, "u21": n}.get(leg, 1 << 16)
+words_b = {"f127": 4 * n, "c127h": n, "c63h": n, "c2": n, "c4": 2 * n, "u31": n, "u21": n}.get(leg, 0)
 
 mode, _, size = args.alloc.partition(":")
 size = int(size or 0)
@@ -138,6 +138,7 @@ if leg in ("u31", "u21"):
 calls = {
     "c2": lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, pa, pb, 0, ASYNC, C.byref(res)),
     "c3": lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, pa, None, 0, ASYNC, C.byref(res)),
+    "f127": lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, pa, pb, ASYNC, C.byref(res)),   # four-word kmers + reverse complements
     "c63": lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, pa, None, 0, ASYNC, C.byref(res)),           # two-word canonical kmers, one array
     "c127h": lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, pa, pb, 0, ASYNC, C.byref(res)),            # four-word canonical kmers + hashes
     "c63h": lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, pa, pb, 0, ASYNC, C.byref(res)),   # two-word canonical kmers + hashes
@@ -151,7 +152,7 @@ calls = {
     "minhash": lambda: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, 2, 0, 1000, sk.ctypes.data_as(C.c_void_p), cap.MEM_DEVICE, C.byref(res)),
     "comp8": lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), K, pa, cap.MEM_DEVICE, C.byref(res)),
 }
-alg = {"c63": 16.5 * n, "c127h": 40.5 * n, "c63h": 24.5 * n, "f3": 16.5 * n, "c2": 16.5 * n, "c3": 8.25 * n, "c4": 32.5 * n, "c4t": 32.5 * n, "c5": 0.5 * L + 8.0 * n,
+alg = {"f127": 64.5 * n, "c63": 16.5 * n, "c127h": 40.5 * n, "c63h": 24.5 * n, "f3": 16.5 * n, "c2": 16.5 * n, "c3": 8.25 * n, "c4": 32.5 * n, "c4t": 32.5 * n, "c5": 0.5 * L + 8.0 * n,
        "u31": 0.5 * L + 16.0 * m_kept, "u21": 0.5 * L + 16.0 * m_kept}.get(leg)
 
 
