@@ -109,7 +109,12 @@ inline void arena_commit(kmers_arena &a, std::map<size_t, size_t>::iterator rang
 // against its two arrays in two different classes, profiles/r03_alloc.md; the array that is the ONLY output of its launches is
 // the one that gains -- arena_take_straddling below, asked for by role.)
 inline bool arena_take(kmers_arena &a, size_t need, size_t *off_out) {
-    if (!a.run_start.empty()) {
+    // A block of a quarter of the arena or more (the 80 GB arrays of a 10 Gbase launch) is not put inside one run even where one
+    // would hold it: the FIRST goes to the bottom of the block, which leaves the next one the whole rest to choose from, and the
+    // next is placed by the sampled search below (on a box with the map A16 B24 C13 the first array inside B left the second
+    // 71 % of its length beside another class; bottom + search: all of it).
+    const bool huge = need >= a.bytes / 4;
+    if (!a.run_start.empty() && !huge) {
         auto best_range = a.free_ranges.end();
         size_t best_off = 0, best_slack = 0;
         float best_score = -1.f;
@@ -184,7 +189,11 @@ inline bool arena_take(kmers_arena &a, size_t need, size_t *off_out) {
             }
         }
         const float end_score = best_score;
-        for (auto it = a.free_ranges.begin(); it != a.free_ranges.end(); ++it) {
+        // (a place inside a range splits it: only when no further block of this size would fit into the arena anyway)
+        size_t free_total = 0;
+        for (const auto &f : a.free_ranges) free_total += f.second;
+        const bool may_split = free_total - need < need;
+        for (auto it = a.free_ranges.begin(); may_split && it != a.free_ranges.end(); ++it) {
             if (it->second < need) continue;
             const size_t lo = it->first, hi = (it->first + it->second - need) / GRANULE * GRANULE;
             for (size_t off = lo + REGION / 2; off < hi; off += REGION / 2) {

@@ -150,6 +150,21 @@ int main() {
         size_t src;
         EXPECT(take(a, 5 * GiB, &src));   // the sequence still fits
     }
+    {  // ---- the same on a COARSE map where one run could hold the first block: A 64, B 96, C 52 GiB (a box of round 3)
+        kmers_arena a = fresh(212 * GiB);
+        set_map(a, {{0, 0}, {64, 1}, {160, 2}});
+        const size_t need = round_up((size_t)80 * 1000 * 1000 * 1000);
+        size_t first, second, src;
+        EXPECT(take(a, need, &first) && first == 0);          // not inside B: the bottom of the block
+        EXPECT(take(a, need, &second));
+        int same = 0;
+        for (int i = 0; i < 64; ++i) {
+            const size_t t = (size_t)((2 * i + 1) * (double)need / 128.0);
+            same += class_at(a, first + t) == class_at(a, second + t);
+        }
+        EXPECT(same == 0);                                     // [0, 74.5) = A, B against [138.5, 213) = B, C: never the same class
+        EXPECT(take(a, 5 * GiB, &src));
+    }
     {  // ---- invariants under a random sequence of requests (with a fragmented map)
         kmers_arena a = fresh(96 * GiB + 6 * MiB);
         set_map(a, {{0, 0}, {16, 1}, {20, 0}, {40, 2}, {72, 1}, {80, 0}});
