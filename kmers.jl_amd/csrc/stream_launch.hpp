@@ -87,41 +87,41 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
 #else
     const bool fwd = MODE == MODE_FW && dst_bits == 2 && !a.out_b && !a.tuples;  // no reverse complements wanted
 #endif
-    // Launch shape of the two-output, one-word-element launches (canonical kmers + hashes -- the headline --, forward + reverse
-    // complements, forward kmers + start indices), measured in round 3 (profiles/r03_tuning.md, 1 Gbase, fresh processes):
-    //   * the two arrays in well-separated region classes of HBM -- which the launcher knows for blocks of the context's arena
-    //     (kmers_arena_spread) --: 24 KiB of output per workgroup (1536 kmers) and workgroups of 128 threads: 0.876-0.895 of
-    //     8 TB/s against 0.819-0.840 with round 2's 16 KiB x 256 and 0.866-0.872 with 24 KiB x 256;
-    //   * anything else (two plain allocations, one region class): 16 KiB x 256 threads stays: 0.788-0.801 in six processes, where
-    //     24 KiB is bimodal (0.727-0.728 in three of them, 0.79-0.81 in the others) and 128 threads lose 3-5 %.
-    // Every other shape keeps 16 KiB and 256 threads (C3 0.80-0.82 / 0.72-0.77 with 128, C4 0.87 at 512 x 256 in both
-    // placements, C5 0.75-0.76 / 0.72-0.76).
-    const bool two_word_streams = n_words == 1 && stride1 && !a.tuples && a.out_a && (a.out_b || a.out_starts) &&
-                                  (MODE == MODE_FW || MODE == MODE_CANON);
-    const bool spread = two_word_streams && kmers_arena_spread(ctx->arena, a.out_a, a.out_b ? (const void *)a.out_b : (const void *)a.out_starts,
-                                                                  (size_t)a.n_kmers * 8u);
-    // ONE output array that lies across a class boundary of the arena (kmers_dev_alloc_role(KMERS_ALLOC_LONE_OUTPUT)): written
-    // through two windows, one per class (split order), by workgroups of 128 threads -- C3 0.80-0.82 -> 0.867-0.870, a two-word
-    // kmer array 0.80 -> 0.856, C5 0.75 -> 0.77; a tuple array (32-byte elements) 0.61 -> 0.82-0.83 with 256 threads and six times
-    // the tile (profiles/r03_tuning.md section 5; three fresh processes each)
+    // ---- launch shape: threads per workgroup and kmers per tile (one tile per workgroup) -----------------------------------
+    // The base rule (round 1): about 16 KiB of output per workgroup, 256 threads.  Round 3 measured every shape below against
+    // it with the outputs in KNOWN places (profiles/r03_tuning.md sections 2, 5, 6, 7; fractions of 8 TB/s, fresh processes):
+    //
+    //   launch                                            | placement the launcher sees          | threads x kmers      | gain
+    //   one-word elements, two arrays (C2 headline, FwRv, | well placed (kmers_arena_spread)     | 128 x 1536 (24 KiB)  | 0.82-0.84 -> 0.88-0.90
+    //     kmers + starts)                                 | anything else                        | 256 x 1024 (rule)    | (24 KiB bimodal there)
+    //   two-word kmers + reverse complements (C4)         | well placed                          | 256 x 768            | 0.87 -> 0.90-0.915
+    //   three- / four-word kmers + reverse complements    | well placed                          | 256 x 512            | 0.75 -> 0.80 (four-word)
+    //   two-word canonical kmers + hashes                 | well placed                          | 128 x 768            | 0.71 -> 0.87-0.88
+    //                                                     | anything else                        | 128 x 512            | 0.70 -> 0.80-0.85
+    //   three- / four-word canonical kmers + hashes       | any                                  | 128 x 512            | 0.58 -> 0.69 (four-word)
+    //   ONE output array across a class boundary of the   | kmers_arena_straddles                | 128 x 16 KiB, split  | C3 0.81 -> 0.87, two-word 0.80 -> 0.86
+    //     arena (kmers_dev_alloc_role LONE_OUTPUT)        |   ... strided (SpacedKmers, C5)      | 256 x 40 KiB, split  | 0.75 -> 0.78-0.79
+    //                                                     |   ... tuple elements                 | 256 x 6 x rule, split| 0.61 -> 0.82-0.83
+    //   everything else                                   |                                      | 256 x rule           |
+    //
+    // "well placed" = both arrays inside the context's arena, in runs whose MEASURED two-stream rate is within 5 % of the block's
+    // best pair; "split" = two write windows half an array apart (stream_kernel.hpp, SPLIT ORDER).  KMERS_PARAM_TILE_KMERS /
+    // _BLOCK_THREADS / _SPLIT_ORDER override the table (tests, tools/).
     const bool materialises = MODE == MODE_FW || MODE == MODE_CANON;
+    const bool two_arrays = materialises && stride1 && a.out_a && !a.tuples;
+    const bool one_word_pair = two_arrays && n_words == 1 && (a.out_b || a.out_starts);
+    const bool spread = one_word_pair && kmers_arena_spread(ctx->arena, a.out_a, a.out_b ? (const void *)a.out_b : (const void *)a.out_starts,
+                                                            (size_t)a.n_kmers * 8u);
+    const bool fwrc_wide = two_arrays && MODE == MODE_FW && n_words >= 2 && a.out_b &&
+                           kmers_arena_spread(ctx->arena, a.out_a, a.out_b, (size_t)a.n_kmers * 8u * (size_t)n_words);
+    const bool canon_wide = two_arrays && MODE == MODE_CANON && n_words >= 2 && a.out_b;
+    const bool canon2_spread = canon_wide && n_words == 2 &&
+                               kmers_arena_spread(ctx->arena, a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u);
     const uint32_t lone_bytes = a.tuples ? (MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u) : 8u * n_words;
     const bool lone = materialises && ctx->split_order >= 0 && a.out_a && !a.out_b && !a.out_starts &&
                       kmers_arena_straddles(ctx->arena, a.out_a, (size_t)a.n_kmers * lone_bytes);
-    // (strided lone outputs -- C5's SpacedKmers -- want the opposite shape: 256 threads and the longest tile the LDS stream holds,
-    // 40 KiB of output per workgroup at J = 3: 0.788-0.804 against 0.765-0.772 at 128 x 16 KiB, tools/r3_c5_fine.sh)
-    // Two-word canonical kmers + their hashes (CanonicalDNAMers{33..64} + fx_hash: 24 bytes per kmer in two arrays).  The 16 KiB
-    // rule rounds to 256 x 512 = 12 KiB per workgroup here and that is the worst shape measured: 0.69-0.72 in every placement
-    // (tools/r3_c2_shapes.sh with LEG=c63h, tools/r3_c63h_plain.sh).  128 threads x 512 kmers: 0.80-0.82 with both arrays in one
-    // class, 0.82-0.85 elsewhere; 128 x 768 with the arrays well placed: 0.87-0.88 (and 0.65 in one class: only when the map says so).
-    // Four-word kmers + hashes (40 bytes per kmer; the rule gives 256 x 256): 0.58 -> 0.69 at 128 x 512 (0.65 at 256 x 512, 0.68 at
-    // 64 x 256; three fresh processes each), where the canonical comparison of four-word kmers is most of what is left; three-word
-    // kmers take the same shape unmeasured.
-    const bool canon2 = MODE == MODE_CANON && n_words >= 2 && stride1 && !a.tuples && a.out_a && a.out_b;
-    const bool canon2_spread = canon2 && n_words == 2 &&
-                               kmers_arena_spread(ctx->arena, a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u);
     uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads
-                                              : ((spread || canon2 || (lone && !a.tuples && J == 1)) ? 128u : (uint32_t)BLOCK);
+                                              : ((spread || canon_wide || (lone && !a.tuples && J == 1)) ? 128u : (uint32_t)BLOCK);
     if (threads != 64u && threads != 128u) threads = (uint32_t)BLOCK;
     const uint32_t pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * threads;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
@@ -132,20 +132,14 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     uint32_t max_tile_symbols = (uint32_t)MAX_TILE_BITS / (uint32_t)dst_bits;
     if (MODE == MODE_MINIMIZER) max_tile_symbols -= std::min<uint32_t>(max_tile_symbols / 2, a.window_kmers);  // room for the longer overlap
     uint32_t tile = ctx->tile_kmers > 0 ? (uint32_t)ctx->tile_kmers : default_tile(out_bytes, pass);
-    if (ctx->tile_kmers <= 0 && spread) tile = tile * 3 / 2 / pass * pass;  // 24 KiB per workgroup (see above)
-    // two-word kmers + their reverse complements (C4) in two well-placed arrays: 12 KiB of each per workgroup instead of 8 --
-    // 0.886-0.901 in four fresh processes against 0.867-0.873 (64 threads x 4 KiB run the same; 128 threads lose;
-    // tools/r3_c4_shapes.sh); in one class the shorter tile stays (0.86 against 0.81-0.84, profiles/r03_tuning.md section 2)
-    // (four-word kmers + reverse complements, 64 bytes per kmer: 256 x 512 = 16 KiB of each array 0.798-0.802 against 0.751-0.756
-    // at the rule's 256 x 256; 128 x 512 0.771-0.778; three-word kmers take 512 too, unmeasured)
-    if (ctx->tile_kmers <= 0 && n_words >= 2 && stride1 && !a.tuples && MODE == MODE_FW && a.out_a && a.out_b &&
-        kmers_arena_spread(ctx->arena, a.out_a, a.out_b, (size_t)a.n_kmers * 8u * (size_t)n_words))
-        tile = n_words == 2 ? tile * 3u / 2u / pass * pass : 512u;
-    if (ctx->tile_kmers <= 0 && canon2) tile = canon2_spread ? 768u : 512u;      // (see above)
-    if (ctx->tile_kmers <= 0 && lone && a.tuples) tile *= 6u;                // tuple arrays through two windows (see above)
-    if (ctx->tile_kmers <= 0 && lone && J > 1 && !a.tuples) tile = tile * 5u / 2u;  // strided: 40 KiB per workgroup (clamped below)
-    // (round 2 doubled the tile of strided launches -- 32 KiB of output per workgroup; with two lattice kmers per lane the 16 KiB
-    // tile is as fast or faster on every box measured in round 3: 0.73-0.76 against 0.70-0.74, profiles/r03_tuning.md)
+    if (ctx->tile_kmers <= 0) {  // the table above
+        if (spread) tile = tile * 3u / 2u / pass * pass;
+        else if (fwrc_wide) tile = n_words == 2 ? tile * 3u / 2u / pass * pass : 512u;
+        else if (canon_wide) tile = canon2_spread ? 768u : 512u;
+        else if (lone && a.tuples) tile *= 6u;
+        else if (lone && J > 1) tile = tile * 5u / 2u;  // (clamped to what the LDS stream holds below: 5120 kmers at J = 3)
+    }
+    // (strided launches in ONE class: round 2's 32 KiB tile lost to 16 KiB on every box of round 3, 0.70-0.74 against 0.73-0.76)
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);
     tile = std::max<uint32_t>(pass, tile / pass * pass);
     if ((uint64_t)(tile - 1) * J + 1 > (uint64_t)max_tile_symbols) return fail(ctx, KMERS_E_UNSUPPORTED, "stride too large for the tile kernel");
