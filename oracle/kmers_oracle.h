@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ORC_MAX_N 8 /* words per kmer supported by the oracle (K <= 256 2-bit) */
+#define ORC_MAX_N 64 /* words per kmer supported by the oracle (K <= 2048 2-bit, K <= 1024 4-bit) */
 
 /* src_bps codes for AsciiEncode sources: `seq` is then a byte string (1 byte per symbol) and the
  * validity table is the one of the KMER's alphabet (DNA: T, RNA: U). */

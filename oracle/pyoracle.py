@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ORC_MAX_N = 8
+ORC_MAX_N = 64
 OK, E_ENCODE, E_BADARG = 0, 1, 2
 
 

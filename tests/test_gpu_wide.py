@@ -38,8 +38,10 @@ def source_words(text, src):
     return naive.ascii_words(text) if src == 8 else naive.longseq_words(text if text else "A", src)
 
 
-# (source bits, kmer alphabet bits, K): every RecodingScheme, five to eight words
-WIDE = [(2, 2, 129), (2, 2, 256), (4, 2, 160), (4, 2, 255), (4, 4, 65), (4, 4, 128), (2, 4, 100), (8, 2, 130), (8, 4, 70)]
+# (source bits, kmer alphabet bits, K): every RecodingScheme, five to eight words and -- the oracle goes to 64 words, checked
+# against the naive slicer in tests/test_oracle_property.py -- 19, 32 and 63
+WIDE = [(2, 2, 129), (2, 2, 256), (4, 2, 160), (4, 2, 255), (4, 4, 65), (4, 4, 128), (2, 4, 100), (8, 2, 130), (8, 4, 70),
+        (4, 2, 600), (2, 4, 512), (8, 2, 2001)]
 
 
 def test_transforms_of_wide_kmers(km, ctx, orc):
@@ -48,10 +50,10 @@ def test_transforms_of_wide_kmers(km, ctx, orc):
     vs text operations; overlapping device arrays."""
     cap = km._capi
     rng = np.random.default_rng(8)
-    for bits, ks in ((2, (129, 160, 200, 255, 256)), (4, (65, 80, 100, 127, 128))):
+    for bits, ks in ((2, (129, 160, 200, 255, 256, 1000, 2048)), (4, (65, 80, 100, 127, 128, 333, 1024))):
         for K in ks:
             N = (K * bits + 63) // 64
-            assert 4 < N <= 8
+            assert 4 < N <= 64
             n = 257
             texts = [naive.random_text(rng, K, p_amb=0.2 if bits == 4 else 0.0) for _ in range(n)]
             texts[0] = ("ACGT" * K)[:K // 2] + naive.revcomp_text(("ACGT" * K)[:K // 2]) + ("" if K % 2 == 0 else "A")  # (nearly) its own reverse complement
@@ -102,7 +104,7 @@ def test_tuple_layouts_of_wide_kmers(km, ctx, orc):
     rng = np.random.default_rng(9)
     for src, dst, K in WIDE:
         N = (K * dst + 63) // 64
-        for L in (K, K + 1, 1777):
+        for L in (K, K + 1, max(1777, K + 300)):
             text = naive.random_text(rng, L, p_amb=0.05 if dst == 4 and src != 2 else 0.0)
             words = source_words(text, src)
             seq = cap.Seq(words.ctypes.data, L, 0, 0, src, 0)
@@ -409,7 +411,7 @@ def test_tile_form_at_every_tile_length(km, orc):
             for tile in (1, 7, 64, 333, 5000):
                 ctx.set_param(cap.PARAM_TILE_KMERS, tile)
                 first = int(rng.choice([0, 1, 5, 15, 16, 31, 32, 33, 63, 64, 100]))
-                L = int(rng.choice([K, K + 1, K + 63, 1500, 4000])) if tile > 1 else int(rng.choice([K, K + 40]))
+                L = int(rng.choice([K, K + 1, K + 63, K + 1500, max(4000, K + 700)])) if tile > 1 else int(rng.choice([K, K + 40]))
                 text = naive.random_text(rng, first + L, p_amb=0.05 if dst == 4 and src != 2 else 0.0)
                 words = source_words(text, src)
                 view = source_words(text[first:], src)
@@ -450,7 +452,7 @@ def test_tile_form_at_every_tile_length(km, orc):
                     assert val.value == int(np.bitwise_xor.reduce(es[:, 0])), tag + (J,)
             if dst == 2 and src in (4, 8):
                 ctx.set_param(cap.PARAM_TILE_KMERS, 64)
-                L = 3000
+                L = max(3000, 3 * K + 400)
                 t = list(naive.random_text(rng, L))
                 t[2900], t[1234], t[1300] = "N", "R", "-"
                 words = source_words("".join(t), src)

@@ -215,3 +215,31 @@ def test_minimizers_definition(orc):
                         h, kmer = nh, nk
                 exp0.append(split(kmer))
             assert rows(got0) == exp0
+
+
+def test_oracle_at_many_words_matches_the_naive_slicer(orc):
+    """The oracle's width limit is 64 words (ORC_MAX_N): FwRvIterator, CanonicalKmers + fx_hash, SpacedKmers and UnambiguousKmers of
+    9 to 64 words against the independent big-integer slicer of tests/naive.py (the layout rule only, no shifting)."""
+    import naive
+    rng = np.random.default_rng(77)
+    for src, dst, K in ((2, 2, 289), (4, 2, 700), (4, 2, 2048), (4, 4, 300), (2, 4, 1024), (8, 2, 1000)):
+        L = K + 57
+        text = naive.random_text(rng, L, p_amb=0.02 if dst == 4 and src != 2 else 0.0)
+        words = naive.ascii_words(text) if src == 8 else naive.longseq_words(text, src)
+        f, r, res = orc.fwrv(words, L, src, dst, K)
+        assert res.status == 0
+        pairs = naive.fwrv(text, K, dst)
+        assert [tuple(int(x) for x in a) for a in f] == [tuple(a) for a, _ in pairs]
+        assert [tuple(int(x) for x in a) for a in r] == [tuple(b) for _, b in pairs]
+        k, h, _ = orc.canonical(words, L, src, dst, K, seed=9)
+        canon = naive.canonical(text, K, dst)
+        assert [tuple(int(x) for x in a) for a in k] == [tuple(c) for c in canon]
+        assert h.tolist() == [naive.fx_hash(list(c), 9) for c in canon]
+        s, _ = orc.spaced(words, L, src, dst, K, 7)
+        assert [tuple(int(x) for x in a) for a in s] == [tuple(a) for a in naive.spaced(text, K, 7, dst)]
+    text = "".join("N" if rng.random() < 0.002 else c for c in naive.random_text(rng, 6000))
+    words = naive.longseq_words(text, 4)
+    for K in (300, 1500):
+        uk, us, _ = orc.unambiguous(words, len(text), 4, K)
+        want = naive.unambiguous(text, K)
+        assert [tuple(int(x) for x in a) for a in uk] == [tuple(a) for a, _ in want] and us.tolist() == [i for _, i in want]
