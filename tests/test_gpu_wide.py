@@ -1,7 +1,7 @@
 """Kmers of more than four words through EVERY entry point.  Kmer{A,K,N} has no upper bound on N (src/kmer.jl:97-111:
 N = cld(K * bits_per_symbol, 64)); the tile kernels are compiled for N = 1..4, everything wider runs on run-time-width
 kernels (wide_kernel.hpp, transform_kernel_any, ragged_wide_kernel, record_sketch_kernel<.., 0, ..>).  Bit-exact against the
-oracle up to its eight words, against the independent big-integer slicer (tests/naive.py) beyond."""
+oracle (up to its 64 words), and against the independent big-integer slicer (tests/naive.py)."""
 import ctypes as C
 
 import numpy as np
