@@ -149,7 +149,7 @@ int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t
  *     each; tools/xcd_affinity.hip, profiles/r03_alloc.md) share about 6.0 TB/s, streams in different classes reach about 7.1:
  *     the two output arrays of one launch are two such streams, and where two plain allocations happen to lie decides whether
  *     FwDNAMers{63} + reverse complements runs at 0.72 or at 0.89 of 8 TB/s (canonical 31-mers + hashes: 0.80 or 0.855).
- *     kmers_arena_reserve measures the map of its block (about 0.1 s for 200 GB; only blocks of 16 GiB or more;
+ *     kmers_arena_reserve measures the map of its block (about 0.3 s for 200 GB; only blocks of 16 GiB or more;
  *     KMERS_PARAM_ARENA_NO_PROBE = 1 skips it) and kmers_dev_alloc places a block where the MEASURED two-stream rate beside the
  *     blocks that are live is highest (the previous allocation counting double): allocate the arrays of one launch one after
  *     the other and they end up in different classes.  kmers_arena_regions reports the map.  The launchers consult it too: two

@@ -102,6 +102,9 @@ def _link(objs, lib, verbose):
 def build(force=False, verbose=False):
     """Compile the HIP kernels + C ABI for gfx950 and link them with the HIP runtime (RCCL is bound lazily, comm_api.hip).
     Returns the path of the shared library."""
+    if not force and not stale():
+        # a tree that received the library without its objects (the GPU box: .gpurunignore drops csrc/build/): up to date as it is
+        return LIB
     jobs = [(s, _object(s), []) for s in SOURCES if force or _newer(_object(s), dependencies(s))]
     _compile(jobs, verbose)
     objs = [_object(s) for s in SOURCES]
@@ -112,9 +115,13 @@ def build(force=False, verbose=False):
 
 def build_variant(name, defines, units=None, out=None, force=False, verbose=False):
     """libkmers_hip_<name>.so: the product's objects with `units` (default: all) recompiled under the extra flags `defines`."""
-    build(verbose=verbose)
     units = list(units or SOURCES)
     out = out or os.path.join(CSRC, f"libkmers_hip_{name}.so")
+    if not force and not stale(out):
+        return out
+    build(verbose=verbose)
+    if any(not os.path.exists(_object(s)) for s in SOURCES):  # (the product came without its objects: compile them to link against)
+        build(force=True, verbose=verbose)
     jobs = [(s, _object(s, name), list(defines)) for s in units if force or _newer(_object(s, name), dependencies(s))]
     _compile(jobs, verbose)
     objs = [_object(s, name) if s in units else _object(s) for s in SOURCES]

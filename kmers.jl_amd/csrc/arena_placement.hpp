@@ -255,6 +255,7 @@ inline bool arena_take_straddling(kmers_arena &a, size_t need, size_t *off_out) 
 }
 
 inline void arena_give(kmers_arena &a, size_t off, size_t len) {
+    if (off == a.last_off) a.last_len = 0;  // the "previous allocation" the placement scores against is gone
     auto next = a.free_ranges.lower_bound(off);
     if (next != a.free_ranges.end() && off + len == next->first) {  // merge with the range behind
         len += next->second;

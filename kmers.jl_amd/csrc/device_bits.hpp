@@ -59,6 +59,33 @@ __device__ __forceinline__ uint32_t bad_bits16(uint64_t bad) {
     return (uint32_t)f & 0xFFFFu;
 }
 
+// The same recoding for the kernels that keep their LDS stream in KMER order (cut_fw: symbol 15 of the word in bits [0, 2),
+// symbol 0 in bits [30, 32)) and want one ambiguity bit per symbol: done on the 32-bit halves, the symbol reversal folded into
+// one v_bfrev per half (after it A = 8, C = 4, G = 2, T = 1: code bit 0 = nibble bits 2 | 0, bit 1 = nibble bits 1 | 0).  41
+// vector instructions per word where pack_4to2 + rev2_32 + bad_bits16 take 59 (profiles/r04_unamb.md).  The code of a symbol
+// that is not one-hot is unspecified (its windows are never kept).
+__device__ __forceinline__ uint32_t recode4_half_kmer_order(uint32_t r) {  // r = __brev(half word): 8 symbols, last one first
+    const uint32_t c = ((r | (r >> 2)) & 0x11111111u) | ((r | (r << 1)) & 0x22222222u);  // 2-bit code in the low bits of each nibble
+    const uint32_t u = (c | (c >> 2)) & 0x0F0F0F0Fu;
+    return u | (u >> 4);  // bytes 0 and 2: four codes each
+}
+__device__ __forceinline__ uint32_t recode4_kmer_order(uint64_t x) {
+    const uint32_t vl = recode4_half_kmer_order(__brev((uint32_t)x)), vh = recode4_half_kmer_order(__brev((uint32_t)(x >> 32)));
+    return __builtin_amdgcn_perm(vl, vh, 0x06040200u);  // bytes: vh.0, vh.2 (symbols 15..8), vl.0, vl.2 (symbols 7..0)
+}
+// bit j set: symbol j of the word has count_ones != 1 (construction_utils.jl:50).  With p0 = n0 | n1, p1 = n2 | n3, q0 = n0 & n1,
+// q1 = n2 & n3 a nibble is one-hot iff (p0 ^ p1) & ~q0 & ~q1; the eight flags of a half word (one per nibble) are gathered by
+// one v_dot4_u32_u8 (bytes of two 2-bit fields times 1, 4, 16, 64).
+__device__ __forceinline__ uint32_t ambiguous8(uint32_t h) {
+    const uint32_t s = h >> 1, o = h | s, n = h & s;
+    const uint32_t f = (~(o ^ (o >> 2)) | n | (n >> 2)) & 0x11111111u;
+    const uint32_t g = (f | (f >> 3)) & 0x03030303u;
+    return __builtin_amdgcn_udot4(g, 0x40100401u, 0u, false);
+}
+__device__ __forceinline__ uint32_t ambiguous16(uint64_t x) {
+    return ambiguous8((uint32_t)x) | (ambiguous8((uint32_t)(x >> 32)) << 8);
+}
+
 // Put this before the __syncthreads() that follows LDS atomics WITHOUT a return value (ds_add_u32, ds_max_u32 ...)
 // whose results other wavefronts read after the barrier.  hipcc emits a bare s_barrier there: its workgroup-scope
 // release relies on the LDS queue being in order, and under heavy same-address contention that was observed to be

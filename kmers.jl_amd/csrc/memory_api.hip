@@ -95,8 +95,9 @@ int calibrate(kmers_ctx *ctx) {
                     c = (int)r;
                     break;
                 }
-                float t;
+                float t = 0.f;
                 rc = probe_ms(ctx, e0, e1, g * REGION, refs[r] * REGION + REGION / 2, &t);
+                if (rc != KMERS_OK) break;
                 if (t >= threshold) c = (int)r;
             }
             if (c < 0) {
@@ -118,7 +119,7 @@ int calibrate(kmers_ctx *ctx) {
         for (size_t g = 1; g + 1 < n && rc == KMERS_OK; ++g) {
             if (cls[g - 1] != cls[g + 1] || cls[g] == cls[g - 1]) continue;
             const size_t r = refs[cls[g - 1]];
-            float t0, t1;
+            float t0 = 0.f, t1 = 0.f;
             rc = probe_ms(ctx, e0, e1, g * REGION, r * REGION + REGION / 2, &t0);
             if (rc == KMERS_OK) rc = probe_ms(ctx, e0, e1, g * REGION + REGION / 2, r * REGION + REGION / 2, &t1);
             if (rc == KMERS_OK && (t0 >= threshold || t1 >= threshold)) cls[g] = cls[g - 1];
@@ -140,8 +141,9 @@ int calibrate(kmers_ctx *ctx) {
                 size_t lo = (g - 1) * REGION, hi = g * REGION;
                 while (hi - lo > PROBE && rc == KMERS_OK) {
                     const size_t mid = lo + (hi - lo) / 2 / GRANULE * GRANULE;
-                    float t;
+                    float t = 0.f;
                     rc = probe_ms(ctx, e0, e1, mid, r * REGION + (mid >= r * REGION + REGION / 2 && mid < (r + 1) * REGION ? 0 : REGION / 2), &t);
+                    if (rc != KMERS_OK) break;
                     if (t >= threshold) lo = mid;
                     else hi = mid;
                 }

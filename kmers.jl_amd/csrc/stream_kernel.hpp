@@ -361,8 +361,12 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     // alphabet's 256-entry table in LDS
     const uint32_t text = (SRC_BITS == 8 && DST == 2 && a.ascii_table <= 1u) ? 1u + a.ascii_table : 0u;
     if constexpr (SRC_BITS == 8) {
-        if (!text)
-            for (uint32_t i = tid; i < 256u; i += TB) lut[i] = ascii_entry(a.ascii_table, i);  // computed, not loaded; visible after the tile loop's first barrier
+        if (!text) {  // (uniform: every thread takes the same side)
+            for (uint32_t i = tid; i < 256u; i += TB) lut[i] = ascii_entry(a.ascii_table, i);  // computed, not loaded
+            // the strided kernels stage their first tile BEFORE the tile loop's first barrier: every wavefront's share of the table
+            // must be in LDS before any wavefront looks a byte up (one barrier per workgroup, not per tile)
+            block_sync();
+        }
     }
     static_assert(!PAIR || (!STRIDE1 && N == 1 && !TUPLES && (MODE == MODE_FW || MODE == MODE_XOR)), "PAIR: strided one-word kmers");
     constexpr uint32_t KPL = ((STRIDE1 || PAIR) && N == 1 && !TUPLES) ? 2u : 1u;  // kmers per lane per pass -> 16 B stores

@@ -63,12 +63,21 @@ void launch_unambiguous(kmers_ctx *ctx, int src_bits, int nw, dim3 grid, const U
 // longest kmer the single-pass kernel stages (a tile and its K-1 symbols of overlap must fit the LDS stream)
 constexpr int UNAMB_MAX_K = 30720;
 static_assert(UNAMB_MAX_K <= (int)UTILE_MAX - 2048, "a tile and its K - 1 symbols of overlap must fit the LDS stream");
-uint32_t unambiguous_tile(kmers_ctx *ctx, int k) {
-    // candidate starts per tile: a multiple of 1024 (one wavefront round), at most UTILE_MAX.  Long tiles keep the rate of
+uint32_t unambiguous_tile(kmers_ctx *ctx, int k, int stride) {
+    // candidate starts per tile: a multiple of 1024, at most UTILE_MAX.  Long tiles keep the rate of
     // tile descriptors low enough for the look-back; very long kmers leave room for their overlap.
     uint32_t t = ctx->tile_kmers > 0 ? (uint32_t)std::min<int64_t>(ctx->tile_kmers, UTILE_MAX) : UTILE_MAX;
     if (k > 128) t = std::min<uint32_t>(t, (UTILE_MAX - (uint32_t)k) / UROUND * UROUND);
-    return std::max<uint32_t>(UROUND, t / UROUND * UROUND);
+    t = std::max<uint32_t>(UROUND, t / UROUND * UROUND);
+    // a stride lattice: a tile length that is a multiple of the stride too puts the lattice at the same place in every tile (the
+    // kernel then needs no division per tile), if at least half of the length survives
+    if (stride > 1) {
+        uint64_t g = UROUND, s = (uint64_t)stride;
+        while (s) { const uint64_t r = g % s; g = s; s = r; }      // gcd(1024, stride)
+        const uint64_t unit = (uint64_t)UROUND / g * (uint64_t)stride;  // lcm
+        if (unit <= t && t / unit * unit >= t / 2) t = (uint32_t)(t / unit * unit);
+    }
+    return t;
 }
 
 // UnambiguousKmers: ONE pass over the source (unambiguous_kernel.hpp): tile descriptors + decoupled look-back inside the
@@ -104,7 +113,8 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
     a.k = (uint32_t)k;
     a.stride = (uint32_t)stride;
     a.index_origin = seq->index_origin;
-    a.tile_starts = unambiguous_tile(ctx, k);
+    a.tile_starts = unambiguous_tile(ctx, k, stride);
+    a.tile_phase = stride > 1 && a.tile_starts % (uint32_t)stride != 0 ? 1u : 0u;
     a.n_words = (uint32_t)nw;
     a.n_tiles = (n + a.tile_starts - 1) / a.tile_starts;
     a.tuples = tuples ? 1u : 0u;
@@ -227,6 +237,7 @@ int kmers::unambiguous_xor(kmers_ctx *ctx, const kmers_seq *seq, int k, int stri
     a.stride = (uint32_t)stride;
     a.index_origin = seq->index_origin;
     a.tile_starts = kk > 128 ? (UTILE_MAX - (uint32_t)kk) / UROUND * UROUND : UTILE_MAX;  // nothing is streamed out: long tiles
+    a.tile_phase = stride > 1 && a.tile_starts % (uint32_t)stride != 0 ? 1u : 0u;
     a.n_words = (uint32_t)kmers_words_per_kmer(kk, 2);
     a.n_tiles = (n + a.tile_starts - 1) / a.tile_starts;
     a.total = reinterpret_cast<unsigned long long *>(ctx->d_scratch);

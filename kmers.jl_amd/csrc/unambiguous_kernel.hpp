@@ -6,19 +6,28 @@
 // are all zero, which selects exactly the same windows.  The output position of a kept window is the number of kept
 // windows before it -- a prefix sum over the whole sequence -- and it is resolved INSIDE the emitting kernel:
 //
-//   tile     a workgroup draws a ticket (tiles are numbered in the order workgroups start), stages its source words once,
-//            resolves all of its candidate starts bit-parallel (64 starts per lane: the "good" bits AND-ed with themselves
-//            shifted by 1, 2, 4, ...), and publishes its kept count as an AGGREGATE in its tile descriptor;
+//   tile     a workgroup draws a ticket (tiles are numbered in the order workgroups reach for them), stages its source words
+//            once, resolves all of its candidate starts bit-parallel (64 starts per lane: the ambiguity bits OR-ed with
+//            themselves shifted by 1, 2, 4, ...), and publishes its kept count as an AGGREGATE in its tile descriptor;
 //   look-back   one wavefront then sums the descriptors of the preceding tiles, nearest first, 256 per step, until it meets
 //            one that already holds an inclusive PREFIX (decoupled look-back: it never waits for a predecessor's prefix,
 //            only for aggregates, which every started tile publishes unconditionally -- no circular wait), publishes its
 //            own inclusive prefix and hands the exclusive one to the workgroup;
-//   emit     every wavefront lists the kept starts of 1024-2048 candidates at a time in LDS (their order is the reference's)
-//            and works the list off with every lane busy: window cut + contiguous stores.  A stretch with nothing dropped
-//            (real sequence outside its N blocks) skips the list: two kmers per lane, 16-byte stores.
-//   pipeline the grid is persistent (four workgroups per CU) and a workgroup runs the first step of its NEXT tile before the
-//            last two of the current one, so that an aggregate is out microseconds after its ticket.  Between the two a
-//            tile's keep mask and prefix counts stay in the registers of the lanes that resolved them; its codes in LDS.
+//   emit     every wavefront lists the kept starts of up to 4096 candidates at a time in LDS (their order is the reference's)
+//            and works the list off with every lane busy: window cut + contiguous 16-byte stores in aligned frames.  A stretch
+//            with nothing dropped (real sequence outside its N blocks) skips the list.
+//   pipeline the grid is persistent (four workgroups per CU).  A workgroup has the source words of the tile after next in
+//            flight (registers) while it emits, and runs the first step of its NEXT tile before the last two of the current
+//            one, so that an aggregate is out microseconds after its ticket; the ticket itself is drawn while the tile before
+//            it is resolved.  Between front and back a tile's keep mask stays in the registers of the lanes that resolved it.
+//
+// Round 4 (profiles/r04_unamb.md): the kernel is bound by the latency of its dependent chains at four wavefronts per SIMD, not
+// by instruction issue (a SIMD takes a vector instruction every 1.6-2.7 cycles from four wavefronts, tools/valu_rates.hip; the
+// round-3 kernel issued one every 5.6).  What this version removes: the lane shuffles of every round (a lane now owns the
+// qwords lane, 64 + lane, 128 + lane of its wavefront's quarter, and a round is exactly one qword per lane), half of the
+// rounds (4096 starts instead of 2048), the exposed load latency of every tile (prefetch) and two barriers + one atomic
+// round trip per tile (asynchronous ticket); the recoding of a 4-bit word takes 41 instructions instead of 59 and the
+// window test runs on 32-bit words with v_alignbit.
 //
 // A descriptor is ONE 64-bit word (status in the top two bits, count below) moved with relaxed agent-scope atomics, so
 // no fence is needed: the word is the whole hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, "8-B agent atomics
@@ -28,43 +37,45 @@
 
 namespace kmers {
 
-// 49152-start tiles, four workgroups per CU (36 KiB of LDS each): late in round 3, with the outputs in two region classes, fewer
+// 49152-start tiles, four workgroups per CU (37.5 KiB of LDS each): late in round 3, with the outputs in two region classes, fewer
 // and longer tiles win -- K = 31 0.71 -> 0.73, the stride-3 lattice 0.58 -> 0.61 of 8 TB/s; 6 x 32768 (rounds 2-3), 5 x 40960 and
 // 3 x 65536 run the same, 7 x 28672, 8 x 24576 and 2 x 98304 lose (profiles/r03_tuning.md, tools/r3_unamb_occupancy.sh)
 #ifndef KMERS_UTILE_MAX
 #define KMERS_UTILE_MAX 49152
 #endif
-constexpr uint32_t UTILE_MAX = KMERS_UTILE_MAX;  // candidate starts per tile (a multiple of 1024), at most
-#ifndef KMERS_UROUND
-#define KMERS_UROUND 1024
-#endif
-constexpr uint32_t UROUND = KMERS_UROUND;  // starts per wavefront round (16 or 8 per lane)
-constexpr uint32_t USLICE = UROUND / 64;  // consecutive starts per lane
-// A round whose kept starts fit the wavefront's list takes 2048 candidate starts at once (32 per lane): with 14-28 % of the
-// starts kept, a 1024-start round lists 140-290 elements and fills its last 128-element store pass badly.  (4096-start rounds
-// with 2048-entry lists ran the same and cost 8 KiB of LDS more; the kernel's time falls with every resident workgroup,
-// profiles/r02_tuning.md section 6)
-#ifndef KMERS_ULONG
-#define KMERS_ULONG 2048
-#endif
+constexpr uint32_t UTILE_MAX = KMERS_UTILE_MAX;  // candidate starts per tile, at most: a multiple of 64 x BLOCK (whole qwords per thread)
+constexpr uint32_t UROUND = 1024;                // granularity of the tile length (unambiguous_api.hip)
+// A ROUND is one keep-mask qword per lane: 4096 consecutive candidate starts of the wavefront's quarter of the tile.  Its kept
+// starts are listed in LDS in one PASS if they fit the wavefront's list, else in two passes (lanes 0-31, 32-63) or in passes of
+// 16 lanes (1024 starts: always fit).
 #ifndef KMERS_ULIST
-#define KMERS_ULIST 1024
+#define KMERS_ULIST 1536
 #endif
-constexpr uint32_t ULONG = KMERS_ULONG, ULIST = KMERS_ULIST;
+constexpr uint32_t ULIST = KMERS_ULIST;
 // The emitting path stores in FRAMES: 128 consecutive output elements, aligned to 128 in the OUTPUT index (lane l of a frame owns
-// elements 2l and 2l + 1: one 16-byte store per lane and array, 1 KiB = eight whole 128-byte lines per wave store).  What a
-// round lists beyond its last whole frame stays at the head of the list for the next round (fewer than UFRAME entries), so a
-// wavefront issues partial store instructions only at the two ends of its quarter of the tile, not at the ends of every round
-// (with 14-28 % of the starts kept a 2048-start round used to end in a store pass that was 25-50 % full, plus up to four
-// one-lane stores for odd heads and tails: 45-65 % of the bytes a store instruction can carry, profiles/r03_unamb.md).
+// elements 2l and 2l + 1: one 16-byte store per lane and array, 1 KiB = eight whole 128-byte lines per wave store).  The list
+// is kept frame-aligned too (slot s of the list holds the element with output index frame_base + s), so that a lane reads its
+// two entries with one 32-bit load; what a pass lists beyond its last whole frame stays at the head of the list for the next one
+// (fewer than UFRAME entries), so a wavefront issues partial store instructions only at the two ends of its quarter of the tile.
 constexpr uint32_t UFRAME = 128;
-constexpr uint32_t ULSTRIDE = ULIST + UFRAME;  // list entries per wavefront: a round's kept starts behind the carried ones
-static_assert(ULIST >= UROUND, "a short round may keep every one of its starts");
-static_assert(ULONG % UROUND == 0 && (ULONG == 1024 || ULONG == 2048 || ULONG == 4096) && 64 % USLICE == 0, "a lane's slice of a round lies in one keep-mask qword");
+constexpr uint32_t ULSTRIDE = ULIST + UFRAME;  // list entries per wavefront: a pass's kept starts behind the carried ones
+static_assert(ULIST >= 1024 && ULIST % 2 == 0, "a pass of 16 lanes (1024 starts) may keep every one of its starts");
+#ifndef KMERS_UCUT
+#define KMERS_UCUT 0  // diagnostic builds only: 1 = stage, 2 = whole front, 3 = front + look-back, 4 = loads only, 5 = stage without loads, 6 = everything but the stores of whole frames
+#endif
+#ifndef KMERS_UPREFETCH
+#define KMERS_UPREFETCH 0  // source words per lane of the tile after next that EMIT loads while it emits (registers: two VGPRs each)
+#endif
+#ifndef KMERS_USTAGGER
+#define KMERS_USTAGGER 0  // start delay of a workgroup in units of s_sleep 127 (3.6 us) per quarter step
+#endif
+#ifndef KMERS_USTAGGER_HASH
+#define KMERS_USTAGGER_HASH 0
+#endif
 #ifndef KMERS_UNAMB_WGS
 #define KMERS_UNAMB_WGS 4
 #endif
-constexpr int UNAMB_EMIT_WGS = KMERS_UNAMB_WGS;  // workgroups per CU of the emitting mode (36 KiB of LDS each)
+constexpr int UNAMB_EMIT_WGS = KMERS_UNAMB_WGS;  // workgroups per CU of the emitting mode
 constexpr uint64_t DESC_VALUE = (1ull << 62) - 1ull;
 constexpr uint64_t DESC_AGGREGATE = 1ull << 62, DESC_PREFIX = 2ull << 62;
 constexpr int LOOKBACK = 4;               // descriptors per lane and look-back step (256 tiles per step)
@@ -105,6 +116,7 @@ struct UnambArgs {
     uint32_t tuples;               // 1: out_kmers receives Tuple{Kmer,Int} elements (N + 1 words each), out_starts unused
     uint32_t vec16;                // out_kmers / out_starts are 16-byte aligned (16-byte stores allowed)
     uint32_t n_words;              // words per kmer (the N = 0 instantiation takes it at run time: kmers of more than four words)
+    uint32_t tile_phase;           // 1: tile_starts is not a multiple of the stride (the lattice begins at a different place in every tile)
     uint64_t *stamps;              // diagnostic builds (-DKMERS_STAMPS) only: 8 s_memrealtime stamps per tile
 };
 
@@ -118,22 +130,30 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// inclusive prefix sum over the 64 lanes of a wavefront, in the vector pipe (six v_add with DPP operands; a __shfl_up ladder is
+// six LDS-crossbar round trips): shifts inside rows of 16 lanes, then the last lane of a row broadcast to the rows behind it
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);  // row_shr:4 (lanes 4-15 of a row)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);  // row_shr:8 (lanes 8-15)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// a value that is the same in every lane, moved to scalar registers
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+// lane `l` (the same in every lane) of v
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
 // bit j of the result: K unambiguous symbols begin at symbol (bit + j) of the flag stream (one bit per symbol, set =
 // ambiguous).  The window of start j spans flag bits [j, j + K): up to 64 + 127 bits for 64 starts and K <= 128.
+// (K > 65 only: shorter kmers take keep_qword32 below)
 __device__ __forceinline__ uint64_t keep_qword(const uint64_t *amb, uint32_t bit, uint32_t k) {
     const uint32_t Q = bit >> 6, sft = bit & 63u;
     uint64_t lo = ~funnel64(amb[Q], amb[Q + 1], sft), mid = ~funnel64(amb[Q + 1], amb[Q + 2], sft);
-    if (k <= 65) {
-        uint32_t have = 1;
-        while (have < k) {
-            const uint32_t step = have < k - have ? have : k - have;  // 1..32: good[j..j+have) & good[j+step..j+step+have)
-            lo &= (lo >> step) | ((mid << 1) << (63u - step));
-            mid &= mid >> step;  // (the bits shifted in from beyond `mid` are never needed: have + step <= 65)
-            have += step;
-        }
-        return lo;
-    }
     if (k > 129) {
         // kmers of more than four words (an edge path): start j is kept iff the flag bits [j, j + K) are all zero, tested word
         // by word; every lane walks the 64 + K bits behind its 64 starts once, keeping the distance to the next flag
@@ -158,6 +178,31 @@ __device__ __forceinline__ uint64_t keep_qword(const uint64_t *amb, uint32_t bit
     }
     return lo;
 }
+// The same for K <= 32 ND - 63 on 32-bit words: x[i] = flag bits [bit + 32 i, + 32) (ND words cover the 63 + K bits behind the
+// 64 starts), x |= x >> step with the steps 1, 2, 4, ... (wave-uniform), every word one v_alignbit_b32 + one v_or_b32; what is
+// shifted into the last word from beyond it only ever reaches starts above the 64.  `bit` < 32 (the stream starts in its word).
+template <int ND>
+__device__ __forceinline__ uint64_t keep_qword32(const uint32_t *amb32, uint32_t q, uint32_t bit, uint32_t k) {
+    uint32_t d[ND + 1], x[ND];
+#pragma unroll
+    for (int i = 0; i <= ND; ++i) d[i] = amb32[2u * q + (uint32_t)i];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) x[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], bit);
+    uint32_t have = 1;
+    while (have < k) {
+        const uint32_t step = have < k - have ? have : k - have;  // 1..32
+        if (step == 32u) {  // (v_alignbit takes its shift modulo 32)
+#pragma unroll
+            for (int i = 0; i + 1 < ND; ++i) x[i] |= x[i + 1];
+        } else {
+#pragma unroll
+            for (int i = 0; i + 1 < ND; ++i) x[i] |= __builtin_amdgcn_alignbit(x[i + 1], x[i], step);
+            x[ND - 1] |= x[ND - 1] >> step;
+        }
+        have += step;
+    }
+    return ~(((uint64_t)x[1] << 32) | x[0]);
+}
 
 // This kernel only ever needs FORWARD kmers, so it stages the 2-bit codes of a tile in KMER order (cut_fw, stream_kernel.hpp).
 
@@ -168,21 +213,21 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     constexpr uint32_t STREAM_QWORDS = (UTILE_MAX + 128 + 64) / 32 + 4;   // 2-bit codes of the tile + its K-1 overlap
     constexpr uint32_t AMB_QWORDS = (UTILE_MAX + 128 + 64) / 64 + 6;
     constexpr uint32_t MAXQ = UTILE_MAX / 64;
+    static_assert(BLOCK == 256 && MAXQ % (uint32_t)BLOCK == 0, "whole keep-mask qwords per thread");
     __shared__ uint64_t lds2[NBUF][STREAM_QWORDS];
-    // The keep mask of a tile and the kept starts before each of its 64-start qwords never go to LDS: thread t resolves
-    // qwords QPT*t .. QPT*t + QPT-1 and keeps them in registers until the tile is emitted (one whole front later); wavefront
-    // w then works on exactly the qwords its own lanes hold, and fetches what a lane needs with a lane shuffle.
-    constexpr uint32_t QPT = (MAXQ + (uint32_t)BLOCK - 1u) / (uint32_t)BLOCK;  // qwords per thread (two with 32768-start tiles)
-    constexpr uint32_t WQ = 64u * QPT;                                          // qwords per wavefront
+    // The keep mask of a tile never goes to LDS: wavefront w owns the qwords [WQ w, WQ (w + 1)) of the tile (64 starts each), its
+    // lane l resolves the qwords l, 64 + l, ... of them and keeps them in registers until the tile is emitted (one whole front
+    // later).  A round of the emitting half is then exactly one qword per lane: nothing moves between lanes.
+    constexpr uint32_t QPT = MAXQ / (uint32_t)BLOCK;  // qwords per thread = rounds per wavefront (three with 49152-start tiles)
+    constexpr uint32_t WQ = 64u * QPT;                // qwords per wavefront
     struct TileRegs {
-        uint64_t k[QPT];   // bit j of k[h]: start 64 (QPT t + h) + j is kept
-        uint32_t p[QPT];   // kept starts of the tile before that qword
-        uint32_t wave_end; // ... before the first qword of the next wavefront
-        uint32_t total;    // kept starts of the tile
+        uint64_t k[QPT];     // bit j of k[h]: start 64 (WQ wave + 64 h + lane) + j of the tile is kept
+        uint32_t wave_base;  // kept starts of the tile before the wavefront's quarter (the same in every lane)
+        uint32_t total;      // kept starts of the tile
     };
     // flag stream (between stage and resolve of the tile ahead) and, in the same space, the per-wavefront lists of kept starts
-    // of the tile being emitted: the flag stream is dead by then (the scan's barrier lies between its last reader and the first
-    // list entry, the barrier that opens the next front between the last list reader and the next flag)
+    // of the tile being emitted: the flag stream is dead by then (the barrier behind the resolve lies between its last reader and
+    // the first list entry, the barrier that opens the next front between the last list reader and the next flag)
     constexpr uint32_t LIST_BYTES = UMODE == UMODE_COUNT ? 0u : (uint32_t)WAVES * ULSTRIDE * 2u;
     constexpr uint32_t AMB_ALLOC = AMB_QWORDS * 8u > LIST_BYTES ? AMB_QWORDS : (LIST_BYTES + 7u) / 8u;
     __shared__ uint64_t amb[AMB_ALLOC];
@@ -192,7 +237,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if constexpr (SRC_BITS == 8) {
-        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);
+        for (uint32_t i = tid; i < 256u; i += BLOCK) lut[i] = ascii_entry(a.ascii_table, i);  // (visible behind the front's first barrier)
     }
     const uint32_t k = a.k;
     const uint64_t mask = head_mask((int)k, 2);
@@ -201,10 +246,18 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     constexpr int NW = WIDE ? 1 : N;                     // (register arrays of the fixed-width paths)
     const uint32_t n_words = WIDE ? a.n_words : (uint32_t)N;
     uint64_t acc = 0;  // COUNT: kept starts; XOR: fold of the head words
-    uint64_t lattice = ~0ull;  // bit j set iff j % stride == 0 (stride < 64; a larger stride has one lattice start per qword at most)
+    // Stride lattices: bit j of `lattice` set iff j % stride == 0 (stride < 64; a larger stride has one lattice start per qword at
+    // most); ph[h] = (tile-relative first start of this lane's qword h) % stride, once per kernel: the per-tile phase is then two
+    // conditional subtractions (the general modulo was 45 instructions per qword, four of them multiplications)
+    uint64_t lattice = ~0ull;
+    uint32_t ph[QPT];
+#pragma unroll
+    for (uint32_t h = 0; h < QPT; ++h) ph[h] = 0;
     if (a.stride > 1) {
         lattice = 0;
         for (uint32_t j = 0; j < 64u; j += a.stride) lattice |= 1ull << j;
+#pragma unroll
+        for (uint32_t h = 0; h < QPT; ++h) ph[h] = (64u * (wave * WQ + 64u * h + lane)) % a.stride;
     }
 
     struct Geom {
@@ -227,93 +280,164 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     };
 #ifdef KMERS_STAMPS
     uint64_t ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tp[4] = {0, 0, 0, 0}, tp0 = 0;  // shader cycles of a tile's back spent listing / emitting / carrying / scanning
 #define USTAMP(i) ts[i] = __builtin_amdgcn_s_memrealtime()
+#define UPHASE_BEGIN() tp0 = __builtin_amdgcn_s_memtime()
+#define UPHASE_END(i) tp[i] += __builtin_amdgcn_s_memtime() - tp0
 #else
 #define USTAMP(i)
+#define UPHASE_BEGIN()
+#define UPHASE_END(i)
 #endif
 
-    // ---- front of a tile: stage its source words once, resolve every candidate start, publish the AGGREGATE -----------
-    auto front = [&](uint64_t tile, uint32_t buf) {
+    // ---- the source words of a tile: PRE per lane, all in flight together.  EMIT issues them one whole `back` ahead --------
+    // (a 49152-start tile of a 4-bit source is 3074 words + its alignment: thirteen per lane; byte sources take a second batch)
+    constexpr uint32_t PRE = SRC_BITS == 2 ? 7u : 13u;
+    constexpr uint32_t AHEAD = KMERS_UPREFETCH < PRE ? KMERS_UPREFETCH : PRE;  // words per lane loaded one whole `back` ahead
+    constexpr uint32_t XS = AHEAD ? AHEAD : 1u;
+    auto load_words = [&](uint64_t tile, uint64_t (&xs)[XS]) {
+        if constexpr (AHEAD > 0) {
+            const Geom g = geometry(tile);
+#pragma unroll
+            for (uint32_t j = 0; j < AHEAD; ++j) {
+                const uint32_t wi = tid + j * BLOCK;
+                xs[j] = wi < g.nw ? a.src[g.w0 + wi] : 0;
+            }
+        }
+    };
+    // one source word -> 2-bit codes (in kmer order) + one ambiguity flag per symbol
+    auto stage_one = [&](uint64_t *lds, uint32_t nw, uint64_t w0, uint32_t wi, uint64_t x) {
+        if constexpr (SRC_BITS == 8) {
+            uint32_t codes = 0, flags = 0;
+            uint64_t f = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                uint32_t v = lut[(x >> (8 * b)) & 0xffu];
+                codes |= (v & 3u) << (2 * b);
+                flags |= (v >= 0xf0u ? 1u : 0u) << b;             // 0xf0: ambiguous -> skip the window
+                f |= (uint64_t)(v == 0xffu ? 1u : 0u) << (8 * b);  // 0xff: not a nucleotide -> throw
+            }
+            reinterpret_cast<uint16_t *>(lds)[nw - 1u - wi] = (uint16_t)(rev2_32(codes) >> 16);
+            reinterpret_cast<uint8_t *>(amb)[wi] = (uint8_t)flags;
+            if (f) report_bad_symbols<8, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, w0 + wi, f, x, a.index_origin);
+        } else if constexpr (SRC_BITS == 4) {
+            reinterpret_cast<uint32_t *>(lds)[nw - 1u - wi] = recode4_kmer_order(x);
+            reinterpret_cast<uint16_t *>(amb)[wi] = (uint16_t)ambiguous16(x);
+        } else {
+            lds[nw - 1u - wi] = rev2(x);
+            reinterpret_cast<uint32_t *>(amb)[wi] = 0u;  // 32 symbols per 2-bit word, none ambiguous
+        }
+    };
+
+    // ---- front of a tile: stage its source words (already in registers), resolve every candidate start, publish the AGGREGATE
+    // `ticket_next`: EMIT draws the ticket after next inside this front -- thread 0 of the workgroup issues the atomic behind the
+    // stage and hands the result over at the barrier behind the resolve, so that neither its round trip nor a barrier of its own
+    // is paid for (2.4 us under the kernel's store traffic, profiles/r03_tuning.md)
+    auto front = [&](uint64_t tile, uint32_t buf, const uint64_t (&xs)[XS], bool ticket_next) {
         uint64_t *const lds = lds2[buf];
         TileRegs tr;
         const Geom g = geometry(tile);
         const uint32_t nw = g.nw, b0 = g.b0, mt = g.mt, nq = g.nq;
         const uint64_t w0 = g.w0, m0 = g.m0;
-        const uint32_t tile_rem = a.stride > 1 ? (uint32_t)(m0 % a.stride) : 0u;  // wave-uniform
+        // (m0 % stride, wave-uniform: a 64-bit division by a run-time value -- a hundred instructions -- unless the host could make
+        // the tile length a multiple of the stride, unambiguous_api.hip)
+        const uint32_t tile_rem = a.tile_phase ? (uint32_t)(m0 % a.stride) : 0u;
+        // the words that were not loaded ahead: the rest of the first batch (all of its loads in flight before the first is used, and
+        // while the prefetched words are staged), then further batches (byte sources, very long kmers)
+        constexpr uint32_t REST = PRE - AHEAD;
+        uint64_t ys[REST ? REST : 1u];
+#pragma unroll
+        for (uint32_t j = 0; j < REST; ++j) {
+            const uint32_t wi = tid + (AHEAD + j) * BLOCK;
+#if KMERS_UCUT == 5  // phase accounting: no loads at all (the stage works on made-up words)
+            ys[j] = (uint64_t)(wi + 1u) * 0x9E3779B97F4A7C15ull + tile;
+#else
+            ys[j] = wi < nw ? a.src[w0 + wi] : 0;
+#endif
+        }
+        unsigned long long drawn = 0;
+        if constexpr (EMIT) {
+            // (behind the loads of this tile in the memory queue, so that waiting for them does not wait for it; in flight until
+            // the barrier behind the resolve)
+            if (ticket_next && tid == 0) drawn = atomicAdd(a.ticket, 1ull);
+        }
         block_sync();  // the readers of this buffer (the tile before last), of the flag stream and of the list are done
         USTAMP(1);
-        // stage: source words -> 2-bit codes (in kmer order) + one ambiguity flag per symbol
-        // (all of a lane's loads of a batch are in flight before the first is used -- a 32768-start tile of a 4-bit source is
-        // 2050 words, nine per lane -- so that a tile pays one memory latency; byte sources take two such batches)
-        constexpr uint32_t PRE = 9;
-        for (uint32_t wbase = 0; wbase < nw; wbase += PRE * BLOCK) {
-            uint64_t xs[PRE];
+#pragma unroll
+        for (uint32_t j = 0; j < AHEAD; ++j) {
+            const uint32_t wi = tid + j * BLOCK;
+            if (wi < nw) stage_one(lds, nw, w0, wi, xs[j]);
+        }
+#if KMERS_UCUT == 4  // phase accounting: the loads only, nothing recoded
+        {
+            uint64_t fold = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < REST; ++j) fold ^= ys[j];
+            if (fold == 0x6b6d657273756374ull) a.desc[tid] = fold;
+        }
+#else
+#pragma unroll
+        for (uint32_t j = 0; j < REST; ++j) {
+            const uint32_t wi = tid + (AHEAD + j) * BLOCK;
+            if (wi < nw) stage_one(lds, nw, w0, wi, ys[j]);
+        }
+#endif
+        for (uint32_t wbase = PRE * BLOCK; wbase < nw; wbase += PRE * BLOCK) {
+            uint64_t zs[PRE];
 #pragma unroll
             for (uint32_t j = 0; j < PRE; ++j) {
                 const uint32_t wi = wbase + tid + j * BLOCK;
-                xs[j] = wi < nw ? a.src[w0 + wi] : 0;
+                zs[j] = wi < nw ? a.src[w0 + wi] : 0;
             }
 #pragma unroll
             for (uint32_t j = 0; j < PRE; ++j) {
                 const uint32_t wi = wbase + tid + j * BLOCK;
-                const uint64_t x = xs[j];
-                if (wi < nw) {
-                    if constexpr (SRC_BITS == 8) {
-                        uint32_t codes = 0, flags = 0;
-                        uint64_t f = 0;
-#pragma unroll
-                        for (int b = 0; b < 8; ++b) {
-                            uint32_t v = lut[(x >> (8 * b)) & 0xffu];
-                            codes |= (v & 3u) << (2 * b);
-                            flags |= (v >= 0xf0u ? 1u : 0u) << b;             // 0xf0: ambiguous -> skip the window
-                            f |= (uint64_t)(v == 0xffu ? 1u : 0u) << (8 * b);  // 0xff: not a nucleotide -> throw
-                        }
-                        reinterpret_cast<uint16_t *>(lds)[nw - 1u - wi] = (uint16_t)(rev2_32(codes) >> 16);
-                        reinterpret_cast<uint8_t *>(amb)[wi] = (uint8_t)flags;
-                        if (f) report_bad_symbols<8, true>(a.err_slot, a.first_bit, a.n_bases, 1u, k, w0 + wi, f, x, a.index_origin);
-                    } else if constexpr (SRC_BITS == 4) {
-                        uint64_t bad;
-                        uint32_t c = pack_4to2(x, bad);
-                        reinterpret_cast<uint32_t *>(lds)[nw - 1u - wi] = rev2_32(c);
-                        reinterpret_cast<uint16_t *>(amb)[wi] = (uint16_t)bad_bits16(bad);
-                    } else {
-                        lds[nw - 1u - wi] = rev2(x);
-                        reinterpret_cast<uint32_t *>(amb)[wi] = 0u;  // 32 symbols per 2-bit word, none ambiguous
-                    }
-                }
+                if (wi < nw) stage_one(lds, nw, w0, wi, zs[j]);
             }
         }
         // (flag and code bits past the staged words only ever reach starts >= mt, which are masked out below)
         USTAMP(2);
         block_sync();
         USTAMP(3);
-        // resolve: thread t owns QPT consecutive qwords of the keep mask (64 starts each)
-        uint32_t c2[QPT];
+#if KMERS_UCUT == 1 || KMERS_UCUT == 4 || KMERS_UCUT == 5  // phase accounting (tools/r4_unamb_account.sh): the kernel ends behind the stage; the read keeps the LDS stores alive
+        if (a.capacity == 0x6b6d657273756374ull) a.desc[tid] = lds[tid] + amb[tid];
+        tr = TileRegs{};
+        if (tid == 0) s_tile = drawn;
+        block_sync();
+        return tr;
+#endif
+        // resolve: this lane's qwords of the keep mask (64 starts each)
+        const uint32_t *const amb32 = reinterpret_cast<const uint32_t *>(amb);
         uint32_t c = 0;
 #pragma unroll
         for (uint32_t h = 0; h < QPT; ++h) {
-            const uint32_t q = QPT * tid + h;
+            const uint32_t q = wave * WQ + 64u * h + lane;
             uint64_t keep = 0;
-            if (q < nq) {
-                keep = keep_qword(amb, 64u * q + b0, k);
-                const uint32_t valid = mt - 64u * q;  // starts of this qword that exist
-                if (valid < 64u) keep &= (1ull << valid) - 1ull;
-                if (a.stride > 1) {                   // keep only starts with (m0 + 64q + j) % stride == 0
-                    const uint32_t rem = (tile_rem + (64u * q) % a.stride) % a.stride;   // (m0 + 64q) % stride
-                    const uint32_t first = rem ? a.stride - rem : 0u;                    // first lattice start of the qword, then every stride-th
+            if (64u * (wave * WQ + 64u * h) < mt) {  // (wave-uniform: the round exists)
+                if (q < nq) {
+                    if (k <= 33u) keep = keep_qword32<3>(amb32, q, b0, k);
+                    else if (k <= 65u) keep = keep_qword32<4>(amb32, q, b0, k);
+                    else keep = keep_qword(amb, 64u * q + b0, k);
+                }
+                if (64u * (wave * WQ + 64u * h + 64u) > mt) {  // (wave-uniform: the round holds the end of the tile)
+                    const uint32_t valid = q < nq ? mt - 64u * q : 0u;  // starts of this qword that exist
+                    if (valid < 64u) keep &= (1ull << valid) - 1ull;
+                }
+                if (a.stride > 1) {  // keep only starts with (m0 + 64q + j) % stride == 0
+                    uint32_t rem = ph[h] + tile_rem;                    // (m0 + 64q) % stride, before the reduction: < 2 stride
+                    rem = rem - a.stride < rem ? rem - a.stride : rem;  // (unsigned: the difference wraps when rem < stride)
+                    const uint32_t first = rem ? a.stride - rem : 0u;   // first lattice start of the qword, then every stride-th
                     keep = first < 64u ? keep & (lattice << first) : 0;
                 }
             }
             tr.k[h] = keep;
-            c2[h] = (uint32_t)__popcll(keep);
-            c += c2[h];
+            c += (uint32_t)__popcll(keep);
         }
-        uint32_t incl = c;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(incl, d, 64);
-            if ((int)lane >= d) incl += y;
-        }
+        const uint32_t incl = wave_scan_incl(c);
         if (lane == 63) s_wave_total[wave] = incl;
+        if constexpr (EMIT) {
+            if (ticket_next && tid == 0) s_tile = drawn;
+        }
         block_sync();
         uint32_t before = 0, tile_total = 0;
 #pragma unroll
@@ -322,14 +446,8 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             if (w < wave) before += wt;
             tile_total += wt;
         }
-        uint32_t running = before + incl - c;
-#pragma unroll
-        for (uint32_t h = 0; h < QPT; ++h) {
-            tr.p[h] = running;
-            running += c2[h];
-        }
-        tr.wave_end = before + (uint32_t)__shfl(incl, 63, 64);
-        tr.total = tile_total;
+        tr.wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);  // (the same in every lane: scalar registers)
+        tr.total = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_total);
         if (tid == 0) {
             if constexpr (UMODE == UMODE_COUNT) acc += tile_total;
             // the aggregate is out as early as it can be: the tiles behind this one wait for nothing else of it
@@ -345,6 +463,10 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     // ---- back of a tile: its exclusive prefix (look-back), then list and emit its kept starts --------------------------
     auto back = [&](uint64_t tile, uint32_t buf, const TileRegs &tr) {
         const uint64_t *const lds = lds2[buf];
+#if KMERS_UCUT == 1 || KMERS_UCUT == 2 || KMERS_UCUT == 4 || KMERS_UCUT == 5  // phase accounting: fronts only (nobody looks back, so nobody waits)
+        if (a.capacity == 0x6b6d657273756374ull) a.desc[tid] = lds[tid] + tr.k[0] + tr.wave_base + tr.total;
+        return;
+#endif
         const Geom g = geometry(tile);
         const uint32_t mt = g.mt, kbit0 = g.kbit0;
         const uint64_t m0 = g.m0;
@@ -408,292 +530,354 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             block_sync();
             USTAMP(6);
         }
-        const uint64_t base = EMIT ? s_base : 0;
+        const uint64_t base = EMIT ? uniform64(s_base) : 0;
+#if KMERS_UCUT == 3  // phase accounting: fronts and look-backs, nothing listed or stored
+        if (a.capacity == 0x6b6d657273756374ull) a.desc[tid] = lds[tid] + tr.k[0] + tr.wave_base + base;
+        return;
+#endif
 
         // every wavefront takes the CONTIGUOUS quarter of the tile whose keep mask its own lanes resolved, so that its stores
         // sweep one contiguous region of each output array and the mask never leaves the registers
-        uint16_t *mine = kept + wave * ULSTRIDE;
-        const uint32_t qw0 = wave * WQ;                                       // the wavefront's first qword
-        const uint32_t wave_end = (qw0 + WQ) * 64u < mt ? (qw0 + WQ) * 64u : mt;
-        // kept starts of the tile before qword qw0 + qrel (qrel <= WQ, the same in every lane)
-        auto prefix_at = [&](uint32_t qrel) -> uint32_t {
-            if (qrel >= WQ) return tr.wave_end;
-            uint32_t v = 0;
-#pragma unroll
-            for (uint32_t h = 0; h < QPT; ++h) {
-                const uint32_t x = (uint32_t)__shfl(tr.p[h], (int)(qrel / QPT), 64);
-                if (qrel % QPT == h) v = x;
-            }
-            return v;
-        };
+        uint16_t *const mine = kept + wave * ULSTRIDE;
+        const uint32_t qbase = wave * WQ * 64u;                 // tile-relative start of the wavefront's quarter
+        const uint64_t origin = m0 + 1 + a.index_origin;        // start of candidate r is origin + r
+        uint32_t roff = tr.wave_base;                           // kept starts of the tile before the current round
         bool framed = false;
         if constexpr (EMIT && !WIDE) framed = a.vec16 && !a.tuples;
-        if constexpr (EMIT && !WIDE) {
-            if (framed) {
-                // ---- the framed path (separate 16-byte aligned arrays, kmers of one to four words) -------------------------
-                const uint32_t qbase = qw0 * 64u;                       // tile-relative start of the wavefront's quarter
-                const uint64_t origin = m0 + 1 + a.index_origin;        // start of candidate r is origin + r
-                uint32_t list_n = 0;                                    // listed, not yet emitted (quarter-relative starts)
-                uint64_t list_pos = base + prefix_at(0);                // output index of the first element not yet emitted
-                // elements with output indexes [lo, hi) -> memory, frame by frame; start_of(j) = tile-relative start of element lo + j
-                auto emit_range = [&](uint64_t lo, uint64_t hi, auto start_of) {
-                    // (elements at or beyond the capacity are not stored: the host reports KMERS_E_CAPACITY with the count needed)
-                    const uint64_t room = a.capacity > lo ? a.capacity - lo : 0;
-                    const uint32_t n = (uint32_t)(hi - lo < room ? hi - lo : room);
-                    const uint32_t head = (uint32_t)lo & (UFRAME - 1u);  // where `lo` lies in its frame
-                    for (uint32_t f = 0; f < head + n; f += UFRAME) {
-                        const uint32_t j0 = f + 2u * lane - head, j1 = j0 + 1u;  // element numbers relative to lo (wrapped if before it)
-                        const bool v0 = j0 < n, v1 = j1 < n;
-                        if (!(v0 || v1)) continue;
-                        uint32_t ra = 0, rb = 0;
-                        uint64_t fa[NW], fb[NW];
-                        if (v0) {
-                            ra = start_of(j0);
-                            cut_fw<NW>(lds, kbit0 - 2u * ra, mask, fa);
-                        }
-                        if (v1) {
-                            rb = start_of(j1);
-                            cut_fw<NW>(lds, kbit0 - 2u * rb, mask, fb);
-                        }
-                        const uint64_t i1 = lo + j1, i0 = i1 - 1u;  // (i1 is the one that always exists: j1 = 0 when `lo` is odd)
-                        if (v0 && v1) {
-                            if (a.out_kmers) {
-                                if constexpr (N == 1) {
-                                    *reinterpret_cast<ulonglong2 *>(a.out_kmers + i0) = make_ulonglong2(fa[0], fb[0]);
-                                } else {
-                                    store_kmer<NW>(a.out_kmers, i0, fa);
-                                    store_kmer<NW>(a.out_kmers, i1, fb);
-                                }
+
+        // state of the framed path: slot s of the wavefront's list holds the element with output index frame_base + s; the
+        // listed, not yet emitted elements are the slots [head, head + list_n)
+        uint64_t frame_base = (base + roff) & ~(uint64_t)(UFRAME - 1u);
+        uint32_t head = (uint32_t)(base + roff) & (UFRAME - 1u), list_n = 0;
+
+        // elements with output indexes [lo, hi) -> memory, frame by frame with per-lane bounds (partial frames, rounds with nothing
+        // dropped); start_of(j) = tile-relative start of element lo + j
+        auto emit_range = [&](uint64_t lo, uint64_t hi, auto start_of) {
+            if constexpr (EMIT && !WIDE) {
+                // (elements at or beyond the capacity are not stored: the host reports KMERS_E_CAPACITY with the count needed)
+                const uint64_t room = a.capacity > lo ? a.capacity - lo : 0;
+                const uint32_t n = (uint32_t)(hi - lo < room ? hi - lo : room);
+                const uint32_t hd = (uint32_t)lo & (UFRAME - 1u);  // where `lo` lies in its frame
+                for (uint32_t f = 0; f < hd + n; f += UFRAME) {
+                    const uint32_t j0 = f + 2u * lane - hd, j1 = j0 + 1u;  // element numbers relative to lo (wrapped if before it)
+                    const bool v0 = j0 < n, v1 = j1 < n;
+                    if (!(v0 || v1)) continue;
+                    uint32_t ra = 0, rb = 0;
+                    uint64_t fa[NW], fb[NW];
+                    if (v0) {
+                        ra = start_of(j0);
+                        cut_fw<NW>(lds, kbit0 - 2u * ra, mask, fa);
+                    }
+                    if (v1) {
+                        rb = start_of(j1);
+                        cut_fw<NW>(lds, kbit0 - 2u * rb, mask, fb);
+                    }
+                    const uint64_t i1 = lo + j1, i0 = i1 - 1u;  // (i1 is the one that always exists: j1 = 0 when `lo` is odd)
+                    if (v0 && v1) {
+                        if (a.out_kmers) {
+                            if constexpr (N == 1) {
+                                *reinterpret_cast<ulonglong2 *>(a.out_kmers + i0) = make_ulonglong2(fa[0], fb[0]);
+                            } else {
+                                store_kmer<NW>(a.out_kmers, i0, fa);
+                                store_kmer<NW>(a.out_kmers, i1, fb);
                             }
-                            if (a.out_starts) *reinterpret_cast<ulonglong2 *>(a.out_starts + i0) = make_ulonglong2(origin + ra, origin + rb);
-                        } else {  // the first element of an odd range / the last of one that ends on an even index
-                            const uint64_t i = v0 ? i0 : i1;
-                            if (a.out_kmers) {
+                        }
+                        if (a.out_starts) *reinterpret_cast<ulonglong2 *>(a.out_starts + i0) = make_ulonglong2(origin + ra, origin + rb);
+                    } else {  // the first element of an odd range / the last of one that ends on an even index
+                        const uint64_t i = v0 ? i0 : i1;
+                        if (a.out_kmers) {
 #pragma unroll
-                                for (int wd = 0; wd < NW; ++wd) a.out_kmers[i * NW + wd] = v0 ? fa[wd] : fb[wd];
-                            }
-                            if (a.out_starts) a.out_starts[i] = (long long)(origin + (v0 ? ra : rb));
+                            for (int wd = 0; wd < NW; ++wd) a.out_kmers[i * NW + wd] = v0 ? fa[wd] : fb[wd];
+                        }
+                        if (a.out_starts) a.out_starts[i] = (long long)(origin + (v0 ? ra : rb));
+                    }
+                }
+            }
+        };
+        // whole frames of the list: slots [128 f0, 128 f1) -> memory, every lane two elements, no bounds (the caller checked the
+        // capacity); a lane's two entries are one aligned 32-bit word of the list
+        auto emit_frames = [&](uint32_t f0, uint32_t f1) {
+            if constexpr (EMIT && !WIDE) {
+                const uint32_t *const pairs = reinterpret_cast<const uint32_t *>(mine);
+                auto put = [&](uint64_t i0, uint32_t ra, uint32_t rb, const uint64_t (&fa)[NW], const uint64_t (&fb)[NW]) {
+#if KMERS_UCUT == 6  // phase accounting: the whole kernel without the stores of its whole frames
+                    if (fa[0] != 0x6b6d657273756374ull) return;
+#endif
+                    if (a.out_kmers) {
+                        if constexpr (N == 1) {
+                            *reinterpret_cast<ulonglong2 *>(a.out_kmers + i0) = make_ulonglong2(fa[0], fb[0]);
+                        } else {
+                            store_kmer<NW>(a.out_kmers, i0, fa);
+                            store_kmer<NW>(a.out_kmers, i0 + 1u, fb);
                         }
                     }
+                    if (a.out_starts) *reinterpret_cast<ulonglong2 *>(a.out_starts + i0) = make_ulonglong2(origin + ra, origin + rb);
                 };
-                auto listed = [&](uint32_t j) { return qbase + (uint32_t)mine[j]; };
-                uint32_t n_round = 0;
-                for (uint32_t r_begin = qbase; r_begin < wave_end; r_begin += n_round) {
-                    const uint32_t q0 = r_begin >> 6;
-                    const uint32_t round_off = prefix_at(q0 - qw0);
-                    // a long round if its kept starts fit the list (or nothing at all is dropped), else 1024 starts
-                    n_round = wave_end - r_begin < ULONG ? wave_end - r_begin : ULONG;
-                    uint32_t q1 = (r_begin + n_round + 63u) >> 6;
-                    uint32_t cnt = prefix_at(q1 - qw0) - round_off;
-                    uint32_t usl = ULONG / 64u;
-                    if (n_round > UROUND && cnt > ULIST && cnt != n_round) {
-                        n_round = UROUND;
-                        q1 = q0 + UROUND / 64u;
-                        cnt = prefix_at(q1 - qw0) - round_off;
-                        usl = USLICE;
-                    } else if (n_round <= UROUND) {
-                        usl = USLICE;
-                    }
-                    if (cnt == 0) continue;
-                    if (cnt == n_round) {
-                        // a round with nothing dropped (real sequence outside its N blocks) needs no list: element j starts at
-                        // r_begin + j.  Whatever is still listed goes first (output order).
-                        if (list_n) {
-                            emit_range(list_pos, list_pos + list_n, listed);
-                            list_pos += list_n;
-                            list_n = 0;
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                        emit_range(list_pos, list_pos + cnt, [&](uint32_t j) { return r_begin + j; });
-                        list_pos += cnt;
-                        continue;
-                    }
-                    // this lane's qword of the mask and the kept starts before it, from the lane that holds them
-                    const uint32_t sl = (lane * usl) & 63u;
-                    uint32_t qrel = q0 - qw0 + ((lane * usl) >> 6);
-                    if (qrel >= WQ) qrel = WQ - 1u;  // (a lane past the end of the round: its slice is empty, any qword will do)
-                    uint64_t km = 0;
-                    uint32_t km_before = 0;
+                uint32_t f = f0;
+                if constexpr (N == 1) {
+                    if (a.out_kmers && a.out_starts && f + 2u <= f1) {
+                        // The usual case (one-word kmers, both arrays), two frames per step and software-pipelined: a wavefront of
+                        // this kernel pays one LDS round trip per DEPENDENT step whatever the number of loads in it, and the faster
+                        // an emitting wavefront gets its stores out, the fewer of them it takes to keep the CU's store path busy
+                        // (profiles/r04_unamb.md).  The list words of the next step are in flight while the code words of this one
+                        // are cut; all twelve code words of a step are read before the first is used.
+                        const uint32_t *const codes = reinterpret_cast<const uint32_t *>(lds);
+                        const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+                        uint32_t p0 = pairs[64u * f + lane], p1 = pairs[64u * f + 64u + lane];
+                        for (; f + 2u <= f1; f += 2u) {
+                            const uint32_t r[4] = {qbase + (p0 & 0xffffu), qbase + (p0 >> 16), qbase + (p1 & 0xffffu), qbase + (p1 >> 16)};
+                            uint32_t w[4][3], o[4];
 #pragma unroll
-                    for (uint32_t h = 0; h < QPT; ++h) {
-                        const uint64_t xk = __shfl(tr.k[h], (int)(qrel / QPT), 64);
-                        const uint32_t xp = (uint32_t)__shfl(tr.p[h], (int)(qrel / QPT), 64);
-                        if (qrel % QPT == h) {
-                            km = xk;
-                            km_before = xp;
+                            for (int e = 0; e < 4; ++e) {
+                                o[e] = kbit0 - 2u * r[e];
+                                const uint32_t *const d = codes + (o[e] >> 5);
+                                w[e][0] = d[0];
+                                w[e][1] = d[1];
+                                w[e][2] = d[2];
+                            }
+                            if (f + 4u <= f1) {  // (wave-uniform)
+                                p0 = pairs[64u * f + 128u + lane];
+                                p1 = pairs[64u * f + 192u + lane];
+                            }
+                            uint32_t lo[4], hi[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                lo[e] = __builtin_amdgcn_alignbit(w[e][1], w[e][0], o[e] & 31u) & mlo;
+                                hi[e] = __builtin_amdgcn_alignbit(w[e][2], w[e][1], o[e] & 31u) & mhi;
+                            }
+                            const uint64_t i0 = frame_base + UFRAME * f + 2u * lane;
+#if KMERS_UCUT == 6  // phase accounting: the whole kernel without the stores of its whole frames
+                            if ((lo[0] ^ lo[1] ^ lo[2] ^ lo[3] ^ hi[0] ^ hi[1]) != 0x6b6d6572u) continue;
+#endif
+                            *reinterpret_cast<uint4 *>(a.out_kmers + i0) = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+                            *reinterpret_cast<ulonglong2 *>(a.out_starts + i0) = make_ulonglong2(origin + r[0], origin + r[1]);
+                            *reinterpret_cast<uint4 *>(a.out_kmers + i0 + UFRAME) = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+                            *reinterpret_cast<ulonglong2 *>(a.out_starts + i0 + UFRAME) = make_ulonglong2(origin + r[2], origin + r[3]);
                         }
                     }
-                    const uint32_t mine_n = lane * usl < n_round ? (n_round - lane * usl < usl ? n_round - lane * usl : usl) : 0u;
-                    const uint64_t keep16 = (km >> sl) & (mine_n >= 64u ? ~0ull : ((1ull << mine_n) - 1ull));
-                    // list the round's kept starts behind the carried ones, in order, relative to the quarter
-                    uint32_t o = list_n + km_before - round_off + (uint32_t)__popcll(km & ((1ull << sl) - 1ull));
-                    const uint32_t s0 = r_begin - qbase + lane * usl;
-                    uint32_t half_lo = (uint32_t)keep16, half_hi = (uint32_t)(keep16 >> 32);
-                    while (half_lo) {
-                        mine[o++] = (uint16_t)(s0 + (uint32_t)__builtin_ctz(half_lo));
-                        half_lo &= half_lo - 1u;
+                }
+                for (; f < f1; ++f) {
+                    const uint32_t pr = pairs[64u * f + lane];
+                    const uint32_t ra = qbase + (pr & 0xffffu), rb = qbase + (pr >> 16);
+                    uint64_t fa[NW], fb[NW];
+                    cut_fw<NW>(lds, kbit0 - 2u * ra, mask, fa);
+                    cut_fw<NW>(lds, kbit0 - 2u * rb, mask, fb);
+                    put(frame_base + UFRAME * f + 2u * lane, ra, rb, fa, fb);
+                }
+            }
+        };
+        auto listed = [&](uint32_t j) { return qbase + (uint32_t)mine[head + j]; };  // element j of the pending list
+#define LIST_FENCE(order)                          \
+    do {                                           \
+        __builtin_amdgcn_fence(order, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();           \
+    } while (0)
+        // everything still listed -> memory (a partial frame at its end); afterwards the list is empty and begins at `next`
+        auto flush_list = [&](uint64_t next) {
+            if (list_n) {
+                emit_range(frame_base + head, frame_base + head + list_n, listed);
+                LIST_FENCE(__ATOMIC_ACQUIRE);  // the list is rewritten by the next pass
+            }
+            frame_base = next & ~(uint64_t)(UFRAME - 1u);
+            head = (uint32_t)next & (UFRAME - 1u);
+            list_n = 0;
+        };
+        // the kept starts of the lanes [la, lb) of a round -> list slots, in order; o = this lane's first slot, s0 the
+        // quarter-relative start of its qword
+        auto list_lanes = [&](uint64_t km, uint32_t la, uint32_t lb, uint32_t o, uint32_t s0) {
+            uint32_t lo32 = (uint32_t)km, hi32 = (uint32_t)(km >> 32);
+            if (lane < la || lane >= lb) lo32 = hi32 = 0;
+            // (half by half: the 64-bit form of this loop is twelve instructions per listed start, a 32-bit half seven; the two
+            // halves side by side in one loop: 12.5, profiles/r04_unamb.md)
+            while (lo32) {
+                mine[o++] = (uint16_t)(s0 + (uint32_t)__builtin_ctz(lo32));
+                lo32 &= lo32 - 1u;
+            }
+            while (hi32) {
+                mine[o++] = (uint16_t)(s0 + 32u + (uint32_t)__builtin_ctz(hi32));
+                hi32 &= hi32 - 1u;
+            }
+        };
+        // a pass of a round: the lanes [la, lb) -- all that are left if their kept starts fit the list, else up to the next
+        // multiple of 32, else 16 lanes (1024 starts: always fit).  Returns lb; `cntp` = kept starts of the pass, `ea` = kept
+        // starts of the round before lane la
+        auto next_pass = [&](uint32_t la, uint32_t excl, uint32_t cnt, uint32_t &ea, uint32_t &cntp) {
+            ea = lane_value(excl, la);
+            uint32_t lb = 64u;
+            cntp = cnt - ea;
+            if (cntp > ULIST) {
+                lb = (la & ~31u) + 32u;
+                cntp = (lb < 64u ? lane_value(excl, lb) : cnt) - ea;
+                if (cntp > ULIST) {
+                    lb = la + 16u;
+                    cntp = (lb < 64u ? lane_value(excl, lb) : cnt) - ea;
+                }
+            }
+            return lb;
+        };
+
+        // (the masks of the rounds move down one place after every round, so that the loop always works on rot[0]: indexing the
+        // registers with the loop counter would put the tile's masks into scratch memory)
+        uint64_t rot[QPT];
+#pragma unroll
+        for (uint32_t hh = 0; hh < QPT; ++hh) rot[hh] = tr.k[hh];
+#pragma unroll 1
+        for (uint32_t h = 0; h < QPT; ++h) {
+            const uint32_t r_begin = qbase + 4096u * h;  // tile-relative first start of the round
+            if (r_begin >= mt) break;
+            const uint32_t n_round = mt - r_begin < 4096u ? mt - r_begin : 4096u;
+            UPHASE_BEGIN();
+            const uint64_t km = rot[0];
+#pragma unroll
+            for (uint32_t hh = 0; hh + 1 < QPT; ++hh) rot[hh] = rot[hh + 1];
+            const uint32_t c = (uint32_t)__popcll(km);
+            const uint32_t incl = wave_scan_incl(c), excl = incl - c;  // kept starts of the round before this lane's qword
+            const uint32_t cnt = lane_value(incl, 63);
+            UPHASE_END(3);
+            if (cnt == 0) continue;
+            const uint32_t s0 = 4096u * h + 64u * lane;  // quarter-relative first start of this lane's qword
+            if (framed) {
+                if (cnt == n_round) {
+                    // a round with nothing dropped (real sequence outside its N blocks) needs no list: element j starts at
+                    // r_begin + j.  Whatever is still listed goes first (output order).
+                    flush_list(base + roff);
+                    emit_range(base + roff, base + roff + cnt, [&](uint32_t j) { return r_begin + j; });
+                    roff += cnt;
+                    flush_list(base + roff);
+                    continue;
+                }
+                for (uint32_t la = 0; la < 64u;) {
+                    uint32_t ea, cntp;
+                    const uint32_t lb = next_pass(la, excl, cnt, ea, cntp);
+                    UPHASE_BEGIN();
+                    list_lanes(km, la, lb, head + list_n + excl - ea, s0);
+                    LIST_FENCE(__ATOMIC_RELEASE);
+                    UPHASE_END(0);
+                    const uint32_t end = head + list_n + cntp;          // slots [head, end) are listed
+                    uint32_t f0 = 0;
+                    if (head && end >= UFRAME) {  // the first frame of the quarter begins in the middle: per-lane bounds
+                        emit_range(frame_base + head, frame_base + UFRAME, listed);
+                        f0 = 1;
                     }
-                    while (half_hi) {
-                        mine[o++] = (uint16_t)(s0 + 32u + (uint32_t)__builtin_ctz(half_hi));
-                        half_hi &= half_hi - 1u;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const uint32_t total = list_n + cnt;
-                    const uint64_t end_emit = (list_pos + total) & ~(uint64_t)(UFRAME - 1u);  // the last whole frame's end
-                    if (end_emit > list_pos) {
-                        const uint32_t E = (uint32_t)(end_emit - list_pos), left = total - E;  // left < UFRAME
-                        emit_range(list_pos, end_emit, listed);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                    const uint32_t f1 = end / UFRAME;                    // whole frames: [f0, f1)
+                    if (f1 > f0 || f0) {
+                        UPHASE_BEGIN();
+                        if (f1 > f0) {
+                            if (frame_base + (uint64_t)UFRAME * f1 <= a.capacity) emit_frames(f0, f1);
+                            else emit_range(frame_base + (uint64_t)UFRAME * f0, frame_base + (uint64_t)UFRAME * f1,
+                                            [&](uint32_t j) { return qbase + (uint32_t)mine[UFRAME * f0 + j]; });
+                        }
+                        LIST_FENCE(__ATOMIC_ACQUIRE);
+                        UPHASE_END(1);
+                        UPHASE_BEGIN();
                         // what is left moves to the head of the list: every lane reads before any lane writes
+                        const uint32_t E = UFRAME * f1, left = end - E;  // left < UFRAME
                         uint16_t x0 = 0, x1 = 0;
                         if (lane < left) x0 = mine[E + lane];
                         if (lane + 64u < left) x1 = mine[E + lane + 64u];
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                        LIST_FENCE(__ATOMIC_ACQ_REL);
                         if (lane < left) mine[lane] = x0;
                         if (lane + 64u < left) mine[lane + 64u] = x1;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        list_pos = end_emit;
+                        LIST_FENCE(__ATOMIC_RELEASE);
+                        frame_base += E;
+                        head = 0;
                         list_n = left;
+                        UPHASE_END(2);
                     } else {
-                        list_n = total;
+                        list_n += cntp;
                     }
+                    la = lb;
                 }
-                if (list_n) emit_range(list_pos, list_pos + list_n, listed);  // the tail of the quarter: one partial frame
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next tile
+                roff += cnt;
+                continue;
             }
-        }
-        // ---- the generic path: one element per lane (Tuple{Kmer,Int} elements, unaligned outputs, kmers of run-time width, and
-        // the XOR reducer, which stores nothing)
-        uint32_t n_round = 0;
-        for (uint32_t r_begin = qw0 * 64u; r_begin < wave_end && !framed; r_begin += n_round) {
-            const uint32_t q0 = r_begin >> 6;
-            const uint32_t round_off = prefix_at(q0 - qw0);
-            // a long round if its kept starts fit the list (or nothing at all is dropped), else 1024 starts
-            n_round = wave_end - r_begin < ULONG ? wave_end - r_begin : ULONG;
-            uint32_t q1 = (r_begin + n_round + 63u) >> 6;
-            uint32_t cnt = prefix_at(q1 - qw0) - round_off;                // kept starts of this round
-            uint32_t usl = ULONG / 64u;                                    // consecutive starts per lane
-            uint64_t pos = base + round_off;                               // output index of the round's first
-            if (n_round > UROUND && cnt > ULIST) {
-                n_round = UROUND;
-                q1 = q0 + UROUND / 64u;
-                cnt = prefix_at(q1 - qw0) - round_off;
-                usl = USLICE;
-            } else if (n_round <= UROUND) {
-                usl = USLICE;
-            }
-            // this lane's qword of the mask and the kept starts before it, from the lane that holds them
-            const uint32_t sl = (lane * usl) & 63u;
-            uint32_t qrel = q0 - qw0 + ((lane * usl) >> 6);
-            if (qrel >= WQ) qrel = WQ - 1u;  // (a lane past the end of the round: its slice is empty, any qword will do)
-            uint64_t km = 0;
-            uint32_t km_before = 0;
-#pragma unroll
-            for (uint32_t h = 0; h < QPT; ++h) {
-                const uint64_t xk = __shfl(tr.k[h], (int)(qrel / QPT), 64);
-                const uint32_t xp = (uint32_t)__shfl(tr.p[h], (int)(qrel / QPT), 64);
-                if (qrel % QPT == h) {
-                    km = xk;
-                    km_before = xp;
-                }
-            }
-            // this lane's slice of the keep mask: `usl` consecutive starts, cut at the end of the round (the starts behind it
-            // belong to the next wavefront's chunk)
-            const uint32_t mine_n = lane * usl < n_round ? (n_round - lane * usl < usl ? n_round - lane * usl : usl) : 0u;
-            uint64_t keep16 = (km >> sl) & (mine_n >= 64u ? ~0ull : ((1ull << mine_n) - 1ull));
-            if (cnt == 0) continue;
-            const uint64_t origin = m0 + 1 + a.index_origin;                     // start of candidate r is origin + r
-            // list the kept starts of the round in LDS, in order: this lane's slice of consecutive starts begins at list index o
-            uint32_t o = km_before - round_off + (uint32_t)__popcll(km & ((1ull << sl) - 1ull));
-            const uint32_t s0 = lane * usl;  // round-relative index of the slice's first start
-            // (half by half: the 64-bit form of this loop is twelve instructions per listed start, a 32-bit half seven)
-            uint32_t half_lo = (uint32_t)keep16, half_hi = (uint32_t)(keep16 >> 32);
-            while (half_lo) {
-                mine[o++] = (uint16_t)(s0 + (uint32_t)__builtin_ctz(half_lo));
-                half_lo &= half_lo - 1u;
-            }
-            while (half_hi) {
-                mine[o++] = (uint16_t)(s0 + 32u + (uint32_t)__builtin_ctz(half_hi));
-                half_hi &= half_hi - 1u;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // one listed element: window cut + stores (also the generic path: tuples, unaligned outputs, the XOR reducer)
-            auto emit_one = [&](uint32_t i) {
-                const uint32_t r = r_begin + (uint32_t)mine[i];
-                if constexpr (WIDE) {
-                    // run-time width: word n_words-1-j of the kmer = stream bits [o + 64j, +64), straight to memory
-                    const uint32_t o = kbit0 - 2u * r, q = o >> 6, sh = o & 63u;
-                    const uint64_t o2 = pos + i;
-                    uint64_t lo = lds[q], head = 0;
-                    for (uint32_t j = 0; j < n_words; ++j) {
-                        const uint64_t hi = lds[q + j + 1u];
-                        uint64_t w = funnel64(lo, hi, sh);
-                        lo = hi;
-                        if (j + 1u == n_words) head = w &= mask;
-                        if constexpr (UMODE != UMODE_XOR) {
-                            if (o2 < a.capacity && a.out_kmers) a.out_kmers[o2 * (n_words + (a.tuples ? 1u : 0u)) + (n_words - 1u - j)] = w;
+            // ---- the generic path: one element per lane (Tuple{Kmer,Int} elements, unaligned outputs, kmers of run-time width, and
+            // the XOR reducer, which stores nothing)
+            for (uint32_t la = 0; la < 64u;) {
+                uint32_t ea, cntp;
+                const uint32_t lb = next_pass(la, excl, cnt, ea, cntp);
+                list_lanes(km, la, lb, excl - ea, s0);
+                LIST_FENCE(__ATOMIC_RELEASE);
+                const uint64_t pos = base + roff + ea;  // output index of the pass's first element
+                // one listed element: window cut + stores
+                auto emit_one = [&](uint32_t i) {
+                    const uint32_t r = qbase + (uint32_t)mine[i];
+                    if constexpr (WIDE) {
+                        // run-time width: word n_words-1-j of the kmer = stream bits [o + 64j, +64), straight to memory
+                        const uint32_t o = kbit0 - 2u * r, q = o >> 6, sh = o & 63u;
+                        const uint64_t o2 = pos + i;
+                        uint64_t lo = lds[q], head_word = 0;
+                        for (uint32_t j = 0; j < n_words; ++j) {
+                            const uint64_t hi = lds[q + j + 1u];
+                            uint64_t w = funnel64(lo, hi, sh);
+                            lo = hi;
+                            if (j + 1u == n_words) head_word = w &= mask;
+                            if constexpr (UMODE != UMODE_XOR) {
+                                if (o2 < a.capacity && a.out_kmers) a.out_kmers[o2 * (n_words + (a.tuples ? 1u : 0u)) + (n_words - 1u - j)] = w;
+                            }
                         }
+                        if constexpr (UMODE == UMODE_XOR) {
+                            acc ^= head_word;
+                        } else if (o2 < a.capacity) {
+                            if (a.tuples) a.out_kmers[o2 * (n_words + 1u) + n_words] = origin + r;
+                            else if (a.out_starts) a.out_starts[o2] = (long long)(origin + r);
+                        }
+                        return;
                     }
+                    uint64_t fw[NW];
+                    cut_fw<NW>(lds, kbit0 - 2u * r, mask, fw);
                     if constexpr (UMODE == UMODE_XOR) {
-                        acc ^= head;
-                    } else if (o2 < a.capacity) {
-                        if (a.tuples) a.out_kmers[o2 * (n_words + 1u) + n_words] = origin + r;
-                        else if (a.out_starts) a.out_starts[o2] = (long long)(origin + r);
-                    }
-                    return;
-                }
-                uint64_t fw[NW];
-                cut_fw<NW>(lds, kbit0 - 2u * r, mask, fw);
-                if constexpr (UMODE == UMODE_XOR) {
-                    acc ^= fw[0];
-                } else {
-                    const uint64_t o2 = pos + i;
-                    if (o2 < a.capacity) {
-                        if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
-                            if (N == 1 && a.vec16) {  // one 16-byte store per element
-                                *reinterpret_cast<ulonglong2 *>(a.out_kmers + 2u * o2) = make_ulonglong2(fw[0], origin + r);
+                        acc ^= fw[0];
+                    } else {
+                        const uint64_t o2 = pos + i;
+                        if (o2 < a.capacity) {
+                            if (a.tuples) {  // Tuple{Kmer,Int}: eltype of UnambiguousKmers (UnambiguousKmers.jl:39-41)
+                                if (N == 1 && a.vec16) {  // one 16-byte store per element
+                                    *reinterpret_cast<ulonglong2 *>(a.out_kmers + 2u * o2) = make_ulonglong2(fw[0], origin + r);
+                                } else {
+#pragma unroll
+                                    for (int wd = 0; wd < NW; ++wd) a.out_kmers[o2 * (NW + 1) + wd] = fw[wd];
+                                    a.out_kmers[o2 * (NW + 1) + NW] = origin + r;
+                                }
                             } else {
+                                if (a.out_kmers) {
 #pragma unroll
-                                for (int wd = 0; wd < NW; ++wd) a.out_kmers[o2 * (NW + 1) + wd] = fw[wd];
-                                a.out_kmers[o2 * (NW + 1) + NW] = origin + r;
+                                    for (int wd = 0; wd < NW; ++wd) a.out_kmers[o2 * NW + wd] = fw[wd];
+                                }
+                                if (a.out_starts) a.out_starts[o2] = (long long)(origin + r);
                             }
-                        } else {
-                            if (a.out_kmers) {
-#pragma unroll
-                                for (int wd = 0; wd < NW; ++wd) a.out_kmers[o2 * NW + wd] = fw[wd];
-                            }
-                            if (a.out_starts) a.out_starts[o2] = (long long)(origin + r);
                         }
                     }
-                }
-            };
-            for (uint32_t i = lane; i < cnt; i += 64u) emit_one(i);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next round
+                };
+                for (uint32_t i = lane; i < cntp; i += 64u) emit_one(i);
+                LIST_FENCE(__ATOMIC_ACQUIRE);  // the list is rewritten by the next pass
+                la = lb;
+            }
+            roff += cnt;
         }
+        if (framed) flush_list(0);  // the tail of the quarter: one partial frame
 #ifdef KMERS_STAMPS
         USTAMP(7);  // this wavefront's stores issued
         if (a.stamps && (tile & 15u) == 0 && lane == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            uint64_t *o = a.stamps + ((tile >> 4) * WAVES + wave) * 10;
+            uint64_t *o = a.stamps + ((tile >> 4) * WAVES + wave) * 16;
             for (int i = 0; i < 8; ++i) o[i] = ts[i];
             o[8] = __builtin_amdgcn_s_memrealtime();  // ... and drained
             o[9] = tile;
+            for (int i = 0; i < 4; ++i) o[10 + i] = tp[i];
         }
+        for (int i = 0; i < 4; ++i) tp[i] = 0;
 #endif
     };
+
+#undef LIST_FENCE
 
     if constexpr (!EMIT) {
         // COUNT / XOR: a persistent grid strides over the tiles; nothing is placed, so no descriptors
         for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-            const TileRegs tr = front(tile, 0);
+            uint64_t xs[XS];
+            load_words(tile, xs);
+            const TileRegs tr = front(tile, 0, xs, false);
             if constexpr (UMODE == UMODE_XOR) {
                 block_sync();
                 back(tile, 0, tr);
@@ -707,27 +891,50 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         // staged, resolved and its aggregate published before tile n looks back and emits.  An aggregate is thus out a few
         // microseconds after its ticket was drawn, and by the time a tile looks back -- one whole front later -- its
         // predecessors have published theirs: the look-back finds what it needs at once (it waited 14 us per tile, with
-        // three of the four wavefronts idle, when it ran right behind the tile's own resolve).
-        auto draw = [&]() {
-            block_sync();  // (everybody has read the previous s_tile)
-            if (tid == 0) s_tile = atomicAdd(a.ticket, 1ull);
-            block_sync();
-            return (uint64_t)s_tile;
-        };
-        uint64_t cur = draw();
+        // three of the four wavefronts idle, when it ran right behind the tile's own resolve).  The tile after next (`nn`) has
+        // its ticket drawn inside the front of `nxt` and its source words in flight while `cur` is emitted.  (A workgroup holds
+        // three tickets; the smallest tile without an aggregate is either about to be resolved by a workgroup whose look-back --
+        // for a smaller tile -- finds every aggregate it needs, or it is that workgroup's `nn`, one `back` of that kind away
+        // from its front: still no circular wait.)
+        uint64_t xs[XS];
+#if KMERS_USTAGGER > 0
+        // The workgroups of a launch start together and their tiles take about the same time: without this their fronts (no
+        // stores) and their backs (nothing but stores) stay in step across the whole device, and the store path idles through
+        // every front.  A quarter, a half, three quarters of a tile time late, before the first ticket is drawn (nobody waits for
+        // a workgroup that holds no ticket).
+        {
+            const uint32_t step = (KMERS_USTAGGER_HASH ? (blockIdx.x * 2654435761u) >> 30 : (blockIdx.x >> 8)) & 3u;
+            for (uint32_t i = 0; i < step * (uint32_t)KMERS_USTAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+#endif
+        block_sync();
+        if (tid == 0) s_tile = atomicAdd(a.ticket, 1ull);
+        block_sync();
+        uint64_t cur = uniform64(s_tile);
         uint32_t buf = 0;
         TileRegs tr_cur{}, tr_nxt{};
-        if (cur < a.n_tiles) tr_cur = front(cur, buf);
+        uint64_t nxt = ~0ull;
+        if (cur < a.n_tiles) {
+            load_words(cur, xs);
+            tr_cur = front(cur, buf, xs, true);  // (draws the second ticket on the way)
+            nxt = uniform64(s_tile);
+            if (nxt < a.n_tiles) load_words(nxt, xs);
+        }
         while (cur < a.n_tiles) {
 #ifdef KMERS_STAMPS
             ts[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-            const uint64_t nxt = draw();
-            if (nxt < a.n_tiles) tr_nxt = front(nxt, buf ^ 1u);
+            uint64_t nn = ~0ull;
+            if (nxt < a.n_tiles) {
+                tr_nxt = front(nxt, buf ^ 1u, xs, true);
+                nn = uniform64(s_tile);
+                if (nn < a.n_tiles) load_words(nn, xs);  // in flight while `cur` is emitted
+            }
             block_sync();  // the codes of the tile are staged for every wavefront
             back(cur, buf, tr_cur);
             tr_cur = tr_nxt;
             cur = nxt;
+            nxt = nn;
             buf ^= 1u;
         }
     }

@@ -28,10 +28,11 @@ constexpr uint32_t WIDE_TILE_LDS_BYTES = 60u * 1024u;  // budget of the staged s
 
 // 64-bit words of LDS stream a tile of `tile` windows needs (the stream starts at the source word that holds the tile's
 // first symbol; two spare words behind it: a chunk read may touch the word after its last symbol)
-inline uint32_t wide_tile_stream_words(uint32_t tile, uint32_t k, uint32_t stride, int src_bits, int dst_bits) {
+// (64-bit: a tile of a very long stride must compare as too large for the LDS budget, not wrap around to a small number)
+inline uint64_t wide_tile_stream_words(uint32_t tile, uint32_t k, uint32_t stride, int src_bits, int dst_bits) {
     const uint64_t symbols = (uint64_t)(tile - 1u) * stride + k + (uint64_t)(64 / src_bits - 1);
     const uint64_t src_words = (symbols * (uint64_t)src_bits + 63u) / 64u + 1u;
-    return (uint32_t)((src_words * (uint64_t)dst_bits + (uint64_t)src_bits - 1u) / (uint64_t)src_bits + 2u);
+    return (src_words * (uint64_t)dst_bits + (uint64_t)src_bits - 1u) / (uint64_t)src_bits + 2u;
 }
 
 template <int SRC_BITS, int DST, int WMODE>
@@ -254,7 +255,7 @@ int launch_wide_tile(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, 
                   : WMODE == WMODE_CANON ? std::max<uint32_t>((uint32_t)BLOCK, (2048u / n_words + BLOCK - 1u) / BLOCK * BLOCK) : 2048u;
     if (ctx->tile_kmers > 0) tile = (uint32_t)std::min<int64_t>(ctx->tile_kmers, 1 << 16);  // tests, tuning
     tile = (uint32_t)std::min<uint64_t>(tile, a.n_kmers);
-    auto lds_bytes = [&](uint32_t t) { return (size_t)wide_tile_stream_words(t, a.k, a.stride, src_bits, dst_bits) * 8u + ((t + 7u) & ~7u); };
+    auto lds_bytes = [&](uint32_t t) { return wide_tile_stream_words(t, a.k, a.stride, src_bits, dst_bits) * 8u + ((t + 7u) & ~7u); };
     const uint32_t word_pitch = n_words | 1u;  // (odd: the fold's lanes read LDS words `pitch` apart)
     while (tile > 1u && lds_bytes(tile) > WIDE_TILE_LDS_BYTES) tile /= 2u;
     if (lds_bytes(tile) > WIDE_TILE_LDS_BYTES) return -1;
@@ -262,7 +263,7 @@ int launch_wide_tile(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, 
     if (n_tiles >= (1ull << 31)) return -1;
     a.tile_kmers = tile;
     a.n_tiles = n_tiles;
-    const uint32_t sw = wide_tile_stream_words(tile, a.k, a.stride, src_bits, dst_bits);
+    const uint32_t sw = (uint32_t)wide_tile_stream_words(tile, a.k, a.stride, src_bits, dst_bits);  // (fits: lds_bytes(tile) is within the budget)
     size_t dyn = lds_bytes(tile);
     uint32_t cw_pitch = 0;  // CANON with hashes: the tile's canonical words staged in LDS for the fold, if they fit
     if (WMODE == WMODE_CANON && (a.out_b || a.tuples) && dyn + (size_t)tile * word_pitch * 8u <= WIDE_TILE_LDS_BYTES) {

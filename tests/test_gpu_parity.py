@@ -265,6 +265,43 @@ def test_ascii_sources(km, ctx, orc):
         assert np.array_equal(out, ek), first
 
 
+def test_ascii_table_sources_on_strided_and_tuple_kernels(km, ctx, orc):
+    """Text into a 4-bit alphabet goes through the alphabet's 256-entry table in LDS (stage_word), and the strided / tuple
+    instantiations of the stream kernel stage their first tile before the tile loop's first barrier: the table must be complete
+    before any wavefront looks a byte up (round 3 advisor: a missing barrier behind the table fill).  Many workgroups of 256
+    threads, repeated: SpacedKmers with strides 2..32, Tuple{Kmer,Kmer} and Tuple{Kmer,UInt64} elements, against the oracle."""
+    cap = km._capi
+    rng = np.random.default_rng(4242)
+    L = 400_000
+    text = naive.random_text(rng, L, p_amb=0.05)
+    text = "".join(c.lower() if rng.random() < 0.3 else c for c in text)
+    seq, keep = ascii_seq(km, text, L)
+    res = cap.Result()
+    ctx.set_param(cap.PARAM_BLOCK_THREADS, 256)
+    try:
+        for rep in range(3):
+            for K, J in ((5, 3), (21, 3), (16, 2), (7, 32)):
+                n = (L - K) // J + 1
+                N = (4 * K + 63) // 64
+                out = np.zeros((n, N), np.uint64)
+                assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq), K, J, 4, vp(out), 0, C.byref(res)) == 0, ctx.last_error()
+                ek, er = orc.spaced(keep, L, 8, 4, K, J)
+                assert er.status == 0 and np.array_equal(out, ek), (rep, K, J)
+            for K in (9, 16, 31):
+                n = L - K + 1
+                N = (4 * K + 63) // 64
+                t = np.zeros((n, 2 * N), np.uint64)
+                assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 4, vp(t), None, cap.OUT_TUPLES, C.byref(res)) == 0, ctx.last_error()
+                efw, erv, _ = orc.fwrv(keep, L, 8, 4, K)
+                assert np.array_equal(t, np.concatenate([efw, erv], axis=1)), (rep, K)
+                t = np.zeros((n, N + 1), np.uint64)
+                assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 4, vp(t), None, 3, cap.OUT_TUPLES, C.byref(res)) == 0
+                ek, eh, _ = orc.canonical(keep, L, 8, 4, K, seed=3)
+                assert np.array_equal(t, np.concatenate([ek, eh[:, None]], axis=1)), (rep, K)
+    finally:
+        ctx.set_param(cap.PARAM_BLOCK_THREADS, 0)
+
+
 def test_ascii_errors(km, ctx, orc):
     cap = km._capi
     rng = np.random.default_rng(89)
@@ -1282,7 +1319,7 @@ import numpy as np
 import kmers_jl_amd as km
 cap = km._capi
 ctx = km.Context(0)
-L, K = 200_000, 31                      # seven tiles of 32768 candidate starts
+L, K = 400_000, 31                      # nine tiles of 49152 candidate starts (any tile length below L / 2 leaves a tile 1 AND a tile 2 to wait for it)
 nw = L // 16 + 1
 d_w, d_k, d_s = ctx.alloc(nw * 8 + 8), ctx.alloc(L * 8), ctx.alloc(L * 8)
 ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, 3, 0, nw, 4, 2621, d_w), "synth")

@@ -24,7 +24,7 @@ for label, amb, K, J in CASES[:int(os.environ.get("KMERS_STAMPS_CASES", "3"))]:
     assert lib.kmers_synth_dna(h, 7, 0, nw, 4, amb, buf.data_ptr()) == 0
     for tile in [int(t) for t in os.environ.get("KMERS_STAMPS_TILES", "32768,8192").split(",")]:
         ntiles = (L - K + 1 + tile - 1) // tile
-        st = torch.zeros(((ntiles >> 4) + 2) * 4 * 10, dtype=torch.int64, device=dev)
+        st = torch.zeros(((ntiles >> 4) + 2) * 4 * 16, dtype=torch.int64, device=dev)
         lib.kmers_ctx_set_param(h, cap.PARAM_TILE_KMERS, tile)
         lib.kmers_ctx_set_param(h, 3, st.data_ptr())
         seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0); res = cap.Result()
@@ -32,7 +32,7 @@ for label, amb, K, J in CASES[:int(os.environ.get("KMERS_STAMPS_CASES", "3"))]:
             st.zero_(); torch.cuda.synchronize()
             rc = lib.kmers_unambiguous(h, C.byref(seq), K, J, kk.data_ptr(), ss.data_ptr(), L, cap.MEM_DEVICE, C.byref(res))
             assert rc == 0, rc
-        s = st.cpu().numpy().reshape(-1, 10)
+        s = st.cpu().numpy().reshape(-1, 16)
         s = s[s[:, 0] != 0]
         d = np.diff(s[:, :9], axis=1) * 10.0  # 100 MHz ticks -> ns
         span = (s[:, 8].max() - s[:, 0].min()) * 10.0
@@ -40,6 +40,8 @@ for label, amb, K, J in CASES[:int(os.environ.get("KMERS_STAMPS_CASES", "3"))]:
         for i, nm in enumerate(names):
             print(f"    {nm:26s} mean {d[:, i].mean():8.0f} ns   median {np.median(d[:, i]):8.0f}   p90 {np.percentile(d[:, i], 90):8.0f}")
         print(f"    {'total':26s} mean {d.sum(axis=1).mean():8.0f} ns")
+        for i, nm in enumerate(["back: listing", "back: whole frames", "back: carry", "back: round scan"]):  # shader cycles (s_memtime)
+            print(f"    {nm:26s} mean {s[:, 10 + i].mean():8.0f} cycles")
         # start time of a tile against its ticket: how many are in flight
         t0 = s[:, 0].astype(np.float64) * 10.0; t0 -= t0.min()
         order = np.argsort(s[:, 9])
