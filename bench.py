@@ -50,7 +50,13 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB
 FX_CONSTANT = 0x517CC1B727220A95
 GOLDEN = 0x9E3779B97F4A7C15
 NORTH_STAR_BASES = 10_000_000_000
-N_SIMDS = 1024  # 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its SIMD for 4 cycles
+N_SIMDS = 1024  # 256 CUs x 4 SIMDs
+# What a SIMD of this device issues (tools/valu_rates.hip, profiles/r04_valu_rates.txt; cycles per wave64 vector instruction at
+# eight wavefronts per SIMD): 1.32 for the two-operand integer instructions (v_and / v_add / v_lshrrev_b32; three-register
+# v_bitop3), 2.35 for everything else these kernels use (v_alignbit, v_perm, v_lshl_or, v_bfe, v_mul_lo, 64-bit shifts, ...).  ONE
+# wavefront alone issues one every 4.5-4.9 cycles: the "4 cycles per instruction" of rounds 2-3 was that, not the SIMD's limit
+# (which is why a kernel could "beat" it).  A true floor prices every instruction at the fastest class.
+VALU_CYCLES_FAST, VALU_CYCLES_SLOW = 1.32, 2.35
 
 
 def log(*a):
@@ -77,7 +83,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--alloc", choices=("arena", "plain"), default="arena",
                     help="arena: buffers from kmers_arena_reserve + kmers_dev_alloc (the product's allocator); plain: torch allocations")
-    ap.add_argument("--arena-gb", type=float, default=0.0, help="size of the arena (0 = three quarters of the free memory)")
+    ap.add_argument("--arena-gb", type=float, default=208.0,
+                    help="size of the arena in GB: an explicit amount (the 10 Gbase leg needs 165 GB of it; the PMC child processes take "
+                         "theirs from what is left); 0 = three quarters of the free memory; a reservation that fails falls back to that")
     ap.add_argument("--wake-s", type=float, default=1.0, help="seconds of plain fills before the W warm-up steps (a fresh or idle device is slower at first)")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)  # internal: the profiled child ("headline" or "legs")
     return ap.parse_args(argv)
@@ -296,7 +304,7 @@ def busy_timed(ctx, stream, fn, reps=7, busy_s=0.05):
     return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
-def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7):
+def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_gbps=HBM_PEAK_GBPS, write_ceiling_source="8 TB/s spec (no arena map)"):
     """Kernel rates of the other BASELINE.json configs (parity-test cases, not the headline): C3 shape
     per GPU, C4, C5 strict and skip, and the north-star size (10 Gbase LongDNA{4}).  Resident data, HIP events on
     the library's stream, median of reps.  The 10 Gbase leg comes last: 165 GB of output per launch leave the device in a
@@ -324,17 +332,24 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7):
                      "GB_per_s": round(alg_bytes / ms / 1e6, 1), "frac_of_8TBps": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBPS, 4), **extra}
 
     def ceilings(leg, ms, alg_bytes):
-        """What bounds a leg that is not purely a store stream: its HBM floor (algorithmic bytes at the device's measured
-        two-array store rate of 6.3 TB/s), its VALU floor (instructions x 4 cycles / 1024 SIMDs at the measured clock) and
-        the fraction of the larger of the two that the measured time reaches."""
+        """What bounds a leg that is not purely a store stream.  Every ratio is formed inside ONE profiled dispatch (its duration,
+        its SQ_INSTS_VALU and its GRBM_GUI_ACTIVE, measure_legs); the unprofiled time of this run stands beside them, it is
+        not divided into them.  hbm_floor: algorithmic bytes at the two-stream rate the arena MEASURED for its best pair of
+        places (kmers_arena_rates; 8 TB/s spec if there is no map); valu_floor: every vector instruction at the fastest rate
+        the SIMDs issue (VALU_CYCLES_FAST) -- a floor no instruction mix can beat, `valu_floor_ms_all_slow` the same at the
+        three-operand rate; frac_of_max_floor = the larger floor / the profiled duration (<= 1 by construction)."""
         v = valu.get(leg)
         if not v:
             return {"valu_issue": "not measured (no PMC pass)"}
-        hbm_floor = alg_bytes / 6.3e12 * 1e3 if alg_bytes else 0.0
+        hbm_floor = alg_bytes / (write_ceiling_gbps * 1e9) * 1e3 if alg_bytes else 0.0
         floor = max(hbm_floor, v["valu_floor_ms"] or 0.0)
-        return {"valu_issue_frac": v["valu_issue_frac"], "valu_insts_per_launch": v["valu_insts"], "valu_floor_ms": v["valu_floor_ms"],
-                "hbm_floor_ms_at_6.3TBps": round(hbm_floor, 4), "frac_of_max_floor": round(floor / ms, 4) if ms else None,
-                "valu_source": v["source"]}
+        prof = v["profiled_ms"]
+        return {"profiled_ms": prof, "profiled_clock_GHz": v["clock_GHz"], "unprofiled_ms_this_run": round(ms, 4),
+                "valu_insts_per_launch": v["valu_insts"], "valu_cycles_per_inst_per_simd": v["cycles_per_inst"],
+                "valu_floor_ms": v["valu_floor_ms"], "valu_floor_ms_all_slow": v["valu_floor_ms_slow"],
+                "valu_frac_of_floor": round((v["valu_floor_ms"] or 0.0) / prof, 4) if prof else None,
+                "hbm_floor_ms": round(hbm_floor, 4), "hbm_floor_rate_GBps": round(write_ceiling_gbps, 1), "hbm_floor_rate_source": write_ceiling_source,
+                "frac_of_max_floor": round(floor / prof, 4) if prof else None, "valu_source": v["source"]}
 
     with torch.cuda.stream(stream):
         # C3: CanonicalDNAMers{31} over 10 Gbase LongDNA{2} sharded 8 ways -> 1.25 Gbase per GPU, kmers only
@@ -386,7 +401,8 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7):
         # issue rate, SURVEY.md 8d -- kmers/s and the VALU issue share, not HBM bytes)
         def fused(name, leg, ms, n_kmers):
             out[name] = {"ms": round(ms, 4), "Gbases_per_s": round(L / ms / 1e6, 1), "G_kmers_per_s": round(n_kmers / ms / 1e6, 1),
-                         "bound": "VALU issue", **ceilings(leg, ms, 0.0)}
+                         "bound": "instruction issue (nothing is materialised: 0.5 B/base of HBM reads); valu_cycles_per_inst_per_simd "
+                                  "against the 1.32-2.35 the SIMDs can issue says how far from it", **ceilings(leg, ms, 0.0)}
         val = C.c_uint64()
         ms = timed(lambda: ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), 31, 2, 1, C.byref(val), cap.MEM_DEVICE, C.byref(res)))
         fused("fused XOR-reduce of CanonicalDNAMers{31} (test/benchmark.jl:9-15)", "xor", ms, L - 30)
@@ -439,8 +455,70 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7):
         mem.free(a, b, buf)
         del a, b, buf
         torch.cuda.empty_cache()
+        try:
+            out["e2e host pointers (H2D + kernel + D2H; never `value`)"] = host_pointer_path(ctx, cap, dev)
+        except Exception as e:  # noqa: BLE001
+            out["e2e host pointers (H2D + kernel + D2H; never `value`)"] = {"error": repr(e)}
         # N1 (north star): CanonicalDNAMers{31} + fx_hash over 10 Gbase LongDNA{4} on ONE GPU: 5 GB in, 160 GB out
         out.update(north_star_one_gpu(ctx, cap, stream, dev, mem, reps))
+    return out
+
+
+def host_pointer_path(ctx, cap, dev, L=256_000_000, K=31):
+    """The path a host WITHOUT device memory of its own takes (Julia's collect(CanonicalDNAMers{31}(seq)),
+    src/iterators/CanonicalKmers.jl:220-225): kmers_canonical with KMERS_MEM_HOST -- the words go up, kmers + hashes come
+    down, 16.5 bytes per kmer over PCIe.  End to end, wall clock, best of three, into pageable and into pinned host arrays;
+    beside it what one plain copy of the same bytes to the same kind of host memory takes on this box (kmers_memcpy_d2h =
+    hipMemcpyAsync + stream wait), and the same call as ONE launch + one copy (KMERS_PARAM_HOST_CHUNKS = -1).  Never `value`."""
+    import numpy as np
+    import torch
+
+    from oracle import pyoracle
+    orc = pyoracle.get()
+    res = cap.Result()
+    nw = (L * 4 + 63) // 64
+    words = orc.synth_words(GOLDEN ^ 21, 0, nw + 1, 4)
+    n = L - K + 1
+    seq = cap.Seq(words.ctypes.data, L, 0, 0, 4, 0)
+    moved = nw * 8 + 16 * n
+    out = {"workload": f"CanonicalDNAMers{{{K}}} + fx_hash over {L / 1e6:.0f} Mbase LongDNA{{4}}, host pointers in and out (KMERS_MEM_HOST), "
+                       f"{moved / 1e9:.2f} GB over PCIe per call"}
+    dbuf = ctx.alloc(8 * n)
+    try:
+        for kind in ("pageable", "pinned"):
+            if kind == "pageable":
+                ka, ha = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+            else:
+                tk, th = torch.empty(n, dtype=torch.int64, pin_memory=True), torch.empty(n, dtype=torch.int64, pin_memory=True)
+                ka, ha = tk.numpy().view(np.uint64), th.numpy().view(np.uint64)
+            entry = {}
+            for label, chunks in (("chunked", 0), ("one_launch_one_copy", -1)):
+                ctx.set_param(cap.PARAM_HOST_CHUNKS, chunks)
+                best = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, ka.ctypes.data_as(C.c_void_p), ha.ctypes.data_as(C.c_void_p), 0,
+                                                 cap.MEM_HOST, C.byref(res))
+                    best = min(best, time.perf_counter() - t0)
+                    assert rc == 0, ctx.last_error()
+                entry[label] = {"ms": round(best * 1e3, 2), "Gbases_per_s": round(L / best / 1e9, 3), "PCIe_GBps": round(moved / best / 1e9, 2)}
+            ctx.set_param(cap.PARAM_HOST_CHUNKS, 0)
+            # the first 1 Mi elements against the oracle (the whole path is compared in tests/test_gpu_parity.py)
+            ek, eh, _ = orc.canonical(words, (1 << 20) + K - 1, 4, 2, K)
+            entry["verified_head"] = bool(np.array_equal(ka[:1 << 20], ek[:, 0]) and np.array_equal(ha[:1 << 20], eh))
+            # the box's plain device-to-host copy into the same kind of memory (8 n bytes, best of three)
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ctx.d2h(ka, dbuf)
+                best = min(best, time.perf_counter() - t0)
+            d2h = 8 * n / best / 1e9
+            entry["plain_d2h_copy_GBps"] = round(d2h, 2)
+            entry["chunked_frac_of_plain_d2h"] = round(entry["chunked"]["PCIe_GBps"] / d2h, 4)
+            out[kind] = entry
+            del ka, ha
+    finally:
+        ctx.free(dbuf)
     return out
 
 
@@ -497,17 +575,27 @@ def pmc_child(args):
             ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, 0, nw, bits, amb, buf.data_ptr()), "kmers_synth_dna")
         return buf
     if args.pmc_child == "headline":
-        buf = synth(GOLDEN ^ 2)
+        # the outputs from an arena of this process's own, as in the timed leg (the parent holds three quarters of the device in
+        # its arena: this one is three quarters of the rest), so that the launcher sees placed arrays and picks the same shape;
+        # the shape it picked goes to stdout for the parent
         n = L - K + 1
         N = cap.load().kmers_words_per_kmer(K, 2)
-        out_k = torch.empty(n * N, dtype=torch.int64, device=dev)
-        out_h = None if args.no_hash else torch.empty(n, dtype=torch.int64, device=dev)
+        if args.alloc == "arena":
+            ctx.arena_reserve(0)
+            p_k = ctx.alloc(8 * n * N)
+            p_h = None if args.no_hash else ctx.alloc(8 * n)
+        else:
+            out_k = torch.empty(n * N, dtype=torch.int64, device=dev)
+            out_h = None if args.no_hash else torch.empty(n, dtype=torch.int64, device=dev)
+            p_k, p_h = out_k.data_ptr(), (out_h.data_ptr() if out_h is not None else None)
+        buf = synth(GOLDEN ^ 2)
         seq = cap.Seq(buf.data_ptr(), L, 0, 0, bits, 0)
         for _ in range(3):
-            rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, out_k.data_ptr(), out_h.data_ptr() if out_h is not None else None,
-                                         0, cap.MEM_DEVICE, C.byref(res))
+            rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, p_k, p_h, 0, cap.MEM_DEVICE, C.byref(res))
             assert rc == 0, ctx.last_error()
         torch.cuda.synchronize()
+        t, tile, split = ctx.last_launch_shape()
+        print(f"PMC_CHILD_SHAPE {t}x{tile}" + (" split" if split else ""), flush=True)
         return
     a = torch.empty(L, dtype=torch.int64, device=dev)
     b = torch.empty(L, dtype=torch.int64, device=dev)
@@ -554,6 +642,7 @@ def run_pmc_pass(args, which, counters, device_index, timeout):
                os.path.abspath(__file__), "--pmc-child", which, "--bases", str(args.bases), "--k", str(args.k), "--src-bits", str(args.src_bits)]
         if args.no_hash:
             cmd.append("--no-hash")
+        cmd += ["--alloc", getattr(args, "alloc", "arena")]
         # a clean environment for the child: no profiler variables of an outer run, one visible device (the rank's own)
         env = {k: v for k, v in os.environ.items()
                if not k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER_")) and k not in ("LD_PRELOAD", "RANK", "LOCAL_RANK", "WORLD_SIZE",
@@ -571,7 +660,8 @@ def run_pmc_pass(args, which, counters, device_index, timeout):
         for f in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 durs.append((r.get("Kernel_Name", ""), int(r.get("Dispatch_Id", 0)), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-        return rows, durs
+        shape = [l.split(" ", 1)[1] for l in p.stdout.splitlines() if l.startswith("PMC_CHILD_SHAPE ")]
+        return rows, durs, (shape[-1] if shape else None)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -581,9 +671,10 @@ def measure_traffic(args, device_index=0, timeout=600):
     if profiler_in_environment():
         return None, "this run is itself under a profiler (LD_PRELOAD / ROCP_* set): no nested rocprofv3"
     vals = {}
+    shape = None
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            rows, _ = run_pmc_pass(args, "headline", [counter], device_index, timeout)
+            rows, _, shape = run_pmc_pass(args, "headline", [counter], device_index, timeout)
             v = [x for (name, _, cn, x) in rows if "stream_kernel" in name and cn == counter]
             if not v:
                 return None, f"no {counter} rows for stream_kernel in the rocprofv3 output"
@@ -593,18 +684,20 @@ def measure_traffic(args, device_index=0, timeout=600):
     # units and gfx950 corrections exactly as MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KiB;
     # FETCH_SIZE reports half of a coalesced streaming read on gfx950 -> doubled; WRITE_SIZE is exact for 16 B/lane stores
     traffic = int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)
-    return traffic, (f"measured in this run: two rocprofv3 --pmc child passes over the same launch (FETCH_SIZE {vals['FETCH_SIZE']:.1f} KiB "
+    return traffic, (f"measured in this run: two rocprofv3 --pmc child passes, each a fresh process that launches the headline kernel at the "
+                     f"headline size into outputs from an arena of its own (launch shape there: {shape}) (FETCH_SIZE {vals['FETCH_SIZE']:.1f} KiB "
                      f"x 2 [gfx950 correction], WRITE_SIZE {vals['WRITE_SIZE']:.1f} KiB)")
 
 
 def measure_legs(args, device_index=0, timeout=600):
-    """VALU issue share of the legs whose roofline is not (only) HBM: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs against the
-    cycles the XCDs were active (GRBM_GUI_ACTIVE / 8), one rocprofv3 --pmc child over the `legs` program.  Returns
-    {leg: {...}} (empty when the pass could not run).  The legs are told apart by kernel name and dispatch order."""
+    """Vector-instruction account of the legs whose roofline is not (only) HBM, from one rocprofv3 --pmc child over the `legs`
+    program: per leg ONE dispatch's duration (kernel trace), SQ_INSTS_VALU and GRBM_GUI_ACTIVE (/ 8 XCDs = active cycles, so
+    clock = cycles / duration).  Returns {leg: {...}} (empty when the pass could not run).  The legs are told apart by kernel
+    name and dispatch order."""
     if profiler_in_environment():
         return {}
     try:
-        rows, durs = run_pmc_pass(args, "legs", ["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], device_index, timeout)
+        rows, durs, _ = run_pmc_pass(args, "legs", ["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], device_index, timeout)
     except Exception as e:
         log(f"VALU pass failed: {e!r}")
         return {}
@@ -629,15 +722,18 @@ def measure_legs(args, device_index=0, timeout=600):
     for leg, ds in groups.items():
         if not ds:
             continue
-        d = ds[-1]
+        d = ds[-1]  # ONE dispatch: its duration, its instruction count and its active cycles
         valu, act = d["SQ_INSTS_VALU"], d.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
-        cyc = valu * 4.0 / N_SIMDS
         ns = d.get("ns", 0)
-        clock_ghz = act / ns if ns else 0.0
-        res[leg] = {"valu_insts": int(valu), "valu_issue_frac": round(cyc / act, 4) if act else None,
-                    "valu_floor_ms": round(cyc / (clock_ghz * 1e6), 4) if clock_ghz else None,
-                    "source": f"measured in this run: rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE child pass, kernel {d['name'][:60]}, "
-                              f"{ns / 1e6:.3f} ms under the profiler at {clock_ghz:.2f} GHz"}
+        if not (valu and act and ns):
+            continue
+        clock_ghz = act / ns
+        res[leg] = {"valu_insts": int(valu), "profiled_ms": round(ns / 1e6, 4), "clock_GHz": round(clock_ghz, 3),
+                    "cycles_per_inst": round(act * N_SIMDS / valu, 3),
+                    "valu_floor_ms": round(valu * VALU_CYCLES_FAST / N_SIMDS / (clock_ghz * 1e6), 4),
+                    "valu_floor_ms_slow": round(valu * VALU_CYCLES_SLOW / N_SIMDS / (clock_ghz * 1e6), 4),
+                    "source": f"one dispatch of a rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace child pass of this run, kernel {d['name'][:60]}; "
+                              f"issue rates {VALU_CYCLES_FAST} / {VALU_CYCLES_SLOW} cycles per instruction and SIMD: tools/valu_rates.hip, profiles/r04_valu_rates.txt"}
     return res
 
 
@@ -857,8 +953,13 @@ def main():
         except Exception as e:
             plain_alloc = {"error": repr(e)}
     arena_gb, arena_map = 0.0, None
+    write_ceiling = (HBM_PEAK_GBPS, "8 TB/s spec (no arena map in this run)")
     if use_arena:
-        arena_gb = round(ctx.arena_reserve(int(args.arena_gb * 1e9)) / 1e9, 1)
+        try:
+            arena_gb = round(ctx.arena_reserve(int(args.arena_gb * 1e9)) / 1e9, 1)
+        except Exception as e:  # noqa: BLE001  (a device with less free memory than the explicit size)
+            log(f"arena of {args.arena_gb} GB could not be reserved ({e!r}): three quarters of the free memory instead")
+            arena_gb = round(ctx.arena_reserve(0) / 1e9, 1)
         _base, gran, classes = ctx.arena_regions()
         if gran:  # run-length form of the measured map: "A16 B16 C4 ..." = 16 granules of class A, 16 of class B, ...
             runs, start = [], 0
@@ -867,6 +968,10 @@ def main():
                     runs.append(f"{chr(65 + classes[start])}{i - start}")
                     start = i
             arena_map = f"{gran >> 30} GiB granules: " + " ".join(runs)
+        best_pair, one_class = ctx.arena_rates()
+        if best_pair > 0:
+            write_ceiling = (best_pair, f"kmers_arena_rates: best pair of places of this run's arena, two 1 GiB store streams side by side "
+                                        f"({best_pair:.0f} GB/s; inside one region class {one_class:.0f} GB/s)")
     mem = env.mem = Memory(ctx, dev, use_arena)
     if grouped and transport == "native":
         if backend != "nccl":
@@ -910,8 +1015,32 @@ def main():
     per_rank = gather_floats(env, [elapsed, kern_ms, halo_ms, float(sh.n_kmers)])
     elapsed = max(p[0] for p in per_rank)
 
+    chosen_shape = ctx.last_launch_shape()
     # ---- integrity of what the timed kernel wrote (outside the timed region) --------------
     verified = leg.verify()
+    # ---- the launcher's choice against the alternatives of its table (stream_launch.hpp), same arrays, same run --------
+    shape_report = None
+    if rank == 0 and world == 1 and not args.no_other_configs and not args.tile:
+        try:
+            cands = {}
+            for t, tile in ((128, 1536), (256, 1024), (128, 1024), (256, 1536), (256, 2048)):
+                ctx.set_param(cap.PARAM_BLOCK_THREADS, t)
+                ctx.set_param(cap.PARAM_TILE_KMERS, tile)
+                cands[f"{t}x{tile}"] = round(busy_timed(ctx, stream, leg.step, reps=7, busy_s=0.1), 4)
+            ctx.set_param(cap.PARAM_BLOCK_THREADS, 0)
+            ctx.set_param(cap.PARAM_TILE_KMERS, 0)
+            again = round(busy_timed(ctx, stream, leg.step, reps=7, busy_s=0.1), 4)  # the launcher's own choice, measured the same way
+            name = f"{chosen_shape[0]}x{chosen_shape[1]}" + (" split" if chosen_shape[2] else "")
+            best = min(cands, key=cands.get)
+            worst = max(cands, key=cands.get)
+            shape_report = {"chosen": name, "chosen_ms": again, "candidates_ms": cands, "best": best, "worst": worst,
+                            "chosen_over_best": round(again / cands[best], 4),
+                            "what": "threads per workgroup x kmers per tile; every candidate forced with KMERS_PARAM_BLOCK_THREADS / _TILE_KMERS into "
+                                    "the arrays of the timed leg, 7 launches behind 0.1 s of the same launch each, after the timed region"}
+        except Exception as e:  # noqa: BLE001
+            shape_report = {"error": repr(e)}
+            ctx.set_param(cap.PARAM_BLOCK_THREADS, 0)
+            ctx.set_param(cap.PARAM_TILE_KMERS, 0)
     # the two tiny cross-shard reductions of the path, through the same communicator (results known in closed form)
     if comm is not None:
         st, pos, enc = comm.first_error(1 if rank == world - 1 else 0, err_pos=sh.first_base + 5, err_enc=0xF)
@@ -1028,6 +1157,11 @@ def main():
             rf["frac_per_rank"] = [round(x, 4) for x in fracs]
             rf["halo_step_ms_per_rank"] = [round(x, 4) for x in halo_list]
             rf["halo_step_share"] = round(max(halo_list) / max(1e-9, max(halo_list) + max(kern_list)), 5)
+        rf["write_ceiling_GBps"] = round(write_ceiling[0], 1)
+        rf["write_ceiling_source"] = write_ceiling[1]
+        rf["frac_of_write_ceiling"] = round(achieved / write_ceiling[0], 4)
+        if shape_report is not None:
+            rf["launch_shape"] = shape_report
         if plain_alloc is not None:
             rf["plain_alloc"] = plain_alloc
         if fill_gbps:
@@ -1053,7 +1187,8 @@ def main():
         if world == 1 and not args.no_other_configs:
             valu = {} if args.no_pmc else measure_legs(pmc_args, dev_index, child_timeout)
             try:  # informative extras; never allowed to break the headline line
-                line["other_configs"] = other_configs(ctx, cap, stream, dev, mem, valu)
+                line["other_configs"] = other_configs(ctx, cap, stream, dev, mem, valu, write_ceiling_gbps=write_ceiling[0],
+                                                      write_ceiling_source=write_ceiling[1])
             except Exception as e:
                 line["other_configs"] = {"error": repr(e)}
         if not args.no_cpu_baseline:

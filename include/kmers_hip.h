@@ -121,8 +121,16 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 #define KMERS_PARAM_BLOCK_THREADS 10   /* threads per workgroup of the tile kernels: 64, 128 or 256 (0: chosen per output shape) */
 #define KMERS_PARAM_WIDE_NO_TILES 11   /* A/B, tests.  1: kmers of more than four words always on the one-lane-per-kmer kernel; 2: the
                                         * run-time-width tile form also for kmers of one to four words (it loses there: profiles/r03_wide.md) */
+#define KMERS_PARAM_HOST_CHUNKS 12      /* -1: a host-pointer call (KMERS_MEM_HOST) is one launch + one copy whatever its size; 0 (default): outputs of
+                                        * 96 MiB or more travel in chunks, the kernel of the next chunk beside the copy of the current one */
 #define KMERS_PARAM_SUBTILES 7         /* strided tile kernels (kmers_spaced, kmers_minimizers): consecutive tiles per workgroup, the next one's source words in flight */
 int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
+/* The launch shape the library chose for the most recent launch of its tile kernel in this context (kmers_fw / kmers_canonical /
+ * kmers_spaced and the fused consumers that run on it): threads per workgroup, kmers per tile, and whether every output array
+ * was written through two windows.  The table behind the choice (csrc/stream_launch.hpp) depends on the kmer width, the number
+ * of output arrays and on where the arena says they lie; this is how a host, a test or bench.py sees what it came to, and
+ * times the alternatives against it (KMERS_PARAM_TILE_KMERS / _BLOCK_THREADS / _SPLIT_ORDER).  All zero before any launch. */
+int kmers_last_launch_shape(kmers_ctx *ctx, int *threads, int *tile_kmers, int *split_order);
 
 /* ---- device memory ---------------------------------------------------------------------------
  * For hosts without a HIP binding of their own (the reference allocates its outputs itself: `collect` makes one Vector per
@@ -166,6 +174,11 @@ int kmers_arena_info(kmers_ctx *ctx, size_t *reserved, size_t *in_use, size_t *l
  * more finely than a granule).  *region_bytes = 0: no map (block too small, probing switched off, or one class only).  Any
  * output may be NULL. */
 int kmers_arena_regions(kmers_ctx *ctx, void **base, size_t *region_bytes, unsigned char *classes, size_t capacity, size_t *n_regions);
+/* What the probes of kmers_arena_reserve measured, in GB/s of two store streams side by side (1 GiB each, the shape of the stream
+ * kernels' outputs): the best pair of places of the block (two region classes; about 7000 on MI355X) and two streams inside one
+ * granule (one class; about 6000).  Both 0 without an arena or without a map.  The first is the write ceiling bench.py prices the
+ * materialising kernels against (the HBM floor of a launch = its algorithmic bytes / this rate).  Either output may be NULL. */
+int kmers_arena_rates(kmers_ctx *ctx, double *best_pair_gbps, double *one_class_gbps);
 /* For hosts that allocate their outputs themselves (no arena): the write rate, in GB/s, of two store streams side by side into
  * two device buffers the host is about to use as the output arrays of a launch -- the measurement the arena makes of its own
  * block.  DESTRUCTIVE: the first min(bytes, 2 GiB) of both buffers are overwritten.  About 7000 = the buffers lie in different

@@ -25,6 +25,7 @@ struct kmers_arena {
     std::vector<uint8_t> run_class;        //   boundaries refined to about half a gigabyte
     std::vector<float> pair_rate;          // measured: pair_rate[i * n_runs + j] = GB/s of two store streams, one in run i, one in run j
     float best_pair_rate = 0.f;            // the largest of them
+    float one_class_rate = 0.f;            // measured: GB/s of two store streams inside ONE granule (the median over the granules)
     int n_classes = 0;
     int last_run = -1, last2_run = -1;     // runs of the two most recent allocations
     size_t last_off = 0, last_len = 0;     // the most recent allocation itself (placement of blocks longer than a run)

@@ -5,11 +5,22 @@
 
 #include <cstdint>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/kmers_hip.h"
 #include "arena_placement.hpp"
+
+// The arena of ONE DEVICE (memory_api.hip): one block of HBM and its measured map, shared by every context of the process that
+// attaches to it with kmers_arena_reserve -- a second context on the device does not get a second three quarters of what is
+// free, it gets this one.  Sub-allocation is serialised by `mu`; the map is read-only once it has been measured.
+struct kmers_device_arena {
+    kmers_arena a;
+    std::mutex mu;
+    int refs = 0;
+    int device = 0;
+};
 
 struct kmers_ctx {
     int device = 0;
@@ -37,7 +48,16 @@ struct kmers_ctx {
     bool sketch_host_only = false;  // KMERS_PARAM_SKETCH_HOST_ONLY: force the host-feedback MinHash path (tests)
     int64_t batch_passes = 0;       // KMERS_PARAM_BATCH_PASSES (tests, tuning); 0 = default
     int64_t sketch_batch_lds = 0;   // KMERS_PARAM_SKETCH_BATCH_LDS (tuning); 0 = default
-    kmers_arena arena;              // memory_api.hip
+    kmers_device_arena *shared_arena = nullptr;  // the device's arena, if this context is attached to it (memory_api.hip)
+    // the arena's map for the launchers (an empty one without an arena: every placement question is then answered "no")
+    const kmers_arena &arena() const {
+        static const kmers_arena none;
+        return shared_arena ? shared_arena->a : none;
+    }
+    hipStream_t copy_stream = nullptr;   // host-pointer calls in chunks (iterators_api.hip): the copies to the host, beside the kernels
+    hipEvent_t pipe_events[4] = {};      //   ... kernel done [2], chunk copied [2]
+    int64_t host_chunks = 0;             // KMERS_PARAM_HOST_CHUNKS: -1 = host-pointer calls never in chunks (A/B, tests)
+    int last_threads = 0, last_tile = 0, last_split = 0;  // shape of the most recent tile-kernel launch (kmers_last_launch_shape)
     bool unamb_pending = false;     // an asynchronous kmers_unambiguous has run since the last kmers_sync: its count is in h_result[8..10]
     uint64_t unamb_capacity = 0;
 };
@@ -62,6 +82,10 @@ inline int fail(kmers_ctx *ctx, int code, const char *what, hipError_t e = hipSu
         hipError_t e_ = (call);                                        \
         if (e_ != hipSuccess) return fail(ctx, KMERS_E_HIP, #call, e_); \
     } while (0)
+
+// memory_api.hip: detach the context from its device's arena; the last one out frees the block (`force`: even with blocks still
+// allocated -- context destruction; otherwise KMERS_E_BADARG)
+int arena_detach(kmers_ctx *ctx, bool force);
 
 // grow-only device staging buffers owned by the context
 inline int ensure_stage(kmers_ctx *ctx, int slot, size_t bytes) {

@@ -115,7 +115,13 @@ void kmers_ctx_destroy(kmers_ctx *ctx) {
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
     if (ctx->d_recent) (void)hipFree(ctx->d_recent);
-    if (ctx->arena.base) (void)hipFree(ctx->arena.base);  // with whatever blocks of it are still out
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        for (auto &e : ctx->pipe_events)
+            if (e) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    kmers::arena_detach(ctx, true);  // the last context of the device frees the block, with whatever blocks of it are still out
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -133,10 +139,19 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value) {
     else if (param == KMERS_PARAM_ARENA_NO_PROBE) ctx->arena_no_probe = value;
     else if (param == KMERS_PARAM_SPLIT_ORDER) ctx->split_order = value;
     else if (param == KMERS_PARAM_STAMPS_PTR) ctx->stamps_ptr = value;
+    else if (param == KMERS_PARAM_HOST_CHUNKS) ctx->host_chunks = value;
     else if (param == KMERS_PARAM_SKETCH_HOST_ONLY) ctx->sketch_host_only = value != 0;
     else if (param == KMERS_PARAM_BATCH_PASSES) ctx->batch_passes = value;
     else if (param == KMERS_PARAM_SKETCH_BATCH_LDS) ctx->sketch_batch_lds = value;
     else return fail(ctx, KMERS_E_BADARG, "unknown parameter");
+    return KMERS_OK;
+}
+
+int kmers_last_launch_shape(kmers_ctx *ctx, int *threads, int *tile_kmers, int *split_order) {
+    if (!ctx) return KMERS_E_BADARG;
+    if (threads) *threads = ctx->last_threads;
+    if (tile_kmers) *tile_kmers = ctx->last_tile;
+    if (split_order) *split_order = ctx->last_split;
     return KMERS_OK;
 }
 

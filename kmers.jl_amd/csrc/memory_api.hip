@@ -30,6 +30,10 @@ using namespace kmers::arena;  // GRANULE, REGION, round_up, run_of, arena_take 
 static_assert(GRANULE == KMERS_ARENA_GRANULE, "arena_placement.hpp and include/kmers_hip.h disagree about the granule");
 constexpr size_t PROBE = (size_t)1 << 30;     // bytes per stream of one probe
 
+// one arena per device and process (kmers_device_arena, context.hpp)
+std::mutex g_registry_mu;
+std::map<int, kmers_device_arena *> g_device_arenas;
+
 // two store streams, 8 KiB of each per workgroup, 16 bytes per lane: the shape of the stream kernels' outputs
 __global__ __launch_bounds__(256) void arena_probe_kernel(ulonglong2 *a, ulonglong2 *b) {
     const uint64_t w = blockIdx.x;
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256) void arena_probe_kernel(ulonglong2 *a, ulonglo
 
 // milliseconds of one probe (the fastest of three): PROBE bytes at offset x and PROBE bytes at offset y of the block
 int probe_ms(kmers_ctx *ctx, hipEvent_t e0, hipEvent_t e1, size_t x, size_t y, float *out) {
-    char *base = ctx->arena.base;
+    char *base = ctx->shared_arena->a.base;
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
@@ -63,7 +67,7 @@ int probe_ms(kmers_ctx *ctx, hipEvent_t e0, hipEvent_t e1, size_t x, size_t y, f
 // "Slow" is calibrated on the block itself: the two halves of one granule are in one class (the median over all granules
 // discards the few that straddle a boundary).
 int calibrate(kmers_ctx *ctx) {
-    kmers_arena &a = ctx->arena;
+    kmers_arena &a = ctx->shared_arena->a;
     a.region.clear();
     a.run_start.clear();
     a.run_class.clear();
@@ -71,6 +75,7 @@ int calibrate(kmers_ctx *ctx) {
     a.n_classes = 0;
     a.pair_rate.clear();
     a.best_pair_rate = 0.f;
+    a.one_class_rate = 0.f;
     a.last_run = a.last2_run = -1;
     const size_t n = a.bytes / REGION;
     if (n < 4 || ctx->arena_no_probe) return KMERS_OK;
@@ -172,6 +177,11 @@ int calibrate(kmers_ctx *ctx) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != KMERS_OK) return rc;
+    {
+        std::vector<float> sorted = same;
+        std::sort(sorted.begin(), sorted.end());
+        a.one_class_rate = (float)(2.0 * (double)PROBE / 1e6 / (double)sorted[n / 2]);  // GB/s of the two streams of the median probe
+    }
     if (refs.size() >= 2) {
         a.region = cls;
         a.region_bytes = REGION;
@@ -193,12 +203,42 @@ int calibrate(kmers_ctx *ctx) {
 
 }  // namespace
 
+int kmers::arena_detach(kmers_ctx *ctx, bool force) {
+    kmers_device_arena *d = ctx->shared_arena;
+    if (!d) return KMERS_OK;
+    std::lock_guard<std::mutex> registry(g_registry_mu);
+    bool last;
+    {
+        std::lock_guard<std::mutex> lock(d->mu);
+        last = d->refs == 1;
+        if (last && !force && !d->a.used.empty()) return fail(ctx, KMERS_E_BADARG, "kmers_arena_release: blocks of the arena are still allocated");
+        --d->refs;
+    }
+    ctx->shared_arena = nullptr;
+    if (last) {
+        g_device_arenas.erase(d->device);
+        (void)hipFree(d->a.base);
+        delete d;
+    }
+    return KMERS_OK;
+}
+
 extern "C" {
 
 int kmers_arena_reserve(kmers_ctx *ctx, size_t bytes) {
     if (!ctx) return KMERS_E_BADARG;
-    if (ctx->arena.base) return fail(ctx, KMERS_E_BADARG, "kmers_arena_reserve: this context already holds an arena (release it first)");
+    if (ctx->shared_arena) return fail(ctx, KMERS_E_BADARG, "kmers_arena_reserve: this context already holds an arena (release it first)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> registry(g_registry_mu);
+    auto it = g_device_arenas.find(ctx->device);
+    if (it != g_device_arenas.end()) {
+        // the device has its arena already (another context of this process reserved it): ATTACH -- `bytes` is not a second
+        // reservation (kmers_arena_info says what there is)
+        std::lock_guard<std::mutex> lock(it->second->mu);
+        ++it->second->refs;
+        ctx->shared_arena = it->second;
+        return KMERS_OK;
+    }
     if (bytes == 0) {  // default: three quarters of what is free now
         size_t free_b = 0, total_b = 0;
         HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -208,22 +248,30 @@ int kmers_arena_reserve(kmers_ctx *ctx, size_t bytes) {
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return fail(ctx, KMERS_E_NOMEM, "kmers_arena_reserve: hipMalloc", e);
-    ctx->arena.base = static_cast<char *>(p);
-    ctx->arena.bytes = bytes;
-    ctx->arena.free_ranges.clear();
-    ctx->arena.used.clear();
-    ctx->arena.free_ranges[0] = bytes;
+    kmers_device_arena *d = new (std::nothrow) kmers_device_arena();
+    if (!d) {
+        (void)hipFree(p);
+        return fail(ctx, KMERS_E_NOMEM, "kmers_arena_reserve: out of host memory");
+    }
+    d->device = ctx->device;
+    d->refs = 1;
+    d->a.base = static_cast<char *>(p);
+    d->a.bytes = bytes;
+    d->a.free_ranges[0] = bytes;
+    ctx->shared_arena = d;
     if (int rc = calibrate(ctx)) {  // (a failed probe is a HIP failure: give the block back)
-        (void)hipFree(ctx->arena.base);
-        ctx->arena = kmers_arena();
+        (void)hipFree(p);
+        ctx->shared_arena = nullptr;
+        delete d;
         return rc;
     }
+    g_device_arenas[ctx->device] = d;
     return KMERS_OK;
 }
 
 int kmers_arena_regions(kmers_ctx *ctx, void **base, size_t *region_bytes, unsigned char *classes, size_t capacity, size_t *n_regions) {
     if (!ctx) return KMERS_E_BADARG;
-    const kmers_arena &a = ctx->arena;
+    const kmers_arena &a = ctx->arena();
     if (base) *base = a.base;
     if (region_bytes) *region_bytes = a.region_bytes;
     if (n_regions) *n_regions = a.region.size();
@@ -234,23 +282,32 @@ int kmers_arena_regions(kmers_ctx *ctx, void **base, size_t *region_bytes, unsig
 
 int kmers_arena_release(kmers_ctx *ctx) {
     if (!ctx) return KMERS_E_BADARG;
-    if (!ctx->arena.base) return KMERS_OK;
-    if (!ctx->arena.used.empty()) return fail(ctx, KMERS_E_BADARG, "kmers_arena_release: blocks of the arena are still allocated");
+    if (!ctx->shared_arena) return KMERS_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipFree(ctx->arena.base));
-    ctx->arena = kmers_arena();
-    return KMERS_OK;
+    return arena_detach(ctx, false);
 }
 
 int kmers_arena_info(kmers_ctx *ctx, size_t *reserved, size_t *in_use, size_t *largest_free) {
     if (!ctx) return KMERS_E_BADARG;
-    size_t used = 0, largest = 0;
-    for (const auto &u : ctx->arena.used) used += u.second;
-    for (const auto &f : ctx->arena.free_ranges) largest = f.second > largest ? f.second : largest;
-    if (reserved) *reserved = ctx->arena.bytes;
+    size_t used = 0, largest = 0, bytes = 0;
+    if (ctx->shared_arena) {
+        std::lock_guard<std::mutex> lock(ctx->shared_arena->mu);
+        const kmers_arena &a = ctx->shared_arena->a;
+        for (const auto &u : a.used) used += u.second;
+        for (const auto &f : a.free_ranges) largest = f.second > largest ? f.second : largest;
+        bytes = a.bytes;
+    }
+    if (reserved) *reserved = bytes;
     if (in_use) *in_use = used;
     if (largest_free) *largest_free = largest;
+    return KMERS_OK;
+}
+
+int kmers_arena_rates(kmers_ctx *ctx, double *best_pair_gbps, double *one_class_gbps) {
+    if (!ctx) return KMERS_E_BADARG;
+    if (best_pair_gbps) *best_pair_gbps = (double)ctx->arena().best_pair_rate;
+    if (one_class_gbps) *one_class_gbps = (double)ctx->arena().one_class_rate;
     return KMERS_OK;
 }
 
@@ -289,13 +346,15 @@ int kmers_dev_alloc_role(kmers_ctx *ctx, size_t bytes, int role, void **out) {
     if (!ctx || !out) return KMERS_E_BADARG;
     *out = nullptr;
     if (role != KMERS_ALLOC_DEFAULT && role != KMERS_ALLOC_LONE_OUTPUT) return fail(ctx, KMERS_E_BADARG, "unknown allocation role");
-    if (ctx->arena.base) {
+    if (ctx->shared_arena) {
         size_t off = 0;
         const size_t need = round_up(bytes ? bytes : 8);
+        std::lock_guard<std::mutex> lock(ctx->shared_arena->mu);
+        kmers_arena &ar = ctx->shared_arena->a;
         // the only output array of its launches: across a class boundary if one has room (else like any other block)
-        if ((role == KMERS_ALLOC_LONE_OUTPUT && need >= ((size_t)64 << 20) && arena_take_straddling(ctx->arena, need, &off)) ||
-            arena_take(ctx->arena, need, &off)) {
-            *out = ctx->arena.base + off;
+        if ((role == KMERS_ALLOC_LONE_OUTPUT && need >= ((size_t)64 << 20) && arena_take_straddling(ar, need, &off)) ||
+            arena_take(ar, need, &off)) {
+            *out = ar.base + off;
             return KMERS_OK;
         }
     }  // no arena, or no range of it fits: a plain allocation
@@ -309,9 +368,10 @@ int kmers_dev_free(kmers_ctx *ctx, void *p) {
     if (!ctx) return KMERS_E_BADARG;
     if (!p) return KMERS_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // work of this context that still uses the block
-    kmers_arena &a = ctx->arena;
     const char *c = static_cast<const char *>(p);
-    if (a.base && c >= a.base && c < a.base + a.bytes) {
+    if (ctx->shared_arena && c >= ctx->shared_arena->a.base && c < ctx->shared_arena->a.base + ctx->shared_arena->a.bytes) {
+        std::lock_guard<std::mutex> lock(ctx->shared_arena->mu);
+        kmers_arena &a = ctx->shared_arena->a;
         auto it = a.used.find((size_t)(c - a.base));
         if (it == a.used.end()) return fail(ctx, KMERS_E_BADARG, "kmers_dev_free: not the start of a block of the arena");
         const size_t off = it->first, len = it->second;

@@ -110,16 +110,16 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     const bool materialises = MODE == MODE_FW || MODE == MODE_CANON;
     const bool two_arrays = materialises && stride1 && a.out_a && !a.tuples;
     const bool one_word_pair = two_arrays && n_words == 1 && (a.out_b || a.out_starts);
-    const bool spread = one_word_pair && kmers_arena_spread(ctx->arena, a.out_a, a.out_b ? (const void *)a.out_b : (const void *)a.out_starts,
+    const bool spread = one_word_pair && kmers_arena_spread(ctx->arena(), a.out_a, a.out_b ? (const void *)a.out_b : (const void *)a.out_starts,
                                                             (size_t)a.n_kmers * 8u);
     const bool fwrc_wide = two_arrays && MODE == MODE_FW && n_words >= 2 && a.out_b &&
-                           kmers_arena_spread(ctx->arena, a.out_a, a.out_b, (size_t)a.n_kmers * 8u * (size_t)n_words);
+                           kmers_arena_spread(ctx->arena(), a.out_a, a.out_b, (size_t)a.n_kmers * 8u * (size_t)n_words);
     const bool canon_wide = two_arrays && MODE == MODE_CANON && n_words >= 2 && a.out_b;
     const bool canon2_spread = canon_wide && n_words == 2 &&
-                               kmers_arena_spread(ctx->arena, a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u);
+                               kmers_arena_spread(ctx->arena(), a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u);
     const uint32_t lone_bytes = a.tuples ? (MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u) : 8u * n_words;
     const bool lone = materialises && ctx->split_order >= 0 && a.out_a && !a.out_b && !a.out_starts &&
-                      kmers_arena_straddles(ctx->arena, a.out_a, (size_t)a.n_kmers * lone_bytes);
+                      kmers_arena_straddles(ctx->arena(), a.out_a, (size_t)a.n_kmers * lone_bytes);
     uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads
                                               : ((spread || canon_wide || (lone && !a.tuples && J == 1)) ? 128u : (uint32_t)BLOCK);
     if (threads != 64u && threads != 128u) threads = (uint32_t)BLOCK;
@@ -157,6 +157,9 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     const uint64_t slots = a.split_order ? 2 * ((visits + 1) / 2) : visits;
     dim3 grid((unsigned)std::min<uint64_t>(slots, cap));
     dim3 block(threads);
+    ctx->last_threads = (int)threads;
+    ctx->last_tile = (int)tile;
+    ctx->last_split = (int)a.split_order;
     if (src_bits == 8 && dst_bits == 2) launch_widths<MODE, 8, 2>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
     else if (src_bits == 8) launch_widths<MODE, 8, 4>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);
     else if (src_bits == 4 && dst_bits == 2) launch_widths<MODE, 4, 2>(n_words, stride1, pair, fwd, grid, block, ctx->stream, a, dyn_lds);

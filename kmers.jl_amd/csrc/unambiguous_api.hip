@@ -168,8 +168,8 @@ int run_unambiguous(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, uin
         a.out_starts = d_s;
         a.capacity = dev ? capacity : total;
         a.vec16 = ((!d_k || aligned16(d_k)) && (!d_s || aligned16(d_s))) ? 1u : 0u;
-        // a persistent grid: every workgroup draws tickets until none is left (UNAMB_EMIT_WGS = four workgroups per CU, 36 KiB
-        // of LDS and 80 VGPRs each; the kernel's time falls with every resident workgroup, profiles/r02_tuning.md section 6)
+        // a persistent grid: every workgroup draws tickets until none is left (UNAMB_EMIT_WGS workgroups per CU: three, 46 KiB of
+        // LDS each; unambiguous_kernel.hpp says why not four)
         dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, std::min<uint64_t>(cap_grid, (uint64_t)ctx->n_cus * UNAMB_EMIT_WGS)));
         launch_unambiguous<UMODE_EMIT>(ctx, seq->src_bits, nw, grid, a);
         HIP_TRY(ctx, hipGetLastError());

@@ -16,18 +16,22 @@
 //   emit     every wavefront lists the kept starts of up to 4096 candidates at a time in LDS (their order is the reference's)
 //            and works the list off with every lane busy: window cut + contiguous 16-byte stores in aligned frames.  A stretch
 //            with nothing dropped (real sequence outside its N blocks) skips the list.
-//   pipeline the grid is persistent (four workgroups per CU).  A workgroup has the source words of the tile after next in
-//            flight (registers) while it emits, and runs the first step of its NEXT tile before the last two of the current
-//            one, so that an aggregate is out microseconds after its ticket; the ticket itself is drawn while the tile before
-//            it is resolved.  Between front and back a tile's keep mask stays in the registers of the lanes that resolved it.
+//   pipeline the grid is persistent (three workgroups per CU).  A workgroup runs the first step of its NEXT tile before the last
+//            two of the current one, so that an aggregate is out microseconds after its ticket; the ticket itself is drawn
+//            while the tile before it is resolved.  Between front and back a tile's keep mask stays in the registers of the
+//            lanes that resolved it.  (Source words of the tile after next in flight while a tile is emitted: built,
+//            KMERS_UPREFETCH, and slower -- the kernel does not wait for its loads, profiles/r04_unamb.md.)
 //
-// Round 4 (profiles/r04_unamb.md): the kernel is bound by the latency of its dependent chains at four wavefronts per SIMD, not
-// by instruction issue (a SIMD takes a vector instruction every 1.6-2.7 cycles from four wavefronts, tools/valu_rates.hip; the
-// round-3 kernel issued one every 5.6).  What this version removes: the lane shuffles of every round (a lane now owns the
-// qwords lane, 64 + lane, 128 + lane of its wavefront's quarter, and a round is exactly one qword per lane), half of the
-// rounds (4096 starts instead of 2048), the exposed load latency of every tile (prefetch) and two barriers + one atomic
-// round trip per tile (asynchronous ticket); the recoding of a 4-bit word takes 41 instructions instead of 59 and the
-// window test runs on 32-bit words with v_alignbit.
+// Round 4 (profiles/r04_unamb.md).  Measured first: a SIMD of this device takes a vector instruction every 1.3-2.7 cycles from four
+// or more wavefronts and one every 4.5-4.9 from a single one (tools/valu_rates.hip), so round 3's "VALU issue share 0.70" was a
+// third of the pipe; the kernel without its stores runs in 0.35 ms per Gbase on the C5 lattice and 0.50 at K = 31, its stores alone
+// take 0.30 / 0.60 ms at the 7.4 TB/s a persistent grid writes into two region classes, and together they take 0.55 / 0.86: a
+// wavefront that meets a full store queue stalls with its arithmetic behind it, and what is left to win is overlap, not
+// instructions.  What this version changed: a lane owns the qwords lane, 64 + lane, ... of its wavefront's quarter and a round is
+// exactly one qword per lane (no lane shuffles, half the rounds), the list is frame-aligned and worked off two frames per step
+// with the next step's list words in flight, the ticket is drawn inside the previous front, the recoding of a 4-bit word takes 41
+// instructions instead of 59 and the window test runs on 32-bit words with v_alignbit (27 % fewer vector instructions on the
+// lattice, 13 % at K = 31) -- and fewer, longer-lived-per-tile workgroups (3 x 65536): +4 % on the lattice, +2.5 % at K = 31.
 //
 // A descriptor is ONE 64-bit word (status in the top two bits, count below) moved with relaxed agent-scope atomics, so
 // no fence is needed: the word is the whole hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, "8-B agent atomics
@@ -37,11 +41,13 @@
 
 namespace kmers {
 
-// 49152-start tiles, four workgroups per CU (37.5 KiB of LDS each): late in round 3, with the outputs in two region classes, fewer
-// and longer tiles win -- K = 31 0.71 -> 0.73, the stride-3 lattice 0.58 -> 0.61 of 8 TB/s; 6 x 32768 (rounds 2-3), 5 x 40960 and
-// 3 x 65536 run the same, 7 x 28672, 8 x 24576 and 2 x 98304 lose (profiles/r03_tuning.md, tools/r3_unamb_occupancy.sh)
+// 65536-start tiles, three workgroups per CU (46.5 KiB of LDS each).  Round 3 ran 4 x 49152 (with its kernel 6 x 32768, 5 x 40960
+// and 3 x 65536 ran the same, 7 x 28672, 8 x 24576 and 2 x 98304 lost: profiles/r03_tuning.md); with this round's kernel, on one
+// box: 4 x 49152 K = 31 0.900-0.917 ms / lattice 0.565-0.577, 3 x 49152 0.870-0.885 / 0.558, 3 x 65536 0.842-0.852 / 0.542-0.551
+// (round 3's kernel beside them: 0.860-0.866 / 0.565; profiles/r04_unamb.md) -- the kernel writes at the rate the device takes
+// stores from a persistent grid, and that rate falls with the number of resident workgroups (tools/store_pacing.hip)
 #ifndef KMERS_UTILE_MAX
-#define KMERS_UTILE_MAX 49152
+#define KMERS_UTILE_MAX 65536
 #endif
 constexpr uint32_t UTILE_MAX = KMERS_UTILE_MAX;  // candidate starts per tile, at most: a multiple of 64 x BLOCK (whole qwords per thread)
 constexpr uint32_t UROUND = 1024;                // granularity of the tile length (unambiguous_api.hip)
@@ -73,7 +79,7 @@ static_assert(ULIST >= 1024 && ULIST % 2 == 0, "a pass of 16 lanes (1024 starts)
 #define KMERS_USTAGGER_HASH 0
 #endif
 #ifndef KMERS_UNAMB_WGS
-#define KMERS_UNAMB_WGS 4
+#define KMERS_UNAMB_WGS 3
 #endif
 constexpr int UNAMB_EMIT_WGS = KMERS_UNAMB_WGS;  // workgroups per CU of the emitting mode
 constexpr uint64_t DESC_VALUE = (1ull << 62) - 1ull;
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     // The keep mask of a tile never goes to LDS: wavefront w owns the qwords [WQ w, WQ (w + 1)) of the tile (64 starts each), its
     // lane l resolves the qwords l, 64 + l, ... of them and keeps them in registers until the tile is emitted (one whole front
     // later).  A round of the emitting half is then exactly one qword per lane: nothing moves between lanes.
-    constexpr uint32_t QPT = MAXQ / (uint32_t)BLOCK;  // qwords per thread = rounds per wavefront (three with 49152-start tiles)
+    constexpr uint32_t QPT = MAXQ / (uint32_t)BLOCK;  // qwords per thread = rounds per wavefront (four with 65536-start tiles)
     constexpr uint32_t WQ = 64u * QPT;                // qwords per wavefront
     struct TileRegs {
         uint64_t k[QPT];     // bit j of k[h]: start 64 (WQ wave + 64 h + lane) + j of the tile is kept
@@ -291,8 +297,8 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
 #endif
 
     // ---- the source words of a tile: PRE per lane, all in flight together.  EMIT issues them one whole `back` ahead --------
-    // (a 49152-start tile of a 4-bit source is 3074 words + its alignment: thirteen per lane; byte sources take a second batch)
-    constexpr uint32_t PRE = SRC_BITS == 2 ? 7u : 13u;
+    // (a 65536-start tile of a 4-bit source is 4098 words + its alignment: seventeen per lane; byte sources take a second batch)
+    constexpr uint32_t PRE = ((UTILE_MAX + 128u + 64u) * (SRC_BITS == 8 ? 4u : (uint32_t)SRC_BITS) / 64u + 2u + (uint32_t)BLOCK - 1u) / (uint32_t)BLOCK;
     constexpr uint32_t AHEAD = KMERS_UPREFETCH < PRE ? KMERS_UPREFETCH : PRE;  // words per lane loaded one whole `back` ahead
     constexpr uint32_t XS = AHEAD ? AHEAD : 1u;
     auto load_words = [&](uint64_t tile, uint64_t (&xs)[XS]) {

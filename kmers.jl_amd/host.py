@@ -159,6 +159,18 @@ class Context:
         self.check(self.lib.kmers_arena_info(self.handle, C.byref(r), C.byref(u), C.byref(f)), "kmers_arena_info")
         return r.value, u.value, f.value
 
+    def last_launch_shape(self):
+        """(threads per workgroup, kmers per tile, two write windows) of the most recent tile-kernel launch (kmers_last_launch_shape)."""
+        t, k, sp = C.c_int(), C.c_int(), C.c_int()
+        self.check(self.lib.kmers_last_launch_shape(self.handle, C.byref(t), C.byref(k), C.byref(sp)), "kmers_last_launch_shape")
+        return t.value, k.value, sp.value
+
+    def arena_rates(self):
+        """(best pair of places, one region class): GB/s of two store streams side by side as kmers_arena_reserve measured them."""
+        b, o = C.c_double(), C.c_double()
+        self.check(self.lib.kmers_arena_rates(self.handle, C.byref(b), C.byref(o)), "kmers_arena_rates")
+        return b.value, o.value
+
     def arena_regions(self):
         """(base address, granule bytes, [class of every granule]) of the arena's measured region map; granule 0 without one."""
         g, n, base = C.c_size_t(), C.c_size_t(), C.c_void_p()

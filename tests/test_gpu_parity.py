@@ -265,6 +265,58 @@ def test_ascii_sources(km, ctx, orc):
         assert np.array_equal(out, ek), first
 
 
+def test_host_pointer_calls_in_chunks(km, ctx, orc):
+    """Host-pointer calls with outputs of 96 MiB or more run in chunks (iterators_api.hip, run_chunked: the kernel of chunk c + 1
+    beside the copy of chunk c): every element of a call that spans four chunks equals the oracle's and the one-launch path's
+    (KMERS_PARAM_HOST_CHUNKS = -1), for CanonicalDNAMers{31} + fx_hash, FwDNAMers{63} + reverse complements (two-word elements) and
+    SpacedDNAMers{21,3}; an ambiguous symbol in the third chunk gives the reference's EncodeError position
+    (src/iterators/CanonicalKmers.jl:131-144, :220-225; SpacedKmers.jl:121-139)."""
+    cap = km._capi
+    res = cap.Result()
+    # canonical + hashes: 13.5 M elements -> 2 x 108 MB -> four chunks of 4 Mi elements
+    L, K = 13_500_000, 31
+    words = orc.synth_words(77, 0, L // 16 + 2, 4)
+    seq, keep = make_seq(km, words, L, 4)
+    n = L - K + 1
+    ek, eh, _ = orc.canonical(words, L, 4, 2, K, seed=9)
+    for chunks in (0, -1):
+        ctx.set_param(cap.PARAM_HOST_CHUNKS, chunks)
+        k_out, h_out = np.zeros((n, 1), np.uint64), np.zeros(n, np.uint64)
+        assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, vp(k_out), vp(h_out), 9, cap.MEM_HOST, C.byref(res)) == 0, ctx.last_error()
+        assert res.n_out == n and np.array_equal(k_out, ek) and np.array_equal(h_out, eh), chunks
+    ctx.set_param(cap.PARAM_HOST_CHUNKS, 0)
+    # an N in the third chunk (and a later one): the first one is reported, 1-based
+    bad = words.copy()
+    for pos in (9_000_123, 12_000_000):
+        bad[(pos * 4) >> 6] |= np.uint64(0xF) << np.uint64((pos * 4) & 63)
+    seqb, keepb = make_seq(km, bad, L, 4)
+    rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(seqb), K, 2, vp(k_out), vp(h_out), 9, cap.MEM_HOST, C.byref(res))
+    assert (rc, res.err_pos, res.err_enc) == (cap.E_ENCODE, 9_000_124, 0xF)
+    # two-word elements, two arrays: 6.5 M x 16 B -> 2 x 104 MB -> four chunks of 2 Mi elements; a view that starts inside a word
+    # (first_base = 5: the expected values come from the same symbols re-packed from symbol 0 on)
+    L2, K2, first = 6_500_000, 63, 5
+    seq2 = cap.Seq(words.ctypes.data, L2, first, 0, 4, 0)
+    n2 = L2 - K2 + 1
+    fw, rv = np.zeros((n2, 2), np.uint64), np.zeros((n2, 2), np.uint64)
+    assert ctx.lib.kmers_fw(ctx.handle, C.byref(seq2), K2, 2, vp(fw), vp(rv), cap.MEM_HOST, C.byref(res)) == 0, ctx.last_error()
+    nibbles = np.stack([(words >> np.uint64(4 * j)) & np.uint64(0xF) for j in range(16)], axis=1).reshape(-1)[first:first + L2]
+    pad = np.concatenate([nibbles, np.zeros((-len(nibbles)) % 16 + 16, np.uint64)]).reshape(-1, 16)
+    sub = np.zeros(len(pad), np.uint64)
+    for j in range(16):
+        sub |= pad[:, j] << np.uint64(4 * j)
+    efw, erv, _ = orc.fwrv(sub, L2, 4, 2, K2)
+    assert np.array_equal(fw, efw) and np.array_equal(rv, erv)
+    # SpacedDNAMers{21,3}: 13 M elements of 8 B -> 104 MB -> four chunks
+    L3, K3, J3 = 39_000_000, 21, 3
+    w3 = orc.synth_words(78, 0, L3 // 16 + 2, 4)
+    seq3, keep3 = make_seq(km, w3, L3, 4)
+    n3 = (L3 - K3) // J3 + 1
+    sp = np.zeros((n3, 1), np.uint64)
+    assert ctx.lib.kmers_spaced(ctx.handle, C.byref(seq3), K3, J3, 2, vp(sp), cap.MEM_HOST, C.byref(res)) == 0, ctx.last_error()
+    es, _ = orc.spaced(w3, L3, 4, 2, K3, J3)
+    assert res.n_out == n3 and np.array_equal(sp, es)
+
+
 def test_ascii_table_sources_on_strided_and_tuple_kernels(km, ctx, orc):
     """Text into a 4-bit alphabet goes through the alphabet's 256-entry table in LDS (stage_word), and the strided / tuple
     instantiations of the stream kernel stage their first tile before the tile loop's first barrier: the table must be complete
