@@ -83,7 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--alloc", choices=("arena", "plain"), default="arena",
                     help="arena: buffers from kmers_arena_reserve + kmers_dev_alloc (the product's allocator); plain: torch allocations")
-    ap.add_argument("--arena-gb", type=float, default=208.0,
+    ap.add_argument("--arena-gb", type=float, default=230.0,
                     help="size of the arena in GB: an explicit amount (the 10 Gbase leg needs 165 GB of it; the PMC child processes take "
                          "theirs from what is left); 0 = three quarters of the free memory; a reservation that fails falls back to that")
     ap.add_argument("--wake-s", type=float, default=1.0, help="seconds of plain fills before the W warm-up steps (a fresh or idle device is slower at first)")
