@@ -850,6 +850,91 @@ def gather_floats(env, values):
     return [list(map(float, p.tolist())) for p in parts]
 
 
+def strong_scaling_entry(args, K, bits, world, strong_bases, s_per_rank, bytes_per_kmer, verified, solo):
+    """The `strong_scaling` object of a weak N > 1 line: the north-star input split over the N ranks (per-rank [elapsed s, kernel
+    ms, halo-step ms, kmers]) and, when rank 0 also ran it alone (`solo` = [elapsed s, kernel ms]), the ratio of the two."""
+    tN = max(p[0] for p in s_per_rank) / args.steps
+    entry = {
+        "workload": f"CanonicalDNAMers{{{K}}} + fx_hash over ONE sequence of {strong_bases / 1e9:g} Gbase LongDNA{{{bits}}} split over {world} GPUs "
+                    f"(kmers_shard_plan: contiguous kmer ranges, (K-1)-base halo), same steps / warm-up / fences as the headline",
+        "scaling": "strong", "total_bases": strong_bases, "n_gpus": world,
+        "ms_per_step": round(tN * 1e3, 4), "value": round(strong_bases / tN / 1e9, 3), "unit": "Gbases/s",
+        "kernel_ms_per_rank": [round(p[1], 4) for p in s_per_rank], "halo_ms_per_rank": [round(p[2], 4) for p in s_per_rank],
+        "frac_per_rank": [round(bytes_per_kmer * p[3] / p[1] / 1e6 / HBM_PEAK_GBPS, 4) if p[1] else None for p in s_per_rank],
+        "verified": verified,
+    }
+    if solo and solo[0]:
+        t1 = solo[0] / args.steps
+        entry["one_gpu"] = {"ms_per_step": round(t1 * 1e3, 4), "value": round(strong_bases / t1 / 1e9, 3), "kernel_ms": round(solo[1], 4),
+                            "what": "the same input on rank 0's GPU alone, same run, same steps"}
+        entry["speedup_vs_one_gpu"] = round(t1 / tN, 3)
+    return entry
+
+
+def assemble_line(args, K, bits, world, strong, grouped, backend, transport, total_bases, plan_bases, seed, elapsed, per_rank, bytes_per_kmer,
+                  verified, use_arena, arena_gb, arena_map, write_ceiling, shape_report, plain_alloc, fill_gbps, strong_extra):
+    """Rank 0's JSON line from what the ranks measured (per_rank[r] = [elapsed s, kernel ms, halo-step ms, kmers]); pure, so that
+    tests/test_bench_contract.py can check the N > 1 schema on a machine without GPUs.  roofline.traffic, other_configs and
+    cpu_baseline are filled in by the caller."""
+    kern_list = [p[1] for p in per_rank]
+    halo_list = [p[2] for p in per_rank]
+    fracs = [bytes_per_kmer * p[3] / p[1] / 1e6 / HBM_PEAK_GBPS if p[1] else 0.0 for p in per_rank]
+    worst = min(range(len(fracs)), key=fracs.__getitem__)  # the slowest GPU bounds the job
+    achieved = fracs[worst] * HBM_PEAK_GBPS
+    if not grouped:
+        sharding = "single shard"
+    else:
+        how = {"native": "kmers_halo_exchange of the C ABI: grouped ncclSend/ncclRecv on the kernel's stream (RCCL; torch carried only the ncclUniqueId)",
+               "allgather": f"torch.distributed all_gather of <= 32 B per rank ({backend})",
+               "p2p": f"torch.distributed batch_isend_irecv between neighbours ({backend})"}[transport]
+        sharding = f"contiguous kmer-start ranges, (K-1)-base halo from rank+1 each step; backend {backend}; transport {transport}: {how}"
+    what = f"CanonicalDNAMers{{{K}}}" + ("" if args.no_hash else " + fx_hash")
+    if strong:
+        workload = (f"{what} over ONE sequence of {total_bases / 1e9:g} Gbase LongDNA{{{bits}}} split over {world} GPU(s) "
+                    f"(north star: 10 Gbase LongDNA{{4}}), kmers and hashes materialised in HBM")
+    else:
+        workload = (f"{what} over {args.bases / 1e9:g} Gbase LongDNA{{{bits}}} per GPU (BASELINE.json configs[1]), "
+                    f"kmers and hashes materialised in HBM")
+    line = {
+        "metric": METRIC, "value": round(total_bases * args.steps / elapsed / 1e9, 3), "unit": "Gbases/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": workload, "k": K, "src_bits": bits, "total_bases": total_bases,
+                   "bases_per_gpu": plan_bases if strong else args.bases,
+                   "sharding": sharding, "backend": backend, "halo_transport": transport if grouped else None,
+                   "seed": hex(seed), "wake_s": args.wake_s,
+                   "alloc": (f"kmers_arena_reserve ({arena_gb} GB, one block) + kmers_dev_alloc" if use_arena else "torch.empty (hipMalloc)"),
+                   "arena_region_map": arena_map},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": "not measured",
+                     "kernel": "stream_kernel<src_bits,N,CANON,stride1>", "kernel_ms": round(kern_list[worst], 4),
+                     "bytes_per_kmer": bytes_per_kmer, "kmers_per_launch": int(per_rank[worst][3])},
+        "verified": verified,
+    }
+    rf = line["roofline"]
+    if grouped:
+        rf["per_gpu"] = "achieved / frac / kernel_ms are those of the slowest GPU; the lists are in rank order"
+        rf["kernel_ms_per_rank"] = [round(x, 4) for x in kern_list]
+        rf["kernel_ms_min"], rf["kernel_ms_max"] = round(min(kern_list), 4), round(max(kern_list), 4)
+        rf["frac_per_rank"] = [round(x, 4) for x in fracs]
+        rf["halo_step_ms_per_rank"] = [round(x, 4) for x in halo_list]
+        rf["halo_step_share"] = round(max(halo_list) / max(1e-9, max(halo_list) + max(kern_list)), 5)
+    rf["write_ceiling_GBps"] = round(write_ceiling[0], 1)
+    rf["write_ceiling_source"] = write_ceiling[1]
+    rf["frac_of_write_ceiling"] = round(achieved / write_ceiling[0], 4)
+    if shape_report is not None:
+        rf["launch_shape"] = shape_report
+    if plain_alloc is not None:
+        rf["plain_alloc"] = plain_alloc
+    if fill_gbps:
+        rf["torch_fill_GBps"] = round(fill_gbps, 1)  # torch.Tensor.fill_ over the same two arrays, same run
+        rf["vs_torch_fill"] = round(achieved / fill_gbps, 4)
+    if strong_extra is not None:
+        line["strong_scaling"] = strong_extra
+    return line
+
+
 def main():
     args = parse_args()
     if args.pmc_child:
@@ -1091,21 +1176,8 @@ def main():
             env.world, env.grouped, env.comm = world, grouped, comm
         sv = torch.tensor([1 if s_ok else 0], device=dev)
         dist.all_reduce(sv, op=dist.ReduceOp.MIN)
-        tN = max(p[0] for p in s_per_rank) / args.steps
-        strong_extra = {
-            "workload": f"CanonicalDNAMers{{{K}}} + fx_hash over ONE sequence of {strong_bases / 1e9:g} Gbase LongDNA{{{bits}}} split over {world} GPUs "
-                        f"(kmers_shard_plan: contiguous kmer ranges, (K-1)-base halo), same steps / warm-up / fences as the headline",
-            "scaling": "strong", "total_bases": strong_bases, "n_gpus": world,
-            "ms_per_step": round(tN * 1e3, 4), "value": round(strong_bases / tN / 1e9, 3), "unit": "Gbases/s",
-            "kernel_ms_per_rank": [round(p[1], 4) for p in s_per_rank], "halo_ms_per_rank": [round(p[2], 4) for p in s_per_rank],
-            "frac_per_rank": [round(bytes_per_kmer * p[3] / p[1] / 1e6 / HBM_PEAK_GBPS, 4) if p[1] else None for p in s_per_rank],
-            "verified": bool(sv.item()),
-        }
-        if rank == 0 and solo[0]:
-            t1 = solo[0] / args.steps
-            strong_extra["one_gpu"] = {"ms_per_step": round(t1 * 1e3, 4), "value": round(strong_bases / t1 / 1e9, 3), "kernel_ms": round(solo[1], 4),
-                                       "what": "the same input on rank 0's GPU alone, same run, same steps"}
-            strong_extra["speedup_vs_one_gpu"] = round(t1 / tN, 3)
+        strong_extra = strong_scaling_entry(args, K, bits, world, strong_bases, s_per_rank, bytes_per_kmer, bool(sv.item()),
+                                            solo if rank == 0 else None)
         verified &= bool(sv.item())
     v = torch.tensor([1 if verified else 0], device=dev)
     if grouped:
@@ -1113,62 +1185,10 @@ def main():
     verified = bool(v.item())
 
     if rank == 0:
-        kern_list = [p[1] for p in per_rank]
-        halo_list = [p[2] for p in per_rank]
-        fracs = [bytes_per_kmer * p[3] / p[1] / 1e6 / HBM_PEAK_GBPS if p[1] else 0.0 for p in per_rank]
-        worst = int(np.argmin(fracs))  # the slowest GPU bounds the job
-        achieved = fracs[worst] * HBM_PEAK_GBPS
-        if not grouped:
-            sharding = "single shard"
-        else:
-            how = {"native": "kmers_halo_exchange of the C ABI: grouped ncclSend/ncclRecv on the kernel's stream (RCCL; torch carried only the ncclUniqueId)",
-                   "allgather": f"torch.distributed all_gather of <= 32 B per rank ({backend})",
-                   "p2p": f"torch.distributed batch_isend_irecv between neighbours ({backend})"}[transport]
-            sharding = f"contiguous kmer-start ranges, (K-1)-base halo from rank+1 each step; backend {backend}; transport {transport}: {how}"
-        what = f"CanonicalDNAMers{{{K}}}" + ("" if args.no_hash else " + fx_hash")
-        if strong:
-            workload = (f"{what} over ONE sequence of {total_bases / 1e9:g} Gbase LongDNA{{{bits}}} split over {world} GPU(s) "
-                        f"(north star: 10 Gbase LongDNA{{4}}), kmers and hashes materialised in HBM")
-        else:
-            workload = (f"{what} over {args.bases / 1e9:g} Gbase LongDNA{{{bits}}} per GPU (BASELINE.json configs[1]), "
-                        f"kmers and hashes materialised in HBM")
-        line = {
-            "metric": METRIC, "value": round(total_bases * args.steps / elapsed / 1e9, 3), "unit": "Gbases/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": workload, "k": K, "src_bits": bits, "total_bases": total_bases,
-                       "bases_per_gpu": [s.n_bases for s in plan] if strong else args.bases,
-                       "sharding": sharding, "backend": backend, "halo_transport": transport if grouped else None,
-                       "seed": hex(seed), "wake_s": args.wake_s,
-                       "alloc": (f"kmers_arena_reserve ({arena_gb} GB, one block) + kmers_dev_alloc" if use_arena else "torch.empty (hipMalloc)"),
-                       "arena_region_map": arena_map},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": "not measured",
-                         "kernel": "stream_kernel<src_bits,N,CANON,stride1>", "kernel_ms": round(kern_list[worst], 4),
-                         "bytes_per_kmer": bytes_per_kmer, "kmers_per_launch": int(per_rank[worst][3])},
-            "verified": verified,
-        }
+        line = assemble_line(args, K, bits, world, strong, grouped, backend, transport, total_bases, [s.n_bases for s in plan], seed, elapsed,
+                             per_rank, bytes_per_kmer, verified, use_arena, arena_gb, arena_map, write_ceiling, shape_report, plain_alloc,
+                             fill_gbps, strong_extra)
         rf = line["roofline"]
-        if grouped:
-            rf["per_gpu"] = "achieved / frac / kernel_ms are those of the slowest GPU; the lists are in rank order"
-            rf["kernel_ms_per_rank"] = [round(x, 4) for x in kern_list]
-            rf["kernel_ms_min"], rf["kernel_ms_max"] = round(min(kern_list), 4), round(max(kern_list), 4)
-            rf["frac_per_rank"] = [round(x, 4) for x in fracs]
-            rf["halo_step_ms_per_rank"] = [round(x, 4) for x in halo_list]
-            rf["halo_step_share"] = round(max(halo_list) / max(1e-9, max(halo_list) + max(kern_list)), 5)
-        rf["write_ceiling_GBps"] = round(write_ceiling[0], 1)
-        rf["write_ceiling_source"] = write_ceiling[1]
-        rf["frac_of_write_ceiling"] = round(achieved / write_ceiling[0], 4)
-        if shape_report is not None:
-            rf["launch_shape"] = shape_report
-        if plain_alloc is not None:
-            rf["plain_alloc"] = plain_alloc
-        if fill_gbps:
-            rf["torch_fill_GBps"] = round(fill_gbps, 1)  # torch.Tensor.fill_ over the same two arrays, same run
-            rf["vs_torch_fill"] = round(achieved / fill_gbps, 4)
-        if strong_extra is not None:
-            line["strong_scaling"] = strong_extra
         # the PMC child passes, rank 0's device (the other ranks wait in the barrier at the end)
         pmc_args = argparse.Namespace(**vars(args))
         if strong:  # the child profiles a launch of the rank's shard size, capped at what fits beside this process's arena

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         USTAMP(2);
         block_sync();
         USTAMP(3);
-#if KMERS_UCUT == 1 || KMERS_UCUT == 4 || KMERS_UCUT == 5  // phase accounting (tools/r4_unamb_account.sh): the kernel ends behind the stage; the read keeps the LDS stores alive
+#if KMERS_UCUT == 1 || KMERS_UCUT == 4 || KMERS_UCUT == 5  // phase accounting (tools/unamb_account.sh): the kernel ends behind the stage; the read keeps the LDS stores alive
         if (a.capacity == 0x6b6d657273756374ull) a.desc[tid] = lds[tid] + amb[tid];
         tr = TileRegs{};
         if (tid == 0) s_tile = drawn;

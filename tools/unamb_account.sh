@@ -4,7 +4,7 @@
 # K = 31; then the in-kernel stamps of the -DKMERS_STAMPS build.  Variant libraries are built beforehand (they travel with the tree):
 #   for c in 1 2 3; do python -m kmers_jl_amd.build variant ucut$c -DKMERS_UCUT=$c unambiguous_api.hip; done
 #   python -m kmers_jl_amd.build variant stamps -DKMERS_STAMPS unambiguous_api.hip
-# Run on the GPU box from the repo root: gpurun --timeout 1500 -- 'bash tools/r4_unamb_account.sh <tag>'
+# Run on the GPU box from the repo root: gpurun --timeout 1500 -- 'bash tools/unamb_account.sh <tag>'
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 TAG="${1:-r4acc}"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # UnambiguousKmers after a kernel change: its GPU tests, the random geometries of tools/stress_unamb.py and the two timed legs.
-#   gpurun --timeout 1500 -- 'bash tools/r4_unamb_check.sh <tag> [stress cases]'
+#   gpurun --timeout 1500 -- 'bash tools/unamb_check.sh <tag> [stress cases]'
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 TAG="${1:-r4chk}"; CASES="${2:-80}"

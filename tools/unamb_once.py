@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """UnambiguousKmers on the C5 lattice (K = 21, stride 3) and at K = 31, two launches each and nothing else: the program the
-PMC passes of tools/r4_unamb_account.sh profile (KMERS_HIP_LIB selects the build: the product or a -DKMERS_UCUT=n phase cut)."""
+PMC passes of tools/unamb_account.sh profile (KMERS_HIP_LIB selects the build: the product or a -DKMERS_UCUT=n phase cut)."""
 import ctypes as C
 import os
 import sys

@@ -1,5 +1,6 @@
 #!/bin/bash
-# legs of the stream kernels with the product library and with a variant, same box: bash tools/r4_legs_ab.sh <tag> "<legs>" <variant> ...
+# legs of tools/leg.py over builds of the library, same box, two fresh processes per cell: bash tools/variants.sh <tag> "<legs>" <variant> ...
+#   variant = product | <name> of a kmers.jl_amd/csrc/libkmers_hip_<name>.so (python -m kmers_jl_amd.build variant <name> -DFLAG ... [unit.hip ...])
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"; TAG="$1"; LEGS="$2"; shift 2
 E="$ROOT/gpurun_out/$TAG"; mkdir -p "$E"
