@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Files what `tools/evidence.sh` measured on the GPU box (gpurun_out/r3ev/) under profiles/r03_*:
+"""Files what `tools/evidence.sh` measured on the GPU box (gpurun_out/<round>ev/) under profiles/<round>_* (KMERS_ROUND, default r04):
 
-  r03_bench.json                 the driver's command, as printed
-  r03_bench_under_rocprof.json   the same program under rocprofv3 --kernel-trace --stats (its line) ...
-  r03_kernel_stats.csv           ... and rocprofv3's per-kernel summary of that run
-  r03_kernel_stats_<leg>.csv     one --kernel-trace --stats pass per leg (tools/leg.py): each leg is a row of its own file
-  r03_legs.md                    per leg: rocprofv3's average kernel duration -> fraction of 8 TB/s on the algorithmic bytes of
+  <round>_bench.json                 the driver's command, as printed
+  <round>_bench_under_rocprof.json   the same program under rocprofv3 --kernel-trace --stats (its line) ...
+  <round>_kernel_stats.csv           ... and rocprofv3's per-kernel summary of that run
+  <round>_kernel_stats_<leg>.csv     one --kernel-trace --stats pass per leg (tools/leg.py): each leg is a row of its own file
+  <round>_legs.md                    per leg: rocprofv3's average kernel duration -> fraction of 8 TB/s on the algorithmic bytes of
                                  SURVEY.md 8(d), next to the leg's own HIP-event median; HBM bytes per launch from the
                                  FETCH_SIZE / WRITE_SIZE passes (gfx950 correction as MI355X_MICROARCH.md prescribes)
   pmc_traffic.json               the headline launch's bytes (bench.py replays it only when its live passes fail, and says so)
@@ -19,7 +19,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-E = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r3ev")
+RND = os.environ.get("KMERS_ROUND", "r04")
+E = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else RND + "ev")
 P = os.path.join(ROOT, "profiles")
 L = 1_000_000_000
 LEGS = {  # leg -> (label, kernel substring, algorithmic bytes per launch given the leg's printed line)
@@ -57,18 +58,18 @@ def main():
     for name in ("bench.json", "bench_under_rocprof.json"):
         d = first_json_line(os.path.join(E, name))
         if d:
-            json.dump(d, open(os.path.join(P, "r03_" + name), "w"), indent=1)
-    copy(os.path.join(E, "kernel_stats.csv"), "r03_kernel_stats.csv")
+            json.dump(d, open(os.path.join(P, RND + "_" + name), "w"), indent=1)
+    copy(os.path.join(E, "kernel_stats.csv"), RND + "_kernel_stats.csv")
     bench = first_json_line(os.path.join(E, "bench.json")) or {}
-    rows = ["# Round 3: every leg in a rocprofv3 pass of its own (`tools/evidence.sh`, one MI355X, outputs from the context's arena)", "",
-            "`ms (rocprofv3)` = average duration of the leg's kernel in `profiles/r03_kernel_stats_<leg>.csv` (a `--kernel-trace --stats` pass over",
+    rows = [f"# Round {RND[1:].lstrip('0')}: every leg in a rocprofv3 pass of its own (`tools/evidence.sh`, one MI355X, outputs from the context's arena)", "",
+            f"`ms (rocprofv3)` = average duration of the leg's kernel in `profiles/{RND}_kernel_stats_<leg>.csv` (a `--kernel-trace --stats` pass over",
             "`tools/leg.py --leg <leg>`: warm-up launches + 20 timed ones); `ms (HIP events)` = the median the same process printed; fractions",
             "are of 8 TB/s on the algorithmic bytes of SURVEY.md 8(d).  HBM bytes: `FETCH_SIZE x 2` (gfx950: the counter reports half of a",
             "coalesced streaming read) `+ WRITE_SIZE`, separate passes over two bare launches (`leg.py --once`).", "",
             "| leg | kernel | calls | ms (rocprofv3) | frac | ms (HIP events) | frac | HBM bytes / algorithmic |", "|---|---|---|---|---|---|---|---|"]
     for leg, (label, sub, alg_of) in LEGS.items():
         stats = os.path.join(E, f"kernel_stats_{leg}.csv")
-        if not copy(stats, f"r03_kernel_stats_{leg}.csv"):
+        if not copy(stats, f"{RND}_kernel_stats_{leg}.csv"):
             continue
         kept, ev_ms = 0, None
         try:
@@ -102,11 +103,11 @@ def main():
             traffic = f"{tot / 1e9:.3f} GB / {alg / 1e9:.3f} GB = {tot / alg:.3f}"
         fr = lambda t: f"{alg / t / 1e6 / 8000:.3f}" if alg and t else "-"
         rows.append(f"| {label} | `{best['Name'][:70]}` | {best['Calls']} | {ms:.4f} | {fr(ms)} | {ev_ms if ev_ms else '-'} | {fr(ev_ms)} | {traffic} |")
-    open(os.path.join(P, "r03_legs.md"), "w").write("\n".join(rows) + "\n")
+    open(os.path.join(P, RND + "_legs.md"), "w").write("\n".join(rows) + "\n")
     rf = bench.get("roofline", {})
     if rf.get("traffic") and "measured in this run" in rf.get("traffic_source", ""):
         json.dump({"bases": bench["config"].get("bases_per_gpu"), "k": bench["config"]["k"], "src_bits": bench["config"]["src_bits"],
-                   "traffic_bytes_per_launch": rf["traffic"], "source": "profiles/r03_bench.json: " + rf["traffic_source"]},
+                   "traffic_bytes_per_launch": rf["traffic"], "source": f"profiles/{RND}_bench.json: " + rf["traffic_source"]},
                   open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
     print("\n".join(rows))
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything committed under profiles/r03_* comes from this script, run on the GPU box from the repo root:
+# Everything committed under profiles/<round>_* (KMERS_ROUND, default r04) comes from this script, run on the GPU box from the repo root:
 #   gpurun --timeout 1700 -- 'bash tools/evidence.sh'      then, here:   python tools/evidence.py
 #   1. the driver's command (bench.py with its own PMC child passes)                          -> bench.json
 #   2. the same program under rocprofv3 --kernel-trace --stats, headline leg only (--no-other-configs: the other legs launch the
@@ -8,7 +8,8 @@
 #   4. one FETCH_SIZE and one WRITE_SIZE pass per leg (separate passes: TCC slots)             -> pmc_<counter>_<leg>/
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
-E="$ROOT/gpurun_out/r3ev"
+RND="${KMERS_ROUND:-r04}"
+E="$ROOT/gpurun_out/${RND}ev"
 rm -rf "$E"; mkdir -p "$E"
 cd "$ROOT"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$E/bench.json" 2> "$E/bench.err"; echo "bench rc $?"

@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 SETA="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 SETB="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE"
 rocprofv3 -L > "$E/counters.txt" 2>&1
-for v in "" ucut1 ucut2 ucut3; do
+for v in "" ucut1 ucut2 ucut3 ucut4 ucut5 ucut6; do
   lib="$CS/libkmers_hip.so"; name=full
   if [ -n "$v" ]; then lib="$CS/libkmers_hip_$v.so"; name=$v; fi
   [ -f "$lib" ] || { echo "missing $lib"; continue; }
