@@ -21,7 +21,7 @@ struct Stamp { uint64_t cyc, real; };
     asm volatile(I8(I) I8(I)                                                                                                      \
                  : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7) \
                  : [b] "v"(b), [s] "s"(sv), [c] "v"(c), [m4] "v"(addr4), [m8] "v"(addr8)                                         \
-                 : "s20", "vcc")
+                 : "s20", "s21", "vcc")
 
 // A: the accumulator (read and written); [b], [c]: further vector operands; [s]: a scalar operand; [m4] / [m8]: lane-linear LDS byte
 // addresses (4 and 8 bytes per lane)
@@ -82,6 +82,24 @@ BENCH(k_ffbl, uint32_t, I_FFBL)
 BENCH(k_mbcnt, uint32_t, I_MBCNT)
 #define I_CNDMASK(A) "v_cndmask_b32 %[" #A "], %[" #A "], %[b], vcc\n"
 BENCH(k_cndmask, uint32_t, I_CNDMASK)
+#define I_CNDMASK_S(A) "v_cndmask_b32_e64 %[" #A "], %[" #A "], %[b], s[20:21]\n"
+BENCH(k_cndmask_s, uint32_t, I_CNDMASK_S)
+#define I_CMP32(A) "v_cmp_lt_u32_e32 vcc, %[" #A "], %[b]\n"
+BENCH(k_cmp32, uint32_t, I_CMP32)
+#define I_CMP32S(A) "v_cmp_lt_u32_e64 s[20:21], %[" #A "], %[b]\n"
+BENCH(k_cmp32s, uint32_t, I_CMP32S)
+#define I_CMP_CND(A) "v_cmp_lt_u32_e32 vcc, %[" #A "], %[b]\n v_cndmask_b32_e32 %[" #A "], %[" #A "], %[c], vcc\n"
+BENCH(k_cmp_cnd, uint32_t, I_CMP_CND)
+#define I_ADD_CO(A) "v_add_co_u32_e32 %[" #A "], vcc, %[" #A "], %[b]\n"
+BENCH(k_add_co, uint32_t, I_ADD_CO)
+#define I_ADDC_CO(A) "v_addc_co_u32_e32 %[" #A "], vcc, %[" #A "], %[b], vcc\n"
+BENCH(k_addc_co, uint32_t, I_ADDC_CO)
+#define I_MIN(A) "v_min_u32_e32 %[" #A "], %[" #A "], %[b]\n"
+BENCH(k_min, uint32_t, I_MIN)
+#define I_ASHR(A) "v_ashrrev_i32_e32 %[" #A "], 31, %[" #A "]\n"
+BENCH(k_ashr, uint32_t, I_ASHR)
+#define I_XOR(A) "v_xor_b32_e32 %[" #A "], %[" #A "], %[b]\n"
+BENCH(k_xor, uint32_t, I_XOR)
 #define I_MUL_LO(A) "v_mul_lo_u32 %[" #A "], %[" #A "], %[b]\n"
 BENCH(k_mul_lo, uint32_t, I_MUL_LO)
 #define I_MUL_HI(A) "v_mul_hi_u32 %[" #A "], %[" #A "], %[b]\n"
@@ -175,6 +193,15 @@ int main() {
     R32(k_ffbl, "v_ffbl_b32")
     R32(k_mbcnt, "v_mbcnt_lo_u32_b32")
     R32(k_cndmask, "v_cndmask_b32")
+    R32(k_cndmask_s, "v_cndmask_b32_e64 (mask in s[20:21])")
+    R32(k_cmp32, "v_cmp_lt_u32 -> vcc")
+    R32(k_cmp32s, "v_cmp_lt_u32 -> s[20:21]")
+    R32(k_cmp_cnd, "v_cmp + v_cndmask (2 instr)")
+    R32(k_add_co, "v_add_co_u32 (carry out -> vcc)")
+    R32(k_addc_co, "v_addc_co_u32 (carry in and out)")
+    R32(k_min, "v_min_u32")
+    R32(k_ashr, "v_ashrrev_i32")
+    R32(k_xor, "v_xor_b32")
     R32(k_mul_lo, "v_mul_lo_u32")
     R32(k_mul_hi, "v_mul_hi_u32")
     R32(k_mul_u24, "v_mul_u32_u24")
