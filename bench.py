@@ -51,12 +51,15 @@ FX_CONSTANT = 0x517CC1B727220A95
 GOLDEN = 0x9E3779B97F4A7C15
 NORTH_STAR_BASES = 10_000_000_000
 N_SIMDS = 1024  # 256 CUs x 4 SIMDs
-# What a SIMD of this device issues (tools/valu_rates.hip, profiles/r04_valu_rates.txt; cycles per wave64 vector instruction at
-# eight wavefronts per SIMD): 1.32 for the two-operand integer instructions (v_and / v_add / v_lshrrev_b32; three-register
-# v_bitop3), 2.35 for everything else these kernels use (v_alignbit, v_perm, v_lshl_or, v_bfe, v_mul_lo, 64-bit shifts, ...).  ONE
-# wavefront alone issues one every 4.5-4.9 cycles: the "4 cycles per instruction" of rounds 2-3 was that, not the SIMD's limit
-# (which is why a kernel could "beat" it).  A true floor prices every instruction at the fastest class.
-VALU_CYCLES_FAST, VALU_CYCLES_SLOW = 1.32, 2.35
+# What a SIMD of this device issues (tools/valu_rates.hip, profiles/r04_valu_rates.txt; cycles per wave64 vector instruction,
+# instructions of a launch / the launch's span, two or more wavefronts per SIMD): 2.24 for the simple two-operand integer
+# instructions (v_and / v_xor / v_add / 32-bit shifts; v_bitop3 over three registers), 4.1 for everything else these kernels use
+# (v_alignbit, v_perm, v_lshl_or, v_bfe, v_cndmask, compares, multiplies, every 64-bit shift) -- ONE wavefront alone already
+# issues one every 4.5-4.9 cycles, i.e. more wavefronts buy nothing for that class.  (The first version of the tool divided by the
+# mean LIFETIME of the wavefronts instead of the span; the arbiter prefers the oldest wavefront, lifetimes are staggered, and it
+# reported 1.32 / 2.35.  The "4 cycles per instruction" of rounds 2-3 was right for the slow class.)  A true floor prices every
+# instruction at the fast class.
+VALU_CYCLES_FAST, VALU_CYCLES_SLOW = 2.24, 4.1
 
 
 def log(*a):
@@ -337,7 +340,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
         not divided into them.  hbm_floor: algorithmic bytes at the two-stream rate the arena MEASURED for its best pair of
         places (kmers_arena_rates; 8 TB/s spec if there is no map); valu_floor: every vector instruction at the fastest rate
         the SIMDs issue (VALU_CYCLES_FAST) -- a floor no instruction mix can beat, `valu_floor_ms_all_slow` the same at the
-        three-operand rate; frac_of_max_floor = the larger floor / the profiled duration (<= 1 by construction)."""
+        rate of every other instruction class; frac_of_max_floor = the larger floor / the profiled duration (<= 1 by construction)."""
         v = valu.get(leg)
         if not v:
             return {"valu_issue": "not measured (no PMC pass)"}
@@ -402,7 +405,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
         def fused(name, leg, ms, n_kmers):
             out[name] = {"ms": round(ms, 4), "Gbases_per_s": round(L / ms / 1e6, 1), "G_kmers_per_s": round(n_kmers / ms / 1e6, 1),
                          "bound": "instruction issue (nothing is materialised: 0.5 B/base of HBM reads); valu_cycles_per_inst_per_simd "
-                                  "against the 1.32-2.35 the SIMDs can issue says how far from it", **ceilings(leg, ms, 0.0)}
+                                  "against the 2.24-4.1 the SIMDs can issue says how far from it", **ceilings(leg, ms, 0.0)}
         val = C.c_uint64()
         ms = timed(lambda: ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), 31, 2, 1, C.byref(val), cap.MEM_DEVICE, C.byref(res)))
         fused("fused XOR-reduce of CanonicalDNAMers{31} (test/benchmark.jl:9-15)", "xor", ms, L - 30)

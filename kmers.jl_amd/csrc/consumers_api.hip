@@ -79,6 +79,7 @@ int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int 
     a.stride = 1;
     a.ascii_table = ascii_table(ctx, 2, seq->alphabet);
     a.n_tiles = (a.n_kmers + RTILE - 1) / RTILE;
+    a.stamps = reinterpret_cast<uint64_t *>(ctx->stamps_ptr);  // (diagnostic builds only)
     const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (uint64_t)ctx->n_cus * 8;  // persistent grid
     dim3 grid((unsigned)std::min<uint64_t>(a.n_tiles, resident)), block(RBLOCK);
 #define RUNK(SB)                                                                                             \

@@ -119,11 +119,20 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
         else candidate(fx_hash<N>(c, a.seed));                      // kmer.jl:255-261
     };
 
+#ifdef KMERS_STAMPS  // diagnostic builds: where a wavefront of this kernel spends its life (tools/run_stamps.py)
+    const uint64_t st_rt0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t st_c[4] = {0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime(), st_tiles = 0;
+#define RSTAMP(i) do { const uint64_t n_ = __builtin_amdgcn_s_memtime(); st_c[i] += n_ - st_t; st_t = n_; } while (0)
+#else
+#define RSTAMP(i)
+#endif
     uint64_t tile = blockIdx.x;
     if (tile < a.n_tiles) prefetch(geometry(tile));
     for (; tile < a.n_tiles; tile += gridDim.x) {
         const Geo g = geometry(tile);
+        RSTAMP(3);     // (roll of the previous tile)
         block_sync();  // previous tile's readers are done with the stream
+        RSTAMP(0);     // waiting for the workgroup
 #pragma unroll
         for (int i = 0; i < PRE; ++i) {
             const uint32_t wi = tid + (uint32_t)i * RBLOCK;
@@ -135,7 +144,12 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
             }
         }
         if (tile + gridDim.x < a.n_tiles) prefetch(geometry(tile + gridDim.x));
+        RSTAMP(1);     // stage (incl. the wait for this tile's words)
         block_sync();
+        RSTAMP(2);     // waiting for the workgroup's stage
+#ifdef KMERS_STAMPS
+        ++st_tiles;
+#endif
 
         const uint32_t r0 = tid * RRUN;
         if (r0 < g.mt) {
@@ -211,6 +225,16 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
         }
     }
 
+#ifdef KMERS_STAMPS
+    RSTAMP(3);
+    if (a.stamps && (tid & 63u) == 0) {
+        uint64_t *o = a.stamps + ((uint64_t)blockIdx.x * 4 + (tid >> 6)) * 8;
+        o[0] = st_rt0;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 4; ++i) o[2 + i] = st_c[i];
+        o[6] = st_tiles;
+    }
+#endif
     if constexpr (RMODE == RMODE_XOR) {
         // wavefront XOR-reduce (64 lanes), then one atomic per wave
         for (int off = 32; off > 0; off >>= 1) xacc ^= __shfl_xor(xacc, off, 64);

@@ -22,12 +22,11 @@
 //            lanes that resolved it.  (Source words of the tile after next in flight while a tile is emitted: built,
 //            KMERS_UPREFETCH, and slower -- the kernel does not wait for its loads, profiles/r04_unamb.md.)
 //
-// Round 4 (profiles/r04_unamb.md).  Measured first: a SIMD of this device takes a vector instruction every 1.3-2.7 cycles from four
-// or more wavefronts and one every 4.5-4.9 from a single one (tools/valu_rates.hip), so round 3's "VALU issue share 0.70" was a
-// third of the pipe; the kernel without its stores runs in 0.35 ms per Gbase on the C5 lattice and 0.50 at K = 31, its stores alone
-// take 0.30 / 0.60 ms at the 7.4 TB/s a persistent grid writes into two region classes, and together they take 0.55 / 0.86: a
-// wavefront that meets a full store queue stalls with its arithmetic behind it, and what is left to win is overlap, not
-// instructions.  What this version changed: a lane owns the qwords lane, 64 + lane, ... of its wavefront's quarter and a round is
+// Round 4 (profiles/r04_unamb.md).  The kernel without its stores runs in 0.35 ms per Gbase on the C5 lattice and 0.50 at K = 31
+// (close to what its vector instructions cost the SIMDs: 2.24 cycles each for the simple two-operand integer ones, 4.1 for all
+// others, tools/valu_rates.hip), its stores alone take 0.30 / 0.60 ms at the 7.4 TB/s a persistent grid writes into two region
+// classes, and together they take 0.55 / 0.86: a wavefront that meets a full store queue stalls with its arithmetic behind it.
+// What this version changed: a lane owns the qwords lane, 64 + lane, ... of its wavefront's quarter and a round is
 // exactly one qword per lane (no lane shuffles, half the rounds), the list is frame-aligned and worked off two frames per step
 // with the next step's list words in flight, the ticket is drawn inside the previous front, the recoding of a 4-bit word takes 41
 // instructions instead of 59 and the window test runs on 32-bit words with v_alignbit (27 % fewer vector instructions on the

@@ -13,19 +13,28 @@
 
 constexpr int ITERS = 2048;
 
-struct Stamp { uint64_t cyc, real; };
+struct Stamp { uint64_t cyc, real, r0, r1; };
 
 // ONE asm statement per 16 instructions (hipcc puts an s_nop between separate asm statements): I(A) names the accumulator operand
 #define I8(I) I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7)
+#define D8(I) I(a0) I(a0) I(a0) I(a0) I(a0) I(a0) I(a0) I(a0)  // one dependent chain: every instruction reads the previous one's result
 #define BODY(I)                                                                                                                   \
     asm volatile(I8(I) I8(I)                                                                                                      \
                  : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7) \
                  : [b] "v"(b), [s] "s"(sv), [c] "v"(c), [m4] "v"(addr4), [m8] "v"(addr8)                                         \
                  : "s20", "s21", "vcc")
 
+#define BODY_DEP(I)                                                                                                               \
+    asm volatile(D8(I) D8(I)                                                                                                      \
+                 : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7) \
+                 : [b] "v"(b), [s] "s"(sv), [c] "v"(c), [m4] "v"(addr4), [m8] "v"(addr8)                                         \
+                 : "s20", "s21", "vcc")
+
 // A: the accumulator (read and written); [b], [c]: further vector operands; [s]: a scalar operand; [m4] / [m8]: lane-linear LDS byte
 // addresses (4 and 8 bytes per lane)
-#define BENCH(NAME, TYPE, INSTR)                                                                         \
+#define BENCH(NAME, TYPE, INSTR) BENCH_(NAME, TYPE, INSTR, BODY)
+#define BENCH_DEP(NAME, TYPE, INSTR) BENCH_(NAME, TYPE, INSTR, BODY_DEP)
+#define BENCH_(NAME, TYPE, INSTR, BODYM)                                                                         \
     __global__ __launch_bounds__(256) void NAME(TYPE *out, Stamp *st, uint32_t sv) {                      \
         __shared__ uint32_t lds[4096];                                                                    \
         for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i * 2654435761u;                          \
@@ -38,12 +47,12 @@ struct Stamp { uint64_t cyc, real; };
         const uint32_t addr4 = t * 4u, addr8 = t * 8u;                                                    \
         const uint64_t r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();          \
         for (int i = 0; i < ITERS; ++i) {                                                                 \
-            BODY(INSTR);                                                                                  \
+            BODYM(INSTR);                                                                                 \
         }                                                                                                 \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
         const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();          \
         out[blockIdx.x * 256 + t] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                \
-        if ((t & 63u) == 0) st[blockIdx.x * 4 + (t >> 6)] = Stamp{t1 - t0, r1 - r0};                     \
+        if ((t & 63u) == 0) st[blockIdx.x * 4 + (t >> 6)] = Stamp{t1 - t0, r1 - r0, r0, r1};                     \
     }
 
 #define I_AND(A) "v_and_b32 %[" #A "], %[" #A "], %[b]\n"
@@ -137,6 +146,21 @@ BENCH(k_ds_write16, uint32_t, I_DS_WRITE16)
 #define I_DS_WRITE32(A) "ds_write_b32 %[m4], %[" #A "]\n s_waitcnt lgkmcnt(7)\n"
 BENCH(k_ds_write32, uint32_t, I_DS_WRITE32)
 
+#define I_CMP64(A) "v_cmp_lt_u64_e32 vcc, %[" #A "], %[b]\n"
+BENCH(k_cmp64, uint64_t, I_CMP64)
+// the select of the fused XOR reducer's roll step (run_kernel.hpp): 64-bit compare, the wait state hipcc puts behind it, two selects
+#define I_MIN64(A) "v_cmp_lt_u64_e32 vcc, %[" #A "], %[b]\n s_nop 1\n v_cndmask_b32_e32 %[m4], %[m4], %[m8], vcc\n v_cndmask_b32_e32 %[m8], %[m8], %[m4], vcc\n"
+BENCH(k_min64, uint64_t, I_MIN64)
+#define I_MIN64_NONOP(A) "v_cmp_lt_u64_e64 s[20:21], %[" #A "], %[b]\n v_and_b32 %[m4], %[m4], %[m8]\n v_and_b32 %[m8], %[m8], %[m4]\n"
+BENCH(k_min64_nonop, uint64_t, I_MIN64_NONOP)
+#define I_NOP(A) "s_nop 1\n"
+BENCH(k_snop, uint32_t, I_NOP)
+BENCH_DEP(k_dep_and, uint32_t, I_AND)
+BENCH_DEP(k_dep_alignbit, uint32_t, I_ALIGNBIT)
+BENCH_DEP(k_dep_lshr64, uint64_t, I_LSHR64)
+BENCH_DEP(k_dep_add64, uint64_t, I_ADD64)
+BENCH_DEP(k_dep_cmp_cnd, uint32_t, I_CMP_CND)
+
 struct Entry {
     const char *name;
     void *fn;
@@ -152,15 +176,22 @@ static int run(const char *name, void (*fn)(T *, Stamp *, uint32_t), T *out, Sta
         hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, 0, out, st, 11u);
         CHECK(hipDeviceSynchronize());
         CHECK(hipMemcpy(h.data(), st, sizeof(Stamp) * grid * 4, hipMemcpyDeviceToHost));
+        // per wavefront: shader cycles and 100 MHz ticks between its first and its last instruction -> the clock.  For the launch:
+        // first start to last end.  The SIMD's rate is instructions / SPAN: the arbiter prefers the oldest wavefront, so the
+        // wavefronts of a SIMD finish one after the other and the mean of their lifetimes is shorter than the time the SIMD needed
+        // (the first version of this tool divided by that mean and credited a SIMD with up to 1.8x what it issues).
         double cyc = 0, real = 0;
+        uint64_t first = ~0ull, last = 0;
         for (int i = 0; i < grid * 4; ++i) {
             cyc += (double)h[i].cyc;
             real += (double)h[i].real;
+            first = h[i].r0 < first ? h[i].r0 : first;
+            last = h[i].r1 > last ? h[i].r1 : last;
         }
-        cyc /= grid * 4;
-        real /= grid * 4;
-        const double per = cyc / (ITERS * 16.0) / w;  // cycles of one SIMD per wave-instruction
-        printf("  w%d %6.2f cyc (%.2f GHz)", w, per, cyc / (real * 10.0));
+        const double ghz = cyc / (real * 10.0);
+        const double span_cycles = (double)(last - first) * 10.0 * ghz;
+        const double per = span_cycles / (ITERS * 16.0) / w;  // cycles of one SIMD per wave-instruction
+        printf("  w%d %6.2f cyc (%.2f GHz)", w, per, ghz);
     }
     printf("\n");
     return 0;
@@ -202,6 +233,15 @@ int main() {
     R32(k_min, "v_min_u32")
     R32(k_ashr, "v_ashrrev_i32")
     R32(k_xor, "v_xor_b32")
+    R64(k_cmp64, "v_cmp_lt_u64 -> vcc")
+    R64(k_min64, "v_cmp_lt_u64 + s_nop 1 + 2 v_cndmask (4 instr)")
+    R64(k_min64_nonop, "v_cmp_lt_u64 -> sgpr + 2 v_and (3 instr)")
+    R32(k_snop, "s_nop 1")
+    R32(k_dep_and, "DEPENDENT chain: v_and_b32")
+    R32(k_dep_alignbit, "DEPENDENT chain: v_alignbit_b32")
+    R64(k_dep_lshr64, "DEPENDENT chain: v_lshrrev_b64")
+    R64(k_dep_add64, "DEPENDENT chain: v_lshl_add_u64")
+    R32(k_dep_cmp_cnd, "DEPENDENT chain: v_cmp + v_cndmask (2 instr)")
     R32(k_mul_lo, "v_mul_lo_u32")
     R32(k_mul_hi, "v_mul_hi_u32")
     R32(k_mul_u24, "v_mul_u32_u24")
