@@ -49,6 +49,29 @@ __device__ __forceinline__ uint32_t pack_4to2(uint64_t x, uint64_t &bad) {
     return __builtin_amdgcn_perm(hi, lo, 0x06040200u);  // bytes: lo.0, lo.2, hi.0, hi.2
 }
 
+// The same codes at what the SIMDs charge (profiles/r04_valu_rates.txt: 2.24 cycles for a simple two-operand integer instruction,
+// 4.1 for every other one -- a 64-bit shift, v_perm, v_bcnt): on the 32-bit halves, trailing_zeros of a one-hot nibble n as
+// (n >> 1) - (n >> 3) (1, 2, 4, 8 -> 0, 1, 2, 3; no borrow leaves a nibble), and ONE verdict for the word instead of a flag per
+// symbol: every nibble non-zero and 16 bits set <=> every symbol one-hot.  About 85 cycles of a SIMD per word where pack_4to2
+// takes about 300; the caller computes pack_4to2's `bad` only if `any_bad` says so.  Codes of symbols that are not one-hot are
+// unspecified (the call fails on them).
+__device__ __forceinline__ uint32_t pack_4to2_checked(uint64_t x, uint32_t &any_bad) {
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    auto half = [](uint32_t h) {
+        const uint32_t c = ((h >> 1) & 0x77777777u) - ((h >> 3) & 0x11111111u);  // 2-bit code in the low bits of each nibble
+        const uint32_t u = (c | (c >> 2)) & 0x0F0F0F0Fu;
+        return u | (u >> 4);  // bytes 0 and 2: four codes each
+    };
+    const uint32_t nz_lo = ((lo & 0x77777777u) + 0x77777777u) | lo, nz_hi = ((hi & 0x77777777u) + 0x77777777u) | hi;  // bit 3 of a nibble: it is not 0
+    any_bad = (~(nz_lo & nz_hi) & 0x88888888u) | ((uint32_t)__popcll(x) ^ 16u);
+    return __builtin_amdgcn_perm(half(hi), half(lo), 0x06040200u);  // bytes: lo.0, lo.2, hi.0, hi.2
+}
+// pack_4to2's `bad` alone (the rare path behind pack_4to2_checked)
+__device__ __forceinline__ uint64_t bad_nibbles4(uint64_t x) {
+    const uint64_t M1 = 0x1111111111111111ull;
+    return ((x & M1) + ((x >> 1) & M1) + ((x >> 2) & M1) + ((x >> 3) & M1)) ^ M1;
+}
+
 // one bit per symbol (bit j set = symbol j of the word is ambiguous) from pack_4to2's `bad`
 __device__ __forceinline__ uint32_t bad_bits16(uint64_t bad) {
     uint64_t f = (bad | (bad >> 1) | (bad >> 2)) & 0x1111111111111111ull;

@@ -17,14 +17,19 @@ namespace kmers {
 
 constexpr int RBLOCK = 256;
 constexpr int RRUN = 32;                   // consecutive kmers per lane (16 until late in round 2: the window cut is 45 instructions a run)
-constexpr int RTILE = RBLOCK * RRUN;       // kmers per tile
+constexpr int RSYMS = RBLOCK * RRUN;       // source symbols staged per tile: one load round of RSYMS * SRC_BITS / 64 words, nothing more
+// kmers per tile: 253 runs.  The last run's window (31 further starts, K - 1 <= 63 symbols of overlap) and up to 31 symbols of
+// misalignment in front of the first fit into the RSYMS staged symbols, so a tile needs no extra staging pass for its overlap --
+// a pass costs the wavefront the same 160 cycles whether 8 lanes or 64 have a word to recode (three lanes idle in the roll instead).
+constexpr int RTILE = (RBLOCK - 3) * RRUN;
+static_assert(RTILE + 63 + 31 <= RSYMS, "a tile's windows fit into one load round");
 enum RunMode { RMODE_XOR = 0, RMODE_SKETCH = 1 };
 
 // CANON: canonical kmers (always for the sketch); false = the forward kmers (kmers_reduce_xor with canonical = 0)
 template <int SRC_BITS, int RMODE, int N = 1, bool CANON = true>
 __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
     static_assert(RMODE != RMODE_SKETCH || CANON, "the sketch is over canonical kmers");
-    __shared__ uint64_t lds[RTILE * 2 / 64 + 16];  // + K - 1 <= 63 symbols of overlap + 32 of misalignment + the (N+1)-th window word
+    __shared__ uint64_t lds[RSYMS * 2 / 64 + 8];  // the staged 2-bit stream + the window words past it (read, never used)
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t k = a.k;
@@ -45,7 +50,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
             for (uint32_t i = tid; i < nb; i += RBLOCK) sbest[i] = a.best[i];  // visible after the tile loop's first barrier
         }
     }
-    uint64_t xacc = 0;
+    uint64_t xacc = 0, xacc_left = 0;  // (xacc_left: XOR of LEFT-aligned one-word kmers, see the full-run path below)
 
     struct Geo { uint64_t w0; uint32_t b0, nw, mt; };
     auto geometry = [&](uint64_t tile) {
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
         g.nw = (uint32_t)(((end_bit + 63) >> 6) - g.w0);
         return g;
     };
-    constexpr int PRE = (RTILE + 96) * SRC_BITS / 64 / RBLOCK + 1;  // source words per thread per tile
+    constexpr int PRE = RSYMS * SRC_BITS / 64 / RBLOCK;  // source words per thread per tile: 1, 2 or 4
     uint64_t pre[PRE];
     auto prefetch = [&](const Geo &g) {
 #pragma unroll
@@ -167,6 +172,45 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
                     lo = hi;
                 }
             }
+            bool consumed = false;
+            if constexpr (N == 1) {
+                if (cnt == (uint32_t)RRUN) {
+                    // A full run of one-word kmers, priced by profiles/r04_valu_rates.txt (everything but the simplest integer
+                    // instructions costs a SIMD 4.1 cycles): the 32 kmers are WINDOWS of two 128-bit streams, cut with two
+                    // v_alignbit each at shifts known at compile time -- no rolling recurrence, no masks.  Kmers are kept
+                    // LEFT-aligned (first symbol in bits 62..63): the forward kmer j is bits [64 - 2j, 128 - 2j) of the
+                    // symbol-reversed stream rev2(W0):rev2(W1) whatever K is, the reverse complement bits [2j, 2j + 64) of the
+                    // complemented stream moved down by 2K bits once per run.  Below a kmer's 2K bits sit later symbols of the
+                    // stream: they cannot change fw < rc unless the kmers are equal (then either is the canonical one) and they
+                    // are shifted out where the kmer is used (XOR: once per lane at the end, shifts commute with XOR).
+                    // 36 cycles of a SIMD per kmer where the rolling step takes 50-54 (tools/roll_rate.hip).
+                    const uint32_t up = 64u - 2u * k;  // 0..62
+                    const uint64_t n0 = ~W[0], n1 = ~W[1];
+                    const uint64_t A = n0 << up, B = ((n0 >> (2u * k - 1u)) >> 1) | (n1 << up);  // (~W0 : ~W1) >> 2K, zeros below
+                    const uint64_t R0 = rev2(W[0]), R1 = rev2(W[1]);
+                    const uint32_t rd[4] = {(uint32_t)R1, (uint32_t)(R1 >> 32), (uint32_t)R0, (uint32_t)(R0 >> 32)};
+                    const uint32_t td[4] = {(uint32_t)A, (uint32_t)(A >> 32), (uint32_t)B, (uint32_t)(B >> 32)};
+                    auto cut = [](const uint32_t (&d)[4], uint32_t bit) {  // 64 bits of the 128-bit stream from `bit` (<= 64) on
+                        const uint32_t i = bit >> 5, sh = bit & 31u;
+                        const uint32_t lo = sh ? __builtin_amdgcn_alignbit(d[i + 1], d[i], sh) : d[i];
+                        const uint32_t hi = i + 2 < 4 ? (sh ? __builtin_amdgcn_alignbit(d[i + 2], d[i + 1], sh) : d[i + 1]) : d[i + 1] >> sh;
+                        return ((uint64_t)hi << 32) | lo;
+                    };
+#pragma unroll
+                    for (uint32_t j = 0; j < (uint32_t)RRUN; ++j) {
+                        const uint64_t f = cut(rd, 64u - 2u * j), r = cut(td, 2u * j);
+                        const uint64_t c = (!CANON || f < r) ? f : r;  // fw < rv ? fw : rv, CanonicalKmers.jl:220-225
+                        if constexpr (RMODE == RMODE_XOR) {
+                            xacc_left ^= c;
+                        } else {
+                            const uint64_t cr[1] = {c >> up};
+                            candidate(fx_hash<1>(cr, a.seed));
+                        }
+                    }
+                    consumed = true;
+                }
+            }
+            if (!consumed) {  // two-word kmers, and the last (short) run of a sequence: the rolling recurrence
             // first kmer of the run (see stream_kernel.hpp `window`): fw = symbol-reversed window, rc = complement
             uint64_t fw[N], rc[N];
             {
@@ -208,6 +252,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
             } else {
                 for (uint32_t j = 1; j < cnt; ++j) roll(j);
             }
+            }
         }
         if constexpr (RMODE == RMODE_SKETCH) {
             block_sync();
@@ -236,6 +281,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
     }
 #endif
     if constexpr (RMODE == RMODE_XOR) {
+        if constexpr (N == 1) xacc ^= xacc_left >> (64u - 2u * k);
         // wavefront XOR-reduce (64 lanes), then one atomic per wave
         for (int off = 32; off > 0; off >>= 1) xacc ^= __shfl_xor(xacc, off, 64);
         if ((tid & 63u) == 0) atomicXor(reinterpret_cast<unsigned long long *>(a.out_a), (unsigned long long)xacc);

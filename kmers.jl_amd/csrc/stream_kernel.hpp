@@ -305,10 +305,10 @@ __device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint6
         lds[wi] = REV ? rev2(x) : x;
         return 0;
     } else if constexpr (SRC == 4) {  // FourToTwo: trailing_zeros of a one-hot nibble, validated
-        uint64_t bad;
-        const uint32_t c = pack_4to2(x, bad);
+        uint32_t any_bad;
+        const uint32_t c = pack_4to2_checked(x, any_bad);
         reinterpret_cast<uint32_t *>(lds)[wi] = REV ? rev2_32(c) : c;
-        return bad ? flags_from_bad4(bad) : 0;
+        return any_bad ? flags_from_bad4(bad_nibbles4(x)) : 0;
     } else {  // TwoToFour
         lds[2 * wi] = expand_2to4((uint32_t)x);
         lds[2 * wi + 1] = expand_2to4((uint32_t)(x >> 32));

@@ -3,7 +3,7 @@
 # stamps of the XOR reducer.  Run on the GPU box: bash tools/fused_sweep.sh <outdir>
 OUT=${1:-gpurun_out/fused}; mkdir -p "$OUT"
 C=kmers.jl_amd/csrc
-for v in "" _dc2 _dc8; do
+for v in ""; do
   [ -f $C/libkmers_hip$v.so ] || continue
   for leg in xor minhash; do
     echo "== lib$v $leg" >> "$OUT/legs.log"
