@@ -266,8 +266,25 @@ __device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint6
         // byte is a symbol iff its upper-cased value is the letter its code stands for (BioSequences.ascii_encode restated;
         // ascii_tables.hpp holds the table this replaces, tests/c/ascii_entry_check.cpp compares the two over all 256 bytes).
         if (text) {
+            // On the 32-bit halves, priced by profiles/r04_valu_rates.txt: the letter a code stands for comes from ONE v_perm
+            // (the code bytes select from "ACGT" / "ACGU"), the four codes of a half are gathered by ONE v_dot4 (bytes times
+            // 1, 4, 16, 64), and the word gets one verdict; the flag of every byte is only computed if a byte is off.
+            const uint32_t letters = text == 2u ? 0x55474341u : 0x54474341u;
+            auto half = [&](uint32_t d, uint32_t &off) {
+                const uint32_t U = d & 0xDFDFDFDFu;                   // upper case
+                const uint32_t c2 = (U >> 1) & 0x03030303u;
+                const uint32_t code = c2 ^ ((c2 >> 1) & 0x01010101u);
+                off |= U ^ __builtin_amdgcn_perm(letters, letters, code);  // (selector bytes 0..3: bytes of `letters`)
+                return __builtin_amdgcn_udot4(code, 0x40100401u, 0u, false);
+            };
+            uint32_t off = 0;
+            const uint32_t lo = half((uint32_t)x, off), hi = half((uint32_t)(x >> 32), off);
+            const uint32_t codes = lo | (hi << 8);
+            if constexpr (REV) reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)(rev2_32(codes) >> 16);
+            else reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)codes;
+            if (!off) return 0;
             const uint64_t B1 = 0x0101010101010101ull;
-            const uint64_t U = x & 0xDFDFDFDFDFDFDFDFull;                 // upper case
+            const uint64_t U = x & 0xDFDFDFDFDFDFDFDFull;
             const uint64_t c2 = (U >> 1) & (3ull * B1);
             const uint64_t code = c2 ^ ((c2 >> 1) & B1);
             const uint64_t b0 = code & B1, b1 = (code >> 1) & B1;
@@ -276,16 +293,7 @@ __device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint6
             uint64_t E = 0x41ull * B1 + (is1 << 1) + (is2 << 1) + (is2 << 2) + (is3 << 4) + (is3 << 1) + is3;
             if (text == 2u) E += is3;
             const uint64_t bad = U ^ E;
-            const uint64_t nz = ((bad | ((bad & (0x7Full * B1)) + (0x7Full * B1))) >> 7) & B1;  // bit 8j: byte j is not a symbol
-            uint64_t t = code | (code >> 6);
-            t &= 0x000F000F000F000Full;
-            t |= t >> 12;
-            t &= 0x000000FF000000FFull;
-            t |= t >> 24;
-            const uint32_t codes = (uint32_t)t & 0xFFFFu;
-            if constexpr (REV) reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)(rev2_32(codes) >> 16);
-            else reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)codes;
-            return nz;
+            return ((bad | ((bad & (0x7Full * B1)) + (0x7Full * B1))) >> 7) & B1;  // bit 8j: byte j is not a symbol
         }
     }
     if constexpr (SRC == 8) {  // AsciiEncode: 8 bytes -> 8 symbols through the alphabet's table

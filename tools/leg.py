@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One leg of the hot path in ONE fresh process: the program every timing sweep and every `rocprofv3` pass of round 3 runs.
 
-    python3 tools/leg.py --leg c2|c3|c4|c4t|c5|u31|u21|xor|minhash|comp8 [--alloc plain|carve:GB|prefree:GB|arena:GB] [--reps N]
+    python3 tools/leg.py --leg c2|f1|c3|c4|c4t|c5|u31|u21|xor|minhash|comp8 [--alloc plain|carve:GB|prefree:GB|arena:GB] [--reps N]
                          [--busy-ms MS] [--tile T] [--once]
 
 legs (1 Gbase LongDNA{4} unless stated; algorithmic bytes per SURVEY.md section 8d):
@@ -71,14 +71,14 @@ if args.split:
 
 leg = args.leg
 L = 1_250_000_000 if leg == "c3" else args.bases
-bits = 2 if leg == "c3" else 4
+bits = 2 if leg == "c3" else 8 if leg == "f1" else 4
 amb = 2621 if leg in ("u31", "u21") else 0
 seed = {"c2": 2, "c3": 3, "c4": 4, "c4t": 4, "c5": 5, "u31": 5, "u21": 5}.get(leg, 5)
-K = {"f127": 127, "c63": 63, "c127h": 127, "c63h": 63, "f3": 31, "c2": 31, "c3": 31, "c4": 63, "c4t": 63, "c5": 21, "u31": 31, "u21": 21, "xor": 31, "minhash": 16, "comp8": 8}[leg]
+K = {"f127": 127, "c63": 63, "c127h": 127, "c63h": 63, "f3": 31, "c2": 31, "f1": 31, "c3": 31, "c4": 63, "c4t": 63, "c5": 21, "u31": 31, "u21": 21, "xor": 31, "minhash": 16, "comp8": 8}[leg]
 J = 3 if leg in ("c5", "u21") else 1
 n = (L - K) // J + 1
-words_a = {"f127": 4 * n, "c63": 2 * n, "c127h": 4 * n, "c63h": 2 * n, "f3": 2 * n, "c2": n, "c3": n, "c4": 2 * n, "c4t": 4 * n, "c5": n, "u31": n, "u21": n}.get(leg, 1 << 16)
-words_b = {"f127": 4 * n, "c127h": n, "c63h": n, "c2": n, "c4": 2 * n, "u31": n, "u21": n}.get(leg, 0)
+words_a = {"f127": 4 * n, "c63": 2 * n, "c127h": 4 * n, "c63h": 2 * n, "f3": 2 * n, "c2": n, "f1": n, "c3": n, "c4": 2 * n, "c4t": 4 * n, "c5": n, "u31": n, "u21": n}.get(leg, 1 << 16)
+words_b = {"f127": 4 * n, "c127h": n, "c63h": n, "c2": n, "f1": n, "c4": 2 * n, "u31": n, "u21": n}.get(leg, 0)
 
 mode, _, size = args.alloc.partition(":")
 size = int(size or 0)
@@ -86,7 +86,15 @@ keep = []
 with torch.cuda.stream(stream):
     nw = (L * bits + 63) // 64
     src = torch.zeros(nw + 2, dtype=torch.int64, device=dev)
-    ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, GOLDEN ^ seed, 0, nw, bits, amb, src.data_ptr()), "synth")
+    if leg == "f1":  # ASCII text: "ACGT" drawn uniformly
+        idx = torch.randint(0, 4, (L,), dtype=torch.uint8, device=dev)
+        text = src.view(torch.uint8)
+        text.fill_(65)
+        for code, add in ((1, 2), (2, 6), (3, 19)):
+            text[:L] += idx.eq(code).to(torch.uint8) * add
+        del idx
+    else:
+        ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, GOLDEN ^ seed, 0, nw, bits, amb, src.data_ptr()), "synth")
     if mode == "prefree":
         tmp = torch.empty(size * (1 << 30) // 8, dtype=torch.int64, device=dev)
         del tmp
@@ -137,6 +145,7 @@ if leg in ("u31", "u21"):
 
 calls = {
     "c2": lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, pa, pb, 0, ASYNC, C.byref(res)),
+    "f1": lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, pa, pb, 0, ASYNC, C.byref(res)),   # the headline launch from ASCII text
     "c3": lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, pa, None, 0, ASYNC, C.byref(res)),
     "f127": lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, pa, pb, ASYNC, C.byref(res)),   # four-word kmers + reverse complements
     "c63": lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, pa, None, 0, ASYNC, C.byref(res)),           # two-word canonical kmers, one array
@@ -152,7 +161,7 @@ calls = {
     "minhash": lambda: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, 2, 0, 1000, sk.ctypes.data_as(C.c_void_p), cap.MEM_DEVICE, C.byref(res)),
     "comp8": lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), K, pa, cap.MEM_DEVICE, C.byref(res)),
 }
-alg = {"f127": 64.5 * n, "c63": 16.5 * n, "c127h": 40.5 * n, "c63h": 24.5 * n, "f3": 16.5 * n, "c2": 16.5 * n, "c3": 8.25 * n, "c4": 32.5 * n, "c4t": 32.5 * n, "c5": 0.5 * L + 8.0 * n,
+alg = {"f127": 64.5 * n, "c63": 16.5 * n, "c127h": 40.5 * n, "c63h": 24.5 * n, "f3": 16.5 * n, "c2": 16.5 * n, "f1": 17.0 * n, "c3": 8.25 * n, "c4": 32.5 * n, "c4t": 32.5 * n, "c5": 0.5 * L + 8.0 * n,
        "u31": 0.5 * L + 16.0 * m_kept, "u21": 0.5 * L + 16.0 * m_kept}.get(leg)
 
 
