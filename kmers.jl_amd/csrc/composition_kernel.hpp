@@ -27,12 +27,7 @@ namespace kmers {
 
 constexpr int CBLOCK = 1024;                       // threads per workgroup
 constexpr int CRUN = 16;                           // consecutive kmers per lane (one 64-bit window: K <= 16)
-constexpr int CSYMS = CBLOCK * CRUN;               // source symbols staged per tile: 16384, 4 KiB of 2-bit stream
-// kmers per tile: 1020 runs, so that the last run's window (15 further starts, K - 1 <= 15 symbols) and up to 31 symbols of
-// misalignment fit into the staged symbols -- no staging pass for the overlap alone (a pass costs a wavefront the same 160
-// cycles whether one lane or all have a word to recode, profiles/r04_fused.md)
-constexpr int CTILE = (CBLOCK - 4) * CRUN;
-static_assert(CTILE + 15 + 15 + 31 <= CSYMS, "a tile's windows fit into one load round");
+constexpr int CTILE = CBLOCK * CRUN;               // kmers per tile = 16384 symbols of 2-bit stream (4 KiB)
 constexpr uint32_t CBINS_LOG2 = 16;                // bins per pass
 constexpr uint32_t CHIST_WORDS = 1u << (CBINS_LOG2 - 1);  // two 16-bit counters per word
 constexpr uint32_t COUNTER_LIMIT = 0xFFFFu;
@@ -57,7 +52,7 @@ struct CompositionArgs {
 template <int SRC_BITS>
 __global__ __launch_bounds__(CBLOCK) void composition_kernel(const CompositionArgs a) {
     extern __shared__ uint32_t hist[];                      // a.hist_words words
-    __shared__ uint64_t lds[CSYMS * 2 / 64 + 16];           // the tile's 2-bit stream
+    __shared__ uint64_t lds[CTILE * 2 / 64 + 16];           // the tile's 2-bit stream
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
     __shared__ uint32_t wave_max[CBLOCK / 64];
     const uint32_t tid = threadIdx.x;
@@ -97,8 +92,8 @@ __global__ __launch_bounds__(CBLOCK) void composition_kernel(const CompositionAr
         g.nw = (uint32_t)(((end_bit + 63) >> 6) - g.w0);
         return g;
     };
-    // source words of a tile per thread: 16384 symbols over 1024 threads
-    constexpr int PRE = CSYMS * SRC_BITS / 64 / CBLOCK > 0 ? CSYMS * SRC_BITS / 64 / CBLOCK : 1;  // 1, 1 or 2
+    // source words of a tile per thread: 16384 + K - 1 + 31 symbols over 1024 threads
+    constexpr int PRE = (CTILE + 64) * SRC_BITS / 64 / CBLOCK + 1;
     uint64_t pre[PRE];
     auto prefetch = [&](const Geo &g) {
 #pragma unroll

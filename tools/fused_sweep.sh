@@ -5,7 +5,7 @@ OUT=${1:-gpurun_out/fused}; mkdir -p "$OUT"
 C=kmers.jl_amd/csrc
 for v in ""; do
   [ -f $C/libkmers_hip$v.so ] || continue
-  for leg in xor minhash; do
+  for leg in comp8 xor; do
     echo "== lib$v $leg" >> "$OUT/legs.log"
     KMERS_HIP_LIB=$PWD/$C/libkmers_hip$v.so python3 tools/leg.py --leg $leg 2>&1 | grep " ms " >> "$OUT/legs.log"
   done
