@@ -936,6 +936,43 @@ def test_reduce_xor(km, ctx, orc):
             assert rc == 0 and val.value == int(np.bitwise_xor.reduce(fw[:, 0]))
 
 
+def test_reduce_xor_every_k_sources_views_and_run_edges(km, ctx, orc):
+    """The fused XOR reducer cuts a full run of 32 one-word kmers as windows of two 128-bit streams (run_kernel.hpp) and rolls
+    the last, short run and two-word kmers: every K of both paths, every source width, views that start inside a word, and
+    lengths that end a run / a tile (253 runs of 32 kmers) exactly, one kmer early and one kmer late."""
+    cap = km._capi
+    rng = np.random.default_rng(4242)
+    tile = 253 * 32
+    text = naive.random_text(rng, 3 * tile + 200)
+    sources = {2: naive.longseq_words(text, 2), 4: naive.longseq_words(text, 4), 8: naive.ascii_words(text)}
+
+    def check(bits, first, L, K):
+        seq, keep = make_seq(km, sources[bits], L, bits, first)
+        sub = text[first:first + L]
+        ow = naive.ascii_words(sub) if bits == 8 else naive.longseq_words(sub if sub else "A", bits)
+        val, res = C.c_uint64(), cap.Result()
+        for canonical in (1, 0):
+            rc = ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, 2, canonical, C.byref(val), cap.MEM_HOST, C.byref(res))
+            assert rc == 0, (bits, first, L, K, ctx.last_error())
+            if canonical:
+                exp, _ = orc.reduce_xor_canonical(ow, L, bits, 2, K)
+            else:
+                fw, _ = orc.fw_kmers(ow, L, bits, 2, K)
+                exp = int(np.bitwise_xor.reduce(fw[:, 0])) if len(fw) else 0
+            assert val.value == exp, (bits, first, L, K, canonical)
+
+    for bits in (2, 4, 8):
+        for K in list(range(1, 34)) + [47, 64]:
+            check(bits, 0, 5000 + K, K)
+        for first in (1, 7, 15, 16, 31, 33, 63):
+            for K in (1, 16, 17, 31, 32):
+                check(bits, first, 9000, K)
+        for K in (5, 31, 32):
+            for n_kmers in (1, 31, 32, 33, 63, 64, 65, tile - 1, tile, tile + 1, tile + 32, 2 * tile, 2 * tile + 31, 3 * tile):
+                check(bits, 3, n_kmers + K - 1, K)
+        check(bits, 0, 3, 5)  # shorter than a kmer: nothing to reduce
+
+
 def test_batch_fx_hash_and_transforms(km, ctx, orc):
     """fx_hash and reverse/complement/reverse_complement/canonical/iscanonical on kmer arrays
     (kmer.jl:255-261; transformations.jl:1-41)."""
