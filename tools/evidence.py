@@ -31,7 +31,9 @@ LEGS = {  # leg -> (label, kernel substring, algorithmic bytes per launch given 
     "f3": ("f3 FwKmers{DNAAlphabet{4},31}: two-word kmers of a 4-bit alphabet, one array", "stream_kernel<4, 4, 2, 0", lambda kept: 16.5 * (L - 30)),
     "u31": ("UnambiguousDNAMers{31}, p(N) = 0.04", "unambiguous_kernel<4, 1, 0", lambda kept: 0.5 * L + 16.0 * kept),
     "u21": ("C5 skip variant: UnambiguousDNAMers{21} on the stride-3 lattice, p(N) = 0.04", "unambiguous_kernel<4, 1, 0", lambda kept: 0.5 * L + 16.0 * kept),
-    "xor": ("fused XOR-reduce of CanonicalDNAMers{31}", "run_kernel<4", lambda kept: 0.0),
+    "xor": ("fused XOR-reduce of CanonicalDNAMers{31}", "run_kernel<4, 0", lambda kept: 0.0),
+    "minhash": ("fused MinHash candidates, CanonicalDNAMers{16}, bottom 1000", "run_kernel<4, 1", lambda kept: 0.0),
+    "f1": ("f1 CanonicalDNAMers{31} + fx_hash from ASCII text", "stream_kernel<8, 2, 1, 1", lambda kept: 17.0 * (L - 30)),
 }
 
 
