@@ -58,7 +58,9 @@ __device__ __forceinline__ uint32_t pack_4to2(uint64_t x, uint64_t &bad) {
 __device__ __forceinline__ uint32_t pack_4to2_checked(uint64_t x, uint32_t &any_bad) {
     const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
     auto half = [](uint32_t h) {
-        const uint32_t c = ((h >> 1) & 0x77777777u) - ((h >> 3) & 0x11111111u);  // 2-bit code in the low bits of each nibble
+        // 2-bit code in the low bits of each nibble; a nibble that is NOT one-hot (a symbol outside the view or past the end that
+        // shares the word: nobody asks for its code) must not spill into its neighbour's field below: 0xF gives 7 - 1 = 6
+        const uint32_t c = (((h >> 1) & 0x77777777u) - ((h >> 3) & 0x11111111u)) & 0x33333333u;
         const uint32_t u = (c | (c >> 2)) & 0x0F0F0F0Fu;
         return u | (u >> 4);  // bytes 0 and 2: four codes each
     };

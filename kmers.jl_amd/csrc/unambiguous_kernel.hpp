@@ -285,7 +285,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     };
 #ifdef KMERS_STAMPS
     uint64_t ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t tp[4] = {0, 0, 0, 0}, tp0 = 0;  // shader cycles of a tile's back spent listing / emitting / carrying / scanning
+    uint64_t tp[6] = {0, 0, 0, 0, 0, 0}, tp0 = 0;  // shader cycles of a tile's back spent listing / emitting / carrying / scanning / in partial frames
 #define USTAMP(i) ts[i] = __builtin_amdgcn_s_memrealtime()
 #define UPHASE_BEGIN() tp0 = __builtin_amdgcn_s_memtime()
 #define UPHASE_END(i) tp[i] += __builtin_amdgcn_s_memtime() - tp0
@@ -563,6 +563,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                 const uint64_t room = a.capacity > lo ? a.capacity - lo : 0;
                 const uint32_t n = (uint32_t)(hi - lo < room ? hi - lo : room);
                 const uint32_t hd = (uint32_t)lo & (UFRAME - 1u);  // where `lo` lies in its frame
+                UPHASE_BEGIN();
                 for (uint32_t f = 0; f < hd + n; f += UFRAME) {
                     const uint32_t j0 = f + 2u * lane - hd, j1 = j0 + 1u;  // element numbers relative to lo (wrapped if before it)
                     const bool v0 = j0 < n, v1 = j1 < n;
@@ -597,6 +598,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                         if (a.out_starts) a.out_starts[i] = (long long)(origin + (v0 ? ra : rb));
                     }
                 }
+                UPHASE_END(4);
             }
         };
         // whole frames of the list: slots [128 f0, 128 f1) -> memory, every lane two elements, no bounds (the caller checked the
@@ -869,9 +871,9 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
             for (int i = 0; i < 8; ++i) o[i] = ts[i];
             o[8] = __builtin_amdgcn_s_memrealtime();  // ... and drained
             o[9] = tile;
-            for (int i = 0; i < 4; ++i) o[10 + i] = tp[i];
+            for (int i = 0; i < 6; ++i) o[10 + i] = tp[i];
         }
-        for (int i = 0; i < 4; ++i) tp[i] = 0;
+        for (int i = 0; i < 6; ++i) tp[i] = 0;
 #endif
     };
 

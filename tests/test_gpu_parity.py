@@ -563,6 +563,35 @@ def test_offset_views(km, ctx, orc):
                 assert np.array_equal(hashes, eh)
 
 
+def test_symbols_outside_a_view_do_not_touch_its_kmers(km, ctx, orc):
+    """A view (first_base != 0, or a length that ends inside a word) shares its first and last source word with symbols that are
+    not part of it.  Whatever those are -- every one of the 16 values of a LongDNA{4} nibble, gap and ambiguity codes included --
+    the kmers of the view are the kmers of the view (found by the extended fuzz, seed 5071: the 4-bit staging let the code of
+    a nibble that is not one-hot spill into its neighbour's field)."""
+    cap = km._capi
+    rng = np.random.default_rng(5071)
+    alphabet = "-ACMGRSVTWYHKDBN"  # nibble value = index
+    for K, L, first in ((32, 33, 63), (31, 40, 15), (5, 20, 17), (32, 64, 1), (17, 100, 48)):
+        clean = naive.random_text(rng, first + L + 40)
+        for v in range(16):
+            for where in ("before", "after", "both"):
+                t = list(clean)
+                if where in ("before", "both"):
+                    t[first - 1] = alphabet[v]
+                if where in ("after", "both"):
+                    t[first + L] = alphabet[v]
+                text = "".join(t)
+                words = naive.longseq_words(text, 4)
+                sub = naive.longseq_words(text[first:first + L], 4)
+                rc, kmers, hashes, res = run_canonical(km, ctx, words, L, 4, K, 3, first_base=first)
+                ek, eh, _ = orc.canonical(sub, L, 4, 2, K, seed=3)
+                assert rc == 0 and np.array_equal(kmers, ek) and np.array_equal(hashes, eh), (K, L, first, v, where)
+                seq, keep = make_seq(km, words, L, 4, first)
+                val, r2 = C.c_uint64(), cap.Result()
+                assert ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, 2, 1, C.byref(val), cap.MEM_HOST, C.byref(r2)) == 0
+                assert val.value == orc.reduce_xor_canonical(sub, L, 4, 2, K)[0], (K, L, first, v, where)
+
+
 def test_encode_errors_match_oracle(km, ctx, orc):
     """First offending symbol (position and raw encoding) exactly as the reference would throw
     (construction.jl:108-110; raise sites FwKmers.jl:112, CanonicalKmers.jl:139)."""

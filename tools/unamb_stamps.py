@@ -40,7 +40,7 @@ for label, amb, K, J in CASES[:int(os.environ.get("KMERS_STAMPS_CASES", "3"))]:
         for i, nm in enumerate(names):
             print(f"    {nm:26s} mean {d[:, i].mean():8.0f} ns   median {np.median(d[:, i]):8.0f}   p90 {np.percentile(d[:, i], 90):8.0f}")
         print(f"    {'total':26s} mean {d.sum(axis=1).mean():8.0f} ns")
-        for i, nm in enumerate(["back: listing", "back: whole frames", "back: carry", "back: round scan"]):  # shader cycles (s_memtime)
+        for i, nm in enumerate(["back: listing", "back: whole frames", "back: carry", "back: round scan", "back: partial frames"]):  # shader cycles (s_memtime)
             print(f"    {nm:26s} mean {s[:, 10 + i].mean():8.0f} cycles")
         # start time of a tile against its ticket: how many are in flight
         t0 = s[:, 0].astype(np.float64) * 10.0; t0 -= t0.min()
