@@ -52,7 +52,7 @@ def same_error(rc, res, eres, first_origin=0):
     return rc == 1 and res.err_pos == eres.err_pos + first_origin and res.err_enc == eres.err_enc
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(10))
 def test_fuzz_iterators(km, ctx, orc, seed):
     cap = km._capi
     rng = np.random.default_rng(1000 + seed)
@@ -138,7 +138,7 @@ def test_fuzz_iterators(km, ctx, orc, seed):
         ctx.set_param(prm, 0)
 
 
-@pytest.mark.parametrize("seed", range(2))
+@pytest.mark.parametrize("seed", range(4))
 def test_fuzz_fused_consumers(km, ctx, orc, seed):
     cap = km._capi
     rng = np.random.default_rng(2000 + seed)
