@@ -3,13 +3,14 @@
 //                canonical (or forward) kmers' data words;
 //   RMODE_SKETCH MinHash candidates: fx_hash(canonical kmer) below the running threshold
 //                (docs/src/minhash.md:31-35).
-// These are ALU-bound (0.25-0.5 B of source per kmer), so the kernel spends as few instructions
-// per kmer as the reference's own recurrence allows: a lane builds the first kmer of a RUN of 32
-// from the LDS window (symbol reversal, complement) and then ROLLS the forward and
-// reverse-complement kmers one symbol at a time -- shift_encoding / shift_first_encoding, exactly
-// the step of CanonicalKmers.jl:131-144 -- taking the 31 entering symbols from the same stream bits
-// it already holds (K + 31 <= 64 N + 31 symbols: the N + 1 window words).  The next tile's source words travel from HBM while the current tile
-// is consumed (register prefetch).
+// These are issue-bound (0.25-0.5 B of source per kmer), so the kernel spends as few issue CYCLES per kmer as it can
+// (profiles/r04_valu_rates.txt: a SIMD of gfx950 takes a simple two-operand integer instruction every 2.24 cycles and every
+// other vector instruction every 4.1).  A lane takes a RUN of 32 consecutive kmers from the N + 1 window words of the LDS
+// stream it needs anyway (K + 31 <= 64 N + 31 symbols).  One-word kmers of a full run are CUT as windows of two 128-bit
+// streams, two v_alignbit each (see the tile loop); two-word kmers and the last, short run of a sequence are built once
+// (symbol reversal, complement) and then ROLLED one symbol at a time -- shift_encoding / shift_first_encoding, exactly the step
+// of CanonicalKmers.jl:131-144.  The next tile's source words travel from HBM while the current tile is consumed (register
+// prefetch).  profiles/r04_fused.md: what the kernel costs per phase, and the structural experiments that did not help.
 #pragma once
 #include "stream_kernel.hpp"
 
