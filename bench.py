@@ -53,8 +53,9 @@ NORTH_STAR_BASES = 10_000_000_000
 N_SIMDS = 1024  # 256 CUs x 4 SIMDs
 # What a SIMD of this device issues (tools/valu_rates.hip, profiles/r04_valu_rates.txt; cycles per wave64 vector instruction,
 # instructions of a launch / the launch's span, two or more wavefronts per SIMD): 2.24 for the simple two-operand integer
-# instructions (v_and / v_xor / v_add / 32-bit shifts; v_bitop3 over three registers), 4.1 for everything else these kernels use
-# (v_alignbit, v_perm, v_lshl_or, v_bfe, v_cndmask, compares, multiplies, every 64-bit shift) -- ONE wavefront alone already
+# instructions over registers or literals (v_and / v_or / v_xor / v_add / v_sub / v_mov / right shifts; v_bitop3 over three
+# registers), 4.1 for everything else these kernels use (v_alignbit, v_perm, v_lshl_or, v_bfe, v_cndmask, compares, multiplies,
+# every 64-bit shift, v_lshlrev_b32, anything with an SGPR operand) -- ONE wavefront alone already
 # issues one every 4.5-4.9 cycles, i.e. more wavefronts buy nothing for that class.  (The first version of the tool divided by the
 # mean LIFETIME of the wavefronts instead of the span; the arbiter prefers the oldest wavefront, lifetimes are staggered, and it
 # reported 1.32 / 2.35.  The "4 cycles per instruction" of rounds 2-3 was right for the slow class.)  A true floor prices every

@@ -172,10 +172,10 @@ __global__ __launch_bounds__(256) void recode_kernel(const RecodeArgs a) {
     for (uint64_t wi = (uint64_t)blockIdx.x * 256u + threadIdx.x; wi < a.n_words; wi += stride) {
         const uint64_t x = a.src[wi];
         if constexpr (SRC == 4 && DST == 2) {
-            uint64_t bad;
-            reinterpret_cast<uint32_t *>(a.stream)[wi] = pack_4to2(x, bad);
-            reinterpret_cast<uint16_t *>(a.flags)[wi] = (uint16_t)bad_bits16(bad);
-            if (bad) *a.any_flag = 1;  // rare; any writer, same value
+            uint32_t any_bad;  // (one verdict per word; the flag of every symbol only where a symbol is off: device_bits.hpp)
+            reinterpret_cast<uint32_t *>(a.stream)[wi] = pack_4to2_checked(x, any_bad);
+            reinterpret_cast<uint16_t *>(a.flags)[wi] = any_bad ? (uint16_t)bad_bits16(bad_nibbles4(x)) : (uint16_t)0;
+            if (any_bad) *a.any_flag = 1;  // rare; any writer, same value
         } else if constexpr (SRC == 8) {
             uint32_t codes = 0, f = 0;
 #pragma unroll

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Issue cost of gfx950 code by instruction class (profiles/r04_valu_rates.txt): the simple two-operand integer instructions and
-v_bitop3 over registers cost a SIMD 2.24 cycles per wave64 instruction, every other vector instruction 4.1; ds_read 8, ds_write 16,
+"""Issue cost of gfx950 code by instruction class (profiles/r04_valu_rates.txt): v_and / v_or / v_xor / v_add / v_sub / v_mov / v_not /
+right shifts over registers, inline constants or literals (and v_bitop3 over registers) cost a SIMD 2.24 cycles per wave64
+instruction; every other vector instruction -- v_lshlrev_b32 and any of the above with an SGPR operand included -- 4.1; ds_read 8, ds_write 16,
 ds_bpermute 24 cycles of the CU's LDS pipe.  Static: per kernel (or per label range) the number of instructions of each class
 and their cycles -- loops count once, so compare straight-line code (an unrolled step, a device function in a test kernel).
 
@@ -10,15 +11,16 @@ import re
 import sys
 from collections import Counter
 
-FAST = {"v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_lshlrev_b32", "v_ashrrev_i32",
-        "v_mov_b32", "v_not_b32", "v_xnor_b32", "v_add_co_u32x"}   # measured: and, xor, add, lshrrev, ashrrev (or/sub/lshl/mov/not assumed alike)
+FAST = {"v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_ashrrev_i32",
+        "v_mov_b32", "v_not_b32"}   # measured at 2.24 (v_subrev assumed like v_sub); v_lshlrev_b32 is NOT: 4.1
 FAST_IF_VGPR = {"v_bitop3_b32"}
 
 
 def classify(op, args):
     base = re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
     if base.startswith("v_"):
-        if base in FAST and not op.endswith(("_e64", "_dpp", "_sdwa")):
+        sgpr = re.search(r"(^|[ ,])(s\d+|s\[\d+:\d+\]|vcc|exec)", args.split(",", 1)[1] if "," in args else "")  # a scalar SOURCE operand
+        if base in FAST and not op.endswith(("_e64", "_dpp", "_sdwa")) and not sgpr:
             return "fast"
         if base in FAST_IF_VGPR and not re.search(r"\bs\d|\bs\[|vcc|exec", args):
             return "fast"

@@ -153,6 +153,30 @@ BENCH(k_cmp64, uint64_t, I_CMP64)
 BENCH(k_min64, uint64_t, I_MIN64)
 #define I_MIN64_NONOP(A) "v_cmp_lt_u64_e64 s[20:21], %[" #A "], %[b]\n v_and_b32 %[m4], %[m4], %[m8]\n v_and_b32 %[m8], %[m8], %[m4]\n"
 BENCH(k_min64_nonop, uint64_t, I_MIN64_NONOP)
+#define I_OR(A) "v_or_b32_e32 %[" #A "], %[" #A "], %[b]\n"
+BENCH(k_or, uint32_t, I_OR)
+#define I_SUB(A) "v_sub_u32_e32 %[" #A "], %[" #A "], %[b]\n"
+BENCH(k_sub, uint32_t, I_SUB)
+#define I_LSHL32(A) "v_lshlrev_b32_e32 %[" #A "], 3, %[" #A "]\n"
+BENCH(k_lshl32, uint32_t, I_LSHL32)
+#define I_LSHR32V(A) "v_lshrrev_b32_e32 %[" #A "], %[b], %[" #A "]\n"
+BENCH(k_lshr32v, uint32_t, I_LSHR32V)
+#define I_MOV(A) "v_mov_b32_e32 %[" #A "], %[b]\n"
+BENCH(k_mov, uint32_t, I_MOV)
+#define I_NOT(A) "v_not_b32_e32 %[" #A "], %[" #A "]\n"
+BENCH(k_not, uint32_t, I_NOT)
+#define I_AND_S(A) "v_and_b32_e32 %[" #A "], %[s], %[" #A "]\n"
+BENCH(k_and_s, uint32_t, I_AND_S)
+#define I_AND_LIT(A) "v_and_b32_e32 %[" #A "], 0x77777777, %[" #A "]\n"
+BENCH(k_and_lit, uint32_t, I_AND_LIT)
+#define I_ADD3(A) "v_add3_u32 %[" #A "], %[" #A "], %[b], %[c]\n"
+BENCH(k_add3, uint32_t, I_ADD3)
+#define I_LSHL_ADD(A) "v_lshl_add_u32 %[" #A "], %[" #A "], 2, %[b]\n"
+BENCH(k_lshl_add, uint32_t, I_LSHL_ADD)
+#define I_XAD(A) "v_xad_u32 %[" #A "], %[" #A "], %[b], %[c]\n"
+BENCH(k_xad, uint32_t, I_XAD)
+#define I_MAD64(A) "v_mad_u64_u32 %[" #A "], s[20:21], %[m4], %[m8], %[" #A "]\n"
+BENCH(k_mad64, uint64_t, I_MAD64)
 #define I_NOP(A) "s_nop 1\n"
 BENCH(k_snop, uint32_t, I_NOP)
 BENCH_DEP(k_dep_and, uint32_t, I_AND)
@@ -207,6 +231,18 @@ int main() {
 #define R32(NAME, INSTR) if (run<uint32_t>(INSTR, NAME, out, st, h)) return 1;
 #define R64(NAME, INSTR) if (run<uint64_t>(INSTR, NAME, (uint64_t *)out, st, h)) return 1;
     R32(k_and, "v_and_b32")
+    R32(k_or, "v_or_b32")
+    R32(k_sub, "v_sub_u32")
+    R32(k_lshl32, "v_lshlrev_b32 (const)")
+    R32(k_lshr32v, "v_lshrrev_b32 (v shift)")
+    R32(k_mov, "v_mov_b32")
+    R32(k_not, "v_not_b32")
+    R32(k_and_s, "v_and_b32 with an SGPR operand")
+    R32(k_and_lit, "v_and_b32 with a literal")
+    R32(k_add3, "v_add3_u32")
+    R32(k_lshl_add, "v_lshl_add_u32")
+    R32(k_xad, "v_xad_u32")
+    R64(k_mad64, "v_mad_u64_u32")
     R32(k_add, "v_add_u32")
     R32(k_lshr32, "v_lshrrev_b32 (const)")
     R32(k_lshl_or, "v_lshl_or_b32")
