@@ -32,6 +32,7 @@ __host__ __device__ inline uint64_t head_mask(int k, int bps) {
 // ---- 4-bit one-hot -> 2-bit codes, 16 symbols of one LongDNA{4} word at a time ------------
 // code = trailing_zeros(nibble) (construction_utils.jl:51): bit0 = C|T, bit1 = G|T.
 // `bad` gets a non-zero nibble for every symbol with count_ones != 1 (construction_utils.jl:50).
+// (The plain statement of the recoding, kept for reference: since round 4 the kernels call pack_4to2_checked below.)
 __device__ __forceinline__ uint32_t pack_4to2(uint64_t x, uint64_t &bad) {
     const uint64_t M1 = 0x1111111111111111ull;
     uint64_t x1 = x >> 1, x2 = x >> 2, x3 = x >> 3;
