@@ -85,9 +85,11 @@ int launch_consumer(kmers_ctx *ctx, const kmers_seq *seq, const Staged &st, int 
 #define RUNK(SB)                                                                                             \
     do {                                                                                                     \
         if (RMODE == RMODE_XOR && !a.xor_canonical) {                                                        \
-            if (k <= 32) hipLaunchKernelGGL((run_kernel<SB, RMODE_XOR, 1, false>), grid, block, best_bytes, ctx->stream, a); \
+            if (k <= 16) hipLaunchKernelGGL((run_kernel<SB, RMODE_XOR, 1, false, true>), grid, block, best_bytes, ctx->stream, a); \
+            else if (k <= 32) hipLaunchKernelGGL((run_kernel<SB, RMODE_XOR, 1, false>), grid, block, best_bytes, ctx->stream, a);  \
             else hipLaunchKernelGGL((run_kernel<SB, RMODE_XOR, 2, false>), grid, block, best_bytes, ctx->stream, a);         \
-        } else if (k <= 32) hipLaunchKernelGGL((run_kernel<SB, RMODE, 1, true>), grid, block, best_bytes, ctx->stream, a);   \
+        } else if (k <= 16) hipLaunchKernelGGL((run_kernel<SB, RMODE, 1, true, true>), grid, block, best_bytes, ctx->stream, a); \
+        else if (k <= 32) hipLaunchKernelGGL((run_kernel<SB, RMODE, 1, true>), grid, block, best_bytes, ctx->stream, a);   \
         else hipLaunchKernelGGL((run_kernel<SB, RMODE, 2, true>), grid, block, best_bytes, ctx->stream, a);  \
     } while (0)
     if (seq->src_bits == 8) RUNK(8);

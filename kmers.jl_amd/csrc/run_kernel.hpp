@@ -27,8 +27,10 @@ static_assert(RTILE + 63 + 31 <= RSYMS, "a tile's windows fit into one load roun
 enum RunMode { RMODE_XOR = 0, RMODE_SKETCH = 1 };
 
 // CANON: canonical kmers (always for the sketch); false = the forward kmers (kmers_reduce_xor with canonical = 0)
-template <int SRC_BITS, int RMODE, int N = 1, bool CANON = true>
+// HALF: one-word kmers of at most 32 bits (K <= 16), chosen by the host: their full runs work on the high halves of the windows
+template <int SRC_BITS, int RMODE, int N = 1, bool CANON = true, bool HALF = false>
 __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
+    static_assert(!HALF || N == 1, "HALF: one-word kmers");
     static_assert(RMODE != RMODE_SKETCH || CANON, "the sketch is over canonical kmers");
     __shared__ uint64_t lds[RSYMS * 2 / 64 + 8];  // the staged 2-bit stream + the window words past it (read, never used)
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
         }
     }
     uint64_t xacc = 0, xacc_left = 0;  // (xacc_left: XOR of LEFT-aligned one-word kmers, see the full-run path below)
+    uint32_t xacc_left_hi = 0;         // (... of their high halves alone when K <= 16)
 
     struct Geo { uint64_t w0; uint32_t b0, nw, mt; };
     auto geometry = [&](uint64_t tile) {
@@ -197,15 +200,37 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
                         const uint32_t hi = i + 2 < 4 ? (sh ? __builtin_amdgcn_alignbit(d[i + 2], d[i + 1], sh) : d[i + 1]) : d[i + 1] >> sh;
                         return ((uint64_t)hi << 32) | lo;
                     };
+                    if constexpr (HALF) {
+                        // kmers of at most 32 bits sit whole in the HIGH halves of the left-aligned windows: one
+                        // v_alignbit per kmer and strand, and the canonical one is v_min_u32 -- 14 cycles of a SIMD per kmer for
+                        // the XOR instead of 36.  (MinHash.jl's example sketches CanonicalDNAMers{16}, docs/src/minhash.md:34.)
+                        auto cut_hi = [](const uint32_t (&d)[4], uint32_t bit) {  // bits [bit + 32, bit + 64) of the stream
+                            const uint32_t i = bit >> 5, sh = bit & 31u;
+                            return i + 2 < 4 ? (sh ? __builtin_amdgcn_alignbit(d[i + 2], d[i + 1], sh) : d[i + 1]) : d[i + 1] >> sh;
+                        };
+                        const uint32_t up32 = 32u - 2u * k;  // 0..30
 #pragma unroll
-                    for (uint32_t j = 0; j < (uint32_t)RRUN; ++j) {
-                        const uint64_t f = cut(rd, 64u - 2u * j), r = cut(td, 2u * j);
-                        const uint64_t c = (!CANON || f < r) ? f : r;  // fw < rv ? fw : rv, CanonicalKmers.jl:220-225
-                        if constexpr (RMODE == RMODE_XOR) {
-                            xacc_left ^= c;
-                        } else {
-                            const uint64_t cr[1] = {c >> up};
-                            candidate(fx_hash<1>(cr, a.seed));
+                        for (uint32_t j = 0; j < (uint32_t)RRUN; ++j) {
+                            const uint32_t f = cut_hi(rd, 64u - 2u * j), r = cut_hi(td, 2u * j);
+                            const uint32_t c = CANON ? (f < r ? f : r) : f;
+                            if constexpr (RMODE == RMODE_XOR) {
+                                xacc_left_hi ^= c;
+                            } else {
+                                const uint64_t cr[1] = {(uint64_t)(c >> up32)};
+                                candidate(fx_hash<1>(cr, a.seed));
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (uint32_t j = 0; j < (uint32_t)RRUN; ++j) {
+                            const uint64_t f = cut(rd, 64u - 2u * j), r = cut(td, 2u * j);
+                            const uint64_t c = (!CANON || f < r) ? f : r;  // fw < rv ? fw : rv, CanonicalKmers.jl:220-225
+                            if constexpr (RMODE == RMODE_XOR) {
+                                xacc_left ^= c;
+                            } else {
+                                const uint64_t cr[1] = {c >> up};
+                                candidate(fx_hash<1>(cr, a.seed));
+                            }
                         }
                     }
                     consumed = true;
@@ -282,7 +307,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
     }
 #endif
     if constexpr (RMODE == RMODE_XOR) {
-        if constexpr (N == 1) xacc ^= xacc_left >> (64u - 2u * k);
+        if constexpr (N == 1) xacc ^= (xacc_left ^ ((uint64_t)xacc_left_hi << 32)) >> (64u - 2u * k);
         // wavefront XOR-reduce (64 lanes), then one atomic per wave
         for (int off = 32; off > 0; off >>= 1) xacc ^= __shfl_xor(xacc, off, 64);
         if ((tid & 63u) == 0) atomicXor(reinterpret_cast<unsigned long long *>(a.out_a), (unsigned long long)xacc);
