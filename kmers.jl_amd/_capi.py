@@ -20,7 +20,7 @@ BATCH_SKIP = 16
 (OP_REVERSE, OP_COMPLEMENT, OP_REVCOMP, OP_CANONICAL, OP_ISCANONICAL, OP_TO_LONGSEQ, OP_COUNT_GC, OP_AS_INTEGER,
  OP_FROM_INTEGER) = range(9)
 PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY, PARAM_BATCH_PASSES, PARAM_SKETCH_BATCH_LDS, PARAM_SUBTILES, PARAM_ARENA_NO_PROBE, PARAM_SPLIT_ORDER, PARAM_BLOCK_THREADS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-PARAM_WIDE_NO_TILES, PARAM_HOST_CHUNKS = 11, 12
+PARAM_WIDE_NO_TILES, PARAM_HOST_CHUNKS, PARAM_SHAPE_CALIBRATE = 11, 12, 13
 ALLOC_DEFAULT, ALLOC_LONE_OUTPUT = 0, 1
 
 STATUS_NAMES = {OK: "KMERS_OK", E_ENCODE: "KMERS_E_ENCODE", E_BADARG: "KMERS_E_BADARG",

@@ -58,6 +58,18 @@ struct kmers_ctx {
     hipEvent_t pipe_events[4] = {};      //   ... kernel done [2], chunk copied [2]
     int64_t host_chunks = 0;             // KMERS_PARAM_HOST_CHUNKS: -1 = host-pointer calls never in chunks (A/B, tests)
     int last_threads = 0, last_tile = 0, last_split = 0;  // shape of the most recent tile-kernel launch (kmers_last_launch_shape)
+    // The launcher's table (stream_launch.hpp) against its base rule, timed once per pair of output arrays (KMERS_PARAM_SHAPE_CALIBRATE):
+    // what the first large launch into (a, b) measured, reused by every later launch into the same arrays
+    struct shape_choice {
+        const void *a, *b;
+        uint64_t n_kmers;
+        int threads, tile;
+        float table_ms, rule_ms;
+    };
+    std::vector<shape_choice> shape_cache;
+    int64_t shape_calibrate = 1;  // KMERS_PARAM_SHAPE_CALIBRATE: 0 = trust the table
+    bool calibrating = false;
+    hipEvent_t cal_events[2] = {nullptr, nullptr};
     bool unamb_pending = false;     // an asynchronous kmers_unambiguous has run since the last kmers_sync: its count is in h_result[8..10]
     uint64_t unamb_capacity = 0;
 };

@@ -115,6 +115,8 @@ void kmers_ctx_destroy(kmers_ctx *ctx) {
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
     if (ctx->d_recent) (void)hipFree(ctx->d_recent);
+    for (auto &e : ctx->cal_events)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         for (auto &e : ctx->pipe_events)
@@ -140,6 +142,7 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value) {
     else if (param == KMERS_PARAM_SPLIT_ORDER) ctx->split_order = value;
     else if (param == KMERS_PARAM_STAMPS_PTR) ctx->stamps_ptr = value;
     else if (param == KMERS_PARAM_HOST_CHUNKS) ctx->host_chunks = value;
+    else if (param == KMERS_PARAM_SHAPE_CALIBRATE) ctx->shape_calibrate = value;
     else if (param == KMERS_PARAM_SKETCH_HOST_ONLY) ctx->sketch_host_only = value != 0;
     else if (param == KMERS_PARAM_BATCH_PASSES) ctx->batch_passes = value;
     else if (param == KMERS_PARAM_SKETCH_BATCH_LDS) ctx->sketch_batch_lds = value;

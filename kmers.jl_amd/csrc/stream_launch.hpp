@@ -139,6 +139,49 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
         else if (lone && a.tuples) tile *= 6u;
         else if (lone && J > 1) tile = tile * 5u / 2u;  // (clamped to what the LDS stream holds below: 5120 kmers at J = 3)
     }
+    // The table is what round 3 measured on a handful of boxes; the region map of a box can be finer than an array (runs of one
+    // 4 GiB granule), and there the table's shape lost 13 % to the base rule (headline 0.70 instead of 0.80, profiles/r04_shape.md).
+    // So the first large launch into a pair of arrays for which the table departs from the rule times both and remembers.
+    if ((spread || fwrc_wide || canon_wide) && ctx->tile_kmers <= 0 && ctx->block_threads <= 0 && ctx->shape_calibrate > 0 && !ctx->calibrating &&
+        (uint64_t)a.n_kmers * out_bytes >= ((uint64_t)1 << 30)) {
+        const void *const kb = a.out_b ? (const void *)a.out_b : (const void *)a.out_starts;
+        const kmers_ctx::shape_choice *hit = nullptr;
+        for (const auto &c : ctx->shape_cache)
+            if (c.a == (const void *)a.out_a && c.b == kb && c.n_kmers == a.n_kmers) hit = &c;
+        if (!hit) {
+            const uint32_t rule_pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * (uint32_t)BLOCK;
+            const int cand[2][2] = {{(int)threads, (int)std::max<uint32_t>(pass, tile / pass * pass)},
+                                    {BLOCK, (int)default_tile(out_bytes, rule_pass)}};
+            float ms[2] = {0.f, 0.f};
+            for (auto &e : ctx->cal_events)
+                if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->calibrating = true;
+            int rc = KMERS_OK;
+            for (int c = 0; c < 2 && rc == KMERS_OK; ++c) {
+                ctx->block_threads = cand[c][0];
+                ctx->tile_kmers = cand[c][1];
+                for (int rep = 0; rep < 3 && rc == KMERS_OK; ++rep) {  // one to warm up, two timed
+                    if (rep == 1 && hipEventRecord(ctx->cal_events[0], ctx->stream) != hipSuccess) rc = KMERS_E_HIP;
+                    StreamArgs copy = a;
+                    if (rc == KMERS_OK) rc = launch_stream<MODE>(ctx, copy, src_bits, dst_bits, n_words, vec_ok, dyn_lds);
+                }
+                if (rc == KMERS_OK && (hipEventRecord(ctx->cal_events[1], ctx->stream) != hipSuccess ||
+                                       hipEventSynchronize(ctx->cal_events[1]) != hipSuccess ||
+                                       hipEventElapsedTime(&ms[c], ctx->cal_events[0], ctx->cal_events[1]) != hipSuccess))
+                    rc = KMERS_E_HIP;
+            }
+            ctx->block_threads = 0;
+            ctx->tile_kmers = 0;
+            ctx->calibrating = false;
+            if (rc != KMERS_OK) return rc == KMERS_E_HIP ? fail(ctx, KMERS_E_HIP, "launch-shape calibration") : rc;
+            const int best = ms[1] < ms[0] ? 1 : 0;
+            if (ctx->shape_cache.size() >= 16) ctx->shape_cache.erase(ctx->shape_cache.begin());
+            ctx->shape_cache.push_back({(const void *)a.out_a, kb, a.n_kmers, cand[best][0], cand[best][1], ms[0] * 0.5f, ms[1] * 0.5f});
+            hit = &ctx->shape_cache.back();
+        }
+        threads = (uint32_t)hit->threads;
+        tile = (uint32_t)hit->tile;
+    }
     // (strided launches in ONE class: round 2's 32 KiB tile lost to 16 KiB on every box of round 3, 0.70-0.74 against 0.73-0.76)
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);
     tile = std::max<uint32_t>(pass, tile / pass * pass);
