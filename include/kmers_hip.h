@@ -124,8 +124,9 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 #define KMERS_PARAM_HOST_CHUNKS 12      /* -1: a host-pointer call (KMERS_MEM_HOST) is one launch + one copy whatever its size; 0 (default): outputs of
                                         * 96 MiB or more travel in chunks, the kernel of the next chunk beside the copy of the current one */
 #define KMERS_PARAM_SHAPE_CALIBRATE 13   /* 1 (default): the first launch of 1 GB or more into a pair of arena arrays for which the launcher's table departs from
-                                         * its base rule times both shapes (three launches each, the call blocks for that long once) and every later
-                                         * launch into the same arrays uses the faster one; 0: the table is trusted.  kmers_last_launch_shape tells. */
+                                         * its base rule times both shapes (eight launches, alternately; the call blocks for that long once) and every later
+                                         * launch into the same arrays uses the table's shape unless the rule's was 3 % faster; 0: the table is trusted.
+                                         * kmers_last_launch_shape tells. */
 #define KMERS_PARAM_SUBTILES 7         /* strided tile kernels (kmers_spaced, kmers_minimizers): consecutive tiles per workgroup, the next one's source words in flight */
 int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
 /* The launch shape the library chose for the most recent launch of its tile kernel in this context (kmers_fw / kmers_canonical /

@@ -64,6 +64,7 @@ struct kmers_ctx {
         const void *a, *b;
         uint64_t n_kmers;
         int threads, tile;
+        bool rule;  // the base rule's shape won
         float table_ms, rule_ms;
     };
     std::vector<shape_choice> shape_cache;

@@ -44,6 +44,7 @@ ap.add_argument("--subtiles", type=int, default=0)
 ap.add_argument("--threads", type=int, default=0, help="threads per workgroup of the tile kernels (KMERS_PARAM_BLOCK_THREADS)")
 ap.add_argument("--split", action="store_true", help="two write windows per array (KMERS_PARAM_SPLIT_ORDER)")
 ap.add_argument("--once", action="store_true")
+ap.add_argument("--no-calibrate", action="store_true", help="KMERS_PARAM_SHAPE_CALIBRATE = 0: the launcher trusts its table")
 ap.add_argument("--no-role", action="store_true", help="arena mode: a single output array is allocated like any other block (not by KMERS_ALLOC_LONE_OUTPUT)")
 ap.add_argument("--straddle-b", type=int, default=0, help="with --straddle: the second array centred on the n-th class boundary after the first")
 ap.add_argument("--straddle", action="store_true", help="arenacarve mode: the first array centred on the first class boundary of the arena's map")
@@ -68,6 +69,8 @@ if args.threads:
     ctx.set_param(cap.PARAM_BLOCK_THREADS, args.threads)
 if args.split:
     ctx.set_param(cap.PARAM_SPLIT_ORDER, 1)
+if args.no_calibrate:
+    ctx.set_param(cap.PARAM_SHAPE_CALIBRATE, 0)
 
 leg = args.leg
 L = 1_250_000_000 if leg == "c3" else args.bases
@@ -219,4 +222,5 @@ ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.reps)]
 med = float(np.median(ts))
 frac = f"frac {alg / med / 1e6 / 8000:.4f}" if alg else ""
 nosplit = " split" if args.split else ""
-print(f"{leg:7s} {args.alloc:12s} tile {args.tile:5d} thr {args.threads:3d} sub {args.subtiles}{nosplit}: {med:.4f} ms (min {min(ts):.4f} max {max(ts):.4f}) {frac} kept={m_kept} a at {pa:#x}", flush=True)
+shape = "x".join(str(v) for v in ctx.last_launch_shape())
+print(f"{leg:7s} {args.alloc:12s} shape {shape} tile {args.tile:5d} thr {args.threads:3d} sub {args.subtiles}{nosplit}: {med:.4f} ms (min {min(ts):.4f} max {max(ts):.4f}) {frac} kept={m_kept} a at {pa:#x}", flush=True)
