@@ -285,6 +285,7 @@ int kmers_arena_release(kmers_ctx *ctx) {
     if (!ctx->shared_arena) return KMERS_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->shape_cache.clear();  // (what launches into this arena's arrays measured says nothing about the next arena's)
     return arena_detach(ctx, false);
 }
 
@@ -368,6 +369,8 @@ int kmers_dev_free(kmers_ctx *ctx, void *p) {
     if (!ctx) return KMERS_E_BADARG;
     if (!p) return KMERS_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // work of this context that still uses the block
+    for (size_t i = ctx->shape_cache.size(); i-- > 0;)  // (what launches into this block measured goes with it)
+        if (ctx->shape_cache[i].a == p || ctx->shape_cache[i].b == p) ctx->shape_cache.erase(ctx->shape_cache.begin() + (long)i);
     const char *c = static_cast<const char *>(p);
     if (ctx->shared_arena && c >= ctx->shared_arena->a.base && c < ctx->shared_arena->a.base + ctx->shared_arena->a.bytes) {
         std::lock_guard<std::mutex> lock(ctx->shared_arena->mu);
