@@ -1105,6 +1105,7 @@ def main():
     elapsed = max(p[0] for p in per_rank)
 
     chosen_shape = ctx.last_launch_shape()
+    chosen_calibration = ctx.last_shape_calibration()  # (what the launcher itself measured on its first launch into these arrays)
     # ---- integrity of what the timed kernel wrote (outside the timed region) --------------
     verified = leg.verify()
     # ---- the launcher's choice against the alternatives of its table (stream_launch.hpp), same arrays, same run --------
@@ -1124,6 +1125,12 @@ def main():
             worst = max(cands, key=cands.get)
             shape_report = {"chosen": name, "chosen_ms": again, "candidates_ms": cands, "best": best, "worst": worst,
                             "chosen_over_best": round(again / cands[best], 4),
+                            "launcher_calibration": ({"table_ms": round(chosen_calibration[0], 4), "rule_ms": round(chosen_calibration[1], 4),
+                                                      "rule_chosen": chosen_calibration[2],
+                                                      "what": "KMERS_PARAM_SHAPE_CALIBRATE: the library's own timing of its tabulated shape against "
+                                                              "its base rule's (256 x 1024 here) on the first launch into these arrays, best of three "
+                                                              "each; the rule has to be 3 % faster to be taken"}
+                                                     if chosen_calibration[0] > 0 else None),
                             "what": "threads per workgroup x kmers per tile; every candidate forced with KMERS_PARAM_BLOCK_THREADS / _TILE_KMERS into "
                                     "the arrays of the timed leg, 7 launches behind 0.1 s of the same launch each, after the timed region"}
         except Exception as e:  # noqa: BLE001

@@ -135,6 +135,11 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
  * of output arrays and on where the arena says they lie; this is how a host, a test or bench.py sees what it came to, and
  * times the alternatives against it (KMERS_PARAM_TILE_KMERS / _BLOCK_THREADS / _SPLIT_ORDER).  All zero before any launch. */
 int kmers_last_launch_shape(kmers_ctx *ctx, int *threads, int *tile_kmers, int *split_order);
+/* What the shape of the most recent tile-kernel launch rested on when KMERS_PARAM_SHAPE_CALIBRATE applied to it: the best of three
+ * timed launches of the launcher's tabulated shape and of its base rule's in the launch's own output arrays (milliseconds), and
+ * whether the rule's was taken (it has to be 3 % faster).  All zero when no calibration applied (small launches, overrides,
+ * plain allocations, shapes the table does not touch). */
+int kmers_last_shape_calibration(kmers_ctx *ctx, double *table_ms, double *rule_ms, int *rule_chosen);
 
 /* ---- device memory ---------------------------------------------------------------------------
  * For hosts without a HIP binding of their own (the reference allocates its outputs itself: `collect` makes one Vector per

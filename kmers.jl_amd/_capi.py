@@ -68,6 +68,7 @@ SYMBOLS = {
     "kmers_arena_info": (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "kmers_arena_rates": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "kmers_last_launch_shape": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "kmers_last_shape_calibration": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "kmers_arena_regions": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "kmers_placement_probe": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_double)]),
     "kmers_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),

@@ -68,6 +68,8 @@ struct kmers_ctx {
         float table_ms, rule_ms;
     };
     std::vector<shape_choice> shape_cache;
+    float last_cal_table_ms = 0.f, last_cal_rule_ms = 0.f;  // what the most recent launch's choice rested on (0: no calibration applied)
+    int last_cal_rule = 0;
     int64_t shape_calibrate = 1;  // KMERS_PARAM_SHAPE_CALIBRATE: 0 = trust the table
     bool calibrating = false;
     hipEvent_t cal_events[2] = {nullptr, nullptr};

@@ -158,6 +158,14 @@ int kmers_last_launch_shape(kmers_ctx *ctx, int *threads, int *tile_kmers, int *
     return KMERS_OK;
 }
 
+int kmers_last_shape_calibration(kmers_ctx *ctx, double *table_ms, double *rule_ms, int *rule_chosen) {
+    if (!ctx) return KMERS_E_BADARG;
+    if (table_ms) *table_ms = ctx->last_cal_table_ms;
+    if (rule_ms) *rule_ms = ctx->last_cal_rule_ms;
+    if (rule_chosen) *rule_chosen = ctx->last_cal_rule;
+    return KMERS_OK;
+}
+
 int kmers_sync(kmers_ctx *ctx, kmers_result *res) {
     if (!ctx) return KMERS_E_BADARG;
     clear(res);

@@ -191,6 +191,12 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
         threads = (uint32_t)hit->threads;
         tile = (uint32_t)hit->tile;
         if (hit->rule) lone = false;  // (one write window)
+        ctx->last_cal_table_ms = hit->table_ms;
+        ctx->last_cal_rule_ms = hit->rule_ms;
+        ctx->last_cal_rule = hit->rule ? 1 : 0;
+    } else if (!ctx->calibrating) {
+        ctx->last_cal_table_ms = ctx->last_cal_rule_ms = 0.f;
+        ctx->last_cal_rule = 0;
     }
     // (strided launches in ONE class: round 2's 32 KiB tile lost to 16 KiB on every box of round 3, 0.70-0.74 against 0.73-0.76)
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);

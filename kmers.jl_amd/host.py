@@ -165,6 +165,13 @@ class Context:
         self.check(self.lib.kmers_last_launch_shape(self.handle, C.byref(t), C.byref(k), C.byref(sp)), "kmers_last_launch_shape")
         return t.value, k.value, sp.value
 
+    def last_shape_calibration(self):
+        """(table ms, rule ms, rule chosen) behind the shape of the most recent tile-kernel launch; zeros if no calibration applied
+        (kmers_last_shape_calibration)."""
+        t, r, c = C.c_double(), C.c_double(), C.c_int()
+        self.check(self.lib.kmers_last_shape_calibration(self.handle, C.byref(t), C.byref(r), C.byref(c)), "kmers_last_shape_calibration")
+        return t.value, r.value, bool(c.value)
+
     def arena_rates(self):
         """(best pair of places, one region class): GB/s of two store streams side by side as kmers_arena_reserve measured them."""
         b, o = C.c_double(), C.c_double()

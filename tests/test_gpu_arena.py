@@ -458,8 +458,12 @@ def test_launch_shape_calibration_keeps_results_and_remembers(km):
     ctx.set_param(cap.PARAM_SHAPE_CALIBRATE, 1)
     first = run()
     assert first[0] in (table_shape, (256, 1024)) and first[1:] == (fk, fh), (first, table_shape)
+    t_ms, r_ms, rule = ctx.last_shape_calibration()
+    if table_shape != (256, 1024):                                 # (the table departs from the rule: both were timed)
+        assert 0 < t_ms < 50 and 0 < r_ms < 50 and rule == (first[0] == (256, 1024) != table_shape) and (not rule or r_ms < 0.97 * t_ms), (t_ms, r_ms, rule)
     again = run()
     assert again == first                                          # remembered: the same shape, the same outputs
     ctx.set_param(cap.PARAM_SHAPE_CALIBRATE, 0)
     assert run() == (table_shape, fk, fh)
+    assert ctx.last_shape_calibration() == (0.0, 0.0, False)
     ctx.close()
