@@ -70,6 +70,28 @@ int main() {
         give(a, x); give(a, z); give(a, w); give(a, v);
         EXPECT(a.used.empty() && a.free_ranges.size() == 1 && a.free_ranges.begin()->first == 0 && a.free_ranges.begin()->second == 130 * MiB);
     }
+    {  // ---- the finest map a box of round 4 showed (4 GiB granules: A16 B7 C1 A1 B3 C1 A1 B3 C3 A1 C4 A1 B4 C5 A1 B1,
+       //      profiles/r04_shape.md): the two 8 GB outputs of the headline launch still land each inside ONE run, in two classes
+        kmers_arena a = fresh(212 * GiB);
+        std::vector<std::pair<size_t, int>> runs;
+        const int cls[] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 2, 0, 1, 2, 0, 1};
+        const size_t len[] = {16, 7, 1, 1, 3, 1, 1, 3, 3, 1, 4, 1, 4, 5, 1, 1};
+        size_t at = 0;
+        for (int i = 0; i < 16; ++i) {
+            runs.push_back({at, cls[i]});
+            at += 4 * len[i];
+        }
+        EXPECT(at == 212);
+        set_map(a, runs);
+        size_t k1, k2, src;
+        EXPECT(take(a, (size_t)8e9, &k1));
+        EXPECT(take(a, (size_t)8e9, &k2));
+        EXPECT(take(a, (size_t)5e8, &src));
+        EXPECT(run_of(a, k1) == run_of(a, k1 + (size_t)8e9 - 1) && run_of(a, k2) == run_of(a, k2 + (size_t)8e9 - 1));
+        EXPECT(class_at(a, k1) != class_at(a, k2));
+        EXPECT(kmers_arena_spread(a, a.base + k1, a.base + k2, (size_t)8e9));
+        give(a, k1); give(a, k2); give(a, src);
+    }
     {  // ---- a map: A [0,64) B [64,128) C [128,160) A [160,200) GiB
         kmers_arena a = fresh(200 * GiB);
         set_map(a, {{0, 0}, {64, 1}, {128, 2}, {160, 0}});
