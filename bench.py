@@ -83,6 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-hash", action="store_true", help="materialise canonical kmers only (8.5 / 8.25 B per kmer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra C3/C4/C5/10 Gbase rates (N = 1 only)")
+    ap.add_argument("--no-shape-calibration", action="store_true", help="KMERS_PARAM_SHAPE_CALIBRATE = 0 (profiling runs: one kernel shape per trace row)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic / VALU issue shares with rocprofv3 --pmc child runs")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--alloc", choices=("arena", "plain"), default="arena",
@@ -995,6 +996,8 @@ def main():
         dist.barrier()
     cap = km._capi
     ctx = km.Context(dev_index)
+    if args.no_shape_calibration:
+        ctx.set_param(cap.PARAM_SHAPE_CALIBRATE, 0)
     stream = torch.cuda.ExternalStream(ctx.lib.kmers_ctx_stream(ctx.handle), device=dev)
     if args.tile:
         ctx.set_param(cap.PARAM_TILE_KMERS, args.tile)

@@ -15,7 +15,7 @@ rm -rf "$E"; mkdir -p "$E"
 cd "$ROOT"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$E/bench.json" 2> "$E/bench.err"; echo "bench rc $?"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$E/trace" -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-other-configs --no-cpu-baseline --no-pmc > "$E/bench_under_rocprof.json" 2> "$E/trace.err"; echo "rocprof rc $?"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$E/trace" -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-other-configs --no-cpu-baseline --no-pmc --no-shape-calibration > "$E/bench_under_rocprof.json" 2> "$E/trace.err"; echo "rocprof rc $?"
 find "$E/trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$E/kernel_stats.csv"
 for leg in c2 c3 c4 c5 f1 f3 u31 u21 xor minhash; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$E/stats_$leg" -- python3 "$ROOT/tools/leg.py" --leg $leg --alloc arena:0 --reps 20 --no-calibrate > "$E/stats_$leg.txt" 2>&1
