@@ -123,10 +123,16 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
                                         * run-time-width tile form also for kmers of one to four words (it loses there: profiles/r03_wide.md) */
 #define KMERS_PARAM_HOST_CHUNKS 12      /* -1: a host-pointer call (KMERS_MEM_HOST) is one launch + one copy whatever its size; 0 (default): outputs of
                                         * 96 MiB or more travel in chunks, the kernel of the next chunk beside the copy of the current one */
-#define KMERS_PARAM_SHAPE_CALIBRATE 13   /* 1 (default): the first launch of 1 GB or more into a pair of arena arrays for which the launcher's table departs from
-                                         * its base rule times both shapes (eight launches, alternately; the call blocks for that long once) and every later
-                                         * launch into the same arrays uses the table's shape unless the rule's was 3 % faster; 0: the table is trusted.
-                                         * kmers_last_launch_shape tells. */
+#define KMERS_PARAM_SHAPE_CALIBRATE 13   /* 1 (default): the first SYNCHRONOUS launch of 1 GB or more into arrays of the ARENA for which the launcher's table departs
+                                         * from its base rule times both shapes (eight launches, alternately; the call blocks for that long once).  The answer is
+                                         * remembered per launch configuration and PLACEMENT (the runs of the arena the arrays start in, a size bucket), not per
+                                         * pointer: fresh arrays of a later call meet it again, kmers_dev_free forgets nothing.  Never inside a KMERS_ASYNC call
+                                         * (the table's shape runs; a later synchronous call may calibrate), never for blocks of the striped pool (placed well by
+                                         * construction) or plain allocations.  0: the table is trusted.  kmers_last_launch_shape tells. */
+#define KMERS_PARAM_POOL 14             /* 1 (default): without an arena, kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the device's striped pool
+                                         * (below); 0: plain hipMalloc */
+#define KMERS_PARAM_POOL_SEARCH_GIB 15  /* how far past a request the pool may grow in search of memory of a second region class (default 64); 0: never */
+#define KMERS_PARAM_POOL_MAX_GIB 16     /* cap on the physical memory the pool holds (0, default: what the device has) */
 #define KMERS_PARAM_SUBTILES 7         /* strided tile kernels (kmers_spaced, kmers_minimizers): consecutive tiles per workgroup, the next one's source words in flight */
 int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
 /* The launch shape the library chose for the most recent launch of its tile kernel in this context (kmers_fw / kmers_canonical /
@@ -140,10 +146,24 @@ int kmers_last_launch_shape(kmers_ctx *ctx, int *threads, int *tile_kmers, int *
  * whether the rule's was taken (it has to be 3 % faster).  All zero when no calibration applied (small launches, overrides,
  * plain allocations, shapes the table does not touch). */
 int kmers_last_shape_calibration(kmers_ctx *ctx, double *table_ms, double *rule_ms, int *rule_chosen);
+/* How many calibrations (timed launches of both shapes) this context has run since it was created. */
+int kmers_shape_calibrations(kmers_ctx *ctx, uint64_t *count);
 
 /* ---- device memory ---------------------------------------------------------------------------
  * For hosts without a HIP binding of their own (the reference allocates its outputs itself: `collect` makes one Vector per
- * call).  kmers_dev_free first waits for the context's stream. */
+ * call).  kmers_dev_free first waits for the context's stream (and, for blocks of the pool, for the device).
+ *
+ * WHERE an array lies matters on MI355X: HBM behaves as three REGION CLASSES of physical memory; store streams that run side by
+ * side inside one class share about 6.0-6.4 TB/s, streams in different classes reach 7.1-7.2 (profiles/r03_alloc.md,
+ * profiles/r05_vmm.md).  A plain hipMalloc lies wherever the driver puts it -- usually inside one class.  So, by default, a
+ * block of KMERS_POOL_MIN_BYTES or more comes from the device's STRIPED POOL: physical memory in 32 MiB handles of HIP's
+ * virtual-memory management, each handle's class measured once when the pool grows (1 GiB at a time, about 3 ms of probes),
+ * each block mapped from handles of ALTERNATING classes.  Every write window of every launch then spans both classes, whatever
+ * the number of arrays, their roles or the launch shape; no reservation is needed.  The pool holds what was asked of it plus
+ * what it had to walk past in search of a second class (KMERS_PARAM_POOL_SEARCH_GIB) until kmers_pool_trim or until the last
+ * context of the device that used it is destroyed; 512 MiB per class found stay with the pool as the yardstick later units are
+ * measured against.  One pool per device and process, shared by its contexts, thread-safe.
+ * Smaller blocks, a device without virtual-memory management, or KMERS_PARAM_POOL = 0: plain hipMalloc. */
 int kmers_dev_alloc(kmers_ctx *ctx, size_t bytes, void **out);
 /* The same with a word about what the block is for, which the arena (below) uses for its placement; without an arena, or when
  * the preferred place is taken, exactly kmers_dev_alloc.
@@ -158,7 +178,26 @@ int kmers_dev_free(kmers_ctx *ctx, void *p);
 int kmers_memcpy_h2d(kmers_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
-/* The context's ARENA: one large block of HBM reserved once, out of which kmers_dev_alloc then serves every request that fits
+#define KMERS_POOL_MIN_BYTES ((size_t)64 << 20)
+#define KMERS_POOL_CLASSES 4
+/* The device's striped pool: physical bytes it holds, bytes in blocks that are out, region classes found so far, bytes held per
+ * class (KMERS_POOL_CLASSES entries), and what its probes measured in GB/s of two store streams side by side (512 MiB each, the
+ * shape of the stream kernels' outputs): the fastest probe (two classes; about 7100; 0 while only one class is known) and the
+ * slowest (one class; about 6200).  The first is the write ceiling bench.py prices the materialising kernels against.  Any
+ * output may be NULL; all zero before the first block. */
+int kmers_pool_info(kmers_ctx *ctx, size_t *held, size_t *in_use, int *n_classes, size_t *class_bytes, double *two_class_gbps, double *one_class_gbps);
+/* Return to the driver every 1 GiB unit of the pool none of whose chunks is in a block (everything, if no block is out). */
+int kmers_pool_trim(kmers_ctx *ctx, size_t *released);
+/* The stripes of the pool block that holds `block`: *n_chunks chunks of *chunk_bytes, chunk i in class classes[i]
+ * (KMERS_POOL_CLASSES = class unknown; at most `capacity` entries are written).  *n_chunks = 0: not a block of the pool. */
+int kmers_pool_layout(kmers_ctx *ctx, const void *block, size_t *chunk_bytes, unsigned char *classes, size_t capacity, size_t *n_chunks);
+/* The virtual-memory calls the pool relies on, checked on this box (csrc/pool_api.hip): KMERS_OK, or KMERS_E_HIP with the reason in
+ * kmers_last_error.  *stale_without_flush = 1: a re-used address range showed the memory of its PREVIOUS mapping until the pool's
+ * flush ran -- the behaviour of this stack (ROCm 7.2) that every unmap of the pool guards against. */
+int kmers_pool_selftest(kmers_ctx *ctx, int *stale_without_flush);
+
+/* The ARENA (rounds 3-4; the pool above replaces it as the default and needs no reservation): one large block of HBM reserved
+ * once, out of which kmers_dev_alloc then serves every request of a context attached to it that fits
  * (KMERS_ARENA_GRANULE-aligned ranges; a request that does not fit falls through to a plain allocation; kmers_dev_free returns
  * a range to the arena and merges it with its free neighbours).  Two reasons to use it:
  * (1) a collect per sequence allocates and releases tens of gigabytes, and a plain allocation of that size costs milliseconds;
@@ -171,8 +210,12 @@ int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t
  *     blocks that are live is highest (the previous allocation counting double): allocate the arrays of one launch one after
  *     the other and they end up in different classes.  kmers_arena_regions reports the map.  The launchers consult it too: two
  *     output arrays that they can see are well placed get the launch shape that is fastest for such arrays.
- * bytes = 0 reserves three quarters of the memory that is free at the time of the call.  One arena per context;
- * kmers_arena_release fails with KMERS_E_BADARG while blocks of it are allocated; kmers_ctx_destroy releases it. */
+ * bytes = 0 reserves three quarters of the memory that is free at the time of the call.
+ * ONE arena per DEVICE and process: the first kmers_arena_reserve on a device makes it, a later one (another context of the
+ * device) ATTACHES to it -- its `bytes` and KMERS_PARAM_ARENA_NO_PROBE are ignored, kmers_arena_info says what there is.  Every
+ * block remembers the context that allocated it: kmers_arena_release detaches the calling context and fails with KMERS_E_BADARG
+ * while blocks IT allocated are out; kmers_ctx_destroy gives them back.  The last context to leave frees the block.  Any context
+ * of the device may kmers_dev_free a block of the arena (the allocating context's stream is waited for). */
 #define KMERS_ARENA_GRANULE ((size_t)2 << 20)
 int kmers_arena_reserve(kmers_ctx *ctx, size_t bytes);
 int kmers_arena_release(kmers_ctx *ctx);
@@ -185,7 +228,7 @@ int kmers_arena_info(kmers_ctx *ctx, size_t *reserved, size_t *in_use, size_t *l
 int kmers_arena_regions(kmers_ctx *ctx, void **base, size_t *region_bytes, unsigned char *classes, size_t capacity, size_t *n_regions);
 /* What the probes of kmers_arena_reserve measured, in GB/s of two store streams side by side (1 GiB each, the shape of the stream
  * kernels' outputs): the best pair of places of the block (two region classes; about 7000 on MI355X) and two streams inside one
- * granule (one class; about 6000).  Both 0 without an arena or without a map.  The first is the write ceiling bench.py prices the
+ * granule (one class; about 6000).  Both 0 without an arena or without a map (block too small, probing off, one class only).  The first is the write ceiling bench.py prices the
  * materialising kernels against (the HBM floor of a launch = its algorithmic bytes / this rate).  Either output may be NULL. */
 int kmers_arena_rates(kmers_ctx *ctx, double *best_pair_gbps, double *one_class_gbps);
 /* For hosts that allocate their outputs themselves (no arena): the write rate, in GB/s, of two store streams side by side into

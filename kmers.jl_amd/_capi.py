@@ -21,6 +21,8 @@ BATCH_SKIP = 16
  OP_FROM_INTEGER) = range(9)
 PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY, PARAM_BATCH_PASSES, PARAM_SKETCH_BATCH_LDS, PARAM_SUBTILES, PARAM_ARENA_NO_PROBE, PARAM_SPLIT_ORDER, PARAM_BLOCK_THREADS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 PARAM_WIDE_NO_TILES, PARAM_HOST_CHUNKS, PARAM_SHAPE_CALIBRATE = 11, 12, 13
+PARAM_POOL, PARAM_POOL_SEARCH_GIB, PARAM_POOL_MAX_GIB = 14, 15, 16
+POOL_MIN_BYTES, POOL_CLASSES = 64 << 20, 4
 ALLOC_DEFAULT, ALLOC_LONE_OUTPUT = 0, 1
 
 STATUS_NAMES = {OK: "KMERS_OK", E_ENCODE: "KMERS_E_ENCODE", E_BADARG: "KMERS_E_BADARG",
@@ -69,6 +71,12 @@ SYMBOLS = {
     "kmers_arena_rates": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "kmers_last_launch_shape": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kmers_last_shape_calibration": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "kmers_shape_calibrations": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "kmers_pool_info": (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double)]),
+    "kmers_pool_trim": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    "kmers_pool_layout": (C.c_int, [_P, _P, C.POINTER(C.c_size_t), _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "kmers_pool_selftest": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "kmers_arena_regions": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "kmers_placement_probe": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_double)]),
     "kmers_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libkmers_hip.so")
 SOURCES = ["iterators_api.hip", "consumers_api.hip", "unambiguous_api.hip", "batch_api.hip", "elementwise_api.hip", "context_api.hip",
-           "memory_api.hip", "comm_api.hip"]
+           "memory_api.hip", "pool_api.hip", "comm_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-array-bounds"]
 # the look-back of unambiguous_kernel.hpp gives up instead of hanging the device; this build provokes it (one tile never
 # publishes its count) so that the abort / drain path and the host's KMERS_E_HIP are exercised once on hardware

@@ -11,15 +11,27 @@
 
 #include "../../include/kmers_hip.h"
 #include "arena_placement.hpp"
+#include "stripe_pool.hpp"
 
 // The arena of ONE DEVICE (memory_api.hip): one block of HBM and its measured map, shared by every context of the process that
 // attaches to it with kmers_arena_reserve -- a second context on the device does not get a second three quarters of what is
 // free, it gets this one.  Sub-allocation is serialised by `mu`; the map is read-only once it has been measured.
+struct kmers_ctx;
 struct kmers_device_arena {
     kmers_arena a;
     std::mutex mu;
     int refs = 0;
     int device = 0;
+    std::map<size_t, kmers_ctx *> owner;  // offset of a block in use -> the context that allocated it (its stream is what may still write it)
+};
+struct kmers_device_pool;  // pool_api.hip
+// What ONE DEVICE of the process holds for its contexts: the arena (memory_api.hip) and the striped pool (pool_api.hip).  `mu`
+// serialises attaching, reserving, growing and releasing on that device only (a reservation's probes take 0.3 s: other devices
+// are not held up by them); slots are never destroyed.
+struct kmers_device_slot {
+    std::mutex mu;
+    kmers_device_arena *arena = nullptr;
+    kmers_device_pool *pool = nullptr;
 };
 
 struct kmers_ctx {
@@ -49,6 +61,11 @@ struct kmers_ctx {
     int64_t batch_passes = 0;       // KMERS_PARAM_BATCH_PASSES (tests, tuning); 0 = default
     int64_t sketch_batch_lds = 0;   // KMERS_PARAM_SKETCH_BATCH_LDS (tuning); 0 = default
     kmers_device_arena *shared_arena = nullptr;  // the device's arena, if this context is attached to it (memory_api.hip)
+    bool uses_pool = false;        // this context has taken part in the device's striped pool (pool_api.hip): counted in its refs
+    int64_t pool_enable = 1;       // KMERS_PARAM_POOL: kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the striped pool (no arena attached)
+    int64_t pool_search_gib = -1;  // KMERS_PARAM_POOL_SEARCH_GIB: how far past a request the pool may grow in search of a second class (-1: 64)
+    int64_t pool_max_gib = 0;      // KMERS_PARAM_POOL_MAX_GIB: cap on what the pool holds (0: what the device has)
+    int call_flags = KMERS_ASYNC;  // flags of the entry point that is running (the launcher must not block inside a KMERS_ASYNC call)
     // the arena's map for the launchers (an empty one without an arena: every placement question is then answered "no")
     const kmers_arena &arena() const {
         static const kmers_arena none;
@@ -60,13 +77,16 @@ struct kmers_ctx {
     int last_threads = 0, last_tile = 0, last_split = 0;  // shape of the most recent tile-kernel launch (kmers_last_launch_shape)
     // The launcher's table (stream_launch.hpp) against its base rule, timed once per pair of output arrays (KMERS_PARAM_SHAPE_CALIBRATE):
     // what the first large launch into (a, b) measured, reused by every later launch into the same arrays
+    // keyed by what decides the answer -- the launch (mode, element width, layout, stride, a size bucket) and the PLACEMENT of its
+    // arrays (runs of the arena / striped blocks of the pool) -- not by pointers: a host that allocates fresh arrays per call
+    // (the reference's collect) meets its earlier measurement again, and kmers_dev_free forgets nothing
     struct shape_choice {
-        const void *a, *b;
-        uint64_t n_kmers;
+        uint64_t key;
         int threads, tile;
         bool rule;  // the base rule's shape won
         float table_ms, rule_ms;
     };
+    uint64_t calibrations = 0;  // launches that were timed (kmers_shape_calibrations: tests assert it stays at one)
     std::vector<shape_choice> shape_cache;
     float last_cal_table_ms = 0.f, last_cal_rule_ms = 0.f;  // what the most recent launch's choice rested on (0: no calibration applied)
     int last_cal_rule = 0;
@@ -98,9 +118,18 @@ inline int fail(kmers_ctx *ctx, int code, const char *what, hipError_t e = hipSu
         if (e_ != hipSuccess) return fail(ctx, KMERS_E_HIP, #call, e_); \
     } while (0)
 
-// memory_api.hip: detach the context from its device's arena; the last one out frees the block (`force`: even with blocks still
-// allocated -- context destruction; otherwise KMERS_E_BADARG)
+// memory_api.hip: the process's slot for a device (created on first use)
+kmers_device_slot &device_slot(int device);
+// memory_api.hip: detach the context from its device's arena.  Its own blocks go back to the arena (`force`: context destruction)
+// or make the call fail with KMERS_E_BADARG; the last context out frees the block.
 int arena_detach(kmers_ctx *ctx, bool force);
+// pool_api.hip: a block of the device's striped pool (KMERS_E_UNSUPPORTED: no virtual-memory management here -- plain hipMalloc then);
+// free it if `p` is one (*handled); leave the pool (the last context out returns everything to the driver); the fraction of
+// neighbouring stripes of the block holding [p, p + bytes) that lie in different region classes (-1: not a block of the pool)
+int pool_alloc(kmers_ctx *ctx, size_t bytes, void **out);
+int pool_free(kmers_ctx *ctx, void *p, bool *handled);
+void pool_detach(kmers_ctx *ctx);
+float pool_alternation(kmers_ctx *ctx, const void *p, size_t bytes);
 
 // grow-only device staging buffers owned by the context
 inline int ensure_stage(kmers_ctx *ctx, int slot, size_t bytes) {

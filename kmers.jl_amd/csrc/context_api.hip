@@ -123,7 +123,8 @@ void kmers_ctx_destroy(kmers_ctx *ctx) {
             if (e) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
-    kmers::arena_detach(ctx, true);  // the last context of the device frees the block, with whatever blocks of it are still out
+    kmers::pool_detach(ctx);         // the last context of the device that used the striped pool returns its memory to the driver
+    kmers::arena_detach(ctx, true);  // this context's blocks go back to the arena; the last context of the device frees the block
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -143,6 +144,9 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value) {
     else if (param == KMERS_PARAM_STAMPS_PTR) ctx->stamps_ptr = value;
     else if (param == KMERS_PARAM_HOST_CHUNKS) ctx->host_chunks = value;
     else if (param == KMERS_PARAM_SHAPE_CALIBRATE) ctx->shape_calibrate = value;
+    else if (param == KMERS_PARAM_POOL) ctx->pool_enable = value;
+    else if (param == KMERS_PARAM_POOL_SEARCH_GIB) ctx->pool_search_gib = value;
+    else if (param == KMERS_PARAM_POOL_MAX_GIB) ctx->pool_max_gib = value;
     else if (param == KMERS_PARAM_SKETCH_HOST_ONLY) ctx->sketch_host_only = value != 0;
     else if (param == KMERS_PARAM_BATCH_PASSES) ctx->batch_passes = value;
     else if (param == KMERS_PARAM_SKETCH_BATCH_LDS) ctx->sketch_batch_lds = value;
@@ -163,6 +167,12 @@ int kmers_last_shape_calibration(kmers_ctx *ctx, double *table_ms, double *rule_
     if (table_ms) *table_ms = ctx->last_cal_table_ms;
     if (rule_ms) *rule_ms = ctx->last_cal_rule_ms;
     if (rule_chosen) *rule_chosen = ctx->last_cal_rule;
+    return KMERS_OK;
+}
+
+int kmers_shape_calibrations(kmers_ctx *ctx, uint64_t *count) {
+    if (!ctx || !count) return KMERS_E_BADARG;
+    *count = ctx->calibrations;
     return KMERS_OK;
 }
 

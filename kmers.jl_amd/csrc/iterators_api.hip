@@ -179,7 +179,9 @@ int run_stream(kmers_ctx *ctx, const kmers_seq *seq, int k, int stride, int dst_
         return fail(ctx, KMERS_E_BADARG, "two- and four-word kmer outputs must be 16-byte aligned");
     if (tuples && !aligned16(d_a)) return fail(ctx, KMERS_E_BADARG, "tuple outputs must be 16-byte aligned");
 
+    ctx->call_flags = flags;  // (the launcher may time its shape table inside a synchronous call only, stream_launch.hpp)
     int rc = launch_range(ctx, seq, st, k, stride, dst_bits, mode, tuples, seed, 0, n, d_a, d_b, b_is_hash, flags);
+    ctx->call_flags = KMERS_ASYNC;
     if (rc) return rc;
     if (flags & KMERS_ASYNC) {
         if (res) { res->status = KMERS_OK; res->n_out = n; }

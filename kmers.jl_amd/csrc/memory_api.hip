@@ -30,9 +30,9 @@ using namespace kmers::arena;  // GRANULE, REGION, round_up, run_of, arena_take 
 static_assert(GRANULE == KMERS_ARENA_GRANULE, "arena_placement.hpp and include/kmers_hip.h disagree about the granule");
 constexpr size_t PROBE = (size_t)1 << 30;     // bytes per stream of one probe
 
-// one arena per device and process (kmers_device_arena, context.hpp)
+// one slot per device and process (kmers_device_slot, context.hpp): the global mutex guards the map only
 std::mutex g_registry_mu;
-std::map<int, kmers_device_arena *> g_device_arenas;
+std::map<int, kmers_device_slot *> g_device_slots;
 
 // two store streams, 8 KiB of each per workgroup, 16 bytes per lane: the shape of the stream kernels' outputs
 __global__ __launch_bounds__(256) void arena_probe_kernel(ulonglong2 *a, ulonglong2 *b) {
@@ -203,20 +203,48 @@ int calibrate(kmers_ctx *ctx) {
 
 }  // namespace
 
+kmers_device_slot &kmers::device_slot(int device) {
+    std::lock_guard<std::mutex> registry(g_registry_mu);
+    kmers_device_slot *&slot = g_device_slots[device];
+    if (!slot) slot = new kmers_device_slot();
+    return *slot;
+}
+
 int kmers::arena_detach(kmers_ctx *ctx, bool force) {
     kmers_device_arena *d = ctx->shared_arena;
     if (!d) return KMERS_OK;
-    std::lock_guard<std::mutex> registry(g_registry_mu);
+    kmers_device_slot &slot = device_slot(ctx->device);
+    std::lock_guard<std::mutex> on_device(slot.mu);
     bool last;
     {
         std::lock_guard<std::mutex> lock(d->mu);
+        // the blocks THIS context allocated: a context that leaves takes them with it (its stream is the one that may still
+        // write them, and nobody could free them through it afterwards)
+        size_t mine = 0;
+        for (const auto &o : d->owner) mine += o.second == ctx;
+        if (mine && !force) return fail(ctx, KMERS_E_BADARG, "kmers_arena_release: blocks this context took from the arena are still allocated");
+        if (mine) {
+            (void)hipStreamSynchronize(ctx->stream);
+            for (auto it = d->owner.begin(); it != d->owner.end();) {
+                if (it->second != ctx) {
+                    ++it;
+                    continue;
+                }
+                auto u = d->a.used.find(it->first);
+                if (u != d->a.used.end()) {
+                    const size_t off = u->first, len = u->second;
+                    d->a.used.erase(u);
+                    arena_give(d->a, off, len);
+                }
+                it = d->owner.erase(it);
+            }
+        }
         last = d->refs == 1;
-        if (last && !force && !d->a.used.empty()) return fail(ctx, KMERS_E_BADARG, "kmers_arena_release: blocks of the arena are still allocated");
         --d->refs;
     }
     ctx->shared_arena = nullptr;
     if (last) {
-        g_device_arenas.erase(d->device);
+        slot.arena = nullptr;
         (void)hipFree(d->a.base);
         delete d;
     }
@@ -229,14 +257,14 @@ int kmers_arena_reserve(kmers_ctx *ctx, size_t bytes) {
     if (!ctx) return KMERS_E_BADARG;
     if (ctx->shared_arena) return fail(ctx, KMERS_E_BADARG, "kmers_arena_reserve: this context already holds an arena (release it first)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    std::lock_guard<std::mutex> registry(g_registry_mu);
-    auto it = g_device_arenas.find(ctx->device);
-    if (it != g_device_arenas.end()) {
+    kmers_device_slot &slot = device_slot(ctx->device);
+    std::lock_guard<std::mutex> on_device(slot.mu);  // (this device only: the probes below take 0.3 s)
+    if (slot.arena) {
         // the device has its arena already (another context of this process reserved it): ATTACH -- `bytes` is not a second
         // reservation (kmers_arena_info says what there is)
-        std::lock_guard<std::mutex> lock(it->second->mu);
-        ++it->second->refs;
-        ctx->shared_arena = it->second;
+        std::lock_guard<std::mutex> lock(slot.arena->mu);
+        ++slot.arena->refs;
+        ctx->shared_arena = slot.arena;
         return KMERS_OK;
     }
     if (bytes == 0) {  // default: three quarters of what is free now
@@ -265,7 +293,7 @@ int kmers_arena_reserve(kmers_ctx *ctx, size_t bytes) {
         delete d;
         return rc;
     }
-    g_device_arenas[ctx->device] = d;
+    slot.arena = d;
     return KMERS_OK;
 }
 
@@ -285,7 +313,6 @@ int kmers_arena_release(kmers_ctx *ctx) {
     if (!ctx->shared_arena) return KMERS_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->shape_cache.clear();  // (what launches into this arena's arrays measured says nothing about the next arena's)
     return arena_detach(ctx, false);
 }
 
@@ -308,7 +335,7 @@ int kmers_arena_info(kmers_ctx *ctx, size_t *reserved, size_t *in_use, size_t *l
 int kmers_arena_rates(kmers_ctx *ctx, double *best_pair_gbps, double *one_class_gbps) {
     if (!ctx) return KMERS_E_BADARG;
     if (best_pair_gbps) *best_pair_gbps = (double)ctx->arena().best_pair_rate;
-    if (one_class_gbps) *one_class_gbps = (double)ctx->arena().one_class_rate;
+    if (one_class_gbps) *one_class_gbps = ctx->arena().run_start.empty() ? 0.0 : (double)ctx->arena().one_class_rate;  // (no map: nothing to price against)
     return KMERS_OK;
 }
 
@@ -355,10 +382,16 @@ int kmers_dev_alloc_role(kmers_ctx *ctx, size_t bytes, int role, void **out) {
         // the only output array of its launches: across a class boundary if one has room (else like any other block)
         if ((role == KMERS_ALLOC_LONE_OUTPUT && need >= ((size_t)64 << 20) && arena_take_straddling(ar, need, &off)) ||
             arena_take(ar, need, &off)) {
+            ctx->shared_arena->owner[off] = ctx;
             *out = ar.base + off;
             return KMERS_OK;
         }
-    }  // no arena, or no range of it fits: a plain allocation
+    } else if (ctx->pool_enable > 0 && bytes >= KMERS_POOL_MIN_BYTES) {
+        // no arena: arrays of a launch come from the device's striped pool (pool_api.hip) -- every block made of physical chunks
+        // of alternating region classes, so the role does not matter
+        const int rc = pool_alloc(ctx, bytes, out);
+        if (rc != KMERS_E_UNSUPPORTED) return rc;
+    }  // no arena and no pool, a small block, or no range of the arena fits: a plain allocation
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(out, bytes ? bytes : 8);
     if (e != hipSuccess) return fail(ctx, KMERS_E_NOMEM, "hipMalloc", e);
@@ -369,14 +402,28 @@ int kmers_dev_free(kmers_ctx *ctx, void *p) {
     if (!ctx) return KMERS_E_BADARG;
     if (!p) return KMERS_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // work of this context that still uses the block
-    for (size_t i = ctx->shape_cache.size(); i-- > 0;)  // (what launches into this block measured goes with it)
-        if (ctx->shape_cache[i].a == p || ctx->shape_cache[i].b == p) ctx->shape_cache.erase(ctx->shape_cache.begin() + (long)i);
+    bool handled = false;
+    if (const int rc = pool_free(ctx, p, &handled)) return rc;
+    if (handled) return KMERS_OK;
     const char *c = static_cast<const char *>(p);
-    if (ctx->shared_arena && c >= ctx->shared_arena->a.base && c < ctx->shared_arena->a.base + ctx->shared_arena->a.bytes) {
-        std::lock_guard<std::mutex> lock(ctx->shared_arena->mu);
-        kmers_arena &a = ctx->shared_arena->a;
+    // the device's arena, whether or not THIS context is attached to it (any context of the device may free a block; the stream
+    // of the context that allocated it is waited for, it may still be writing)
+    kmers_device_arena *d = ctx->shared_arena;
+    if (!d) {
+        kmers_device_slot &slot = device_slot(ctx->device);
+        std::lock_guard<std::mutex> on_device(slot.mu);
+        d = slot.arena;
+    }
+    if (d && c >= d->a.base && c < d->a.base + d->a.bytes) {
+        std::lock_guard<std::mutex> lock(d->mu);
+        kmers_arena &a = d->a;
         auto it = a.used.find((size_t)(c - a.base));
         if (it == a.used.end()) return fail(ctx, KMERS_E_BADARG, "kmers_dev_free: not the start of a block of the arena");
+        auto own = d->owner.find(it->first);
+        if (own != d->owner.end()) {
+            if (own->second != ctx) HIP_TRY(ctx, hipStreamSynchronize(own->second->stream));
+            d->owner.erase(own);
+        }
         const size_t off = it->first, len = it->second;
         a.used.erase(it);
         arena_give(a, off, len);

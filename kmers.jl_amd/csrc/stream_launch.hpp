@@ -110,18 +110,29 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     const bool materialises = MODE == MODE_FW || MODE == MODE_CANON;
     const bool two_arrays = materialises && stride1 && a.out_a && !a.tuples;
     const bool one_word_pair = two_arrays && n_words == 1 && (a.out_b || a.out_starts);
-    const bool spread = one_word_pair && kmers_arena_spread(ctx->arena(), a.out_a, a.out_b ? (const void *)a.out_b : (const void *)a.out_starts,
-                                                            (size_t)a.n_kmers * 8u);
+    const void *const second = a.out_b ? (const void *)a.out_b : (const void *)a.out_starts;
+    const size_t bytes_a = (size_t)a.n_kmers * 8u * (size_t)n_words;
+    const size_t bytes_b = (size_t)a.n_kmers * (MODE == MODE_CANON || !a.out_b ? 8u : 8u * (size_t)n_words);
+    // Blocks of the striped pool (pool_api.hip) are well placed by construction: both region classes inside every write window.
+    constexpr float STRIPED = 0.9f;
+    const bool striped_a = materialises && a.out_a && pool_alternation(ctx, a.out_a, a.tuples ? (size_t)a.n_kmers * 8u : bytes_a) >= STRIPED;
+    const bool striped_pair = striped_a && second && pool_alternation(ctx, second, bytes_b) >= STRIPED;
+    const bool in_arena = ctx->shared_arena != nullptr;
+    const bool spread = one_word_pair && (striped_pair || kmers_arena_spread(ctx->arena(), a.out_a, second, (size_t)a.n_kmers * 8u));
     const bool fwrc_wide = two_arrays && MODE == MODE_FW && n_words >= 2 && a.out_b &&
-                           kmers_arena_spread(ctx->arena(), a.out_a, a.out_b, (size_t)a.n_kmers * 8u * (size_t)n_words);
+                           (striped_pair || kmers_arena_spread(ctx->arena(), a.out_a, a.out_b, bytes_a));
     const bool canon_wide = two_arrays && MODE == MODE_CANON && n_words >= 2 && a.out_b;
     const bool canon2_spread = canon_wide && n_words == 2 &&
-                               kmers_arena_spread(ctx->arena(), a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u);
+                               (striped_pair || kmers_arena_spread(ctx->arena(), a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u));
     const uint32_t lone_bytes = a.tuples ? (MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u) : 8u * n_words;
-    bool lone = materialises && ctx->split_order >= 0 && a.out_a && !a.out_b && !a.out_starts &&
+    // ONE output array: across a class boundary of the arena it is written through two windows; a striped block needs no
+    // second window (both classes are inside the one it has) but likes the same long tiles
+    const bool lone_output = materialises && a.out_a && !a.out_b && !a.out_starts;
+    const bool lone_striped = lone_output && striped_a && ctx->split_order >= 0;
+    bool lone = lone_output && !lone_striped && ctx->split_order >= 0 &&
                 kmers_arena_straddles(ctx->arena(), a.out_a, (size_t)a.n_kmers * lone_bytes);  // (the calibration below may overrule it)
     uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads
-                                              : ((spread || canon_wide || (lone && !a.tuples && J == 1)) ? 128u : (uint32_t)BLOCK);
+                                              : ((spread || canon_wide || ((lone || lone_striped) && !a.tuples && J == 1)) ? 128u : (uint32_t)BLOCK);
     if (threads != 64u && threads != 128u) threads = (uint32_t)BLOCK;
     const uint32_t pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * threads;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
@@ -136,19 +147,32 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
         if (spread) tile = tile * 3u / 2u / pass * pass;
         else if (fwrc_wide) tile = n_words == 2 ? tile * 3u / 2u / pass * pass : 512u;
         else if (canon_wide) tile = canon2_spread ? 768u : 512u;
-        else if (lone && a.tuples) tile *= 6u;
-        else if (lone && J > 1) tile = tile * 5u / 2u;  // (clamped to what the LDS stream holds below: 5120 kmers at J = 3)
+        else if ((lone || lone_striped) && a.tuples) tile *= 6u;
+        else if ((lone || lone_striped) && J > 1) tile = tile * 5u / 2u;  // (clamped to what the LDS stream holds below: 5120 kmers at J = 3)
     }
-    // The table is what round 3 measured on a handful of boxes; the region map of a box can be finer than an array (runs of one
+    // The table is what rounds 3-4 measured on a handful of boxes; the region map of an arena can be finer than an array (runs of one
     // 4 GiB granule), and there the table's shape lost 13 % to the base rule (headline 0.70 instead of 0.80, profiles/r04_shape.md).
-    // So the first large launch into a pair of arrays for which the table departs from the rule times both and remembers.
-    if ((spread || fwrc_wide || canon_wide || lone) && ctx->tile_kmers <= 0 && ctx->block_threads <= 0 && ctx->shape_calibrate > 0 && !ctx->calibrating &&
+    // So the first large SYNCHRONOUS launch into arrays of the ARENA for which the table departs from the rule times both and
+    // remembers -- per launch configuration and placement, not per pointer (context.hpp, shape_choice).  Blocks of the striped
+    // pool are placed well by construction and are never timed; nothing is ever timed inside a KMERS_ASYNC call.
+    const bool arena_placed = in_arena && !striped_a && (spread || fwrc_wide || canon_wide || lone);
+    if (arena_placed && ctx->tile_kmers <= 0 && ctx->block_threads <= 0 && ctx->shape_calibrate > 0 && !ctx->calibrating &&
         (uint64_t)a.n_kmers * out_bytes >= ((uint64_t)1 << 30)) {
-        const void *const kb = a.out_b ? (const void *)a.out_b : (const void *)a.out_starts;
+        const kmers_arena &ar = ctx->arena();
+        auto run_at = [&](const void *q) -> uint64_t {
+            const char *c = static_cast<const char *>(q);
+            if (!q || ar.run_start.empty() || c < ar.base || c >= ar.base + ar.bytes) return 0xffu;
+            return (uint64_t)kmers_arena_run_of(ar, (size_t)(c - ar.base)) & 0xffu;
+        };
+        uint64_t bucket = 0;  // log2 of the bytes written
+        for (uint64_t v = (uint64_t)a.n_kmers * out_bytes; v > 1; v >>= 1) ++bucket;
+        const uint64_t key = (uint64_t)MODE | (uint64_t)n_words << 4 | (uint64_t)(a.tuples ? 1 : 0) << 8 | (uint64_t)(a.out_b ? 1 : 0) << 9 |
+                             (uint64_t)(a.out_starts ? 1 : 0) << 10 | (uint64_t)(src_bits & 15) << 11 | (uint64_t)(dst_bits & 15) << 15 |
+                             (uint64_t)std::min<uint32_t>(J, 255u) << 19 | bucket << 27 | run_at(a.out_a) << 35 | run_at(second) << 43;
         const kmers_ctx::shape_choice *hit = nullptr;
         for (const auto &c : ctx->shape_cache)
-            if (c.a == (const void *)a.out_a && c.b == kb && c.n_kmers == a.n_kmers) hit = &c;
-        if (!hit) {
+            if (c.key == key) hit = &c;
+        if (!hit && !(ctx->call_flags & KMERS_ASYNC)) {
             const uint32_t rule_pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * (uint32_t)BLOCK;
             const int cand[2][2] = {{(int)threads, (int)std::max<uint32_t>(pass, tile / pass * pass)},
                                     {BLOCK, (int)default_tile(out_bytes, rule_pass)}};
@@ -159,6 +183,7 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
             for (auto &e : ctx->cal_events)
                 if (!e) HIP_TRY(ctx, hipEventCreate(&e));
             ctx->calibrating = true;
+            ++ctx->calibrations;
             int rc = KMERS_OK;
             const int64_t split_saved = ctx->split_order;
             static const int order[8] = {0, 1, 0, 1, 1, 0, 0, 1};  // (the first two: warm-up)
@@ -184,23 +209,29 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
             ctx->calibrating = false;
             if (rc != KMERS_OK) return rc == KMERS_E_HIP ? fail(ctx, KMERS_E_HIP, "launch-shape calibration") : rc;
             const int best = ms[1] < 0.97f * ms[0] ? 1 : 0;
-            if (ctx->shape_cache.size() >= 16) ctx->shape_cache.erase(ctx->shape_cache.begin());
-            ctx->shape_cache.push_back({(const void *)a.out_a, kb, a.n_kmers, cand[best][0], cand[best][1], best == 1, ms[0], ms[1]});
+            if (ctx->shape_cache.size() >= 64) ctx->shape_cache.erase(ctx->shape_cache.begin());
+            ctx->shape_cache.push_back({key, cand[best][0], cand[best][1], best == 1, ms[0], ms[1]});
             hit = &ctx->shape_cache.back();
         }
-        threads = (uint32_t)hit->threads;
-        tile = (uint32_t)hit->tile;
-        if (hit->rule) lone = false;  // (one write window)
-        ctx->last_cal_table_ms = hit->table_ms;
-        ctx->last_cal_rule_ms = hit->rule_ms;
-        ctx->last_cal_rule = hit->rule ? 1 : 0;
+        if (hit) {
+            threads = (uint32_t)hit->threads;
+            tile = (uint32_t)hit->tile;
+            if (hit->rule) lone = false;  // (one write window)
+            ctx->last_cal_table_ms = hit->table_ms;
+            ctx->last_cal_rule_ms = hit->rule_ms;
+            ctx->last_cal_rule = hit->rule ? 1 : 0;
+        } else {
+            ctx->last_cal_table_ms = ctx->last_cal_rule_ms = 0.f;
+            ctx->last_cal_rule = 0;
+        }
     } else if (!ctx->calibrating) {
         ctx->last_cal_table_ms = ctx->last_cal_rule_ms = 0.f;
         ctx->last_cal_rule = 0;
     }
     // (strided launches in ONE class: round 2's 32 KiB tile lost to 16 KiB on every box of round 3, 0.70-0.74 against 0.73-0.76)
+    const uint32_t pass_now = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * threads;  // (the cache may have changed `threads`)
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);
-    tile = std::max<uint32_t>(pass, tile / pass * pass);
+    tile = std::max<uint32_t>(pass_now, tile / pass_now * pass_now);
     if ((uint64_t)(tile - 1) * J + 1 > (uint64_t)max_tile_symbols) return fail(ctx, KMERS_E_UNSUPPORTED, "stride too large for the tile kernel");
     a.tile_kmers = tile;
     a.n_tiles = (a.n_kmers + tile - 1) / tile;

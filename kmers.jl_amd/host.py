@@ -185,6 +185,39 @@ class Context:
         self.check(self.lib.kmers_arena_regions(self.handle, C.byref(base), C.byref(g), buf, 1024, C.byref(n)), "kmers_arena_regions")
         return base.value or 0, g.value, list(buf[:min(n.value, 1024)]) if g.value else []
 
+    # the device's striped pool (include/kmers_hip.h): where alloc() of 64 MiB or more comes from when no arena is attached
+    def pool_info(self):
+        """dict(held, in_use, n_classes, class_bytes, two_class_gbps, one_class_gbps) of the device's striped pool (kmers_pool_info)."""
+        h, u, n = C.c_size_t(), C.c_size_t(), C.c_int()
+        cb = (C.c_size_t * _capi.POOL_CLASSES)()
+        two, one = C.c_double(), C.c_double()
+        self.check(self.lib.kmers_pool_info(self.handle, C.byref(h), C.byref(u), C.byref(n), cb, C.byref(two), C.byref(one)), "kmers_pool_info")
+        return {"held": h.value, "in_use": u.value, "n_classes": n.value, "class_bytes": list(cb), "two_class_gbps": two.value, "one_class_gbps": one.value}
+
+    def pool_trim(self):
+        r = C.c_size_t()
+        self.check(self.lib.kmers_pool_trim(self.handle, C.byref(r)), "kmers_pool_trim")
+        return r.value
+
+    def pool_layout(self, ptr):
+        """(chunk bytes, [region class of every stripe]) of the pool block that holds `ptr`; an empty list if it is not one."""
+        g, n = C.c_size_t(), C.c_size_t()
+        self.check(self.lib.kmers_pool_layout(self.handle, C.c_void_p(ptr), C.byref(g), None, 0, C.byref(n)), "kmers_pool_layout")
+        buf = (C.c_ubyte * max(n.value, 1))()
+        self.check(self.lib.kmers_pool_layout(self.handle, C.c_void_p(ptr), C.byref(g), buf, n.value, C.byref(n)), "kmers_pool_layout")
+        return g.value, list(buf[:n.value])
+
+    def pool_selftest(self):
+        """kmers_pool_selftest: raises on failure; returns whether a stale translation was seen without the pool's flush."""
+        st = C.c_int()
+        self.check(self.lib.kmers_pool_selftest(self.handle, C.byref(st)), "kmers_pool_selftest")
+        return bool(st.value)
+
+    def shape_calibrations(self):
+        n = C.c_uint64()
+        self.check(self.lib.kmers_shape_calibrations(self.handle, C.byref(n)), "kmers_shape_calibrations")
+        return n.value
+
     def placement_probe(self, ptr_a, ptr_b, nbytes):
         """GB/s of two store streams side by side into two (still empty) device buffers; DESTRUCTIVE (kmers_placement_probe)."""
         g = C.c_double()

@@ -13,7 +13,9 @@ alloc (where the output arrays come from -- profiles/r02_tuning.md section 7, pr
   plain       torch allocations (hipMalloc), first allocations of the process
   carve:GB    carved out of one torch allocation of GB gigabytes
   prefree:GB  GB gigabytes allocated and released first, then plain
-  arena:GB    kmers_arena_reserve(GB) + kmers_dev_alloc (the product's arena)
+  arena:GB    kmers_arena_reserve(GB) + kmers_dev_alloc (the arena of rounds 3-4)
+  pool        kmers_dev_alloc without an arena: the device's striped pool (round 5, the product's default)
+  pool:src    ... the source sequence from the pool as well
 --once: two launches and nothing else (the form the PMC passes profile).
 Prints one line: leg, alloc, median ms, fraction of 8 TB/s (materialising legs).
 """
@@ -123,6 +125,17 @@ with torch.cuda.stream(stream):
                 print(f"straddle: b across the boundary at {g2 * gran >> 30} GiB", flush=True)
             print(f"straddle: boundary at {g * gran >> 30} GiB, a at {(pa - abase) / 2**30:.2f} GiB", flush=True)
         mode = "carve"
+    elif mode == "pool":
+        t0 = time.perf_counter()
+        pa = ctx.alloc(8 * words_a)
+        pb = ctx.alloc(8 * max(words_b, 1))
+        info = ctx.pool_info()
+        lay = lambda p: "".join("ABCD?"[c] for c in ctx.pool_layout(p)[1])
+        la, lb = lay(pa), lay(pb)
+        short = lambda t: t if len(t) <= 48 else t[:40] + "..." + t[-5:]
+        print(f"pool: {time.perf_counter() - t0:.2f} s; held {info['held'] / 2**30:.1f} GiB, in use {info['in_use'] / 2**30:.1f}, classes {info['n_classes']} "
+              f"{[round(b / 2**30, 1) for b in info['class_bytes']]} GiB, probes two-class {info['two_class_gbps']:.0f} one-class {info['one_class_gbps']:.0f} GB/s; "
+              f"a {short(la)} b {short(lb)}", flush=True)
     elif mode == "arena":
         ctx.check(ctx.lib.kmers_arena_reserve(ctx.handle, size << 30), "kmers_arena_reserve")
         pa = ctx.alloc(8 * words_a, lone_output=(words_b == 0 and not args.no_role))  # the only output of its launch: by role
