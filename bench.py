@@ -24,9 +24,10 @@ the north-star input (`strong_scaling` in the line: K steps of 10 Gbase over the
 max-over-ranks rule, then the same 10 Gbase on rank 0 alone, and the ratio of the two) so that the contract's plain
 `--gpus N` command yields the fixed-input speedup as well.
 
-Memory: the buffers come from the product's arena (kmers_arena_reserve + kmers_dev_alloc, include/kmers_hip.h) -- what a Julia
-or C host gets from the library -- not from an allocate-and-release trick of the bench (round 2); `--alloc plain` uses torch
-allocations instead, and `roofline.plain_alloc` reports the same launch into plain allocations made BEFORE the arena.
+Memory: the buffers come from the library's allocator (kmers_dev_alloc, include/kmers_hip.h) -- what a Julia or C host gets:
+by default the device's CLASS POOL (round 5: 1 GiB handles of HIP's virtual-memory management, each block assembled by HBM
+region class; no reservation), with `--alloc arena` the reservation of rounds 3-4 (kmers_arena_reserve, `--arena-gb`), with
+`--alloc plain` torch allocations; `roofline.plain_alloc` reports the same launch into plain allocations made before either.
 """
 import argparse
 import ctypes as C
@@ -86,8 +87,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-shape-calibration", action="store_true", help="KMERS_PARAM_SHAPE_CALIBRATE = 0 (profiling runs: one kernel shape per trace row)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic / VALU issue shares with rocprofv3 --pmc child runs")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
-    ap.add_argument("--alloc", choices=("arena", "plain"), default="arena",
-                    help="arena: buffers from kmers_arena_reserve + kmers_dev_alloc (the product's allocator); plain: torch allocations")
+    ap.add_argument("--alloc", choices=("pool", "arena", "plain"), default="pool",
+                    help="pool: buffers from kmers_dev_alloc, served by the device's class pool (the product's default); arena: "
+                         "kmers_arena_reserve(--arena-gb) + kmers_dev_alloc (rounds 3-4); plain: torch allocations")
     ap.add_argument("--arena-gb", type=float, default=230.0,
                     help="size of the arena in GB: an explicit amount (the 10 Gbase leg needs 165 GB of it; the PMC child processes take "
                          "theirs from what is left); 0 = three quarters of the free memory; a reservation that fails falls back to that")
@@ -137,18 +139,29 @@ def launch_ranks(args):
 
 
 # --------------------------------------------------------------------------------------------
-# device memory: the product's arena, viewed as torch tensors for the checks
+# device memory: the library's blocks, viewed as torch tensors for the checks
 class _RawDeviceArray:
     def __init__(self, ptr, n_words):
         self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i8", "data": (ptr, False), "version": 2, "strides": None}
 
 
 class Memory:
-    """Where the bench's buffers come from.  arena: ctx.alloc (kmers_dev_alloc, served by the context's arena) wrapped as
-    int64 torch tensors through __cuda_array_interface__; plain: torch.empty."""
+    """Where the bench's buffers come from.  use_arena (historical name: the LIBRARY's allocator, pool or arena): ctx.alloc
+    (kmers_dev_alloc) wrapped as int64 torch tensors through __cuda_array_interface__; else torch.empty."""
 
-    def __init__(self, ctx, dev, use_arena):
-        self.ctx, self.dev, self.use_arena, self.live = ctx, dev, use_arena, {}
+    def __init__(self, ctx, dev, use_arena, kind="arena"):
+        self.ctx, self.dev, self.use_arena, self.live, self.kind = ctx, dev, use_arena, {}, kind
+
+    def room(self):
+        """bytes a new block can still get"""
+        import torch
+        if self.use_arena and self.kind == "arena":
+            return self.ctx.arena_info()[2]
+        free = torch.cuda.mem_get_info(self.dev)[0]
+        if self.use_arena:
+            info = self.ctx.pool_info()
+            free += info["held"] - info["in_use"] - (info["n_classes"] << 30)
+        return free
 
     def empty(self, n_words, lone_output=False):
         """lone_output: the only output array of the launches that fill it (kmers_dev_alloc_role(KMERS_ALLOC_LONE_OUTPUT))."""
@@ -171,6 +184,16 @@ class Memory:
                 ptr = t.data_ptr()
                 del self.live[ptr]
                 self.ctx.free(ptr)
+
+
+def run_lengths(seq):
+    out = []
+    for c in seq:
+        if out and out[-1][0] == c:
+            out[-1][1] += 1
+        else:
+            out.append([c, 1])
+    return out
 
 
 def xor_fold(t):
@@ -533,12 +556,9 @@ def north_star_one_gpu(ctx, cap, stream, dev, mem, reps=7, L=NORTH_STAR_BASES):
     K = 31
     n = L - K + 1
     need = 8 * (2 * n + L // 16 + 2)
-    if mem.use_arena:
-        room = ctx.arena_info()[2]
-    else:
-        room = torch.cuda.mem_get_info(dev)[0]
+    room = mem.room()
     name = f"N1 north star: CanonicalDNAMers{{31}} + fx_hash, {L / 1e9:g} Gbase LongDNA{{4}}, one GPU, 16.5 B/kmer"
-    if room < need + (2 << 30):
+    if room < need + (6 << 30):
         return {name: {"skipped": f"needs {need / 1e9:.0f} GB of HBM, {room / 1e9:.0f} GB available"}}
     seed10 = GOLDEN ^ 10
     nw = (L * 4 + 63) // 64
@@ -585,9 +605,10 @@ def pmc_child(args):
         # the shape it picked goes to stdout for the parent
         n = L - K + 1
         N = cap.load().kmers_words_per_kmer(K, 2)
-        if args.alloc == "arena":
-            ctx.arena_reserve(0)
-            p_k = ctx.alloc(8 * n * N)
+        if args.alloc in ("arena", "pool"):
+            if args.alloc == "arena":
+                ctx.arena_reserve(0)
+            p_k = ctx.alloc(8 * n * N, lone_output=args.no_hash)
             p_h = None if args.no_hash else ctx.alloc(8 * n)
         else:
             out_k = torch.empty(n * N, dtype=torch.int64, device=dev)
@@ -767,9 +788,9 @@ class Leg:
         sh = self.sh = self.plan[env.rank]
         self.N = cap.load().kmers_words_per_kmer(args.k, 2)
         with torch.cuda.stream(env.stream):
-            # the two output arrays first and one right after the other: the arena places consecutive blocks where they are
-            # written fastest together (and the 80 GB arrays of the 10 Gbase legs find their room before the small block does)
-            self.out_k = mem.empty(sh.n_kmers * self.N)
+            # the two output arrays first and one right after the other: the library gives consecutive blocks different region
+            # classes (and in an arena the 80 GB arrays of the 10 Gbase legs find their room before the small block does)
+            self.out_k = mem.empty(sh.n_kmers * self.N, lone_output=args.no_hash)
             self.out_h = None if args.no_hash else mem.empty(sh.n_kmers)
             self.buf = mem.empty(sh.n_own_words + sh.halo_words + 2)
             self.buf.zero_()
@@ -1015,7 +1036,8 @@ def main():
     # hands the 128-byte ncclUniqueId around); under gloo (shared-device debugging, CPU tests) torch.distributed's
     transport = os.environ.get("KMERS_HALO_TRANSPORT", "native" if backend == "nccl" else "allgather")
     shared_device = grouped and backend != "nccl"  # (gloo debugging mode: the ranks share one device and its memory)
-    use_arena = args.alloc == "arena" and not shared_device
+    use_arena = args.alloc in ("arena", "pool") and not shared_device  # (the library's allocator: the class pool, or the arena of rounds 3-4)
+    use_pool = use_arena and args.alloc == "pool"
 
     env = Env()
     env.args, env.ctx, env.cap, env.dev, env.stream = args, ctx, cap, dev, stream
@@ -1038,7 +1060,7 @@ def main():
             leg0 = Leg(env, total_bases, seed)
             ms0 = busy_timed(ctx, stream, leg0.step, reps=7, busy_s=0.3)
             plain_alloc = {"kernel_ms": round(ms0, 4), "frac": round(bytes_per_kmer * leg0.sh.n_kmers / ms0 / 1e6 / HBM_PEAK_GBPS, 4),
-                           "what": "the headline launch into two torch (hipMalloc) allocations made before the arena was reserved; "
+                           "what": "the headline launch into two torch (hipMalloc) allocations made before the library's allocator was used; "
                                    "7 launches behind 0.3 s of the same launch, outside the timed region"}
             del leg0
             torch.cuda.empty_cache()
@@ -1046,7 +1068,7 @@ def main():
             plain_alloc = {"error": repr(e)}
     arena_gb, arena_map = 0.0, None
     write_ceiling = (HBM_PEAK_GBPS, "8 TB/s spec (no arena map in this run)")
-    if use_arena:
+    if use_arena and not use_pool:
         try:
             arena_gb = round(ctx.arena_reserve(int(args.arena_gb * 1e9)) / 1e9, 1)
         except Exception as e:  # noqa: BLE001  (a device with less free memory than the explicit size)
@@ -1064,7 +1086,7 @@ def main():
         if best_pair > 0:
             write_ceiling = (best_pair, f"kmers_arena_rates: best pair of places of this run's arena, two 1 GiB store streams side by side "
                                         f"({best_pair:.0f} GB/s; inside one region class {one_class:.0f} GB/s)")
-    mem = env.mem = Memory(ctx, dev, use_arena)
+    mem = env.mem = Memory(ctx, dev, use_arena, "pool" if use_pool else "arena")
     if grouped and transport == "native":
         if backend != "nccl":
             raise SystemExit("KMERS_HALO_TRANSPORT=native needs one GPU per rank (RCCL); the gloo mode shares a device")
@@ -1090,6 +1112,17 @@ def main():
 
     leg = Leg(env, total_bases, seed)
     sh, plan = leg.sh, leg.plan
+    pool_report = None
+    if use_pool:  # what the pool made of the two arrays, and the write ceiling ITS probes measured on this box
+        info = ctx.pool_info()
+        runs = lambda p: " ".join(f"{'ABCD?'[c]}{n}" for c, n in run_lengths(ctx.pool_layout(p)[1])) if p else None
+        pool_report = {"held_GB": round(info["held"] / 1e9, 1), "in_use_GB": round(info["in_use"] / 1e9, 1), "classes": info["n_classes"],
+                       "GB_per_class": [round(b / 1e9, 1) for b in info["class_bytes"]],
+                       "kmers_array": runs(leg.out_k.data_ptr()), "hashes_array": runs(leg.out_h.data_ptr() if leg.out_h is not None else 0),
+                       "what": "1 GiB handles of HIP virtual-memory management, class of each measured by the pool; arrays as runs of handles per class"}
+        if info["two_class_gbps"] > 0:
+            write_ceiling = (info["two_class_gbps"], f"kmers_pool_info: the fastest probe of this run's pool, two 1 GiB store streams side by side in two "
+                                                     f"region classes ({info['two_class_gbps']:.0f} GB/s; inside one class {info['one_class_gbps']:.0f} GB/s)")
 
     # Wake the device: after an idle gap (allocation, data generation, process start) this device runs its next ~10 ms
     # 10-25 % slower (profiles/r02_tuning.md section 1) and the first second of a fresh process 2 % slower than the ninety
@@ -1202,6 +1235,10 @@ def main():
         line = assemble_line(args, K, bits, world, strong, grouped, backend, transport, total_bases, [s.n_bases for s in plan], seed, elapsed,
                              per_rank, bytes_per_kmer, verified, use_arena, arena_gb, arena_map, write_ceiling, shape_report, plain_alloc,
                              fill_gbps, strong_extra)
+        if pool_report is not None:
+            line["config"]["alloc"] = "kmers_dev_alloc: the device's class pool (no reservation)"
+            line["config"]["pool"] = pool_report
+            ctx.pool_trim()  # (the profiled child processes below make pools of their own)
         rf = line["roofline"]
         # the PMC child passes, rank 0's device (the other ranks wait in the barrier at the end)
         pmc_args = argparse.Namespace(**vars(args))

@@ -129,9 +129,9 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
                                          * pointer: fresh arrays of a later call meet it again, kmers_dev_free forgets nothing.  Never inside a KMERS_ASYNC call
                                          * (the table's shape runs; a later synchronous call may calibrate), never for blocks of the striped pool (placed well by
                                          * construction) or plain allocations.  0: the table is trusted.  kmers_last_launch_shape tells. */
-#define KMERS_PARAM_POOL 14             /* 1 (default): without an arena, kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the device's striped pool
+#define KMERS_PARAM_POOL 14             /* 1 (default): without an arena, kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the device's class pool
                                          * (below); 0: plain hipMalloc */
-#define KMERS_PARAM_POOL_SEARCH_GIB 15  /* how far past a request the pool may grow in search of memory of a second region class (default 64); 0: never */
+#define KMERS_PARAM_POOL_SEARCH_GIB 15  /* how far past a request the pool may grow in search of memory of the classes it wants (default 64); 0: never */
 #define KMERS_PARAM_POOL_MAX_GIB 16     /* cap on the physical memory the pool holds (0, default: what the device has) */
 #define KMERS_PARAM_SUBTILES 7         /* strided tile kernels (kmers_spaced, kmers_minimizers): consecutive tiles per workgroup, the next one's source words in flight */
 int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
@@ -156,14 +156,17 @@ int kmers_shape_calibrations(kmers_ctx *ctx, uint64_t *count);
  * WHERE an array lies matters on MI355X: HBM behaves as three REGION CLASSES of physical memory; store streams that run side by
  * side inside one class share about 6.0-6.4 TB/s, streams in different classes reach 7.1-7.2 (profiles/r03_alloc.md,
  * profiles/r05_vmm.md).  A plain hipMalloc lies wherever the driver puts it -- usually inside one class.  So, by default, a
- * block of KMERS_POOL_MIN_BYTES or more comes from the device's STRIPED POOL: physical memory in 32 MiB handles of HIP's
- * virtual-memory management, each handle's class measured once when the pool grows (1 GiB at a time, about 3 ms of probes),
- * each block mapped from handles of ALTERNATING classes.  Every write window of every launch then spans both classes, whatever
- * the number of arrays, their roles or the launch shape; no reservation is needed.  The pool holds what was asked of it plus
- * what it had to walk past in search of a second class (KMERS_PARAM_POOL_SEARCH_GIB) until kmers_pool_trim or until the last
- * context of the device that used it is destroyed; 512 MiB per class found stay with the pool as the yardstick later units are
- * measured against.  One pool per device and process, shared by its contexts, thread-safe.
- * Smaller blocks, a device without virtual-memory management, or KMERS_PARAM_POOL = 0: plain hipMalloc. */
+ * block of KMERS_POOL_MIN_BYTES or more comes from the device's CLASS POOL: physical memory in 1 GiB handles of HIP's
+ * virtual-memory management, the class of each handle measured once when the pool takes it (about 1 ms of probes), each block
+ * mapped from handles chosen by class: a block differs from the block allocated before it (the most recent one that is still
+ * out) at every relative position -- allocate the arrays of one launch one after the other and they are written at the
+ * two-class rate; KMERS_ALLOC_LONE_OUTPUT gives a block whose second half differs from its first, for launches with one output
+ * (written through two windows half an array apart).  No reservation is needed and it does not matter how finely the classes
+ * are interleaved in a box's physical memory.  Blocks are whole handles (sizes round up to 1 GiB).  The pool holds what was
+ * asked of it plus what it had to walk past in search of the classes it wanted (KMERS_PARAM_POOL_SEARCH_GIB) until
+ * kmers_pool_trim or until the last context of the device that used it is destroyed; one handle per class found stays with the
+ * pool as the yardstick later handles are measured against.  One pool per device and process, shared by its contexts,
+ * thread-safe.  Smaller blocks, a device without virtual-memory management, or KMERS_PARAM_POOL = 0: plain hipMalloc. */
 int kmers_dev_alloc(kmers_ctx *ctx, size_t bytes, void **out);
 /* The same with a word about what the block is for, which the arena (below) uses for its placement; without an arena, or when
  * the preferred place is taken, exactly kmers_dev_alloc.
@@ -178,17 +181,17 @@ int kmers_dev_free(kmers_ctx *ctx, void *p);
 int kmers_memcpy_h2d(kmers_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
-#define KMERS_POOL_MIN_BYTES ((size_t)64 << 20)
+#define KMERS_POOL_MIN_BYTES ((size_t)1 << 30)
 #define KMERS_POOL_CLASSES 4
-/* The device's striped pool: physical bytes it holds, bytes in blocks that are out, region classes found so far, bytes held per
- * class (KMERS_POOL_CLASSES entries), and what its probes measured in GB/s of two store streams side by side (512 MiB each, the
- * shape of the stream kernels' outputs): the fastest probe (two classes; about 7100; 0 while only one class is known) and the
- * slowest (one class; about 6200).  The first is the write ceiling bench.py prices the materialising kernels against.  Any
+/* The device's class pool: physical bytes it holds, bytes in blocks that are out, region classes found so far, bytes held per
+ * class (KMERS_POOL_CLASSES entries), and what its probes measured in GB/s of two store streams side by side (1 GiB each, the
+ * shape of the stream kernels' outputs): the fastest probe (two classes; about 7200; 0 while only one class is known) and the
+ * slowest pair of the calibration (one class; about 6200).  The first is the write ceiling bench.py prices the materialising kernels against.  Any
  * output may be NULL; all zero before the first block. */
 int kmers_pool_info(kmers_ctx *ctx, size_t *held, size_t *in_use, int *n_classes, size_t *class_bytes, double *two_class_gbps, double *one_class_gbps);
-/* Return to the driver every 1 GiB unit of the pool none of whose chunks is in a block (everything, if no block is out). */
+/* Return to the driver every handle of the pool that is not part of a block (everything, yardsticks included, if no block is out). */
 int kmers_pool_trim(kmers_ctx *ctx, size_t *released);
-/* The stripes of the pool block that holds `block`: *n_chunks chunks of *chunk_bytes, chunk i in class classes[i]
+/* The handles of the pool block that holds `block`: *n_chunks chunks of *chunk_bytes, chunk i in class classes[i]
  * (KMERS_POOL_CLASSES = class unknown; at most `capacity` entries are written).  *n_chunks = 0: not a block of the pool. */
 int kmers_pool_layout(kmers_ctx *ctx, const void *block, size_t *chunk_bytes, unsigned char *classes, size_t capacity, size_t *n_chunks);
 /* The virtual-memory calls the pool relies on, checked on this box (csrc/pool_api.hip): KMERS_OK, or KMERS_E_HIP with the reason in

@@ -11,7 +11,7 @@
 
 #include "../../include/kmers_hip.h"
 #include "arena_placement.hpp"
-#include "stripe_pool.hpp"
+#include "class_pool.hpp"
 
 // The arena of ONE DEVICE (memory_api.hip): one block of HBM and its measured map, shared by every context of the process that
 // attaches to it with kmers_arena_reserve -- a second context on the device does not get a second three quarters of what is
@@ -25,7 +25,7 @@ struct kmers_device_arena {
     std::map<size_t, kmers_ctx *> owner;  // offset of a block in use -> the context that allocated it (its stream is what may still write it)
 };
 struct kmers_device_pool;  // pool_api.hip
-// What ONE DEVICE of the process holds for its contexts: the arena (memory_api.hip) and the striped pool (pool_api.hip).  `mu`
+// What ONE DEVICE of the process holds for its contexts: the arena (memory_api.hip) and the class pool (pool_api.hip).  `mu`
 // serialises attaching, reserving, growing and releasing on that device only (a reservation's probes take 0.3 s: other devices
 // are not held up by them); slots are never destroyed.
 struct kmers_device_slot {
@@ -61,8 +61,8 @@ struct kmers_ctx {
     int64_t batch_passes = 0;       // KMERS_PARAM_BATCH_PASSES (tests, tuning); 0 = default
     int64_t sketch_batch_lds = 0;   // KMERS_PARAM_SKETCH_BATCH_LDS (tuning); 0 = default
     kmers_device_arena *shared_arena = nullptr;  // the device's arena, if this context is attached to it (memory_api.hip)
-    bool uses_pool = false;        // this context has taken part in the device's striped pool (pool_api.hip): counted in its refs
-    int64_t pool_enable = 1;       // KMERS_PARAM_POOL: kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the striped pool (no arena attached)
+    bool uses_pool = false;        // this context has taken part in the device's class pool (pool_api.hip): counted in its refs
+    int64_t pool_enable = 1;       // KMERS_PARAM_POOL: kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the class pool (no arena attached)
     int64_t pool_search_gib = -1;  // KMERS_PARAM_POOL_SEARCH_GIB: how far past a request the pool may grow in search of a second class (-1: 64)
     int64_t pool_max_gib = 0;      // KMERS_PARAM_POOL_MAX_GIB: cap on what the pool holds (0: what the device has)
     int call_flags = KMERS_ASYNC;  // flags of the entry point that is running (the launcher must not block inside a KMERS_ASYNC call)
@@ -78,7 +78,7 @@ struct kmers_ctx {
     // The launcher's table (stream_launch.hpp) against its base rule, timed once per pair of output arrays (KMERS_PARAM_SHAPE_CALIBRATE):
     // what the first large launch into (a, b) measured, reused by every later launch into the same arrays
     // keyed by what decides the answer -- the launch (mode, element width, layout, stride, a size bucket) and the PLACEMENT of its
-    // arrays (runs of the arena / striped blocks of the pool) -- not by pointers: a host that allocates fresh arrays per call
+    // arrays (runs of the arena) -- not by pointers: a host that allocates fresh arrays per call
     // (the reference's collect) meets its earlier measurement again, and kmers_dev_free forgets nothing
     struct shape_choice {
         uint64_t key;
@@ -123,13 +123,15 @@ kmers_device_slot &device_slot(int device);
 // memory_api.hip: detach the context from its device's arena.  Its own blocks go back to the arena (`force`: context destruction)
 // or make the call fail with KMERS_E_BADARG; the last context out frees the block.
 int arena_detach(kmers_ctx *ctx, bool force);
-// pool_api.hip: a block of the device's striped pool (KMERS_E_UNSUPPORTED: no virtual-memory management here -- plain hipMalloc then);
-// free it if `p` is one (*handled); leave the pool (the last context out returns everything to the driver); the fraction of
-// neighbouring stripes of the block holding [p, p + bytes) that lie in different region classes (-1: not a block of the pool)
-int pool_alloc(kmers_ctx *ctx, size_t bytes, void **out);
+// pool_api.hip: a block of the device's class pool (KMERS_E_UNSUPPORTED: no virtual-memory management here -- plain hipMalloc then);
+// free it if `p` is one (*handled); leave the pool (the last context out returns everything to the driver).  For the launchers:
+// the fraction of 64 relative positions at which two arrays lie in different region classes / at which the two halves of one
+// array do (-1: not inside blocks of the pool).
+int pool_alloc(kmers_ctx *ctx, size_t bytes, int role, void **out);
 int pool_free(kmers_ctx *ctx, void *p, bool *handled);
 void pool_detach(kmers_ctx *ctx);
-float pool_alternation(kmers_ctx *ctx, const void *p, size_t bytes);
+float pool_arrays_differ(kmers_ctx *ctx, const void *a, size_t bytes_a, const void *b, size_t bytes_b);
+float pool_halves_differ(kmers_ctx *ctx, const void *a, size_t bytes);
 
 // grow-only device staging buffers owned by the context
 inline int ensure_stage(kmers_ctx *ctx, int slot, size_t bytes) {

@@ -387,9 +387,9 @@ int kmers_dev_alloc_role(kmers_ctx *ctx, size_t bytes, int role, void **out) {
             return KMERS_OK;
         }
     } else if (ctx->pool_enable > 0 && bytes >= KMERS_POOL_MIN_BYTES) {
-        // no arena: arrays of a launch come from the device's striped pool (pool_api.hip) -- every block made of physical chunks
-        // of alternating region classes, so the role does not matter
-        const int rc = pool_alloc(ctx, bytes, out);
+        // no arena: arrays of a launch come from the device's class pool (pool_api.hip) -- a block of physical chunks whose region
+        // classes differ from those of the block before it at every relative position (by role: the second half from the first)
+        const int rc = pool_alloc(ctx, bytes, role, out);
         if (rc != KMERS_E_UNSUPPORTED) return rc;
     }  // no arena and no pool, a small block, or no range of the arena fits: a plain allocation
     HIP_TRY(ctx, hipSetDevice(ctx->device));

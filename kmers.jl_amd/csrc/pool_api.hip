@@ -1,20 +1,21 @@
-// pool_api.hip -- the device's STRIPED POOL behind kmers_dev_alloc (include/kmers_hip.h, "device memory"): physical memory in
-// 32 MiB handles of HIP's virtual-memory management, every handle's HBM region class MEASURED once, every block assembled from
-// handles of alternating classes.  The pure logic (which chunks, in which order) is csrc/stripe_pool.hpp; the measurements behind
+// pool_api.hip -- the device's CLASS POOL behind kmers_dev_alloc (include/kmers_hip.h, "device memory"): physical memory in 1 GiB
+// handles of HIP's virtual-memory management, the HBM region class of every handle MEASURED once, every block assembled from
+// handles of the classes it should have.  The pure logic (which classes where) is csrc/class_pool.hpp; the measurements behind
 // the design are profiles/r05_vmm.md (tools/vmm_va.hip, vmm_stripes.hip, vmm_life.hip).
 //
 // What the reference does here: `collect(CanonicalDNAMers{31}(seq))` allocates one Vector per call (src/iterators/CanonicalKmers.jl:
 // 199-225 yields the elements; Base.collect makes the array).  On this device WHERE such an array lies is worth 15 % of the rate
-// it can be written at, and rounds 3-4 bought that with a reservation of most of HBM (the arena, memory_api.hip).  The pool needs
-// no reservation: it grows by 1 GiB units as blocks are asked for and holds what it was asked for (plus what it had to walk
-// past to find a second class, until kmers_pool_trim).
+// it can be written at, and rounds 3-4 bought that with a reservation of most of HBM (the arena, memory_api.hip) whose map had to
+// be coarse enough for whole arrays to fit its runs.  The pool needs no reservation and does not care how finely the classes are
+// interleaved in physical memory: it grows by one handle at a time as blocks are asked for and holds what it was asked for plus
+// what it had to walk past to find the classes it wanted (until kmers_pool_trim).
 //
 // Three properties of the VMM calls on this stack (ROCm 7.2, measured by tools/vmm_life.hip) shape the code:
-//   * hipMemMap takes whole handles (no offset): a stripe IS a handle.
+//   * hipMemMap takes whole handles (no offset).
 //   * A range that is unmapped and mapped again -- in place, or after hipMemAddressFree and a new reservation that returns the
 //     same address -- keeps its OLD translations in the device's TLB until something flushes it; a hipMalloc + hipFree does
 //     (the legacy unmap goes through KFD, which invalidates).  Every unmap here is followed by that flush, and every new block is
-//     checked: a tag written through the chunk's home mapping must be readable through the block.
+//     checked: a tag written through a chunk's home mapping must be readable through the block.
 //   * Physical memory returns to the driver only when the RESERVATION it was mapped under is freed (unmap + release alone keep it).
 #include <hip/hip_runtime.h>
 
@@ -36,16 +37,16 @@ struct kmers_device_pool {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipMemAllocationProp prop = {};
     hipMemAccessDesc access = {};
-    bool warm = false;
+    float same_ms = 0.f;  // a probe that takes this long or longer ran inside ONE class
     uint64_t tag = 0x6b6d657273000000ull;
     size_t n_probes = 0;
 };
 
 namespace {
 
-constexpr size_t HALF = UNIT_BYTES / 2;
-constexpr float SAME_CLASS = 0.89f;  // a probe at this fraction of the slowest probe's time or more ran inside ONE class (one class:
-                                     // 0.94-1.0 of the slowest, two classes: 0.84-0.85; profiles/r05_vmm.md)
+constexpr float SAME_CLASS = 0.93f;  // of the calibration's slowest pair (one class: 0.96-1.0 of it, two classes: 0.84-0.87; profiles/r05_vmm.md)
+constexpr size_t FLUSH_BYTES = (size_t)32 << 20;
+constexpr float GOOD_PLAN = 0.95f;  // the pool grows (within its search budget) until a block's plan is this good
 
 // two store streams, 8 KiB of each per workgroup, 16 bytes per lane: the shape of the stream kernels' outputs
 __global__ __launch_bounds__(256) void pool_probe_kernel(ulonglong2 *a, ulonglong2 *b) {
@@ -57,12 +58,12 @@ __global__ __launch_bounds__(256) void pool_probe_kernel(ulonglong2 *a, ulonglon
     }
 }
 
-// milliseconds of two streams of HALF bytes at a and b side by side, the best of three
+// milliseconds of two streams of one chunk each side by side, the best of three
 bool probe_ms(kmers_device_pool *P, char *a, char *b, float *out) {
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         if (hipEventRecord(P->e0, P->stream) != hipSuccess) return false;
-        hipLaunchKernelGGL(pool_probe_kernel, dim3((unsigned)(HALF / 8192)), dim3(256), 0, P->stream, reinterpret_cast<ulonglong2 *>(a),
+        hipLaunchKernelGGL(pool_probe_kernel, dim3((unsigned)(CHUNK_BYTES / 8192)), dim3(256), 0, P->stream, reinterpret_cast<ulonglong2 *>(a),
                            reinterpret_cast<ulonglong2 *>(b));
         float ms = 0.f;
         if (hipEventRecord(P->e1, P->stream) != hipSuccess || hipEventSynchronize(P->e1) != hipSuccess ||
@@ -78,162 +79,173 @@ bool probe_ms(kmers_device_pool *P, char *a, char *b, float *out) {
 // the device's TLB may hold translations of ranges that were just unmapped (header comment): the legacy allocation path flushes it
 void flush_tlb() {
     void *p = nullptr;
-    if (hipMalloc(&p, CHUNK_BYTES) == hipSuccess) (void)hipFree(p);
+    if (hipMalloc(&p, FLUSH_BYTES) == hipSuccess) (void)hipFree(p);
     else (void)hipGetLastError();
 }
 
-// one more unit: UNIT_CHUNKS handles, mapped side by side under a reservation of their own (the unit's home), each half
-// classified against the representatives.  false: the device has no more memory to give (nothing is left half-made).
-bool grow_unit(kmers_device_pool *P) {
-    State &s = P->s;
-    std::vector<hipMemGenericAllocationHandle_t> hs;
-    hs.reserve(UNIT_CHUNKS);
-    auto undo = [&](char *home, uint32_t mapped) {
-        for (uint32_t i = 0; i < mapped; ++i) (void)hipMemUnmap(home + (size_t)i * CHUNK_BYTES, CHUNK_BYTES);
-        for (auto h : hs) (void)hipMemRelease(h);
-        if (home) (void)hipMemAddressFree(home, UNIT_BYTES);
-        if (mapped) flush_tlb();
+bool reserve(void **va, size_t bytes) {
+    if (hipMemAddressReserve(va, bytes, CHUNK_BYTES, nullptr, 0) == hipSuccess) return true;
+    (void)hipGetLastError();
+    if (hipMemAddressReserve(va, bytes, 0, nullptr, 0) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
+// one more handle, mapped under a reservation of its own (its home); not yet in any free list.  false: the device has no
+// more memory to give (nothing is left half-made).
+bool create_chunk(kmers_device_pool *P, uint32_t *id) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, CHUNK_BYTES, &P->prop, 0) != hipSuccess) {
         (void)hipGetLastError();
-    };
-    for (uint32_t i = 0; i < UNIT_CHUNKS; ++i) {
-        hipMemGenericAllocationHandle_t h;
-        if (hipMemCreate(&h, CHUNK_BYTES, &P->prop, 0) != hipSuccess) {
-            undo(nullptr, 0);
-            return false;
-        }
-        hs.push_back(h);
-    }
-    void *home_v = nullptr;
-    if (hipMemAddressReserve(&home_v, UNIT_BYTES, CHUNK_BYTES, nullptr, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        if (hipMemAddressReserve(&home_v, UNIT_BYTES, 0, nullptr, 0) != hipSuccess) {
-            undo(nullptr, 0);
-            return false;
-        }
-    }
-    char *home = static_cast<char *>(home_v);
-    for (uint32_t i = 0; i < UNIT_CHUNKS; ++i)
-        if (hipMemMap(home + (size_t)i * CHUNK_BYTES, CHUNK_BYTES, 0, hs[i], 0) != hipSuccess) {
-            undo(home, i);
-            return false;
-        }
-    if (hipMemSetAccess(home, UNIT_BYTES, &P->access, 1) != hipSuccess) {
-        undo(home, UNIT_CHUNKS);
         return false;
     }
-    const uint32_t u = (uint32_t)s.units.size(), first = (uint32_t)s.chunks.size();
-    Unit unit;
-    unit.home = home;
-    unit.first_chunk = first;
-    s.units.push_back(unit);
-    for (uint32_t i = 0; i < UNIT_CHUNKS; ++i) {
-        Chunk c;
-        c.handle = hs[i];
-        c.unit = u;
-        s.chunks.push_back(c);
+    void *home = nullptr;
+    if (!reserve(&home, CHUNK_BYTES)) {
+        (void)hipMemRelease(h);
+        return false;
     }
-    s.held_bytes += UNIT_BYTES;
-    if (!P->warm) {  // the first launches of a process find the clocks idle
-        float t;
-        for (int i = 0; i < 3; ++i) (void)probe_ms(P, home, home + HALF, &t);
-        P->warm = true;
+    if (hipMemMap(home, CHUNK_BYTES, 0, h, 0) != hipSuccess || hipMemSetAccess(home, CHUNK_BYTES, &P->access, 1) != hipSuccess) {
+        (void)hipMemUnmap(home, CHUNK_BYTES);
+        (void)hipMemRelease(h);
+        (void)hipMemAddressFree(home, CHUNK_BYTES);
+        (void)hipGetLastError();
+        flush_tlb();
+        return false;
     }
-    // classify the two halves (a failed probe leaves them unknown: still usable memory)
-    const bool debug = std::getenv("KMERS_POOL_DEBUG") != nullptr;
-    char dbg[256];
-    int dbg_n = 0;
-    dbg[0] = 0;
-    for (uint32_t h = 0; h < 2; ++h) {
-        char *ptr = home + (size_t)h * HALF;
-        int label = -1;
-        bool missing = false;
-        if (s.n_classes == 0) {  // the very first half IS class A; the probe of the unit's two halves sets the scale
-            float t = 0.f;
-            if (probe_ms(P, home, home + HALF, &t)) {
-                s.slow_ms = s.fast_ms = t;
-                label = 0;
-                s.rep_ptr[0] = ptr;
-                s.rep_unit[0] = u;
-                s.rep_half[0] = h;
-                s.n_classes = 1;
-            }
-        } else {
-            for (int c = 0; c < s.n_classes && label < 0; ++c) {
-                float t = 0.f;
-                if (!probe_ms(P, ptr, s.rep_ptr[c], &t)) {
-                    missing = true;
-                    break;
-                }
-                if (t > 1.10f * s.slow_ms) {  // slower than anything so far: a hiccup, or the scale was set by a mixed unit -- ask again
-                    float t2 = 0.f;
-                    if (probe_ms(P, ptr, s.rep_ptr[c], &t2)) t = std::min(t, t2);
-                }
-                if (debug && dbg_n < 200) dbg_n += std::snprintf(dbg + dbg_n, sizeof dbg - (size_t)dbg_n, " %c%c:%.1f", h ? 'h' : 'l', 'A' + c, 1e3 * t);
-                s.slow_ms = std::max(s.slow_ms, t);
-                s.fast_ms = std::min(s.fast_ms, t);
-                if (t >= SAME_CLASS * s.slow_ms) label = c;
-            }
-            if (label < 0 && !missing && s.n_classes < MAX_CLASSES) {  // fast beside every representative: a new class
-                label = s.n_classes++;
-                s.rep_ptr[label] = ptr;
-                s.rep_unit[label] = u;
-                s.rep_half[label] = h;
-            }
-        }
-        const uint8_t cls = label < 0 ? CLASS_UNKNOWN : (uint8_t)label;
-        const bool is_rep = label >= 0 && s.rep_ptr[label] == ptr;
-        for (uint32_t i = 0; i < UNIT_CHUNKS / 2; ++i) {
-            const uint32_t id = first + h * (UNIT_CHUNKS / 2) + i;
-            s.chunks[id].cls = cls;
-            s.chunks[id].rep = is_rep;
-        }
-        // into the free list, in DEscending order so that the list hands them out in creation order; a representative stays out:
-        // it is what later units are compared with, and the probes write into it
-        for (uint32_t i = UNIT_CHUNKS / 2; !is_rep && i-- > 0;) s.free_list[cls].push_back(first + h * (UNIT_CHUNKS / 2) + i);
-    }
-    if (debug)
-        std::fprintf(stderr, "pool unit %3u: %c %c  (slow %.1f us, fast %.1f us; probes%s)\n", u, 'A' + s.chunks[first].cls, 'A' + s.chunks[first + UNIT_CHUNKS / 2].cls,
-                     1e3 * s.slow_ms, 1e3 * s.fast_ms, dbg);
+    Chunk c;
+    c.handle = h;
+    c.home = static_cast<char *>(home);
+    *id = (uint32_t)P->s.chunks.size();
+    P->s.chunks.push_back(c);
+    P->s.held_bytes += CHUNK_BYTES;
     return true;
 }
 
-// give a unit's memory back to the driver (all of its chunks are free and out of the free lists)
-void release_unit(kmers_device_pool *P, uint32_t u) {
-    State &s = P->s;
-    Unit &unit = s.units[u];
-    for (uint32_t i = 0; i < UNIT_CHUNKS; ++i) {
-        (void)hipMemUnmap(unit.home + (size_t)i * CHUNK_BYTES, CHUNK_BYTES);
-        (void)hipMemRelease(static_cast<hipMemGenericAllocationHandle_t>(s.chunks[unit.first_chunk + i].handle));
-        s.chunks[unit.first_chunk + i].handle = nullptr;
-    }
-    (void)hipMemAddressFree(unit.home, UNIT_BYTES);
+// give a chunk's memory back to the driver (it is free and out of the free lists); the caller flushes
+void destroy_chunk(kmers_device_pool *P, uint32_t id) {
+    Chunk &c = P->s.chunks[id];
+    (void)hipMemUnmap(c.home, CHUNK_BYTES);
+    (void)hipMemRelease(static_cast<hipMemGenericAllocationHandle_t>(c.handle));
+    (void)hipMemAddressFree(c.home, CHUNK_BYTES);
     (void)hipGetLastError();
-    unit.released = true;
-    unit.home = nullptr;
-    s.held_bytes -= UNIT_BYTES;
+    c.handle = nullptr;
+    c.home = nullptr;
+    P->s.held_bytes -= CHUNK_BYTES;
 }
 
-// units without a chunk in use go back to the driver; `all`: the representatives too (the pool forgets its classes with them)
+void debug_chunk(const State &s, uint32_t id, const char *probes) {
+    if (std::getenv("KMERS_POOL_DEBUG"))
+        std::fprintf(stderr, "pool chunk %3u: %c%s  (one class %.1f us, fastest %.1f us;%s)\n", id, "ABCD?"[s.chunks[id].cls], s.chunks[id].rep ? " (representative)" : "",
+                     1e3 * s.slow_ms, 1e3 * s.fast_ms, probes);
+}
+
+// The first four handles: every pair probed.  With three classes two of the four share one, so the SLOWEST pair is two streams
+// inside one class: the scale every later probe is read against.
+bool calibrate(kmers_device_pool *P) {
+    State &s = P->s;
+    uint32_t id[4];
+    int made = 0;
+    for (; made < 4; ++made)
+        if (!create_chunk(P, &id[made])) break;
+    if (made < 4) {
+        for (int i = 0; i < made; ++i) destroy_chunk(P, id[i]);
+        s.chunks.clear();
+        if (made) flush_tlb();
+        return false;
+    }
+    float t[4][4] = {}, warm;
+    for (int i = 0; i < 3; ++i) (void)probe_ms(P, s.chunks[id[0]].home, s.chunks[id[1]].home, &warm);  // the first launches of a process find the clocks idle
+    float slow = 0.f, fast = 1e30f;
+    bool ok = true;
+    for (int i = 0; i < 4 && ok; ++i)
+        for (int j = i + 1; j < 4 && ok; ++j) {
+            ok = probe_ms(P, s.chunks[id[i]].home, s.chunks[id[j]].home, &t[i][j]);
+            slow = std::max(slow, t[i][j]);
+            fast = std::min(fast, t[i][j]);
+        }
+    if (!ok) {  // probes do not run: memory without classes (everything unknown), still a pool
+        for (int i = 0; i < 4; ++i) s.free_list[CLASS_UNKNOWN].push_back(id[i]);
+        s.slow_ms = s.fast_ms = 0.f;
+        P->same_ms = 1e30f;
+        return true;
+    }
+    s.slow_ms = slow;
+    s.fast_ms = fast;
+    P->same_ms = SAME_CLASS * slow;
+    for (int i = 0; i < 4; ++i) {
+        int label = -1;
+        for (int j = 0; j < i && label < 0; ++j)
+            if (t[j][i] >= P->same_ms) label = s.chunks[id[j]].cls;
+        Chunk &c = s.chunks[id[i]];
+        if (label < 0) {
+            label = s.n_classes++;
+            s.rep_chunk[label] = id[i];
+            c.rep = true;
+        }
+        c.cls = (uint8_t)label;
+        if (!c.rep) s.free_list[label].push_back(id[i]);
+        char buf[96];
+        int n = 0;
+        buf[0] = 0;
+        for (int j = 0; j < i; ++j) n += std::snprintf(buf + n, sizeof buf - (size_t)n, " %u:%.1f", id[j], 1e3 * t[j][i]);
+        debug_chunk(s, id[i], buf);
+    }
+    return true;
+}
+
+// one more chunk, classified against the representatives and put into its free list (a new class: it becomes the representative)
+bool grow(kmers_device_pool *P) {
+    State &s = P->s;
+    if (s.chunks.empty() || (s.n_classes == 0 && s.slow_ms == 0.f && P->same_ms == 0.f)) return calibrate(P);
+    uint32_t id;
+    if (!create_chunk(P, &id)) return false;
+    Chunk &c = s.chunks[id];
+    int label = -1;
+    bool failed = P->same_ms >= 1e29f;
+    char buf[128];
+    int n = 0;
+    buf[0] = 0;
+    for (int k = 0; k < s.n_classes && label < 0 && !failed; ++k) {
+        float t = 0.f;
+        if (!probe_ms(P, c.home, s.chunks[s.rep_chunk[k]].home, &t)) {
+            failed = true;
+            break;
+        }
+        n += std::snprintf(buf + n, sizeof buf - (size_t)n, " %c:%.1f", 'A' + k, 1e3 * t);
+        s.fast_ms = std::min(s.fast_ms, t);
+        if (t >= P->same_ms) label = k;
+    }
+    if (label < 0 && !failed && s.n_classes < MAX_CLASSES) {  // fast beside every representative: a new class, and its yardstick
+        label = s.n_classes++;
+        s.rep_chunk[label] = id;
+        c.rep = true;
+    }
+    c.cls = label < 0 ? CLASS_UNKNOWN : (uint8_t)label;
+    if (!c.rep) s.free_list[c.cls].push_back(id);
+    debug_chunk(s, id, buf);
+    return true;
+}
+
+// free chunks go back to the driver; `all`: the representatives too (the pool forgets its classes with them)
 size_t trim(kmers_device_pool *P, bool all) {
     State &s = P->s;
     size_t released = 0;
-    for (uint32_t u = 0; u < s.units.size(); ++u) {
-        Unit &unit = s.units[u];
-        if (unit.released || unit.in_use) continue;
-        bool holds_rep = false;
-        for (uint32_t i = 0; i < UNIT_CHUNKS; ++i) holds_rep |= s.chunks[unit.first_chunk + i].rep;
-        if (holds_rep && !all) continue;
-        for (auto &list : s.free_list)
-            list.erase(std::remove_if(list.begin(), list.end(), [&](uint32_t id) { return s.chunks[id].unit == u; }), list.end());
-        release_unit(P, u);
-        released += UNIT_BYTES;
+    for (auto &list : s.free_list) {
+        for (uint32_t id : list) {
+            destroy_chunk(P, id);
+            released += CHUNK_BYTES;
+        }
+        list.clear();
     }
-    if (all && s.held_bytes == 0) {  // nothing left: a later block starts a new pool (classes are measured again)
-        s.chunks.clear();
-        s.units.clear();
+    if (all && s.in_use_bytes == 0) {
+        for (int k = 0; k < s.n_classes; ++k) {
+            destroy_chunk(P, s.rep_chunk[k]);
+            released += CHUNK_BYTES;
+        }
+        s.chunks.clear();  // a later block starts a new pool (classes are measured again)
         s.n_classes = 0;
         s.slow_ms = s.fast_ms = 0.f;
-        for (auto &p : s.rep_ptr) p = nullptr;
+        P->same_ms = 0.f;
     }
     if (released) flush_tlb();
     return released;
@@ -275,9 +287,15 @@ kmers_device_pool *attach(kmers_ctx *ctx, kmers_device_slot &slot) {  // slot.mu
     return slot.pool;
 }
 
+bool room_for_a_chunk(const kmers_ctx *ctx, const State &s) {
+    const size_t max_held = ctx->pool_max_gib > 0 ? (size_t)ctx->pool_max_gib << 30 : ~(size_t)0;
+    size_t free_b = 0, total_b = 0;
+    return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= 2 * CHUNK_BYTES && s.held_bytes + CHUNK_BYTES <= max_held;
+}
+
 }  // namespace
 
-int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, void **out) {
+int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, int role, void **out) {
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     kmers_device_slot &slot = device_slot(ctx->device);
@@ -287,31 +305,25 @@ int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, void **out) {
     State &s = P->s;
     const size_t n = chunks_for(bytes);
     const size_t search_limit = ctx->pool_search_gib >= 0 ? (size_t)ctx->pool_search_gib << 30 : (size_t)64 << 30;
-    const size_t max_held = ctx->pool_max_gib > 0 ? (size_t)ctx->pool_max_gib << 30 : ~(size_t)0;
-    size_t searched = 0;
-    for (;;) {
-        size_t free_counts[N_LISTS], total = 0;
-        for (int i = 0; i < N_LISTS; ++i) total += free_counts[i] = s.free_list[i].size();
-        const bool enough = total >= n;
-        if (enough && (balanced(free_counts, n) || searched >= search_limit)) break;
-        size_t free_b = 0, total_b = 0;
-        const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= UNIT_BYTES + ((size_t)1 << 30) && s.held_bytes + UNIT_BYTES <= max_held;
-        if (!room || !grow_unit(P)) {
-            (void)hipGetLastError();
-            if (enough) break;
+    const Block *partner = role == ROLE_DEFAULT ? partner_block(s) : nullptr;
+    std::vector<uint8_t> seq;
+    for (size_t searched = 0;;) {
+        size_t free_counts[N_LISTS];
+        for (int i = 0; i < N_LISTS; ++i) free_counts[i] = s.free_list[i].size();
+        float quality = 0.f;
+        seq = plan(free_counts, bytes, partner, role, &quality);
+        if (!seq.empty() && (quality >= GOOD_PLAN || searched >= search_limit)) break;
+        if (!room_for_a_chunk(ctx, s) || !grow(P)) {
+            if (!seq.empty()) break;
             return fail(ctx, KMERS_E_NOMEM, "kmers_dev_alloc: the device has no memory left for the pool");
         }
-        if (enough) searched += UNIT_BYTES;
+        if (!seq.empty()) searched += CHUNK_BYTES;
     }
-    std::vector<uint32_t> ids = take(s, n);
-    if (ids.size() != n) return fail(ctx, KMERS_E_NOMEM, "kmers_dev_alloc: pool bookkeeping");
+    std::vector<uint32_t> ids = take(s, seq);
     void *va = nullptr;
-    if (hipMemAddressReserve(&va, n * CHUNK_BYTES, CHUNK_BYTES, nullptr, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        if (hipMemAddressReserve(&va, n * CHUNK_BYTES, 0, nullptr, 0) != hipSuccess) {
-            give(s, ids);
-            return fail(ctx, KMERS_E_NOMEM, "kmers_dev_alloc: hipMemAddressReserve");
-        }
+    if (!reserve(&va, n * CHUNK_BYTES)) {
+        give(s, ids);
+        return fail(ctx, KMERS_E_NOMEM, "kmers_dev_alloc: hipMemAddressReserve");
     }
     char *base = static_cast<char *>(va);
     hipError_t e = hipSuccess;
@@ -323,11 +335,9 @@ int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, void **out) {
     // the block must show the chunks it was made of: first and last chunk, a tag written through the home mapping
     for (int end = 0; end < 2 && e == hipSuccess; ++end) {
         const size_t k = end ? n - 1 : 0;
-        const Chunk &c = s.chunks[ids[k]];
-        char *home = s.units[c.unit].home + (size_t)(ids[k] - s.units[c.unit].first_chunk) * CHUNK_BYTES;
         const uint64_t tag = ++P->tag;
         uint64_t seen = 0;
-        e = hipMemcpy(home, &tag, 8, hipMemcpyHostToDevice);
+        e = hipMemcpy(s.chunks[ids[k]].home, &tag, 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(&seen, base + k * CHUNK_BYTES, 8, hipMemcpyDeviceToHost);
         if (e == hipSuccess && seen != tag) {  // a stale translation: flush and look again
             flush_tlb();
@@ -348,8 +358,10 @@ int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, void **out) {
     }
     Block b;
     b.bytes = n * CHUNK_BYTES;
-    b.alternation = alternation_of(s, ids);
+    b.req_bytes = bytes;
     b.chunks = std::move(ids);
+    b.classes = std::move(seq);
+    b.serial = ++s.serial;
     s.blocks[base] = std::move(b);
     *out = base;
     return KMERS_OK;
@@ -401,13 +413,18 @@ void kmers::pool_detach(kmers_ctx *ctx) {
     delete P;
 }
 
-float kmers::pool_alternation(kmers_ctx *ctx, const void *p, size_t bytes) {
-    if (!ctx->uses_pool || !p || !bytes) return -1.f;
+float kmers::pool_arrays_differ(kmers_ctx *ctx, const void *a, size_t bytes_a, const void *b, size_t bytes_b) {
+    if (!ctx->uses_pool) return -1.f;
     kmers_device_slot &slot = device_slot(ctx->device);
     std::lock_guard<std::mutex> lock(slot.mu);
-    if (!slot.pool) return -1.f;
-    const Block *b = block_of(slot.pool->s, p, bytes);
-    return b ? b->alternation : -1.f;
+    return slot.pool ? arrays_differ(slot.pool->s, a, bytes_a, b, bytes_b) : -1.f;
+}
+
+float kmers::pool_halves_differ(kmers_ctx *ctx, const void *a, size_t bytes) {
+    if (!ctx->uses_pool) return -1.f;
+    kmers_device_slot &slot = device_slot(ctx->device);
+    std::lock_guard<std::mutex> lock(slot.mu);
+    return slot.pool ? halves_differ(slot.pool->s, a, bytes) : -1.f;
 }
 
 extern "C" {
@@ -427,9 +444,10 @@ int kmers_pool_info(kmers_ctx *ctx, size_t *held, size_t *in_use, int *n_classes
                 for (const Chunk &ch : P->s.chunks) nb += ch.handle && ch.cls == c ? CHUNK_BYTES : 0;
             class_bytes[c] = nb;
         }
-    // GB/s of two store streams side by side, as the probes measured them (512 MiB each)
-    if (two_class_gbps) *two_class_gbps = P && P->s.n_classes >= 2 && P->s.fast_ms > 0.f ? 2.0 * (double)HALF / 1e6 / (double)P->s.fast_ms : 0.0;
-    if (one_class_gbps) *one_class_gbps = P && P->s.slow_ms > 0.f ? 2.0 * (double)HALF / 1e6 / (double)P->s.slow_ms : 0.0;
+    // GB/s of two store streams side by side, as the probes measured them (1 GiB each)
+    const bool two = P && P->s.n_classes >= 2 && P->s.fast_ms > 0.f;
+    if (two_class_gbps) *two_class_gbps = two ? 2.0 * (double)CHUNK_BYTES / 1e6 / (double)P->s.fast_ms : 0.0;
+    if (one_class_gbps) *one_class_gbps = P && P->s.slow_ms > 0.f ? 2.0 * (double)CHUNK_BYTES / 1e6 / (double)P->s.slow_ms : 0.0;
     return KMERS_OK;
 }
 
@@ -452,12 +470,11 @@ int kmers_pool_layout(kmers_ctx *ctx, const void *block, size_t *chunk_bytes, un
     kmers_device_slot &slot = device_slot(ctx->device);
     std::lock_guard<std::mutex> lock(slot.mu);
     if (!slot.pool) return KMERS_OK;
-    const char *base = nullptr;
-    const Block *b = block ? block_of(slot.pool->s, block, 1, &base) : nullptr;
+    const Block *b = block ? block_of(slot.pool->s, block, 1) : nullptr;
     if (!b) return KMERS_OK;
     if (n_chunks) *n_chunks = b->chunks.size();
     if (classes)
-        for (size_t i = 0; i < b->chunks.size() && i < capacity; ++i) classes[i] = slot.pool->s.chunks[b->chunks[i]].cls;
+        for (size_t i = 0; i < b->classes.size() && i < capacity; ++i) classes[i] = b->classes[i];
     return KMERS_OK;
 }
 
@@ -474,19 +491,24 @@ int kmers_pool_selftest(kmers_ctx *ctx, int *stale_without_flush) {
     kmers_device_pool *P = attach(ctx, slot);
     if (!P) return fail(ctx, KMERS_E_UNSUPPORTED, "no virtual-memory management on this device");
     State &s = P->s;
-    size_t total = 0;
-    for (auto &l : s.free_list) total += l.size();
-    if (total < 2 && !grow_unit(P)) return fail(ctx, KMERS_E_NOMEM, "kmers_pool_selftest: no memory");
-    std::vector<uint32_t> ids = take(s, 2);
+    auto n_free = [&] {
+        size_t total = 0;
+        for (auto &l : s.free_list) total += l.size();
+        return total;
+    };
+    while (n_free() < 2)
+        if (!room_for_a_chunk(ctx, s) || !grow(P)) return fail(ctx, KMERS_E_NOMEM, "kmers_pool_selftest: no memory");
+    size_t free_counts[N_LISTS];
+    for (int i = 0; i < N_LISTS; ++i) free_counts[i] = s.free_list[i].size();
+    std::vector<uint32_t> ids = take(s, plan(free_counts, 2 * CHUNK_BYTES, nullptr, ROLE_DEFAULT, nullptr));
     if (ids.size() != 2) return fail(ctx, KMERS_E_NOMEM, "kmers_pool_selftest: two free chunks");
-    auto home_of = [&](uint32_t id) { return s.units[s.chunks[id].unit].home + (size_t)(id - s.units[s.chunks[id].unit].first_chunk) * CHUNK_BYTES; };
     int rc = KMERS_OK;
     for (int with_flush = 0; with_flush < 2 && rc == KMERS_OK; ++with_flush) {
         uint64_t tags[2] = {++P->tag, ++P->tag}, seen[2] = {0, 0};
         void *va[2] = {nullptr, nullptr};
         hipError_t e = hipSuccess;
         for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-            e = hipMemcpy(home_of(ids[k]), &tags[k], 8, hipMemcpyHostToDevice);
+            e = hipMemcpy(s.chunks[ids[k]].home, &tags[k], 8, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemAddressReserve(&va[k], CHUNK_BYTES, CHUNK_BYTES, nullptr, 0);
             if (e == hipSuccess) e = hipMemMap(va[k], CHUNK_BYTES, 0, static_cast<hipMemGenericAllocationHandle_t>(s.chunks[ids[k]].handle), 0);
             if (e == hipSuccess) e = hipMemSetAccess(va[k], CHUNK_BYTES, &P->access, 1);

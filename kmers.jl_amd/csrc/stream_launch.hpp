@@ -113,26 +113,26 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     const void *const second = a.out_b ? (const void *)a.out_b : (const void *)a.out_starts;
     const size_t bytes_a = (size_t)a.n_kmers * 8u * (size_t)n_words;
     const size_t bytes_b = (size_t)a.n_kmers * (MODE == MODE_CANON || !a.out_b ? 8u : 8u * (size_t)n_words);
-    // Blocks of the striped pool (pool_api.hip) are well placed by construction: both region classes inside every write window.
-    constexpr float STRIPED = 0.9f;
-    const bool striped_a = materialises && a.out_a && pool_alternation(ctx, a.out_a, a.tuples ? (size_t)a.n_kmers * 8u : bytes_a) >= STRIPED;
-    const bool striped_pair = striped_a && second && pool_alternation(ctx, second, bytes_b) >= STRIPED;
+    // Blocks of the class pool (pool_api.hip) are assembled so that the arrays of a launch lie in different region classes at every
+    // relative position, and a lone output's second half in another class than its first: the same two questions the arena's map
+    // answers for its blocks.
+    constexpr float PLACED = 0.9f;
+    const bool pool_pair = materialises && a.out_a && second && pool_arrays_differ(ctx, a.out_a, bytes_a, second, bytes_b) >= PLACED;
     const bool in_arena = ctx->shared_arena != nullptr;
-    const bool spread = one_word_pair && (striped_pair || kmers_arena_spread(ctx->arena(), a.out_a, second, (size_t)a.n_kmers * 8u));
+    const bool spread = one_word_pair && (pool_pair || kmers_arena_spread(ctx->arena(), a.out_a, second, (size_t)a.n_kmers * 8u));
     const bool fwrc_wide = two_arrays && MODE == MODE_FW && n_words >= 2 && a.out_b &&
-                           (striped_pair || kmers_arena_spread(ctx->arena(), a.out_a, a.out_b, bytes_a));
+                           (pool_pair || kmers_arena_spread(ctx->arena(), a.out_a, a.out_b, bytes_a));
     const bool canon_wide = two_arrays && MODE == MODE_CANON && n_words >= 2 && a.out_b;
     const bool canon2_spread = canon_wide && n_words == 2 &&
-                               (striped_pair || kmers_arena_spread(ctx->arena(), a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u));
+                               (pool_pair || kmers_arena_spread(ctx->arena(), a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u));
     const uint32_t lone_bytes = a.tuples ? (MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u) : 8u * n_words;
-    // ONE output array: across a class boundary of the arena it is written through two windows; a striped block needs no
-    // second window (both classes are inside the one it has) but likes the same long tiles
-    const bool lone_output = materialises && a.out_a && !a.out_b && !a.out_starts;
-    const bool lone_striped = lone_output && striped_a && ctx->split_order >= 0;
-    bool lone = lone_output && !lone_striped && ctx->split_order >= 0 &&
-                kmers_arena_straddles(ctx->arena(), a.out_a, (size_t)a.n_kmers * lone_bytes);  // (the calibration below may overrule it)
+    // ONE output array whose two halves lie in different classes (across a class boundary of the arena, or a block of the pool
+    // made that way by role) is written through two windows half an array apart
+    const bool lone_output = materialises && a.out_a && !a.out_b && !a.out_starts && ctx->split_order >= 0;
+    const bool lone_pool = lone_output && pool_halves_differ(ctx, a.out_a, (size_t)a.n_kmers * lone_bytes) >= 0.75f;  // (whole handles: short arrays cannot do better)
+    bool lone = lone_pool || (lone_output && kmers_arena_straddles(ctx->arena(), a.out_a, (size_t)a.n_kmers * lone_bytes));  // (the calibration below may overrule it)
     uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads
-                                              : ((spread || canon_wide || ((lone || lone_striped) && !a.tuples && J == 1)) ? 128u : (uint32_t)BLOCK);
+                                              : ((spread || canon_wide || (lone && !a.tuples && J == 1)) ? 128u : (uint32_t)BLOCK);
     if (threads != 64u && threads != 128u) threads = (uint32_t)BLOCK;
     const uint32_t pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * threads;  // kmers per workgroup pass
     uint32_t out_bytes = 8u * n_words * ((a.out_a ? 1u : 0u) + (MODE == MODE_FW && a.out_b ? 1u : 0u)) +
@@ -147,15 +147,15 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
         if (spread) tile = tile * 3u / 2u / pass * pass;
         else if (fwrc_wide) tile = n_words == 2 ? tile * 3u / 2u / pass * pass : 512u;
         else if (canon_wide) tile = canon2_spread ? 768u : 512u;
-        else if ((lone || lone_striped) && a.tuples) tile *= 6u;
-        else if ((lone || lone_striped) && J > 1) tile = tile * 5u / 2u;  // (clamped to what the LDS stream holds below: 5120 kmers at J = 3)
+        else if (lone && a.tuples) tile *= 6u;
+        else if (lone && J > 1) tile = tile * 5u / 2u;  // (clamped to what the LDS stream holds below: 5120 kmers at J = 3)
     }
     // The table is what rounds 3-4 measured on a handful of boxes; the region map of an arena can be finer than an array (runs of one
     // 4 GiB granule), and there the table's shape lost 13 % to the base rule (headline 0.70 instead of 0.80, profiles/r04_shape.md).
     // So the first large SYNCHRONOUS launch into arrays of the ARENA for which the table departs from the rule times both and
-    // remembers -- per launch configuration and placement, not per pointer (context.hpp, shape_choice).  Blocks of the striped
-    // pool are placed well by construction and are never timed; nothing is ever timed inside a KMERS_ASYNC call.
-    const bool arena_placed = in_arena && !striped_a && (spread || fwrc_wide || canon_wide || lone);
+    // remembers -- per launch configuration and placement, not per pointer (context.hpp, shape_choice).  Blocks of the pool are
+    // placed well by construction and are never timed; nothing is ever timed inside a KMERS_ASYNC call.
+    const bool arena_placed = in_arena && !pool_pair && !lone_pool && (spread || fwrc_wide || canon_wide || lone);
     if (arena_placed && ctx->tile_kmers <= 0 && ctx->block_threads <= 0 && ctx->shape_calibrate > 0 && !ctx->calibrating &&
         (uint64_t)a.n_kmers * out_bytes >= ((uint64_t)1 << 30)) {
         const kmers_arena &ar = ctx->arena();

@@ -135,8 +135,8 @@ class Context:
 
     # device memory
     def alloc(self, nbytes, lone_output=False):
-        """kmers_dev_alloc_role: `lone_output` = the only output array of the launches that fill it (the arena places it across
-        a class boundary of HBM and such a launch writes it through two windows, include/kmers_hip.h)."""
+        """kmers_dev_alloc_role: `lone_output` = the only output array of the launches that fill it (its two halves are put into
+        different region classes of HBM and such a launch writes it through two windows, include/kmers_hip.h)."""
         p = C.c_void_p()
         role = _capi.ALLOC_LONE_OUTPUT if lone_output else _capi.ALLOC_DEFAULT
         self.check(self.lib.kmers_dev_alloc_role(self.handle, nbytes, role, C.byref(p)), "kmers_dev_alloc_role")
@@ -185,9 +185,9 @@ class Context:
         self.check(self.lib.kmers_arena_regions(self.handle, C.byref(base), C.byref(g), buf, 1024, C.byref(n)), "kmers_arena_regions")
         return base.value or 0, g.value, list(buf[:min(n.value, 1024)]) if g.value else []
 
-    # the device's striped pool (include/kmers_hip.h): where alloc() of 64 MiB or more comes from when no arena is attached
+    # the device's class pool (include/kmers_hip.h): where alloc() of 1 GiB or more comes from when no arena is attached
     def pool_info(self):
-        """dict(held, in_use, n_classes, class_bytes, two_class_gbps, one_class_gbps) of the device's striped pool (kmers_pool_info)."""
+        """dict(held, in_use, n_classes, class_bytes, two_class_gbps, one_class_gbps) of the device's class pool (kmers_pool_info)."""
         h, u, n = C.c_size_t(), C.c_size_t(), C.c_int()
         cb = (C.c_size_t * _capi.POOL_CLASSES)()
         two, one = C.c_double(), C.c_double()
@@ -200,7 +200,7 @@ class Context:
         return r.value
 
     def pool_layout(self, ptr):
-        """(chunk bytes, [region class of every stripe]) of the pool block that holds `ptr`; an empty list if it is not one."""
+        """(chunk bytes, [region class of every 1 GiB handle]) of the pool block that holds `ptr`; an empty list if it is not one."""
         g, n = C.c_size_t(), C.c_size_t()
         self.check(self.lib.kmers_pool_layout(self.handle, C.c_void_p(ptr), C.byref(g), None, 0, C.byref(n)), "kmers_pool_layout")
         buf = (C.c_ubyte * max(n.value, 1))()

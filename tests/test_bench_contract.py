@@ -57,7 +57,7 @@ def test_bench_never_nests_a_profiler(monkeypatch):
             monkeypatch.delenv(k, raising=False)
     assert bench.profiler_in_environment() is False
     args = bench.parse_args(["--steps", "1"])
-    assert args.alloc == "arena" and args.total_bases == 0 and args.strong_bases == -1 and args.gpus == 1
+    assert args.alloc == "pool" and args.total_bases == 0 and args.strong_bases == -1 and args.gpus == 1
     monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     assert bench.profiler_in_environment() is True
     traffic, why = bench.measure_traffic(args)

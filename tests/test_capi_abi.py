@@ -108,13 +108,14 @@ def test_arena_placement_logic_on_the_cpu(tmp_path):
     assert out.returncode == 0 and "arena placement ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
 
 
-def test_stripe_pool_logic_on_the_cpu(tmp_path):
-    """csrc/stripe_pool.hpp -- which chunks make up a block of the device's striped pool and in which order, pure host code --
-    under AddressSanitizer + UBSan: the water-filling over the classes' free lists, the order in which neighbours differ whenever
-    no class holds more than half, representatives handed out last, the books under random take / give."""
+def test_class_pool_logic_on_the_cpu(tmp_path):
+    """csrc/class_pool.hpp -- which region classes the chunks of a new block of the device's pool get, pure host code -- under
+    AddressSanitizer + UBSan: blocks as pure as the stock allows, the second array of a launch in another class than the first at
+    every relative position (an exact small transport problem, not a greedy walk), a lone output's halves in different classes,
+    the questions the launchers ask about arrays inside blocks, the books under take / give, 3000 random stocks and partners."""
     import subprocess
-    exe = tmp_path / "stripe_pool_check"
+    exe = tmp_path / "class_pool_check"
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                    "-I", os.path.join(ROOT, "kmers.jl_amd", "csrc"), "-o", str(exe), os.path.join(ROOT, "tests", "c", "stripe_pool_check.cpp")], check=True)
+                    "-I", os.path.join(ROOT, "kmers.jl_amd", "csrc"), "-o", str(exe), os.path.join(ROOT, "tests", "c", "class_pool_check.cpp")], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "stripe_pool_check: ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0 and "class_pool_check: ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])

@@ -14,8 +14,7 @@ alloc (where the output arrays come from -- profiles/r02_tuning.md section 7, pr
   carve:GB    carved out of one torch allocation of GB gigabytes
   prefree:GB  GB gigabytes allocated and released first, then plain
   arena:GB    kmers_arena_reserve(GB) + kmers_dev_alloc (the arena of rounds 3-4)
-  pool        kmers_dev_alloc without an arena: the device's striped pool (round 5, the product's default)
-  pool:src    ... the source sequence from the pool as well
+  pool        kmers_dev_alloc without an arena: the device's class pool (round 5, the product's default)
 --once: two launches and nothing else (the form the PMC passes profile).
 Prints one line: leg, alloc, median ms, fraction of 8 TB/s (materialising legs).
 """
@@ -127,7 +126,7 @@ with torch.cuda.stream(stream):
         mode = "carve"
     elif mode == "pool":
         t0 = time.perf_counter()
-        pa = ctx.alloc(8 * words_a)
+        pa = ctx.alloc(8 * words_a, lone_output=(words_b == 0 and not args.no_role))  # the only output of its launch: by role
         pb = ctx.alloc(8 * max(words_b, 1))
         info = ctx.pool_info()
         lay = lambda p: "".join("ABCD?"[c] for c in ctx.pool_layout(p)[1])
