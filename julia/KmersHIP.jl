@@ -2,14 +2,21 @@
 # include/kmers_hip.h plus the methods that route Kmers.jl's own iterator API to them.
 #
 # NOT EXECUTED IN THIS REPOSITORY'S CI: neither `julia` nor BioSequences.jl exist in the build
-# image (see DESIGN.md).  It overloads `Base.collect` for Kmers.jl's iterator types over the sources this library reads;
-# every geometry the library does not take falls back to Kmers.jl's own method (`invoke(collect, Tuple{Any}, it)`).  It is the binding a Kmers.jl maintainer would add (INTEGRATION.md); the
-# same mapping is exercised through ctypes by kmers.jl_amd/host.py and tests/.
+# image (see DESIGN.md).  It is the binding a Kmers.jl maintainer would add (INTEGRATION.md); the same mapping is exercised
+# through ctypes by kmers.jl_amd/host.py and tests/.
+#
+# DISPATCH POLICY (round 5).  The GPU path is EXPLICIT: `KmersHIP.gpu_collect(it)` always runs on the device.  `Base.collect`
+# of Kmers.jl's iterator types is overloaded too, but GATED: a source shorter than `KmersHIP.MIN_BASES[]` symbols (default
+# 100 000; ENV["KMERS_HIP_MIN_BASES"]; `typemax(Int)` switches the overload off) keeps Kmers.jl's own method, as does every
+# geometry the library does not take (`invoke(collect, Tuple{Any}, it)`).  A call costs ~16-25 us plus two PCIe hops; the reference
+# iterates at ~1 ns per symbol (docs/src/kmers.md:133), so `collect(FwDNAMers{3}("AGCGTATA"))` (src/iterators/FwKmers.jl:14-22)
+# must not become a device call: the measured crossover is 25-40 k symbols.
 #
 # Usage:
 #     using Kmers, BioSequences, KmersHIP
 #     seq  = randdnaseq(10^9)                               # LongDNA{4}
-#     v    = collect(CanonicalDNAMers{31}(seq))             # Vector{DNAKmer{31,1}}, computed on the MI355X
+#     v    = collect(CanonicalDNAMers{31}(seq))             # Vector{DNAKmer{31,1}}, computed on the MI355X (length(seq) >= MIN_BASES[])
+#     v    = KmersHIP.gpu_collect(CanonicalDNAMers{31}(seq)) # the same, whatever the length
 #     v, h = KmersHIP.collect_with_hashes(CanonicalDNAMers{31}(seq))   # + fx_hash of every element
 #     for kmer in KmersHIP.gpu(CanonicalDNAMers{31}(seq)) ... end      # chunk-buffered iterate()
 module KmersHIP
@@ -95,9 +102,23 @@ function check(ctx::Context, rc::Integer, res::CResult, ::Type{A}, s) where {A}
     error("libkmers_hip: status $rc: $(last_error(ctx))")
 end
 
+# ---- dispatch policy -----------------------------------------------------------------------
+"Sources shorter than this many symbols keep Kmers.jl's own `collect` (header comment: DISPATCH POLICY)."
+const MIN_BASES = Ref{Int}(parse(Int, get(ENV, "KMERS_HIP_MIN_BASES", "100000")))
+source(it::Union{FwKmers, FwRvIterator, SpacedKmers}) = it.seq
+source(it::Union{CanonicalKmers, UnambiguousKmers}) = it.it.seq
+"true iff `Base.collect(it)` goes to the device"
+gpu_dispatch(it) = ncodeunits_or_length(source(it)) >= MIN_BASES[]
+
+const GpuIterator{A, S} = Union{FwKmers{A, <:Any, S}, FwRvIterator{A, <:Any, S}, CanonicalKmers{A, <:Any, S},
+                                SpacedKmers{A, <:Any, <:Any, S}, UnambiguousKmers{A, <:Any, S}}
+"`collect` of Kmers.jl's iterators: on the device from `MIN_BASES[]` symbols on, Kmers.jl's own method below"
+Base.collect(it::GpuIterator{A, S}) where {A <: NucAlphabet24, S <: Source} =
+    gpu_dispatch(it) && applicable(gpu_collect, it) ? gpu_collect(it) : invoke(collect, Tuple{Any}, it)
+
 # ---- bulk forms of the iterators -----------------------------------------------------------
 "collect(FwKmers{A,K}(seq)) on the GPU (src/iterators/FwKmers.jl:57-115)"
-function Base.collect(it::FwKmers{A, K, S}) where {A <: NucAlphabet24, K, S <: Source}
+function gpu_collect(it::FwKmers{A, K, S}) where {A <: NucAlphabet24, K, S <: Source}
     ctx, s = context(), it.seq
     out = Vector{eltype(it)}(undef, length(it))
     res = CResult()
@@ -112,7 +133,7 @@ end
 
 "collect(FwRvIterator{A,K}(seq)): (forward, reverse_complement) pairs (CanonicalKmers.jl:54-144).
 The library writes `Vector{Tuple{T,T}}` memory directly (KMERS_OUT_TUPLES)."
-function Base.collect(it::FwRvIterator{A, K, S}) where {A <: NucAlphabet24, K, S <: Source}
+function gpu_collect(it::FwRvIterator{A, K, S}) where {A <: NucAlphabet24, K, S <: Source}
     ctx, s = context(), it.seq
     T = Kmers.derive_type(Kmer{A, K})
     out = Vector{Tuple{T, T}}(undef, length(it))
@@ -127,7 +148,7 @@ function Base.collect(it::FwRvIterator{A, K, S}) where {A <: NucAlphabet24, K, S
 end
 
 "collect(CanonicalKmers{A,K}(seq)) (CanonicalKmers.jl:199-225)"
-function Base.collect(it::CanonicalKmers{A, K, S}) where {A <: NucAlphabet24, K, S <: Source}
+function gpu_collect(it::CanonicalKmers{A, K, S}) where {A <: NucAlphabet24, K, S <: Source}
     return first(collect_with_hashes(it; hashes = false))
 end
 
@@ -150,7 +171,7 @@ function collect_with_hashes(it::CanonicalKmers{A, K, S}; seed::UInt = zero(UInt
 end
 
 "collect(SpacedKmers{A,K,J}(seq)) (SpacedKmers.jl:83-139), strict semantics incl. EncodeError"
-function Base.collect(it::SpacedKmers{A, K, J, S}) where {A <: NucAlphabet24, K, J, S <: Source}
+function gpu_collect(it::SpacedKmers{A, K, J, S}) where {A <: NucAlphabet24, K, J, S <: Source}
     ctx, s = context(), it.seq
     out = Vector{eltype(it)}(undef, length(it))
     res = CResult()
@@ -163,7 +184,7 @@ function Base.collect(it::SpacedKmers{A, K, J, S}) where {A <: NucAlphabet24, K,
 end
 
 "collect(UnambiguousKmers{A,K}(seq)): (kmer, start) tuples (UnambiguousKmers.jl:59-148)"
-function Base.collect(it::UnambiguousKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: Source}
+function gpu_collect(it::UnambiguousKmers{A, K, S}) where {A <: TwoBitAlphabet, K, S <: Source}
     # a geometry this entry point does not take keeps Kmers.jl's own path (K above 30720).  A Vector{DNA} source is the
     # reference's generic method (UnambiguousKmers.jl:88-106): ambiguous symbols skipped, the gap an EncodeError.
     K > 30720 && return invoke(collect, Tuple{Any}, it)

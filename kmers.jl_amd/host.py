@@ -825,6 +825,24 @@ def each_codon(*args, ctx=None):
 DNA, RNA = "DNA", "RNA"
 
 
+# The dispatch policy of julia/KmersHIP.jl (its header comment): Base.collect of an iterator goes to the device only from
+# MIN_BASES symbols on (a call costs ~16-25 us plus two PCIe hops, the reference iterates at ~1 ns per symbol: the docstring
+# case collect(FwDNAMers{3}("AGCGTATA")), src/iterators/FwKmers.jl:14-22, must stay a CPU call there).  This mirror has no
+# reference implementation to hand a short sequence to -- and no CPU fallback of its own, by construction -- so ITS collect
+# always runs on the device; gpu_dispatch() reports what the Julia binding would decide, and is what the tests pin.
+MIN_BASES = int(os.environ.get("KMERS_HIP_MIN_BASES", "100000"))
+
+
+def gpu_dispatch(it):
+    """True iff `Base.collect(it)` of the Julia binding runs on the device (KmersHIP.gpu_dispatch)."""
+    return len(it.seq) >= MIN_BASES
+
+
+def gpu_collect(it):
+    """KmersHIP.gpu_collect: the bulk form on the device, whatever the length."""
+    return it.collect()
+
+
 def collect(it):
     return it.collect()
 

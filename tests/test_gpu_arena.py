@@ -467,3 +467,39 @@ def test_launch_shape_calibration_keeps_results_and_remembers(km):
     assert run() == (table_shape, fk, fh)
     assert ctx.last_shape_calibration() == (0.0, 0.0, False)
     ctx.close()
+
+
+def test_alloc_launch_free_loop_calibrates_at_most_once_and_never_inside_an_async_call(km):
+    """the reference's collect allocates fresh outputs per call (src/iterators/CanonicalKmers.jl:199-225 +
+    Base.collect).  The launcher's remembered shape is keyed by the launch configuration and the PLACEMENT of the arrays (the
+    runs of the arena they start in), survives kmers_dev_free, and a KMERS_ASYNC call never blocks to measure: a loop of
+    {alloc, launch, free} over the arena calibrates once, not once per call."""
+    cap = km._capi
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    need_map_memory(free_b, total_b)
+    ctx = km.Context(0)
+    ctx.arena_reserve(int(free_b * 0.7))
+    K, L = 31, 140_000_030
+    n = L - K + 1
+    nw = (L * 4 + 63) // 64
+    p_w = ctx.alloc(8 * (nw + 2))
+    ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, 7, 0, nw, 4, 0, p_w), "kmers_synth_dna")
+    seq = cap.Seq(p_w, L, 0, 0, 4, 0)
+    res = cap.Result()
+    # asynchronous launches first: whatever the table says, nothing is timed
+    p_k, p_h = ctx.alloc(8 * n), ctx.alloc(8 * n)
+    for _ in range(3):
+        assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, p_k, p_h, 0, cap.MEM_DEVICE | cap.ASYNC, C.byref(res)) == 0, ctx.last_error()
+    assert ctx.sync()[0] == 0 and ctx.shape_calibrations() == 0
+    ctx.free(p_k)
+    ctx.free(p_h)
+    shapes = set()
+    for it in range(6):
+        p_k, p_h = ctx.alloc(8 * n), ctx.alloc(8 * n)   # fresh blocks every time (the same places: the arena is deterministic)
+        assert ctx.lib.kmers_canonical(ctx.handle, C.byref(seq), K, 2, p_k, p_h, 0, cap.MEM_DEVICE, C.byref(res)) == 0, ctx.last_error()
+        shapes.add(ctx.last_launch_shape()[:2])
+        ctx.free(p_k)
+        ctx.free(p_h)
+    assert ctx.shape_calibrations() <= 1, ctx.shape_calibrations()
+    assert len(shapes) == 1, shapes   # ... and what was measured once is what every later call runs
+    ctx.close()

@@ -399,3 +399,19 @@ def test_wide_kmers_through_the_mirror(km, orc):
     for r, got in zip(recs, sk):
         want = np.unique(orc.canonical(naive.ascii_words(r), len(r), 8, 2, K)[1])[:50] if len(r) >= K else np.zeros(0, np.uint64)
         assert np.array_equal(got, want)
+
+
+def test_dispatch_gate_of_the_binding(km, kats):
+    """VERDICT r4 (missing 4): the Julia binding's Base.collect goes to the device only from MIN_BASES symbols on
+    (julia/KmersHIP.jl, DISPATCH POLICY); the docstring case of src/iterators/FwKmers.jl:14-22 stays the reference's own CPU call.
+    The mirror pins the decision function; its explicit gpu_collect runs on the device whatever the length."""
+    from kmers_jl_amd import host
+    c = kats["G5_fw"]["cases"][0]
+    tiny = km.FwDNAMers[3](km.LongDNA[4](c["seq"]))
+    assert host.MIN_BASES == 100_000 and not host.gpu_dispatch(tiny)
+    assert texts(host.gpu_collect(tiny)) == c["kmers"]          # explicit: on the device even for eight symbols
+    rng = np.random.default_rng(3)
+    text = "".join(rng.choice(list("ACGT"), host.MIN_BASES))
+    assert host.gpu_dispatch(km.CanonicalDNAMers[31](km.LongDNA[4](text)))
+    assert not host.gpu_dispatch(km.CanonicalDNAMers[31](km.LongDNA[4](text[:-1])))
+    assert host.gpu_dispatch(km.SpacedDNAMers[21, 3](text)) and host.gpu_dispatch(km.UnambiguousDNAMers[31](km.LongDNA[4](text)))
