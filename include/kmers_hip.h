@@ -132,6 +132,7 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 #define KMERS_PARAM_POOL 14             /* 1 (default): without an arena, kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the device's class pool
                                          * (below); 0: plain hipMalloc */
 #define KMERS_PARAM_POOL_SEARCH_GIB 15  /* how far past a request the pool may grow in search of memory of the classes it wants (default 64); 0: never */
+#define KMERS_PARAM_BATCH_DENSE 17       /* A/B, tests.  -1: kmers_batch never takes its dense tile path (csrc/ragged_kernels.hpp); 0 (default): wherever a tile allows */
 #define KMERS_PARAM_POOL_MAX_GIB 16     /* cap on the physical memory the pool holds (0, default: what the device has) */
 #define KMERS_PARAM_SUBTILES 7         /* strided tile kernels (kmers_spaced, kmers_minimizers): consecutive tiles per workgroup, the next one's source words in flight */
 int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);

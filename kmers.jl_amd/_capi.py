@@ -21,7 +21,7 @@ BATCH_SKIP = 16
  OP_FROM_INTEGER) = range(9)
 PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY, PARAM_BATCH_PASSES, PARAM_SKETCH_BATCH_LDS, PARAM_SUBTILES, PARAM_ARENA_NO_PROBE, PARAM_SPLIT_ORDER, PARAM_BLOCK_THREADS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 PARAM_WIDE_NO_TILES, PARAM_HOST_CHUNKS, PARAM_SHAPE_CALIBRATE = 11, 12, 13
-PARAM_POOL, PARAM_POOL_SEARCH_GIB, PARAM_POOL_MAX_GIB = 14, 15, 16
+PARAM_POOL, PARAM_POOL_SEARCH_GIB, PARAM_POOL_MAX_GIB, PARAM_BATCH_DENSE = 14, 15, 16, 17
 POOL_MIN_BYTES, POOL_CLASSES = 1 << 30, 4
 ALLOC_DEFAULT, ALLOC_LONE_OUTPUT = 0, 1
 

@@ -160,8 +160,9 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     const uint32_t tile_elems = (uint32_t)((passes * RG_UNIT + RG_PASS - 1) / RG_PASS * RG_PASS);
     const uint64_t n_tiles = (total + tile_elems - 1) / tile_elems;
     const bool wide = nw > 4;  // kmers of more than four words: ragged_wide_kernel, one lane per element, no tiles
-    if (int rc = ensure_stage(ctx, 6, wide ? 16 : (size_t)n_tiles * sizeof(RaggedTile))) return rc;
+    if (int rc = ensure_stage(ctx, 6, wide ? 16 : (size_t)n_tiles * sizeof(RaggedTile) + (size_t)n_tiles + 16)) return rc;
     RaggedTile *d_tiles = static_cast<RaggedTile *>(ctx->stage[6]);
+    uint8_t *d_status = reinterpret_cast<uint8_t *>(d_tiles + n_tiles);  // one byte per tile: the optimistic launch below
 
     Staged st;
     if (int rc = stage_sequence(ctx, pool, flags, &st)) return rc;
@@ -187,12 +188,28 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     a.skip = (flags & KMERS_BATCH_SKIP) ? 1u : 0u;
     a.tile = tile_elems;
     a.stride = (uint32_t)stride;
+    a.dense = (int32_t)ctx->batch_dense;
     a.stream_origin = origin;
+    // One-word 2-bit kmers out of a 4-bit pool (LongDNA{4}, what BioSequences reads FASTA into): the OPTIMISTIC launch first --
+    // no recode pass, every tile recodes its own stretch and takes the dense path (ragged_kernels.hpp), the pool is read once.
+    // Tiles that could not (short or scattered records, a symbol that is not one-hot) count themselves; only then do the recode
+    // pass and the general launch run, for those tiles.  The skip mode needs the per-symbol flags: it goes the classic way.
+    const bool optimistic = !wide && sb == 4 && dst_bits == 2 && nw == 1 && stride == 1 && !(flags & KMERS_BATCH_SKIP) && ctx->batch_dense >= 0 &&
+                            tile_elems <= (uint32_t)(RG_MAX_PASSES * RG_UNIT);
+    unsigned long long *d_redo = reinterpret_cast<unsigned long long *>(ctx->d_scratch + 2);
     PoolStream ps;
-    if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;
-    a.stream = ps.stream;
-    a.flags = ps.flags;
-    a.any_flag = ps.any_flag;
+    if (!optimistic) {
+        if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;
+        a.stream = ps.stream;
+        a.flags = ps.flags;
+        a.any_flag = ps.any_flag;
+    } else {
+        a.src4 = src0;
+        a.tile_status = d_status;
+        a.redo_count = d_redo;
+        HIP_TRY(ctx, hipMemsetAsync(d_status, 0, (size_t)n_tiles, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(d_redo, 0, 8, ctx->stream));
+    }
 
     uint64_t *d_a = out_a, *d_b = out_b;
     const bool b_is_hash = mode == KMERS_BATCH_CANONICAL;
@@ -224,6 +241,27 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         } else {
             if (mode == KMERS_BATCH_FW) hipLaunchKernelGGL((ragged_wide_kernel<4, MODE_FW>), grid, block, 0, ctx->stream, a, nwu);
             else hipLaunchKernelGGL((ragged_wide_kernel<4, MODE_CANON>), grid, block, 0, ctx->stream, a, nwu);
+        }
+    } else if (optimistic && !vec) {  // unaligned outputs: no dense path to be optimistic about
+        if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;
+        a.stream = ps.stream;
+        a.flags = ps.flags;
+        a.any_flag = ps.any_flag;
+        a.src4 = nullptr;
+        a.tile_status = nullptr;
+        RGN(2);
+    } else if (optimistic) {
+        RGM(2, 1);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result + 2, d_redo, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_result[2]) {  // some tiles are left: the recode pass and the general launch for them
+            if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;
+            a.stream = ps.stream;
+            a.flags = ps.flags;
+            a.any_flag = ps.any_flag;
+            a.src4 = nullptr;
+            RGM(2, 1);
         }
     } else if (dst_bits == 2) RGN(2);
     else RGN(4);

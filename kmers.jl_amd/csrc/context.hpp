@@ -59,6 +59,7 @@ struct kmers_ctx {
     int n_cus = 256;                // multiProcessorCount
     bool sketch_host_only = false;  // KMERS_PARAM_SKETCH_HOST_ONLY: force the host-feedback MinHash path (tests)
     int64_t batch_passes = 0;       // KMERS_PARAM_BATCH_PASSES (tests, tuning); 0 = default
+    int64_t batch_dense = 0;        // KMERS_PARAM_BATCH_DENSE: -1 = kmers_batch never takes the dense tile path (A/B, tests)
     int64_t sketch_batch_lds = 0;   // KMERS_PARAM_SKETCH_BATCH_LDS (tuning); 0 = default
     kmers_device_arena *shared_arena = nullptr;  // the device's arena, if this context is attached to it (memory_api.hip)
     bool uses_pool = false;        // this context has taken part in the device's class pool (pool_api.hip): counted in its refs

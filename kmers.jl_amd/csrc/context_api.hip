@@ -149,6 +149,7 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value) {
     else if (param == KMERS_PARAM_POOL_MAX_GIB) ctx->pool_max_gib = value;
     else if (param == KMERS_PARAM_SKETCH_HOST_ONLY) ctx->sketch_host_only = value != 0;
     else if (param == KMERS_PARAM_BATCH_PASSES) ctx->batch_passes = value;
+    else if (param == KMERS_PARAM_BATCH_DENSE) ctx->batch_dense = value;
     else if (param == KMERS_PARAM_SKETCH_BATCH_LDS) ctx->sketch_batch_lds = value;
     else return fail(ctx, KMERS_E_BADARG, "unknown parameter");
     return KMERS_OK;

@@ -16,6 +16,9 @@
 //      window that covers a flagged symbol reports its element index (atomicMin): the smallest one is
 //      the first element the reference would have failed on, in record order, and its first flagged
 //      symbol the one it throws for.
+//   3b. (round 5) tiles of reads in pool order take the DENSE path of the same kernel (below): 32-bit tile-relative indices, the
+//      record of a run from a bitmap, two elements per lane and 16-byte stores side by side; from a 4-bit pool it runs FIRST and
+//      alone, recoding its own stretches (the optimistic launch, batch_api.hip), and step 1 happens only if a tile asks for it.
 #pragma once
 #include <type_traits>
 
@@ -30,6 +33,12 @@ constexpr int RG_RUN = KMERS_RG_RUN;     // consecutive elements per lane and pa
 constexpr int RG_UNIT = 1024;            // tile lengths are given in units of this many elements (KMERS_PARAM_BATCH_PASSES)
 constexpr int RG_PASS = 256 * RG_RUN;    // elements per workgroup and pass of the run path; a tile is a multiple of it, 1..RG_MAX_PASSES units
 constexpr int RG_MAX_PASSES = 8;
+#ifndef KMERS_RG_DENSE_RUN
+#define KMERS_RG_DENSE_RUN 2
+#endif
+constexpr int RG_DENSE_RUN = KMERS_RG_DENSE_RUN;  // the dense tile path: consecutive elements per lane and pass.  TWO: one 16-byte store per lane, array and pass, the
+                                         // lanes' stores side by side -- every store instruction writes 1 KiB of whole cache lines.  Four (32 contiguous bytes per
+                                         // lane, two half-line stores) writes at 5.4 TB/s with NO arithmetic at all (profiles/r05_batch.md)
 constexpr int RG_SLOTS = 448;            // records of a tile staged in LDS (more: the global-search path)
 constexpr int RG_STAGE = 1024;           // stream words of a tile staged in LDS (records in pool order: the usual case)
 
@@ -79,6 +88,14 @@ struct RaggedArgs {
     uint32_t skip;               // 1: elements whose window holds a flagged symbol are written as all-ones instead of failing
     uint32_t tile;               // output elements per workgroup: a multiple of RG_PASS
     uint32_t stride;             // symbols between the windows of a record: 1, or J of SpacedKmers{A,K,J} (forward kmers only)
+    int32_t dense;               // KMERS_PARAM_BATCH_DENSE: -1 = never take the dense tile path (A/B, tests)
+    // The OPTIMISTIC launch straight from a 4-bit pool (batch_api.hip): no recode pass has run, `stream` is NULL, every tile tries
+    // the dense path and recodes its stretch of `src4` itself (one verdict per word, device_bits.hpp); a tile that is not dense or
+    // meets a symbol that is not one-hot writes nothing, sets its status byte and counts itself.  If any did, the host runs the
+    // recode pass and launches again with `stream` set: tiles whose status is 0 are done and leave at once.
+    const uint64_t *src4;
+    uint8_t *tile_status;
+    unsigned long long *redo_count;
 };
 
 struct RecodeArgs {
@@ -241,12 +258,208 @@ __device__ __forceinline__ void window_words(Load load, uint32_t s, uint32_t k, 
     for (int i = 1; i < N; ++i) fw[i] = (R[i] >> sh) | ((R[i - 1] << 1) << (63u - sh));
 }
 
+// ---- the DENSE tile path (round 5; profiles/r05_batch.md) -----------------------------------------------------------------
+// ragged_kernel's general element loop costs 84 vector instructions per element on the bench's batch (8 M reads x 125 bases,
+// SQ_INSTS_VALU = 1.0e9 wave instructions for 760 M elements) at 5.2 cycles of a SIMD each: the launch is bound by instruction
+// issue (2.6 ms), not by its 12.2 GB of stores (1.75 ms at the two-class write rate).  What costs: 64-bit element and symbol
+// indices everywhere, a binary search per run, a second window cut in every wavefront (one lane in 24 crosses a record boundary,
+// so 87 % of the wavefronts pay for both cuts), the flag logic of pools that hold no flagged symbol, per-access "is it staged"
+// tests.  A tile is DENSE when none of that is needed: every record of it owns at least RG_DENSE_RUN elements (a run crosses at most one
+// boundary and no record is empty), its records lie inside the staged stretch of the stream, and no symbol of the pool is flagged.
+// Then, with every index relative to the tile and 32 bits wide:
+//   * the record of a run comes from a BITMAP of the run indices at which a record begins (one bit per run, set with LDS atomics
+//     from the staged offsets) and a prefix count per 64 runs: one broadcast read and a population count per run, no search;
+//   * every lane cuts its run's first window and rolls the rest (CanonicalKmers.jl:131-144); only a lane whose run crosses into
+//     the next record cuts that record's first window as well;
+//   * every run leaves with two 16-byte stores per array: the launch waits for its store instructions, not for their bytes.
+// Same results as the general path: tests/test_gpu_batch.py and the batch fuzz run both (KMERS_PARAM_BATCH_DENSE = -1 forces the
+// general path).
+template <int DST>
+__device__ __forceinline__ void dense_cut(const uint64_t *src_l, uint32_t p, uint32_t k, uint64_t mask, uint64_t &fw, uint64_t &rc, uint32_t &next_syms) {
+    const uint32_t bit = p * (uint32_t)DST, q = bit >> 6, sh = bit & 63u;
+    const uint64_t l0 = src_l[q], l1 = src_l[q + 1u], l2 = src_l[q + 2u];  // (the staged array is two words longer than the stretch)
+    const uint64_t W0 = funnel64(l0, l1, sh), W1 = funnel64(l1, l2, sh);
+    const uint64_t W = W0 & mask;
+    fw = rev_symbols<DST>(W) >> (64u - (uint32_t)DST * k);
+    rc = comp_symbols<DST>(W);
+    if constexpr (DST == 2) rc &= mask;
+    next_syms = (uint32_t)((uint32_t)DST * k == 64u ? W1 : funnel64(W0, W1, (uint32_t)DST * k));  // symbols K, K + 1, ... of the sub-run
+}
+template <int DST>
+__device__ __forceinline__ void dense_roll(uint64_t &fw, uint64_t &rc, uint32_t syms, uint32_t j, uint64_t mask, uint32_t top) {
+    const uint64_t sym = (syms >> ((uint32_t)DST * j)) & ((1u << DST) - 1u);  // the (j + 1)-th symbol after the first window
+    uint64_t csym;
+    if constexpr (DST == 2) csym = sym ^ 3u;
+    else csym = ((sym & 1u) << 3) | ((sym & 2u) << 1) | ((sym & 4u) >> 1) | ((sym & 8u) >> 3);
+    fw = ((fw << DST) | sym) & mask;       // shift_encoding, construction_utils.jl:129-134
+    rc = (rc >> DST) | (csym << top);      // shift_first_encoding of the complement, kmer.jl:511-518
+}
+template <int MODE>
+__device__ __forceinline__ void dense_finish(uint64_t fw, uint64_t rc, uint64_t seed_rot, uint64_t &x, uint64_t &y) {
+    if constexpr (MODE == MODE_FW) {
+        x = fw;
+        y = rc;
+    } else {
+        x = fw < rc ? fw : rc;             // CanonicalKmers.jl:220-225
+        y = (seed_rot ^ x) * FX_CONSTANT;  // fx_hash of one word, kmer.jl:255-261 (seed_rot = rotl(seed, 5))
+    }
+}
+
+struct DenseLds {                        // carved out of ragged_kernel's LDS arrays
+    uint64_t *slot;                      // [RG_SLOTS + 1]: low half = the record's first element relative to the tile (clamped to [0, 2^31)),
+                                         //   high half = first stream symbol of element 0 of the TILE if it belonged to this record, relative to the staged stretch
+    uint64_t *src;                       // [RG_STAGE + 2]
+    uint64_t *bits;                      // [RG_MAX_PASSES * RG_UNIT / RG_RUN / 64]: bit j: a record begins in run j or between run j - 1's first element and it
+    uint32_t *base;                      // [... + 1]: records that begin before the word's first run
+};
+
+// true: the tile was written.  false (uniformly): the tile is not dense, nothing was written, the general path must run.
+template <int DST, int MODE, bool FROM4>
+__device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const RaggedTile &d, uint64_t e0, uint32_t n_el, const DenseLds &L) {
+    constexpr uint32_t RUN = RG_DENSE_RUN, SPW = 64u / (uint32_t)DST;
+    const uint32_t tid = threadIdx.x, k = a.k, n_rec = d.n_slots;
+    const uint64_t mask = head_mask((int)k, DST);
+    const uint64_t sym0 = d.q_lo * SPW;                     // stream symbol at bit 0 of the staged stretch
+    const uint32_t staged_syms = d.n_words * SPW;
+    // ---- stage the record slots, the stream stretch; test the tile
+    uint32_t bad = (d.n_words == 0u || n_rec > (uint32_t)RG_SLOTS + 1u || n_rec < 2u) ? 1u : 0u;
+    // (the stretch of the stream first: its loads are in flight beside those of the record slots -- one round trip, not two)
+    if constexpr (FROM4) {
+        uint32_t *src32 = reinterpret_cast<uint32_t *>(L.src);
+        for (uint32_t i = tid; i < 2u * d.n_words; i += 256u) {
+            uint32_t any_bad;
+            src32[i] = pack_4to2_checked(a.src4[2u * d.q_lo + i], any_bad);   // FourToTwo, construction_utils.jl:47-52
+            bad |= any_bad ? 1u : 0u;                                         // (a symbol that is not one-hot: the general path finds which, and whether a window holds it)
+        }
+    } else {
+        for (uint32_t i = tid; i < d.n_words; i += 256u) L.src[i] = a.stream[d.q_lo + i];
+    }
+    if (tid < 2u) L.src[d.n_words + tid] = 0;
+    for (uint32_t i = tid; i < n_rec; i += 256u) {
+        const uint64_t rec = d.r_lo + (uint64_t)i;
+        const uint64_t o = a.rec_off[rec];
+        const bool real = rec < a.n_records;
+        const RaggedSpan sp = real ? a.spans[rec] : RaggedSpan{0, 0};
+        const uint32_t rel = o <= e0 ? 0u : (o - e0 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)(o - e0));
+        const uint32_t delta = (uint32_t)(sp.first_base + a.stream_origin + e0 - o - sym0);
+        L.slot[i] = (uint64_t)rel | ((uint64_t)delta << 32);
+        if (i + 1u == n_rec && rel < n_el) bad = 1u;        // more records than slots: the staged slice does not close the tile
+        if (i + 1u < n_rec && real) {                       // (the last slot only closes the search range)
+            const uint64_t o_next = a.rec_off[rec + 1];
+            const uint64_t lo_e = o > e0 ? o : e0, hi_e = o_next < e0 + n_el ? o_next : e0 + n_el;  // its elements inside the tile
+            if (o_next - o < (uint64_t)RUN) bad = 1u;       // a record that owns fewer than RUN elements (or none)
+            if (hi_e > lo_e) {                              // its windows must lie in the staged stretch (RUN - 1 symbols of slack for the roll)
+                const uint64_t first = sp.first_base + a.stream_origin + (lo_e - o), end = sp.first_base + a.stream_origin + (hi_e - 1u - o) + k;
+                if (first < sym0 || end > sym0 + staged_syms) bad = 1u;
+            }
+        }
+    }
+    constexpr uint32_t N_WORDS = RG_MAX_PASSES * RG_UNIT / RUN / 64;
+    static_assert(N_WORDS <= 64, "one wavefront scans the bitmap's words");
+    if (tid < N_WORDS) L.bits[tid] = 0;
+    lds_atomics_settle();
+    if (__syncthreads_or((int)bad)) return false;           // (also orders the staging before what follows)
+    // ---- the bitmap of record beginnings
+    uint32_t *bits32 = reinterpret_cast<uint32_t *>(L.bits);
+    for (uint32_t i = 1u + tid; i < n_rec; i += 256u) {
+        const uint32_t rel = (uint32_t)L.slot[i];
+        const uint32_t j = (rel + RUN - 1u) / RUN;          // the first run that starts at or behind the record's first element
+        if (rel > 0u && j * RUN < n_el) atomicOr(&bits32[j >> 5], 1u << (j & 31u));  // (a record that begins inside the LAST run needs no bit)
+    }
+    block_sync();
+    if (tid < 64u) {                                        // exclusive prefix of the words' population counts (one wavefront)
+        uint32_t c = tid < N_WORDS ? (uint32_t)__popcll(L.bits[tid]) : 0u, incl = c;
+#pragma unroll
+        for (uint32_t step = 1; step < 64u; step <<= 1) {
+            const uint32_t up = __shfl_up(incl, step, 64);
+            if (tid >= step) incl += up;
+        }
+        if (tid < N_WORDS) L.base[tid] = incl - c;
+    }
+    block_sync();
+    // ---- the runs
+    const uint32_t top = (uint32_t)DST * (k - 1u);
+    const uint64_t seed_rot = (a.seed << 5) | (a.seed >> 59);
+    for (uint32_t j = tid; j * RUN < n_el; j += 256u) {
+        const uint32_t e = j * RUN;
+        const uint64_t word = L.bits[j >> 6];               // (the same word for the whole wavefront)
+        const uint32_t lane = j & 63u;
+        const uint32_t r = L.base[j >> 6] + (uint32_t)__popcll(word & ((2ull << lane) - 1ull));  // records that begin at or before element e
+        const uint64_t s0 = L.slot[r], s1 = L.slot[r + 1u];
+        const uint32_t left_in_tile = n_el - e;
+        const uint32_t to_boundary = (uint32_t)s1 - e;      // > 0: slot r + 1 begins behind e
+        const uint32_t cnt = left_in_tile < RUN ? left_in_tile : RUN;
+        const uint32_t lenA = to_boundary < cnt ? to_boundary : cnt;
+        uint64_t fw, rc, X[RUN], Y[RUN];
+        uint32_t syms;
+#if defined(KMERS_RG_CUT) && KMERS_RG_CUT == 2  // diagnostic build: the stores and the lookups, no window arithmetic
+        for (uint32_t t = 0; t < RUN; ++t) {
+            X[t] = s0 + t;
+            Y[t] = s1 + lenA;
+        }
+        if (true) {
+            const uint64_t g2 = e0 + e;
+            for (uint32_t t = 0; t < RUN; t += 2) *reinterpret_cast<ulonglong2 *>(a.out_a + g2 + t) = make_ulonglong2(X[t], X[t + 1]);
+            for (uint32_t t = 0; t < RUN; t += 2) *reinterpret_cast<ulonglong2 *>(a.out_b + g2 + t) = make_ulonglong2(Y[t], Y[t + 1]);
+            continue;
+        }
+#endif
+        dense_cut<DST>(L.src, (uint32_t)(s0 >> 32) + e, k, mask, fw, rc, syms);
+        // a lane whose run crosses into the next record cuts that record's first window too (one lane in 24 at 95 kmers per read:
+        // most wavefronts run this once, for a few lanes) -- every lane then holds a whole run and stores it with 16-byte stores
+        // (a version that left the sub-runs to a list and stored them element by element had half the vector instructions of
+        // this one and was SLOWER: 2.4 times the store instructions, and those are what the launch waits for)
+        uint64_t fwB = 0, rcB = 0;
+        uint32_t symsB = 0;
+        if (lenA < cnt) dense_cut<DST>(L.src, (uint32_t)(s1 >> 32) + e + lenA, k, mask, fwB, rcB, symsB);
+        dense_finish<MODE>(fw, rc, seed_rot, X[0], Y[0]);
+#pragma unroll
+        for (uint32_t t = 1; t < RUN; ++t) {
+            if (t == lenA) {                                // the next record's first element
+                fw = fwB;
+                rc = rcB;
+                syms = symsB << ((uint32_t)DST * t);        // (its following symbols are indexed from t on below)
+            } else {
+                dense_roll<DST>(fw, rc, syms, t - 1u, mask, top);
+            }
+            dense_finish<MODE>(fw, rc, seed_rot, X[t], Y[t]);
+        }
+        const uint64_t g = e0 + e;
+#if defined(KMERS_RG_CUT) && KMERS_RG_CUT == 1  // diagnostic build: everything but the stores (profiles/r05_batch.md)
+        {
+            uint64_t all = 0;
+            for (uint32_t t = 0; t < RUN; ++t) all ^= X[t] ^ Y[t];
+            if (all != 0x0123456789abcdefull) continue;
+        }
+#endif
+        if (cnt == RUN) {
+            if (a.out_a) {
+#pragma unroll
+                for (uint32_t t = 0; t < RUN; t += 2) *reinterpret_cast<ulonglong2 *>(a.out_a + g + t) = make_ulonglong2(X[t], X[t + 1]);
+            }
+            if (a.out_b) {
+#pragma unroll
+                for (uint32_t t = 0; t < RUN; t += 2) *reinterpret_cast<ulonglong2 *>(a.out_b + g + t) = make_ulonglong2(Y[t], Y[t + 1]);
+            }
+        } else {                                            // the end of the batch inside the run
+#pragma unroll
+            for (uint32_t t = 0; t < RUN; ++t) {
+                if (t < cnt) {
+                    if (a.out_a) a.out_a[g + t] = X[t];
+                    if (a.out_b) a.out_b[g + t] = Y[t];
+                }
+            }
+        }
+    }
+    return true;
+}
+
 // VEC: out_a / out_b are 16-byte aligned (one-word kmers: RG_RUN elements per lane and pass, 16-byte stores)
 template <int DST, int N, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
     __shared__ uint64_t off_l[RG_SLOTS + 1];    // element offset of every record slot of the tile
     __shared__ uint64_t delta_l[RG_SLOTS + 1];  // first stream symbol of the slot's record minus offset * stride: window of element g = delta + g * stride
-    __shared__ uint64_t src_l[RG_STAGE];
+    __shared__ uint64_t src_l[RG_STAGE + 2];
     __shared__ uint64_t flg_l[RG_STAGE / 2 + 2];
     const uint32_t tid = threadIdx.x;
     const uint32_t k = a.k;
@@ -262,6 +475,35 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
     const RaggedTile d = a.tiles[tile];
     const uint64_t r_lo = d.r_lo;
     const uint64_t e_last = (e0 + a.tile < a.n_elems ? e0 + a.tile : a.n_elems) - 1;
+    if constexpr (N == 1 && VEC) {
+        // dense tiles (comment above ragged_dense_tile): one-word kmers, aligned outputs, consecutive windows, a pool without flagged symbols
+        if constexpr (DST == 2) {
+            if (a.src4) {  // the optimistic launch (RaggedArgs): dense or nothing
+                DenseLds L;
+                L.slot = off_l;
+                L.src = src_l;
+                L.bits = flg_l;
+                L.base = reinterpret_cast<uint32_t *>(flg_l + RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64);
+                const bool done = a.tile <= (uint32_t)(RG_MAX_PASSES * RG_UNIT) && ragged_dense_tile<DST, MODE, true>(a, d, e0, (uint32_t)(e_last - e0 + 1), L);
+                if (!done && tid == 0) {
+                    a.tile_status[tile] = 1;
+                    atomicAdd(a.redo_count, 1ull);
+                }
+                return;
+            }
+        }
+        if (a.tile_status && !a.tile_status[tile]) return;  // (the launch after an optimistic one: this tile is done)
+        if (a.stride == 1u && !flags && a.dense >= 0 && a.tile <= (uint32_t)(RG_MAX_PASSES * RG_UNIT)) {
+            static_assert(sizeof(flg_l) >= (RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64) * 12 + 16, "LDS carve");
+            DenseLds L;
+            L.slot = off_l;
+            L.src = src_l;
+            L.bits = flg_l;
+            L.base = reinterpret_cast<uint32_t *>(flg_l + RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64);
+            if (ragged_dense_tile<DST, MODE, false>(a, d, e0, (uint32_t)(e_last - e0 + 1), L)) return;
+            block_sync();  // (not dense: the general path below re-stages the tile)
+        }
+    }
     // Everything the tile reads is requested here, in ONE round of loads (a load takes about 5 us while the
     // device is saturated with the stores of the other workgroups: rounds are what a tile's time is made of).
     // Offsets and first symbols of the tile's records: r_lo .. the record that owns the next tile's first

@@ -514,3 +514,47 @@ def test_collect_batch_skip_ambiguous(km):
     assert list(rec1 == ones) == [False, True, True, True, True] + [False] * 4   # windows 2..5 cover the N
     assert (kmers.words[offs[2]:offs[3], 0] == ones).all() and offs[3] - offs[2] == 1
     assert not (kmers.words[offs[0]:offs[1], 0] == ones).any() and not (kmers.words[offs[3]:offs[4], 0] == ones).any()
+
+
+@pytest.mark.parametrize("src", [2, 4, 8])
+def test_batch_dense_tiles_equal_the_general_path_and_the_oracle(km, ctx, orc, src):
+    """The dense tile path of ragged_kernel (csrc/ragged_kernels.hpp: record lookup by bitmap, one window cut per run, sub-runs at
+    record boundaries from a list) against the oracle AND against the general path of the same library (KMERS_PARAM_BATCH_DENSE =
+    -1): reads long enough for every record to own RG_RUN elements, in pool order with and without filler between them, tile
+    lengths of 1, 3 and 8 passes, batches that end inside a run, and batches in which a short or empty record here and there sends
+    single tiles back to the general path."""
+    cap = km._capi
+    rng = np.random.default_rng(500 + src)
+    cases = []
+    for dst, K in ((2, 31), (2, 32), (2, 5), (4, 16), (4, 9)):
+        for n_rec, lo, hi, scatter, spoil in ((3000, K + 3, K + 4, False, 0), (2500, K + 3, 160, True, 0), (1800, 100, 400, False, 0),
+                                              (2500, K + 3, 160, False, 40), (40, 3000, 9000, True, 0), (1, 70000, 70001, False, 0)):
+            cases.append((dst, K, n_rec, lo, hi, scatter, spoil))
+    for dst, K, n_rec, lo, hi, scatter, spoil in cases:
+        lens = rng.integers(lo, hi, n_rec)
+        for i in rng.integers(0, n_rec, spoil):          # records that own fewer than four elements, or none
+            lens[i] = int(rng.choice([0, K - 1, K, K + 2]))
+        texts = [naive.random_text(rng, int(l)) for l in lens]
+        if src == 8:
+            texts = ["".join(c.lower() if rng.random() < 0.3 else c for c in t) for t in texts]
+        words, spans, n_pool = build_pool(texts, src, rng, scatter)
+        seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+        for mode in (cap.BATCH_FW, cap.BATCH_CANONICAL):
+            ea, eb, eoff = expected(orc, texts, src, dst, K, mode, 9)
+            total = int(eoff[-1])
+            got = {}
+            for dense in (0, -1):
+                ctx.set_param(cap.PARAM_BATCH_DENSE, dense)
+                ctx.set_param(cap.PARAM_BATCH_PASSES, int(rng.choice([0, 1, 3, 8])))
+                a = np.full((max(total, 1), 1), 0xAAAAAAAAAAAAAAAA, np.uint64)
+                b = np.full((max(total, 1), 1) if mode == cap.BATCH_FW else max(total, 1), 0xBBBBBBBBBBBBBBBB, np.uint64)
+                off = np.zeros(n_rec + 1, np.uint64)
+                res = cap.Result()
+                rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, n_rec, mode, K, dst, vp(a), vp(b), 9, vp(off), total, 0, C.byref(res))
+                tag = (src, dst, K, n_rec, lo, hi, scatter, spoil, mode, dense)
+                assert rc == 0 and res.n_out == total and np.array_equal(off, eoff), tag + (ctx.last_error(),)
+                assert np.array_equal(a[:total], ea) and np.array_equal(b[:total], eb), tag
+                got[dense] = (a, b)
+            assert np.array_equal(got[0][0], got[-1][0]) and np.array_equal(got[0][1], got[-1][1])
+    ctx.set_param(cap.PARAM_BATCH_DENSE, 0)
+    ctx.set_param(cap.PARAM_BATCH_PASSES, 0)
