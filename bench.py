@@ -487,6 +487,10 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
             out["e2e host pointers (H2D + kernel + D2H; never `value`)"] = host_pointer_path(ctx, cap, dev)
         except Exception as e:  # noqa: BLE001
             out["e2e host pointers (H2D + kernel + D2H; never `value`)"] = {"error": repr(e)}
+        try:
+            out["e2e host pointers, fused consumers (H2D + kernel; never `value`)"] = host_pointer_consumers(ctx, cap, dev)
+        except Exception as e:  # noqa: BLE001
+            out["e2e host pointers, fused consumers (H2D + kernel; never `value`)"] = {"error": repr(e)}
         # N1 (north star): CanonicalDNAMers{31} + fx_hash over 10 Gbase LongDNA{4} on ONE GPU: 5 GB in, 160 GB out
         out.update(north_star_one_gpu(ctx, cap, stream, dev, mem, reps))
     return out
@@ -545,6 +549,107 @@ def host_pointer_path(ctx, cap, dev, L=256_000_000, K=31):
             entry["chunked_frac_of_plain_d2h"] = round(entry["chunked"]["PCIe_GBps"] / d2h, 4)
             out[kind] = entry
             del ka, ha
+    finally:
+        ctx.free(dbuf)
+    return out
+
+
+def host_pointer_consumers(ctx, cap, dev, L=1_000_000_000):
+    """The callers that WIN from a host-memory start (missing 5): the fused consumers move 0.5-1 B/base up and almost
+    nothing down -- the reference's documented uses (test/benchmark.jl:9-15; MinHash over FASTA records, docs/src/minhash.md:31-41;
+    composition, docs/src/composition.md:28-39).  Each: kmers_* with KMERS_MEM_HOST over `L` symbols of a 4-bit LongSequence and of
+    ASCII text, from pageable and from pinned host memory, wall clock, best of three; beside it one plain hipMemcpy of the same
+    bytes from the same memory (the call cannot be faster than its input's trip), and the oracle's rate for the SAME consumer on
+    one host thread and on all of them (a bounded sample).  Never `value`."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import pyoracle
+    orc = pyoracle.Oracle(pyoracle.build(native=True))
+    res = cap.Result()
+    out = {"workload": f"{L / 1e9:g} Gbase in host memory -> one call -> a word / a sketch / a table back"}
+    nw4 = (L * 4 + 63) // 64
+    rng = np.random.default_rng(5)
+    src = {}
+    pinned4 = torch.empty(nw4 + 2, dtype=torch.int64, pin_memory=True)
+    w4 = pinned4.numpy().view(np.uint64)
+    CH = 1 << 24
+    for lo in range(0, nw4 + 1, CH):  # the synthetic sequence, in pieces (the oracle's generator is the library's)
+        hi = min(nw4 + 1, lo + CH)
+        w4[lo:hi] = orc.synth_words(GOLDEN ^ 22, lo, hi - lo, 4)
+    src["LongDNA{4}", "pinned"] = (w4, 4, pinned4)
+    src["LongDNA{4}", "pageable"] = (w4.copy(), 4, None)
+    pinned8 = torch.empty(L + 16, dtype=torch.uint8, pin_memory=True)
+    t8 = pinned8.numpy()
+    for lo in range(0, L, 1 << 27):
+        hi = min(L, lo + (1 << 27))
+        t8[lo:hi] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, hi - lo, dtype=np.uint8)]
+    src["ASCII text", "pinned"] = (t8, 8, pinned8)
+    src["ASCII text", "pageable"] = (t8.copy(), 8, None)
+    dbuf = ctx.alloc(L + 64)
+    sk = np.zeros(1000, np.uint64)
+    counts = np.zeros(4 ** 8, np.uint32)
+    val = C.c_uint64()
+    consumers = {
+        "reduce_xor CanonicalDNAMers{31}": lambda seq: ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), 31, 2, 1, C.byref(val), cap.MEM_HOST, C.byref(res)),
+        "minhash(fx_hash, CanonicalDNAMers{16}, 1000)": lambda seq: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), 16, 2, 0, 1000, sk.ctypes.data_as(C.c_void_p),
+                                                                                          cap.MEM_HOST, C.byref(res)),
+        "composition FwDNAMers{8}": lambda seq: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), 8, counts.ctypes.data_as(C.c_void_p), cap.MEM_HOST, C.byref(res)),
+    }
+    try:
+        for (what, kind), (arr, bits, _keep) in src.items():
+            nbytes = (L * bits + 7) // 8
+            seq = cap.Seq(arr.ctypes.data, L, 0, 0, bits, 0)
+            best = 1e9
+            for _ in range(3):  # the plain copy of the same bytes from the same memory
+                t0 = time.perf_counter()
+                ctx.check(ctx.lib.kmers_memcpy_h2d(ctx.handle, C.c_void_p(dbuf), arr.ctypes.data_as(C.c_void_p), nbytes), "kmers_memcpy_h2d")
+                best = min(best, time.perf_counter() - t0)
+            h2d = nbytes / best / 1e9
+            entry = {"bytes_up_GB": round(nbytes / 1e9, 3), "plain_h2d_copy_GBps": round(h2d, 2)}
+            for name, call in consumers.items():
+                best = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    rc = call(seq)
+                    best = min(best, time.perf_counter() - t0)
+                    assert rc == 0, ctx.last_error()
+                entry[name] = {"ms": round(best * 1e3, 2), "Gbases_per_s": round(L / best / 1e9, 2), "frac_of_plain_h2d": round(nbytes / best / 1e9 / h2d, 4)}
+            out[f"{what}, {kind} host memory"] = entry
+        # the same consumers on the host cores (the oracle: C restatement of the reference, -O3 -march=native), 16 Mbase per thread
+        S = 1 << 24
+        ws = orc.synth_words(GOLDEN ^ 22, 0, S // 16 + 1, 4)
+        ncpu = len(os.sched_getaffinity(0))
+
+        def xor_cpu(_i=0):
+            return orc.reduce_xor_canonical(ws, S, 4, 2, 31)[0]
+
+        def minhash_cpu(_i=0):  # sketch(fx_hash, CanonicalDNAMers{16}(seq), 1000), docs/src/minhash.md:31-35: hashes, then the 1000 smallest distinct
+            _, eh, _ = orc.canonical(ws, S, 4, 2, 16)
+            return np.unique(np.partition(eh, 4000)[:4000])[:1000]
+
+        def comp_cpu(_i=0):     # counts[as_integer(kmer) + 1] += 1 over FwDNAMers{8}, docs/src/composition.md:28-39
+            fw, _ = orc.fw_kmers(ws, S, 4, 2, 8)
+            return np.bincount(fw[:, 0].astype(np.int64), minlength=4 ** 8)
+        cpu = {}
+        for name, fn in (("reduce_xor CanonicalDNAMers{31}", xor_cpu), ("minhash(fx_hash, CanonicalDNAMers{16}, 1000)", minhash_cpu),
+                         ("composition FwDNAMers{8}", comp_cpu)):
+            t0 = time.perf_counter()
+            fn()
+            one = S / (time.perf_counter() - t0) / 1e9
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(ncpu) as ex:
+                list(ex.map(fn, range(ncpu)))
+            allc = ncpu * S / (time.perf_counter() - t0) / 1e9
+            cpu[name] = {"one_thread_Gbases_per_s": round(one, 3), "all_cores_Gbases_per_s": round(allc, 3), "cores": ncpu}
+        # the GPU's answers against the host's on the sample: XOR word, sketch, table
+        seq_s = cap.Seq(ws.ctypes.data, S, 0, 0, 4, 0)
+        ok = consumers["reduce_xor CanonicalDNAMers{31}"](seq_s) == 0 and val.value == xor_cpu()
+        ok &= consumers["minhash(fx_hash, CanonicalDNAMers{16}, 1000)"](seq_s) == 0 and bool(np.array_equal(sk, minhash_cpu()))
+        ok &= consumers["composition FwDNAMers{8}"](seq_s) == 0 and bool(np.array_equal(counts, comp_cpu().astype(np.uint32)))
+        out["cpu_port_same_consumers"] = dict(cpu, sample=f"{S >> 20} Mi-base of the same generator per thread, oracle (C restatement, gcc -O3 -march=native) + numpy for "
+                                                           "the sketch's selection and the table", verified_against_gpu=bool(ok))
     finally:
         ctx.free(dbuf)
     return out
@@ -831,6 +936,12 @@ class Leg:
         import numpy as np
         import torch
         env = self.env
+        if getattr(env.mem, "kind", "") == "arena" and env.mem.use_arena and not solo and env.world == 1:
+            # the arena's launcher may time its shape table against its base rule ONCE, in a synchronous call (never inside the
+            # asynchronous steps below: KMERS_PARAM_SHAPE_CALIBRATE); the pool's blocks need no such check
+            rc = env.ctx.lib.kmers_canonical(env.ctx.handle, C.byref(self.seq), env.args.k, 2, self.out_k.data_ptr(), self.ph, 0, env.cap.MEM_DEVICE,
+                                             C.byref(self.res))
+            assert rc == 0, env.ctx.last_error()
         for _ in range(warmup):
             self.step()
         rc, _ = env.ctx.sync()

@@ -118,6 +118,21 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
             }
         }
     };
+    // MinHash: a hash can only be a candidate if its HIGH half is at most the threshold's (for the bottom 1000 of a Gbase the
+    // threshold is about 2^44: one kmer in a million passes).  The high half of the last fx_hash step, ((rotl(h, 5) ^ w) * C) >> 32,
+    // is mul_hi(y_lo, C_lo) + y_lo * C_hi + y_hi * C_lo -- for kmers of at most 32 bits and seed 0 two multiplies and an add where
+    // the full product, the 64-bit compare and the test against the previous candidate took twice that (round 5; the full hash is
+    // computed for the survivors only, candidate() keeps the exact test).
+    const uint32_t thr_hi = (uint32_t)(threshold >> 32);
+    auto sketch_one = [&](const uint64_t (&c)[N]) {
+        uint64_t h = a.seed;
+#pragma unroll
+        for (int w = 0; w + 1 < N; ++w) h = fx_step(h, c[w]);
+        const uint64_t y = ((h << 5) | (h >> 59)) ^ c[N - 1];
+        const uint32_t ylo = (uint32_t)y, yhi = (uint32_t)(y >> 32);
+        const uint32_t hhi = __umulhi(ylo, (uint32_t)FX_CONSTANT) + ylo * (uint32_t)(FX_CONSTANT >> 32) + yhi * (uint32_t)FX_CONSTANT;
+        if (hhi <= thr_hi) candidate(y * FX_CONSTANT);
+    };
     // one kmer (N words, head first) and its reverse complement -> the consumer
     auto consume = [&](const uint64_t (&fw)[N], const uint64_t (&rc)[N]) {
         const bool lt = !CANON || kmer_less<N>(fw, rc);  // fw < rv ? fw : rv, CanonicalKmers.jl:220-225
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
 #pragma unroll
         for (int w = 0; w < N; ++w) c[w] = lt ? fw[w] : rc[w];
         if constexpr (RMODE == RMODE_XOR) xacc ^= c[0];            // the reducer of test/benchmark.jl:9-15: kmer.data[1]
-        else candidate(fx_hash<N>(c, a.seed));                      // kmer.jl:255-261
+        else sketch_one(c);                                         // kmer.jl:255-261
     };
 
 #ifdef KMERS_STAMPS  // diagnostic builds: where a wavefront of this kernel spends its life (tools/run_stamps.py)
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
                                 xacc_left_hi ^= c;
                             } else {
                                 const uint64_t cr[1] = {(uint64_t)(c >> up32)};
-                                candidate(fx_hash<1>(cr, a.seed));
+                                sketch_one(cr);
                             }
                         }
                     } else {
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
                                 xacc_left ^= c;
                             } else {
                                 const uint64_t cr[1] = {c >> up};
-                                candidate(fx_hash<1>(cr, a.seed));
+                                sketch_one(cr);
                             }
                         }
                     }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Files what `tools/evidence.sh` measured on the GPU box (gpurun_out/<round>ev/) under profiles/<round>_* (KMERS_ROUND, default r04):
+"""Files what `tools/evidence.sh` measured on the GPU box (gpurun_out/<round>ev/) under profiles/<round>_* (KMERS_ROUND, default r05):
 
   <round>_bench.json                 the driver's command, as printed
   <round>_bench_under_rocprof.json   the same program under rocprofv3 --kernel-trace --stats (its line) ...
@@ -19,12 +19,13 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = os.environ.get("KMERS_ROUND", "r04")
+RND = os.environ.get("KMERS_ROUND", "r05")
 E = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else RND + "ev")
 P = os.path.join(ROOT, "profiles")
 L = 1_000_000_000
 LEGS = {  # leg -> (label, kernel substring, algorithmic bytes per launch given the leg's printed line)
     "c2": ("C2 CanonicalDNAMers{31} + fx_hash, 1 Gbase LongDNA{4}", "stream_kernel<4, 2, 1, 1", lambda kept: 16.5 * (L - 30)),
+    "n1": ("N1 north star: CanonicalDNAMers{31} + fx_hash, 10 Gbase LongDNA{4}, ONE launch", "stream_kernel<4, 2, 1, 1", lambda kept: 16.5 * (10 * L - 30)),
     "c3": ("C3 CanonicalDNAMers{31}, 1.25 Gbase LongDNA{2}", "stream_kernel<2, 2, 1, 1", lambda kept: 8.25 * (1_250_000_000 - 30)),
     "c4": ("C4 FwDNAMers{63} + reverse complements", "stream_kernel<4, 2, 2, 0", lambda kept: 32.5 * (L - 62)),
     "c5": ("C5 strict SpacedDNAMers{21,3}", "stream_kernel<4, 2, 1, 0, false", lambda kept: 0.5 * L + 8.0 * ((L - 21) // 3 + 1)),
@@ -34,6 +35,12 @@ LEGS = {  # leg -> (label, kernel substring, algorithmic bytes per launch given 
     "xor": ("fused XOR-reduce of CanonicalDNAMers{31}", "run_kernel<4, 0", lambda kept: 0.0),
     "minhash": ("fused MinHash candidates, CanonicalDNAMers{16}, bottom 1000", "run_kernel<4, 1", lambda kept: 0.0),
     "f1": ("f1 CanonicalDNAMers{31} + fx_hash from ASCII text", "stream_kernel<8, 2, 1, 1", lambda kept: 17.0 * (L - 30)),
+    "f4h": ("f4 fx_hash over an array of 1 G one-word kmers", "fx_hash_kernel", lambda kept: 16.0 * L),
+    "f4r": ("f4 reverse_complement over an array of 1 G DNAKmer{31}", "transform_kernel", lambda kept: 16.0 * L),
+    "c63h": ("CanonicalDNAMers{63} + fx_hash (two-word kmers + hashes)", "stream_kernel<4, 2, 2, 1", lambda kept: 24.5 * (L - 62)),
+    "f127": ("FwDNAMers{127} + reverse complements (four-word kmers)", "stream_kernel<4, 2, 4, 0", lambda kept: 64.5 * (L - 126)),
+    "comp8": ("fused composition counts of FwDNAMers{8}", "composition_kernel", lambda kept: 0.0),
+    "batch": ("kmers_batch: 8 M reads x 125 bases, CanonicalDNAMers{31} + fx_hash per read (element kernel only)", "ragged_kernel", lambda kept: 16.0 * 8_000_000 * 95 + 0.5 * 1e9),
 }
 
 
@@ -63,7 +70,7 @@ def main():
             json.dump(d, open(os.path.join(P, RND + "_" + name), "w"), indent=1)
     copy(os.path.join(E, "kernel_stats.csv"), RND + "_kernel_stats.csv")
     bench = first_json_line(os.path.join(E, "bench.json")) or {}
-    rows = [f"# Round {RND[1:].lstrip('0')}: every leg in a rocprofv3 pass of its own (`tools/evidence.sh`, one MI355X, outputs from the context's arena)", "",
+    rows = [f"# Round {RND[1:].lstrip('0')}: every leg in a rocprofv3 pass of its own (`tools/evidence.sh`, one MI355X, outputs from the device's class pool)", "",
             f"`ms (rocprofv3)` = average duration of the leg's kernel in `profiles/{RND}_kernel_stats_<leg>.csv` (a `--kernel-trace --stats` pass over",
             "`tools/leg.py --leg <leg>`: warm-up launches + 20 timed ones); `ms (HIP events)` = the median the same process printed; fractions",
             "are of 8 TB/s on the algorithmic bytes of SURVEY.md 8(d).  HBM bytes: `FETCH_SIZE x 2` (gfx950: the counter reports half of a",
@@ -75,7 +82,7 @@ def main():
             continue
         kept, ev_ms = 0, None
         try:
-            last = [l for l in open(os.path.join(E, f"stats_{leg}.txt")) if l.startswith(leg)][-1]
+            last = [l for l in open(os.path.join(E, f"stats_{leg}.txt")) if l.startswith(leg) or l.startswith("kmers_batch")][-1]
             m = re.search(r"kept=(\d+)", last)
             kept = int(m.group(1)) if m else 0
             m = re.search(r": ([0-9.]+) ms", last)
@@ -105,6 +112,17 @@ def main():
             traffic = f"{tot / 1e9:.3f} GB / {alg / 1e9:.3f} GB = {tot / alg:.3f}"
         fr = lambda t: f"{alg / t / 1e6 / 8000:.3f}" if alg and t else "-"
         rows.append(f"| {label} | `{best['Name'][:70]}` | {best['Calls']} | {ms:.4f} | {fr(ms)} | {ev_ms if ev_ms else '-'} | {fr(ev_ms)} | {traffic} |")
+    # the headline launch by allocator
+    sweep = []
+    for f in sorted(glob.glob(os.path.join(E, "alloc_*.json"))):
+        d = first_json_line(f)
+        if d:
+            cfgd = d.get("config", {})
+            sweep.append(f"| {cfgd.get('alloc', '?')} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} | {d['value']} | "
+                         f"{(cfgd.get('pool') or {}).get('held_GB', '') or cfgd.get('arena_region_map') or ''} |")
+    if sweep:
+        rows += ["", "## The headline launch (C2, 1 Gbase) by where its arrays come from (`bench.py --alloc ...`, same box, one process each)", "",
+                 "| allocator | kernel ms | frac of 8 TB/s | Gbases/s | pool: GB held / arena: measured map |", "|---|---|---|---|---|"] + sweep
     open(os.path.join(P, RND + "_legs.md"), "w").write("\n".join(rows) + "\n")
     rf = bench.get("roofline", {})
     if rf.get("traffic") and "measured in this run" in rf.get("traffic_source", ""):

@@ -74,15 +74,17 @@ if args.no_calibrate:
     ctx.set_param(cap.PARAM_SHAPE_CALIBRATE, 0)
 
 leg = args.leg
+if leg == "n1":  # the north star: the C2 launch over 10 Gbase on one GPU
+    leg, args.bases = "c2", 10_000_000_000
 L = 1_250_000_000 if leg == "c3" else args.bases
 bits = 2 if leg == "c3" else 8 if leg == "f1" else 4
 amb = 2621 if leg in ("u31", "u21") else 0
 seed = {"c2": 2, "c3": 3, "c4": 4, "c4t": 4, "c5": 5, "u31": 5, "u21": 5}.get(leg, 5)
-K = {"f127": 127, "c63": 63, "c127h": 127, "c63h": 63, "f3": 31, "c2": 31, "f1": 31, "c3": 31, "c4": 63, "c4t": 63, "c5": 21, "u31": 31, "u21": 21, "xor": 31, "minhash": 16, "comp8": 8}[leg]
+K = {"f127": 127, "c63": 63, "c127h": 127, "c63h": 63, "f3": 31, "c2": 31, "f1": 31, "c3": 31, "c4": 63, "c4t": 63, "c5": 21, "u31": 31, "u21": 21, "xor": 31, "minhash": 16, "minhash31": 31, "comp8": 8, "comp4": 4, "comp6": 6, "f4h": 31, "f4r": 31}[leg]
 J = 3 if leg in ("c5", "u21") else 1
 n = (L - K) // J + 1
-words_a = {"f127": 4 * n, "c63": 2 * n, "c127h": 4 * n, "c63h": 2 * n, "f3": 2 * n, "c2": n, "f1": n, "c3": n, "c4": 2 * n, "c4t": 4 * n, "c5": n, "u31": n, "u21": n}.get(leg, 1 << 16)
-words_b = {"f127": 4 * n, "c127h": n, "c63h": n, "c2": n, "f1": n, "c4": 2 * n, "u31": n, "u21": n}.get(leg, 0)
+words_a = {"f4h": L, "f4r": L, "f127": 4 * n, "c63": 2 * n, "c127h": 4 * n, "c63h": 2 * n, "f3": 2 * n, "c2": n, "f1": n, "c3": n, "c4": 2 * n, "c4t": 4 * n, "c5": n, "u31": n, "u21": n}.get(leg, 1 << 16)
+words_b = {"f4h": L, "f4r": L, "f127": 4 * n, "c127h": n, "c63h": n, "c2": n, "f1": n, "c4": 2 * n, "u31": n, "u21": n}.get(leg, 0)
 
 mode, _, size = args.alloc.partition(":")
 size = int(size or 0)
@@ -175,8 +177,13 @@ calls = {
     "xor": lambda: ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), K, 2, 1, C.byref(val), cap.MEM_DEVICE, C.byref(res)),
     "minhash": lambda: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, 2, 0, 1000, sk.ctypes.data_as(C.c_void_p), cap.MEM_DEVICE, C.byref(res)),
     "comp8": lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), K, pa, cap.MEM_DEVICE, C.byref(res)),
+    "f4h": lambda: ctx.lib.kmers_fx_hash(ctx.handle, pa, 1, L, 0, pb, ASYNC),                        # fx_hash over an array of 1 G one-word kmers
+    "f4r": lambda: ctx.lib.kmers_transform(ctx.handle, cap.OP_REVCOMP, pa, K, 2, L, pb, ASYNC),       # reverse_complement over the same
+    "comp4": lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), K, pa, cap.MEM_DEVICE, C.byref(res)),
+    "comp6": lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), K, pa, cap.MEM_DEVICE, C.byref(res)),
+    "minhash31": lambda: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), K, 2, 0, 1000, sk.ctypes.data_as(C.c_void_p), cap.MEM_DEVICE, C.byref(res)),
 }
-alg = {"f127": 64.5 * n, "c63": 16.5 * n, "c127h": 40.5 * n, "c63h": 24.5 * n, "f3": 16.5 * n, "c2": 16.5 * n, "f1": 17.0 * n, "c3": 8.25 * n, "c4": 32.5 * n, "c4t": 32.5 * n, "c5": 0.5 * L + 8.0 * n,
+alg = {"f4h": 16.0 * L, "f4r": 16.0 * L, "f127": 64.5 * n, "c63": 16.5 * n, "c127h": 40.5 * n, "c63h": 24.5 * n, "f3": 16.5 * n, "c2": 16.5 * n, "f1": 17.0 * n, "c3": 8.25 * n, "c4": 32.5 * n, "c4t": 32.5 * n, "c5": 0.5 * L + 8.0 * n,
        "u31": 0.5 * L + 16.0 * m_kept, "u21": 0.5 * L + 16.0 * m_kept}.get(leg)
 
 
@@ -193,7 +200,7 @@ if args.once:
     fn()
     torch.cuda.synchronize()
     ctx.sync()
-    print(f"{leg} {args.alloc} once kept={m_kept}", flush=True)
+    print(f"{args.leg} {args.alloc} once kept={m_kept}", flush=True)
     sys.exit(0)
 
 if args.shifts:
@@ -235,4 +242,4 @@ med = float(np.median(ts))
 frac = f"frac {alg / med / 1e6 / 8000:.4f}" if alg else ""
 nosplit = " split" if args.split else ""
 shape = "x".join(str(v) for v in ctx.last_launch_shape())
-print(f"{leg:7s} {args.alloc:12s} shape {shape} tile {args.tile:5d} thr {args.threads:3d} sub {args.subtiles}{nosplit}: {med:.4f} ms (min {min(ts):.4f} max {max(ts):.4f}) {frac} kept={m_kept} a at {pa:#x}", flush=True)
+print(f"{args.leg:7s} {args.alloc:12s} shape {shape} tile {args.tile:5d} thr {args.threads:3d} sub {args.subtiles}{nosplit}: {med:.4f} ms (min {min(ts):.4f} max {max(ts):.4f}) {frac} kept={m_kept} a at {pa:#x}", flush=True)
