@@ -497,8 +497,27 @@ function Base.close(c::Comm)
     return nothing
 end
 
-# ---- device memory: the context's arena (include/kmers_hip.h, "device memory") -------------------------------------------
-"One large block of HBM per context (`bytes = 0`: three quarters of what is free), out of which `device_alloc` serves."
+# ---- device memory (include/kmers_hip.h, "device memory") ------------------------------------------------------------------
+# `device_alloc` of 1 GiB or more comes from the device's CLASS POOL: physical memory whose HBM region class the library has
+# measured, every block assembled so that the arrays of one launch differ in class at every position (no reservation; `pool_info`,
+# `pool_trim!`).  `arena_reserve!` is the one-block reservation of rounds 3-4, for a host that wants it.
+"What the device's class pool holds: (bytes held, bytes in blocks, classes found, GB/s of two store streams in two classes / in one)."
+function pool_info(ctx::Context = context())
+    held, used, ncls = Ref{Csize_t}(0), Ref{Csize_t}(0), Ref{Cint}(0)
+    two, one = Ref{Cdouble}(0), Ref{Cdouble}(0)
+    rc = @ccall LIB.kmers_pool_info(ctx.handle::Ptr{Cvoid}, held::Ptr{Csize_t}, used::Ptr{Csize_t}, ncls::Ptr{Cint}, C_NULL::Ptr{Csize_t},
+                                    two::Ptr{Cdouble}, one::Ptr{Cdouble})::Cint
+    rc == OK || error("kmers_pool_info: status $rc: $(last_error(ctx))")
+    return (held = Int(held[]), in_use = Int(used[]), classes = Int(ncls[]), two_class_gbps = two[], one_class_gbps = one[])
+end
+"Return the pool's free handles to the driver; the bytes released."
+function pool_trim!(ctx::Context = context())
+    r = Ref{Csize_t}(0)
+    rc = @ccall LIB.kmers_pool_trim(ctx.handle::Ptr{Cvoid}, r::Ptr{Csize_t})::Cint
+    rc == OK || error("kmers_pool_trim: status $rc: $(last_error(ctx))")
+    return Int(r[])
+end
+"One large block of HBM per DEVICE (`bytes = 0`: three quarters of what is free), out of which `device_alloc` of an attached context serves."
 function arena_reserve!(ctx::Context = context(); bytes::Integer = 0)
     rc = @ccall LIB.kmers_arena_reserve(ctx.handle::Ptr{Cvoid}, bytes::Csize_t)::Cint
     rc == OK || error("kmers_arena_reserve: status $rc: $(last_error(ctx))")
@@ -510,10 +529,10 @@ function arena_release!(ctx::Context = context())
     return nothing
 end
 """
-`n` elements of `T` in HBM (a range of the arena when one is reserved and has room, else a plain allocation).
-`lone_output = true`: the ONLY output array of the launches that fill it (`collect` of an iterator without hashes / reverse
-complements): the arena places it across a class boundary of HBM and such a launch writes it through two windows
-(`kmers_dev_alloc_role`, `KMERS_ALLOC_LONE_OUTPUT`).
+`n` elements of `T` in HBM: from 1 GiB on a block of the device's class pool (or a range of the arena when this context reserved
+one), else a plain allocation.  `lone_output = true`: the ONLY output array of the launches that fill it (`collect` of an iterator
+without hashes / reverse complements): its second half lies in another region class of HBM than its first and such a launch
+writes it through two windows (`kmers_dev_alloc_role`, `KMERS_ALLOC_LONE_OUTPUT`).
 """
 function device_alloc(ctx::Context, ::Type{T}, n::Integer; lone_output::Bool = false) where {T}
     p = Ref{Ptr{Cvoid}}(C_NULL)

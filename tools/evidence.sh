@@ -38,7 +38,7 @@ done
 # where the headline's arrays come from: the class pool (default), the arena of rounds 3-4 at three sizes, plain allocations
 cd "$ROOT"
 for mode in "--alloc pool" "--alloc arena --arena-gb 32" "--alloc arena --arena-gb 64" "--alloc arena --arena-gb 230" "--alloc plain"; do
-  python3 bench.py --steps 20 --warmup 5 --no-other-configs --no-cpu-baseline --no-pmc $mode 2>/dev/null | head -c 1200 > "$E/alloc_$(echo $mode | tr -d ' -').json"
+  python3 bench.py --steps 20 --warmup 5 --no-other-configs --no-cpu-baseline --no-pmc $mode 2>/dev/null > "$E/alloc_$(echo $mode | tr -d ' -').json"
 done
 cd /tmp
 cd "$ROOT"
