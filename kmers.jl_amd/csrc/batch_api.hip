@@ -224,6 +224,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     a.out_a = d_a;
     a.out_b = d_b;
     const bool vec = (!d_a || aligned16(d_a)) && (!d_b || aligned16(d_b));
+    bool have_result = false;  // the error slot has already travelled to the host (the optimistic launch)
     dim3 grid((unsigned)n_tiles), block(256);
 #define RG(DB, NN, MD)                                                                                         \
     do {                                                                                                       \
@@ -253,8 +254,10 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     } else if (optimistic) {
         RGM(2, 1);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result + 2, d_redo, 8, hipMemcpyDeviceToHost, ctx->stream));
+        // (scratch words 0..2 in one copy: with device-resident outputs this is the call's only wait when no tile is left)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_scratch, 24, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        have_result = out_dev && ctx->h_result[2] == 0;
         if (ctx->h_result[2]) {  // some tiles are left: the recode pass and the general launch for them
             if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;
             a.stream = ps.stream;
@@ -273,8 +276,10 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         if (out_a) HIP_TRY(ctx, hipMemcpyAsync(out_a, d_a, bytes_a, hipMemcpyDeviceToHost, ctx->stream));
         if (out_b) HIP_TRY(ctx, hipMemcpyAsync(out_b, d_b, bytes_b, hipMemcpyDeviceToHost, ctx->stream));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_scratch, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!have_result) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_scratch, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const uint64_t g = ctx->h_result[1];
     if (g == NO_ERROR_POS) {
         if (res) res->status = KMERS_OK;

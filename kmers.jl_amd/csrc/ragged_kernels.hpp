@@ -32,7 +32,7 @@ namespace kmers {
 constexpr int RG_RUN = KMERS_RG_RUN;     // consecutive elements per lane and pass (one-word kmers: 32 contiguous bytes per lane and array; 64 write at 60 % of that rate, profiles/r01_tuning.md)
 constexpr int RG_UNIT = 1024;            // tile lengths are given in units of this many elements (KMERS_PARAM_BATCH_PASSES)
 constexpr int RG_PASS = 256 * RG_RUN;    // elements per workgroup and pass of the run path; a tile is a multiple of it, 1..RG_MAX_PASSES units
-constexpr int RG_MAX_PASSES = 8;
+constexpr int RG_MAX_PASSES = 8;         // (16 measured in round 5: the same time; the dense path's prefix scan takes up to 128 bitmap words)
 #ifndef KMERS_RG_DENSE_RUN
 #define KMERS_RG_DENSE_RUN 2
 #endif
@@ -355,7 +355,7 @@ __device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const Rag
         }
     }
     constexpr uint32_t N_WORDS = RG_MAX_PASSES * RG_UNIT / RUN / 64;
-    static_assert(N_WORDS <= 64, "one wavefront scans the bitmap's words");
+    static_assert(N_WORDS <= 128 && N_WORDS % 2 == 0, "one wavefront scans the bitmap's words, two per lane");
     if (tid < N_WORDS) L.bits[tid] = 0;
     lds_atomics_settle();
     if (__syncthreads_or((int)bad)) return false;           // (also orders the staging before what follows)
@@ -367,14 +367,19 @@ __device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const Rag
         if (rel > 0u && j * RUN < n_el) atomicOr(&bits32[j >> 5], 1u << (j & 31u));  // (a record that begins inside the LAST run needs no bit)
     }
     block_sync();
-    if (tid < 64u) {                                        // exclusive prefix of the words' population counts (one wavefront)
-        uint32_t c = tid < N_WORDS ? (uint32_t)__popcll(L.bits[tid]) : 0u, incl = c;
+    if (tid < 64u) {                                        // exclusive prefix of the words' population counts (one wavefront, two words per lane)
+        const uint32_t c0 = 2u * tid < N_WORDS ? (uint32_t)__popcll(L.bits[2u * tid]) : 0u;
+        const uint32_t c1 = 2u * tid + 1u < N_WORDS ? (uint32_t)__popcll(L.bits[2u * tid + 1u]) : 0u;
+        uint32_t incl = c0 + c1;
 #pragma unroll
         for (uint32_t step = 1; step < 64u; step <<= 1) {
             const uint32_t up = __shfl_up(incl, step, 64);
             if (tid >= step) incl += up;
         }
-        if (tid < N_WORDS) L.base[tid] = incl - c;
+        if (2u * tid < N_WORDS) {
+            L.base[2u * tid] = incl - c0 - c1;
+            L.base[2u * tid + 1u] = incl - c1;
+        }
     }
     block_sync();
     // ---- the runs
