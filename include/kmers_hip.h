@@ -131,7 +131,7 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
                                          * construction) or plain allocations.  0: the table is trusted.  kmers_last_launch_shape tells. */
 #define KMERS_PARAM_POOL 14             /* 1 (default): without an arena, kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the device's class pool
                                          * (below); 0: plain hipMalloc */
-#define KMERS_PARAM_POOL_SEARCH_GIB 15  /* how far past a request the pool may grow in search of memory of the classes it wants (default 64); 0: never */
+#define KMERS_PARAM_POOL_SEARCH_GIB 15  /* how far past a request the pool may grow in search of memory of the classes it wants (default 128); 0: never */
 #define KMERS_PARAM_BATCH_DENSE 17       /* A/B, tests.  -1: kmers_batch never takes its dense tile path (csrc/ragged_kernels.hpp); 0 (default): wherever a tile allows */
 #define KMERS_PARAM_POOL_MAX_GIB 16     /* cap on the physical memory the pool holds (0, default: what the device has) */
 #define KMERS_PARAM_SUBTILES 7         /* strided tile kernels (kmers_spaced, kmers_minimizers): consecutive tiles per workgroup, the next one's source words in flight */
@@ -164,7 +164,7 @@ int kmers_shape_calibrations(kmers_ctx *ctx, uint64_t *count);
  * two-class rate; KMERS_ALLOC_LONE_OUTPUT gives a block whose second half differs from its first, for launches with one output
  * (written through two windows half an array apart).  No reservation is needed and it does not matter how finely the classes
  * are interleaved in a box's physical memory.  Blocks are whole handles (sizes round up to 1 GiB).  The pool holds what was
- * asked of it plus what it had to walk past in search of the classes it wanted (KMERS_PARAM_POOL_SEARCH_GIB) until
+ * asked of it plus what it had to walk past in search of the classes it wanted (KMERS_PARAM_POOL_SEARCH_GIB, default 128) until
  * kmers_pool_trim or until the last context of the device that used it is destroyed; one handle per class found stays with the
  * pool as the yardstick later handles are measured against.  One pool per device and process, shared by its contexts,
  * thread-safe.  Smaller blocks, a device without virtual-memory management, or KMERS_PARAM_POOL = 0: plain hipMalloc. */
@@ -185,7 +185,7 @@ int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t
 #define KMERS_POOL_MIN_BYTES ((size_t)1 << 30)
 #define KMERS_POOL_CLASSES 4
 /* The device's class pool: physical bytes it holds, bytes in blocks that are out, region classes found so far, bytes held per
- * class (KMERS_POOL_CLASSES entries), and what its probes measured in GB/s of two store streams side by side (1 GiB each, the
+ * class (KMERS_POOL_CLASSES entries: classes 0..2, then memory the pool could not classify), and what its probes measured in GB/s of two store streams side by side (1 GiB each, the
  * shape of the stream kernels' outputs): the fastest probe (two classes; about 7200; 0 while only one class is known) and the
  * slowest pair of the calibration (one class; about 6200).  The first is the write ceiling bench.py prices the materialising kernels against.  Any
  * output may be NULL; all zero before the first block. */
@@ -193,7 +193,7 @@ int kmers_pool_info(kmers_ctx *ctx, size_t *held, size_t *in_use, int *n_classes
 /* Return to the driver every handle of the pool that is not part of a block (everything, yardsticks included, if no block is out). */
 int kmers_pool_trim(kmers_ctx *ctx, size_t *released);
 /* The handles of the pool block that holds `block`: *n_chunks chunks of *chunk_bytes, chunk i in class classes[i]
- * (KMERS_POOL_CLASSES = class unknown; at most `capacity` entries are written).  *n_chunks = 0: not a block of the pool. */
+ * (0..2, or KMERS_POOL_CLASSES - 1 = not classified; at most `capacity` entries are written).  *n_chunks = 0: not a block of the pool. */
 int kmers_pool_layout(kmers_ctx *ctx, const void *block, size_t *chunk_bytes, unsigned char *classes, size_t capacity, size_t *n_chunks);
 /* The virtual-memory calls the pool relies on, checked on this box (csrc/pool_api.hip): KMERS_OK, or KMERS_E_HIP with the reason in
  * kmers_last_error.  *stale_without_flush = 1: a re-used address range showed the memory of its PREVIOUS mapping until the pool's

@@ -25,8 +25,8 @@ namespace kmers {
 namespace pool {
 
 constexpr size_t CHUNK_BYTES = (size_t)1 << 30;  // one physical handle, one probe stream
-constexpr int MAX_CLASSES = 4;                   // three have been seen; a fourth label absorbs a noisy probe
-constexpr uint8_t CLASS_UNKNOWN = MAX_CLASSES;   // a probe failed: usable memory of no known class, its own free list
+constexpr int MAX_CLASSES = 3;                   // what the device has (profiles/r05_vmm.md); a chunk that looks like none of them gets the nearest
+constexpr uint8_t CLASS_UNKNOWN = MAX_CLASSES;   // the probes did not run: usable memory of no known class, its own free list
 constexpr int N_LISTS = MAX_CLASSES + 1;
 constexpr uint8_t NO_CLASS = 0xff;
 
@@ -43,6 +43,7 @@ struct Chunk {
 struct Block {
     size_t bytes = 0;      // of the reservation: chunks.size() * CHUNK_BYTES
     size_t req_bytes = 0;  // what was asked for: the array a launch writes
+    size_t user_off = 0;   // where the caller's pointer lies inside the reservation (a lone output is shifted so that its MIDDLE is a chunk boundary)
     std::vector<uint32_t> chunks;
     std::vector<uint8_t> classes;  // of the chunks, in order
     uint64_t serial = 0;
@@ -215,7 +216,7 @@ inline std::vector<uint8_t> plan(const size_t free_counts[N_LISTS], size_t bytes
     if (partner && !partner->classes.empty() && partner->req_bytes)
         for (size_t i = 0; i < n; ++i) {
             const double x = std::min(1.0, ((double)i + 0.5) * (double)CHUNK_BYTES / (double)bytes);  // relative position of the chunk's middle
-            forbidden[i] = partner->classes[std::min(partner->classes.size() - 1, (size_t)(x * (double)partner->req_bytes / (double)CHUNK_BYTES))];
+            forbidden[i] = partner->classes[std::min(partner->classes.size() - 1, (size_t)(((double)partner->user_off + x * (double)partner->req_bytes) / (double)CHUNK_BYTES))];
         }
     seq = plan_with(free_counts, forbidden);
     if (quality) *quality = plan_quality(seq, forbidden);

@@ -64,7 +64,7 @@ struct kmers_ctx {
     kmers_device_arena *shared_arena = nullptr;  // the device's arena, if this context is attached to it (memory_api.hip)
     bool uses_pool = false;        // this context has taken part in the device's class pool (pool_api.hip): counted in its refs
     int64_t pool_enable = 1;       // KMERS_PARAM_POOL: kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the class pool (no arena attached)
-    int64_t pool_search_gib = -1;  // KMERS_PARAM_POOL_SEARCH_GIB: how far past a request the pool may grow in search of a second class (-1: 64)
+    int64_t pool_search_gib = -1;  // KMERS_PARAM_POOL_SEARCH_GIB: how far past a request the pool may grow in search of the classes it wants (-1: 128)
     int64_t pool_max_gib = 0;      // KMERS_PARAM_POOL_MAX_GIB: cap on what the pool holds (0: what the device has)
     int call_flags = KMERS_ASYNC;  // flags of the entry point that is running (the launcher must not block inside a KMERS_ASYNC call)
     // the arena's map for the launchers (an empty one without an arena: every placement question is then answered "no")

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 
 #include "context.hpp"
@@ -37,14 +38,15 @@ struct kmers_device_pool {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipMemAllocationProp prop = {};
     hipMemAccessDesc access = {};
-    float same_ms = 0.f;  // a probe that takes this long or longer ran inside ONE class
+    float same_ms = 0.f;  // a probe that takes this long or longer ran inside ONE class: the geometric mean of the two levels below
+    float one_ms = 0.f, two_ms = 0.f;  // running estimates of the two levels (one class / two classes), updated by every confident probe
     uint64_t tag = 0x6b6d657273000000ull;
     size_t n_probes = 0;
 };
 
 namespace {
 
-constexpr float SAME_CLASS = 0.93f;  // of the calibration's slowest pair (one class: 0.96-1.0 of it, two classes: 0.84-0.87; profiles/r05_vmm.md)
+constexpr float SAME_CLASS = 0.93f;  // of the one-class level while the two-class level is unknown (one class: 0.96-1.0 of it, two classes: 0.82-0.87)
 constexpr size_t FLUSH_BYTES = (size_t)32 << 20;
 constexpr float GOOD_PLAN = 0.95f;  // the pool grows (within its search budget) until a block's plan is this good
 
@@ -135,12 +137,22 @@ void destroy_chunk(kmers_device_pool *P, uint32_t id) {
 
 void debug_chunk(const State &s, uint32_t id, const char *probes) {
     if (std::getenv("KMERS_POOL_DEBUG"))
-        std::fprintf(stderr, "pool chunk %3u: %c%s  (one class %.1f us, fastest %.1f us;%s)\n", id, "ABCD?"[s.chunks[id].cls], s.chunks[id].rep ? " (representative)" : "",
+        std::fprintf(stderr, "pool chunk %3u: %c%s  (one class %.1f us, two %.1f us;%s)\n", id, "ABC?"[s.chunks[id].cls], s.chunks[id].rep ? " (representative)" : "",
                      1e3 * s.slow_ms, 1e3 * s.fast_ms, probes);
 }
 
-// The first four handles: every pair probed.  With three classes two of the four share one, so the SLOWEST pair is two streams
-// inside one class: the scale every later probe is read against.
+void set_levels(kmers_device_pool *P, float one_ms, float two_ms) {
+    P->one_ms = one_ms;
+    P->two_ms = two_ms;
+    P->same_ms = two_ms > 0.f ? std::sqrt(one_ms * two_ms) : SAME_CLASS * one_ms;
+    P->s.slow_ms = one_ms;
+    if (two_ms > 0.f) P->s.fast_ms = two_ms;
+}
+
+// The first four handles: every pair probed.  With three classes two of the four share one, so the slow end of the six times is
+// two streams inside one class; the widest gap between neighbouring times (if it is 6 % or more) separates the two levels, and
+// the MEDIAN of each side is its estimate (a single slow outlier as the yardstick made same-class probes look fast: spurious
+// fourth and fifth classes on two boxes of round 5).
 bool calibrate(kmers_device_pool *P) {
     State &s = P->s;
     uint32_t id[4];
@@ -155,13 +167,12 @@ bool calibrate(kmers_device_pool *P) {
     }
     float t[4][4] = {}, warm;
     for (int i = 0; i < 3; ++i) (void)probe_ms(P, s.chunks[id[0]].home, s.chunks[id[1]].home, &warm);  // the first launches of a process find the clocks idle
-    float slow = 0.f, fast = 1e30f;
+    std::vector<float> all;
     bool ok = true;
     for (int i = 0; i < 4 && ok; ++i)
         for (int j = i + 1; j < 4 && ok; ++j) {
             ok = probe_ms(P, s.chunks[id[i]].home, s.chunks[id[j]].home, &t[i][j]);
-            slow = std::max(slow, t[i][j]);
-            fast = std::min(fast, t[i][j]);
+            all.push_back(t[i][j]);
         }
     if (!ok) {  // probes do not run: memory without classes (everything unknown), still a pool
         for (int i = 0; i < 4; ++i) s.free_list[CLASS_UNKNOWN].push_back(id[i]);
@@ -169,18 +180,30 @@ bool calibrate(kmers_device_pool *P) {
         P->same_ms = 1e30f;
         return true;
     }
-    s.slow_ms = slow;
-    s.fast_ms = fast;
-    P->same_ms = SAME_CLASS * slow;
+    std::sort(all.begin(), all.end());
+    size_t cut = 0;  // all[cut ..] is the slow side
+    float widest = 0.f;
+    for (size_t i = 1; i < all.size(); ++i) {
+        const float gap = all[i] / all[i - 1] - 1.f;
+        if (gap > widest) {
+            widest = gap;
+            cut = i;
+        }
+    }
+    auto median = [&](size_t lo, size_t hi) { return all[lo + (hi - lo - 1) / 2]; };
+    if (widest >= 0.06f) set_levels(P, median(cut, all.size()), median(0, cut));
+    else set_levels(P, median(0, all.size()), 0.f);  // one level only: the four share a class
     for (int i = 0; i < 4; ++i) {
         int label = -1;
         for (int j = 0; j < i && label < 0; ++j)
             if (t[j][i] >= P->same_ms) label = s.chunks[id[j]].cls;
         Chunk &c = s.chunks[id[i]];
-        if (label < 0) {
+        if (label < 0 && s.n_classes < MAX_CLASSES) {
             label = s.n_classes++;
             s.rep_chunk[label] = id[i];
             c.rep = true;
+        } else if (label < 0) {
+            label = 0;
         }
         c.cls = (uint8_t)label;
         if (!c.rep) s.free_list[label].push_back(id[i]);
@@ -193,32 +216,53 @@ bool calibrate(kmers_device_pool *P) {
     return true;
 }
 
-// one more chunk, classified against the representatives and put into its free list (a new class: it becomes the representative)
+// one more chunk, probed beside the representative of EVERY class found so far: it belongs to the class it is slowest beside, if
+// that probe is on the one-class side; a chunk that is fast beside all of them is a new class while fewer than three are known,
+// and otherwise (a handle that straddles a boundary of the physical map, a noisy probe: asked again first) the nearest one.
+// Confident probes move the two levels (exponential averages), so the yardstick follows the box.
 bool grow(kmers_device_pool *P) {
     State &s = P->s;
     if (s.chunks.empty() || (s.n_classes == 0 && s.slow_ms == 0.f && P->same_ms == 0.f)) return calibrate(P);
     uint32_t id;
     if (!create_chunk(P, &id)) return false;
     Chunk &c = s.chunks[id];
-    int label = -1;
     bool failed = P->same_ms >= 1e29f;
     char buf[128];
     int n = 0;
     buf[0] = 0;
-    for (int k = 0; k < s.n_classes && label < 0 && !failed; ++k) {
-        float t = 0.f;
-        if (!probe_ms(P, c.home, s.chunks[s.rep_chunk[k]].home, &t)) {
+    float t[MAX_CLASSES] = {};
+    int best = -1;
+    for (int k = 0; k < s.n_classes && !failed; ++k) {
+        if (!probe_ms(P, c.home, s.chunks[s.rep_chunk[k]].home, &t[k])) {
             failed = true;
             break;
         }
-        n += std::snprintf(buf + n, sizeof buf - (size_t)n, " %c:%.1f", 'A' + k, 1e3 * t);
-        s.fast_ms = std::min(s.fast_ms, t);
-        if (t >= P->same_ms) label = k;
+        n += std::snprintf(buf + n, sizeof buf - (size_t)n, " %c:%.1f", 'A' + k, 1e3 * t[k]);
+        if (best < 0 || t[k] > t[best]) best = k;
     }
-    if (label < 0 && !failed && s.n_classes < MAX_CLASSES) {  // fast beside every representative: a new class, and its yardstick
-        label = s.n_classes++;
-        s.rep_chunk[label] = id;
-        c.rep = true;
+    int label = -1;
+    if (!failed && best >= 0) {
+        if (t[best] < P->same_ms && s.n_classes >= MAX_CLASSES) {  // like none of the three: ask the nearest again
+            float t2 = 0.f;
+            if (probe_ms(P, c.home, s.chunks[s.rep_chunk[best]].home, &t2)) t[best] = std::max(t[best], t2);
+            n += std::snprintf(buf + n, sizeof buf - (size_t)n, " %c again:%.1f", 'A' + best, 1e3 * t2);
+        }
+        if (t[best] >= P->same_ms) {
+            label = best;
+            float one = 0.9f * P->one_ms + 0.1f * t[best], two = P->two_ms;
+            for (int k = 0; k < s.n_classes; ++k)
+                if (k != best && t[k] < P->same_ms) two = two > 0.f ? 0.9f * two + 0.1f * t[k] : t[k];
+            set_levels(P, one, two);
+        } else if (s.n_classes < MAX_CLASSES) {  // fast beside every representative: a new class, and its yardstick
+            label = s.n_classes++;
+            s.rep_chunk[label] = id;
+            c.rep = true;
+            float two = P->two_ms;
+            for (int k = 0; k < label; ++k) two = two > 0.f ? 0.9f * two + 0.1f * t[k] : t[k];
+            set_levels(P, P->one_ms, two);
+        } else {
+            label = best;  // the nearest
+        }
     }
     c.cls = label < 0 ? CLASS_UNKNOWN : (uint8_t)label;
     if (!c.rep) s.free_list[c.cls].push_back(id);
@@ -303,15 +347,24 @@ int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, int role, void **out) {
     kmers_device_pool *P = attach(ctx, slot);
     if (!P) return KMERS_E_UNSUPPORTED;  // no virtual-memory management on this device: the caller falls back to hipMalloc
     State &s = P->s;
-    const size_t n = chunks_for(bytes);
-    const size_t search_limit = ctx->pool_search_gib >= 0 ? (size_t)ctx->pool_search_gib << 30 : (size_t)64 << 30;
+    // A lone output is written through two windows half an array apart: its MIDDLE is put on a chunk boundary (the block is the
+    // two halves rounded up to whole chunks each, the caller's pointer lies `user_off` inside it), so that the first half is one
+    // run of chunks and the second another, whatever the array's size (C3: 9.31 GiB -> 5 + 5 chunks, the pointer 0.34 GiB in).
+    size_t user_off = 0, plan_bytes = bytes;
+    if (role == ROLE_LONE_OUTPUT && bytes >= 2 * CHUNK_BYTES) {
+        const size_t half = (bytes / 2 + 4095) / 4096 * 4096, k1 = chunks_for(half);
+        user_off = k1 * CHUNK_BYTES - half;
+        plan_bytes = 2 * k1 * CHUNK_BYTES;
+    }
+    const size_t n = chunks_for(plan_bytes);
+    const size_t search_limit = ctx->pool_search_gib >= 0 ? (size_t)ctx->pool_search_gib << 30 : (size_t)128 << 30;
     const Block *partner = role == ROLE_DEFAULT ? partner_block(s) : nullptr;
     std::vector<uint8_t> seq;
     for (size_t searched = 0;;) {
         size_t free_counts[N_LISTS];
         for (int i = 0; i < N_LISTS; ++i) free_counts[i] = s.free_list[i].size();
         float quality = 0.f;
-        seq = plan(free_counts, bytes, partner, role, &quality);
+        seq = plan(free_counts, plan_bytes, partner, role, &quality);
         if (!seq.empty() && (quality >= GOOD_PLAN || searched >= search_limit)) break;
         if (!room_for_a_chunk(ctx, s) || !grow(P)) {
             if (!seq.empty()) break;
@@ -359,11 +412,12 @@ int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, int role, void **out) {
     Block b;
     b.bytes = n * CHUNK_BYTES;
     b.req_bytes = bytes;
+    b.user_off = user_off;
     b.chunks = std::move(ids);
     b.classes = std::move(seq);
     b.serial = ++s.serial;
     s.blocks[base] = std::move(b);
-    *out = base;
+    *out = base + user_off;
     return KMERS_OK;
 }
 
@@ -373,18 +427,15 @@ int kmers::pool_free(kmers_ctx *ctx, void *p, bool *handled) {
     std::lock_guard<std::mutex> lock(slot.mu);
     kmers_device_pool *P = slot.pool;
     if (!P) return KMERS_OK;
-    auto it = P->s.blocks.find(static_cast<const char *>(p));
-    if (it == P->s.blocks.end()) {
-        if (block_of(P->s, p, 1)) {
-            *handled = true;
-            return fail(ctx, KMERS_E_BADARG, "kmers_dev_free: not the start of a block of the pool");
-        }
-        return KMERS_OK;
-    }
+    const char *base = nullptr;
+    const Block *blk = block_of(P->s, p, 1, &base);
+    if (!blk) return KMERS_OK;
     *handled = true;
+    if (static_cast<const char *>(p) != base + blk->user_off) return fail(ctx, KMERS_E_BADARG, "kmers_dev_free: not the start of a block of the pool");
+    auto it = P->s.blocks.find(base);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());  // whatever stream of whatever context still writes into it
-    unmap_block(static_cast<char *>(p), it->second.chunks.size());
+    unmap_block(const_cast<char *>(base), it->second.chunks.size());
     give(P->s, it->second.chunks);
     P->s.blocks.erase(it);
     return KMERS_OK;

@@ -41,7 +41,7 @@ int main() {
     float q = 0.f;
     // no partner: as pure as the stock allows, the fullest class first
     {
-        size_t fr[N_LISTS] = {5, 9, 2, 0, 0};
+        size_t fr[N_LISTS] = {5, 9, 2, 0};
         auto s = plan(fr, 8 * G, nullptr, ROLE_DEFAULT, &q);
         REQUIRE(s == runs({{1, 8}}) && q == 1.f);
         s = plan(fr, 12 * G - 5, nullptr, ROLE_DEFAULT, &q);
@@ -51,12 +51,12 @@ int main() {
     }
     // the second array of a launch: another class at every position
     {
-        size_t fr[N_LISTS] = {20, 8, 3, 0, 0};
+        size_t fr[N_LISTS] = {20, 8, 3, 0};
         Block a = block_of_classes(runs({{0, 8}}), 8 * G - 400000000);
         auto b = plan(fr, 8 * G - 400000000, &a, ROLE_DEFAULT, &q);
         REQUIRE(b == runs({{1, 8}}) && q == 1.f);
         // the partner spans three classes; the stock is exactly what a perfect answer needs, and the greedy choice alone gets stuck
-        size_t eq[N_LISTS] = {25, 25, 25, 0, 0};
+        size_t eq[N_LISTS] = {25, 25, 25, 0};
         Block p3 = block_of_classes(runs({{0, 25}, {1, 25}, {2, 25}}));
         auto s = plan(eq, 75 * G, &p3, ROLE_DEFAULT, &q);
         REQUIRE(s.size() == 75 && q == 1.f && n_runs(s) == 3);
@@ -64,17 +64,17 @@ int main() {
         auto half = plan(eq, 75 * G / 2, &p3, ROLE_DEFAULT, &q);
         REQUIRE(half.size() == 38 && q >= 0.9f);
         // not enough of the other classes: as many positions as possible, the rest from what there is
-        size_t poor[N_LISTS] = {30, 3, 0, 0, 0};
+        size_t poor[N_LISTS] = {30, 3, 0, 0};
         auto r = plan(poor, 8 * G, &a, ROLE_DEFAULT, &q);
         REQUIRE(r.size() == 8 && q == 3.f / 8.f);
         // unknown chunks are better than the forbidden class, but count for nothing
-        size_t unk[N_LISTS] = {30, 0, 0, 0, 8};
+        size_t unk[N_LISTS] = {30, 0, 0, 8};
         r = plan(unk, 8 * G, &a, ROLE_DEFAULT, &q);
         REQUIRE(r == runs({{CLASS_UNKNOWN, 8}}) && q == 0.f);
     }
     // the only output of a launch: second half against first half, in BYTES of the array (not in chunks of the block)
     {
-        size_t fr[N_LISTS] = {20, 8, 3, 0, 0};
+        size_t fr[N_LISTS] = {20, 8, 3, 0};
         auto s = plan(fr, 10 * G, nullptr, ROLE_LONE_OUTPUT, &q);
         REQUIRE(s == runs({{0, 5}, {1, 5}}) && q == 1.f);
         // 9.31 GiB (1.25 G kmers): the middle of the array is inside chunk 4, whose middle lies in the first half
@@ -83,16 +83,16 @@ int main() {
         // 2.48 GiB (C5: 333 M kmers): one chunk in front, two behind
         s = plan(fr, (size_t)2666666664, nullptr, ROLE_LONE_OUTPUT, &q);
         REQUIRE(s == runs({{0, 1}, {1, 2}}) && q == 1.f);
-        size_t two[N_LISTS] = {6, 5, 0, 0, 0};
+        size_t two[N_LISTS] = {6, 5, 0, 0};
         s = plan(two, 10 * G, nullptr, ROLE_LONE_OUTPUT, &q);
         REQUIRE(s.size() == 10 && q == 1.f);
-        size_t one[N_LISTS] = {12, 0, 0, 0, 0};
+        size_t one[N_LISTS] = {12, 0, 0, 0};
         s = plan(one, 10 * G, nullptr, ROLE_LONE_OUTPUT, &q);
         REQUIRE(s.size() == 10 && q == 0.f);
-        size_t big[N_LISTS] = {40, 30, 20, 0, 0};  // no class covers a half AND leaves the rest to the others... two do
+        size_t big[N_LISTS] = {40, 30, 20, 0};  // no class covers a half AND leaves the rest to the others... two do
         s = plan(big, 80 * G, nullptr, ROLE_LONE_OUTPUT, &q);
         REQUIRE(s.size() == 80 && q == 1.f);
-        size_t tight[N_LISTS] = {30, 30, 20, 0, 0};  // no class holds a half of 40: the first half is mixed, the second still differs everywhere
+        size_t tight[N_LISTS] = {30, 30, 20, 0};  // no class holds a half of 40: the first half is mixed, the second still differs everywhere
         s = plan(tight, 80 * G, nullptr, ROLE_LONE_OUTPUT, &q);
         REQUIRE(s.size() == 80 && q == 1.f);
     }
@@ -101,7 +101,7 @@ int main() {
     for (int trial = 0; trial < 3000; ++trial) {
         size_t fr[N_LISTS];
         size_t total = 0;
-        for (int c = 0; c < N_LISTS; ++c) total += fr[c] = c < 3 ? rng() % 40 : (c == 4 ? rng() % 3 : 0);
+        for (int c = 0; c < N_LISTS; ++c) total += fr[c] = c < 3 ? rng() % 40 : rng() % 3;
         if (!total) continue;
         const size_t n = 1 + rng() % total;
         const size_t bytes = n * G - (rng() % 2 ? rng() % (G / 2) : 0);
@@ -127,7 +127,7 @@ int main() {
         for (int c = 0; c < N_LISTS; ++c) REQUIRE(used[c] <= fr[c]);
         if (role == ROLE_DEFAULT && !partner.classes.empty()) {
             bool plenty = true;  // every forbidden class can be avoided everywhere
-            for (int f = 0; f < 3; ++f) plenty &= total - fr[f] - fr[4] >= n;
+            for (int f = 0; f < 3; ++f) plenty &= total - fr[f] - fr[CLASS_UNKNOWN] >= n;
             if (plenty) REQUIRE(q == 1.f);
         }
     }

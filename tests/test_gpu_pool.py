@@ -64,6 +64,15 @@ def test_blocks_are_assembled_by_class_and_hold_their_data(ctx):
     cl = ctx.pool_layout(lone)[1]
     assert all(cl[i] != cl[i + 4] for i in range(4)), cl
     assert ctx.placement_probe(lone, lone + 4 * GiB, GiB) > 6700
+    # ... whatever the size: the array's MIDDLE lies on a handle boundary (the block is the two halves rounded up, the pointer inside it)
+    odd_bytes = 10_000_000_000 - 8 * 30          # C3's output: 9.31 GiB
+    odd = ctx.alloc(odd_bytes, lone_output=True)
+    co = ctx.pool_layout(odd)[1]
+    assert len(co) == 10 and len(set(co[:5])) == 1 and all(co[i] != co[i + 5] for i in range(5)), co
+    half = -(-(odd_bytes // 2) // 4096) * 4096                 # the second half begins on the boundary between handle 4 and handle 5
+    assert odd % 4096 == 0 and ctx.placement_probe(odd, odd + half, GiB) > 6700 and ctx.placement_probe(odd + half - GiB, odd + half, GiB) > 6700
+    assert ctx.lib.kmers_dev_free(ctx.handle, C.c_void_p(odd + 4096)) == cap.E_BADARG
+    ctx.free(odd)
     # a pattern across every chunk boundary, written and read through the C ABI's copies
     rng = np.random.default_rng(11)
     for off in (0, GiB - 4096, 3 * GiB - 8, na - 8192):

@@ -131,7 +131,7 @@ with torch.cuda.stream(stream):
         pa = ctx.alloc(8 * words_a, lone_output=(words_b == 0 and not args.no_role))  # the only output of its launch: by role
         pb = ctx.alloc(8 * max(words_b, 1))
         info = ctx.pool_info()
-        lay = lambda p: "".join("ABCD?"[c] for c in ctx.pool_layout(p)[1])
+        lay = lambda p: "".join("ABC?"[c] for c in ctx.pool_layout(p)[1])
         la, lb = lay(pa), lay(pb)
         short = lambda t: t if len(t) <= 48 else t[:40] + "..." + t[-5:]
         print(f"pool: {time.perf_counter() - t0:.2f} s; held {info['held'] / 2**30:.1f} GiB, in use {info['in_use'] / 2**30:.1f}, classes {info['n_classes']} "

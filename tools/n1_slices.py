@@ -38,7 +38,7 @@ n = L - K + 1
 nw = (L * 4 + 63) // 64
 pa, pb, psrc = ctx.alloc(8 * n), ctx.alloc(8 * n), ctx.alloc(8 * (nw + 2))
 info = ctx.pool_info()
-runs = lambda p: "".join("ABCD?"[c] for c in ctx.pool_layout(p)[1])
+runs = lambda p: "".join("ABC?"[c] for c in ctx.pool_layout(p)[1])
 print(f"pool held {info['held'] / 2**30:.0f} GiB, in use {info['in_use'] / 2**30:.0f}; a {runs(pa)}\n{' ' * 38}b {runs(pb)}", flush=True)
 ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, 0x9E3779B97F4A7C15 ^ 10, 0, nw, 4, 0, psrc), "synth")
 res = cap.Result()
