@@ -67,16 +67,19 @@ inline size_t chunks_for(size_t bytes) { return (bytes + CHUNK_BYTES - 1) / CHUN
 // than the one forbidden there: segments = maximal runs of positions with one forbidden class.  A transport problem with a handful
 // of nodes on either side, solved exactly by augmenting paths (a segment that finds the classes it may take exhausted makes another
 // segment switch to a class that still has stock), in three levels: known allowed classes; then chunks of unknown class; then the
-// forbidden class itself for what is still missing.  take[s][c] = chunks of class c for segment s.
-inline void assign_segments(const std::vector<uint8_t> &forbidden, const std::vector<size_t> &seg_len, const size_t free_counts[N_LISTS],
-                            std::vector<std::vector<size_t>> &take) {
+// forbidden class itself for what is still missing.  A segment has a SECOND class to stay away from if it can (that of another
+// recent block: with three classes the arrays of a launch and the sequence they are computed from all differ): given up first.
+// take[s][c] = chunks of class c for segment s.
+inline void assign_segments(const std::vector<uint8_t> &forbidden, const std::vector<uint8_t> &forbidden2, const std::vector<size_t> &seg_len,
+                            const size_t free_counts[N_LISTS], std::vector<std::vector<size_t>> &take) {
     const size_t S = seg_len.size();
     take.assign(S, std::vector<size_t>(N_LISTS, 0));
     std::vector<size_t> need(seg_len), left(free_counts, free_counts + N_LISTS);
-    for (int level = 0; level < 3; ++level) {
+    for (int level = 0; level < 4; ++level) {
         auto allowed = [&](size_t s, int c) {
-            if (c == forbidden[s]) return level >= 2;
-            if (c == CLASS_UNKNOWN) return level >= 1;
+            if (c == forbidden[s]) return level >= 3;
+            if (c == CLASS_UNKNOWN) return level >= 2;
+            if (c == forbidden2[s]) return level >= 1;
             return true;
         };
         std::vector<size_t> order(S);  // longest segments first: they get the fullest classes, in one piece
@@ -130,26 +133,29 @@ inline void assign_segments(const std::vector<uint8_t> &forbidden, const std::ve
     }
 }
 
-// The classes of the chunks of a new block, in order, given the class each position should NOT have (NO_CLASS: any).  Segments =
-// maximal runs of one forbidden class; within a segment the chunks of one class stay together (long pure runs), and a run
+// The classes of the chunks of a new block, in order, given the class each position should NOT have (NO_CLASS: any) and a second
+// one it should avoid if it can.  Segments = maximal runs of one pair of forbidden classes; within a segment the chunks of one class stay together (long pure runs), and a run
 // continues the class of the run before it when it can.  An empty result: fewer chunks are free than positions.
-inline std::vector<uint8_t> plan_with(const size_t free_counts[N_LISTS], const std::vector<uint8_t> &forbidden_at) {
+inline std::vector<uint8_t> plan_with(const size_t free_counts[N_LISTS], const std::vector<uint8_t> &forbidden_at,
+                                      const std::vector<uint8_t> &second_at = std::vector<uint8_t>()) {
     const size_t n = forbidden_at.size();
     size_t total = 0;
     for (int i = 0; i < N_LISTS; ++i) total += free_counts[i];
     std::vector<uint8_t> seq;
     if (total < n || n == 0) return seq;
-    std::vector<uint8_t> forbidden;
+    std::vector<uint8_t> forbidden, forbidden2;
     std::vector<size_t> seg_len;
     for (size_t i = 0; i < n; ++i) {
-        if (forbidden.empty() || forbidden.back() != forbidden_at[i]) {
+        const uint8_t f2 = second_at.empty() ? NO_CLASS : second_at[i];
+        if (forbidden.empty() || forbidden.back() != forbidden_at[i] || forbidden2.back() != f2) {
             forbidden.push_back(forbidden_at[i]);
+            forbidden2.push_back(f2);
             seg_len.push_back(0);
         }
         ++seg_len.back();
     }
     std::vector<std::vector<size_t>> take;
-    assign_segments(forbidden, seg_len, free_counts, take);
+    assign_segments(forbidden, forbidden2, seg_len, free_counts, take);
     seq.reserve(n);
     for (size_t s = 0; s < seg_len.size(); ++s) {
         std::vector<int> cs;  // classes of the segment: the one the previous run ended with first, then by amount
@@ -176,12 +182,14 @@ inline float plan_quality(const std::vector<uint8_t> &seq, const std::vector<uin
 
 // A new block of `bytes` bytes (n = chunks_for(bytes) chunks).
 //   ROLE_DEFAULT: beside `partner` (the block it will most likely be written with; nullptr: none): chunk i should differ from the
-//     partner's chunk at the same RELATIVE byte position of the two arrays (a launch writes element e of both at the same time).
+//     partner's chunk at the same RELATIVE byte position of the two arrays (a launch writes element e of both at the same time),
+//     and from `other`'s (another recent block: the sequence the arrays are computed from, a third array) if the stock allows.
 //   ROLE_LONE_OUTPUT: the array is written through two windows half an array apart: the chunks of its second half should
 //     differ from the chunks half an array before them.  The first half is taken from ONE class if one has the stock and leaves
 //     enough of the others.
 // *quality = the fraction of positions that got what they should; an empty result: fewer than n chunks are free.
-inline std::vector<uint8_t> plan(const size_t free_counts[N_LISTS], size_t bytes, const Block *partner, int role, float *quality) {
+inline std::vector<uint8_t> plan(const size_t free_counts[N_LISTS], size_t bytes, const Block *partner, int role, float *quality,
+                                 const Block *other = nullptr) {
     const size_t n = chunks_for(bytes);
     std::vector<uint8_t> forbidden(n, NO_CLASS), seq;
     if (quality) *quality = 0.f;
@@ -213,12 +221,17 @@ inline std::vector<uint8_t> plan(const size_t free_counts[N_LISTS], size_t bytes
         if (quality) *quality = plan_quality(second, second_forbidden);
         return seq;
     }
-    if (partner && !partner->classes.empty() && partner->req_bytes)
-        for (size_t i = 0; i < n; ++i) {
-            const double x = std::min(1.0, ((double)i + 0.5) * (double)CHUNK_BYTES / (double)bytes);  // relative position of the chunk's middle
-            forbidden[i] = partner->classes[std::min(partner->classes.size() - 1, (size_t)(((double)partner->user_off + x * (double)partner->req_bytes) / (double)CHUNK_BYTES))];
-        }
-    seq = plan_with(free_counts, forbidden);
+    std::vector<uint8_t> second(n, NO_CLASS);
+    auto class_beside = [&](const Block *b, size_t i) -> uint8_t {
+        if (!b || b->classes.empty() || !b->req_bytes) return NO_CLASS;
+        const double x = std::min(1.0, ((double)i + 0.5) * (double)CHUNK_BYTES / (double)bytes);  // relative position of the chunk's middle
+        return b->classes[std::min(b->classes.size() - 1, (size_t)(((double)b->user_off + x * (double)b->req_bytes) / (double)CHUNK_BYTES))];
+    };
+    for (size_t i = 0; i < n; ++i) {
+        forbidden[i] = class_beside(partner, i);
+        second[i] = class_beside(other, i);
+    }
+    seq = plan_with(free_counts, forbidden, second);
     if (quality) *quality = plan_quality(seq, forbidden);
     return seq;
 }
@@ -264,12 +277,25 @@ inline float halves_differ(const State &s, const void *p, size_t bytes) {
     return (float)ok / 64.f;
 }
 
-// the most recently made block that is still out: what a new block will most likely be written beside
-inline const Block *partner_block(const State &s) {
-    const Block *best = nullptr;
-    for (const auto &b : s.blocks)
-        if (!best || b.second.serial > best->serial) best = &b.second;
-    return best;
+// What a new block of `bytes` bytes will most likely be written beside: the most recent block still out that is at least half its
+// size (the other array of the launch; a small block allocated in between -- the sequence, a scratch array -- must not take its
+// place: with kmers, text, hashes allocated in this order the hashes landed in the kmers' class, 0.745 instead of 0.80).  *other:
+// the most recent block apart from that one.
+inline const Block *partner_block(const State &s, size_t bytes, const Block **other) {
+    const Block *recent = nullptr, *second = nullptr, *partner = nullptr;
+    for (const auto &b : s.blocks) {
+        const Block *p = &b.second;
+        if (!recent || p->serial > recent->serial) {
+            second = recent;
+            recent = p;
+        } else if (!second || p->serial > second->serial) {
+            second = p;
+        }
+        if (p->req_bytes >= bytes / 2 && (!partner || p->serial > partner->serial)) partner = p;
+    }
+    if (!partner) partner = recent;
+    if (other) *other = recent != partner ? recent : second;
+    return partner;
 }
 
 // Take the chunks for the planned classes out of the free lists.

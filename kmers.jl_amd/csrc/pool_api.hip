@@ -358,13 +358,14 @@ int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, int role, void **out) {
     }
     const size_t n = chunks_for(plan_bytes);
     const size_t search_limit = ctx->pool_search_gib >= 0 ? (size_t)ctx->pool_search_gib << 30 : (size_t)128 << 30;
-    const Block *partner = role == ROLE_DEFAULT ? partner_block(s) : nullptr;
+    const Block *other = nullptr;
+    const Block *partner = role == ROLE_DEFAULT ? partner_block(s, bytes, &other) : nullptr;
     std::vector<uint8_t> seq;
     for (size_t searched = 0;;) {
         size_t free_counts[N_LISTS];
         for (int i = 0; i < N_LISTS; ++i) free_counts[i] = s.free_list[i].size();
         float quality = 0.f;
-        seq = plan(free_counts, plan_bytes, partner, role, &quality);
+        seq = plan(free_counts, plan_bytes, partner, role, &quality, other);
         if (!seq.empty() && (quality >= GOOD_PLAN || searched >= search_limit)) break;
         if (!room_for_a_chunk(ctx, s) || !grow(P)) {
             if (!seq.empty()) break;

@@ -62,6 +62,8 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restr
                                                           const uint64_t *__restrict__ seg_sums, uint64_t n_seg,
                                                           uint64_t *__restrict__ offsets) {
     __shared__ uint32_t c[SCAN_SEG];
+    __shared__ uint64_t o[SCAN_SEG];  // the segment's offsets, so that they leave with the lanes side by side (a lane's own eight
+                                      // consecutive offsets are 64 contiguous bytes per lane: the store shape that writes slowly)
     __shared__ uint64_t wave_tot[4];
     const uint32_t t = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_SEG;
@@ -91,9 +93,12 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restr
     for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
     const uint64_t excl = before + incl - sum;
 #pragma unroll
+    for (uint32_t j = 0; j < SCAN_SEG / 256; ++j) o[t * (SCAN_SEG / 256) + j] = excl + local[j];
+    block_sync();
+#pragma unroll
     for (uint32_t j = 0; j < SCAN_SEG / 256; ++j) {
-        uint64_t i = base + (uint64_t)t * (SCAN_SEG / 256) + j;
-        if (i < n) offsets[i] = excl + local[j];
+        const uint64_t i = base + t + 256u * j;
+        if (i < n) offsets[i] = o[t + 256u * j];
     }
     if (blockIdx.x == 0 && t == 0) offsets[n] = seg_sums[n_seg];
 }

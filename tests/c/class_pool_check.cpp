@@ -72,6 +72,29 @@ int main() {
         r = plan(unk, 8 * G, &a, ROLE_DEFAULT, &q);
         REQUIRE(r == runs({{CLASS_UNKNOWN, 8}}) && q == 0.f);
     }
+    // a second block to stay away from if the stock allows: the third class for the sequence; given up before the first
+    {
+        size_t fr[N_LISTS] = {10, 10, 10, 0};
+        Block a = block_of_classes(runs({{0, 8}})), b = block_of_classes(runs({{1, 8}}));
+        auto t = plan(fr, 2 * G, &b, ROLE_DEFAULT, &q, &a);
+        REQUIRE(t == runs({{2, 2}}) && q == 1.f);
+        size_t no_c[N_LISTS] = {10, 10, 0, 0};
+        t = plan(no_c, 2 * G, &b, ROLE_DEFAULT, &q, &a);
+        REQUIRE(t == runs({{0, 2}}) && q == 1.f);        // (quality counts the partner only)
+        // kmers, then a small block, then the hashes: the hashes are planned beside the KMERS
+        State s;
+        char *base = reinterpret_cast<char *>((size_t)1 << 40);
+        Block small = block_of_classes(runs({{1, 1}}));
+        a.serial = 1;
+        small.serial = 2;
+        s.blocks[base] = a;
+        s.blocks[base + 16 * G] = small;
+        const Block *other = nullptr;
+        const Block *p = partner_block(s, 8 * G, &other);
+        REQUIRE(p->serial == 1 && other->serial == 2);
+        auto h = plan(fr, 8 * G, p, ROLE_DEFAULT, &q, other);
+        REQUIRE(h == runs({{2, 8}}) && q == 1.f);
+    }
     // the only output of a launch: second half against first half, in BYTES of the array (not in chunks of the block)
     {
         size_t fr[N_LISTS] = {20, 8, 3, 0};
@@ -177,7 +200,9 @@ int main() {
         REQUIRE(arrays_differ(s, base, bytes, base + 4096, bytes - 4096) == 0.f);
         REQUIRE(arrays_differ(s, base, bytes, base + 8 * CHUNK_BYTES, 16) == -1.f);  // not inside a block
         REQUIRE(halves_differ(s, base, bytes) == 0.f && halves_differ(s, base + 32 * CHUNK_BYTES, bytes) == 1.f);
-        REQUIRE(partner_block(s)->serial == 3);
+        const Block *other = nullptr;
+        REQUIRE(partner_block(s, 8 * G, &other)->serial == 3 && other && other->serial == 2);
+        REQUIRE(partner_block(s, 100 * G, &other)->serial == 3);   // nothing comparable: the most recent
         REQUIRE(block_of(s, base, 1) && !block_of(s, base + 8 * CHUNK_BYTES, 1) && !block_of(s, base - 1, 1));
     }
     std::puts("class_pool_check: ok");
