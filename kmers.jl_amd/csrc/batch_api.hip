@@ -133,18 +133,29 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     HIP_TRY(ctx, hipMemcpyAsync(h, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(h + 1, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (out_offsets) HIP_TRY(ctx, hipMemcpyAsync(out_offsets, d_off, off_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const uint64_t total = h[0];
-    if (h[1]) return fail(ctx, KMERS_E_BADARG, "a span reaches outside the pool (or holds 2^32 symbols or more)");
-    if (res) res->n_out = total;
-    if (total > capacity || (!out_a && !out_b)) {
-        if (total > capacity && (out_a || out_b)) {
-            if (res) res->status = KMERS_E_CAPACITY;
-            return fail(ctx, KMERS_E_CAPACITY, "output capacity too small");
+    // The element count decides the tile layout, and waiting for it costs the call a host round trip in the middle (the device
+    // idles between the scan and the element kernel).  A caller that passes device outputs and a sane capacity -- the count it
+    // learned from a size query, or an upper bound -- gets the layout sized for the CAPACITY instead, the kernels read the count on
+    // the device, and the call waits once, at its end (round 5: the optimistic launch of one-word kmers from a 4-bit pool only).
+    const bool out_dev_early = (flags & KMERS_MEM_DEVICE) || (flags & INTERNAL_OUT_DEVICE);
+    const bool deferred = out_dev_early && (out_a || out_b) && (!out_a || aligned16(out_a)) && (!out_b || aligned16(out_b)) && pool->src_bits == 4 &&
+                          dst_bits == 2 && nw == 1 && stride == 1 && !(flags & KMERS_BATCH_SKIP) && ctx->batch_dense >= 0 && capacity > 0 &&
+                          capacity <= 2 * pool->n_bases + n;
+    uint64_t total = capacity;  // (deferred: what the layout is sized for; the real count arrives with the final wait)
+    if (!deferred) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        total = h[0];
+        if (h[1]) return fail(ctx, KMERS_E_BADARG, "a span reaches outside the pool (or holds 2^32 symbols or more)");
+        if (res) res->n_out = total;
+        if (total > capacity || (!out_a && !out_b)) {
+            if (total > capacity && (out_a || out_b)) {
+                if (res) res->status = KMERS_E_CAPACITY;
+                return fail(ctx, KMERS_E_CAPACITY, "output capacity too small");
+            }
+            return KMERS_OK;  // size query
         }
-        return KMERS_OK;  // size query
+        if (total == 0) return KMERS_OK;
     }
-    if (total == 0) return KMERS_OK;
     // tile = 1..8 passes of 1024 elements: long tiles amortise the two rounds of loads every tile starts with
     // (each about 5 us under the store load), short ones keep a small batch spread over the device
     uint64_t passes = total / ((uint64_t)RG_UNIT * (uint64_t)ctx->n_cus * 32u);
@@ -173,7 +184,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     const uint64_t n_src_words = ((origin + pool->n_bases) * (uint64_t)sb + 63) / 64;
     if (!wide)
         hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_spans, n, n_tiles,
-                           total, tile_elems, (uint32_t)k, (uint32_t)stride, (uint32_t)dst_bits, origin, d_tiles);
+                           total, deferred ? d_off + n : nullptr, tile_elems, (uint32_t)k, (uint32_t)stride, (uint32_t)dst_bits, origin, d_tiles);
     HIP_TRY(ctx, hipGetLastError());
 
     RaggedArgs a{};
@@ -182,6 +193,8 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     a.tiles = d_tiles;
     a.n_records = n;
     a.n_elems = total;
+    a.n_elems_ptr = deferred ? d_off + n : nullptr;
+    a.capacity = capacity;
     a.seed = seed;
     a.err_slot = ctx->d_err;
     a.k = (uint32_t)k;
@@ -257,6 +270,17 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         // (scratch words 0..2 in one copy: with device-resident outputs this is the call's only wait when no tile is left)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_scratch, 24, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (deferred) {  // the count and the span check have arrived with everything else
+            total = h[0];
+            if (h[1]) return fail(ctx, KMERS_E_BADARG, "a span reaches outside the pool (or holds 2^32 symbols or more)");
+            if (res) res->n_out = total;
+            if (total > capacity) {
+                if (res) res->status = KMERS_E_CAPACITY;
+                return fail(ctx, KMERS_E_CAPACITY, "output capacity too small");
+            }
+            if (total == 0) return KMERS_OK;
+            a.n_elems = total;
+        }
         have_result = out_dev && ctx->h_result[2] == 0;
         if (ctx->h_result[2]) {  // some tiles are left: the recode pass and the general launch for them
             if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;

@@ -80,6 +80,8 @@ struct RaggedArgs {
     const RaggedTile *tiles;     // [n_tiles]
     uint64_t n_records;
     uint64_t n_elems;
+    const uint64_t *n_elems_ptr; // non-NULL: the element count is still on its way when the launch is enqueued (batch_api.hip, the call without a
+    uint64_t capacity;           //   host round trip): read it here; a count above `capacity` (the grid was sized for that) writes nothing
     uint64_t *out_a;             // FW: forward kmers, CANON: canonical kmers
     uint64_t *out_b;             // FW: reverse complements (nullable), CANON: fx_hash (nullable)
     uint64_t seed;
@@ -128,11 +130,16 @@ __global__ __launch_bounds__(256) void ragged_count_kernel(const RaggedSpan *__r
 // One descriptor per tile.  owner(e) = the LAST record i with off[i] <= e (records that own nothing share
 // their offset with the next one and are skipped by "last").
 __global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *__restrict__ off, const RaggedSpan *__restrict__ spans,
-                                                            uint64_t n, uint64_t n_tiles, uint64_t n_elems, uint32_t tile,
-                                                            uint32_t k, uint32_t step, uint32_t dst_bits, uint64_t stream_origin,
+                                                            uint64_t n, uint64_t n_tiles, uint64_t n_elems_arg, const uint64_t *__restrict__ n_elems_ptr,
+                                                            uint32_t tile, uint32_t k, uint32_t step, uint32_t dst_bits, uint64_t stream_origin,
                                                             RaggedTile *__restrict__ tiles) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t >= n_tiles) return;
+    const uint64_t n_elems = n_elems_ptr ? *n_elems_ptr : n_elems_arg;
+    if (t * tile >= n_elems) {  // (a grid sized for the caller's capacity: tiles past the real count)
+        tiles[t] = RaggedTile{0, 0, 0, 0, 0, 0};
+        return;
+    }
     auto owner = [&](uint64_t e, uint64_t lo, bool near) -> uint64_t {  // off[lo] <= e; near: the answer is a few records ahead
         uint64_t hi = n;
         if (near) {
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *__res
     const uint64_t e_last = (e0 + tile < n_elems ? e0 + tile : n_elems) - 1;
     const uint64_t r_lo = owner(e0, 0, false);
     const uint64_t r_hi = owner(e_last, r_lo, true);
-    const uint64_t r_next = t + 1 < n_tiles ? owner(e_last + 1, r_hi, true) : n - 1;  // the last tile's slice ends with off[n]
+    const uint64_t r_next = e_last + 1 < n_elems ? owner(e_last + 1, r_hi, true) : n - 1;  // the last tile's slice ends with off[n]
     const uint64_t want = r_next - r_lo + 2;
     RaggedTile d;
     d.r_lo = (uint32_t)r_lo;
@@ -477,9 +484,11 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
     long long rg_t0 = 0;
 #endif
     RG_PROBE(0);
+    const uint64_t n_elems = a.n_elems_ptr ? *a.n_elems_ptr : a.n_elems;
+    if (e0 >= n_elems || (a.n_elems_ptr && n_elems > a.capacity)) return;  // (a grid sized for the caller's capacity; a count beyond it: KMERS_E_CAPACITY)
     const RaggedTile d = a.tiles[tile];
     const uint64_t r_lo = d.r_lo;
-    const uint64_t e_last = (e0 + a.tile < a.n_elems ? e0 + a.tile : a.n_elems) - 1;
+    const uint64_t e_last = (e0 + a.tile < n_elems ? e0 + a.tile : n_elems) - 1;
     if constexpr (N == 1 && VEC) {
         // dense tiles (comment above ragged_dense_tile): one-word kmers, aligned outputs, consecutive windows, a pool without flagged symbols
         if constexpr (DST == 2) {

@@ -558,3 +558,67 @@ def test_batch_dense_tiles_equal_the_general_path_and_the_oracle(km, ctx, orc, s
             assert np.array_equal(got[0][0], got[-1][0]) and np.array_equal(got[0][1], got[-1][1])
     ctx.set_param(cap.PARAM_BATCH_DENSE, 0)
     ctx.set_param(cap.PARAM_BATCH_PASSES, 0)
+
+
+def test_batch_with_device_outputs_waits_once_and_still_reports_everything(km, ctx, orc):
+    """Device outputs and a sane capacity: the call sizes its layout for the CAPACITY and reads the element count on the device (no
+    host round trip between the scan and the element kernel, csrc/batch_api.hip).  Same elements, the true count in res.n_out,
+    nothing written beyond it; a capacity that is too small, a span outside the pool, an ambiguous symbol and a batch without any
+    element are still reported as before."""
+    cap = km._capi
+    rng = np.random.default_rng(77)
+    K = 31
+    texts = [naive.random_text(rng, int(l)) for l in rng.integers(40, 300, 6000)]
+    texts[17] = "ACGT"                                         # (a record shorter than K: one tile leaves the dense path)
+    words, spans, n_pool = build_pool(texts, 4, rng, False)
+    ea, eb, eoff = expected(orc, texts, 4, 2, K, cap.BATCH_CANONICAL, 5)
+    total = int(eoff[-1])
+    d_w = ctx.alloc(words.nbytes + 16)
+    ctx.h2d(d_w, words)
+    room = total + 70_000
+    d_a, d_b = ctx.alloc(room * 8), ctx.alloc(room * 8)
+    seq = cap.Seq(d_w, n_pool, 0, 0, 4, 0)
+    res = cap.Result()
+    sentinel = np.full(room, 0x5A5A5A5A5A5A5A5A, np.uint64)
+    for capacity in (total, total + 1, room):                  # exact, and two upper bounds (a grid with tiles past the count)
+        ctx.h2d(d_a, sentinel)
+        ctx.h2d(d_b, sentinel)
+        off = np.zeros(len(texts) + 1, np.uint64)
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, K, 2, d_a, d_b, 5, vp(off), capacity,
+                                 cap.MEM_DEVICE, C.byref(res))
+        assert rc == 0 and res.n_out == total and np.array_equal(off, eoff), (capacity, ctx.last_error())
+        a, b = np.zeros(room, np.uint64), np.zeros(room, np.uint64)
+        ctx.d2h(a, d_a)
+        ctx.d2h(b, d_b)
+        assert np.array_equal(a[:total], ea[:, 0]) and np.array_equal(b[:total], eb), capacity
+        assert np.all(a[total:] == sentinel[total:]) and np.all(b[total:] == sentinel[total:]), capacity
+    # too small: the count needed comes back, nothing is written
+    ctx.h2d(d_a, sentinel)
+    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, len(texts), cap.BATCH_CANONICAL, K, 2, d_a, d_b, 5, None, total - 1, cap.MEM_DEVICE,
+                             C.byref(res))
+    assert rc == cap.E_CAPACITY and res.n_out == total
+    a = np.zeros(room, np.uint64)
+    ctx.d2h(a, d_a)
+    assert np.all(a == sentinel)
+    # a span that reaches outside the pool
+    bad = (cap.Span * len(texts))(*[cap.Span(s.first_base, s.n_bases) for s in spans])
+    bad[100] = cap.Span(n_pool - 5, 50)
+    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), bad, len(texts), cap.BATCH_CANONICAL, K, 2, d_a, d_b, 5, None, room, cap.MEM_DEVICE, C.byref(res))
+    assert rc == cap.E_BADARG and "outside the pool" in ctx.last_error()
+    # an ambiguous symbol: the first failing record and the position inside it
+    amb = list(texts)
+    amb[4000] = amb[4000][:33] + "N" + amb[4000][34:]
+    w2, s2, n2 = build_pool(amb, 4, rng, False)
+    ctx.h2d(d_w, w2)
+    seq2 = cap.Seq(d_w, n2, 0, 0, 4, 0)
+    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq2), s2, len(amb), cap.BATCH_CANONICAL, K, 2, d_a, d_b, 5, None, room, cap.MEM_DEVICE, C.byref(res))
+    assert rc == cap.E_ENCODE and res.n_out == 4000 and res.err_pos == 34, (rc, res.n_out, res.err_pos)
+    # no record long enough: nothing to do, status 0
+    short = ["ACGTACGT"] * 50
+    w3, s3, n3 = build_pool(short, 4, rng, False)
+    ctx.h2d(d_w, w3)
+    seq3 = cap.Seq(d_w, n3, 0, 0, 4, 0)
+    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq3), s3, len(short), cap.BATCH_CANONICAL, K, 2, d_a, d_b, 5, None, 1000, cap.MEM_DEVICE, C.byref(res))
+    assert rc == 0 and res.n_out == 0
+    for d in (d_w, d_a, d_b):
+        ctx.free(d)
