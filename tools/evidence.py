@@ -112,6 +112,12 @@ def main():
             traffic = f"{tot / 1e9:.3f} GB / {alg / 1e9:.3f} GB = {tot / alg:.3f}"
         fr = lambda t: f"{alg / t / 1e6 / 8000:.3f}" if alg and t else "-"
         rows.append(f"| {label} | `{best['Name'][:70]}` | {best['Calls']} | {ms:.4f} | {fr(ms)} | {ev_ms if ev_ms else '-'} | {fr(ev_ms)} | {traffic} |")
+    if copy(os.path.join(E, "kernel_stats_minhash_batch.csv"), f"{RND}_kernel_stats_minhash_batch.csv"):
+        try:
+            lines = [l.strip() for l in open(os.path.join(E, "stats_minhash_batch.txt")) if "records" in l or "genomes" in l or "reads" in l]
+            rows += ["", f"`kmers_minhash_batch` (`tools/sketch_batch_rate.py`; its kernels: `profiles/{RND}_kernel_stats_minhash_batch.csv`):", ""] + ["    " + l for l in lines[:8]]
+        except OSError:
+            pass
     # the headline launch by allocator
     sweep = []
     for f in sorted(glob.glob(os.path.join(E, "alloc_*.json"))):

@@ -35,6 +35,10 @@ rm -rf "$E/stats_batch"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$E/pmc_${c}_batch" -- python3 "$ROOT/tools/batch_once.py" --reps 2 > "$E/pmc_${c}_batch.txt" 2>&1
 done
+# kmers_minhash_batch (one sketch per record, three batch shapes): its kernels in one trace
+rocprofv3 --kernel-trace --stats --output-format csv -d "$E/stats_mhb" -- python3 "$ROOT/tools/sketch_batch_rate.py" > "$E/stats_minhash_batch.txt" 2>&1
+find "$E/stats_mhb" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$E/kernel_stats_minhash_batch.csv"
+rm -rf "$E/stats_mhb"
 # where the headline's arrays come from: the class pool (default), the arena of rounds 3-4 at three sizes, plain allocations
 cd "$ROOT"
 for mode in "--alloc pool" "--alloc arena --arena-gb 32" "--alloc arena --arena-gb 64" "--alloc arena --arena-gb 230" "--alloc plain"; do
