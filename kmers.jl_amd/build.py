@@ -17,10 +17,10 @@ LIB = os.path.join(CSRC, "libkmers_hip.so")
 SOURCES = ["iterators_api.hip", "consumers_api.hip", "unambiguous_api.hip", "batch_api.hip", "elementwise_api.hip", "context_api.hip",
            "memory_api.hip", "pool_api.hip", "comm_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-array-bounds"]
-# the look-back of unambiguous_kernel.hpp gives up instead of hanging the device; this build provokes it (one tile never
-# publishes its count) so that the abort / drain path and the host's KMERS_E_HIP are exercised once on hardware
+# the look-backs of unambiguous_kernel.hpp and scan_kernels.hpp give up instead of hanging the device; this build provokes it (one
+# tile / segment never publishes its count) so that the abort / drain path and the host's KMERS_E_HIP are exercised once on hardware
 TEST_ABORT_LIB = os.path.join(CSRC, "libkmers_hip_testabort.so")
-TEST_ABORT = ("testabort", ["-DKMERS_TEST_ABORT"], ["unambiguous_api.hip"])
+TEST_ABORT = ("testabort", ["-DKMERS_TEST_ABORT"], ["unambiguous_api.hip", "batch_api.hip"])
 
 
 def hipcc():

@@ -108,30 +108,58 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         if (out_offsets) out_offsets[0] = 0;
         return KMERS_OK;
     }
-    const uint64_t n_seg = (n + SCAN_SEG - 1) / SCAN_SEG;
-    const size_t span_bytes = (size_t)n * 16, cnt_bytes = ((size_t)n * 4 + 15) & ~(size_t)15, off_bytes = ((size_t)n + 1) * 8,
-                 seg_bytes = ((size_t)n_seg + 2) * 8;
+    const uint64_t n_seg = (n + (uint64_t)LAYOUT_CHUNK * LAYOUT_CHUNKS - 1) / ((uint64_t)LAYOUT_CHUNK * LAYOUT_CHUNKS);  // segments of the layout pass
+    const size_t span_bytes = (size_t)n * 16, off_bytes = ((size_t)n + 1) * 8;
     const bool spans_dev = (flags & KMERS_SPANS_DEVICE) != 0;
-    if (int rc = ensure_stage(ctx, 3, span_bytes + cnt_bytes + off_bytes + seg_bytes)) return rc;
+    if (int rc = ensure_stage(ctx, 3, span_bytes + off_bytes)) return rc;
     char *meta = static_cast<char *>(ctx->stage[3]);
     const RaggedSpan *d_spans = spans_dev ? reinterpret_cast<const RaggedSpan *>(spans) : reinterpret_cast<const RaggedSpan *>(meta);
-    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(meta + span_bytes);
-    uint64_t *d_off = reinterpret_cast<uint64_t *>(meta + span_bytes + cnt_bytes);
-    uint64_t *d_seg = reinterpret_cast<uint64_t *>(meta + span_bytes + cnt_bytes + off_bytes);  // [n_seg + 1], then the bad-span flag
-    uint64_t *d_bad = d_seg + n_seg + 1;
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(meta + span_bytes);
     if (!spans_dev) HIP_TRY(ctx, hipMemcpyAsync(meta, spans, span_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
-    {
-        dim3 g((unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->n_cus * 16)), b(256);
-        hipLaunchKernelGGL(ragged_count_kernel, g, b, 0, ctx->stream, d_spans, n, (uint32_t)k, (uint32_t)stride, pool->n_bases, d_cnt, d_bad);
-        hipLaunchKernelGGL(scan_segment_sums_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, d_cnt, n, d_seg);
-        hipLaunchKernelGGL(scan_segments_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_seg, n_seg);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, d_cnt, n, d_seg, n_seg, d_off);
-        HIP_TRY(ctx, hipGetLastError());
+    // one kernel, nothing cleared before it (scan_kernels.hpp): descriptors tagged with the call's epoch, a ticket counter that only grows
+    if (ctx->layout_segs < n_seg) {
+        if (ctx->d_layout) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_layout);
+            ctx->d_layout = nullptr;
+            ctx->layout_segs = 0;
+        }
+        const size_t segs = std::max<uint64_t>(n_seg + n_seg / 2, 4096);
+        HIP_TRY(ctx, hipMalloc(&ctx->d_layout, (4 + 2 * segs) * 8));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_layout, 0, (4 + 2 * segs) * 8, ctx->stream));
+        ctx->layout_segs = segs;
+        ctx->layout_tickets = 0;
+        ctx->layout_epoch = 0;
     }
-    uint64_t *h = reinterpret_cast<uint64_t *>(ctx->h_bounce);  // pinned: [total, bad]
-    HIP_TRY(ctx, hipMemcpyAsync(h, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(h + 1, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (++ctx->layout_epoch >= LAYOUT_EPOCH_LIMIT) {  // (a billion calls on: the tags start over)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_layout + 4, 0, 2 * ctx->layout_segs * 8, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_scratch + LAYOUT_WORD_BAD, 0, 16, ctx->stream));
+        ctx->layout_epoch = 1;
+    }
+    const uint64_t epoch = ctx->layout_epoch;
+    {
+        LayoutArgs la{};
+        la.spans = d_spans;
+        la.n = n;
+        la.pool_bases = pool->n_bases;
+        la.desc = ctx->d_layout + 4;
+        la.ticket = ctx->d_layout;
+        la.ticket_base = ctx->layout_tickets;
+        la.offsets = d_off;
+        la.header = reinterpret_cast<unsigned long long *>(ctx->d_scratch);
+        la.epoch = (uint32_t)epoch;
+        la.k = (uint32_t)k;
+        la.step = (uint32_t)stride;
+        hipLaunchKernelGGL(ragged_layout_kernel<LAYOUT_CHUNKS>, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, la);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->layout_tickets += n_seg;
+    }
+    uint64_t *const h = ctx->h_result;  // pinned; words 2..5 = [tiles left over, element count, bad span, look-back gave up]
+    auto layout_verdict = [&]() -> int {
+        if (h[LAYOUT_WORD_ABORT] == epoch) return fail(ctx, KMERS_E_HIP, "kmers_batch: the layout pass gave up waiting for a segment");
+        if (h[LAYOUT_WORD_BAD] == epoch) return fail(ctx, KMERS_E_BADARG, "a span reaches outside the pool (or holds 2^32 symbols or more)");
+        return KMERS_OK;
+    };
     if (out_offsets) HIP_TRY(ctx, hipMemcpyAsync(out_offsets, d_off, off_bytes, hipMemcpyDeviceToHost, ctx->stream));
     // The element count decides the tile layout, and waiting for it costs the call a host round trip in the middle (the device
     // idles between the scan and the element kernel).  A caller that passes device outputs and a sane capacity -- the count it
@@ -143,9 +171,10 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
                           capacity <= 2 * pool->n_bases + n;
     uint64_t total = capacity;  // (deferred: what the layout is sized for; the real count arrives with the final wait)
     if (!deferred) {
+        HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_scratch, 48, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        total = h[0];
-        if (h[1]) return fail(ctx, KMERS_E_BADARG, "a span reaches outside the pool (or holds 2^32 symbols or more)");
+        if (int rc = layout_verdict()) return rc;
+        total = h[LAYOUT_WORD_TOTAL];
         if (res) res->n_out = total;
         if (total > capacity || (!out_a && !out_b)) {
             if (total > capacity && (out_a || out_b)) {
@@ -182,10 +211,6 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     const uint64_t *src0 = st.d_words + (st.first_bit >> 6);        // word that holds pool symbol 0
     const uint64_t origin = (st.first_bit & 63u) / (uint64_t)sb;     // its symbol offset inside that word
     const uint64_t n_src_words = ((origin + pool->n_bases) * (uint64_t)sb + 63) / 64;
-    if (!wide)
-        hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_spans, n, n_tiles,
-                           total, deferred ? d_off + n : nullptr, tile_elems, (uint32_t)k, (uint32_t)stride, (uint32_t)dst_bits, origin, d_tiles);
-    HIP_TRY(ctx, hipGetLastError());
 
     RaggedArgs a{};
     a.rec_off = d_off;
@@ -210,6 +235,12 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     const bool optimistic = !wide && sb == 4 && dst_bits == 2 && nw == 1 && stride == 1 && !(flags & KMERS_BATCH_SKIP) && ctx->batch_dense >= 0 &&
                             tile_elems <= (uint32_t)(RG_MAX_PASSES * RG_UNIT);
     unsigned long long *d_redo = reinterpret_cast<unsigned long long *>(ctx->d_scratch + 2);
+    if (!wide)  // (the optimistic launch's status bytes and redo count are cleared by this kernel on its way)
+        hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_spans, n, n_tiles,
+                           total, deferred ? d_off + n : nullptr, tile_elems, (uint32_t)k, (uint32_t)stride, (uint32_t)dst_bits, origin, d_tiles,
+                           optimistic ? d_status : nullptr, optimistic ? d_redo : nullptr, deferred ? d_off + n : nullptr,
+                           reinterpret_cast<const unsigned long long *>(ctx->d_scratch + LAYOUT_WORD_ABORT), epoch);
+    HIP_TRY(ctx, hipGetLastError());
     PoolStream ps;
     if (!optimistic) {
         if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;
@@ -220,8 +251,6 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         a.src4 = src0;
         a.tile_status = d_status;
         a.redo_count = d_redo;
-        HIP_TRY(ctx, hipMemsetAsync(d_status, 0, (size_t)n_tiles, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(d_redo, 0, 8, ctx->stream));
     }
 
     uint64_t *d_a = out_a, *d_b = out_b;
@@ -267,12 +296,12 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     } else if (optimistic) {
         RGM(2, 1);
         HIP_TRY(ctx, hipGetLastError());
-        // (scratch words 0..2 in one copy: with device-resident outputs this is the call's only wait when no tile is left)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_scratch, 24, hipMemcpyDeviceToHost, ctx->stream));
+        // (scratch words 0..5 in one copy: with device-resident outputs this is the call's only wait when no tile is left)
+        HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_scratch, 48, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (deferred) {  // the count and the span check have arrived with everything else
-            total = h[0];
-            if (h[1]) return fail(ctx, KMERS_E_BADARG, "a span reaches outside the pool (or holds 2^32 symbols or more)");
+            if (int rc = layout_verdict()) return rc;
+            total = h[LAYOUT_WORD_TOTAL];
             if (res) res->n_out = total;
             if (total > capacity) {
                 if (res) res->status = KMERS_E_CAPACITY;

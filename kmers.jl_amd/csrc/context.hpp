@@ -38,12 +38,18 @@ struct kmers_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    uint64_t *d_scratch = nullptr;        // 64 words of device scratch; word 0: reduction result, word 1: the error slot
+    uint64_t *d_scratch = nullptr;        // 64 words of device scratch; word 0: reduction result, 1: the error slot, 2-5: kmers_batch (batch_api.hip); zeroed at creation
     unsigned long long *d_err = nullptr;  // = d_scratch + 1: first offending symbol (0-based), ~0 = none
     uint64_t *h_result = nullptr;         // pinned, 16 words: 0..1 mirror of scratch words 0..1 (one small D2H copy per call), 2..7 per-call
                                           // read-backs of the synchronous entry points, 8..10 the asynchronous kmers_unambiguous
     char *h_bounce = nullptr;             // pinned bounce buffer for short host-pointer calls (FASTA-record sized):
                                           // [0, BOUNCE_IN) source words, [BOUNCE_IN, BOUNCE_IN + BOUNCE_OUT) outputs
+    // kmers_batch's layout pass (scan_kernels.hpp): [ticket counter, 3 spare words][descriptors: 2 words per segment], zeroed when
+    // allocated; the counter only grows (layout_tickets: its value on the host), a descriptor word counts only with this call's epoch
+    unsigned long long *d_layout = nullptr;
+    size_t layout_segs = 0;
+    uint64_t layout_tickets = 0;
+    uint32_t layout_epoch = 0;
     uint64_t *d_recent = nullptr;         // MinHash: table of recently appended candidate hashes (RECENT_SLOTS entries)
     void *stage[8] = {};      // 0 source, 1-2 outputs, 3 metadata / scratch, 4-5 recoded stream / flags, 6 tile index, 7 RCCL scratch
     size_t stage_cap[8] = {};

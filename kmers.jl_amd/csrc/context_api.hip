@@ -96,7 +96,7 @@ int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out) {
     if (hipMalloc(&ctx->d_scratch, 64 * 8) != hipSuccess || hipHostMalloc(&ctx->h_result, 128, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(&ctx->h_bounce, BOUNCE_IN + BOUNCE_OUT, hipHostMallocDefault) != hipSuccess ||
         (ctx->d_err = reinterpret_cast<unsigned long long *>(ctx->d_scratch + 1)) == nullptr ||
-        hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream) != hipSuccess ||
+        hipMemsetAsync(ctx->d_scratch, 0, 64 * 8, ctx->stream) != hipSuccess || hipMemsetAsync(ctx->d_err, 0xFF, 8, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
         kmers_ctx_destroy(ctx);
         return KMERS_E_HIP;
@@ -115,6 +115,7 @@ void kmers_ctx_destroy(kmers_ctx *ctx) {
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
     if (ctx->d_recent) (void)hipFree(ctx->d_recent);
+    if (ctx->d_layout) (void)hipFree(ctx->d_layout);
     for (auto &e : ctx->cal_events)
         if (e) (void)hipEventDestroy(e);
     if (ctx->copy_stream) {

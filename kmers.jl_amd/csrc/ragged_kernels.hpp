@@ -109,46 +109,58 @@ struct RecodeArgs {
     uint32_t ascii_table;
 };
 
-// ---- the ragged layout, computed on the device (a batch may hold tens of millions of records) ------
-// elements per record (FwKmers.jl:40-43) for the scan kernels of unambiguous_kernel.hpp; bad[0] != 0 if a
-// span reaches outside the pool or a record is too long for the 32-bit count
-__global__ __launch_bounds__(256) void ragged_count_kernel(const RaggedSpan *__restrict__ spans, uint64_t n, uint32_t k,
-                                                            uint32_t step, uint64_t pool_bases, uint32_t *__restrict__ counts,
-                                                            uint64_t *__restrict__ bad) {
-    const uint64_t stride = (uint64_t)gridDim.x * 256u;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
-        const RaggedSpan sp = spans[i];
-        if (sp.first_base > pool_bases || sp.n_bases > pool_bases - sp.first_base || sp.n_bases >= 0xFFFFFFFFull) {
-            bad[0] = 1;
-            counts[i] = 0;
-        } else {
-            counts[i] = sp.n_bases < k ? 0u : (uint32_t)((sp.n_bases - k) / step + 1u);  // FwKmers.jl:40-43, SpacedKmers.jl:38-42
-        }
-    }
-}
-
-// One descriptor per tile.  owner(e) = the LAST record i with off[i] <= e (records that own nothing share
+// ---- the ragged layout, computed on the device (a batch may hold tens of millions of records): scan_kernels.hpp turns the spans
+// into element offsets; then one descriptor per tile.  owner(e) = the LAST record i with off[i] <= e (records that own nothing share
 // their offset with the next one and are skipped by "last").
-__global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *__restrict__ off, const RaggedSpan *__restrict__ spans,
-                                                            uint64_t n, uint64_t n_tiles, uint64_t n_elems_arg, const uint64_t *__restrict__ n_elems_ptr,
+__global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *off, const RaggedSpan *__restrict__ spans,
+                                                            uint64_t n, uint64_t n_tiles, uint64_t n_elems_arg, const uint64_t *n_elems_ptr,
                                                             uint32_t tile, uint32_t k, uint32_t step, uint32_t dst_bits, uint64_t stream_origin,
-                                                            RaggedTile *__restrict__ tiles) {
+                                                            RaggedTile *__restrict__ tiles, uint8_t *__restrict__ status,
+                                                            unsigned long long *__restrict__ redo_count, uint64_t *count_slot,
+                                                            const unsigned long long *__restrict__ abort_word, uint64_t epoch) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t >= n_tiles) return;
+    // (a call that learns the verdict of its layout pass only at its end, batch_api.hip: if the look-back gave up, the element count
+    // the element kernel is about to read becomes one that no capacity holds, and it writes nothing)
+    if (count_slot && t == 0 && *abort_word == epoch) *count_slot = ~0ull;
+    // (the optimistic launch's status bytes and its count of tiles left over start at zero: cleared here, on the way, instead of by
+    // two fills of their own)
+    if (status) status[t] = 0;
+    if (redo_count && t == 0) *redo_count = 0;
     const uint64_t n_elems = n_elems_ptr ? *n_elems_ptr : n_elems_arg;
     if (t * tile >= n_elems) {  // (a grid sized for the caller's capacity: tiles past the real count)
         tiles[t] = RaggedTile{0, 0, 0, 0, 0, 0};
         return;
     }
-    auto owner = [&](uint64_t e, uint64_t lo, bool near) -> uint64_t {  // off[lo] <= e; near: the answer is a few records ahead
-        uint64_t hi = n;
-        if (near) {
-            uint64_t step = 1;
-            while (lo + step < n && off[lo + step] <= e) {
-                lo += step;
-                step <<= 1;
+    // off[0] = 0 <= e < off[n] = n_elems.  The search starts from a HINT and gallops away from it in doubling steps before it
+    // bisects: reads of one length put the hint (e's share of the records) on the owner or beside it -- two or three dependent loads
+    // where the bisection of 8 M offsets took 23, three times per tile (30 us for 93 k tiles, all of it latency).
+    auto owner = [&](uint64_t e, uint64_t hint) -> uint64_t {
+        uint64_t lo, hi, hop = 1;  // off[lo] <= e < off[hi]
+        if (off[hint] <= e) {
+            lo = hint;
+            hi = n;
+            while (lo + hop < n) {
+                if (off[lo + hop] <= e) {
+                    lo += hop;
+                    hop <<= 1;
+                } else {
+                    hi = lo + hop;
+                    break;
+                }
             }
-            if (lo + step < n) hi = lo + step;
+        } else {
+            hi = hint;
+            lo = 0;
+            while (hi > hop) {
+                if (off[hi - hop] > e) {
+                    hi -= hop;
+                    hop <<= 1;
+                } else {
+                    lo = hi - hop;
+                    break;
+                }
+            }
         }
         while (hi - lo > 1) {
             const uint64_t mid = (lo + hi) >> 1;
@@ -157,11 +169,15 @@ __global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *__res
         }
         return lo;
     };
+    auto share = [&](uint64_t e) -> uint64_t {  // the record that would own e if all records were equally long
+        const uint64_t g = (uint64_t)((double)e / (double)n_elems * (double)n);
+        return g < n ? g : n - 1;
+    };
     const uint64_t e0 = t * tile;
     const uint64_t e_last = (e0 + tile < n_elems ? e0 + tile : n_elems) - 1;
-    const uint64_t r_lo = owner(e0, 0, false);
-    const uint64_t r_hi = owner(e_last, r_lo, true);
-    const uint64_t r_next = e_last + 1 < n_elems ? owner(e_last + 1, r_hi, true) : n - 1;  // the last tile's slice ends with off[n]
+    const uint64_t r_lo = owner(e0, share(e0));
+    const uint64_t r_hi = owner(e_last, share(e_last) > r_lo ? share(e_last) : r_lo);
+    const uint64_t r_next = e_last + 1 < n_elems ? owner(e_last + 1, r_hi) : n - 1;  // the last tile's slice ends with off[n]
     const uint64_t want = r_next - r_lo + 2;
     RaggedTile d;
     d.r_lo = (uint32_t)r_lo;

@@ -622,3 +622,86 @@ def test_batch_with_device_outputs_waits_once_and_still_reports_everything(km, c
     assert rc == 0 and res.n_out == 0
     for d in (d_w, d_a, d_b):
         ctx.free(d)
+
+
+def test_batch_layout_of_millions_of_records_in_one_kernel(km, ctx):
+    """The layout pass (csrc/scan_kernels.hpp: one kernel, segments of 4096 records chained by a decoupled look-back, descriptors
+    tagged with the call's epoch instead of being cleared): offsets of up to three million ragged records -- many of them shorter
+    than K -- equal the running sum of FwKmers.jl:40-43 / SpacedKmers.jl:38-42, call after call with batches that grow and shrink
+    (stale descriptors of earlier calls lie where the next call looks back), at stride 1 and 3."""
+    cap = km._capi
+    rng = np.random.default_rng(2025)
+    n_pool = 1 << 20
+    words = np.zeros(n_pool * 2 // 64 + 2, np.uint64)
+    seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, 2, 0)
+    res = cap.Result()
+    K = 31
+    for n, J in ((700_000, 1), (3_000_000, 1), (4097, 1), (3_000_000, 3), (1_000_001, 1), (8192, 3), (1, 1)):
+        first = rng.integers(0, n_pool - 400, n).astype(np.uint64)
+        length = rng.integers(0, 400, n).astype(np.uint64)
+        length[rng.integers(0, n, n // 50)] = 0
+        spans = np.stack([first, length], axis=1).copy()
+        want = np.zeros(n + 1, np.uint64)
+        cnt = np.where(length >= K, (length - np.uint64(K)) // np.uint64(J) + np.uint64(1), np.uint64(0))
+        np.cumsum(cnt, out=want[1:])
+        off = np.zeros(n + 1, np.uint64)
+        sp = spans.ctypes.data_as(C.POINTER(cap.Span))
+        if J == 1:
+            rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), sp, n, cap.BATCH_FW, K, 2, None, None, 0, vp(off), 0, 0, C.byref(res))
+        else:
+            rc = ctx.lib.kmers_batch_spaced(ctx.handle, C.byref(seq), sp, n, K, J, 2, None, vp(off), 0, 0, C.byref(res))
+        assert rc == 0 and res.n_out == int(want[-1]), (n, J, ctx.last_error())
+        assert np.array_equal(off, want), (n, J, int(np.flatnonzero(off != want)[0]))
+    # a span outside the pool, far into a large batch
+    spans[n // 2, 0] = n_pool
+    spans[n // 2, 1] = 1
+    rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans.ctypes.data_as(C.POINTER(cap.Span)), n, cap.BATCH_FW, K, 2, None, None, 0, None, 0, 0,
+                             C.byref(res))
+    assert rc == cap.E_BADARG and "outside the pool" in ctx.last_error()
+
+
+def test_batch_layout_gives_up_instead_of_hanging(km):
+    """The give-up path of the layout pass's look-back (scan_kernels.hpp: LAYOUT_SPIN_LIMIT, the abort word) cannot be provoked on a
+    healthy device, so the TEST BUILD of the library provokes it (libkmers_hip_testabort.so, -DKMERS_TEST_ABORT: segment 1 never
+    publishes anything).  A size query and a call with device outputs (which learns the verdict only at its end: the element kernel
+    must have written nothing) both come back with KMERS_E_HIP, and the same context serves a batch of one segment right behind
+    them.  A fresh process: one library per process."""
+    import os
+    import subprocess
+    import sys
+    from kmers_jl_amd import build
+    lib = build.TEST_ABORT_LIB
+    assert os.path.exists(lib), "run __graft_entry__.build() first: it builds the test library next to the product"
+    code = r'''
+import ctypes as C, sys
+import numpy as np
+import kmers_jl_amd as km
+cap = km._capi
+ctx = km.Context(0)
+n, rl, K = 20_000, 100, 31                   # five segments of 4096 records: segments 2.. wait for segment 1
+n_pool = n * rl
+nw = n_pool // 16 + 1
+d_w = ctx.alloc(nw * 8 + 8)
+ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, 3, 0, nw, 4, 0, d_w), "synth")
+spans = np.stack([np.arange(n, dtype=np.uint64) * np.uint64(rl), np.full(n, rl, np.uint64)], axis=1).copy()
+sp = spans.ctypes.data_as(C.POINTER(cap.Span))
+total = n * (rl - K + 1)
+d_a, d_b = ctx.alloc(total * 8), ctx.alloc(total * 8)
+sentinel = np.full(total, 0x5A5A5A5A5A5A5A5A, np.uint64)
+ctx.h2d(d_a, sentinel)
+seq = cap.Seq(d_w, n_pool, 0, 0, 4, 0)
+res = cap.Result()
+rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), sp, n, cap.BATCH_CANONICAL, K, 2, None, None, 0, None, 0, cap.MEM_DEVICE, C.byref(res))
+assert rc == cap.E_HIP and "gave up" in ctx.last_error(), (rc, ctx.last_error())
+rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), sp, n, cap.BATCH_CANONICAL, K, 2, d_a, d_b, 0, None, total, cap.MEM_DEVICE, C.byref(res))
+assert rc == cap.E_HIP and "gave up" in ctx.last_error(), (rc, ctx.last_error())
+a = np.zeros(total, np.uint64)
+ctx.d2h(a, d_a)
+assert np.all(a == sentinel)
+rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), sp, 4096, cap.BATCH_CANONICAL, K, 2, d_a, d_b, 0, None, total, cap.MEM_DEVICE, C.byref(res))
+assert rc == 0 and res.n_out == 4096 * (rl - K + 1), (rc, ctx.last_error())
+print("ok", res.n_out)
+'''
+    env = dict(os.environ, KMERS_HIP_LIB=lib, PYTHONPATH=os.pathsep.join(sys.path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout, r.stderr[-2000:])
