@@ -218,8 +218,6 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     a.tiles = d_tiles;
     a.n_records = n;
     a.n_elems = total;
-    a.n_elems_ptr = deferred ? d_off + n : nullptr;
-    a.capacity = capacity;
     a.seed = seed;
     a.err_slot = ctx->d_err;
     a.k = (uint32_t)k;
@@ -238,8 +236,8 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     if (!wide)  // (the optimistic launch's status bytes and redo count are cleared by this kernel on its way)
         hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_spans, n, n_tiles,
                            total, deferred ? d_off + n : nullptr, tile_elems, (uint32_t)k, (uint32_t)stride, (uint32_t)dst_bits, origin, d_tiles,
-                           optimistic ? d_status : nullptr, optimistic ? d_redo : nullptr, deferred ? d_off + n : nullptr,
-                           reinterpret_cast<const unsigned long long *>(ctx->d_scratch + LAYOUT_WORD_ABORT), epoch);
+                           optimistic ? d_status : nullptr, optimistic ? d_redo : nullptr,
+                           reinterpret_cast<const unsigned long long *>(ctx->d_scratch + LAYOUT_WORD_ABORT), epoch, capacity);
     HIP_TRY(ctx, hipGetLastError());
     PoolStream ps;
     if (!optimistic) {

@@ -46,10 +46,13 @@ struct RaggedTile {              // one per tile, written by the layout pass: ev
     uint64_t q_lo;               // ALL of its loads at once (slice of the record table, stream words, flag words).
     uint64_t f_lo;               // Stream words [q_lo, q_lo + n_words) and flag words [f_lo, f_lo + n_fwords) hold the windows
     uint32_t r_lo;               // of the tile's first and last element and what lies between them in the pool; n_words = 0
-    uint32_t n_slots;            // if that stretch is not ascending or longer than RG_STAGE words.  r_lo: the record that
-    uint32_t n_words;            // owns the tile's first element; n_slots: record slots to stage (up to the owner of the next
-    uint32_t n_fwords;           // tile's first element, plus one; at most RG_SLOTS + 1).
+    uint32_t n_el;               // if that stretch is not ascending or longer than RG_STAGE words.  r_lo: the record that
+    uint16_t n_slots;            // owns the tile's first element; n_slots: record slots to stage (up to the owner of the next
+    uint16_t n_words;            // tile's first element, plus one; at most RG_SLOTS + 1).  n_el: the tile's elements -- 0 for
+    uint16_t n_fwords;           // a tile past the batch's end (a grid sized for the caller's capacity), or when the batch does
+    uint16_t unused;             // not fit that capacity: the element kernel never has to wait for the count itself.
 };
+static_assert(sizeof(RaggedTile) == 32 && RG_SLOTS + 1 < 65536 && RG_STAGE < 65536, "one 32-byte descriptor per tile");
 
 #ifdef KMERS_RG_PROBE  // diagnostic build only (tools/ragged_probe.py): time stamps of the kernel's phases, lane 0 of every wavefront
 __device__ unsigned long long rg_probe[16];
@@ -80,8 +83,6 @@ struct RaggedArgs {
     const RaggedTile *tiles;     // [n_tiles]
     uint64_t n_records;
     uint64_t n_elems;
-    const uint64_t *n_elems_ptr; // non-NULL: the element count is still on its way when the launch is enqueued (batch_api.hip, the call without a
-    uint64_t capacity;           //   host round trip): read it here; a count above `capacity` (the grid was sized for that) writes nothing
     uint64_t *out_a;             // FW: forward kmers, CANON: canonical kmers
     uint64_t *out_b;             // FW: reverse complements (nullable), CANON: fx_hash (nullable)
     uint64_t seed;
@@ -116,20 +117,20 @@ __global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *off, 
                                                             uint64_t n, uint64_t n_tiles, uint64_t n_elems_arg, const uint64_t *n_elems_ptr,
                                                             uint32_t tile, uint32_t k, uint32_t step, uint32_t dst_bits, uint64_t stream_origin,
                                                             RaggedTile *__restrict__ tiles, uint8_t *__restrict__ status,
-                                                            unsigned long long *__restrict__ redo_count, uint64_t *count_slot,
-                                                            const unsigned long long *__restrict__ abort_word, uint64_t epoch) {
+                                                            unsigned long long *__restrict__ redo_count,
+                                                            const unsigned long long *__restrict__ abort_word, uint64_t epoch, uint64_t capacity) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t >= n_tiles) return;
-    // (a call that learns the verdict of its layout pass only at its end, batch_api.hip: if the look-back gave up, the element count
-    // the element kernel is about to read becomes one that no capacity holds, and it writes nothing)
-    if (count_slot && t == 0 && *abort_word == epoch) *count_slot = ~0ull;
     // (the optimistic launch's status bytes and its count of tiles left over start at zero: cleared here, on the way, instead of by
     // two fills of their own)
     if (status) status[t] = 0;
     if (redo_count && t == 0) *redo_count = 0;
+    // A call that learns the count and the verdict of its layout pass only at its end (batch_api.hip: n_elems_ptr, abort_word): tiles
+    // past the real count hold nothing (the grid was sized for the caller's capacity); nor does any tile if the batch does not fit
+    // that capacity (KMERS_E_CAPACITY) or the look-back gave up (the offsets are not to be trusted) -- the element kernel writes nothing.
     const uint64_t n_elems = n_elems_ptr ? *n_elems_ptr : n_elems_arg;
-    if (t * tile >= n_elems) {  // (a grid sized for the caller's capacity: tiles past the real count)
-        tiles[t] = RaggedTile{0, 0, 0, 0, 0, 0};
+    if (t * tile >= n_elems || (n_elems_ptr && (n_elems > capacity || *abort_word == epoch))) {
+        tiles[t] = RaggedTile{};
         return;
     }
     // off[0] = 0 <= e < off[n] = n_elems.  The search starts from a HINT and gallops away from it in doubling steps before it
@@ -179,9 +180,10 @@ __global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *off, 
     const uint64_t r_hi = owner(e_last, share(e_last) > r_lo ? share(e_last) : r_lo);
     const uint64_t r_next = e_last + 1 < n_elems ? owner(e_last + 1, r_hi) : n - 1;  // the last tile's slice ends with off[n]
     const uint64_t want = r_next - r_lo + 2;
-    RaggedTile d;
+    RaggedTile d{};
     d.r_lo = (uint32_t)r_lo;
-    d.n_slots = want < (uint64_t)(RG_SLOTS + 1) ? (uint32_t)want : (uint32_t)(RG_SLOTS + 1);
+    d.n_el = (uint32_t)(e_last - e0 + 1);
+    d.n_slots = want < (uint64_t)(RG_SLOTS + 1) ? (uint16_t)want : (uint16_t)(RG_SLOTS + 1);
     const uint64_t p_lo = spans[r_lo].first_base + (e0 - off[r_lo]) * step + stream_origin;          // first symbol of the first window
     const uint64_t p_hi = spans[r_hi].first_base + (e_last - off[r_hi]) * step + k + stream_origin;  // one past the last window
     d.q_lo = (p_lo * dst_bits) >> 6;
@@ -190,8 +192,8 @@ __global__ __launch_bounds__(256) void ragged_tiles_kernel(const uint64_t *off, 
     if (p_hi > p_lo) {
         const uint64_t nw = ((p_hi * dst_bits + 63) >> 6) - d.q_lo;
         if (nw <= (uint64_t)RG_STAGE) {
-            d.n_words = (uint32_t)nw;
-            d.n_fwords = (uint32_t)(((p_hi + 63) >> 6) - d.f_lo);
+            d.n_words = (uint16_t)nw;
+            d.n_fwords = (uint16_t)(((p_hi + 63) >> 6) - d.f_lo);
         }
     }
     tiles[t] = d;
@@ -500,11 +502,12 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
     long long rg_t0 = 0;
 #endif
     RG_PROBE(0);
-    const uint64_t n_elems = a.n_elems_ptr ? *a.n_elems_ptr : a.n_elems;
-    if (e0 >= n_elems || (a.n_elems_ptr && n_elems > a.capacity)) return;  // (a grid sized for the caller's capacity; a count beyond it: KMERS_E_CAPACITY)
+    // (the descriptor says how many elements the tile holds: none past the batch's end or when the batch does not fit the caller's
+    // capacity -- the kernel itself never reads the element count, one round of dependent loads less per tile)
     const RaggedTile d = a.tiles[tile];
+    if (d.n_el == 0u) return;
     const uint64_t r_lo = d.r_lo;
-    const uint64_t e_last = (e0 + a.tile < n_elems ? e0 + a.tile : n_elems) - 1;
+    const uint64_t e_last = e0 + d.n_el - 1u;
     if constexpr (N == 1 && VEC) {
         // dense tiles (comment above ragged_dense_tile): one-word kmers, aligned outputs, consecutive windows, a pool without flagged symbols
         if constexpr (DST == 2) {
