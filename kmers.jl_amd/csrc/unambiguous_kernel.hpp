@@ -53,10 +53,23 @@ constexpr uint32_t UROUND = 1024;                // granularity of the tile leng
 // A ROUND is one keep-mask qword per lane: 4096 consecutive candidate starts of the wavefront's quarter of the tile.  Its kept
 // starts are listed in LDS in one PASS if they fit the wavefront's list, else in two passes (lanes 0-31, 32-63) or in passes of
 // 16 lanes (1024 starts: always fit).
+// Round 5, built and NOT shipped (KMERS_UINTERLEAVE=1; profiles/r05_unamb.md): a wavefront keeps TWO lists and lists its NEXT pass
+// between the stores of the frames of the current one, so that a store that finds the queue full would have had the listing in front
+// of it instead of behind it (the first of the two designs of profiles/r04_unamb.md).  Same results (the 200
+// geometries of the fuzz), and slower at every instalment size: K = 31 1.15-1.19 ms against 0.92 with the same list length and
+// 0.86 shipped; by the stamps a wavefront's listing + frames take 93 k cycles interleaved where they take 62 k one after the
+// other -- the stores do not leave room that listing could fill from inside the same wavefront.
+#ifndef KMERS_UINTERLEAVE
+#define KMERS_UINTERLEAVE 0
+#endif
 #ifndef KMERS_ULIST
-#define KMERS_ULIST 1536
+#define KMERS_ULIST (KMERS_UINTERLEAVE ? 1024 : 1536)
+#endif
+#ifndef KMERS_ULSTEP
+#define KMERS_ULSTEP 16  // entries per lane listed behind every two frames' stores
 #endif
 constexpr uint32_t ULIST = KMERS_ULIST;
+constexpr uint32_t ULISTS = KMERS_UINTERLEAVE ? 2u : 1u;  // lists per wavefront
 // The emitting path stores in FRAMES: 128 consecutive output elements, aligned to 128 in the OUTPUT index (lane l of a frame owns
 // elements 2l and 2l + 1: one 16-byte store per lane and array, 1 KiB = eight whole 128-byte lines per wave store).  The list
 // is kept frame-aligned too (slot s of the list holds the element with output index frame_base + s), so that a lane reads its
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     // flag stream (between stage and resolve of the tile ahead) and, in the same space, the per-wavefront lists of kept starts
     // of the tile being emitted: the flag stream is dead by then (the barrier behind the resolve lies between its last reader and
     // the first list entry, the barrier that opens the next front between the last list reader and the next flag)
-    constexpr uint32_t LIST_BYTES = UMODE == UMODE_COUNT ? 0u : (uint32_t)WAVES * ULSTRIDE * 2u;
+    constexpr uint32_t LIST_BYTES = UMODE == UMODE_COUNT ? 0u : (uint32_t)WAVES * ULISTS * ULSTRIDE * 2u;
     constexpr uint32_t AMB_ALLOC = AMB_QWORDS * 8u > LIST_BYTES ? AMB_QWORDS : (LIST_BYTES + 7u) / 8u;
     __shared__ uint64_t amb[AMB_ALLOC];
     uint16_t *const kept = reinterpret_cast<uint16_t *>(amb);
@@ -543,7 +556,12 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
 
         // every wavefront takes the CONTIGUOUS quarter of the tile whose keep mask its own lanes resolved, so that its stores
         // sweep one contiguous region of each output array and the mask never leaves the registers
-        uint16_t *const mine = kept + wave * ULSTRIDE;
+        // the wavefront's lists: the one being worked off begins at entry m_off, the one the next pass is listed into meanwhile
+        // (interleaved emit) at o_off -- offsets into one LDS array, not pointers that change places: those went through scratch memory
+        uint16_t *const lists = kept + wave * ULISTS * ULSTRIDE;
+        uint32_t m_off = 0, o_off = (ULISTS - 1u) * ULSTRIDE;
+#define mine (lists + m_off)
+#define other (lists + o_off)
         const uint32_t qbase = wave * WQ * 64u;                 // tile-relative start of the wavefront's quarter
         const uint64_t origin = m0 + 1 + a.index_origin;        // start of candidate r is origin + r
         uint32_t roff = tr.wave_base;                           // kept starts of the tile before the current round
@@ -601,8 +619,28 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                 UPHASE_END(4);
             }
         };
+        // The pending LISTING JOB of the interleaved emit: the kept starts of the next pass, still to be written to `other` (this
+        // lane's slots from job_o on).  list_some works off up to n entries per lane -- the low halves of all lanes first, then the
+        // high halves, exactly list_lanes' order and instructions, in instalments.
+        // (one "current half" per lane and a wave-uniform switch to the high halves: written as two symmetric branches the
+        // compiler merged them into one body over a two-element array in scratch memory, 3.6 times the kernel's time)
+        uint32_t job_cur = 0, job_nxt = 0, job_o = 0, job_s0 = 0;
+        auto list_some = [&](uint32_t n) {
+            uint32_t i = n;  // (list_lanes' loop with a budget)
+            while (job_cur != 0u && i != 0u) {
+                other[job_o++] = (uint16_t)(job_s0 + (uint32_t)__builtin_ctz(job_cur));
+                job_cur &= job_cur - 1u;
+                --i;
+            }
+            if (__ballot(job_cur != 0u) == 0) {  // every lane is through with its low half: on to the high halves
+                job_cur = job_nxt;
+                job_nxt = 0;
+                job_s0 += 32u;
+            }
+        };
         // whole frames of the list: slots [128 f0, 128 f1) -> memory, every lane two elements, no bounds (the caller checked the
-        // capacity); a lane's two entries are one aligned 32-bit word of the list
+        // capacity); a lane's two entries are one aligned 32-bit word of the list.  Behind the stores of every step: an instalment
+        // of the pending listing job (nothing if there is none).
         auto emit_frames = [&](uint32_t f0, uint32_t f1) {
             if constexpr (EMIT && !WIDE) {
                 const uint32_t *const pairs = reinterpret_cast<const uint32_t *>(mine);
@@ -660,6 +698,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                             *reinterpret_cast<ulonglong2 *>(a.out_starts + i0) = make_ulonglong2(origin + r[0], origin + r[1]);
                             *reinterpret_cast<uint4 *>(a.out_kmers + i0 + UFRAME) = make_uint4(lo[2], hi[2], lo[3], hi[3]);
                             *reinterpret_cast<ulonglong2 *>(a.out_starts + i0 + UFRAME) = make_ulonglong2(origin + r[2], origin + r[3]);
+                            if constexpr (KMERS_UINTERLEAVE) list_some(KMERS_ULSTEP);
                         }
                     }
                 }
@@ -670,6 +709,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                     cut_fw<NW>(lds, kbit0 - 2u * ra, mask, fa);
                     cut_fw<NW>(lds, kbit0 - 2u * rb, mask, fb);
                     put(frame_base + UFRAME * f + 2u * lane, ra, rb, fa, fb);
+                    if constexpr (KMERS_UINTERLEAVE) list_some(KMERS_ULSTEP / 2);
                 }
             }
         };
@@ -728,6 +768,7 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
         uint64_t rot[QPT];
 #pragma unroll
         for (uint32_t hh = 0; hh < QPT; ++hh) rot[hh] = tr.k[hh];
+        bool pre_listed = false;  // (interleaved emit) the pass about to begin is listed already
 #pragma unroll 1
         for (uint32_t h = 0; h < QPT; ++h) {
             const uint32_t r_begin = qbase + 4096u * h;  // tile-relative first start of the round
@@ -757,8 +798,11 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                     uint32_t ea, cntp;
                     const uint32_t lb = next_pass(la, excl, cnt, ea, cntp);
                     UPHASE_BEGIN();
-                    list_lanes(km, la, lb, head + list_n + excl - ea, s0);
-                    LIST_FENCE(__ATOMIC_RELEASE);
+                    if (!pre_listed) {  // (else: listed between the stores of the pass before)
+                        list_lanes(km, la, lb, head + list_n + excl - ea, s0);
+                        LIST_FENCE(__ATOMIC_RELEASE);
+                    }
+                    pre_listed = false;
                     UPHASE_END(0);
                     const uint32_t end = head + list_n + cntp;          // slots [head, end) are listed
                     uint32_t f0 = 0;
@@ -768,28 +812,76 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
                     }
                     const uint32_t f1 = end / UFRAME;                    // whole frames: [f0, f1)
                     if (f1 > f0 || f0) {
-                        UPHASE_BEGIN();
-                        if (f1 > f0) {
-                            if (frame_base + (uint64_t)UFRAME * f1 <= a.capacity) emit_frames(f0, f1);
-                            else emit_range(frame_base + (uint64_t)UFRAME * f0, frame_base + (uint64_t)UFRAME * f1,
-                                            [&](uint32_t j) { return qbase + (uint32_t)mine[UFRAME * f0 + j]; });
+                        const uint32_t E = UFRAME * f1, left = end - E;  // left < UFRAME: what stays listed
+                        const bool whole = f1 > f0 && frame_base + (uint64_t)UFRAME * f1 <= a.capacity;
+                        // ---- the pass after this one, if its listing can ride along: the next lanes of this round, or the first
+                        //      pass of the next round unless that round is empty, ends the tile or keeps everything (no list)
+                        bool ride = false;
+                        if constexpr (KMERS_UINTERLEAVE) {
+                            uint64_t nkm = km;
+                            uint32_t nla = lb, nexcl = excl, ncnt = cnt, ns0 = s0;
+                            ride = whole;
+                            if (lb >= 64u) {
+                                ride = false;
+                                const uint32_t nr_begin = r_begin + 4096u;
+                                if (whole && h + 1u < QPT && nr_begin < mt) {
+                                    nkm = rot[0];  // (the masks have moved down already: the next round's)
+                                    const uint32_t nn_round = mt - nr_begin < 4096u ? mt - nr_begin : 4096u;
+                                    const uint32_t nc = (uint32_t)__popcll(nkm), nincl = wave_scan_incl(nc);
+                                    nexcl = nincl - nc;
+                                    ncnt = lane_value(nincl, 63);
+                                    nla = 0;
+                                    ns0 = s0 + 4096u;
+                                    ride = ncnt != 0u && ncnt != nn_round;
+                                }
+                            }
+                            if (ride) {
+                                uint32_t nea, ncntp;
+                                const uint32_t nlb = next_pass(nla, nexcl, ncnt, nea, ncntp);
+                                job_cur = (uint32_t)nkm;
+                                job_nxt = (uint32_t)(nkm >> 32);
+                                if (lane < nla || lane >= nlb) job_cur = job_nxt = 0;
+                                job_o = left + nexcl - nea;  // (behind what this pass leaves: head = 0, list_n = left from here on)
+                                job_s0 = ns0;
+                            }
                         }
-                        LIST_FENCE(__ATOMIC_ACQUIRE);
-                        UPHASE_END(1);
                         UPHASE_BEGIN();
-                        // what is left moves to the head of the list: every lane reads before any lane writes
-                        const uint32_t E = UFRAME * f1, left = end - E;  // left < UFRAME
-                        uint16_t x0 = 0, x1 = 0;
-                        if (lane < left) x0 = mine[E + lane];
-                        if (lane + 64u < left) x1 = mine[E + lane + 64u];
-                        LIST_FENCE(__ATOMIC_ACQ_REL);
-                        if (lane < left) mine[lane] = x0;
-                        if (lane + 64u < left) mine[lane + 64u] = x1;
-                        LIST_FENCE(__ATOMIC_RELEASE);
+                        if (ride) {
+                            // what this pass leaves moves to the head of the OTHER list, then its frames go out with the next
+                            // pass's listing between their stores; the lists change places
+                            if (lane < left) other[lane] = mine[E + lane];
+                            if (lane + 64u < left) other[lane + 64u] = mine[E + lane + 64u];
+                            emit_frames(f0, f1);
+                            list_some(64u);  // (whatever of the job the frames did not cover: the rest of one half,
+                            list_some(64u);  // then all of the other)
+                            LIST_FENCE(__ATOMIC_ACQ_REL);
+                            const uint32_t t_off = m_off;
+                            m_off = o_off;
+                            o_off = t_off;
+                            pre_listed = true;
+                            UPHASE_END(1);
+                        } else {
+                            if (f1 > f0) {
+                                if (whole) emit_frames(f0, f1);
+                                else emit_range(frame_base + (uint64_t)UFRAME * f0, frame_base + (uint64_t)UFRAME * f1,
+                                                [&](uint32_t j) { return qbase + (uint32_t)mine[UFRAME * f0 + j]; });
+                            }
+                            LIST_FENCE(__ATOMIC_ACQUIRE);
+                            UPHASE_END(1);
+                            UPHASE_BEGIN();
+                            // what is left moves to the head of the list: every lane reads before any lane writes
+                            uint16_t x0 = 0, x1 = 0;
+                            if (lane < left) x0 = mine[E + lane];
+                            if (lane + 64u < left) x1 = mine[E + lane + 64u];
+                            LIST_FENCE(__ATOMIC_ACQ_REL);
+                            if (lane < left) mine[lane] = x0;
+                            if (lane + 64u < left) mine[lane + 64u] = x1;
+                            LIST_FENCE(__ATOMIC_RELEASE);
+                            UPHASE_END(2);
+                        }
                         frame_base += E;
                         head = 0;
                         list_n = left;
-                        UPHASE_END(2);
                     } else {
                         list_n += cntp;
                     }
@@ -878,6 +970,8 @@ __global__ __launch_bounds__(BLOCK, UMODE == UMODE_EMIT ? UNAMB_EMIT_WGS : 4) vo
     };
 
 #undef LIST_FENCE
+#undef mine
+#undef other
 
     if constexpr (!EMIT) {
         // COUNT / XOR: a persistent grid strides over the tiles; nothing is placed, so no descriptors
