@@ -591,11 +591,20 @@ def host_pointer_consumers(ctx, cap, dev, L=1_000_000_000):
     sk = np.zeros(1000, np.uint64)
     counts = np.zeros(4 ** 8, np.uint32)
     val = C.c_uint64()
+    # one sketch per FASTA record (docs/src/minhash.md:31-41): the same symbols as 10 000 records of 100 kbase, spans in host memory,
+    # 10 000 x 1000 hashes (80 MB) and the counts back to host memory
+    n_rec, rec_len = 10_000, L // 10_000
+    spans = np.stack([np.arange(n_rec, dtype=np.uint64) * np.uint64(rec_len), np.full(n_rec, rec_len, np.uint64)], axis=1).copy()
+    sk_b = np.zeros((n_rec, 1000), np.uint64)
+    cnt_b = np.zeros(n_rec, np.uint64)
+    BATCH = f"minhash_batch(fx_hash, CanonicalDNAMers{{16}}, 1000) over {n_rec} records of {rec_len} bases"
     consumers = {
         "reduce_xor CanonicalDNAMers{31}": lambda seq: ctx.lib.kmers_reduce_xor(ctx.handle, C.byref(seq), 31, 2, 1, C.byref(val), cap.MEM_HOST, C.byref(res)),
         "minhash(fx_hash, CanonicalDNAMers{16}, 1000)": lambda seq: ctx.lib.kmers_minhash(ctx.handle, C.byref(seq), 16, 2, 0, 1000, sk.ctypes.data_as(C.c_void_p),
                                                                                           cap.MEM_HOST, C.byref(res)),
         "composition FwDNAMers{8}": lambda seq: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), 8, counts.ctypes.data_as(C.c_void_p), cap.MEM_HOST, C.byref(res)),
+        BATCH: lambda seq: ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq), spans.ctypes.data_as(C.c_void_p), n_rec, 16, 2, 0, 1000,
+                                                       sk_b.ctypes.data_as(C.c_void_p), cnt_b.ctypes.data_as(C.c_void_p), cap.MEM_HOST, C.byref(res)),
     }
     try:
         for (what, kind), (arr, bits, _keep) in src.items():
@@ -632,9 +641,17 @@ def host_pointer_consumers(ctx, cap, dev, L=1_000_000_000):
         def comp_cpu(_i=0):     # counts[as_integer(kmer) + 1] += 1 over FwDNAMers{8}, docs/src/composition.md:28-39
             fw, _ = orc.fw_kmers(ws, S, 4, 2, 8)
             return np.bincount(fw[:, 0].astype(np.int64), minlength=4 ** 8)
+
+        def batch_cpu(_i=0):    # the per-record loop of docs/src/minhash.md:31-41 over the sample cut into records of the leg's length
+            outs = []               # (4-bit symbols: record r begins on a word boundary, rec_len * 4 / 64 words in)
+            assert rec_len * 4 % 64 == 0
+            for r in range(S // rec_len):
+                _, eh, _ = orc.canonical(ws[r * rec_len // 16:], rec_len, 4, 2, 16)
+                outs.append(np.unique(np.partition(eh, 4000)[:4000])[:1000])
+            return outs
         cpu = {}
         for name, fn in (("reduce_xor CanonicalDNAMers{31}", xor_cpu), ("minhash(fx_hash, CanonicalDNAMers{16}, 1000)", minhash_cpu),
-                         ("composition FwDNAMers{8}", comp_cpu)):
+                         ("composition FwDNAMers{8}", comp_cpu), (BATCH, batch_cpu)):
             t0 = time.perf_counter()
             fn()
             one = S / (time.perf_counter() - t0) / 1e9
@@ -648,6 +665,10 @@ def host_pointer_consumers(ctx, cap, dev, L=1_000_000_000):
         ok = consumers["reduce_xor CanonicalDNAMers{31}"](seq_s) == 0 and val.value == xor_cpu()
         ok &= consumers["minhash(fx_hash, CanonicalDNAMers{16}, 1000)"](seq_s) == 0 and bool(np.array_equal(sk, minhash_cpu()))
         ok &= consumers["composition FwDNAMers{8}"](seq_s) == 0 and bool(np.array_equal(counts, comp_cpu().astype(np.uint32)))
+        n_s = S // rec_len  # (the batch call over the sample's records: the first n_s spans are the sample's)
+        rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq_s), spans.ctypes.data_as(C.c_void_p), n_s, 16, 2, 0, 1000, sk_b.ctypes.data_as(C.c_void_p),
+                                         cnt_b.ctypes.data_as(C.c_void_p), cap.MEM_HOST, C.byref(res))
+        ok &= rc == 0 and all(int(cnt_b[r]) == len(e) and bool(np.array_equal(sk_b[r, :len(e)], e)) for r, e in enumerate(batch_cpu()))
         out["cpu_port_same_consumers"] = dict(cpu, sample=f"{S >> 20} Mi-base of the same generator per thread, oracle (C restatement, gcc -O3 -march=native) + numpy for "
                                                            "the sketch's selection and the table", verified_against_gpu=bool(ok))
     finally:

@@ -58,8 +58,15 @@ struct Staged {
     uint64_t first_bit = 0;
 };
 
-// Make the sequence words available in HBM.  Host memory: copy the words the view touches.
-inline int stage_sequence(kmers_ctx *ctx, const kmers_seq *seq, int flags, Staged *out) {
+// (a caller that brings a host sequence up in pieces itself: where it comes from; stage 0 byte b is host byte b of `from`)
+struct HostSlice {
+    const char *from = nullptr;
+    size_t bytes = 0;
+};
+
+// Make the sequence words available in HBM.  Host memory: copy the words the view touches -- or, with `defer`, only make room for
+// them and say where they are.
+inline int stage_sequence(kmers_ctx *ctx, const kmers_seq *seq, int flags, Staged *out, HostSlice *defer = nullptr) {
     uint64_t bit0 = seq->first_base * (uint64_t)seq->src_bits;
     if (flags & KMERS_MEM_DEVICE) {
         out->d_words = seq->words;
@@ -70,11 +77,16 @@ inline int stage_sequence(kmers_ctx *ctx, const kmers_seq *seq, int flags, Stage
         size_t nbytes = (size_t)seq->n_bases;
         if (int rc = ensure_stage(ctx, 0, nbytes + 16)) return rc;
         const void *from = reinterpret_cast<const char *>(seq->words) + seq->first_base;
-        if (nbytes && nbytes <= BOUNCE_IN) {
-            std::memcpy(ctx->h_bounce, from, nbytes);
-            from = ctx->h_bounce;
+        if (defer) {
+            defer->from = static_cast<const char *>(from);
+            defer->bytes = nbytes;
+        } else {
+            if (nbytes && nbytes <= BOUNCE_IN) {
+                std::memcpy(ctx->h_bounce, from, nbytes);
+                from = ctx->h_bounce;
+            }
+            if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], from, nbytes, hipMemcpyHostToDevice, ctx->stream));
         }
-        if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], from, nbytes, hipMemcpyHostToDevice, ctx->stream));
         out->d_words = static_cast<const uint64_t *>(ctx->stage[0]);
         out->first_bit = 0;
         return KMERS_OK;
@@ -84,11 +96,16 @@ inline int stage_sequence(kmers_ctx *ctx, const kmers_seq *seq, int flags, Stage
     size_t bytes = (size_t)(w1 - w0) * 8;
     if (int rc = ensure_stage(ctx, 0, bytes + 8)) return rc;
     const void *from = seq->words + w0;
-    if (bytes && bytes <= BOUNCE_IN) {
-        std::memcpy(ctx->h_bounce, from, bytes);
-        from = ctx->h_bounce;
+    if (defer) {
+        defer->from = static_cast<const char *>(from);
+        defer->bytes = bytes;
+    } else {
+        if (bytes && bytes <= BOUNCE_IN) {
+            std::memcpy(ctx->h_bounce, from, bytes);
+            from = ctx->h_bounce;
+        }
+        if (bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], from, bytes, hipMemcpyHostToDevice, ctx->stream));
     }
-    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], from, bytes, hipMemcpyHostToDevice, ctx->stream));
     out->d_words = static_cast<const uint64_t *>(ctx->stage[0]);
     out->first_bit = bit0 & 63u;
     return KMERS_OK;

@@ -15,8 +15,11 @@ using namespace kmers;
 struct PoolStream {
     const uint64_t *stream = nullptr, *flags = nullptr, *any_flag = nullptr;
 };
+// `launch` false: only make room and say where the stream will be; pool_stream_range then recodes it piece by piece.
+static int pool_stream_range(kmers_ctx *ctx, const kmers_seq *pool, const uint64_t *src0, int dst_bits, const PoolStream &ps, uint64_t w_first,
+                             uint64_t n_words);
 static int pool_stream(kmers_ctx *ctx, const kmers_seq *pool, const uint64_t *src0, uint64_t origin, uint64_t n_src_words, int dst_bits,
-                       PoolStream *out) {
+                       PoolStream *out, bool launch = true) {
     (void)origin;
     const int sb = pool->src_bits;
     if (sb == dst_bits) {
@@ -36,17 +39,31 @@ static int pool_stream(kmers_ctx *ctx, const kmers_seq *pool, const uint64_t *sr
         r.any_flag = reinterpret_cast<uint64_t *>(static_cast<char *>(ctx->stage[5]) + ((flag_bytes + 7) & ~(size_t)7));
         HIP_TRY(ctx, hipMemsetAsync(r.any_flag, 0, 8, ctx->stream));
     }
-    if (n_src_words) {
-        dim3 rgrid((unsigned)std::min<uint64_t>((n_src_words + 255) / 256, (uint64_t)ctx->n_cus * 16)), rblock(256);
-        if (sb == 4) hipLaunchKernelGGL((recode_kernel<4, 2>), rgrid, rblock, 0, ctx->stream, r);
-        else if (sb == 2) hipLaunchKernelGGL((recode_kernel<2, 4>), rgrid, rblock, 0, ctx->stream, r);
-        else if (dst_bits == 2) hipLaunchKernelGGL((recode_kernel<8, 2>), rgrid, rblock, 0, ctx->stream, r);
-        else hipLaunchKernelGGL((recode_kernel<8, 4>), rgrid, rblock, 0, ctx->stream, r);
-        HIP_TRY(ctx, hipGetLastError());
-    }
     out->stream = r.stream;
     out->flags = r.flags;
     out->any_flag = r.any_flag;
+    if (launch) return pool_stream_range(ctx, pool, src0, dst_bits, *out, 0, n_src_words);
+    return KMERS_OK;
+}
+
+static int pool_stream_range(kmers_ctx *ctx, const kmers_seq *pool, const uint64_t *src0, int dst_bits, const PoolStream &ps, uint64_t w_first,
+                             uint64_t n_words) {
+    const int sb = pool->src_bits;
+    if (sb == dst_bits || n_words == 0) return KMERS_OK;
+    RecodeArgs r{};
+    r.src = src0;
+    r.n_words = n_words;
+    r.w_first = w_first;
+    r.stream = const_cast<uint64_t *>(ps.stream);
+    r.flags = const_cast<uint64_t *>(ps.flags);
+    r.any_flag = const_cast<uint64_t *>(ps.any_flag);
+    r.ascii_table = ascii_table(ctx, dst_bits, pool->alphabet);
+    dim3 rgrid((unsigned)std::min<uint64_t>((n_words + 255) / 256, (uint64_t)ctx->n_cus * 16)), rblock(256);
+    if (sb == 4) hipLaunchKernelGGL((recode_kernel<4, 2>), rgrid, rblock, 0, ctx->stream, r);
+    else if (sb == 2) hipLaunchKernelGGL((recode_kernel<2, 4>), rgrid, rblock, 0, ctx->stream, r);
+    else if (dst_bits == 2) hipLaunchKernelGGL((recode_kernel<8, 2>), rgrid, rblock, 0, ctx->stream, r);
+    else hipLaunchKernelGGL((recode_kernel<8, 4>), rgrid, rblock, 0, ctx->stream, r);
+    HIP_TRY(ctx, hipGetLastError());
     return KMERS_OK;
 }
 
@@ -397,15 +414,40 @@ static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmer
     if (!spans_dev) HIP_TRY(ctx, hipMemcpyAsync(meta, spans, span_bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
 
-    Staged st;
-    if (int rc = stage_sequence(ctx, pool, flags, &st)) return rc;
     const bool dev = flags & KMERS_MEM_DEVICE;
     const int sb = pool->src_bits;
+    // A large pool in HOST memory whose records lie in pool order (the records of a FASTA file, docs/src/minhash.md:31-41) comes up in
+    // PIECES: the copy of piece c + 1 runs beside the recode pass and the sketch kernel of piece c, whose sketches go down before
+    // piece c + 2 -- the call takes about as long as the copy of its pool alone (bench.py, the e2e legs: 0.69 -> 0.9 of a plain copy).
+    // Anything else (device memory, records out of order or outside the pool, a small pool) takes the one-piece path.
+    constexpr uint64_t PIECE_BYTES = 32ull << 20;
+    std::vector<uint64_t> cut;  // record indices at which a piece begins, then n
+    if (!dev && !spans_dev && (uint64_t)pool->n_bases * sb / 8 >= 4 * PIECE_BYTES && n <= (1ull << 20)) {
+        uint64_t prev = 0, begun = 0;
+        bool ordered = true;
+        cut.push_back(0);
+        for (uint64_t i = 0; i < n && ordered; ++i) {
+            const uint64_t f = spans[i].first_base, l = spans[i].n_bases;
+            ordered = f >= prev && f <= pool->n_bases && l <= pool->n_bases - f;
+            prev = f;
+            if (i && (f - begun) * sb / 8 >= PIECE_BYTES) {
+                cut.push_back(i);
+                begun = f;
+            } else if (!i) {
+                begun = f;
+            }
+        }
+        cut.push_back(n);
+        if (!ordered || cut.size() < 4) cut.clear();
+    }
+    Staged st;
+    HostSlice host;
+    if (int rc = stage_sequence(ctx, pool, flags, &st, cut.empty() ? nullptr : &host)) return rc;
     const uint64_t *src0 = st.d_words + (st.first_bit >> 6);        // word that holds pool symbol 0
     const uint64_t origin = (st.first_bit & 63u) / (uint64_t)sb;     // its symbol offset inside that word
     const uint64_t n_src_words = ((origin + pool->n_bases) * (uint64_t)sb + 63) / 64;
     PoolStream ps;
-    if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps)) return rc;
+    if (int rc = pool_stream(ctx, pool, src0, origin, n_src_words, dst_bits, &ps, cut.empty())) return rc;
 
     const size_t out_bytes = (size_t)n * s * 8, cnt_out_bytes = (size_t)n * 8;
     uint64_t *d_out = out_hashes, *d_cnt = out_counts;
@@ -451,16 +493,63 @@ static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmer
     } while (0)
 #define RSR(DB, NN) do { if (run == 8u) RS(DB, NN, 8); else RS(DB, NN, 4); } while (0)
 #define RSN(DB) do { if (nw == 1) RSR(DB, 1); else if (nw == 2) RSR(DB, 2); else if (nw == 3) RSR(DB, 3); else if (nw == 4) RSR(DB, 4); else RSR(DB, 0); } while (0)
-    if (dst_bits == 2) RSN(2);
-    else RSN(4);
+    if (cut.empty()) {
+        if (dst_bits == 2) RSN(2);
+        else RSN(4);
+        HIP_TRY(ctx, hipGetLastError());
+        if (!dev) {
+            HIP_TRY(ctx, hipMemcpyAsync(out_hashes, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(out_counts, d_cnt, cnt_out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    } else {
+        if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (auto &e : ctx->pipe_events)
+            if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        const size_t pieces = cut.size() - 1;
+        // stage byte b is host byte b; piece c needs the words of its records: [word of its first symbol, word behind the furthest end)
+        auto word_of = [&](uint64_t sym) { return ((origin + sym) * (uint64_t)sb) >> 6; };
+        std::vector<uint64_t> w_lo(pieces), w_hi(pieces);
+        for (size_t c = 0; c < pieces; ++c) {
+            uint64_t end = 0;
+            for (uint64_t i = cut[c]; i < cut[c + 1]; ++i) end = std::max<uint64_t>(end, spans[i].first_base + spans[i].n_bases);
+            w_lo[c] = word_of(spans[cut[c]].first_base) & ~(uint64_t)63;  // (whole 64-word groups: the recode pass writes 1-4 bytes per word)
+            w_hi[c] = std::min<uint64_t>(n_src_words, word_of(end) + 2);
+            if (c) w_hi[c] = std::max(w_hi[c], w_hi[c - 1]);
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->pipe_events[0], ctx->stream));  // (the spans, the flag resets: in front of the first copy)
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->pipe_events[0], 0));
+        uint64_t up = w_lo[0];  // words [w_lo[0], up) are on the device
+        auto copy_up = [&](size_t c) -> int {
+            if (w_hi[c] > up) {
+                const size_t b0 = (size_t)up * 8, b1 = std::min<size_t>((size_t)w_hi[c] * 8, host.bytes);
+                if (b1 > b0)
+                    HIP_TRY(ctx, hipMemcpyAsync(static_cast<char *>(ctx->stage[0]) + b0, host.from + b0, b1 - b0, hipMemcpyHostToDevice, ctx->copy_stream));
+                up = w_hi[c];
+            }
+            HIP_TRY(ctx, hipEventRecord(ctx->pipe_events[1 + (c & 1)], ctx->copy_stream));
+            return KMERS_OK;
+        };
+        if (int rc = copy_up(0)) return rc;
+        for (size_t c = 0; c < pieces; ++c) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_events[1 + (c & 1)], 0));
+            if (int rc = pool_stream_range(ctx, pool, src0, dst_bits, ps, w_lo[c], w_hi[c] - w_lo[c])) return rc;
+            grid = dim3((unsigned)(cut[c + 1] - cut[c]));
+            a.rec_base = cut[c];
+            if (dst_bits == 2) RSN(2);
+            else RSN(4);
+            HIP_TRY(ctx, hipGetLastError());
+            // the next piece's copy is enqueued BEFORE this piece's sketches go down: a copy from or to pageable memory holds the
+            // host until it is done, and the device should have the next piece's kernels to run by then
+            if (c + 1 < pieces)
+                if (int rc = copy_up(c + 1)) return rc;
+            const size_t r0 = (size_t)cut[c], r1 = (size_t)cut[c + 1];
+            HIP_TRY(ctx, hipMemcpyAsync(out_hashes + r0 * s, d_out + r0 * s, (r1 - r0) * s * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(out_counts, d_cnt, cnt_out_bytes, hipMemcpyDeviceToHost, ctx->stream));  // (one copy: every copy to pageable memory is a wait)
+    }
 #undef RSR
 #undef RSN
 #undef RS
-    HIP_TRY(ctx, hipGetLastError());
-    if (!dev) {
-        HIP_TRY(ctx, hipMemcpyAsync(out_hashes, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(out_counts, d_cnt, cnt_out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_scratch, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result + 2, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

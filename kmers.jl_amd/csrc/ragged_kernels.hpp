@@ -107,6 +107,7 @@ struct RecodeArgs {
     uint64_t *stream;
     uint64_t *flags;
     uint64_t *any_flag;          // becomes non-zero if any symbol of the pool cannot be encoded
+    uint64_t w_first;            // the launch recodes the words [w_first, w_first + n_words) (a host pool arriving in pieces, batch_api.hip)
     uint32_t ascii_table;
 };
 
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void recode_kernel(const RecodeArgs a) {
         block_sync();
     }
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
-    for (uint64_t wi = (uint64_t)blockIdx.x * 256u + threadIdx.x; wi < a.n_words; wi += stride) {
+    for (uint64_t wi = a.w_first + (uint64_t)blockIdx.x * 256u + threadIdx.x; wi < a.w_first + a.n_words; wi += stride) {
         const uint64_t x = a.src[wi];
         if constexpr (SRC == 4 && DST == 2) {
             uint32_t any_bad;  // (one verdict per word; the flag of every symbol only where a symbol is off: device_bits.hpp)

@@ -32,6 +32,7 @@ struct RecordSketchArgs {
     uint64_t *bad;               // becomes non-zero if a span reaches outside the pool (or holds 2^32 symbols or more)
     uint32_t k, s, skip, cap;
     uint32_t n_words;            // N == 0 (kmers of more than four words): the run-time width
+    uint64_t rec_base;           // workgroup b of the launch takes record rec_base + b (a batch launched in pieces, batch_api.hip)
 };
 
 // N == 0: kmers of any width (a.n_words); nothing is staged, every window is read from the stream in HBM (an edge path).
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void record_sketch_kernel(const RecordSketchAr
     uint64_t *src_t = v + a.cap;
     uint64_t *flg_t = src_t + RS_STAGE;
     const uint32_t t = threadIdx.x;
-    const uint64_t r = blockIdx.x;
+    const uint64_t r = a.rec_base + blockIdx.x;
     const uint32_t k = a.k, s = a.s;
     const RaggedSpan sp = a.spans[r];
     if (sp.first_base > a.pool_bases || sp.n_bases > a.pool_bases - sp.first_base || sp.n_bases >= 0xFFFFFFFFull) {

@@ -705,3 +705,74 @@ print("ok", res.n_out)
     env = dict(os.environ, KMERS_HIP_LIB=lib, PYTHONPATH=os.pathsep.join(sys.path))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout, r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("src", [4, 8])
+def test_minhash_batch_of_a_large_host_pool_comes_up_in_pieces(km, ctx, orc, src):
+    """A pool of 128 MiB and more in HOST memory whose records lie in pool order is copied, recoded and sketched piece by piece
+    (csrc/batch_api.hip, minhash_batch_fused: the copy of piece c + 1 beside the kernels of piece c).  Same sketches as the one-piece
+    path (the same pool in device memory) for every record -- ragged, overlapping, with gaps, some shorter than K -- and as the oracle
+    for a sample of them; an ambiguous symbol far into the pool is reported with its record and position."""
+    cap = km._capi
+    rng = np.random.default_rng(300 + src)
+    K, s = 21, 200
+    n_pool = (300 if src == 4 else 150) * (1 << 20)          # 150 MiB of source bytes: four pieces and a bit
+    nw = (n_pool * src + 63) // 64
+    d_w = ctx.alloc(nw * 8 + 16)
+    if src == 4:
+        ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, 11, 0, nw, 4, 0, d_w), "synth")
+        words = np.zeros(nw + 2, np.uint64)
+        ctx.d2h(words[:nw], d_w)
+    else:
+        words = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, nw * 8 + 16, dtype=np.uint8)].copy().view(np.uint64)
+        ctx.h2d(d_w, words[:nw])
+    n_rec = 3000
+    first = np.sort(rng.integers(0, n_pool - 200_000, n_rec)).astype(np.uint64)
+    length = rng.integers(0, 200_000, n_rec).astype(np.uint64)
+    length[rng.integers(0, n_rec, 40)] = rng.integers(0, K, 40).astype(np.uint64)
+    first[0] = 0
+    spans = np.stack([first, length], axis=1).copy()
+    sp = spans.ctypes.data_as(C.POINTER(cap.Span))
+    res = cap.Result()
+    out_h, cnt_h = np.zeros((n_rec, s), np.uint64), np.zeros(n_rec, np.uint64)
+    seq_h = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+    rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq_h), sp, n_rec, K, 2, 9, s, vp(out_h), vp(cnt_h), 0, C.byref(res))
+    assert rc == 0 and res.n_out == n_rec, ctx.last_error()
+    d_o, d_c = ctx.alloc(n_rec * s * 8), ctx.alloc(n_rec * 8)
+    seq_d = cap.Seq(d_w, n_pool, 0, 0, src, 0)
+    rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq_d), sp, n_rec, K, 2, 9, s, d_o, d_c, cap.MEM_DEVICE, C.byref(res))
+    assert rc == 0, ctx.last_error()
+    out_d, cnt_d = np.zeros((n_rec, s), np.uint64), np.zeros(n_rec, np.uint64)
+    ctx.d2h(out_d, d_o)
+    ctx.d2h(cnt_d, d_c)
+    assert np.array_equal(cnt_h, cnt_d)
+    for i in range(n_rec):
+        assert np.array_equal(out_h[i, :int(cnt_h[i])], out_d[i, :int(cnt_d[i])]), i
+    for i in (0, 1, 17, n_rec // 2, n_rec - 2, n_rec - 1):                # the oracle, record by record
+        f, l = int(first[i]), int(length[i])
+        if src == 8:
+            w = words.view(np.uint8)[f:f + l + 8].copy()
+            w = np.concatenate([w, np.zeros((-len(w)) % 8, np.uint8)]).view(np.uint64)
+            _, eh, _ = orc.canonical(w, l, 8, 2, K, seed=9)
+        else:
+            sh = f % 16                                                   # (records begin anywhere inside a word)
+            w = words[f // 16:(f + l) // 16 + 2]
+            if sh:
+                w = (w[:-1] >> np.uint64(4 * sh)) | (w[1:] << np.uint64(64 - 4 * sh))
+            _, eh, _ = orc.canonical(np.ascontiguousarray(w), l, 4, 2, K, seed=9)
+        exp = np.unique(eh)[:s] if l >= K else np.zeros(0, np.uint64)
+        assert cnt_h[i] == len(exp) and np.array_equal(out_h[i, :len(exp)], exp), i
+    # an ambiguous symbol in the last piece: the record and the position inside it
+    i_bad = n_rec - 5
+    while int(length[i_bad]) < 1000:
+        i_bad -= 1
+    p_bad = int(first[i_bad]) + 777
+    if src == 8:
+        words.view(np.uint8)[p_bad] = ord("N")
+    else:
+        words[p_bad // 16] |= np.uint64(0xF) << np.uint64(4 * (p_bad % 16))
+    rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq_h), sp, n_rec, K, 2, 9, s, vp(out_h), vp(cnt_h), 0, C.byref(res))
+    first_hit = min(i for i in range(n_rec) if int(first[i]) <= p_bad < int(first[i]) + int(length[i]) and int(length[i]) >= K)
+    assert rc == cap.E_ENCODE and res.n_out == first_hit and res.err_pos == p_bad - int(first[first_hit]) + 1, (rc, res.n_out, res.err_pos, first_hit)
+    for d in (d_w, d_o, d_c):
+        ctx.free(d)
