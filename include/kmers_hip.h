@@ -404,6 +404,8 @@ int kmers_batch_spaced(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *
 int kmers_minhash_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *spans, uint64_t n_spans, int k,
                         int dst_bits, uint64_t seed, uint64_t s, uint64_t *out_hashes, uint64_t *out_counts, int flags,
                         kmers_result *res);
+/* In how many pieces the most recent kmers_minhash_batch of this context brought its pool up (1: one copy, one launch). */
+int kmers_last_batch_pieces(kmers_ctx *ctx, uint64_t *pieces);
 
 /* ---- sharding one long sequence over the GPUs of a node ------- */
 /* The reference has no distributed code; kmer i depends only on symbols [i*stride, i*stride + k),

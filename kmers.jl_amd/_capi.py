@@ -72,6 +72,7 @@ SYMBOLS = {
     "kmers_last_launch_shape": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kmers_last_shape_calibration": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "kmers_shape_calibrations": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "kmers_last_batch_pieces": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "kmers_pool_info": (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]),
     "kmers_pool_trim": (C.c_int, [_P, C.POINTER(C.c_size_t)]),

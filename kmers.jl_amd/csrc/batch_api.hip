@@ -493,6 +493,7 @@ static int minhash_batch_fused(kmers_ctx *ctx, const kmers_seq *pool, const kmer
     } while (0)
 #define RSR(DB, NN) do { if (run == 8u) RS(DB, NN, 8); else RS(DB, NN, 4); } while (0)
 #define RSN(DB) do { if (nw == 1) RSR(DB, 1); else if (nw == 2) RSR(DB, 2); else if (nw == 3) RSR(DB, 3); else if (nw == 4) RSR(DB, 4); else RSR(DB, 0); } while (0)
+    ctx->last_batch_pieces = cut.empty() ? 1 : cut.size() - 1;
     if (cut.empty()) {
         if (dst_bits == 2) RSN(2);
         else RSN(4);
@@ -583,6 +584,12 @@ int kmers_minhash_batch(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span 
     } catch (...) {
         return fail(ctx, KMERS_E_HIP, "unexpected exception in kmers_minhash_batch");
     }
+}
+
+int kmers_last_batch_pieces(kmers_ctx *ctx, uint64_t *pieces) {
+    if (!ctx || !pieces) return KMERS_E_BADARG;
+    *pieces = ctx->last_batch_pieces;
+    return KMERS_OK;
 }
 
 }  // extern "C"

@@ -50,6 +50,7 @@ struct kmers_ctx {
     size_t layout_segs = 0;
     uint64_t layout_tickets = 0;
     uint32_t layout_epoch = 0;
+    uint64_t last_batch_pieces = 0;       // kmers_last_batch_pieces
     uint64_t *d_recent = nullptr;         // MinHash: table of recently appended candidate hashes (RECENT_SLOTS entries)
     void *stage[8] = {};      // 0 source, 1-2 outputs, 3 metadata / scratch, 4-5 recoded stream / flags, 6 tile index, 7 RCCL scratch
     size_t stage_cap[8] = {};

@@ -218,6 +218,12 @@ class Context:
         self.check(self.lib.kmers_shape_calibrations(self.handle, C.byref(n)), "kmers_shape_calibrations")
         return n.value
 
+    def last_batch_pieces(self):
+        """Pieces the most recent kmers_minhash_batch brought its pool up in (kmers_last_batch_pieces)."""
+        n = C.c_uint64()
+        self.check(self.lib.kmers_last_batch_pieces(self.handle, C.byref(n)), "kmers_last_batch_pieces")
+        return n.value
+
     def placement_probe(self, ptr_a, ptr_b, nbytes):
         """GB/s of two store streams side by side into two (still empty) device buffers; DESTRUCTIVE (kmers_placement_probe)."""
         g = C.c_double()

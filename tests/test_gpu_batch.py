@@ -738,10 +738,11 @@ def test_minhash_batch_of_a_large_host_pool_comes_up_in_pieces(km, ctx, orc, src
     seq_h = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
     rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq_h), sp, n_rec, K, 2, 9, s, vp(out_h), vp(cnt_h), 0, C.byref(res))
     assert rc == 0 and res.n_out == n_rec, ctx.last_error()
+    assert ctx.last_batch_pieces() >= 4
     d_o, d_c = ctx.alloc(n_rec * s * 8), ctx.alloc(n_rec * 8)
     seq_d = cap.Seq(d_w, n_pool, 0, 0, src, 0)
     rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq_d), sp, n_rec, K, 2, 9, s, d_o, d_c, cap.MEM_DEVICE, C.byref(res))
-    assert rc == 0, ctx.last_error()
+    assert rc == 0 and ctx.last_batch_pieces() == 1, ctx.last_error()
     out_d, cnt_d = np.zeros((n_rec, s), np.uint64), np.zeros(n_rec, np.uint64)
     ctx.d2h(out_d, d_o)
     ctx.d2h(cnt_d, d_c)
@@ -774,5 +775,17 @@ def test_minhash_batch_of_a_large_host_pool_comes_up_in_pieces(km, ctx, orc, src
     rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq_h), sp, n_rec, K, 2, 9, s, vp(out_h), vp(cnt_h), 0, C.byref(res))
     first_hit = min(i for i in range(n_rec) if int(first[i]) <= p_bad < int(first[i]) + int(length[i]) and int(length[i]) >= K)
     assert rc == cap.E_ENCODE and res.n_out == first_hit and res.err_pos == p_bad - int(first[first_hit]) + 1, (rc, res.n_out, res.err_pos, first_hit)
+    # ... and with KMERS_BATCH_SKIP the windows over it are left out: pieces and one piece agree again (the flags of a piece are
+    # written by that piece's recode pass)
+    rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq_h), sp, n_rec, K, 2, 9, s, vp(out_h), vp(cnt_h), cap.BATCH_SKIP, C.byref(res))
+    assert rc == 0, ctx.last_error()
+    ctx.h2d(d_w, words[:nw])
+    rc = ctx.lib.kmers_minhash_batch(ctx.handle, C.byref(seq_d), sp, n_rec, K, 2, 9, s, d_o, d_c, cap.MEM_DEVICE | cap.BATCH_SKIP, C.byref(res))
+    assert rc == 0, ctx.last_error()
+    ctx.d2h(out_d, d_o)
+    ctx.d2h(cnt_d, d_c)
+    assert np.array_equal(cnt_h, cnt_d)
+    for i in range(n_rec):
+        assert np.array_equal(out_h[i, :int(cnt_h[i])], out_d[i, :int(cnt_d[i])]), i
     for d in (d_w, d_o, d_c):
         ctx.free(d)
