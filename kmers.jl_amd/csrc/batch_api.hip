@@ -264,6 +264,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         a.any_flag = ps.any_flag;
     } else {
         a.src4 = src0;
+        a.n_src4_words = n_src_words;
         a.tile_status = d_status;
         a.redo_count = d_redo;
     }

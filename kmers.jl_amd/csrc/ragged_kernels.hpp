@@ -97,6 +97,7 @@ struct RaggedArgs {
     // meets a symbol that is not one-hot writes nothing, sets its status byte and counts itself.  If any did, the host runs the
     // recode pass and launches again with `stream` set: tiles whose status is 0 are done and leave at once.
     const uint64_t *src4;
+    uint64_t n_src4_words;       // the pool's words: nothing is read beyond them
     uint8_t *tile_status;
     unsigned long long *redo_count;
 };
@@ -353,8 +354,9 @@ __device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const Rag
     if constexpr (FROM4) {
         uint32_t *src32 = reinterpret_cast<uint32_t *>(L.src);
         for (uint32_t i = tid; i < 2u * d.n_words; i += 256u) {
+            const uint64_t wi = 2u * d.q_lo + i;  // (a stretch may end half a stream word past the pool's last word: all A there, in no window)
             uint32_t any_bad;
-            src32[i] = pack_4to2_checked(a.src4[2u * d.q_lo + i], any_bad);   // FourToTwo, construction_utils.jl:47-52
+            src32[i] = pack_4to2_checked(wi < a.n_src4_words ? a.src4[wi] : 0x1111111111111111ull, any_bad);  // FourToTwo, construction_utils.jl:47-52
             bad |= any_bad ? 1u : 0u;                                         // (a symbol that is not one-hot: the general path finds which, and whether a window holds it)
         }
     } else {
