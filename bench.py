@@ -25,9 +25,11 @@ max-over-ranks rule, then the same 10 Gbase on rank 0 alone, and the ratio of th
 `--gpus N` command yields the fixed-input speedup as well.
 
 Memory: the buffers come from the library's allocator (kmers_dev_alloc, include/kmers_hip.h) -- what a Julia or C host gets:
-by default the device's CLASS POOL (round 5: 1 GiB handles of HIP's virtual-memory management, each block assembled by HBM
-region class; no reservation), with `--alloc arena` the reservation of rounds 3-4 (kmers_arena_reserve, `--arena-gb`), with
-`--alloc plain` torch allocations; `roofline.plain_alloc` reports the same launch into plain allocations made before either.
+by default the device's CLASS POOL (1 GiB handles of HIP's virtual-memory management, each block assembled by HBM region
+class; no reservation), with `--alloc plain` torch allocations; `roofline.plain_alloc` reports the same launch into plain
+allocations made before the pool existed.  `fresh_outputs_per_step` is the same K steps with FRESH outputs per step --
+{kmers_dev_alloc, kmers_dev_alloc, launch, kmers_dev_free, kmers_dev_free}, what `collect` per sequence amounts to (Base.collect
+over src/iterators/CanonicalKmers.jl:199-225 makes a new Vector per call) -- beside the resident headline.
 """
 import argparse
 import ctypes as C
@@ -84,15 +86,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-hash", action="store_true", help="materialise canonical kmers only (8.5 / 8.25 B per kmer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra C3/C4/C5/10 Gbase rates (N = 1 only)")
-    ap.add_argument("--no-shape-calibration", action="store_true", help="KMERS_PARAM_SHAPE_CALIBRATE = 0 (profiling runs: one kernel shape per trace row)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic / VALU issue shares with rocprofv3 --pmc child runs")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
-    ap.add_argument("--alloc", choices=("pool", "arena", "plain"), default="pool",
-                    help="pool: buffers from kmers_dev_alloc, served by the device's class pool (the product's default); arena: "
-                         "kmers_arena_reserve(--arena-gb) + kmers_dev_alloc (rounds 3-4); plain: torch allocations")
-    ap.add_argument("--arena-gb", type=float, default=230.0,
-                    help="size of the arena in GB: an explicit amount (the 10 Gbase leg needs 165 GB of it; the PMC child processes take "
-                         "theirs from what is left); 0 = three quarters of the free memory; a reservation that fails falls back to that")
+    ap.add_argument("--alloc", choices=("pool", "plain"), default="pool",
+                    help="pool: buffers from kmers_dev_alloc, served by the device's class pool (the product's default); plain: torch allocations")
     ap.add_argument("--wake-s", type=float, default=1.0, help="seconds of plain fills before the W warm-up steps (a fresh or idle device is slower at first)")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)  # internal: the profiled child ("headline" or "legs")
     return ap.parse_args(argv)
@@ -146,28 +143,26 @@ class _RawDeviceArray:
 
 
 class Memory:
-    """Where the bench's buffers come from.  use_arena (historical name: the LIBRARY's allocator, pool or arena): ctx.alloc
-    (kmers_dev_alloc) wrapped as int64 torch tensors through __cuda_array_interface__; else torch.empty."""
+    """Where the bench's buffers come from.  use_lib: ctx.alloc (kmers_dev_alloc: the device's class pool) wrapped as int64 torch
+    tensors through __cuda_array_interface__; else torch.empty."""
 
-    def __init__(self, ctx, dev, use_arena, kind="arena"):
-        self.ctx, self.dev, self.use_arena, self.live, self.kind = ctx, dev, use_arena, {}, kind
+    def __init__(self, ctx, dev, use_lib):
+        self.ctx, self.dev, self.use_lib, self.live = ctx, dev, use_lib, {}
 
     def room(self):
         """bytes a new block can still get"""
         import torch
-        if self.use_arena and self.kind == "arena":
-            return self.ctx.arena_info()[2]
         free = torch.cuda.mem_get_info(self.dev)[0]
-        if self.use_arena:
-            info = self.ctx.pool_info()
-            free += info["held"] - info["in_use"] - (info["n_classes"] << 30)
+        if self.use_lib:
+            st = self.ctx.pool_stats()
+            free += st["cached"] + st["free"]  # (the pool takes its own idle memory before it asks the driver)
         return free
 
     def empty(self, n_words, lone_output=False):
         """lone_output: the only output array of the launches that fill it (kmers_dev_alloc_role(KMERS_ALLOC_LONE_OUTPUT))."""
         import torch
         n_words = max(int(n_words), 1)
-        if not self.use_arena:
+        if not self.use_lib:
             return torch.empty(n_words, dtype=torch.int64, device=self.dev)
         ptr = self.ctx.alloc(8 * n_words, lone_output=lone_output)
         t = torch.as_tensor(_RawDeviceArray(ptr, n_words), device=self.dev)
@@ -176,11 +171,16 @@ class Memory:
         return t
 
     def free(self, *tensors):
-        """Give the blocks back to the arena (the tensors must not be used afterwards)."""
+        """Give the blocks back to the library (the tensors must not be used afterwards).  kmers_dev_free orders a block's next
+        use behind the work queued on the LIBRARY's streams; torch may have touched these tensors on streams of its own (the
+        checks): the device is waited for first, as include/kmers_hip.h asks of a host framework."""
+        import torch
+        if self.use_lib and any(t is not None for t in tensors):
+            torch.cuda.synchronize()
         for t in tensors:
             if t is None:
                 continue
-            if self.use_arena and t.data_ptr() in self.live:
+            if self.use_lib and t.data_ptr() in self.live:
                 ptr = t.data_ptr()
                 del self.live[ptr]
                 self.ctx.free(ptr)
@@ -332,7 +332,7 @@ def busy_timed(ctx, stream, fn, reps=7, busy_s=0.05):
     return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
-def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_gbps=HBM_PEAK_GBPS, write_ceiling_source="8 TB/s spec (no arena map)"):
+def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_gbps=HBM_PEAK_GBPS, write_ceiling_source="8 TB/s spec (no pool)"):
     """Kernel rates of the other BASELINE.json configs (parity-test cases, not the headline): C3 shape
     per GPU, C4, C5 strict and skip, and the north-star size (10 Gbase LongDNA{4}).  Resident data, HIP events on
     the library's stream, median of reps.  The 10 Gbase leg comes last: 165 GB of output per launch leave the device in a
@@ -362,8 +362,8 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
     def ceilings(leg, ms, alg_bytes):
         """What bounds a leg that is not purely a store stream.  Every ratio is formed inside ONE profiled dispatch (its duration,
         its SQ_INSTS_VALU and its GRBM_GUI_ACTIVE, measure_legs); the unprofiled time of this run stands beside them, it is
-        not divided into them.  hbm_floor: algorithmic bytes at the two-stream rate the arena MEASURED for its best pair of
-        places (kmers_arena_rates; 8 TB/s spec if there is no map); valu_floor: every vector instruction at the fastest rate
+        not divided into them.  hbm_floor: algorithmic bytes at the two-stream rate the pool's probes MEASURED for two region
+        classes (kmers_pool_info; 8 TB/s spec without a pool); valu_floor: every vector instruction at the fastest rate
         the SIMDs issue (VALU_CYCLES_FAST) -- a floor no instruction mix can beat, `valu_floor_ms_all_slow` the same at the
         rate of every other instruction class; frac_of_max_floor = the larger floor / the profiled duration (<= 1 by construction)."""
         v = valu.get(leg)
@@ -382,7 +382,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
     with torch.cuda.stream(stream):
         # C3: CanonicalDNAMers{31} over 10 Gbase LongDNA{2} sharded 8 ways -> 1.25 Gbase per GPU, kmers only
         L, K = 1_250_000_000, 31
-        # (a launch with ONE output array takes it from the arena by role -- kmers_dev_alloc_role(KMERS_ALLOC_LONE_OUTPUT): across a
+        # (a launch with ONE output array takes it from the pool by role -- kmers_dev_alloc_role(KMERS_ALLOC_LONE_OUTPUT): across a
         # class boundary of HBM, written through two windows; sized to the launch, as a host's `collect` would)
         lone = mem.empty(L - K + 1, lone_output=True)
         buf = synth(GOLDEN ^ 3, L, 2)
@@ -457,7 +457,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
         # reverse_complement over an array of kmers (kmer.jl:255-261, transformations.jl:32-34)
         Kf = 31
         idx = torch.randint(0, 4, (L,), dtype=torch.uint8, device=dev)
-        text_words = mem.empty(L // 8 + 2)                                              # (the text lives in the arena like every other buffer)
+        text_words = mem.empty(L // 8 + 2)                                              # (the text comes from kmers_dev_alloc like every other buffer)
         text = text_words.view(torch.uint8)
         text.fill_(65)                                                                   # "A"
         for code, add in ((1, 2), (2, 6), (3, 19)):                                        # "C", "G", "T"
@@ -688,7 +688,7 @@ def north_star_one_gpu(ctx, cap, stream, dev, mem, reps=7, L=NORTH_STAR_BASES):
         return {name: {"skipped": f"needs {need / 1e9:.0f} GB of HBM, {room / 1e9:.0f} GB available"}}
     seed10 = GOLDEN ^ 10
     nw = (L * 4 + 63) // 64
-    a, h = mem.empty(n), mem.empty(n)  # (the 80 GB arrays before the 5 GB one: each must find one free range of the arena)
+    a, h = mem.empty(n), mem.empty(n)  # (the two 80 GB arrays one after the other: different classes at every position)
     buf = mem.empty(nw + 2)
     ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed10, 0, nw, 4, 0, buf.data_ptr()), "kmers_synth_dna")
     seq = cap.Seq(buf.data_ptr(), L, 0, 0, 4, 0)
@@ -726,14 +726,11 @@ def pmc_child(args):
             ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, seed, 0, nw, bits, amb, buf.data_ptr()), "kmers_synth_dna")
         return buf
     if args.pmc_child == "headline":
-        # the outputs from an arena of this process's own, as in the timed leg (the parent holds three quarters of the device in
-        # its arena: this one is three quarters of the rest), so that the launcher sees placed arrays and picks the same shape;
-        # the shape it picked goes to stdout for the parent
+        # the outputs from this process's own pool, as in the timed leg, so that the launcher sees placed arrays and picks the same
+        # shape; the shape it picked goes to stdout for the parent
         n = L - K + 1
         N = cap.load().kmers_words_per_kmer(K, 2)
-        if args.alloc in ("arena", "pool"):
-            if args.alloc == "arena":
-                ctx.arena_reserve(0)
+        if args.alloc == "pool":
             p_k = ctx.alloc(8 * n * N, lone_output=args.no_hash)
             p_h = None if args.no_hash else ctx.alloc(8 * n)
         else:
@@ -794,7 +791,7 @@ def run_pmc_pass(args, which, counters, device_index, timeout):
                os.path.abspath(__file__), "--pmc-child", which, "--bases", str(args.bases), "--k", str(args.k), "--src-bits", str(args.src_bits)]
         if args.no_hash:
             cmd.append("--no-hash")
-        cmd += ["--alloc", getattr(args, "alloc", "arena")]
+        cmd += ["--alloc", getattr(args, "alloc", "pool")]
         # a clean environment for the child: no profiler variables of an outer run, one visible device (the rank's own)
         env = {k: v for k, v in os.environ.items()
                if not k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER_")) and k not in ("LD_PRELOAD", "RANK", "LOCAL_RANK", "WORLD_SIZE",
@@ -837,7 +834,7 @@ def measure_traffic(args, device_index=0, timeout=600):
     # FETCH_SIZE reports half of a coalesced streaming read on gfx950 -> doubled; WRITE_SIZE is exact for 16 B/lane stores
     traffic = int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)
     return traffic, (f"measured in this run: two rocprofv3 --pmc child passes, each a fresh process that launches the headline kernel at the "
-                     f"headline size into outputs from an arena of its own (launch shape there: {shape}) (FETCH_SIZE {vals['FETCH_SIZE']:.1f} KiB "
+                     f"headline size into outputs from a pool of its own (launch shape there: {shape}) (FETCH_SIZE {vals['FETCH_SIZE']:.1f} KiB "
                      f"x 2 [gfx950 correction], WRITE_SIZE {vals['WRITE_SIZE']:.1f} KiB)")
 
 
@@ -914,8 +911,7 @@ class Leg:
         sh = self.sh = self.plan[env.rank]
         self.N = cap.load().kmers_words_per_kmer(args.k, 2)
         with torch.cuda.stream(env.stream):
-            # the two output arrays first and one right after the other: the library gives consecutive blocks different region
-            # classes (and in an arena the 80 GB arrays of the 10 Gbase legs find their room before the small block does)
+            # the two output arrays first and one right after the other: the library gives consecutive blocks different region classes
             self.out_k = mem.empty(sh.n_kmers * self.N, lone_output=args.no_hash)
             self.out_h = None if args.no_hash else mem.empty(sh.n_kmers)
             self.buf = mem.empty(sh.n_own_words + sh.halo_words + 2)
@@ -957,12 +953,6 @@ class Leg:
         import numpy as np
         import torch
         env = self.env
-        if getattr(env.mem, "kind", "") == "arena" and env.mem.use_arena and not solo and env.world == 1:
-            # the arena's launcher may time its shape table against its base rule ONCE, in a synchronous call (never inside the
-            # asynchronous steps below: KMERS_PARAM_SHAPE_CALIBRATE); the pool's blocks need no such check
-            rc = env.ctx.lib.kmers_canonical(env.ctx.handle, C.byref(self.seq), env.args.k, 2, self.out_k.data_ptr(), self.ph, 0, env.cap.MEM_DEVICE,
-                                             C.byref(self.res))
-            assert rc == 0, env.ctx.last_error()
         for _ in range(warmup):
             self.step()
         rc, _ = env.ctx.sync()
@@ -990,6 +980,61 @@ class Leg:
         self.env.mem.free(self.buf, self.out_k, self.out_h)
         self.buf = self.out_k = self.out_h = self.halo = None
         torch.cuda.empty_cache()
+
+
+def fresh_outputs_leg(env, leg, warmup, steps, resident_ms_per_step):
+    """The timed region again with FRESH outputs for every step: {kmers_dev_alloc(kmers), kmers_dev_alloc(hashes), launch,
+    kmers_dev_free, kmers_dev_free} x steps between two fences, same source, same wall clock -- what a host that calls
+    `collect(CanonicalDNAMers{K}(seq))` per sequence pays for its allocator (the headline's allocator must be usable
+    that way).  Host time inside the calls, and what the pool did, are reported beside it."""
+    import numpy as np
+    ctx, cap, args = env.ctx, env.cap, env.args
+    n, N = leg.sh.n_kmers, leg.N
+    res = cap.Result()
+    flags = cap.MEM_DEVICE | cap.ASYNC
+    alloc_us, free_us = [], []
+
+    def one(timed):
+        t0 = time.perf_counter()
+        pk = ctx.alloc(8 * n * N, lone_output=args.no_hash)
+        ph = None if args.no_hash else ctx.alloc(8 * n)
+        t1 = time.perf_counter()
+        rc = ctx.lib.kmers_canonical(ctx.handle, C.byref(leg.seq), args.k, 2, pk, ph, 0, flags, C.byref(res))
+        t2 = time.perf_counter()
+        ctx.free(pk)
+        if ph:
+            ctx.free(ph)
+        t3 = time.perf_counter()
+        if rc != 0:
+            raise RuntimeError(f"kmers_canonical failed: {ctx.last_error()}")
+        if timed:
+            alloc_us.append((t1 - t0) * 1e6)
+            free_us.append((t3 - t2) * 1e6)
+    t_first = time.perf_counter()
+    one(False)  # the first round assembles the blocks (the pool walks for its classes, maps, checks): priced on its own
+    env.fence(True)
+    first_ms = (time.perf_counter() - t_first) * 1e3
+    for _ in range(warmup):
+        one(False)
+    before = ctx.pool_stats()
+    env.fence(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one(True)
+    env.fence(True)
+    elapsed = time.perf_counter() - t0
+    rc, _ = ctx.sync()
+    assert rc == 0, ctx.last_error()
+    after = ctx.pool_stats()
+    ms = elapsed / steps * 1e3
+    return {"what": "the K timed steps again with fresh outputs per step: {kmers_dev_alloc x 2, launch, kmers_dev_free x 2} between two fences "
+                    "(the resident arrays of the headline stay allocated beside them)",
+            "ms_per_step": round(ms, 4), "Gbases_per_s": round(leg.sh.n_bases / ms / 1e6, 2),
+            "over_resident": round(ms / resident_ms_per_step, 4),
+            "alloc_us_per_step": round(float(np.median(alloc_us)), 1), "free_us_per_step": round(float(np.median(free_us)), 1),
+            "first_round_ms": round(first_ms, 2),
+            "pool_cache_hits": after["cache_hits"] - before["cache_hits"], "pool_blocks_assembled": after["cache_misses"] - before["cache_misses"],
+            "pool_handles_created": after["chunks_created"] - before["chunks_created"]}
 
 
 class Env:
@@ -1030,7 +1075,7 @@ def strong_scaling_entry(args, K, bits, world, strong_bases, s_per_rank, bytes_p
 
 
 def assemble_line(args, K, bits, world, strong, grouped, backend, transport, total_bases, plan_bases, seed, elapsed, per_rank, bytes_per_kmer,
-                  verified, use_arena, arena_gb, arena_map, write_ceiling, shape_report, plain_alloc, fill_gbps, strong_extra):
+                  verified, use_lib, write_ceiling, shape_report, plain_alloc, fill_gbps, strong_extra):
     """Rank 0's JSON line from what the ranks measured (per_rank[r] = [elapsed s, kernel ms, halo-step ms, kmers]); pure, so that
     tests/test_bench_contract.py can check the N > 1 schema on a machine without GPUs.  roofline.traffic, other_configs and
     cpu_baseline are filled in by the caller."""
@@ -1062,8 +1107,7 @@ def assemble_line(args, K, bits, world, strong, grouped, backend, transport, tot
                    "bases_per_gpu": plan_bases if strong else args.bases,
                    "sharding": sharding, "backend": backend, "halo_transport": transport if grouped else None,
                    "seed": hex(seed), "wake_s": args.wake_s,
-                   "alloc": (f"kmers_arena_reserve ({arena_gb} GB, one block) + kmers_dev_alloc" if use_arena else "torch.empty (hipMalloc)"),
-                   "arena_region_map": arena_map},
+                   "alloc": ("kmers_dev_alloc: the device's class pool (no reservation)" if use_lib else "torch.empty (hipMalloc)")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": "not measured",
                      "kernel": "stream_kernel<src_bits,N,CANON,stride1>", "kernel_ms": round(kern_list[worst], 4),
@@ -1149,8 +1193,6 @@ def main():
         dist.barrier()
     cap = km._capi
     ctx = km.Context(dev_index)
-    if args.no_shape_calibration:
-        ctx.set_param(cap.PARAM_SHAPE_CALIBRATE, 0)
     stream = torch.cuda.ExternalStream(ctx.lib.kmers_ctx_stream(ctx.handle), device=dev)
     if args.tile:
         ctx.set_param(cap.PARAM_TILE_KMERS, args.tile)
@@ -1168,8 +1210,7 @@ def main():
     # hands the 128-byte ncclUniqueId around); under gloo (shared-device debugging, CPU tests) torch.distributed's
     transport = os.environ.get("KMERS_HALO_TRANSPORT", "native" if backend == "nccl" else "allgather")
     shared_device = grouped and backend != "nccl"  # (gloo debugging mode: the ranks share one device and its memory)
-    use_arena = args.alloc in ("arena", "pool") and not shared_device  # (the library's allocator: the class pool, or the arena of rounds 3-4)
-    use_pool = use_arena and args.alloc == "pool"
+    use_pool = args.alloc == "pool" and not shared_device  # (the library's allocator: the device's class pool)
 
     env = Env()
     env.args, env.ctx, env.cap, env.dev, env.stream = args, ctx, cap, dev, stream
@@ -1182,11 +1223,11 @@ def main():
         torch.cuda.synchronize()
     env.fence = fence
 
-    # ---- the same launch into PLAIN allocations, before the arena exists (rank 0, N = 1; not the headline) -----------
-    # Where the outputs live is worth 3-5 % on this device (profiles/r03_alloc.md): this is what a host gets that allocates
-    # its outputs one hipMalloc each on a fresh machine, kept in the line next to the arena's figure.
+    # ---- the same launch into PLAIN allocations, before the pool exists (rank 0, N = 1; not the headline) -----------
+    # Where the outputs live is worth 8-10 % on this device (profiles/r03_alloc.md, r05_vmm.md): this is what a host gets that
+    # allocates its outputs one hipMalloc each on a fresh machine, kept in the line next to the pool's figure.
     plain_alloc = None
-    if use_arena and world == 1 and not strong and not args.no_other_configs:
+    if use_pool and world == 1 and not strong and not args.no_other_configs:
         try:
             env.mem = Memory(ctx, dev, False)
             leg0 = Leg(env, total_bases, seed)
@@ -1198,27 +1239,8 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             plain_alloc = {"error": repr(e)}
-    arena_gb, arena_map = 0.0, None
-    write_ceiling = (HBM_PEAK_GBPS, "8 TB/s spec (no arena map in this run)")
-    if use_arena and not use_pool:
-        try:
-            arena_gb = round(ctx.arena_reserve(int(args.arena_gb * 1e9)) / 1e9, 1)
-        except Exception as e:  # noqa: BLE001  (a device with less free memory than the explicit size)
-            log(f"arena of {args.arena_gb} GB could not be reserved ({e!r}): three quarters of the free memory instead")
-            arena_gb = round(ctx.arena_reserve(0) / 1e9, 1)
-        _base, gran, classes = ctx.arena_regions()
-        if gran:  # run-length form of the measured map: "A16 B16 C4 ..." = 16 granules of class A, 16 of class B, ...
-            runs, start = [], 0
-            for i in range(1, len(classes) + 1):
-                if i == len(classes) or classes[i] != classes[start]:
-                    runs.append(f"{chr(65 + classes[start])}{i - start}")
-                    start = i
-            arena_map = f"{gran >> 30} GiB granules: " + " ".join(runs)
-        best_pair, one_class = ctx.arena_rates()
-        if best_pair > 0:
-            write_ceiling = (best_pair, f"kmers_arena_rates: best pair of places of this run's arena, two 1 GiB store streams side by side "
-                                        f"({best_pair:.0f} GB/s; inside one region class {one_class:.0f} GB/s)")
-    mem = env.mem = Memory(ctx, dev, use_arena, "pool" if use_pool else "arena")
+    write_ceiling = (HBM_PEAK_GBPS, "8 TB/s spec (no pool in this run)")
+    mem = env.mem = Memory(ctx, dev, use_pool)
     if grouped and transport == "native":
         if backend != "nccl":
             raise SystemExit("KMERS_HALO_TRANSPORT=native needs one GPU per rank (RCCL); the gloo mode shares a device")
@@ -1248,7 +1270,8 @@ def main():
     if use_pool:  # what the pool made of the two arrays, and the write ceiling ITS probes measured on this box
         info = ctx.pool_info()
         runs = lambda p: " ".join(f"{'ABCD?'[c]}{n}" for c, n in run_lengths(ctx.pool_layout(p)[1])) if p else None
-        pool_report = {"held_GB": round(info["held"] / 1e9, 1), "in_use_GB": round(info["in_use"] / 1e9, 1), "classes": info["n_classes"],
+        pool_report = {"held_GB": round(info["held"] / 1e9, 1), "in_use_GB": round(info["in_use"] / 1e9, 1),
+                       "held_over_in_use": round(info["held"] / max(1, info["in_use"]), 3), "classes": info["n_classes"],
                        "GB_per_class": [round(b / 1e9, 1) for b in info["class_bytes"]],
                        "kmers_array": runs(leg.out_k.data_ptr()), "hashes_array": runs(leg.out_h.data_ptr() if leg.out_h is not None else 0),
                        "what": "1 GiB handles of HIP virtual-memory management, class of each measured by the pool; arrays as runs of handles per class"}
@@ -1273,7 +1296,12 @@ def main():
     elapsed = max(p[0] for p in per_rank)
 
     chosen_shape = ctx.last_launch_shape()
-    chosen_calibration = ctx.last_shape_calibration()  # (what the launcher itself measured on its first launch into these arrays)
+    fresh_report = None
+    if use_pool and rank == 0 and world == 1 and not strong:
+        try:
+            fresh_report = fresh_outputs_leg(env, leg, args.warmup, args.steps, elapsed / args.steps * 1e3)
+        except Exception as e:  # noqa: BLE001
+            fresh_report = {"error": repr(e)}
     # ---- integrity of what the timed kernel wrote (outside the timed region) --------------
     verified = leg.verify()
     # ---- the launcher's choice against the alternatives of its table (stream_launch.hpp), same arrays, same run --------
@@ -1293,12 +1321,6 @@ def main():
             worst = max(cands, key=cands.get)
             shape_report = {"chosen": name, "chosen_ms": again, "candidates_ms": cands, "best": best, "worst": worst,
                             "chosen_over_best": round(again / cands[best], 4),
-                            "launcher_calibration": ({"table_ms": round(chosen_calibration[0], 4), "rule_ms": round(chosen_calibration[1], 4),
-                                                      "rule_chosen": chosen_calibration[2],
-                                                      "what": "KMERS_PARAM_SHAPE_CALIBRATE: the library's own timing of its tabulated shape against "
-                                                              "its base rule's (256 x 1024 here) on the first launch into these arrays, best of three "
-                                                              "each; the rule has to be 3 % faster to be taken"}
-                                                     if chosen_calibration[0] > 0 else None),
                             "what": "threads per workgroup x kmers per tile; every candidate forced with KMERS_PARAM_BLOCK_THREADS / _TILE_KMERS into "
                                     "the arrays of the timed leg, 7 launches behind 0.1 s of the same launch each, after the timed region"}
         except Exception as e:  # noqa: BLE001
@@ -1365,16 +1387,17 @@ def main():
 
     if rank == 0:
         line = assemble_line(args, K, bits, world, strong, grouped, backend, transport, total_bases, [s.n_bases for s in plan], seed, elapsed,
-                             per_rank, bytes_per_kmer, verified, use_arena, arena_gb, arena_map, write_ceiling, shape_report, plain_alloc,
-                             fill_gbps, strong_extra)
+                             per_rank, bytes_per_kmer, verified, use_pool, write_ceiling, shape_report, plain_alloc, fill_gbps, strong_extra)
         if pool_report is not None:
-            line["config"]["alloc"] = "kmers_dev_alloc: the device's class pool (no reservation)"
             line["config"]["pool"] = pool_report
+        if fresh_report is not None:
+            line["fresh_outputs_per_step"] = fresh_report
+        if use_pool:
             ctx.pool_trim()  # (the profiled child processes below make pools of their own)
         rf = line["roofline"]
         # the PMC child passes, rank 0's device (the other ranks wait in the barrier at the end)
         pmc_args = argparse.Namespace(**vars(args))
-        if strong:  # the child profiles a launch of the rank's shard size, capped at what fits beside this process's arena
+        if strong:  # the child profiles a launch of the rank's shard size, capped at what fits beside this process's buffers
             pmc_args.bases = max(K, min(sh.n_bases, 2_000_000_000))
         child_timeout = 600 if world == 1 else 200
         traffic, source = (None, "not measured (--no-pmc)") if args.no_pmc else measure_traffic(pmc_args, dev_index, child_timeout)

@@ -1,10 +1,12 @@
 /* resident_pipeline.c -- a plain-C host that keeps its sequence and its outputs in HBM (no Python, no Julia, no HIP headers):
  *   CanonicalDNAMers{31}(seq) + fx_hash of every element (src/iterators/CanonicalKmers.jl:199-225, src/kmer.jl:255-261) over a
  *   synthetic LongDNA{4} sequence, launched asynchronously a few times,
- *     (a) into two plain device allocations (kmers_dev_alloc without an arena = hipMalloc),
- *     (b) into two blocks of the context's ARENA (kmers_arena_reserve: the library measures the region map of its block and
- *         places the arrays of a launch where they are written fastest together, include/kmers_hip.h),
- *   and prints the time per launch of both and the measured map.  The two runs must produce identical elements.
+ *     (a) into two plain device allocations (KMERS_PARAM_POOL = 0: kmers_dev_alloc = hipMalloc),
+ *     (b) into two blocks of the device's CLASS POOL (the default: the arrays of a launch, allocated one after the other, lie in
+ *         different region classes of HBM and are written at the two-class rate, include/kmers_hip.h),
+ *     (c) like (b), but with FRESH outputs for every launch -- {alloc, alloc, launch, free, free}, what `collect` per sequence
+ *         amounts to: a freed block stays mapped in the pool's cache and the next request of its shape takes it back,
+ *   and prints the time per launch of each.  The runs must produce identical elements.
  *
  *   gcc -std=c99 -Iinclude examples/resident_pipeline.c -Lkmers.jl_amd/csrc -lkmers_hip \
  *       -Wl,-rpath,$PWD/kmers.jl_amd/csrc -o resident_pipeline && ./resident_pipeline [Mbases]
@@ -44,20 +46,23 @@ int main(int argc, char **argv) {
         return 2;
     }
     double ms[2] = {0, 0};
-    for (int with_arena = 0; with_arena < 2; ++with_arena) {
-        if (with_arena) {
-            CHECK(kmers_arena_reserve(ctx, 0));
-            size_t gran = 0, n_regions = 0;
-            unsigned char classes[1024];
-            CHECK(kmers_arena_regions(ctx, NULL, &gran, classes, sizeof classes, &n_regions));
-            printf("arena: %zu granules of %zu GiB, classes ", n_regions, gran >> 30);
-            for (size_t i = 0; i < n_regions && i < sizeof classes; ++i) putchar('A' + classes[i]);
-            putchar('\n');
-        }
+    for (int with_pool = 0; with_pool < 2; ++with_pool) {
+        CHECK(kmers_ctx_set_param(ctx, KMERS_PARAM_POOL, with_pool));
         void *words = NULL, *out_kmers = NULL, *out_hashes = NULL;
         CHECK(kmers_dev_alloc(ctx, (n_words + 2) * 8, &words));
         CHECK(kmers_dev_alloc(ctx, n * 8, &out_kmers));   /* the arrays of one launch, one after the other */
         CHECK(kmers_dev_alloc(ctx, n * 8, &out_hashes));
+        if (with_pool) {
+            size_t n_chunks = 0, chunk_bytes = 0;
+            unsigned char classes[2][64];
+            void *arrays[2] = {out_kmers, out_hashes};
+            for (int a = 0; a < 2; ++a) {
+                CHECK(kmers_pool_layout(ctx, arrays[a], &chunk_bytes, classes[a], sizeof classes[a], &n_chunks));
+                printf("pool: %s in %zu handle%s of %zu GiB, classes ", a ? "hashes" : "kmers", n_chunks, n_chunks == 1 ? "" : "s", chunk_bytes >> 30);
+                for (size_t i = 0; i < n_chunks && i < sizeof classes[a]; ++i) putchar('A' + classes[a][i]);
+                putchar('\n');
+            }
+        }
         CHECK(kmers_synth_dna(ctx, 42, 0, n_words, 4, 0, (uint64_t *)words));
         kmers_seq seq = {(const uint64_t *)words, n_bases, 0, 0, 4, 0};
         kmers_result res;
@@ -68,18 +73,43 @@ int main(int argc, char **argv) {
         for (int r = 0; r < reps; ++r)
             CHECK(kmers_canonical(ctx, &seq, k, 2, (uint64_t *)out_kmers, (uint64_t *)out_hashes, 0, KMERS_MEM_DEVICE | KMERS_ASYNC, &res));
         CHECK(kmers_sync(ctx, &res));
-        ms[with_arena] = (now_ms() - t0) / reps;
+        ms[with_pool] = (now_ms() - t0) / reps;
         const uint64_t m = n < HEAD ? n : HEAD;
-        CHECK(kmers_memcpy_d2h(ctx, head[with_arena][0], out_kmers, m * 8));
-        CHECK(kmers_memcpy_d2h(ctx, head[with_arena][1], out_hashes, m * 8));
+        CHECK(kmers_memcpy_d2h(ctx, head[with_pool][0], out_kmers, m * 8));
+        CHECK(kmers_memcpy_d2h(ctx, head[with_pool][1], out_hashes, m * 8));
         for (uint64_t i = 0; i < m; ++i)
-            if (head[with_arena][1][i] != head[with_arena][0][i] * 0x517cc1b727220a95ull) {
+            if (head[with_pool][1][i] != head[with_pool][0][i] * 0x517cc1b727220a95ull) {
                 fprintf(stderr, "hash %llu is not fx_hash of its kmer\n", (unsigned long long)i);
                 return 1;
             }
         printf("%-24s %8.3f ms per launch = %6.1f Gbases/s = %5.2f TB/s of algorithmic traffic (16.5 B per kmer)\n",
-               with_arena ? "outputs from the arena:" : "plain allocations:", ms[with_arena], n_bases / ms[with_arena] / 1e6,
-               16.5 * n / ms[with_arena] / 1e9);
+               with_pool ? "outputs from the pool:" : "plain allocations:", ms[with_pool], n_bases / ms[with_pool] / 1e6,
+               16.5 * n / ms[with_pool] / 1e9);
+        if (with_pool) { /* (c) fresh outputs per launch: the collect loop */
+            CHECK(kmers_dev_free(ctx, out_kmers));
+            CHECK(kmers_dev_free(ctx, out_hashes));
+            const double t1 = now_ms();
+            for (int r = 0; r < reps; ++r) {
+                CHECK(kmers_dev_alloc(ctx, n * 8, &out_kmers));
+                CHECK(kmers_dev_alloc(ctx, n * 8, &out_hashes));
+                CHECK(kmers_canonical(ctx, &seq, k, 2, (uint64_t *)out_kmers, (uint64_t *)out_hashes, 0, KMERS_MEM_DEVICE | KMERS_ASYNC, &res));
+                if (r + 1 < reps) {
+                    CHECK(kmers_dev_free(ctx, out_kmers));   /* no wait: the next user of the block comes after this launch */
+                    CHECK(kmers_dev_free(ctx, out_hashes));
+                }
+            }
+            CHECK(kmers_sync(ctx, &res));
+            const double fresh = (now_ms() - t1) / reps;
+            uint64_t stats[KMERS_POOL_STATS];
+            CHECK(kmers_pool_stats(ctx, stats, KMERS_POOL_STATS));
+            printf("%-24s %8.3f ms per {alloc, alloc, launch, free, free} (%llu of the pool's %llu allocations came from its cache)\n",
+                   "fresh outputs per launch:", fresh, (unsigned long long)stats[4], (unsigned long long)(stats[4] + stats[5]));
+            CHECK(kmers_memcpy_d2h(ctx, head[0][1], out_hashes, m * 8));
+            if (memcmp(head[0][1], head[1][1], m * 8) != 0) {
+                fprintf(stderr, "the launch into fresh outputs differs\n");
+                return 1;
+            }
+        }
         CHECK(kmers_dev_free(ctx, words));
         CHECK(kmers_dev_free(ctx, out_kmers));
         CHECK(kmers_dev_free(ctx, out_hashes));
@@ -90,8 +120,9 @@ int main(int argc, char **argv) {
         return 1;
     }
     printf("both runs: %llu elements, the first %llu identical: equal\n", (unsigned long long)n, (unsigned long long)m);
-    /* A launch with ONE output array (the kmers without their hashes): an ordinary block of the arena against a block taken by
-     * role, which lies across a class boundary of HBM and is written through two windows (include/kmers_hip.h). */
+    /* A launch with ONE output array (the kmers without their hashes): an ordinary block of the pool against a block taken by
+     * role, whose second half lies in another region class than its first and which is written through two windows
+     * (include/kmers_hip.h; arrays of 2 GiB and more: a block is made of whole 1 GiB handles). */
     for (int role = KMERS_ALLOC_DEFAULT; role <= KMERS_ALLOC_LONE_OUTPUT; ++role) {
         void *words = NULL, *only_out = NULL;
         CHECK(kmers_dev_alloc_role(ctx, n * 8, role, &only_out));

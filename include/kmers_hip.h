@@ -114,24 +114,19 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 #define KMERS_PARAM_BATCH_PASSES 5     /* kmers_batch: elements per workgroup tile = 1024 * value (1..8); 0 = chosen from the batch size */
 #define KMERS_PARAM_SKETCH_BATCH_LDS 6 /* kmers_minhash_batch: candidate values per workgroup (2048 / 4096 / 8192); 0 = chosen per call */
 #define KMERS_PARAM_SPLIT_ORDER 9      /* the tile kernels visit the two halves of their tile range alternately (two write windows per output
-                                         * array).  0: when the launch has ONE output array and the arena's map says it lies across a class
-                                         * boundary (kmers_dev_alloc_role(KMERS_ALLOC_LONE_OUTPUT)): +6 % there; 1: always; -1: never.
+                                         * array).  0: when the launch has ONE output array whose halves lie in two region classes (a block
+                                         * taken with kmers_dev_alloc_role(KMERS_ALLOC_LONE_OUTPUT)): +6 % there; 1: always; -1: never.
                                          * Results are identical either way. */
-#define KMERS_PARAM_ARENA_NO_PROBE 8   /* 1: kmers_arena_reserve does not measure the region map of its block (best-fit placement only) */
 #define KMERS_PARAM_BLOCK_THREADS 10   /* threads per workgroup of the tile kernels: 64, 128 or 256 (0: chosen per output shape) */
 #define KMERS_PARAM_WIDE_NO_TILES 11   /* A/B, tests.  1: kmers of more than four words always on the one-lane-per-kmer kernel; 2: the
                                         * run-time-width tile form also for kmers of one to four words (it loses there: profiles/r03_wide.md) */
 #define KMERS_PARAM_HOST_CHUNKS 12      /* -1: a host-pointer call (KMERS_MEM_HOST) is one launch + one copy whatever its size; 0 (default): outputs of
                                         * 96 MiB or more travel in chunks, the kernel of the next chunk beside the copy of the current one */
-#define KMERS_PARAM_SHAPE_CALIBRATE 13   /* 1 (default): the first SYNCHRONOUS launch of 1 GB or more into arrays of the ARENA for which the launcher's table departs
-                                         * from its base rule times both shapes (eight launches, alternately; the call blocks for that long once).  The answer is
-                                         * remembered per launch configuration and PLACEMENT (the runs of the arena the arrays start in, a size bucket), not per
-                                         * pointer: fresh arrays of a later call meet it again, kmers_dev_free forgets nothing.  Never inside a KMERS_ASYNC call
-                                         * (the table's shape runs; a later synchronous call may calibrate), never for blocks of the striped pool (placed well by
-                                         * construction) or plain allocations.  0: the table is trusted.  kmers_last_launch_shape tells. */
-#define KMERS_PARAM_POOL 14             /* 1 (default): without an arena, kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the device's class pool
-                                         * (below); 0: plain hipMalloc */
-#define KMERS_PARAM_POOL_SEARCH_GIB 15  /* how far past a request the pool may grow in search of memory of the classes it wants (default 128); 0: never */
+#define KMERS_PARAM_POOL 14             /* 1 (default): kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the device's class pool (below); 0: plain hipMalloc */
+#define KMERS_PARAM_POOL_SEARCH_GIB 15  /* how far past a request the pool may grow in search of memory of the classes it wants (default: 8 x the request,
+                                         * 16 GiB at least; what it walked past goes back to the driver once the block is made); 0: never */
+#define KMERS_PARAM_POOL_CACHE 18       /* 1 (default): a freed block of the pool stays mapped for the next request of its shape; 0: taken apart at once (the
+                                         * free then waits for the work queued on the device's contexts) */
 #define KMERS_PARAM_BATCH_DENSE 17       /* A/B, tests.  -1: kmers_batch never takes its dense tile path (csrc/ragged_kernels.hpp); 0 (default): wherever a tile allows */
 #define KMERS_PARAM_POOL_MAX_GIB 16     /* cap on the physical memory the pool holds (0, default: what the device has) */
 #define KMERS_PARAM_SUBTILES 7         /* strided tile kernels (kmers_spaced, kmers_minimizers): consecutive tiles per workgroup, the next one's source words in flight */
@@ -139,50 +134,63 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value);
 /* The launch shape the library chose for the most recent launch of its tile kernel in this context (kmers_fw / kmers_canonical /
  * kmers_spaced and the fused consumers that run on it): threads per workgroup, kmers per tile, and whether every output array
  * was written through two windows.  The table behind the choice (csrc/stream_launch.hpp) depends on the kmer width, the number
- * of output arrays and on where the arena says they lie; this is how a host, a test or bench.py sees what it came to, and
+ * of output arrays and on where the pool says they lie; this is how a host, a test or bench.py sees what it came to, and
  * times the alternatives against it (KMERS_PARAM_TILE_KMERS / _BLOCK_THREADS / _SPLIT_ORDER).  All zero before any launch. */
 int kmers_last_launch_shape(kmers_ctx *ctx, int *threads, int *tile_kmers, int *split_order);
-/* What the shape of the most recent tile-kernel launch rested on when KMERS_PARAM_SHAPE_CALIBRATE applied to it: the best of three
- * timed launches of the launcher's tabulated shape and of its base rule's in the launch's own output arrays (milliseconds), and
- * whether the rule's was taken (it has to be 3 % faster).  All zero when no calibration applied (small launches, overrides,
- * plain allocations, shapes the table does not touch). */
-int kmers_last_shape_calibration(kmers_ctx *ctx, double *table_ms, double *rule_ms, int *rule_chosen);
-/* How many calibrations (timed launches of both shapes) this context has run since it was created. */
-int kmers_shape_calibrations(kmers_ctx *ctx, uint64_t *count);
 
 /* ---- device memory ---------------------------------------------------------------------------
  * For hosts without a HIP binding of their own (the reference allocates its outputs itself: `collect` makes one Vector per
- * call).  kmers_dev_free first waits for the context's stream (and, for blocks of the pool, for the device).
+ * call, Base.collect over src/iterators/CanonicalKmers.jl:199-225).
  *
  * WHERE an array lies matters on MI355X: HBM behaves as three REGION CLASSES of physical memory; store streams that run side by
  * side inside one class share about 6.0-6.4 TB/s, streams in different classes reach 7.1-7.2 (profiles/r03_alloc.md,
- * profiles/r05_vmm.md).  A plain hipMalloc lies wherever the driver puts it -- usually inside one class.  So, by default, a
- * block of KMERS_POOL_MIN_BYTES or more comes from the device's CLASS POOL: physical memory in 1 GiB handles of HIP's
- * virtual-memory management, the class of each handle measured once when the pool takes it (about 1 ms of probes), each block
- * mapped from handles chosen by class: a block differs from the block allocated before it (the most recent one that is still
- * out) at every relative position -- allocate the arrays of one launch one after the other and they are written at the
- * two-class rate; KMERS_ALLOC_LONE_OUTPUT gives a block whose second half differs from its first, for launches with one output
- * (written through two windows half an array apart).  No reservation is needed and it does not matter how finely the classes
- * are interleaved in a box's physical memory.  Blocks are whole handles (sizes round up to 1 GiB).  The pool holds what was
- * asked of it plus what it had to walk past in search of the classes it wanted (KMERS_PARAM_POOL_SEARCH_GIB, default 128) until
- * kmers_pool_trim or until the last context of the device that used it is destroyed; one handle per class found stays with the
- * pool as the yardstick later handles are measured against.  One pool per device and process, shared by its contexts,
- * thread-safe.  Smaller blocks, a device without virtual-memory management, or KMERS_PARAM_POOL = 0: plain hipMalloc. */
+ * profiles/r05_vmm.md).  A plain hipMalloc lies wherever the driver puts it -- usually inside one class.  So a block of
+ * KMERS_POOL_MIN_BYTES or more comes from the device's CLASS POOL: physical memory in 1 GiB handles of HIP's virtual-memory
+ * management, the class of each handle measured once when the pool takes it (about 1 ms of probes), each block made of handles
+ * chosen by class: a block differs from the block allocated before it (the most recent one that is still out) at every relative
+ * position -- allocate the arrays of one launch one after the other and they are written at the two-class rate;
+ * KMERS_ALLOC_LONE_OUTPUT gives a block whose second half differs from its first, for launches with one output (written through
+ * two windows half an array apart).  No reservation is needed and it does not matter how finely the classes are interleaved in a
+ * box's physical memory.  Blocks are whole handles (sizes round up to 1 GiB; an array of 128 MiB to 1 GiB is one handle).
+ *
+ * What a block costs (profiles/r06_pool.md).  kmers_dev_free of a pool block does NOT wait and calls nothing in the driver: the
+ * block stays mapped in the pool's cache, and the next kmers_dev_alloc of its shape (same number of handles, same role, classes
+ * that suit its new partner) returns it as it is -- a host loop {alloc, alloc, launch, free, free} (what `collect` per sequence
+ * amounts to) runs within a few microseconds per call of the same loop over resident arrays.  ORDER: the block's next user comes
+ * after everything that was queued, at the time of the free, on the streams of the contexts of this device that use the pool (the
+ * next user's stream waits for events recorded then; a user on the freeing context's own stream waits for nothing).  Work on any
+ * OTHER stream that still touches the block (a host framework's own streams) must have finished before kmers_dev_free -- as with
+ * any stream-ordered allocator.  A cached block nobody asked for over 32 pool calls is taken apart.
+ *
+ * What the pool holds: its blocks (out or cached) plus at most max(4 GiB, a quarter of that) of handles outside blocks -- one
+ * yardstick handle per class it has found, and free handles; what it walked past in search of a class
+ * (KMERS_PARAM_POOL_SEARCH_GIB) goes back to the driver as soon as the block is made.  kmers_pool_trim returns everything that is
+ * not out; so does any allocation of the library that would otherwise fail.  One pool per device and process, shared by its
+ * contexts, thread-safe.  Smaller blocks, a device without virtual-memory management, a pool that cannot get its handles (the
+ * cap KMERS_PARAM_POOL_MAX_GIB, a device too full), or KMERS_PARAM_POOL = 0: plain hipMalloc (kmers_dev_free of those waits for
+ * the context's stream and is a hipFree).  KMERS_E_NOMEM only when that fails too. */
 int kmers_dev_alloc(kmers_ctx *ctx, size_t bytes, void **out);
-/* The same with a word about what the block is for, which the arena (below) uses for its placement; without an arena, or when
- * the preferred place is taken, exactly kmers_dev_alloc.
+/* The same with a word about what the block is for:
  *   KMERS_ALLOC_DEFAULT      anything: inputs, the arrays of a launch with two outputs (placed in different region classes)
  *   KMERS_ALLOC_LONE_OUTPUT  the ONLY output array of the launches that fill it (collect(CanonicalKmers) without hashes,
- *                            FwKmers, SpacedKmers, a tuple array): placed ACROSS a class boundary, and a launch that finds its
- *                            one output there writes it through two windows, one per class (C3: 0.81 -> 0.87 of 8 TB/s). */
+ *                            FwKmers, SpacedKmers, a tuple array): its second half in another class than its first, and a
+ *                            launch that finds its one output there writes it through two windows (C3: 0.81 -> 0.87 of 8 TB/s). */
 #define KMERS_ALLOC_DEFAULT 0
 #define KMERS_ALLOC_LONE_OUTPUT 1
 int kmers_dev_alloc_role(kmers_ctx *ctx, size_t bytes, int role, void **out);
 int kmers_dev_free(kmers_ctx *ctx, void *p);
 int kmers_memcpy_h2d(kmers_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* For a chunk-buffered iterate() that computes chunk c + 1 while the host loops over chunk c (src/iterators/FwKmers.jl:57-66 is
+ * the protocol; julia/KmersHIP.jl GPUIterator and kmers.jl_amd/host.py are the callers): page-locked host memory, and copies that
+ * are only ENQUEUED on the context's stream, behind the launches before them -- complete after kmers_sync.  (From pageable memory
+ * such a copy is staged by the runtime and blocks the caller: use kmers_host_alloc for the buffers.) */
+int kmers_host_alloc(kmers_ctx *ctx, size_t bytes, void **out_host);
+int kmers_host_free(kmers_ctx *ctx, void *p_host);
+int kmers_memcpy_h2d_async(kmers_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int kmers_memcpy_d2h_async(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
-#define KMERS_POOL_MIN_BYTES ((size_t)1 << 30)
+#define KMERS_POOL_MIN_BYTES ((size_t)128 << 20)
 #define KMERS_POOL_CLASSES 4
 /* The device's class pool: physical bytes it holds, bytes in blocks that are out, region classes found so far, bytes held per
  * class (KMERS_POOL_CLASSES entries: classes 0..2, then memory the pool could not classify), and what its probes measured in GB/s of two store streams side by side (1 GiB each, the
@@ -190,7 +198,14 @@ int kmers_memcpy_d2h(kmers_ctx *ctx, void *dst_host, const void *src_dev, size_t
  * slowest pair of the calibration (one class; about 6200).  The first is the write ceiling bench.py prices the materialising kernels against.  Any
  * output may be NULL; all zero before the first block. */
 int kmers_pool_info(kmers_ctx *ctx, size_t *held, size_t *in_use, int *n_classes, size_t *class_bytes, double *two_class_gbps, double *one_class_gbps);
-/* Return to the driver every handle of the pool that is not part of a block (everything, yardsticks included, if no block is out). */
+/* Counters of the pool (at most `capacity` of the KMERS_POOL_STATS entries are written): [0] bytes held, [1] bytes in blocks that
+ * are out, [2] bytes in cached (freed, still mapped) blocks, [3] bytes in free handles, [4] allocations served from the cache,
+ * [5] allocations that assembled a block, [6] cached blocks taken apart, [7] handles created, [8] handles returned to the driver,
+ * [9] class probes run, [10] cached blocks, [11] blocks out. */
+#define KMERS_POOL_STATS 12
+int kmers_pool_stats(kmers_ctx *ctx, uint64_t *out, size_t capacity);
+/* Return to the driver every handle of the pool that is not part of a block that is out: the cache of freed blocks, the free
+ * handles (and the yardsticks too, if no block is out). */
 int kmers_pool_trim(kmers_ctx *ctx, size_t *released);
 /* The handles of the pool block that holds `block`: *n_chunks chunks of *chunk_bytes, chunk i in class classes[i]
  * (0..2, or KMERS_POOL_CLASSES - 1 = not classified; at most `capacity` entries are written).  *n_chunks = 0: not a block of the pool. */
@@ -199,46 +214,9 @@ int kmers_pool_layout(kmers_ctx *ctx, const void *block, size_t *chunk_bytes, un
  * kmers_last_error.  *stale_without_flush = 1: a re-used address range showed the memory of its PREVIOUS mapping until the pool's
  * flush ran -- the behaviour of this stack (ROCm 7.2) that every unmap of the pool guards against. */
 int kmers_pool_selftest(kmers_ctx *ctx, int *stale_without_flush);
-
-/* The ARENA (rounds 3-4; the pool above replaces it as the default and needs no reservation): one large block of HBM reserved
- * once, out of which kmers_dev_alloc then serves every request of a context attached to it that fits
- * (KMERS_ARENA_GRANULE-aligned ranges; a request that does not fit falls through to a plain allocation; kmers_dev_free returns
- * a range to the arena and merges it with its free neighbours).  Two reasons to use it:
- * (1) a collect per sequence allocates and releases tens of gigabytes, and a plain allocation of that size costs milliseconds;
- * (2) PLACEMENT.  On MI355X store streams that run side by side inside one region of HBM (a few classes of tens of gigabytes
- *     each; tools/xcd_affinity.hip, profiles/r03_alloc.md) share about 6.0 TB/s, streams in different classes reach about 7.1:
- *     the two output arrays of one launch are two such streams, and where two plain allocations happen to lie decides whether
- *     FwDNAMers{63} + reverse complements runs at 0.72 or at 0.89 of 8 TB/s (canonical 31-mers + hashes: 0.80 or 0.855).
- *     kmers_arena_reserve measures the map of its block (about 0.3 s for 200 GB; only blocks of 16 GiB or more;
- *     KMERS_PARAM_ARENA_NO_PROBE = 1 skips it) and kmers_dev_alloc places a block where the MEASURED two-stream rate beside the
- *     blocks that are live is highest (the previous allocation counting double): allocate the arrays of one launch one after
- *     the other and they end up in different classes.  kmers_arena_regions reports the map.  The launchers consult it too: two
- *     output arrays that they can see are well placed get the launch shape that is fastest for such arrays.
- * bytes = 0 reserves three quarters of the memory that is free at the time of the call.
- * ONE arena per DEVICE and process: the first kmers_arena_reserve on a device makes it, a later one (another context of the
- * device) ATTACHES to it -- its `bytes` and KMERS_PARAM_ARENA_NO_PROBE are ignored, kmers_arena_info says what there is.  Every
- * block remembers the context that allocated it: kmers_arena_release detaches the calling context and fails with KMERS_E_BADARG
- * while blocks IT allocated are out; kmers_ctx_destroy gives them back.  The last context to leave frees the block.  Any context
- * of the device may kmers_dev_free a block of the arena (the allocating context's stream is waited for). */
-#define KMERS_ARENA_GRANULE ((size_t)2 << 20)
-int kmers_arena_reserve(kmers_ctx *ctx, size_t bytes);
-int kmers_arena_release(kmers_ctx *ctx);
-/* any of the three outputs may be NULL; all zero when no arena is reserved */
-int kmers_arena_info(kmers_ctx *ctx, size_t *reserved, size_t *in_use, size_t *largest_free);
-/* The measured map: the block starts at *base and is *n_regions granules of *region_bytes (the tail that is left belongs to the
- * last one), granule g is in class classes[g] (at most `capacity` entries are written; boundaries are known to the allocator
- * more finely than a granule).  *region_bytes = 0: no map (block too small, probing switched off, or one class only).  Any
- * output may be NULL. */
-int kmers_arena_regions(kmers_ctx *ctx, void **base, size_t *region_bytes, unsigned char *classes, size_t capacity, size_t *n_regions);
-/* What the probes of kmers_arena_reserve measured, in GB/s of two store streams side by side (1 GiB each, the shape of the stream
- * kernels' outputs): the best pair of places of the block (two region classes; about 7000 on MI355X) and two streams inside one
- * granule (one class; about 6000).  Both 0 without an arena or without a map (block too small, probing off, one class only).  The first is the write ceiling bench.py prices the
- * materialising kernels against (the HBM floor of a launch = its algorithmic bytes / this rate).  Either output may be NULL. */
-int kmers_arena_rates(kmers_ctx *ctx, double *best_pair_gbps, double *one_class_gbps);
-/* For hosts that allocate their outputs themselves (no arena): the write rate, in GB/s, of two store streams side by side into
- * two device buffers the host is about to use as the output arrays of a launch -- the measurement the arena makes of its own
- * block.  DESTRUCTIVE: the first min(bytes, 2 GiB) of both buffers are overwritten.  About 7000 = the buffers lie in different
- * region classes, about 6000 = in one; a host with several candidate buffers can pick the pair that writes fastest. */
+/* The pool's own measurement for any two device buffers: the write rate, in GB/s, of two store streams side by side into them
+ * (the shape of the stream kernels' outputs).  DESTRUCTIVE: the first min(bytes, 2 GiB) of both buffers are overwritten.  About
+ * 7000 = the buffers lie in different region classes, about 6000 = in one. */
 int kmers_placement_probe(kmers_ctx *ctx, void *a_dev, void *b_dev, size_t bytes, double *gbps);
 
 /* ---- geometry (src/kmer.jl:117-137; iterator length()) ----------------------- */

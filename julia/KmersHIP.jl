@@ -18,7 +18,9 @@
 #     v    = collect(CanonicalDNAMers{31}(seq))             # Vector{DNAKmer{31,1}}, computed on the MI355X (length(seq) >= MIN_BASES[])
 #     v    = KmersHIP.gpu_collect(CanonicalDNAMers{31}(seq)) # the same, whatever the length
 #     v, h = KmersHIP.collect_with_hashes(CanonicalDNAMers{31}(seq))   # + fx_hash of every element
-#     for kmer in KmersHIP.gpu(CanonicalDNAMers{31}(seq)) ... end      # chunk-buffered iterate()
+#     for kmer in KmersHIP.gpu(CanonicalDNAMers{31}(seq)) ... end      # chunk-buffered iterate(): all five iterator types; chunk c + 1 is
+#                                                                     # computed and copied while the loop consumes chunk c
+#     collect(FwDNAMers{21}(view(seq, 2:length(seq))))                  # a LongSubSeq source: kmers_seq.first_base
 module KmersHIP
 
 using Kmers
@@ -70,7 +72,7 @@ last_error(ctx::Context) = unsafe_string(@ccall LIB.kmers_last_error(ctx.handle:
 
 # ---- helpers -------------------------------------------------------------------------------
 const NucAlphabet24 = Union{DNAAlphabet{2}, DNAAlphabet{4}, RNAAlphabet{2}, RNAAlphabet{4}}
-const NucSeq24 = LongSequence{<:NucAlphabet24}
+const NucSeq24 = Union{LongSequence{<:NucAlphabet24}, LongSubSeq{<:NucAlphabet24}}   # RecodingScheme takes any BioSequence (src/construction.jl:75-100); views: test/runtests.jl:162
 const ByteSource = Union{String, SubString{String}, Vector{UInt8}, Base.CodeUnits{UInt8, String}}
 const SymbolVector = Union{Vector{DNA}, Vector{RNA}}   # GenericRecoding sources whose memory is one BioSymbols value per byte
 const Source = Union{NucSeq24, ByteSource, SymbolVector}
@@ -82,6 +84,10 @@ isrna(::Type{A}) where {A} = Int32(A <: RNAAlphabet)
 # kmers_seq of a source for kmer alphabet A (the ASCII validity table is A's: construction.jl:94-95)
 cseq(s::LongSequence, ::Type{A}) where {A} =
     CSeq(pointer(s.data), length(s) % UInt64, 0, 0, Int32(BioSequences.bits_per_symbol(Alphabet(s))), 0)
+# a view of a LongSequence (BioSequences' LongSubSeq: the parent's `data` and the range `part`): the same words, the view's first
+# symbol `first(part) - 1` symbols in (kmers_seq.first_base, include/kmers_hip.h:75-90); positions are reported relative to the view
+cseq(s::LongSubSeq, ::Type{A}) where {A} =
+    CSeq(pointer(s.data), length(s) % UInt64, (first(s.part) - 1) % UInt64, 0, Int32(BioSequences.bits_per_symbol(Alphabet(s))), 0)
 cseq(s::ByteSource, ::Type{A}) where {A} =
     CSeq(Ptr{UInt64}(pointer(s)), ncodeunits_or_length(s) % UInt64, 0, 0, Int32(8), isrna(A))
 # a Vector{DNA} / Vector{RNA}: GenericRecoding in the reference (src/construction.jl:90-98); its memory is what
@@ -96,7 +102,7 @@ function check(ctx::Context, rc::Integer, res::CResult, ::Type{A}, s) where {A}
     rc == OK && return nothing
     if rc == E_ENCODE
         # LongSequence sources: the offending symbol; byte sources: repr(byte) (FwKmers.jl:124-126)
-        sym = (s isa LongSequence || s isa SymbolVector) ? reinterpret(eltype(s), res.err_enc % UInt8) : repr(res.err_enc % UInt8)
+        sym = (s isa BioSequence || s isa SymbolVector) ? reinterpret(eltype(s), res.err_enc % UInt8) : repr(res.err_enc % UInt8)
         throw(BioSequences.EncodeError(A(), sym))
     end
     error("libkmers_hip: status $rc: $(last_error(ctx))")
@@ -498,9 +504,10 @@ function Base.close(c::Comm)
 end
 
 # ---- device memory (include/kmers_hip.h, "device memory") ------------------------------------------------------------------
-# `device_alloc` of 1 GiB or more comes from the device's CLASS POOL: physical memory whose HBM region class the library has
+# `device_alloc` of 128 MiB or more comes from the device's CLASS POOL: physical memory whose HBM region class the library has
 # measured, every block assembled so that the arrays of one launch differ in class at every position (no reservation; `pool_info`,
-# `pool_trim!`).  `arena_reserve!` is the one-block reservation of rounds 3-4, for a host that wants it.
+# `pool_trim!`).  `device_free` of such a block does not wait: the block stays mapped in the pool's cache for the next request of
+# its shape, whose stream comes after the work that was queued at the free.
 "What the device's class pool holds: (bytes held, bytes in blocks, classes found, GB/s of two store streams in two classes / in one)."
 function pool_info(ctx::Context = context())
     held, used, ncls = Ref{Csize_t}(0), Ref{Csize_t}(0), Ref{Cint}(0)
@@ -517,20 +524,8 @@ function pool_trim!(ctx::Context = context())
     rc == OK || error("kmers_pool_trim: status $rc: $(last_error(ctx))")
     return Int(r[])
 end
-"One large block of HBM per DEVICE (`bytes = 0`: three quarters of what is free), out of which `device_alloc` of an attached context serves."
-function arena_reserve!(ctx::Context = context(); bytes::Integer = 0)
-    rc = @ccall LIB.kmers_arena_reserve(ctx.handle::Ptr{Cvoid}, bytes::Csize_t)::Cint
-    rc == OK || error("kmers_arena_reserve: status $rc: $(last_error(ctx))")
-    return nothing
-end
-function arena_release!(ctx::Context = context())
-    rc = @ccall LIB.kmers_arena_release(ctx.handle::Ptr{Cvoid})::Cint
-    rc == OK || error("kmers_arena_release: status $rc: $(last_error(ctx))")
-    return nothing
-end
 """
-`n` elements of `T` in HBM: from 1 GiB on a block of the device's class pool (or a range of the arena when this context reserved
-one), else a plain allocation.  `lone_output = true`: the ONLY output array of the launches that fill it (`collect` of an iterator
+`n` elements of `T` in HBM: from 128 MiB on a block of the device's class pool, else a plain allocation.  `lone_output = true`: the ONLY output array of the launches that fill it (`collect` of an iterator
 without hashes / reverse complements): its second half lies in another region class of HBM than its first and such a launch
 writes it through two windows (`kmers_dev_alloc_role`, `KMERS_ALLOC_LONE_OUTPUT`).
 """
@@ -572,49 +567,231 @@ function output_offsets(c::Comm, n_local::Integer)
     return Int(off[]), Int(tot[])
 end
 
-# ---- chunk-buffered iterate(): `for kmer in gpu(it)` -----------------------------------------
-"""
-    gpu(it; chunk = 1 << 24)
-
-Wrap a Kmers.jl iterator so that `Base.iterate` pulls elements from GPU-computed chunks.  The
-state is `(buffer, index_in_buffer, next_start)`; a chunk is a view of the sequence
-(`first_base`, K-1 symbols of overlap), exactly how a resumed reference iterator would restart.
-"""
+# ---- chunk-buffered iterate(): `for x in gpu(it)` ------------------------------------------------
+# The reference's protocol (src/iterators/FwKmers.jl:57-66, CanonicalKmers.jl:54-66, SpacedKmers.jl:121-139,
+# UnambiguousKmers.jl:59-62) yields one element per `iterate`; here `iterate` hands out elements of a chunk the device computed
+# while the loop was busy with the chunk before: the source goes to HBM once, two chunk buffers in HBM and two in page-locked host
+# memory take turns -- chunk c + 1 is launched (`KMERS_MEM_DEVICE | KMERS_ASYNC`) and its copy enqueued
+# (`kmers_memcpy_d2h_async`) BEFORE the loop gets chunk c, and `kmers_sync` is only called when the loop has used chunk c up.
+# A chunk is a view of the sequence (`first_base`, `index_origin` = the chunk's offset: EncodeError positions and UnambiguousKmers
+# starts stay those of the whole sequence), K - J symbols of overlap -- exactly how a resumed reference iterator would restart.
+# kmers.jl_amd/host.py (`_ChunkPipe`) is the same pipeline through ctypes, tested on hardware (tests/test_gpu_mirror.py).
 struct GPUIterator{I}
     it::I
     chunk::Int
 end
-gpu(it; chunk::Int = 1 << 24) = GPUIterator(it, chunk)
+gpu(it::GpuIterator; chunk::Int = 1 << 22) = GPUIterator(it, chunk)
+Base.IteratorSize(::Type{GPUIterator{I}}) where {I} = Base.IteratorSize(I)
 Base.length(g::GPUIterator) = length(g.it)
 Base.eltype(::Type{GPUIterator{I}}) where {I} = eltype(I)
 
-function fill_chunk(g::GPUIterator{<:CanonicalKmers{A, K}}, start::Int) where {A, K}
-    s = g.it.it.seq
-    n = min(g.chunk, length(g.it) - start + 1)
-    n <= 0 && return nothing
-    ctx = context()
-    buf = Vector{eltype(g.it)}(undef, n)
-    res = CResult()
-    base = cseq(s, A)
-    view = CSeq(base.words, (n + K - 1) % UInt64, (start - 1) % UInt64, (start - 1) % UInt64, base.src_bits, base.alphabet)
-    GC.@preserve s buf begin
-        rc = @ccall LIB.kmers_canonical(ctx.handle::Ptr{Cvoid}, Ref(view)::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
-                                        pointer(buf)::Ptr{UInt64}, C_NULL::Ptr{UInt64}, 0::UInt64,
-                                        MEM_HOST::Cint, res::Ref{CResult})::Cint
-    end
-    check(ctx, rc, res, A, s)
-    return buf
+kmer_alphabet(::Union{FwKmers{A}, FwRvIterator{A}, CanonicalKmers{A}, SpacedKmers{A}, UnambiguousKmers{A}}) where {A} = A
+ksize_of(::Union{FwKmers{A, K}, FwRvIterator{A, K}, CanonicalKmers{A, K}, SpacedKmers{A, K}, UnambiguousKmers{A, K}}) where {A, K} = K
+stride_of(::SpacedKmers{A, K, J}) where {A, K, J} = J
+stride_of(::Union{FwKmers, FwRvIterator, CanonicalKmers, UnambiguousKmers}) = 1
+# what a chunk is counted in: elements -- for UnambiguousKmers (SizeUnknown, UnambiguousKmers.jl:33) candidate windows
+units(it::Union{FwKmers, FwRvIterator, CanonicalKmers, SpacedKmers}) = length(it)
+units(it::UnambiguousKmers) = max(0, ncodeunits_or_length(source(it)) - ksize_of(it) + 1)
+# units whose windows end before the 0-based symbol `bad0`: what iterate() yields before it throws there (FwKmers.jl:112,
+# CanonicalKmers.jl:139, SpacedKmers.jl:133-134); host.py `_yielded_before`
+function units_before(it, bad0::Int)
+    K, J = ksize_of(it), stride_of(it)
+    J >= K && return bad0 ÷ J
+    bad0 < K && return 0
+    return (bad0 - K) ÷ J + 1
 end
 
-function Base.iterate(g::GPUIterator, state = (eltype(g)[], 1, 1))
-    (buf, i, next_start) = state
-    if i > length(buf)
-        buf = fill_chunk(g, next_start)
-        buf === nothing && return nothing
-        next_start += length(buf)
-        i = 1
+# units [u0, u0 + n) of the iteration as a view of `base` (a kmers_seq over host or device words)
+function chunk_view(base::CSeq, K::Int, J::Int, u0::Int, n::Int)
+    off = u0 * J
+    return CSeq(base.words, ((n - 1) * J + K) % UInt64, base.first_base + off % UInt64, off % UInt64, base.src_bits, base.alphabet)
+end
+
+# One chunk, ENQUEUED: units [u0, u0 + n) into `out` (HBM, room for n elements of eltype(it)); one method per iterator type.
+function fill_chunk(it::FwKmers{A, K}, ctx::Ptr{Cvoid}, base::CSeq, out::Ptr{Cvoid}, u0::Int, n::Int, res::CResult) where {A, K}
+    @ccall LIB.kmers_fw(ctx::Ptr{Cvoid}, Ref(chunk_view(base, K, 1, u0, n))::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
+                        out::Ptr{UInt64}, C_NULL::Ptr{UInt64}, (MEM_DEVICE | ASYNC)::Cint, res::Ref{CResult})::Cint
+end
+function fill_chunk(it::FwRvIterator{A, K}, ctx::Ptr{Cvoid}, base::CSeq, out::Ptr{Cvoid}, u0::Int, n::Int, res::CResult) where {A, K}
+    @ccall LIB.kmers_fw(ctx::Ptr{Cvoid}, Ref(chunk_view(base, K, 1, u0, n))::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
+                        out::Ptr{UInt64}, C_NULL::Ptr{UInt64}, (MEM_DEVICE | ASYNC | OUT_TUPLES)::Cint, res::Ref{CResult})::Cint
+end
+function fill_chunk(it::CanonicalKmers{A, K}, ctx::Ptr{Cvoid}, base::CSeq, out::Ptr{Cvoid}, u0::Int, n::Int, res::CResult) where {A, K}
+    @ccall LIB.kmers_canonical(ctx::Ptr{Cvoid}, Ref(chunk_view(base, K, 1, u0, n))::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
+                               out::Ptr{UInt64}, C_NULL::Ptr{UInt64}, 0::UInt64, (MEM_DEVICE | ASYNC)::Cint, res::Ref{CResult})::Cint
+end
+function fill_chunk(it::SpacedKmers{A, K, J}, ctx::Ptr{Cvoid}, base::CSeq, out::Ptr{Cvoid}, u0::Int, n::Int, res::CResult) where {A, K, J}
+    @ccall LIB.kmers_spaced(ctx::Ptr{Cvoid}, Ref(chunk_view(base, K, J, u0, n))::Ptr{CSeq}, K::Cint, J::Cint, dst_bits(A)::Cint,
+                            out::Ptr{UInt64}, (MEM_DEVICE | ASYNC)::Cint, res::Ref{CResult})::Cint
+end
+# (kmer, start) tuples; the number kept is known at the next kmers_sync (its res.n_out); capacity = the chunk's candidate windows
+function fill_chunk(it::UnambiguousKmers{A, K}, ctx::Ptr{Cvoid}, base::CSeq, out::Ptr{Cvoid}, u0::Int, n::Int, res::CResult) where {A, K}
+    @ccall LIB.kmers_unambiguous(ctx::Ptr{Cvoid}, Ref(chunk_view(base, K, 1, u0, n))::Ptr{CSeq}, K::Cint, 1::Cint,
+                                 out::Ptr{UInt64}, C_NULL::Ptr{Int64}, n::UInt64, (MEM_DEVICE | ASYNC | OUT_TUPLES)::Cint,
+                                 res::Ref{CResult})::Cint
+end
+
+# The same units computed NOW, from host memory into a fresh Vector (the clean prefix of a chunk that met an EncodeError).
+function fill_sync(it, ctx::Context, u0::Int, n::Int)
+    A, s = kmer_alphabet(it), source(it)
+    buf = Vector{eltype(it)}(undef, n)
+    res = CResult()
+    GC.@preserve s buf begin
+        # (the device-pointer form of fill_chunk with host pointers: the flags are replaced, nothing else differs)
+        rc = fill_chunk_host(it, ctx.handle, cseq(s, A), Ptr{Cvoid}(pointer(buf)), u0, n, res)
     end
-    return (@inbounds(buf[i]), (buf, i + 1, next_start))
+    check(ctx, rc, res, A, s)
+    it isa UnambiguousKmers && resize!(buf, Int(res.n_out))
+    return buf
+end
+fill_chunk_host(it::FwKmers{A, K}, ctx, base, out, u0, n, res) where {A, K} =
+    @ccall LIB.kmers_fw(ctx::Ptr{Cvoid}, Ref(chunk_view(base, K, 1, u0, n))::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
+                        out::Ptr{UInt64}, C_NULL::Ptr{UInt64}, MEM_HOST::Cint, res::Ref{CResult})::Cint
+fill_chunk_host(it::FwRvIterator{A, K}, ctx, base, out, u0, n, res) where {A, K} =
+    @ccall LIB.kmers_fw(ctx::Ptr{Cvoid}, Ref(chunk_view(base, K, 1, u0, n))::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
+                        out::Ptr{UInt64}, C_NULL::Ptr{UInt64}, (MEM_HOST | OUT_TUPLES)::Cint, res::Ref{CResult})::Cint
+fill_chunk_host(it::CanonicalKmers{A, K}, ctx, base, out, u0, n, res) where {A, K} =
+    @ccall LIB.kmers_canonical(ctx::Ptr{Cvoid}, Ref(chunk_view(base, K, 1, u0, n))::Ptr{CSeq}, K::Cint, dst_bits(A)::Cint,
+                               out::Ptr{UInt64}, C_NULL::Ptr{UInt64}, 0::UInt64, MEM_HOST::Cint, res::Ref{CResult})::Cint
+fill_chunk_host(it::SpacedKmers{A, K, J}, ctx, base, out, u0, n, res) where {A, K, J} =
+    @ccall LIB.kmers_spaced(ctx::Ptr{Cvoid}, Ref(chunk_view(base, K, J, u0, n))::Ptr{CSeq}, K::Cint, J::Cint, dst_bits(A)::Cint,
+                            out::Ptr{UInt64}, MEM_HOST::Cint, res::Ref{CResult})::Cint
+fill_chunk_host(it::UnambiguousKmers{A, K}, ctx, base, out, u0, n, res) where {A, K} =
+    @ccall LIB.kmers_unambiguous(ctx::Ptr{Cvoid}, Ref(chunk_view(base, K, 1, u0, n))::Ptr{CSeq}, K::Cint, 1::Cint,
+                                 out::Ptr{UInt64}, C_NULL::Ptr{Int64}, n::UInt64, (MEM_HOST | OUT_TUPLES)::Cint,
+                                 res::Ref{CResult})::Cint
+
+# The pipeline's buffers.  It owns a context (= a stream) of its own, so that its finalizer -- a loop left with `break` never
+# reaches the end of the iteration -- touches nothing another task may be using.
+mutable struct ChunkPipe{E}
+    ctx::Ptr{Cvoid}
+    base::CSeq                       # the source in HBM, as a kmers_seq
+    d_src::Ptr{Cvoid}
+    d_out::NTuple{2, Ptr{Cvoid}}
+    h_ptr::NTuple{2, Ptr{Cvoid}}
+    h_out::NTuple{2, Vector{E}}      # the page-locked buffers as Julia arrays (unsafe_wrap, not owned)
+    cap::Int
+    res::CResult
+end
+
+function pipe_call(ctx::Ptr{Cvoid}, rc::Integer, what)
+    rc == OK || error("$what: status $rc: $(unsafe_string(@ccall LIB.kmers_last_error(ctx::Ptr{Cvoid})::Cstring))")
+    return nothing
+end
+
+function ChunkPipe(g::GPUIterator)
+    it = g.it
+    E, A, s = eltype(it), kmer_alphabet(it), source(it)
+    cap = max(1, min(g.chunk, units(it)))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = @ccall LIB.kmers_ctx_create(0::Cint, C_NULL::Ptr{Cvoid}, h::Ptr{Ptr{Cvoid}})::Cint
+    rc == OK || error("kmers_ctx_create failed ($rc): no usable MI355X / HIP device")
+    ctx = h[]
+    alloc(bytes, lone) = (p = Ref{Ptr{Cvoid}}(C_NULL);
+                          pipe_call(ctx, (@ccall LIB.kmers_dev_alloc_role(ctx::Ptr{Cvoid}, bytes::Csize_t, Cint(lone)::Cint, p::Ptr{Ptr{Cvoid}})::Cint), "kmers_dev_alloc_role"); p[])
+    pinned(bytes) = (p = Ref{Ptr{Cvoid}}(C_NULL);
+                     pipe_call(ctx, (@ccall LIB.kmers_host_alloc(ctx::Ptr{Cvoid}, bytes::Csize_t, p::Ptr{Ptr{Cvoid}})::Cint), "kmers_host_alloc"); p[])
+    # the words (bytes) that hold the view go to HBM once
+    host = cseq(s, A)
+    per = 64 ÷ Int(host.src_bits)                         # symbols per 8-byte word
+    w0 = Int(host.first_base) ÷ per
+    src_bytes = host.src_bits == 8 ? Int(host.first_base + host.n_bases) - 8 * w0 :
+                                     8 * (cld(Int(host.first_base + host.n_bases), per) - w0)
+    d_src = alloc(src_bytes + 16, false)
+    GC.@preserve s pipe_call(ctx, (@ccall LIB.kmers_memcpy_h2d(ctx::Ptr{Cvoid}, d_src::Ptr{Cvoid}, (Ptr{UInt8}(host.words) + 8 * w0)::Ptr{Cvoid},
+                                                             src_bytes::Csize_t)::Cint), "kmers_memcpy_h2d")
+    base = CSeq(Ptr{UInt64}(d_src), host.n_bases, host.first_base - (w0 * per) % UInt64, 0, host.src_bits, host.alphabet)
+    d_out = (alloc(cap * sizeof(E), true), alloc(cap * sizeof(E), true))
+    h_ptr = (pinned(cap * sizeof(E)), pinned(cap * sizeof(E)))
+    h_out = (unsafe_wrap(Array, Ptr{E}(h_ptr[1]), cap), unsafe_wrap(Array, Ptr{E}(h_ptr[2]), cap))
+    p = ChunkPipe{E}(ctx, base, d_src, d_out, h_ptr, h_out, cap, CResult())
+    finalizer(close!, p)
+    return p
+end
+
+"Free the pipeline's buffers and its context (idempotent; the finalizer of a pipeline whose loop was left early)."
+function close!(p::ChunkPipe)
+    p.ctx == C_NULL && return nothing
+    ctx = p.ctx
+    p.ctx = C_NULL
+    @ccall LIB.kmers_sync(ctx::Ptr{Cvoid}, C_NULL::Ptr{CResult})::Cint
+    for q in (p.d_src, p.d_out...)
+        @ccall LIB.kmers_dev_free(ctx::Ptr{Cvoid}, q::Ptr{Cvoid})::Cint
+    end
+    for q in p.h_ptr
+        @ccall LIB.kmers_host_free(ctx::Ptr{Cvoid}, q::Ptr{Cvoid})::Cint
+    end
+    @ccall LIB.kmers_ctx_destroy(ctx::Ptr{Cvoid})::Cvoid
+    return nothing
+end
+
+# enqueue units [u0, u0 + n): the kernel, then the copy of its output into the slot's page-locked buffer
+function enqueue!(g::GPUIterator, p::ChunkPipe{E}, slot::Int, u0::Int, n::Int) where {E}
+    rc = fill_chunk(g.it, p.ctx, p.base, p.d_out[slot], u0, n, p.res)
+    pipe_call(p.ctx, rc, "fill_chunk")
+    pipe_call(p.ctx, (@ccall LIB.kmers_memcpy_d2h_async(p.ctx::Ptr{Cvoid}, p.h_ptr[slot]::Ptr{Cvoid}, p.d_out[slot]::Ptr{Cvoid},
+                                                        (n * sizeof(E))::Csize_t)::Cint), "kmers_memcpy_d2h_async")
+    return nothing
+end
+
+mutable struct PipeState{E}
+    pipe::ChunkPipe{E}
+    buf::Vector{E}          # what the loop is consuming: one of the page-locked buffers, or the clean prefix before an error
+    i::Int                  # next element of buf
+    n::Int                  # elements of buf that count
+    slot::Int               # the slot in flight (its chunk: units [u0, u0 + m))
+    u0::Int
+    m::Int                  # 0: nothing in flight
+    err::Union{Nothing, Exception}
+end
+
+function Base.iterate(g::GPUIterator)
+    units(g.it) == 0 && return nothing
+    p = ChunkPipe(g)
+    m = min(p.cap, units(g.it))
+    enqueue!(g, p, 1, 0, m)
+    return iterate(g, PipeState{eltype(g)}(p, p.h_out[1], 1, 0, 1, 0, m, nothing))
+end
+
+function Base.iterate(g::GPUIterator, st::PipeState)
+    p, it = st.pipe, g.it
+    while st.i > st.n                                   # the buffer is used up
+        if st.err !== nothing
+            close!(p)
+            throw(st.err)
+        elseif st.m == 0
+            close!(p)
+            return nothing
+        end
+        rc = @ccall LIB.kmers_sync(p.ctx::Ptr{Cvoid}, p.res::Ref{CResult})::Cint      # the chunk in flight (and only it) is done
+        u0, m, slot = st.u0, st.m, st.slot
+        if rc == E_ENCODE
+            # the reference yields every element whose window ends before the offending symbol, then throws there
+            A, s = kmer_alphabet(it), source(it)
+            sym = (s isa BioSequence || s isa SymbolVector) ? reinterpret(eltype(s), p.res.err_enc % UInt8) : repr(p.res.err_enc % UInt8)
+            st.err = BioSequences.EncodeError(A(), sym)
+            st.m = 0
+            good = units_before(it, Int(p.res.err_pos) - 1) - u0
+            if good > 0
+                st.buf = fill_sync(it, context(), u0, good)
+                st.i, st.n = 1, length(st.buf)
+            end
+            continue
+        end
+        rc == OK || (close!(p); error("libkmers_hip: status $rc"))
+        st.buf, st.i = p.h_out[slot], 1
+        st.n = (it isa UnambiguousKmers && p.base.src_bits != 2) ? Int(p.res.n_out) : m     # (a 2-bit source drops nothing: the count is the chunk's)
+        u1 = u0 + m
+        if u1 < units(it)                               # chunk c + 1 goes to the device before the loop gets chunk c
+            st.slot, st.u0, st.m = 3 - slot, u1, min(p.cap, units(it) - u1)
+            enqueue!(g, p, st.slot, st.u0, st.m)
+        else
+            st.m = 0
+        end
+    end
+    x = @inbounds st.buf[st.i]
+    st.i += 1
+    return (x, st)
 end
 
 end # module

@@ -11,7 +11,6 @@ from . import build as _build
 
 OK, E_ENCODE, E_BADARG, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CAPACITY, E_NCCL = range(8)
 COMM_ID_BYTES = 128
-ARENA_GRANULE = 2 << 20
 MEM_HOST, MEM_DEVICE, ASYNC, OUT_TUPLES = 0, 1, 2, 4
 BATCH_FW, BATCH_CANONICAL = 0, 1
 ITER_FW, ITER_CANONICAL, ITER_SPACED, ITER_UNAMBIGUOUS = 0, 1, 2, 3
@@ -19,10 +18,10 @@ SPANS_DEVICE = 8
 BATCH_SKIP = 16
 (OP_REVERSE, OP_COMPLEMENT, OP_REVCOMP, OP_CANONICAL, OP_ISCANONICAL, OP_TO_LONGSEQ, OP_COUNT_GC, OP_AS_INTEGER,
  OP_FROM_INTEGER) = range(9)
-PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY, PARAM_BATCH_PASSES, PARAM_SKETCH_BATCH_LDS, PARAM_SUBTILES, PARAM_ARENA_NO_PROBE, PARAM_SPLIT_ORDER, PARAM_BLOCK_THREADS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-PARAM_WIDE_NO_TILES, PARAM_HOST_CHUNKS, PARAM_SHAPE_CALIBRATE = 11, 12, 13
-PARAM_POOL, PARAM_POOL_SEARCH_GIB, PARAM_POOL_MAX_GIB, PARAM_BATCH_DENSE = 14, 15, 16, 17
-POOL_MIN_BYTES, POOL_CLASSES = 1 << 30, 4
+PARAM_TILE_KMERS, PARAM_MAX_GRID, PARAM_STAMPS_PTR, PARAM_SKETCH_HOST_ONLY, PARAM_BATCH_PASSES, PARAM_SKETCH_BATCH_LDS, PARAM_SUBTILES, PARAM_SPLIT_ORDER, PARAM_BLOCK_THREADS = 1, 2, 3, 4, 5, 6, 7, 9, 10
+PARAM_WIDE_NO_TILES, PARAM_HOST_CHUNKS = 11, 12
+PARAM_POOL, PARAM_POOL_SEARCH_GIB, PARAM_POOL_MAX_GIB, PARAM_BATCH_DENSE, PARAM_POOL_CACHE = 14, 15, 16, 17, 18
+POOL_MIN_BYTES, POOL_CLASSES, POOL_STATS = 128 << 20, 4, 12
 ALLOC_DEFAULT, ALLOC_LONE_OUTPUT = 0, 1
 
 STATUS_NAMES = {OK: "KMERS_OK", E_ENCODE: "KMERS_E_ENCODE", E_BADARG: "KMERS_E_BADARG",
@@ -65,23 +64,21 @@ SYMBOLS = {
     "kmers_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "kmers_dev_alloc_role": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(_P)]),
     "kmers_dev_free": (C.c_int, [_P, _P]),
-    "kmers_arena_reserve": (C.c_int, [_P, C.c_size_t]),
-    "kmers_arena_release": (C.c_int, [_P]),
-    "kmers_arena_info": (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
-    "kmers_arena_rates": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "kmers_last_launch_shape": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "kmers_last_shape_calibration": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
-    "kmers_shape_calibrations": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "kmers_last_batch_pieces": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "kmers_pool_info": (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]),
+    "kmers_pool_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_size_t]),
     "kmers_pool_trim": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
     "kmers_pool_layout": (C.c_int, [_P, _P, C.POINTER(C.c_size_t), _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "kmers_pool_selftest": (C.c_int, [_P, C.POINTER(C.c_int)]),
-    "kmers_arena_regions": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "kmers_placement_probe": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_double)]),
     "kmers_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "kmers_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "kmers_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "kmers_host_free": (C.c_int, [_P, _P]),
+    "kmers_memcpy_h2d_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "kmers_memcpy_d2h_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "kmers_words_per_kmer": (C.c_int, [C.c_int, C.c_int]),
     "kmers_count": (C.c_uint64, [C.c_uint64, C.c_int, C.c_int]),
     "kmers_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

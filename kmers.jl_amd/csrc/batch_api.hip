@@ -142,11 +142,12 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
             ctx->layout_segs = 0;
         }
         const size_t segs = std::max<uint64_t>(n_seg + n_seg / 2, 4096);
-        HIP_TRY(ctx, hipMalloc(&ctx->d_layout, (4 + 2 * segs) * 8));
+        if (dev_malloc(ctx, reinterpret_cast<void **>(&ctx->d_layout), (4 + 2 * segs) * 8) != hipSuccess) return fail(ctx, KMERS_E_NOMEM, "hipMalloc(batch layout)");
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_layout, 0, (4 + 2 * segs) * 8, ctx->stream));
         ctx->layout_segs = segs;
         ctx->layout_tickets = 0;
-        ctx->layout_epoch = 0;
+        // (the epoch goes on counting: the BAD / ABORT words of d_scratch hold the epoch of an earlier failing call, and a counter
+        // that started over would meet it again -- a valid batch reported as a bad span.  The fresh buffer is zeroed, any epoch > 0 is new to it.)
     }
     if (++ctx->layout_epoch >= LAYOUT_EPOCH_LIMIT) {  // (a billion calls on: the tags start over)
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_layout + 4, 0, 2 * ctx->layout_segs * 8, ctx->stream));

@@ -47,12 +47,19 @@ struct Block {
     std::vector<uint32_t> chunks;
     std::vector<uint8_t> classes;  // of the chunks, in order
     uint64_t serial = 0;
+    int role = 0;          // ROLE_DEFAULT / ROLE_LONE_OUTPUT: what the block was assembled for
+    bool home = false;     // ONE chunk, addressed through the chunk's own (home) mapping: no reservation of its own, nothing to map or unmap
+    float quality = 1.f;   // of the plan it was assembled by (what a later request of its shape may settle for)
+    uint64_t freed_tick = 0;  // cached blocks: State::tick when it was freed
 };
 
 struct State {
     std::vector<Chunk> chunks;
     std::vector<uint32_t> free_list[N_LISTS];  // per class; taken from the back
-    std::map<const char *, Block> blocks;      // by base address
+    std::map<const char *, Block> blocks;      // by base address: blocks that are OUT
+    std::map<const char *, Block> cached;      // freed blocks that are still MAPPED (the next request of their shape takes one as it is)
+    size_t cached_bytes = 0;
+    uint64_t tick = 0;                         // counts allocations and frees: the age of a cached block
     uint32_t rep_chunk[MAX_CLASSES] = {};
     int n_classes = 0;
     float slow_ms = 0.f;       // two 1 GiB streams inside one class (the calibration's slowest pair)
@@ -298,6 +305,76 @@ inline const Block *partner_block(const State &s, size_t bytes, const Block **ot
     return partner;
 }
 
+// ---- the cache of freed blocks, and how much the pool may hold beyond what is asked of it ---------------------------------------
+// The reference's `collect` allocates a fresh Vector per call (Base.collect over src/iterators/CanonicalKmers.jl:199-225): a host
+// loop is {allocate the outputs, launch, consume, free}.  Assembling a block costs a reservation, a map and a set-access per
+// handle, a check of every handle and -- when an address range is re-used -- a TLB flush; freeing it used to cost a device-wide
+// wait on top.  So a freed block stays MAPPED, and the next request of its shape (same number of chunks, same role, classes that
+// suit the new partner as well as a fresh plan could) takes it as it is: no call into the driver at all.
+constexpr uint64_t CACHE_AGE_TICKS = 32;       // a cached block nobody asked for over this many allocations / frees is taken apart
+constexpr size_t HOARD_MIN_CHUNKS = 4;         // what the pool may hold beyond blocks (out or cached): representatives included,
+constexpr size_t HOARD_FRACTION = 4;           //   max(HOARD_MIN_CHUNKS, 1 / HOARD_FRACTION of the chunks in blocks)
+constexpr float GOOD_PLAN = 0.95f;             // the pool grows (within its search budget) until a block's plan is this good
+
+// the classes a new block of `bytes` should NOT have, chunk by chunk, beside `partner` (plan()'s rule for ROLE_DEFAULT)
+inline std::vector<uint8_t> forbidden_beside(const Block *partner, size_t bytes) {
+    const size_t n = chunks_for(bytes);
+    std::vector<uint8_t> forbidden(n, NO_CLASS);
+    if (!partner || partner->classes.empty() || !partner->req_bytes) return forbidden;
+    for (size_t i = 0; i < n; ++i) {
+        const double x = std::min(1.0, ((double)i + 0.5) * (double)CHUNK_BYTES / (double)bytes);
+        forbidden[i] = partner->classes[std::min(partner->classes.size() - 1, (size_t)(((double)partner->user_off + x * (double)partner->req_bytes) / (double)CHUNK_BYTES))];
+    }
+    return forbidden;
+}
+
+// how many chunks a request takes, and where the caller's pointer lies in them (a lone output of two chunks or more: its middle on
+// a chunk boundary)
+inline size_t block_chunks(size_t bytes, int role, size_t *user_off = nullptr, size_t *plan_bytes = nullptr) {
+    size_t off = 0, pb = bytes;
+    if (role == ROLE_LONE_OUTPUT && bytes >= 2 * CHUNK_BYTES) {
+        const size_t half = (bytes / 2 + 4095) / 4096 * 4096, k1 = chunks_for(half);
+        off = k1 * CHUNK_BYTES - half;
+        pb = 2 * k1 * CHUNK_BYTES;
+    }
+    if (user_off) *user_off = off;
+    if (plan_bytes) *plan_bytes = pb;
+    return chunks_for(pb);
+}
+
+// The cached block a request should take, or cached.end(): the same number of chunks and the same role; for ROLE_DEFAULT its
+// classes must differ from the partner's at GOOD_PLAN of the positions -- or at as many as the plan it was assembled by managed
+// (a box whose stock cannot do better must not search again on every call).  The best one wins, the most recently freed on a tie.
+inline std::map<const char *, Block>::iterator find_cached(State &s, size_t bytes, int role, const Block *partner) {
+    const size_t n = block_chunks(bytes, role);
+    auto best = s.cached.end();
+    float best_q = -1.f;
+    const std::vector<uint8_t> forbidden = role == ROLE_DEFAULT ? forbidden_beside(partner, bytes) : std::vector<uint8_t>();
+    for (auto it = s.cached.begin(); it != s.cached.end(); ++it) {
+        const Block &b = it->second;
+        if (b.chunks.size() != n || b.role != role) continue;
+        float q = 1.f;
+        if (role == ROLE_DEFAULT) {
+            q = plan_quality(b.classes, forbidden);
+            if (q < std::min(GOOD_PLAN, b.quality)) continue;
+        }
+        if (q > best_q || (q == best_q && b.freed_tick > best->second.freed_tick)) {
+            best = it;
+            best_q = q;
+        }
+    }
+    return best;
+}
+
+// chunks the pool holds outside blocks (free lists + representatives) beyond what it may: to be returned to the driver
+inline size_t hoard_excess(const State &s) {
+    size_t idle = (size_t)s.n_classes;  // the representatives
+    for (const auto &l : s.free_list) idle += l.size();
+    const size_t in_blocks = (s.in_use_bytes + s.cached_bytes) / CHUNK_BYTES;
+    const size_t allowed = std::max(HOARD_MIN_CHUNKS, in_blocks / HOARD_FRACTION);
+    return idle > allowed ? idle - allowed : 0;
+}
+
 // Take the chunks for the planned classes out of the free lists.
 inline std::vector<uint32_t> take(State &s, const std::vector<uint8_t> &seq) {
     std::vector<uint32_t> out;
@@ -311,13 +388,27 @@ inline std::vector<uint32_t> take(State &s, const std::vector<uint8_t> &seq) {
     s.in_use_bytes += out.size() * CHUNK_BYTES;
     return out;
 }
-inline void give(State &s, const std::vector<uint32_t> &chunks) {
+inline void give(State &s, const std::vector<uint32_t> &chunks, bool from_cache = false) {
     for (size_t k = chunks.size(); k-- > 0;) {  // (back to front: the next block of this shape gets them in the same order)
         Chunk &c = s.chunks[chunks[k]];
         c.in_use = false;
         s.free_list[c.cls].push_back(chunks[k]);
     }
-    s.in_use_bytes -= chunks.size() * CHUNK_BYTES;
+    (from_cache ? s.cached_bytes : s.in_use_bytes) -= chunks.size() * CHUNK_BYTES;
+}
+// a block that is out goes to the cache as it is / a cached block goes out again
+inline void to_cache(State &s, const char *base, Block &&b) {
+    b.freed_tick = s.tick;
+    s.in_use_bytes -= b.bytes;
+    s.cached_bytes += b.bytes;
+    s.cached[base] = std::move(b);
+}
+inline Block from_cache(State &s, std::map<const char *, Block>::iterator it) {
+    Block b = std::move(it->second);
+    s.cached.erase(it);
+    s.cached_bytes -= b.bytes;
+    s.in_use_bytes += b.bytes;
+    return b;
 }
 
 }  // namespace pool

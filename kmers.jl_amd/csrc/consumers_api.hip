@@ -195,7 +195,7 @@ static int minhash_impl(kmers_ctx *ctx, const kmers_seq *seq, int k, int dst_bit
 
     constexpr uint32_t RECENT_SLOTS = 1u << 16;
     if (!ctx->d_recent) {
-        hipError_t e = hipMalloc(&ctx->d_recent, (size_t)RECENT_SLOTS * 8);
+        hipError_t e = dev_malloc(ctx, reinterpret_cast<void **>(&ctx->d_recent), (size_t)RECENT_SLOTS * 8);
         if (e != hipSuccess) return fail(ctx, KMERS_E_NOMEM, "hipMalloc(recent candidates)", e);
     }
     // (a sequence that fits one round needs no duplicate filter: everything is a candidate once and the

@@ -9,29 +9,20 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+
 #include "../../include/kmers_hip.h"
-#include "arena_placement.hpp"
 #include "class_pool.hpp"
 
-// The arena of ONE DEVICE (memory_api.hip): one block of HBM and its measured map, shared by every context of the process that
-// attaches to it with kmers_arena_reserve -- a second context on the device does not get a second three quarters of what is
-// free, it gets this one.  Sub-allocation is serialised by `mu`; the map is read-only once it has been measured.
 struct kmers_ctx;
-struct kmers_device_arena {
-    kmers_arena a;
-    std::mutex mu;
-    int refs = 0;
-    int device = 0;
-    std::map<size_t, kmers_ctx *> owner;  // offset of a block in use -> the context that allocated it (its stream is what may still write it)
-};
 struct kmers_device_pool;  // pool_api.hip
-// What ONE DEVICE of the process holds for its contexts: the arena (memory_api.hip) and the class pool (pool_api.hip).  `mu`
-// serialises attaching, reserving, growing and releasing on that device only (a reservation's probes take 0.3 s: other devices
-// are not held up by them); slots are never destroyed.
+// What ONE DEVICE of the process holds for its contexts: the class pool (pool_api.hip).  `mu` serialises attaching, growing and
+// releasing on that device only; slots are never destroyed.  `generation` changes whenever a block of the pool comes or goes: a
+// launcher that asked where two arrays lie may keep the answer for as long as it stands (no lock on the launch path).
 struct kmers_device_slot {
     std::mutex mu;
-    kmers_device_arena *arena = nullptr;
     kmers_device_pool *pool = nullptr;
+    std::atomic<uint64_t> generation{1};
 };
 
 struct kmers_ctx {
@@ -61,46 +52,30 @@ struct kmers_ctx {
     int64_t block_threads = 0;  // KMERS_PARAM_BLOCK_THREADS: 64 / 128 / 256 threads per workgroup of the tile kernel; 0 = per shape
     int64_t split_order = 0;     // KMERS_PARAM_SPLIT_ORDER: the tile kernels visit the two halves of their tile range alternately
     int64_t wide_no_tiles = 0;  // KMERS_PARAM_WIDE_NO_TILES: kmers of more than four words skip wide_tile_kernel.hpp
-    int64_t arena_no_probe = 0;  // KMERS_PARAM_ARENA_NO_PROBE: kmers_arena_reserve skips the region calibration
     int64_t stamps_ptr = 0;  // diagnostic builds only (KMERS_PARAM_STAMPS_PTR)
     int n_cus = 256;                // multiProcessorCount
     bool sketch_host_only = false;  // KMERS_PARAM_SKETCH_HOST_ONLY: force the host-feedback MinHash path (tests)
     int64_t batch_passes = 0;       // KMERS_PARAM_BATCH_PASSES (tests, tuning); 0 = default
     int64_t batch_dense = 0;        // KMERS_PARAM_BATCH_DENSE: -1 = kmers_batch never takes the dense tile path (A/B, tests)
     int64_t sketch_batch_lds = 0;   // KMERS_PARAM_SKETCH_BATCH_LDS (tuning); 0 = default
-    kmers_device_arena *shared_arena = nullptr;  // the device's arena, if this context is attached to it (memory_api.hip)
     bool uses_pool = false;        // this context has taken part in the device's class pool (pool_api.hip): counted in its refs
-    int64_t pool_enable = 1;       // KMERS_PARAM_POOL: kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the class pool (no arena attached)
-    int64_t pool_search_gib = -1;  // KMERS_PARAM_POOL_SEARCH_GIB: how far past a request the pool may grow in search of the classes it wants (-1: 128)
+    int64_t pool_enable = 1;       // KMERS_PARAM_POOL: kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the class pool
+    int64_t pool_search_gib = -1;  // KMERS_PARAM_POOL_SEARCH_GIB: how far past a request the pool may grow in search of the classes it wants (-1: sized to the request)
     int64_t pool_max_gib = 0;      // KMERS_PARAM_POOL_MAX_GIB: cap on what the pool holds (0: what the device has)
+    int64_t pool_cache = 1;        // KMERS_PARAM_POOL_CACHE: freed blocks stay mapped for the next request of their shape (0: unmapped at once)
+    kmers_device_slot *slot = nullptr;  // the device's slot, looked up once (memory_api.hip)
+    // what the launcher last asked the pool about a pair of arrays / the halves of one, and the pool generation the answer is for
+    struct placement_answer {
+        const void *a = nullptr, *b = nullptr;
+        size_t bytes_a = 0, bytes_b = 0;
+        uint64_t generation = 0;
+        float differ = -1.f;
+    } placed_pair, placed_halves;
     int call_flags = KMERS_ASYNC;  // flags of the entry point that is running (the launcher must not block inside a KMERS_ASYNC call)
-    // the arena's map for the launchers (an empty one without an arena: every placement question is then answered "no")
-    const kmers_arena &arena() const {
-        static const kmers_arena none;
-        return shared_arena ? shared_arena->a : none;
-    }
     hipStream_t copy_stream = nullptr;   // host-pointer calls in chunks (iterators_api.hip): the copies to the host, beside the kernels
     hipEvent_t pipe_events[4] = {};      //   ... kernel done [2], chunk copied [2]
     int64_t host_chunks = 0;             // KMERS_PARAM_HOST_CHUNKS: -1 = host-pointer calls never in chunks (A/B, tests)
     int last_threads = 0, last_tile = 0, last_split = 0;  // shape of the most recent tile-kernel launch (kmers_last_launch_shape)
-    // The launcher's table (stream_launch.hpp) against its base rule, timed once per pair of output arrays (KMERS_PARAM_SHAPE_CALIBRATE):
-    // what the first large launch into (a, b) measured, reused by every later launch into the same arrays
-    // keyed by what decides the answer -- the launch (mode, element width, layout, stride, a size bucket) and the PLACEMENT of its
-    // arrays (runs of the arena) -- not by pointers: a host that allocates fresh arrays per call
-    // (the reference's collect) meets its earlier measurement again, and kmers_dev_free forgets nothing
-    struct shape_choice {
-        uint64_t key;
-        int threads, tile;
-        bool rule;  // the base rule's shape won
-        float table_ms, rule_ms;
-    };
-    uint64_t calibrations = 0;  // launches that were timed (kmers_shape_calibrations: tests assert it stays at one)
-    std::vector<shape_choice> shape_cache;
-    float last_cal_table_ms = 0.f, last_cal_rule_ms = 0.f;  // what the most recent launch's choice rested on (0: no calibration applied)
-    int last_cal_rule = 0;
-    int64_t shape_calibrate = 1;  // KMERS_PARAM_SHAPE_CALIBRATE: 0 = trust the table
-    bool calibrating = false;
-    hipEvent_t cal_events[2] = {nullptr, nullptr};
     bool unamb_pending = false;     // an asynchronous kmers_unambiguous has run since the last kmers_sync: its count is in h_result[8..10]
     uint64_t unamb_capacity = 0;
 };
@@ -128,9 +103,6 @@ inline int fail(kmers_ctx *ctx, int code, const char *what, hipError_t e = hipSu
 
 // memory_api.hip: the process's slot for a device (created on first use)
 kmers_device_slot &device_slot(int device);
-// memory_api.hip: detach the context from its device's arena.  Its own blocks go back to the arena (`force`: context destruction)
-// or make the call fail with KMERS_E_BADARG; the last context out frees the block.
-int arena_detach(kmers_ctx *ctx, bool force);
 // pool_api.hip: a block of the device's class pool (KMERS_E_UNSUPPORTED: no virtual-memory management here -- plain hipMalloc then);
 // free it if `p` is one (*handled); leave the pool (the last context out returns everything to the driver).  For the launchers:
 // the fraction of 64 relative positions at which two arrays lie in different region classes / at which the two halves of one
@@ -138,6 +110,10 @@ int arena_detach(kmers_ctx *ctx, bool force);
 int pool_alloc(kmers_ctx *ctx, size_t bytes, int role, void **out);
 int pool_free(kmers_ctx *ctx, void *p, bool *handled);
 void pool_detach(kmers_ctx *ctx);
+// pool_api.hip: what the pool holds and nobody uses (cached blocks, free handles) goes back to the driver; the bytes returned.
+// memory_api.hip: hipMalloc that tries that before it gives up -- for every buffer the library allocates for itself.
+size_t pool_release_idle(kmers_ctx *ctx);
+hipError_t dev_malloc(kmers_ctx *ctx, void **out, size_t bytes);
 float pool_arrays_differ(kmers_ctx *ctx, const void *a, size_t bytes_a, const void *b, size_t bytes_b);
 float pool_halves_differ(kmers_ctx *ctx, const void *a, size_t bytes);
 
@@ -148,7 +124,7 @@ inline int ensure_stage(kmers_ctx *ctx, int slot, size_t bytes) {
     ctx->stage[slot] = nullptr;
     ctx->stage_cap[slot] = 0;
     size_t cap = bytes + bytes / 8 + 4096;
-    hipError_t e = hipMalloc(&ctx->stage[slot], cap);
+    hipError_t e = dev_malloc(ctx, &ctx->stage[slot], cap);
     if (e != hipSuccess) return fail(ctx, KMERS_E_NOMEM, "hipMalloc(staging)", e);
     ctx->stage_cap[slot] = cap;
     return KMERS_OK;

@@ -85,6 +85,7 @@ int kmers_ctx_create(int device, void *hip_stream, kmers_ctx **out) {
     kmers_ctx *ctx = new (std::nothrow) kmers_ctx();
     if (!ctx) return KMERS_E_NOMEM;
     ctx->device = device;
+    ctx->slot = &device_slot(device);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
     if (hip_stream) {
@@ -116,16 +117,13 @@ void kmers_ctx_destroy(kmers_ctx *ctx) {
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
     if (ctx->d_recent) (void)hipFree(ctx->d_recent);
     if (ctx->d_layout) (void)hipFree(ctx->d_layout);
-    for (auto &e : ctx->cal_events)
-        if (e) (void)hipEventDestroy(e);
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         for (auto &e : ctx->pipe_events)
             if (e) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
-    kmers::pool_detach(ctx);         // the last context of the device that used the striped pool returns its memory to the driver
-    kmers::arena_detach(ctx, true);  // this context's blocks go back to the arena; the last context of the device frees the block
+    kmers::pool_detach(ctx);  // the last context of the device that used the class pool returns its memory to the driver
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -140,14 +138,13 @@ int kmers_ctx_set_param(kmers_ctx *ctx, int param, int64_t value) {
     else if (param == KMERS_PARAM_SUBTILES) ctx->subtiles = value;
     else if (param == KMERS_PARAM_BLOCK_THREADS) ctx->block_threads = value;
     else if (param == KMERS_PARAM_WIDE_NO_TILES) ctx->wide_no_tiles = value;
-    else if (param == KMERS_PARAM_ARENA_NO_PROBE) ctx->arena_no_probe = value;
     else if (param == KMERS_PARAM_SPLIT_ORDER) ctx->split_order = value;
     else if (param == KMERS_PARAM_STAMPS_PTR) ctx->stamps_ptr = value;
     else if (param == KMERS_PARAM_HOST_CHUNKS) ctx->host_chunks = value;
-    else if (param == KMERS_PARAM_SHAPE_CALIBRATE) ctx->shape_calibrate = value;
     else if (param == KMERS_PARAM_POOL) ctx->pool_enable = value;
     else if (param == KMERS_PARAM_POOL_SEARCH_GIB) ctx->pool_search_gib = value;
     else if (param == KMERS_PARAM_POOL_MAX_GIB) ctx->pool_max_gib = value;
+    else if (param == KMERS_PARAM_POOL_CACHE) ctx->pool_cache = value;
     else if (param == KMERS_PARAM_SKETCH_HOST_ONLY) ctx->sketch_host_only = value != 0;
     else if (param == KMERS_PARAM_BATCH_PASSES) ctx->batch_passes = value;
     else if (param == KMERS_PARAM_BATCH_DENSE) ctx->batch_dense = value;
@@ -161,20 +158,6 @@ int kmers_last_launch_shape(kmers_ctx *ctx, int *threads, int *tile_kmers, int *
     if (threads) *threads = ctx->last_threads;
     if (tile_kmers) *tile_kmers = ctx->last_tile;
     if (split_order) *split_order = ctx->last_split;
-    return KMERS_OK;
-}
-
-int kmers_last_shape_calibration(kmers_ctx *ctx, double *table_ms, double *rule_ms, int *rule_chosen) {
-    if (!ctx) return KMERS_E_BADARG;
-    if (table_ms) *table_ms = ctx->last_cal_table_ms;
-    if (rule_ms) *rule_ms = ctx->last_cal_rule_ms;
-    if (rule_chosen) *rule_chosen = ctx->last_cal_rule;
-    return KMERS_OK;
-}
-
-int kmers_shape_calibrations(kmers_ctx *ctx, uint64_t *count) {
-    if (!ctx || !count) return KMERS_E_BADARG;
-    *count = ctx->calibrations;
     return KMERS_OK;
 }
 

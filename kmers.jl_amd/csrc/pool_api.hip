@@ -17,6 +17,23 @@
 //     (the legacy unmap goes through KFD, which invalidates).  Every unmap here is followed by that flush, and every new block is
 //     checked: a tag written through a chunk's home mapping must be readable through the block.
 //   * Physical memory returns to the driver only when the RESERVATION it was mapped under is freed (unmap + release alone keep it).
+//
+// Round 6 -- what a block COSTS (profiles/r06_pool.md; VERDICT r5 "price the class pool on the collect path").  A host loop is
+// {allocate the outputs, launch, consume, free} (Base.collect makes a fresh Vector per call), and round 5's block paid a
+// reservation, a map per handle, two blocking 8-byte copies and -- at the free -- a hipDeviceSynchronize, an unmap per handle and a
+// TLB flush (a hipMalloc + hipFree), beside a 2.3 ms kernel.  Now:
+//   * kmers_dev_free does not wait.  It records an event on the stream of every context of the device that uses the pool and puts
+//     the block, STILL MAPPED, into the pool's cache; the next request of its shape takes it as it is (class_pool.hpp,
+//     find_cached) and its stream waits for those events -- on the device, not on the host; a request from the stream that
+//     freed it waits for nothing.  A loop that allocates the same shapes makes no call into the driver at all.
+//   * A block of ONE handle (arrays of KMERS_POOL_MIN_BYTES = 128 MiB up to 1 GiB) is the handle's home mapping: nothing is
+//     reserved, mapped or unmapped, ever.
+//   * A cached block nobody asked for over CACHE_AGE_TICKS allocations / frees is taken apart (its events waited for, unmapped),
+//     and so is the oldest one whenever the pool would otherwise have to grow past what the device has.
+//   * The hoard is bounded: after every allocation and free the pool returns to the driver what it holds outside blocks beyond
+//     max(4 GiB, a quarter of its blocks) -- the handles it walked past in search of a class are held for the search only.
+//   * EVERY handle of a newly mapped block is checked against its home mapping (round 5: the first and the last), and a TLB flush
+//     that cannot run is an error, not a shrug.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -42,13 +59,21 @@ struct kmers_device_pool {
     float one_ms = 0.f, two_ms = 0.f;  // running estimates of the two levels (one class / two classes), updated by every confident probe
     uint64_t tag = 0x6b6d657273000000ull;
     size_t n_probes = 0;
+    std::vector<kmers_ctx *> users;       // the contexts that take part (their streams are what may still write a freed block)
+    std::vector<hipEvent_t> spare_events;
+    struct Pending {
+        hipStream_t stream;
+        hipEvent_t ev;
+    };
+    std::map<const char *, std::vector<Pending>> pending;  // cached block -> the work that was queued when it was freed
+    bool need_flush = false;  // something was unmapped since the last TLB flush: nothing may be mapped before the next one
+    uint64_t cache_hits = 0, cache_misses = 0, evictions = 0, chunks_created = 0, chunks_returned = 0;
 };
 
 namespace {
 
 constexpr float SAME_CLASS = 0.93f;  // of the one-class level while the two-class level is unknown (one class: 0.96-1.0 of it, two classes: 0.82-0.87)
 constexpr size_t FLUSH_BYTES = (size_t)32 << 20;
-constexpr float GOOD_PLAN = 0.95f;  // the pool grows (within its search budget) until a block's plan is this good
 
 // two store streams, 8 KiB of each per workgroup, 16 bytes per lane: the shape of the stream kernels' outputs
 __global__ __launch_bounds__(256) void pool_probe_kernel(ulonglong2 *a, ulonglong2 *b) {
@@ -78,11 +103,23 @@ bool probe_ms(kmers_device_pool *P, char *a, char *b, float *out) {
     return true;
 }
 
-// the device's TLB may hold translations of ranges that were just unmapped (header comment): the legacy allocation path flushes it
-void flush_tlb() {
-    void *p = nullptr;
-    if (hipMalloc(&p, FLUSH_BYTES) == hipSuccess) (void)hipFree(p);
-    else (void)hipGetLastError();
+// the device's TLB may hold translations of ranges that were just unmapped (header comment): the legacy allocation path flushes
+// it.  Lazy: an unmap only marks the pool, the flush runs before the next map (a loop that frees and allocates pays one).  false:
+// the flush could not run (no 32 MiB for its hipMalloc even after the pool's idle handles went back) -- nothing may be mapped.
+bool release_idle_locked(kmers_device_pool *P, bool cached_too);
+bool flush_tlb(kmers_device_pool *P) {
+    if (!P->need_flush) return true;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        void *p = nullptr;
+        if (hipMalloc(&p, FLUSH_BYTES) == hipSuccess) {
+            (void)hipFree(p);
+            P->need_flush = false;
+            return true;
+        }
+        (void)hipGetLastError();
+        if (attempt == 0 && !release_idle_locked(P, true)) break;  // (returns what is idle; itself ends with need_flush set)
+    }
+    return false;
 }
 
 bool reserve(void **va, size_t bytes) {
@@ -96,6 +133,7 @@ bool reserve(void **va, size_t bytes) {
 // one more handle, mapped under a reservation of its own (its home); not yet in any free list.  false: the device has no
 // more memory to give (nothing is left half-made).
 bool create_chunk(kmers_device_pool *P, uint32_t *id) {
+    if (!flush_tlb(P)) return false;  // (the home reservation may get an address that was unmapped a moment ago)
     hipMemGenericAllocationHandle_t h;
     if (hipMemCreate(&h, CHUNK_BYTES, &P->prop, 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -111,7 +149,7 @@ bool create_chunk(kmers_device_pool *P, uint32_t *id) {
         (void)hipMemRelease(h);
         (void)hipMemAddressFree(home, CHUNK_BYTES);
         (void)hipGetLastError();
-        flush_tlb();
+        P->need_flush = true;
         return false;
     }
     Chunk c;
@@ -120,10 +158,11 @@ bool create_chunk(kmers_device_pool *P, uint32_t *id) {
     *id = (uint32_t)P->s.chunks.size();
     P->s.chunks.push_back(c);
     P->s.held_bytes += CHUNK_BYTES;
+    ++P->chunks_created;
     return true;
 }
 
-// give a chunk's memory back to the driver (it is free and out of the free lists); the caller flushes
+// give a chunk's memory back to the driver (it is free and out of the free lists); the TLB is flushed before the next map
 void destroy_chunk(kmers_device_pool *P, uint32_t id) {
     Chunk &c = P->s.chunks[id];
     (void)hipMemUnmap(c.home, CHUNK_BYTES);
@@ -133,6 +172,8 @@ void destroy_chunk(kmers_device_pool *P, uint32_t id) {
     c.handle = nullptr;
     c.home = nullptr;
     P->s.held_bytes -= CHUNK_BYTES;
+    P->need_flush = true;
+    ++P->chunks_returned;
 }
 
 void debug_chunk(const State &s, uint32_t id, const char *probes) {
@@ -153,16 +194,17 @@ void set_levels(kmers_device_pool *P, float one_ms, float two_ms) {
 // two streams inside one class; the widest gap between neighbouring times (if it is 6 % or more) separates the two levels, and
 // the MEDIAN of each side is its estimate (a single slow outlier as the yardstick made same-class probes look fast: spurious
 // fourth and fifth classes on two boxes of round 5).
-bool calibrate(kmers_device_pool *P) {
+bool room_for_chunks(const kmers_ctx *ctx, const State &s, size_t n);
+bool calibrate(kmers_device_pool *P, const kmers_ctx *ctx) {
     State &s = P->s;
     uint32_t id[4];
     int made = 0;
+    if (!room_for_chunks(ctx, s, 4)) return false;  // (the cap of KMERS_PARAM_POOL_MAX_GIB and the device's free memory hold for the calibration too)
     for (; made < 4; ++made)
         if (!create_chunk(P, &id[made])) break;
     if (made < 4) {
         for (int i = 0; i < made; ++i) destroy_chunk(P, id[i]);
         s.chunks.clear();
-        if (made) flush_tlb();
         return false;
     }
     float t[4][4] = {}, warm;
@@ -220,9 +262,9 @@ bool calibrate(kmers_device_pool *P) {
 // that probe is on the one-class side; a chunk that is fast beside all of them is a new class while fewer than three are known,
 // and otherwise (a handle that straddles a boundary of the physical map, a noisy probe: asked again first) the nearest one.
 // Confident probes move the two levels (exponential averages), so the yardstick follows the box.
-bool grow(kmers_device_pool *P) {
+bool grow(kmers_device_pool *P, const kmers_ctx *ctx) {
     State &s = P->s;
-    if (s.chunks.empty() || (s.n_classes == 0 && s.slow_ms == 0.f && P->same_ms == 0.f)) return calibrate(P);
+    if (s.chunks.empty() || (s.n_classes == 0 && s.slow_ms == 0.f && P->same_ms == 0.f)) return calibrate(P, ctx);
     uint32_t id;
     if (!create_chunk(P, &id)) return false;
     Chunk &c = s.chunks[id];
@@ -270,6 +312,117 @@ bool grow(kmers_device_pool *P) {
     return true;
 }
 
+// ---- events: the work that may still touch a freed block --------------------------------------------------------------------
+hipEvent_t get_event(kmers_device_pool *P) {
+    if (!P->spare_events.empty()) {
+        hipEvent_t e = P->spare_events.back();
+        P->spare_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return e;
+}
+
+// everything queued so far on the streams of the pool's contexts: what a later user of the block has to come after.  A stream an
+// event cannot be recorded on is waited for here and now instead.
+void record_pending(kmers_device_pool *P, const char *base) {
+    std::vector<kmers_device_pool::Pending> &list = P->pending[base];
+    for (kmers_ctx *u : P->users) {
+        bool seen = false;
+        for (const auto &q : list) seen = seen || q.stream == u->stream;
+        if (seen) continue;  // (contexts that borrow one stream)
+        hipEvent_t e = get_event(P);
+        if (e && hipEventRecord(e, u->stream) == hipSuccess) {
+            list.push_back({u->stream, e});
+            continue;
+        }
+        (void)hipGetLastError();
+        if (e) P->spare_events.push_back(e);
+        (void)hipStreamSynchronize(u->stream);
+    }
+}
+void wait_pending_on_host(kmers_device_pool *P, const char *base) {
+    auto it = P->pending.find(base);
+    if (it == P->pending.end()) return;
+    for (auto &q : it->second) {
+        (void)hipEventSynchronize(q.ev);
+        P->spare_events.push_back(q.ev);
+    }
+    (void)hipGetLastError();
+    P->pending.erase(it);
+}
+// the new user's stream comes after them (its own earlier work is before it anyway)
+void wait_pending_on_stream(kmers_device_pool *P, const char *base, hipStream_t st) {
+    auto it = P->pending.find(base);
+    if (it == P->pending.end()) return;
+    for (auto &q : it->second) {
+        if (q.stream != st && hipStreamWaitEvent(st, q.ev, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipEventSynchronize(q.ev);
+        }
+        P->spare_events.push_back(q.ev);  // (a wait refers to the record that was current when it was enqueued: the event may be recorded again)
+    }
+    P->pending.erase(it);
+}
+
+// a block's own mapping goes; its chunks stay with the pool.  The TLB is flushed before the next map (flush_tlb).
+void unmap_block(kmers_device_pool *P, char *base, const Block &b) {
+    if (b.home) return;  // (the chunk's own mapping: it lives as long as the chunk)
+    for (size_t i = 0; i < b.chunks.size(); ++i) (void)hipMemUnmap(base + i * CHUNK_BYTES, CHUNK_BYTES);
+    (void)hipMemAddressFree(base, b.chunks.size() * CHUNK_BYTES);
+    (void)hipGetLastError();
+    P->need_flush = true;
+}
+
+// a cached block is taken apart: the work that was queued when it was freed is waited for (on the host: its memory may go
+// anywhere next), its chunks return to the free lists
+void evict(kmers_device_pool *P, std::map<const char *, Block>::iterator it) {
+    wait_pending_on_host(P, it->first);
+    unmap_block(P, const_cast<char *>(it->first), it->second);
+    give(P->s, it->second.chunks, true);
+    P->s.cached.erase(it);
+    ++P->evictions;
+}
+bool evict_oldest(kmers_device_pool *P) {
+    State &s = P->s;
+    if (s.cached.empty()) return false;
+    auto oldest = s.cached.begin();
+    for (auto it = s.cached.begin(); it != s.cached.end(); ++it)
+        if (it->second.freed_tick < oldest->second.freed_tick) oldest = it;
+    evict(P, oldest);
+    return true;
+}
+void age_out(kmers_device_pool *P) {
+    State &s = P->s;
+    for (auto it = s.cached.begin(); it != s.cached.end();) {
+        auto next = std::next(it);
+        if (s.tick - it->second.freed_tick > CACHE_AGE_TICKS) evict(P, it);
+        it = next;
+    }
+}
+
+// what the pool holds outside blocks beyond what it may (class_pool.hpp, hoard_excess) goes back to the driver: from the fullest
+// free list first, so that what stays is a mix of classes
+size_t trim_hoard(kmers_device_pool *P) {
+    State &s = P->s;
+    size_t released = 0;
+    for (size_t x = hoard_excess(s); x > 0; --x) {
+        int fullest = -1;
+        for (int c = 0; c < N_LISTS; ++c)
+            if (!s.free_list[c].empty() && (fullest < 0 || s.free_list[c].size() > s.free_list[fullest].size())) fullest = c;
+        if (fullest < 0) break;
+        const uint32_t id = s.free_list[fullest].back();
+        s.free_list[fullest].pop_back();
+        destroy_chunk(P, id);
+        released += CHUNK_BYTES;
+    }
+    return released;
+}
+
 // free chunks go back to the driver; `all`: the representatives too (the pool forgets its classes with them)
 size_t trim(kmers_device_pool *P, bool all) {
     State &s = P->s;
@@ -281,7 +434,7 @@ size_t trim(kmers_device_pool *P, bool all) {
         }
         list.clear();
     }
-    if (all && s.in_use_bytes == 0) {
+    if (all && s.in_use_bytes == 0 && s.cached_bytes == 0) {
         for (int k = 0; k < s.n_classes; ++k) {
             destroy_chunk(P, s.rep_chunk[k]);
             released += CHUNK_BYTES;
@@ -291,19 +444,20 @@ size_t trim(kmers_device_pool *P, bool all) {
         s.slow_ms = s.fast_ms = 0.f;
         P->same_ms = 0.f;
     }
-    if (released) flush_tlb();
     return released;
 }
 
-void unmap_block(char *base, size_t n_chunks) {
-    for (size_t i = 0; i < n_chunks; ++i) (void)hipMemUnmap(base + i * CHUNK_BYTES, CHUNK_BYTES);
-    (void)hipMemAddressFree(base, n_chunks * CHUNK_BYTES);
-    (void)hipGetLastError();
-    flush_tlb();
+// everything nobody uses goes back to the driver: cached blocks (if asked) and free chunks.  true: something was returned.
+bool release_idle_locked(kmers_device_pool *P, bool cached_too) {
+    bool any = false;
+    if (cached_too)
+        while (evict_oldest(P)) any = true;
+    return trim(P, false) > 0 || any;
 }
 
-kmers_device_pool *attach(kmers_ctx *ctx, kmers_device_slot &slot) {  // slot.mu is held
+kmers_device_pool *attach(kmers_ctx *ctx, kmers_device_slot &slot, bool create = true) {  // slot.mu is held
     if (!slot.pool) {
+        if (!create) return nullptr;
         kmers_device_pool *P = new (std::nothrow) kmers_device_pool();
         if (!P) return nullptr;
         P->device = ctx->device;
@@ -327,88 +481,132 @@ kmers_device_pool *attach(kmers_ctx *ctx, kmers_device_slot &slot) {  // slot.mu
     if (!ctx->uses_pool) {
         ctx->uses_pool = true;
         ++slot.pool->refs;
+        slot.pool->users.push_back(ctx);
     }
     return slot.pool;
 }
 
-bool room_for_a_chunk(const kmers_ctx *ctx, const State &s) {
+// the device has room for n more handles (and one to spare) and the pool's cap allows them
+bool room_for_chunks(const kmers_ctx *ctx, const State &s, size_t n) {
     const size_t max_held = ctx->pool_max_gib > 0 ? (size_t)ctx->pool_max_gib << 30 : ~(size_t)0;
     size_t free_b = 0, total_b = 0;
-    return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= 2 * CHUNK_BYTES && s.held_bytes + CHUNK_BYTES <= max_held;
+    return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= (n + 1) * CHUNK_BYTES && s.held_bytes + n * CHUNK_BYTES <= max_held;
+}
+
+// every chunk of a newly mapped block must show through the block what was written through its home mapping (a stale translation
+// of the address range would show other memory: kernel stores through it would land in somebody else's block)
+hipError_t verify_block(kmers_device_pool *P, char *base, const std::vector<uint32_t> &ids, bool *stale) {
+    const size_t n = ids.size();
+    std::vector<uint64_t> tags(n), seen(n, 0);
+    hipError_t e = hipSuccess;
+    for (size_t k = 0; k < n && e == hipSuccess; ++k) {
+        tags[k] = ++P->tag;
+        e = hipMemcpyAsync(P->s.chunks[ids[k]].home, &tags[k], 8, hipMemcpyHostToDevice, P->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(P->stream);
+    for (size_t k = 0; k < n && e == hipSuccess; ++k) e = hipMemcpyAsync(&seen[k], base + k * CHUNK_BYTES, 8, hipMemcpyDeviceToHost, P->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(P->stream);
+    *stale = false;
+    for (size_t k = 0; k < n && e == hipSuccess; ++k) *stale = *stale || seen[k] != tags[k];
+    return e;
 }
 
 }  // namespace
 
 int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, int role, void **out) {
     *out = nullptr;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    kmers_device_slot &slot = device_slot(ctx->device);
+    kmers_device_slot &slot = *ctx->slot;
     std::lock_guard<std::mutex> lock(slot.mu);
     kmers_device_pool *P = attach(ctx, slot);
     if (!P) return KMERS_E_UNSUPPORTED;  // no virtual-memory management on this device: the caller falls back to hipMalloc
     State &s = P->s;
+    ++s.tick;
     // A lone output is written through two windows half an array apart: its MIDDLE is put on a chunk boundary (the block is the
     // two halves rounded up to whole chunks each, the caller's pointer lies `user_off` inside it), so that the first half is one
     // run of chunks and the second another, whatever the array's size (C3: 9.31 GiB -> 5 + 5 chunks, the pointer 0.34 GiB in).
     size_t user_off = 0, plan_bytes = bytes;
-    if (role == ROLE_LONE_OUTPUT && bytes >= 2 * CHUNK_BYTES) {
-        const size_t half = (bytes / 2 + 4095) / 4096 * 4096, k1 = chunks_for(half);
-        user_off = k1 * CHUNK_BYTES - half;
-        plan_bytes = 2 * k1 * CHUNK_BYTES;
-    }
-    const size_t n = chunks_for(plan_bytes);
-    const size_t search_limit = ctx->pool_search_gib >= 0 ? (size_t)ctx->pool_search_gib << 30 : (size_t)128 << 30;
+    const size_t n = block_chunks(bytes, role, &user_off, &plan_bytes);
     const Block *other = nullptr;
     const Block *partner = role == ROLE_DEFAULT ? partner_block(s, bytes, &other) : nullptr;
+    // 1. a freed block of this shape that is still mapped: nothing to do but to come after the work that was queued when it was freed
+    if (ctx->pool_cache > 0) {
+        auto hit = find_cached(s, bytes, role, partner);
+        if (hit != s.cached.end()) {
+            const char *base = hit->first;
+            wait_pending_on_stream(P, base, ctx->stream);
+            Block b = from_cache(s, hit);
+            b.req_bytes = bytes;
+            b.user_off = user_off;
+            b.serial = ++s.serial;
+            s.blocks[base] = std::move(b);
+            ++P->cache_hits;
+            slot.generation.fetch_add(1, std::memory_order_release);
+            *out = const_cast<char *>(base) + user_off;
+            return KMERS_OK;
+        }
+    }
+    ++P->cache_misses;
+    age_out(P);  // (their chunks join the stock the plan draws on)
+    {
+        size_t free_b = 0, total_b = 0;  // a request the device could never hold must not walk all of its memory first
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n * CHUNK_BYTES > free_b + s.held_bytes - s.in_use_bytes)
+            return fail(ctx, KMERS_E_NOMEM, "kmers_dev_alloc: more than the device has free");
+    }
+    // 2. a new block, its chunks chosen by class.  The pool may grow past the request in search of the classes it wants: by default
+    // up to 8 x the request (16 GiB at least), and what it walked past goes back to the driver afterwards (trim_hoard).
+    const size_t search_limit = ctx->pool_search_gib >= 0 ? (size_t)ctx->pool_search_gib << 30 : std::max((size_t)16 << 30, 8 * n * CHUNK_BYTES);
     std::vector<uint8_t> seq;
+    float quality = 0.f;
     for (size_t searched = 0;;) {
         size_t free_counts[N_LISTS];
         for (int i = 0; i < N_LISTS; ++i) free_counts[i] = s.free_list[i].size();
-        float quality = 0.f;
+        quality = 0.f;
         seq = plan(free_counts, plan_bytes, partner, role, &quality, other);
         if (!seq.empty() && (quality >= GOOD_PLAN || searched >= search_limit)) break;
-        if (!room_for_a_chunk(ctx, s) || !grow(P)) {
-            if (!seq.empty()) break;
-            return fail(ctx, KMERS_E_NOMEM, "kmers_dev_alloc: the device has no memory left for the pool");
+        if (room_for_chunks(ctx, s, 1) && grow(P, ctx)) {
+            if (!seq.empty()) searched += CHUNK_BYTES;
+            continue;
         }
-        if (!seq.empty()) searched += CHUNK_BYTES;
+        if (evict_oldest(P)) continue;  // the device (or the cap) has no more: what the cache holds is stock too
+        if (!seq.empty()) break;
+        trim_hoard(P);
+        return fail(ctx, KMERS_E_NOMEM, "kmers_dev_alloc: the device has no memory left for the pool");
     }
     std::vector<uint32_t> ids = take(s, seq);
-    void *va = nullptr;
-    if (!reserve(&va, n * CHUNK_BYTES)) {
-        give(s, ids);
-        return fail(ctx, KMERS_E_NOMEM, "kmers_dev_alloc: hipMemAddressReserve");
-    }
-    char *base = static_cast<char *>(va);
-    hipError_t e = hipSuccess;
-    size_t mapped = 0;
-    for (; mapped < n && e == hipSuccess; ++mapped)
-        e = hipMemMap(base + mapped * CHUNK_BYTES, CHUNK_BYTES, 0, static_cast<hipMemGenericAllocationHandle_t>(s.chunks[ids[mapped]].handle), 0);
-    if (e != hipSuccess) --mapped;
-    if (e == hipSuccess) e = hipMemSetAccess(base, n * CHUNK_BYTES, &P->access, 1);
-    // the block must show the chunks it was made of: first and last chunk, a tag written through the home mapping
-    for (int end = 0; end < 2 && e == hipSuccess; ++end) {
-        const size_t k = end ? n - 1 : 0;
-        const uint64_t tag = ++P->tag;
-        uint64_t seen = 0;
-        e = hipMemcpy(s.chunks[ids[k]].home, &tag, 8, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(&seen, base + k * CHUNK_BYTES, 8, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && seen != tag) {  // a stale translation: flush and look again
-            flush_tlb();
-            e = hipMemcpy(&seen, base + k * CHUNK_BYTES, 8, hipMemcpyDeviceToHost);
-            if (e == hipSuccess && seen != tag) {
-                unmap_block(base, n);
-                give(s, ids);
-                return fail(ctx, KMERS_E_HIP, "kmers_dev_alloc: a new block of the pool does not show the memory it was mapped to (stale translations)");
-            }
+    char *base = nullptr;
+    const bool home = n == 1;
+    if (home) {
+        base = s.chunks[ids[0]].home;  // one chunk: its own mapping is the block
+    } else {
+        void *va = nullptr;
+        if (!flush_tlb(P) || !reserve(&va, n * CHUNK_BYTES)) {
+            give(s, ids);
+            trim_hoard(P);
+            return fail(ctx, KMERS_E_NOMEM, "kmers_dev_alloc: no address range (or no TLB flush) for a block of the pool");
         }
-    }
-    if (e != hipSuccess) {
-        for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap(base + i * CHUNK_BYTES, CHUNK_BYTES);
-        (void)hipMemAddressFree(base, n * CHUNK_BYTES);
-        flush_tlb();
-        give(s, ids);
-        return fail(ctx, KMERS_E_HIP, "kmers_dev_alloc: mapping a block of the pool", e);
+        base = static_cast<char *>(va);
+        hipError_t e = hipSuccess;
+        size_t mapped = 0;
+        for (; mapped < n && e == hipSuccess; ++mapped)
+            e = hipMemMap(base + mapped * CHUNK_BYTES, CHUNK_BYTES, 0, static_cast<hipMemGenericAllocationHandle_t>(s.chunks[ids[mapped]].handle), 0);
+        if (e != hipSuccess) --mapped;
+        if (e == hipSuccess) e = hipMemSetAccess(base, n * CHUNK_BYTES, &P->access, 1);
+        bool stale = false;
+        if (e == hipSuccess) e = verify_block(P, base, ids, &stale);
+        if (e == hipSuccess && stale) {  // flush and look again
+            P->need_flush = true;
+            if (flush_tlb(P)) e = verify_block(P, base, ids, &stale);
+        }
+        if (e != hipSuccess || stale) {
+            for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap(base + i * CHUNK_BYTES, CHUNK_BYTES);
+            (void)hipMemAddressFree(base, n * CHUNK_BYTES);
+            (void)hipGetLastError();
+            P->need_flush = true;
+            give(s, ids);
+            trim_hoard(P);
+            if (e == hipSuccess) return fail(ctx, KMERS_E_HIP, "kmers_dev_alloc: a new block of the pool does not show the memory it was mapped to (stale translations)");
+            return fail(ctx, KMERS_E_HIP, "kmers_dev_alloc: mapping a block of the pool", e);
+        }
     }
     Block b;
     b.bytes = n * CHUNK_BYTES;
@@ -417,73 +615,137 @@ int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, int role, void **out) {
     b.chunks = std::move(ids);
     b.classes = std::move(seq);
     b.serial = ++s.serial;
+    b.role = role;
+    b.home = home;
+    b.quality = quality;
     s.blocks[base] = std::move(b);
+    trim_hoard(P);  // what the search walked past goes back to the driver
+    slot.generation.fetch_add(1, std::memory_order_release);
     *out = base + user_off;
     return KMERS_OK;
 }
 
 int kmers::pool_free(kmers_ctx *ctx, void *p, bool *handled) {
     *handled = false;
-    kmers_device_slot &slot = device_slot(ctx->device);
+    kmers_device_slot &slot = *ctx->slot;
     std::lock_guard<std::mutex> lock(slot.mu);
     kmers_device_pool *P = slot.pool;
     if (!P) return KMERS_OK;
+    State &s = P->s;
     const char *base = nullptr;
-    const Block *blk = block_of(P->s, p, 1, &base);
-    if (!blk) return KMERS_OK;
+    const Block *blk = block_of(s, p, 1, &base);
+    if (!blk) {
+        auto c = s.cached.upper_bound(static_cast<const char *>(p));
+        if (c != s.cached.begin()) {
+            --c;
+            if (static_cast<const char *>(p) < c->first + c->second.bytes) {
+                *handled = true;
+                return fail(ctx, KMERS_E_BADARG, "kmers_dev_free: this block of the pool has been freed already");
+            }
+        }
+        return KMERS_OK;
+    }
     *handled = true;
     if (static_cast<const char *>(p) != base + blk->user_off) return fail(ctx, KMERS_E_BADARG, "kmers_dev_free: not the start of a block of the pool");
-    auto it = P->s.blocks.find(base);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipDeviceSynchronize());  // whatever stream of whatever context still writes into it
-    unmap_block(const_cast<char *>(base), it->second.chunks.size());
-    give(P->s, it->second.chunks);
-    P->s.blocks.erase(it);
+    attach(ctx, slot, false);  // (a context that only ever frees: its stream counts from now on)
+    ++s.tick;
+    auto it = s.blocks.find(base);
+    Block b = std::move(it->second);
+    s.blocks.erase(it);
+    // No wait: whatever is queued on the streams of the device's contexts comes BEFORE the block's next use -- events recorded now,
+    // waited for by the stream of whoever takes the block next (or by the host, if the block is taken apart first).
+    record_pending(P, base);
+    if (ctx->pool_cache > 0) {
+        to_cache(s, base, std::move(b));
+    } else {
+        wait_pending_on_host(P, base);
+        unmap_block(P, const_cast<char *>(base), b);
+        give(s, b.chunks);
+    }
+    age_out(P);
+    trim_hoard(P);
+    slot.generation.fetch_add(1, std::memory_order_release);
     return KMERS_OK;
+}
+
+size_t kmers::pool_release_idle(kmers_ctx *ctx) {
+    if (!ctx->slot) return 0;
+    std::lock_guard<std::mutex> lock(ctx->slot->mu);
+    kmers_device_pool *P = ctx->slot->pool;
+    if (!P) return 0;
+    const size_t before = P->s.held_bytes;
+    release_idle_locked(P, true);
+    ctx->slot->generation.fetch_add(1, std::memory_order_release);
+    return before - P->s.held_bytes;
 }
 
 void kmers::pool_detach(kmers_ctx *ctx) {
     if (!ctx->uses_pool) return;
     ctx->uses_pool = false;
-    kmers_device_slot &slot = device_slot(ctx->device);
+    kmers_device_slot &slot = *ctx->slot;
     std::lock_guard<std::mutex> lock(slot.mu);
     kmers_device_pool *P = slot.pool;
-    if (!P || --P->refs > 0) return;
+    if (!P) return;
+    P->users.erase(std::remove(P->users.begin(), P->users.end(), ctx), P->users.end());
+    if (--P->refs > 0) return;  // (its stream has been waited for by kmers_ctx_destroy: events recorded on it are complete)
     // the last context of the device that used the pool: everything goes back, blocks that are still out included
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    while (evict_oldest(P)) {}
     for (auto &b : P->s.blocks) {
-        unmap_block(const_cast<char *>(b.first), b.second.chunks.size());
+        unmap_block(P, const_cast<char *>(b.first), b.second);
         give(P->s, b.second.chunks);
     }
     P->s.blocks.clear();
     trim(P, true);
+    P->need_flush = true;
+    (void)flush_tlb(P);
+    for (hipEvent_t e : P->spare_events) (void)hipEventDestroy(e);
     (void)hipEventDestroy(P->e0);
     (void)hipEventDestroy(P->e1);
     (void)hipStreamDestroy(P->stream);
     slot.pool = nullptr;
+    slot.generation.fetch_add(1, std::memory_order_release);
     delete P;
 }
 
+// The launchers' two questions.  The answer stands for as long as no block of the pool has come or gone (slot.generation): a
+// stream of launches into the same arrays takes no lock and walks no map.
 float kmers::pool_arrays_differ(kmers_ctx *ctx, const void *a, size_t bytes_a, const void *b, size_t bytes_b) {
     if (!ctx->uses_pool) return -1.f;
-    kmers_device_slot &slot = device_slot(ctx->device);
+    kmers_device_slot &slot = *ctx->slot;
+    const uint64_t gen = slot.generation.load(std::memory_order_acquire);
+    kmers_ctx::placement_answer &c = ctx->placed_pair;
+    if (c.generation == gen && c.a == a && c.b == b && c.bytes_a == bytes_a && c.bytes_b == bytes_b) return c.differ;
     std::lock_guard<std::mutex> lock(slot.mu);
-    return slot.pool ? arrays_differ(slot.pool->s, a, bytes_a, b, bytes_b) : -1.f;
+    c.generation = slot.generation.load(std::memory_order_acquire);
+    c.a = a;
+    c.b = b;
+    c.bytes_a = bytes_a;
+    c.bytes_b = bytes_b;
+    c.differ = slot.pool ? arrays_differ(slot.pool->s, a, bytes_a, b, bytes_b) : -1.f;
+    return c.differ;
 }
 
 float kmers::pool_halves_differ(kmers_ctx *ctx, const void *a, size_t bytes) {
     if (!ctx->uses_pool) return -1.f;
-    kmers_device_slot &slot = device_slot(ctx->device);
+    kmers_device_slot &slot = *ctx->slot;
+    const uint64_t gen = slot.generation.load(std::memory_order_acquire);
+    kmers_ctx::placement_answer &c = ctx->placed_halves;
+    if (c.generation == gen && c.a == a && c.bytes_a == bytes) return c.differ;
     std::lock_guard<std::mutex> lock(slot.mu);
-    return slot.pool ? halves_differ(slot.pool->s, a, bytes) : -1.f;
+    c.generation = slot.generation.load(std::memory_order_acquire);
+    c.a = a;
+    c.bytes_a = bytes;
+    c.differ = slot.pool ? halves_differ(slot.pool->s, a, bytes) : -1.f;
+    return c.differ;
 }
 
 extern "C" {
 
 int kmers_pool_info(kmers_ctx *ctx, size_t *held, size_t *in_use, int *n_classes, size_t *class_bytes, double *two_class_gbps, double *one_class_gbps) {
     if (!ctx) return KMERS_E_BADARG;
-    kmers_device_slot &slot = device_slot(ctx->device);
+    kmers_device_slot &slot = *ctx->slot;
     std::lock_guard<std::mutex> lock(slot.mu);
     const kmers_device_pool *P = slot.pool;
     if (held) *held = P ? P->s.held_bytes : 0;
@@ -506,12 +768,61 @@ int kmers_pool_info(kmers_ctx *ctx, size_t *held, size_t *in_use, int *n_classes
 int kmers_pool_trim(kmers_ctx *ctx, size_t *released) {
     if (!ctx) return KMERS_E_BADARG;
     if (released) *released = 0;
-    kmers_device_slot &slot = device_slot(ctx->device);
+    kmers_device_slot &slot = *ctx->slot;
     std::lock_guard<std::mutex> lock(slot.mu);
     if (!slot.pool) return KMERS_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t r = trim(slot.pool, slot.pool->s.blocks.empty());
-    if (released) *released = r;
+    kmers_device_pool *P = slot.pool;
+    const size_t before = P->s.held_bytes;
+    while (evict_oldest(P)) {}  // the cache of freed blocks first: their chunks join the free lists
+    trim(P, P->s.blocks.empty());
+    (void)flush_tlb(P);
+    slot.generation.fetch_add(1, std::memory_order_release);
+    if (released) *released = before - P->s.held_bytes;
+    return KMERS_OK;
+}
+
+int kmers_pool_stats(kmers_ctx *ctx, uint64_t *out, size_t capacity) {
+    if (!ctx || (!out && capacity)) return KMERS_E_BADARG;
+    kmers_device_slot &slot = *ctx->slot;
+    std::lock_guard<std::mutex> lock(slot.mu);
+    const kmers_device_pool *P = slot.pool;
+    size_t idle = 0;
+    if (P)
+        for (const auto &l : P->s.free_list) idle += l.size() * CHUNK_BYTES;
+    const uint64_t v[KMERS_POOL_STATS] = {P ? P->s.held_bytes : 0,   P ? P->s.in_use_bytes : 0, P ? P->s.cached_bytes : 0, idle,
+                                          P ? P->cache_hits : 0,     P ? P->cache_misses : 0,   P ? P->evictions : 0,      P ? P->chunks_created : 0,
+                                          P ? P->chunks_returned : 0, P ? P->n_probes : 0,      P ? P->s.cached.size() : 0, P ? P->s.blocks.size() : 0};
+    for (size_t i = 0; i < capacity && i < KMERS_POOL_STATS; ++i) out[i] = v[i];
+    return KMERS_OK;
+}
+
+int kmers_placement_probe(kmers_ctx *ctx, void *a_dev, void *b_dev, size_t bytes, double *gbps) {
+    if (!ctx) return KMERS_E_BADARG;
+    if (!a_dev || !b_dev || !gbps || bytes < 8192 || ((uintptr_t)a_dev & 15u) || ((uintptr_t)b_dev & 15u))
+        return fail(ctx, KMERS_E_BADARG, "kmers_placement_probe: two 16-byte aligned device buffers of at least 8 KiB");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t groups = std::min<size_t>(bytes, (size_t)2 << 30) / 8192;  // at most 2 GiB of each are written
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    float best = 1e30f;
+    int rc = KMERS_OK;
+    for (int rep = 0; rep < 4 && rc == KMERS_OK; ++rep) {  // (the first one warms up)
+        hipError_t e = hipEventRecord(e0, ctx->stream);
+        hipLaunchKernelGGL(pool_probe_kernel, dim3((unsigned)groups), dim3(256), 0, ctx->stream, static_cast<ulonglong2 *>(a_dev),
+                           static_cast<ulonglong2 *>(b_dev));
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = fail(ctx, KMERS_E_HIP, "kmers_placement_probe", e);
+        else if (rep && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != KMERS_OK) return rc;
+    *gbps = 2.0 * (double)groups * 8192.0 / 1e6 / (double)best;
     return KMERS_OK;
 }
 
@@ -519,7 +830,7 @@ int kmers_pool_layout(kmers_ctx *ctx, const void *block, size_t *chunk_bytes, un
     if (!ctx) return KMERS_E_BADARG;
     if (chunk_bytes) *chunk_bytes = CHUNK_BYTES;
     if (n_chunks) *n_chunks = 0;
-    kmers_device_slot &slot = device_slot(ctx->device);
+    kmers_device_slot &slot = *ctx->slot;
     std::lock_guard<std::mutex> lock(slot.mu);
     if (!slot.pool) return KMERS_OK;
     const Block *b = block ? block_of(slot.pool->s, block, 1) : nullptr;
@@ -538,18 +849,19 @@ int kmers_pool_selftest(kmers_ctx *ctx, int *stale_without_flush) {
     if (!ctx) return KMERS_E_BADARG;
     if (stale_without_flush) *stale_without_flush = 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    kmers_device_slot &slot = device_slot(ctx->device);
+    kmers_device_slot &slot = *ctx->slot;
     std::lock_guard<std::mutex> lock(slot.mu);
     kmers_device_pool *P = attach(ctx, slot);
     if (!P) return fail(ctx, KMERS_E_UNSUPPORTED, "no virtual-memory management on this device");
     State &s = P->s;
+    if (!flush_tlb(P)) return fail(ctx, KMERS_E_NOMEM, "kmers_pool_selftest: the TLB flush could not run");  // (start clean: flushes are lazy)
     auto n_free = [&] {
         size_t total = 0;
         for (auto &l : s.free_list) total += l.size();
         return total;
     };
     while (n_free() < 2)
-        if (!room_for_a_chunk(ctx, s) || !grow(P)) return fail(ctx, KMERS_E_NOMEM, "kmers_pool_selftest: no memory");
+        if (!room_for_chunks(ctx, s, 1) || !grow(P, ctx)) return fail(ctx, KMERS_E_NOMEM, "kmers_pool_selftest: no memory");
     size_t free_counts[N_LISTS];
     for (int i = 0; i < N_LISTS; ++i) free_counts[i] = s.free_list[i].size();
     std::vector<uint32_t> ids = take(s, plan(free_counts, 2 * CHUNK_BYTES, nullptr, ROLE_DEFAULT, nullptr));
@@ -567,7 +879,10 @@ int kmers_pool_selftest(kmers_ctx *ctx, int *stale_without_flush) {
             if (e == hipSuccess) e = hipMemcpy(&seen[k], va[k], 8, hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemUnmap(va[k], CHUNK_BYTES);
             if (e == hipSuccess) e = hipMemAddressFree(va[k], CHUNK_BYTES);
-            if (e == hipSuccess && with_flush) flush_tlb();
+            if (e == hipSuccess && with_flush) {
+                P->need_flush = true;
+                if (!flush_tlb(P)) e = hipErrorOutOfMemory;
+            }
         }
         if (e != hipSuccess) rc = fail(ctx, KMERS_E_HIP, "kmers_pool_selftest", e);
         else if (seen[0] != tags[0]) rc = fail(ctx, KMERS_E_HIP, "kmers_pool_selftest: a fresh mapping does not show its chunk");
@@ -575,9 +890,12 @@ int kmers_pool_selftest(kmers_ctx *ctx, int *stale_without_flush) {
             if (with_flush) rc = fail(ctx, KMERS_E_HIP, "kmers_pool_selftest: stale translation in spite of the flush");
             else if (stale_without_flush) *stale_without_flush = 1;
         }
-        flush_tlb();
+        P->need_flush = true;
+        (void)flush_tlb(P);
     }
     give(s, ids);
+    trim_hoard(P);
+    (void)flush_tlb(P);
     return rc;
 }
 

@@ -92,45 +92,40 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
     // it with the outputs in KNOWN places (profiles/r03_tuning.md sections 2, 5, 6, 7; fractions of 8 TB/s, fresh processes):
     //
     //   launch                                            | placement the launcher sees          | threads x kmers      | gain
-    //   one-word elements, two arrays (C2 headline, FwRv, | well placed (kmers_arena_spread)     | 128 x 1536 (24 KiB)  | 0.82-0.84 -> 0.88-0.90
+    //   one-word elements, two arrays (C2 headline, FwRv, | well placed (pool_arrays_differ)     | 128 x 1536 (24 KiB)  | 0.82-0.84 -> 0.88-0.90
     //     kmers + starts)                                 | anything else                        | 256 x 1024 (rule)    | (24 KiB bimodal there)
     //   two-word kmers + reverse complements (C4)         | well placed                          | 256 x 768            | 0.87 -> 0.90-0.915
     //   three- / four-word kmers + reverse complements    | well placed                          | 256 x 512            | 0.75 -> 0.80 (four-word)
     //   two-word canonical kmers + hashes                 | well placed                          | 128 x 768            | 0.71 -> 0.87-0.88
     //                                                     | anything else                        | 128 x 512            | 0.70 -> 0.80-0.85
     //   three- / four-word canonical kmers + hashes       | any                                  | 128 x 512            | 0.58 -> 0.69 (four-word)
-    //   ONE output array across a class boundary of the   | kmers_arena_straddles                | 128 x 16 KiB, split  | C3 0.81 -> 0.87, two-word 0.80 -> 0.86
-    //     arena (kmers_dev_alloc_role LONE_OUTPUT)        |   ... strided (SpacedKmers, C5)      | 256 x 40 KiB, split  | 0.75 -> 0.78-0.79
+    //   ONE output array whose halves lie in two classes  | pool_halves_differ                   | 128 x 16 KiB, split  | C3 0.81 -> 0.87, two-word 0.80 -> 0.86
+    //     (kmers_dev_alloc_role LONE_OUTPUT)              |   ... strided (SpacedKmers, C5)      | 256 x 40 KiB, split  | 0.75 -> 0.78-0.79
     //                                                     |   ... tuple elements                 | 256 x 6 x rule, split| 0.61 -> 0.82-0.83
     //   everything else                                   |                                      | 256 x rule           |
     //
-    // "well placed" = both arrays inside the context's arena, in runs whose MEASURED two-stream rate is within 5 % of the block's
-    // best pair; "split" = two write windows half an array apart (stream_kernel.hpp, SPLIT ORDER).  KMERS_PARAM_TILE_KMERS /
-    // _BLOCK_THREADS / _SPLIT_ORDER override the table (tests, tools/).
+    // "well placed" = both arrays in blocks of the device's class pool (pool_api.hip) that differ in region class at 90 % of 64
+    // relative positions -- true by construction for arrays allocated one after the other; "split" = two write windows half an
+    // array apart (stream_kernel.hpp, SPLIT ORDER).  Plain allocations get the base rule.  KMERS_PARAM_TILE_KMERS /
+    // _BLOCK_THREADS / _SPLIT_ORDER override the table (tests, tools/).  (Rounds 3-5 also asked the map of a reserved arena and
+    // timed the table against the rule once per placement: gone with the arena, round 6.)
     const bool materialises = MODE == MODE_FW || MODE == MODE_CANON;
     const bool two_arrays = materialises && stride1 && a.out_a && !a.tuples;
     const bool one_word_pair = two_arrays && n_words == 1 && (a.out_b || a.out_starts);
     const void *const second = a.out_b ? (const void *)a.out_b : (const void *)a.out_starts;
     const size_t bytes_a = (size_t)a.n_kmers * 8u * (size_t)n_words;
     const size_t bytes_b = (size_t)a.n_kmers * (MODE == MODE_CANON || !a.out_b ? 8u : 8u * (size_t)n_words);
-    // Blocks of the class pool (pool_api.hip) are assembled so that the arrays of a launch lie in different region classes at every
-    // relative position, and a lone output's second half in another class than its first: the same two questions the arena's map
-    // answers for its blocks.
     constexpr float PLACED = 0.9f;
     const bool pool_pair = materialises && a.out_a && second && pool_arrays_differ(ctx, a.out_a, bytes_a, second, bytes_b) >= PLACED;
-    const bool in_arena = ctx->shared_arena != nullptr;
-    const bool spread = one_word_pair && (pool_pair || kmers_arena_spread(ctx->arena(), a.out_a, second, (size_t)a.n_kmers * 8u));
-    const bool fwrc_wide = two_arrays && MODE == MODE_FW && n_words >= 2 && a.out_b &&
-                           (pool_pair || kmers_arena_spread(ctx->arena(), a.out_a, a.out_b, bytes_a));
+    const bool spread = one_word_pair && pool_pair;
+    const bool fwrc_wide = two_arrays && MODE == MODE_FW && n_words >= 2 && a.out_b && pool_pair;
     const bool canon_wide = two_arrays && MODE == MODE_CANON && n_words >= 2 && a.out_b;
-    const bool canon2_spread = canon_wide && n_words == 2 &&
-                               (pool_pair || kmers_arena_spread(ctx->arena(), a.out_a, (size_t)a.n_kmers * 16u, a.out_b, (size_t)a.n_kmers * 8u));
+    const bool canon2_spread = canon_wide && n_words == 2 && pool_pair;
     const uint32_t lone_bytes = a.tuples ? (MODE == MODE_FW ? 16u * n_words : 8u * n_words + 8u) : 8u * n_words;
-    // ONE output array whose two halves lie in different classes (across a class boundary of the arena, or a block of the pool
-    // made that way by role) is written through two windows half an array apart
+    // ONE output array whose two halves lie in different classes (a block of the pool made that way by role) is written through
+    // two windows half an array apart
     const bool lone_output = materialises && a.out_a && !a.out_b && !a.out_starts && ctx->split_order >= 0;
-    const bool lone_pool = lone_output && pool_halves_differ(ctx, a.out_a, (size_t)a.n_kmers * lone_bytes) >= 0.75f;  // (whole handles: short arrays cannot do better)
-    bool lone = lone_pool || (lone_output && kmers_arena_straddles(ctx->arena(), a.out_a, (size_t)a.n_kmers * lone_bytes));  // (the calibration below may overrule it)
+    const bool lone = lone_output && pool_halves_differ(ctx, a.out_a, (size_t)a.n_kmers * lone_bytes) >= 0.75f;  // (whole handles: short arrays cannot do better)
     uint32_t threads = ctx->block_threads > 0 ? (uint32_t)ctx->block_threads
                                               : ((spread || canon_wide || (lone && !a.tuples && J == 1)) ? 128u : (uint32_t)BLOCK);
     if (threads != 64u && threads != 128u) threads = (uint32_t)BLOCK;
@@ -150,86 +145,8 @@ int launch_stream(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, int
         else if (lone && a.tuples) tile *= 6u;
         else if (lone && J > 1) tile = tile * 5u / 2u;  // (clamped to what the LDS stream holds below: 5120 kmers at J = 3)
     }
-    // The table is what rounds 3-4 measured on a handful of boxes; the region map of an arena can be finer than an array (runs of one
-    // 4 GiB granule), and there the table's shape lost 13 % to the base rule (headline 0.70 instead of 0.80, profiles/r04_shape.md).
-    // So the first large SYNCHRONOUS launch into arrays of the ARENA for which the table departs from the rule times both and
-    // remembers -- per launch configuration and placement, not per pointer (context.hpp, shape_choice).  Blocks of the pool are
-    // placed well by construction and are never timed; nothing is ever timed inside a KMERS_ASYNC call.
-    const bool arena_placed = in_arena && !pool_pair && !lone_pool && (spread || fwrc_wide || canon_wide || lone);
-    if (arena_placed && ctx->tile_kmers <= 0 && ctx->block_threads <= 0 && ctx->shape_calibrate > 0 && !ctx->calibrating &&
-        (uint64_t)a.n_kmers * out_bytes >= ((uint64_t)1 << 30)) {
-        const kmers_arena &ar = ctx->arena();
-        auto run_at = [&](const void *q) -> uint64_t {
-            const char *c = static_cast<const char *>(q);
-            if (!q || ar.run_start.empty() || c < ar.base || c >= ar.base + ar.bytes) return 0xffu;
-            return (uint64_t)kmers_arena_run_of(ar, (size_t)(c - ar.base)) & 0xffu;
-        };
-        uint64_t bucket = 0;  // log2 of the bytes written
-        for (uint64_t v = (uint64_t)a.n_kmers * out_bytes; v > 1; v >>= 1) ++bucket;
-        const uint64_t key = (uint64_t)MODE | (uint64_t)n_words << 4 | (uint64_t)(a.tuples ? 1 : 0) << 8 | (uint64_t)(a.out_b ? 1 : 0) << 9 |
-                             (uint64_t)(a.out_starts ? 1 : 0) << 10 | (uint64_t)(src_bits & 15) << 11 | (uint64_t)(dst_bits & 15) << 15 |
-                             (uint64_t)std::min<uint32_t>(J, 255u) << 19 | bucket << 27 | run_at(a.out_a) << 35 | run_at(second) << 43;
-        const kmers_ctx::shape_choice *hit = nullptr;
-        for (const auto &c : ctx->shape_cache)
-            if (c.key == key) hit = &c;
-        if (!hit && !(ctx->call_flags & KMERS_ASYNC)) {
-            const uint32_t rule_pass = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * (uint32_t)BLOCK;
-            const int cand[2][2] = {{(int)threads, (int)std::max<uint32_t>(pass, tile / pass * pass)},
-                                    {BLOCK, (int)default_tile(out_bytes, rule_pass)}};
-            // Timed fairly: the first launches of a process find the device's clocks idle, so both shapes run once untimed and are
-            // then timed ALTERNATELY, A B | B A | A B, each launch between its own pair of events; the better of three counts.
-            // The table is what several boxes measured: the rule has to beat it by 3 % to overrule it.
-            float ms[2] = {1e30f, 1e30f};
-            for (auto &e : ctx->cal_events)
-                if (!e) HIP_TRY(ctx, hipEventCreate(&e));
-            ctx->calibrating = true;
-            ++ctx->calibrations;
-            int rc = KMERS_OK;
-            const int64_t split_saved = ctx->split_order;
-            static const int order[8] = {0, 1, 0, 1, 1, 0, 0, 1};  // (the first two: warm-up)
-            for (int i = 0; i < 8 && rc == KMERS_OK; ++i) {
-                const int c = order[i];
-                ctx->block_threads = cand[c][0];
-                ctx->tile_kmers = cand[c][1];
-                ctx->split_order = (c == 1 && lone) ? -1 : split_saved;  // (the base rule writes a lone output through ONE window)
-                if (i >= 2 && hipEventRecord(ctx->cal_events[0], ctx->stream) != hipSuccess) rc = KMERS_E_HIP;
-                StreamArgs copy = a;
-                if (rc == KMERS_OK) rc = launch_stream<MODE>(ctx, copy, src_bits, dst_bits, n_words, vec_ok, dyn_lds);
-                if (i >= 2 && rc == KMERS_OK) {
-                    float t = 0.f;
-                    if (hipEventRecord(ctx->cal_events[1], ctx->stream) != hipSuccess || hipEventSynchronize(ctx->cal_events[1]) != hipSuccess ||
-                        hipEventElapsedTime(&t, ctx->cal_events[0], ctx->cal_events[1]) != hipSuccess)
-                        rc = KMERS_E_HIP;
-                    else if (t < ms[c]) ms[c] = t;
-                }
-            }
-            ctx->block_threads = 0;
-            ctx->tile_kmers = 0;
-            ctx->split_order = split_saved;
-            ctx->calibrating = false;
-            if (rc != KMERS_OK) return rc == KMERS_E_HIP ? fail(ctx, KMERS_E_HIP, "launch-shape calibration") : rc;
-            const int best = ms[1] < 0.97f * ms[0] ? 1 : 0;
-            if (ctx->shape_cache.size() >= 64) ctx->shape_cache.erase(ctx->shape_cache.begin());
-            ctx->shape_cache.push_back({key, cand[best][0], cand[best][1], best == 1, ms[0], ms[1]});
-            hit = &ctx->shape_cache.back();
-        }
-        if (hit) {
-            threads = (uint32_t)hit->threads;
-            tile = (uint32_t)hit->tile;
-            if (hit->rule) lone = false;  // (one write window)
-            ctx->last_cal_table_ms = hit->table_ms;
-            ctx->last_cal_rule_ms = hit->rule_ms;
-            ctx->last_cal_rule = hit->rule ? 1 : 0;
-        } else {
-            ctx->last_cal_table_ms = ctx->last_cal_rule_ms = 0.f;
-            ctx->last_cal_rule = 0;
-        }
-    } else if (!ctx->calibrating) {
-        ctx->last_cal_table_ms = ctx->last_cal_rule_ms = 0.f;
-        ctx->last_cal_rule = 0;
-    }
     // (strided launches in ONE class: round 2's 32 KiB tile lost to 16 KiB on every box of round 3, 0.70-0.74 against 0.73-0.76)
-    const uint32_t pass_now = ((stride1 || pair) && n_words == 1 ? 2u : 1u) * threads;  // (the cache may have changed `threads`)
+    const uint32_t pass_now = pass;
     tile = std::min<uint32_t>(tile, max_tile_symbols / J);
     tile = std::max<uint32_t>(pass_now, tile / pass_now * pass_now);
     if ((uint64_t)(tile - 1) * J + 1 > (uint64_t)max_tile_symbols) return fail(ctx, KMERS_E_UNSUPPORTED, "stride too large for the tile kernel");

@@ -270,11 +270,11 @@ int launch_wide_tile(kmers_ctx *ctx, StreamArgs &a, int src_bits, int dst_bits, 
         cw_pitch = word_pitch;
         dyn += (size_t)tile * word_pitch * 8u;
     }
-    // ONE output array (FwKmers, SpacedKmers; CanonicalKmers, whose hashes are a small second stream) that lies across a class
-    // boundary of the arena (kmers_dev_alloc_role): two write windows, like the stream kernels' lone outputs
+    // ONE output array (FwKmers, SpacedKmers; CanonicalKmers, whose hashes are a small second stream) whose halves lie in two region
+    // classes (a block of the pool taken by role, kmers_dev_alloc_role): two write windows, like the stream kernels' lone outputs
     const size_t element_bytes = (size_t)8 * (a.tuples ? (WMODE == WMODE_FW ? 2u * n_words : n_words + 1u) : n_words);
     const bool lone = streams && ctx->max_grid <= 0 && ctx->split_order >= 0 && a.out_a && (WMODE == WMODE_CANON || !a.out_b) &&
-                      kmers_arena_straddles(ctx->arena(), a.out_a, (size_t)a.n_kmers * element_bytes);
+                      pool_halves_differ(ctx, a.out_a, (size_t)a.n_kmers * element_bytes) >= 0.75f;
     a.split_order = (lone || (streams && ctx->max_grid <= 0 && ctx->split_order > 0)) && n_tiles >= 2 ? 1u : 0u;
     const uint64_t slots = a.split_order ? 2u * ((n_tiles + 1u) / 2u) : n_tiles;
     const uint64_t resident = ctx->max_grid > 0 ? (uint64_t)ctx->max_grid : (streams ? slots : (uint64_t)ctx->n_cus * 8u);

@@ -146,46 +146,13 @@ class Context:
         if ptr and self.handle:
             self.lib.kmers_dev_free(self.handle, C.c_void_p(ptr))
 
-    # the context's arena (include/kmers_hip.h): one large block, sub-allocated by alloc()
-    def arena_reserve(self, nbytes=0):
-        self.check(self.lib.kmers_arena_reserve(self.handle, nbytes), "kmers_arena_reserve")
-        return self.arena_info()[0]
-
-    def arena_release(self):
-        self.check(self.lib.kmers_arena_release(self.handle), "kmers_arena_release")
-
-    def arena_info(self):
-        r, u, f = C.c_size_t(), C.c_size_t(), C.c_size_t()
-        self.check(self.lib.kmers_arena_info(self.handle, C.byref(r), C.byref(u), C.byref(f)), "kmers_arena_info")
-        return r.value, u.value, f.value
-
     def last_launch_shape(self):
         """(threads per workgroup, kmers per tile, two write windows) of the most recent tile-kernel launch (kmers_last_launch_shape)."""
         t, k, sp = C.c_int(), C.c_int(), C.c_int()
         self.check(self.lib.kmers_last_launch_shape(self.handle, C.byref(t), C.byref(k), C.byref(sp)), "kmers_last_launch_shape")
         return t.value, k.value, sp.value
 
-    def last_shape_calibration(self):
-        """(table ms, rule ms, rule chosen) behind the shape of the most recent tile-kernel launch; zeros if no calibration applied
-        (kmers_last_shape_calibration)."""
-        t, r, c = C.c_double(), C.c_double(), C.c_int()
-        self.check(self.lib.kmers_last_shape_calibration(self.handle, C.byref(t), C.byref(r), C.byref(c)), "kmers_last_shape_calibration")
-        return t.value, r.value, bool(c.value)
-
-    def arena_rates(self):
-        """(best pair of places, one region class): GB/s of two store streams side by side as kmers_arena_reserve measured them."""
-        b, o = C.c_double(), C.c_double()
-        self.check(self.lib.kmers_arena_rates(self.handle, C.byref(b), C.byref(o)), "kmers_arena_rates")
-        return b.value, o.value
-
-    def arena_regions(self):
-        """(base address, granule bytes, [class of every granule]) of the arena's measured region map; granule 0 without one."""
-        g, n, base = C.c_size_t(), C.c_size_t(), C.c_void_p()
-        buf = (C.c_ubyte * 1024)()
-        self.check(self.lib.kmers_arena_regions(self.handle, C.byref(base), C.byref(g), buf, 1024, C.byref(n)), "kmers_arena_regions")
-        return base.value or 0, g.value, list(buf[:min(n.value, 1024)]) if g.value else []
-
-    # the device's class pool (include/kmers_hip.h): where alloc() of 1 GiB or more comes from when no arena is attached
+    # the device's class pool (include/kmers_hip.h): where alloc() of 128 MiB or more comes from
     def pool_info(self):
         """dict(held, in_use, n_classes, class_bytes, two_class_gbps, one_class_gbps) of the device's class pool (kmers_pool_info)."""
         h, u, n = C.c_size_t(), C.c_size_t(), C.c_int()
@@ -193,6 +160,15 @@ class Context:
         two, one = C.c_double(), C.c_double()
         self.check(self.lib.kmers_pool_info(self.handle, C.byref(h), C.byref(u), C.byref(n), cb, C.byref(two), C.byref(one)), "kmers_pool_info")
         return {"held": h.value, "in_use": u.value, "n_classes": n.value, "class_bytes": list(cb), "two_class_gbps": two.value, "one_class_gbps": one.value}
+
+    POOL_STAT_NAMES = ("held", "in_use", "cached", "free", "cache_hits", "cache_misses", "evictions", "chunks_created", "chunks_returned",
+                       "probes", "cached_blocks", "blocks_out")
+
+    def pool_stats(self):
+        """The pool's counters by name (kmers_pool_stats)."""
+        v = (C.c_uint64 * _capi.POOL_STATS)()
+        self.check(self.lib.kmers_pool_stats(self.handle, v, _capi.POOL_STATS), "kmers_pool_stats")
+        return dict(zip(self.POOL_STAT_NAMES, list(v)))
 
     def pool_trim(self):
         r = C.c_size_t()
@@ -213,10 +189,11 @@ class Context:
         self.check(self.lib.kmers_pool_selftest(self.handle, C.byref(st)), "kmers_pool_selftest")
         return bool(st.value)
 
-    def shape_calibrations(self):
-        n = C.c_uint64()
-        self.check(self.lib.kmers_shape_calibrations(self.handle, C.byref(n)), "kmers_shape_calibrations")
-        return n.value
+    def placement_probe(self, ptr_a, ptr_b, nbytes):
+        """GB/s of two store streams side by side into two (still empty) device buffers; DESTRUCTIVE (kmers_placement_probe)."""
+        g = C.c_double()
+        self.check(self.lib.kmers_placement_probe(self.handle, C.c_void_p(ptr_a), C.c_void_p(ptr_b), nbytes, C.byref(g)), "kmers_placement_probe")
+        return g.value
 
     def last_batch_pieces(self):
         """Pieces the most recent kmers_minhash_batch brought its pool up in (kmers_last_batch_pieces)."""
@@ -224,11 +201,15 @@ class Context:
         self.check(self.lib.kmers_last_batch_pieces(self.handle, C.byref(n)), "kmers_last_batch_pieces")
         return n.value
 
-    def placement_probe(self, ptr_a, ptr_b, nbytes):
-        """GB/s of two store streams side by side into two (still empty) device buffers; DESTRUCTIVE (kmers_placement_probe)."""
-        g = C.c_double()
-        self.check(self.lib.kmers_placement_probe(self.handle, C.c_void_p(ptr_a), C.c_void_p(ptr_b), nbytes, C.byref(g)), "kmers_placement_probe")
-        return g.value
+    def host_alloc(self, nbytes):
+        """Page-locked host memory (kmers_host_alloc): what an enqueued copy needs in order not to block its caller."""
+        p = C.c_void_p()
+        self.check(self.lib.kmers_host_alloc(self.handle, nbytes, C.byref(p)), "kmers_host_alloc")
+        return p.value
+
+    def host_free(self, ptr):
+        if ptr and self.handle:
+            self.lib.kmers_host_free(self.handle, C.c_void_p(ptr))
 
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)
@@ -584,21 +565,49 @@ class AbstractKmerIterator(metaclass=_Parametric):
         return self._wrap(out)
 
     def __iter__(self):
-        """Chunk-buffered iteration with the reference's throw point: elements whose windows end
-        before the first ambiguous symbol are yielded, then EncodeError is raised."""
-        total, done = len(self), 0
-        while done < total:
-            n = min(self.CHUNK, total - done)
-            out, res = self._range(done, n)
-            if res.status == _capi.E_ENCODE:
-                bad0 = int(res.err_pos) - 1  # 0-based symbol index
-                good = self._yielded_before(bad0) - done
-                if good > 0:
-                    out, _ = self._range(done, good)
-                    yield from self._elements(self._wrap(out))
-                _raise_encode(self.alphabet, self.seq, res)
-            yield from self._elements(self._wrap(out))
-            done += n
+        """Chunk-buffered iteration with the reference's throw point: elements whose windows end before the first ambiguous
+        symbol are yielded, then EncodeError is raised.  Chunk c + 1 is launched (KMERS_ASYNC) and its copy into page-locked
+        memory enqueued BEFORE the loop is handed chunk c; kmers_sync is called when chunk c is used up (_ChunkPipe: the pipeline
+        julia/KmersHIP.jl's GPUIterator runs)."""
+        total = self._units()
+        if total == 0:
+            return
+        pipe = _ChunkPipe(self, min(self.CHUNK, total))
+        try:
+            u0, m = 0, min(self.CHUNK, total)
+            pipe.enqueue(0, u0, m)
+            slot = 0
+            while m:
+                rc, res = self.ctx.sync()                      # the chunk in flight, and only it
+                if rc == _capi.E_ENCODE:
+                    good = self._yielded_before(int(res.err_pos) - 1) - u0
+                    if good > 0:
+                        out, _ = self._range(u0, good)
+                        yield from self._elements(self._wrap(out))
+                    _raise_encode(self.alphabet, self.seq, res)
+                self.ctx.check(rc, type(self).__name__)
+                out = pipe.take(slot, int(res.n_out) if self._counted_by_sync and self.seq.src_bits != 2 else m)   # (a 2-bit source drops nothing)
+                u1 = u0 + m
+                m = min(self.CHUNK, total - u1)
+                u0, slot = u1, 1 - slot
+                if m:
+                    pipe.enqueue(slot, u0, m)                  # on its way while the caller loops over `out`
+                yield from self._elements(self._wrap(out))
+        finally:
+            pipe.close()
+
+    _counted_by_sync = False   # UnambiguousKmers: the number of elements of a chunk is known when it has run
+
+    def _units(self):
+        """what a chunk is counted in: elements (UnambiguousKmers: candidate windows)"""
+        return len(self)
+
+    def _widths(self):
+        """words per element of each output array of a chunk"""
+        return [self.N]
+
+    def _enqueue(self, view, n, ptrs, res):
+        raise NotImplementedError
 
     def _yielded_before(self, bad0):
         """Number of elements iterate() yields before it touches symbol bad0 (0-based)."""
@@ -619,11 +628,49 @@ class AbstractKmerIterator(metaclass=_Parametric):
         return ptr
 
 
+class _ChunkPipe:
+    """The buffers of a chunk-buffered iteration: per output array two chunks in HBM and two in page-locked host memory, taking
+    turns.  enqueue() launches units [u0, u0 + n) into one slot and enqueues the copies of its arrays; nothing waits."""
+
+    def __init__(self, it, cap):
+        self.it, self.ctx, self.cap = it, it.ctx, cap
+        self.widths = it._widths()
+        self.dev = [[self.ctx.alloc(max(8, cap * w * 8), lone_output=len(self.widths) == 1) for w in self.widths] for _ in range(2)]
+        self.host = [[self.ctx.host_alloc(max(8, cap * w * 8)) for w in self.widths] for _ in range(2)]
+        self.res = _capi.Result()
+
+    def enqueue(self, slot, u0, n):
+        it = self.it
+        view = it._view(u0 * it.J, (n - 1) * it.J + it.K)
+        rc = it._enqueue(view, n, self.dev[slot], self.res)
+        self.ctx.check(rc, type(it).__name__)
+        for d, h, w in zip(self.dev[slot], self.host[slot], self.widths):
+            self.ctx.check(self.ctx.lib.kmers_memcpy_d2h_async(self.ctx.handle, C.c_void_p(h), C.c_void_p(d), n * w * 8), "kmers_memcpy_d2h_async")
+
+    def take(self, slot, n):
+        """the first n elements of the slot's arrays, copied out of the page-locked buffers (which the chunk after next overwrites)"""
+        outs = []
+        for h, w in zip(self.host[slot], self.widths):
+            a = np.ctypeslib.as_array(C.cast(C.c_void_p(h), C.POINTER(C.c_uint64)), shape=(max(1, self.cap * w),))
+            outs.append(a[:n * w].reshape(n, w).copy())
+        return outs
+
+    def close(self):
+        self.ctx.sync()
+        for slot in self.dev:
+            for p in slot:
+                self.ctx.free(p)
+        for slot in self.host:
+            for p in slot:
+                self.ctx.host_free(p)
+        self.dev, self.host = [], []
+
+
 def _call_with_device_outputs(it, n, widths, call):
     """Allocate device outputs, run `call(ptrs)`, copy back; returns (host arrays, Result)."""
     ctx = it.ctx
-    # the ONLY output array of a launch is allocated by that role (kmers_dev_alloc_role: with an arena reserved it lies across a
-    # class boundary of HBM and the launch writes it through two windows, DESIGN.md section 3.8)
+    # the ONLY output array of a launch is allocated by that role (kmers_dev_alloc_role: its second half in another region class
+    # of HBM than its first, and the launch writes it through two windows, DESIGN.md section 2)
     ptrs = [ctx.alloc(max(8, n * w * 8), lone_output=len(widths) == 1) for w in widths]
     res = _capi.Result()
     try:
@@ -660,6 +707,10 @@ class FwKmers(AbstractKmerIterator):
     def _wrap(self, out):
         return KmerArray(self.alphabet, self.K, out[0])
 
+    def _enqueue(self, view, n, ptrs, res):
+        return self.ctx.lib.kmers_fw(self.ctx.handle, C.byref(view), self.K, self.alphabet.bits, ptrs[0], None,
+                                     _capi.MEM_DEVICE | _capi.ASYNC, C.byref(res))
+
 
 class FwRvIterator(AbstractKmerIterator):
     """FwRvIterator{A,K}(seq): (forward, reverse_complement) pairs (CanonicalKmers.jl:25-144)."""
@@ -682,6 +733,13 @@ class FwRvIterator(AbstractKmerIterator):
 
     def _elements(self, wrapped):
         return zip(iter(wrapped[0]), iter(wrapped[1]))
+
+    def _widths(self):
+        return [self.N, self.N]
+
+    def _enqueue(self, view, n, ptrs, res):
+        return self.ctx.lib.kmers_fw(self.ctx.handle, C.byref(view), self.K, self.alphabet.bits, ptrs[0], ptrs[1],
+                                     _capi.MEM_DEVICE | _capi.ASYNC, C.byref(res))
 
     def collect(self):
         fw, rv = super().collect()
@@ -706,6 +764,10 @@ class CanonicalKmers(AbstractKmerIterator):
 
     def _wrap(self, out):
         return KmerArray(self.alphabet, self.K, out[0])
+
+    def _enqueue(self, view, n, ptrs, res):
+        return self.ctx.lib.kmers_canonical(self.ctx.handle, C.byref(view), self.K, self.alphabet.bits, ptrs[0], None, 0,
+                                            _capi.MEM_DEVICE | _capi.ASYNC, C.byref(res))
 
     def collect_with_hashes(self, seed=0):
         """collect(it) together with fx_hash.(kmers, seed) from the same pass (one fused kernel)."""
@@ -747,6 +809,10 @@ class SpacedKmers(AbstractKmerIterator):
 
     def _wrap(self, out):
         return KmerArray(self.alphabet, self.K, out[0])
+
+    def _enqueue(self, view, n, ptrs, res):
+        return self.ctx.lib.kmers_spaced(self.ctx.handle, C.byref(view), self.K, self.J, self.alphabet.bits, ptrs[0],
+                                         _capi.MEM_DEVICE | _capi.ASYNC, C.byref(res))
 
 
 class UnambiguousKmers(AbstractKmerIterator):
@@ -792,8 +858,40 @@ class UnambiguousKmers(AbstractKmerIterator):
                 ctx.free(ps)
         return list(zip(KmerArray(self.alphabet, self.K, km), st.tolist()))
 
+    # chunk-buffered `for (kmer, start) in it` (UnambiguousKmers.jl:59-62): chunks of candidate windows, the number kept known at
+    # the chunk's kmers_sync; starts are those of the whole sequence (the chunk view's index_origin)
+    _counted_by_sync = True
+
+    def _units(self):
+        return max(0, self.seq.len - self.K + 1)
+
+    def _widths(self):
+        return [self.N, 1]
+
+    def _enqueue(self, view, n, ptrs, res):
+        return self.ctx.lib.kmers_unambiguous(self.ctx.handle, C.byref(view), self.K, 1, ptrs[0], ptrs[1], n,
+                                              _capi.MEM_DEVICE | _capi.ASYNC, C.byref(res))
+
+    def _range(self, start, n):
+        """the kept windows among candidate starts [start, start + n), computed now (the clean prefix before an EncodeError)"""
+        lib, ctx = self.ctx.lib, self.ctx
+        view = self._view(start, n + self.K - 1)
+        out, res = _call_with_device_outputs(
+            self, n, [self.N, 1],
+            lambda ptrs, r: lib.kmers_unambiguous(ctx.handle, C.byref(view), self.K, 1, ptrs[0], ptrs[1], n, _capi.MEM_DEVICE, C.byref(r)))
+        kept = int(res.n_out) if res.status == _capi.OK else 0
+        return [out[0][:kept], out[1][:kept]], res
+
+    def _wrap(self, out):
+        return (KmerArray(self.alphabet, self.K, out[0]), out[1].reshape(-1).astype(np.int64))
+
+    def _elements(self, wrapped):
+        return zip(iter(wrapped[0]), wrapped[1].tolist())
+
     def __iter__(self):
-        return iter(self.collect())
+        if self.lattice != 1:   # (the lattice variant of BASELINE config 5 is not an iterator of the reference)
+            return iter(self.collect())
+        return AbstractKmerIterator.__iter__(self)
 
 
 def _alias(cls, fam):

@@ -205,6 +205,72 @@ int main() {
         REQUIRE(partner_block(s, 100 * G, &other)->serial == 3);   // nothing comparable: the most recent
         REQUIRE(block_of(s, base, 1) && !block_of(s, base + 8 * CHUNK_BYTES, 1) && !block_of(s, base - 1, 1));
     }
+    // the cache of freed blocks and the bound on the hoard (round 6): a collect loop re-uses its blocks, a request beside a new
+    // partner takes the cached block that suits it, nothing else does
+    {
+        State s;
+        char *base = reinterpret_cast<char *>((size_t)1 << 40);
+        auto make = [&](std::vector<uint8_t> classes, size_t req, int role, float quality) {
+            Block b = block_of_classes(classes, req);
+            b.role = role;
+            b.quality = quality;
+            b.serial = ++s.serial;
+            return b;
+        };
+        const size_t bytes = 8 * G - 12345;
+        size_t off = 0, pb = 0;
+        REQUIRE(block_chunks(bytes, ROLE_DEFAULT, &off, &pb) == 8 && off == 0 && pb == bytes);
+        REQUIRE(block_chunks(10 * G - 7 * (G / 10), ROLE_LONE_OUTPUT, &off, &pb) == 10 && pb == 10 * G && off > 0 && off < G);
+        REQUIRE(block_chunks(G / 2, ROLE_LONE_OUTPUT, &off, &pb) == 1 && off == 0);
+        // two arrays out, both freed: k (class 0) then h (class 1)
+        s.blocks[base] = make(runs({{0, 8}}), bytes, ROLE_DEFAULT, 1.f);
+        s.blocks[base + 16 * G] = make(runs({{1, 8}}), bytes, ROLE_DEFAULT, 1.f);
+        s.in_use_bytes = 16 * G;
+        for (char *p : {base, base + 16 * G}) {
+            ++s.tick;
+            auto it = s.blocks.find(p);
+            Block b = std::move(it->second);
+            s.blocks.erase(it);
+            to_cache(s, p, std::move(b));
+        }
+        REQUIRE(s.in_use_bytes == 0 && s.cached_bytes == 16 * G && s.cached.size() == 2);
+        // the next k: no partner, the most recently freed block of its shape
+        auto hit = find_cached(s, bytes, ROLE_DEFAULT, nullptr);
+        REQUIRE(hit != s.cached.end() && hit->first == base + 16 * G);
+        REQUIRE(find_cached(s, 4 * G, ROLE_DEFAULT, nullptr) == s.cached.end());        // another number of chunks
+        REQUIRE(find_cached(s, bytes, ROLE_LONE_OUTPUT, nullptr) == s.cached.end());    // another role
+        const char *hit_base = hit->first;  // (the iterator dies with the cache entry)
+        s.blocks[hit_base] = from_cache(s, hit);
+        REQUIRE(s.in_use_bytes == 8 * G && s.cached_bytes == 8 * G);
+        // the next h beside it: the cached block of the OTHER class
+        const Block *partner = partner_block(s, bytes, nullptr);
+        REQUIRE(partner && partner->classes[0] == 1);
+        hit = find_cached(s, bytes, ROLE_DEFAULT, partner);
+        REQUIRE(hit != s.cached.end() && hit->first == base && hit->second.classes[0] == 0);
+        // a cached block in the partner's own class does not qualify ... unless the plan it was assembled by was no better
+        s.cached[base + 32 * G] = make(runs({{1, 8}}), bytes, ROLE_DEFAULT, 1.f);
+        s.cached_bytes += 8 * G;
+        s.cached.erase(base);
+        s.cached_bytes -= 8 * G;
+        REQUIRE(find_cached(s, bytes, ROLE_DEFAULT, partner) == s.cached.end());
+        s.cached[base + 32 * G].quality = 0.f;
+        REQUIRE(find_cached(s, bytes, ROLE_DEFAULT, partner) != s.cached.end());
+        // the hoard: free chunks + yardsticks beyond max(4 chunks, a quarter of the blocks) go back
+        State h;
+        h.n_classes = 3;
+        for (uint32_t i = 0; i < 40; ++i) {
+            Chunk c;
+            c.cls = (uint8_t)(i % 3);
+            h.chunks.push_back(c);
+            h.free_list[c.cls].push_back(i);
+        }
+        REQUIRE(hoard_excess(h) == 43 - 4);
+        h.in_use_bytes = 16 * G;
+        h.cached_bytes = 16 * G;
+        REQUIRE(hoard_excess(h) == 43 - 8);
+        h.in_use_bytes = 400 * G;
+        REQUIRE(hoard_excess(h) == 0);
+    }
     std::puts("class_pool_check: ok");
     return 0;
 }

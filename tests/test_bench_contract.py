@@ -100,7 +100,7 @@ def test_multi_gpu_line_schema():
     s_per_rank = [[0.061, 2.925, 0.011, float(1_250_000_000 - (0 if r < 7 else K - 1))] for r in range(world)]
     strong = bench.strong_scaling_entry(args, K, bits, world, bench.NORTH_STAR_BASES, s_per_rank, 16.5, True, [0.470, 23.4])
     line = bench.assemble_line(args, K, bits, world, False, True, "nccl", "native", L * world, [L] * world, bench.GOLDEN ^ 2, elapsed, per_rank, 16.5,
-                               True, True, 230.0, "4 GiB granules: A8 B8", (7100.0, "kmers_arena_rates"), None, None, 5000.0, strong)
+                               True, True, (7100.0, "kmers_pool_info"), None, None, 5000.0, strong)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "verified", "strong_scaling"):
         assert key in line, key

@@ -96,23 +96,12 @@ def test_header_is_plain_c_and_example_links(km, tmp_path):
             assert out.returncode == 2 and "no usable HIP device" in out.stderr  # fails loudly, no fallback
 
 
-def test_arena_placement_logic_on_the_cpu(tmp_path):
-    """csrc/arena_placement.hpp -- the allocator of the context's arena and its placement policy, pure host code -- on made-up
-    region maps, under AddressSanitizer + UBSan: best fit and merging, the outputs of a launch in different classes, the sequence
-    in a third one, blocks longer than a run, kmers_arena_spread, and the allocator's invariants under 20 000 random requests."""
-    import subprocess
-    exe = tmp_path / "arena_placement_check"
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                    "-o", str(exe), os.path.join(ROOT, "tests", "c", "arena_placement_check.cpp")], check=True)
-    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "arena placement ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
-
-
 def test_class_pool_logic_on_the_cpu(tmp_path):
     """csrc/class_pool.hpp -- which region classes the chunks of a new block of the device's pool get, pure host code -- under
     AddressSanitizer + UBSan: blocks as pure as the stock allows, the second array of a launch in another class than the first at
     every relative position (an exact small transport problem, not a greedy walk), a lone output's halves in different classes,
-    the questions the launchers ask about arrays inside blocks, the books under take / give, 3000 random stocks and partners."""
+    the questions the launchers ask about arrays inside blocks, the books under take / give, 3000 random stocks and partners; the
+    cache of freed blocks (which cached block a request takes) and the bound on what the pool holds outside blocks."""
     import subprocess
     exe = tmp_path / "class_pool_check"
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",

@@ -15,7 +15,7 @@ import pytest
 import naive
 
 pytestmark = pytest.mark.gpu
-# torch FIRST (tests/test_gpu_arena.py says why): test_unambiguous_geometries keeps its arrays in torch tensors
+# torch FIRST (tests/test_gpu_pool.py says why): test_unambiguous_geometries keeps its arrays in torch tensors
 torch = pytest.importorskip("torch")
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmers.jl_amd", "csrc")

@@ -278,6 +278,71 @@ def test_big_chunked_iteration_matches_collect(km, orc):
     assert np.array_equal(hs, eh) and km_h == whole
 
 
+def test_pipelined_iteration_of_all_five_iterators(km, orc):
+    """`for x in it` for FwKmers, FwRvIterator, CanonicalKmers, SpacedKmers and UnambiguousKmers over several chunks: chunk c + 1 is
+    launched and its copy enqueued before the loop gets chunk c (host._ChunkPipe, the pipeline of julia/KmersHIP.jl's GPUIterator;
+    src/iterators/FwKmers.jl:57-66, CanonicalKmers.jl:54-66, SpacedKmers.jl:121-139, UnambiguousKmers.jl:59-62).  Every element
+    against the oracle, chunk sizes that divide the iteration and that do not, a loop left early, an EncodeError in the third
+    chunk (the elements before it are yielded, then it is thrown), UnambiguousKmers' global starts across chunks."""
+    L = 150_003
+    words = orc.synth_words(9, 0, (L * 4 + 63) // 64, 4)
+    seq = km.LongSequence(km.DNAAlphabet[4], words, L)
+    rows = lambda a: [tuple(int(x) for x in r) for r in a]
+    for chunk in (1 << 14, 50_000, 1 << 20):
+        it = km.FwDNAMers[33](seq)
+        it.CHUNK = chunk
+        assert [k.data for k in it] == rows(orc.fw_kmers(words, L, 4, 2, 33)[0])
+        it = km.FwRvDNAIterator[21](seq)
+        it.CHUNK = chunk
+        f, r, _ = orc.fwrv(words, L, 4, 2, 21)
+        assert [(a.data, b.data) for a, b in it] == list(zip(rows(f), rows(r)))
+        it = km.CanonicalDNAMers[31](seq)
+        it.CHUNK = chunk
+        assert [k.data for k in it] == rows(orc.canonical(words, L, 4, 2, 31)[0])
+        it = km.SpacedDNAMers[21, 3](seq)
+        it.CHUNK = chunk
+        assert [k.data for k in it] == rows(orc.spaced(words, L, 4, 2, 21, 3)[0])
+    # a loop left early frees its buffers (the generator's finally) and the next loop starts over
+    it = km.CanonicalDNAMers[31](seq)
+    it.CHUNK = 1 << 14
+    before = it.ctx.pool_stats()["blocks_out"]
+    for i, _ in enumerate(it):
+        if i == 40_000:
+            break
+    del _
+    import gc
+    gc.collect()
+    assert it.ctx.pool_stats()["blocks_out"] == before
+    # UnambiguousKmers: ambiguity codes sprinkled in, chunks of candidate windows, starts of the WHOLE sequence
+    amb = orc.synth_words(11, 0, (L * 4 + 63) // 64, 4, ambig_per_65536=1500)
+    aseq = km.LongSequence(km.DNAAlphabet[4], amb, L)
+    ek, es, _ = orc.unambiguous(amb, L, 4, 25)
+    for chunk in (1 << 14, 61_000):
+        it = km.UnambiguousDNAMers[25](aseq)
+        it.CHUNK = chunk
+        got = list(it)
+        assert [k.data for k, _ in got] == rows(ek) and [int(i) for _, i in got] == [int(x) for x in es]
+    two = orc.synth_words(12, 0, (L * 2 + 63) // 64, 2)
+    it = km.UnambiguousDNAMers[25](km.LongSequence(km.DNAAlphabet[2], two, L))     # a 2-bit source: nothing dropped, HasLength
+    it.CHUNK = 1 << 15
+    got = list(it)
+    assert len(got) == L - 24 and [int(i) for _, i in got] == list(range(1, L - 23))
+    assert [k.data for k, _ in got[:1000]] == rows(orc.fw_kmers(two, L, 2, 2, 25)[0][:1000])
+    # an EncodeError in the third chunk: everything before it is yielded, then it is thrown at its position
+    bad = 2 * (1 << 14) + 5000                      # 0-based symbol index
+    poisoned = words.copy()
+    w, b = bad * 4 // 64, bad * 4 % 64
+    poisoned[w] = (int(poisoned[w]) & ~(0xF << b)) | (0xF << b)     # N
+    it = km.CanonicalDNAMers[31](km.LongSequence(km.DNAAlphabet[4], poisoned, L))
+    it.CHUNK = 1 << 14
+    got = []
+    with pytest.raises(km.EncodeError) as e:
+        for k in it:
+            got.append(k.data)
+    assert e.value.position == bad + 1
+    assert len(got) == bad - 31 + 1 and got == rows(orc.canonical(words, L, 4, 2, 31)[0][:len(got)])
+
+
 def test_fused_consumers(km, orc):
     """sketch(fx_hash, CanonicalDNAMers{16}(seq), 1000) (docs/src/minhash.md:34) and the composition
     recipe (docs/src/composition.md:28-39) through the mirror."""

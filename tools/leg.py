@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One leg of the hot path in ONE fresh process: the program every timing sweep and every `rocprofv3` pass of round 3 runs.
 
-    python3 tools/leg.py --leg c2|f1|c3|c4|c4t|c5|u31|u21|xor|minhash|comp8 [--alloc plain|carve:GB|prefree:GB|arena:GB] [--reps N]
+    python3 tools/leg.py --leg c2|f1|c3|c4|c4t|c5|u31|u21|xor|minhash|comp8 [--alloc pool|plain|carve:GB|prefree:GB] [--reps N]
                          [--busy-ms MS] [--tile T] [--once]
 
 legs (1 Gbase LongDNA{4} unless stated; algorithmic bytes per SURVEY.md section 8d):
@@ -13,8 +13,7 @@ alloc (where the output arrays come from -- profiles/r02_tuning.md section 7, pr
   plain       torch allocations (hipMalloc), first allocations of the process
   carve:GB    carved out of one torch allocation of GB gigabytes
   prefree:GB  GB gigabytes allocated and released first, then plain
-  arena:GB    kmers_arena_reserve(GB) + kmers_dev_alloc (the arena of rounds 3-4)
-  pool        kmers_dev_alloc without an arena: the device's class pool (round 5, the product's default)
+  pool        kmers_dev_alloc: the device's class pool (the product's default)
 --once: two launches and nothing else (the form the PMC passes profile).
 Prints one line: leg, alloc, median ms, fraction of 8 TB/s (materialising legs).
 """
@@ -30,13 +29,9 @@ import torch
 
 import kmers_jl_amd as km
 
-if os.environ.get("LEG_OLD_ABI"):  # A/B against a library of an earlier round (KMERS_HIP_LIB=tools/libkmers_r02.so): no arena, no sub-tiles
-    for name in [n for n in km._capi.SYMBOLS if "arena" in n]:
-        del km._capi.SYMBOLS[name]
-
 ap = argparse.ArgumentParser()
 ap.add_argument("--leg", default="c2")
-ap.add_argument("--alloc", default="plain")
+ap.add_argument("--alloc", default="pool")
 ap.add_argument("--reps", type=int, default=9)
 ap.add_argument("--busy-ms", type=float, default=300.0)
 ap.add_argument("--tile", type=int, default=0)
@@ -45,10 +40,7 @@ ap.add_argument("--subtiles", type=int, default=0)
 ap.add_argument("--threads", type=int, default=0, help="threads per workgroup of the tile kernels (KMERS_PARAM_BLOCK_THREADS)")
 ap.add_argument("--split", action="store_true", help="two write windows per array (KMERS_PARAM_SPLIT_ORDER)")
 ap.add_argument("--once", action="store_true")
-ap.add_argument("--no-calibrate", action="store_true", help="KMERS_PARAM_SHAPE_CALIBRATE = 0: the launcher trusts its table")
-ap.add_argument("--no-role", action="store_true", help="arena mode: a single output array is allocated like any other block (not by KMERS_ALLOC_LONE_OUTPUT)")
-ap.add_argument("--straddle-b", type=int, default=0, help="with --straddle: the second array centred on the n-th class boundary after the first")
-ap.add_argument("--straddle", action="store_true", help="arenacarve mode: the first array centred on the first class boundary of the arena's map")
+ap.add_argument("--no-role", action="store_true", help="pool mode: a single output array is allocated like any other block (not by KMERS_ALLOC_LONE_OUTPUT)")
 ap.add_argument("--shifts", default="", help="carve mode: comma-separated SA:SB byte shifts of the two output bases inside the block; one timing per pair, same process")
 ap.add_argument("--bases", type=int, default=1_000_000_000)
 args = ap.parse_args()
@@ -70,8 +62,6 @@ if args.threads:
     ctx.set_param(cap.PARAM_BLOCK_THREADS, args.threads)
 if args.split:
     ctx.set_param(cap.PARAM_SPLIT_ORDER, 1)
-if args.no_calibrate:
-    ctx.set_param(cap.PARAM_SHAPE_CALIBRATE, 0)
 
 leg = args.leg
 if leg == "n1":  # the north star: the C2 launch over 10 Gbase on one GPU
@@ -110,22 +100,6 @@ with torch.cuda.stream(stream):
         keep.append(block)
         pa = block.data_ptr()
         pb = pa + ((8 * words_a + (1 << 21) - 1) >> 21 << 21)
-    elif mode == "arenacarve":  # the arena's block and its measured map, but the two arrays at offsets given by --shifts
-        ctx.check(ctx.lib.kmers_arena_reserve(ctx.handle, size << 30), "kmers_arena_reserve")
-        abase, gran, classes = ctx.arena_regions()
-        print("arena map", "".join(chr(65 + c) for c in classes), flush=True)
-        pa = pb = abase
-        if args.straddle:
-            g = next(i for i in range(1, len(classes)) if classes[i] != classes[i - 1])
-            pa = abase + ((g * gran - 4 * words_a) >> 21 << 21)
-            pb = abase + ((g + 6) * gran)   # (a second array, if the leg has one: 24 GiB further on)
-            if args.straddle_b:                # ... or centred on a later boundary (the n-th after the first)
-                bs = [i for i in range(1, len(classes)) if classes[i] != classes[i - 1]]
-                g2 = bs[min(args.straddle_b, len(bs) - 1)]
-                pb = abase + ((g2 * gran - 4 * max(words_b, 1)) >> 21 << 21)
-                print(f"straddle: b across the boundary at {g2 * gran >> 30} GiB", flush=True)
-            print(f"straddle: boundary at {g * gran >> 30} GiB, a at {(pa - abase) / 2**30:.2f} GiB", flush=True)
-        mode = "carve"
     elif mode == "pool":
         t0 = time.perf_counter()
         pa = ctx.alloc(8 * words_a, lone_output=(words_b == 0 and not args.no_role))  # the only output of its launch: by role
@@ -137,15 +111,6 @@ with torch.cuda.stream(stream):
         print(f"pool: {time.perf_counter() - t0:.2f} s; held {info['held'] / 2**30:.1f} GiB, in use {info['in_use'] / 2**30:.1f}, classes {info['n_classes']} "
               f"{[round(b / 2**30, 1) for b in info['class_bytes']]} GiB, probes two-class {info['two_class_gbps']:.0f} one-class {info['one_class_gbps']:.0f} GB/s; "
               f"a {short(la)} b {short(lb)}", flush=True)
-    elif mode == "arena":
-        ctx.check(ctx.lib.kmers_arena_reserve(ctx.handle, size << 30), "kmers_arena_reserve")
-        pa = ctx.alloc(8 * words_a, lone_output=(words_b == 0 and not args.no_role))  # the only output of its launch: by role
-        pb = ctx.alloc(8 * max(words_b, 1))
-        abase, gran, classes = ctx.arena_regions()
-        if gran:
-            cls = lambda p, nbytes: "".join(sorted({chr(65 + classes[min(g, len(classes) - 1)]) for g in range((p - abase) // gran, (p - abase + nbytes - 1) // gran + 1)}))
-            print(f"arena map {''.join(chr(65 + c) for c in classes)}; a at {(pa - abase) / 2**30:.2f} GiB in {cls(pa, 8 * words_a)}, "
-                  f"b at {(pb - abase) / 2**30:.2f} GiB in {cls(pb, 8 * max(words_b, 1))}", flush=True)
     else:
         ta = torch.empty(words_a, dtype=torch.int64, device=dev)
         tb = torch.empty(max(words_b, 1), dtype=torch.int64, device=dev)
