@@ -467,6 +467,13 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
         torch.cuda.synchronize()
         ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(tseq), Kf, 2, a.data_ptr(), b.data_ptr(), 0, ASYNC, C.byref(res)))
         entry("f1 CanonicalDNAMers{31} + fx_hash from 1 Gbase of ASCII text (String source), 17 B/kmer", ms, L, 17.0 * (L - Kf + 1))
+        # kmers_batch on the reads people have (docs/src/minhash.md:31-35, docs/src/faq.md:28-33,
+        # src/iterators/UnambiguousKmers.jl:109-132): the same 8 M x 125 from TEXT; with an N in 1 % / 10 % of the reads under
+        # KMERS_BATCH_SKIP (4-bit pool and text); lengths uniform 50-250 (about 6.7 M reads of the same pool).  Whole calls.
+        try:
+            out.update(batch_read_legs(ctx, cap, dev, seq, tseq, buf, text, a, b, timed, L))
+        except Exception as e:  # noqa: BLE001
+            out["kmers_batch on realistic reads"] = {"error": repr(e)}
         del text
         mem.free(text_words)
         del text_words
@@ -493,6 +500,69 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
             out["e2e host pointers, fused consumers (H2D + kernel; never `value`)"] = {"error": repr(e)}
         # N1 (north star): CanonicalDNAMers{31} + fx_hash over 10 Gbase LongDNA{4} on ONE GPU: 5 GB in, 160 GB out
         out.update(north_star_one_gpu(ctx, cap, stream, dev, mem, reps))
+    return out
+
+
+def batch_read_legs(ctx, cap, dev, seq, tseq, buf, text, a, b, timed, L, K=31):
+    """Whole kmers_batch calls (layout pass, tile descriptors, element kernel; device pool, device spans, device outputs) over
+    reads cut out of the bench's 1 Gbase pool -- `seq` / `buf` the LongDNA{4} words, `tseq` / `text` the same length as ASCII."""
+    import numpy as np
+    import torch
+    res = cap.Result()
+    out = {}
+    rng = np.random.default_rng(20260)
+
+    def spans_of(lengths):
+        starts = np.concatenate([[0], np.cumsum(lengths[:-1])]).astype(np.int64)
+        return torch.from_numpy(np.stack([starts, lengths.astype(np.int64)], axis=1).copy()).to(dev), starts
+
+    def run(name, pool_seq, spans_t, n_reads, total, n_bases, bytes_per_base, flags):
+        ms = timed(lambda: ctx.lib.kmers_batch(ctx.handle, C.byref(pool_seq), spans_t.data_ptr(), n_reads, cap.BATCH_CANONICAL, K, 2, a.data_ptr(),
+                                               b.data_ptr(), 0, None, total, cap.MEM_DEVICE | cap.SPANS_DEVICE | flags, C.byref(res)))
+        assert res.status == 0 and res.n_out == total, (name, res.status, res.n_out, total)
+        alg = 16.0 * total + bytes_per_base * n_bases
+        out[name] = {"ms": round(ms, 4), "G_elements_per_s": round(total / ms / 1e6, 1), "Gbases_per_s": round(n_bases / ms / 1e6, 1),
+                     "GB_per_s": round(alg / ms / 1e6, 1), "frac_of_8TBps": round(alg / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+
+    n_reads, rl = 8_000_000, 125
+    fixed = np.full(n_reads, rl, dtype=np.int64)
+    spans_fixed, starts_fixed = spans_of(fixed)
+    total_fixed = n_reads * (rl - K + 1)
+    run(f"kmers_batch: {n_reads} reads x {rl} bases from ASCII text, CanonicalDNAMers{{31}} + fx_hash per read", tseq, spans_fixed, n_reads,
+        total_fixed, n_reads * rl, 1.0, 0)
+    # an N in a share of the reads: the pool's words / bytes are changed in place and put back afterwards
+    for share in (0.01, 0.10):
+        hit = np.flatnonzero(rng.random(n_reads) < share)
+        pos = starts_fixed[hit] + rng.integers(0, rl, len(hit))
+        w, sh = pos // 16, (pos % 16) * 4
+        masks = np.zeros(len(w), dtype=np.uint64)
+        uw, inv = np.unique(w, return_inverse=True)
+        um = np.zeros(len(uw), dtype=np.uint64)
+        np.bitwise_or.at(um, inv, np.uint64(0xF) << sh.astype(np.uint64))
+        del masks
+        idx = torch.from_numpy(uw.astype(np.int64)).to(dev)
+        saved = buf[idx].clone()
+        buf[idx] = torch.bitwise_or(saved, torch.from_numpy(um.view(np.int64).copy()).to(dev))
+        torch.cuda.synchronize()
+        run(f"kmers_batch: {n_reads} reads x {rl} bases, an N in {share:.0%} of the reads, KMERS_BATCH_SKIP (LongDNA{{4}} pool)", seq, spans_fixed,
+            n_reads, total_fixed, n_reads * rl, 0.5, cap.BATCH_SKIP)
+        buf[idx] = saved
+        tpos = torch.from_numpy(pos.astype(np.int64)).to(dev)
+        tsaved = text[tpos].clone()
+        text[tpos] = 78                                                           # "N"
+        torch.cuda.synchronize()
+        run(f"kmers_batch: {n_reads} reads x {rl} bases from ASCII text, an N in {share:.0%} of the reads, KMERS_BATCH_SKIP", tseq, spans_fixed,
+            n_reads, total_fixed, n_reads * rl, 1.0, cap.BATCH_SKIP)
+        text[tpos] = tsaved
+        torch.cuda.synchronize()
+        del idx, saved, tpos, tsaved
+    # ragged lengths: uniform 50..250 until the pool is used up
+    lengths = rng.integers(50, 251, int(L / 150 * 1.02))
+    lengths = lengths[np.cumsum(lengths) <= L]
+    spans_rag, _ = spans_of(lengths)
+    total_rag = int((lengths - K + 1).sum())
+    run(f"kmers_batch: {len(lengths)} reads of 50-250 bases (uniform), LongDNA{{4}} pool", seq, spans_rag, len(lengths), total_rag, int(lengths.sum()), 0.5, 0)
+    run(f"kmers_batch: {len(lengths)} reads of 50-250 bases (uniform) from ASCII text", tseq, spans_rag, len(lengths), total_rag, int(lengths.sum()), 1.0, 0)
     return out
 
 

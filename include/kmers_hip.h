@@ -123,8 +123,9 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 #define KMERS_PARAM_HOST_CHUNKS 12      /* -1: a host-pointer call (KMERS_MEM_HOST) is one launch + one copy whatever its size; 0 (default): outputs of
                                         * 96 MiB or more travel in chunks, the kernel of the next chunk beside the copy of the current one */
 #define KMERS_PARAM_POOL 14             /* 1 (default): kmers_dev_alloc of KMERS_POOL_MIN_BYTES or more comes from the device's class pool (below); 0: plain hipMalloc */
-#define KMERS_PARAM_POOL_SEARCH_GIB 15  /* how far past a request the pool may grow in search of memory of the classes it wants (default: 8 x the request,
-                                         * 16 GiB at least; what it walked past goes back to the driver once the block is made); 0: never */
+#define KMERS_PARAM_POOL_SEARCH_GIB 15  /* how far past a request the pool may grow in search of memory of the classes it wants (default: 128, at most half
+                                         * of what the device has free; held for the SEARCH only: what it walked past goes back to the driver once the block
+                                         * is made); 0: never */
 #define KMERS_PARAM_POOL_CACHE 18       /* 1 (default): a freed block of the pool stays mapped for the next request of its shape; 0: taken apart at once (the
                                          * free then waits for the work queued on the device's contexts) */
 #define KMERS_PARAM_BATCH_DENSE 17       /* A/B, tests.  -1: kmers_batch never takes its dense tile path (csrc/ragged_kernels.hpp); 0 (default): wherever a tile allows */

@@ -183,9 +183,12 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     // idles between the scan and the element kernel).  A caller that passes device outputs and a sane capacity -- the count it
     // learned from a size query, or an upper bound -- gets the layout sized for the CAPACITY instead, the kernels read the count on
     // the device, and the call waits once, at its end (round 5: the optimistic launch of one-word kmers from a 4-bit pool only).
+    // One-word 2-bit kmers out of a 4-bit pool (LongDNA{4}, what BioSequences reads FASTA into) or out of DNA / RNA text (the bytes
+    // of a FASTA / FASTQ buffer): the OPTIMISTIC launch below.
+    const bool text_pool = pool->src_bits == 8 && pool->alphabet != KMERS_ALPHABET_SYMBOLS;
+    const bool opt_shape = (pool->src_bits == 4 || text_pool) && dst_bits == 2 && nw == 1 && stride == 1 && ctx->batch_dense >= 0;
     const bool out_dev_early = (flags & KMERS_MEM_DEVICE) || (flags & INTERNAL_OUT_DEVICE);
-    const bool deferred = out_dev_early && (out_a || out_b) && (!out_a || aligned16(out_a)) && (!out_b || aligned16(out_b)) && pool->src_bits == 4 &&
-                          dst_bits == 2 && nw == 1 && stride == 1 && !(flags & KMERS_BATCH_SKIP) && ctx->batch_dense >= 0 && capacity > 0 &&
+    const bool deferred = out_dev_early && (out_a || out_b) && (!out_a || aligned16(out_a)) && (!out_b || aligned16(out_b)) && opt_shape && capacity > 0 &&
                           capacity <= 2 * pool->n_bases + n;
     uint64_t total = capacity;  // (deferred: what the layout is sized for; the real count arrives with the final wait)
     if (!deferred) {
@@ -244,12 +247,12 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
     a.stride = (uint32_t)stride;
     a.dense = (int32_t)ctx->batch_dense;
     a.stream_origin = origin;
-    // One-word 2-bit kmers out of a 4-bit pool (LongDNA{4}, what BioSequences reads FASTA into): the OPTIMISTIC launch first --
-    // no recode pass, every tile recodes its own stretch and takes the dense path (ragged_kernels.hpp), the pool is read once.
-    // Tiles that could not (short or scattered records, a symbol that is not one-hot) count themselves; only then do the recode
-    // pass and the general launch run, for those tiles.  The skip mode needs the per-symbol flags: it goes the classic way.
-    const bool optimistic = !wide && sb == 4 && dst_bits == 2 && nw == 1 && stride == 1 && !(flags & KMERS_BATCH_SKIP) && ctx->batch_dense >= 0 &&
-                            tile_elems <= (uint32_t)(RG_MAX_PASSES * RG_UNIT);
+    // The OPTIMISTIC launch first -- no recode pass, every tile recodes its own stretch and takes the dense path
+    // (ragged_kernels.hpp), the pool is read once.  Tiles that could not (short or scattered records) count themselves; only then do
+    // the recode pass and the general launch run, for those tiles.  Round 6: a symbol the kmer alphabet cannot encode no longer
+    // sends its tile there -- the tile makes the flag bits of its own stretch and marks (KMERS_BATCH_SKIP) or reports the elements
+    // whose windows hold one; and text is recoded in the tile like a 4-bit pool is (8 bytes per v_perm / v_dot4 pair).
+    const bool optimistic = !wide && opt_shape && tile_elems <= (uint32_t)(RG_MAX_PASSES * RG_UNIT);
     unsigned long long *d_redo = reinterpret_cast<unsigned long long *>(ctx->d_scratch + 2);
     if (!wide)  // (the optimistic launch's status bytes and redo count are cleared by this kernel on its way)
         hipLaunchKernelGGL(ragged_tiles_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_spans, n, n_tiles,
@@ -264,8 +267,10 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         a.flags = ps.flags;
         a.any_flag = ps.any_flag;
     } else {
-        a.src4 = src0;
-        a.n_src4_words = n_src_words;
+        a.src_opt = src0;
+        a.n_src_words = n_src_words;
+        a.opt_from = sb == 8 ? 8u : 4u;
+        a.text = sb == 8 ? (pool->alphabet == KMERS_ALPHABET_RNA ? 2u : 1u) : 0u;
         a.tile_status = d_status;
         a.redo_count = d_redo;
     }
@@ -307,7 +312,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
         a.stream = ps.stream;
         a.flags = ps.flags;
         a.any_flag = ps.any_flag;
-        a.src4 = nullptr;
+        a.src_opt = nullptr;
         a.tile_status = nullptr;
         RGN(2);
     } else if (optimistic) {
@@ -333,7 +338,7 @@ static int batch_impl(kmers_ctx *ctx, const kmers_seq *pool, const kmers_span *s
             a.stream = ps.stream;
             a.flags = ps.flags;
             a.any_flag = ps.any_flag;
-            a.src4 = nullptr;
+            a.src_opt = nullptr;
             RGM(2, 1);
         }
     } else if (dst_bits == 2) RGN(2);

@@ -104,8 +104,11 @@ bool probe_ms(kmers_device_pool *P, char *a, char *b, float *out) {
 }
 
 // the device's TLB may hold translations of ranges that were just unmapped (header comment): the legacy allocation path flushes
-// it.  Lazy: an unmap only marks the pool, the flush runs before the next map (a loop that frees and allocates pays one).  false:
-// the flush could not run (no 32 MiB for its hipMalloc even after the pool's idle handles went back) -- nothing may be mapped.
+// it.  An unmap marks the pool; the flush runs ONCE at the end of the pool operation that unmapped (settle(), below) and in any
+// case before the next map.  (It must not wait for the next map: between a hipMemAddressFree and the flush's hipMalloc + hipFree
+// the runtime's own books are off -- a plain hipMalloc of the HOST that landed on the freed range aborted inside its hipFree,
+// "Memobj map does not have ptr", tests/test_gpu_pool.py on ROCm 7.2 -- so the flush's allocation is the first one to follow.)
+// false: the flush could not run (no 32 MiB for its hipMalloc even after the pool's idle handles went back) -- nothing may be mapped.
 bool release_idle_locked(kmers_device_pool *P, bool cached_too);
 bool flush_tlb(kmers_device_pool *P) {
     if (!P->need_flush) return true;
@@ -121,6 +124,14 @@ bool flush_tlb(kmers_device_pool *P) {
     }
     return false;
 }
+
+void settle(kmers_device_pool *P) {
+    if (P->need_flush) (void)flush_tlb(P);
+}
+struct Settle {
+    kmers_device_pool *P;
+    ~Settle() { settle(P); }
+};
 
 bool reserve(void **va, size_t bytes) {
     if (hipMemAddressReserve(va, bytes, CHUNK_BYTES, nullptr, 0) == hipSuccess) return true;
@@ -519,6 +530,7 @@ int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, int role, void **out) {
     std::lock_guard<std::mutex> lock(slot.mu);
     kmers_device_pool *P = attach(ctx, slot);
     if (!P) return KMERS_E_UNSUPPORTED;  // no virtual-memory management on this device: the caller falls back to hipMalloc
+    Settle settle_on_return{P};          // (whatever this call unmaps is flushed before it returns)
     State &s = P->s;
     ++s.tick;
     // A lone output is written through two windows half an array apart: its MIDDLE is put on a chunk boundary (the block is the
@@ -552,9 +564,18 @@ int kmers::pool_alloc(kmers_ctx *ctx, size_t bytes, int role, void **out) {
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n * CHUNK_BYTES > free_b + s.held_bytes - s.in_use_bytes)
             return fail(ctx, KMERS_E_NOMEM, "kmers_dev_alloc: more than the device has free");
     }
-    // 2. a new block, its chunks chosen by class.  The pool may grow past the request in search of the classes it wants: by default
-    // up to 8 x the request (16 GiB at least), and what it walked past goes back to the driver afterwards (trim_hoard).
-    const size_t search_limit = ctx->pool_search_gib >= 0 ? (size_t)ctx->pool_search_gib << 30 : std::max((size_t)16 << 30, 8 * n * CHUNK_BYTES);
+    // 2. a new block, its chunks chosen by class.  The pool may grow past the request in search of the classes it wants: what it
+    // walks past is held for the SEARCH only (trim_hoard below returns it to the driver), so the budget is generous -- up to
+    // 128 GiB, at most half of what the device has free: one box begins with 70 GiB of ONE class in the order the driver hands
+    // out handles, and a budget sized to a small request (16 GiB, tried first in round 6) left a 0.4 GB pair of arrays in one
+    // class there.  A handle of memory the device has never used costs 3 us + 1 ms of probes.
+    size_t search_limit = (size_t)128 << 30;
+    if (ctx->pool_search_gib >= 0) {
+        search_limit = (size_t)ctx->pool_search_gib << 30;
+    } else {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) search_limit = std::min(search_limit, free_b / 2);
+    }
     std::vector<uint8_t> seq;
     float quality = 0.f;
     for (size_t searched = 0;;) {
@@ -647,6 +668,7 @@ int kmers::pool_free(kmers_ctx *ctx, void *p, bool *handled) {
     }
     *handled = true;
     if (static_cast<const char *>(p) != base + blk->user_off) return fail(ctx, KMERS_E_BADARG, "kmers_dev_free: not the start of a block of the pool");
+    Settle settle_on_return{P};
     attach(ctx, slot, false);  // (a context that only ever frees: its stream counts from now on)
     ++s.tick;
     auto it = s.blocks.find(base);
@@ -675,6 +697,7 @@ size_t kmers::pool_release_idle(kmers_ctx *ctx) {
     if (!P) return 0;
     const size_t before = P->s.held_bytes;
     release_idle_locked(P, true);
+    settle(P);
     ctx->slot->generation.fetch_add(1, std::memory_order_release);
     return before - P->s.held_bytes;
 }

@@ -17,8 +17,11 @@
 //      the first element the reference would have failed on, in record order, and its first flagged
 //      symbol the one it throws for.
 //   3b. (round 5) tiles of reads in pool order take the DENSE path of the same kernel (below): 32-bit tile-relative indices, the
-//      record of a run from a bitmap, two elements per lane and 16-byte stores side by side; from a 4-bit pool it runs FIRST and
-//      alone, recoding its own stretches (the optimistic launch, batch_api.hip), and step 1 happens only if a tile asks for it.
+//      record of a run from a bitmap, two elements per lane and 16-byte stores side by side; from a 4-bit pool -- round 6: and from
+//      DNA / RNA text -- it runs FIRST and alone, recoding its own stretches (the optimistic launch, batch_api.hip), and step 1
+//      happens only if a tile asks for it.  Round 6: a symbol the kmer alphabet cannot encode (an N in a read) costs the ELEMENTS
+//      whose windows hold it, not the tile: the dense path carries one flag bit per staged symbol and writes the all-ones
+//      sentinel (KMERS_BATCH_SKIP) or reports the first failing element itself.
 #pragma once
 #include <type_traits>
 
@@ -92,12 +95,15 @@ struct RaggedArgs {
     uint32_t tile;               // output elements per workgroup: a multiple of RG_PASS
     uint32_t stride;             // symbols between the windows of a record: 1, or J of SpacedKmers{A,K,J} (forward kmers only)
     int32_t dense;               // KMERS_PARAM_BATCH_DENSE: -1 = never take the dense tile path (A/B, tests)
-    // The OPTIMISTIC launch straight from a 4-bit pool (batch_api.hip): no recode pass has run, `stream` is NULL, every tile tries
-    // the dense path and recodes its stretch of `src4` itself (one verdict per word, device_bits.hpp); a tile that is not dense or
-    // meets a symbol that is not one-hot writes nothing, sets its status byte and counts itself.  If any did, the host runs the
-    // recode pass and launches again with `stream` set: tiles whose status is 0 are done and leave at once.
-    const uint64_t *src4;
-    uint64_t n_src4_words;       // the pool's words: nothing is read beyond them
+    // The OPTIMISTIC launch straight from a 4-bit pool or from DNA / RNA text (batch_api.hip): no recode pass has run, `stream` is
+    // NULL, every tile tries the dense path and recodes its stretch of `src_opt` itself (one verdict per word, device_bits.hpp /
+    // text8_codes; the flag of every symbol only where a word is off); a tile that is not dense writes nothing, sets its status
+    // byte and counts itself.  If any did, the host runs the recode pass and launches again with `stream` set: tiles whose status
+    // is 0 are done and leave at once.
+    const uint64_t *src_opt;
+    uint64_t n_src_words;        // the pool's words: nothing is read beyond them
+    uint32_t opt_from;           // 4: a 4-bit pool; 8: text (one byte per symbol)
+    uint32_t text;               // opt_from == 8: 1 = DNA text (T), 2 = RNA text (U)
     uint8_t *tile_status;
     unsigned long long *redo_count;
 };
@@ -336,83 +342,30 @@ struct DenseLds {                        // carved out of ragged_kernel's LDS ar
     uint64_t *slot;                      // [RG_SLOTS + 1]: low half = the record's first element relative to the tile (clamped to [0, 2^31)),
                                          //   high half = first stream symbol of element 0 of the TILE if it belonged to this record, relative to the staged stretch
     uint64_t *src;                       // [RG_STAGE + 2]
+    uint64_t *flg;                       // [RG_STAGE / 2 + 4]: one "cannot be encoded" bit per symbol of the stretch (round 6)
     uint64_t *bits;                      // [RG_MAX_PASSES * RG_UNIT / RG_RUN / 64]: bit j: a record begins in run j or between run j - 1's first element and it
     uint32_t *base;                      // [... + 1]: records that begin before the word's first run
 };
 
-// true: the tile was written.  false (uniformly): the tile is not dense, nothing was written, the general path must run.
-template <int DST, int MODE, bool FROM4>
-__device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const RaggedTile &d, uint64_t e0, uint32_t n_el, const DenseLds &L) {
-    constexpr uint32_t RUN = RG_DENSE_RUN, SPW = 64u / (uint32_t)DST;
-    const uint32_t tid = threadIdx.x, k = a.k, n_rec = d.n_slots;
+// the eight "byte j is off" bits of text8_bad_bytes (bit 8j) gathered into one byte (the partial products never meet: no carries)
+__device__ __forceinline__ uint32_t gather_byte_flags(uint64_t f) { return (uint32_t)((f * 0x0102040810204080ull) >> 56); }
+
+// The runs of a dense tile.  FLAGGED: the tile's stretch holds a symbol the kmer alphabet cannot encode -- every run looks its
+// windows' flag bits up (bit fbase + p of L.flg = symbol p of the stretch) and either writes the all-ones sentinel for the
+// elements that hold one (a.skip: KMERS_BATCH_SKIP, UnambiguousKmers' selection at the strict call's indices,
+// src/iterators/UnambiguousKmers.jl:109-148) or reports the first of them (the reference throws there, FwKmers.jl:112).
+template <int DST, int MODE, bool FLAGGED>
+__device__ __forceinline__ void dense_runs(const RaggedArgs &a, const DenseLds &L, uint64_t e0, uint32_t n_el, uint32_t fbase) {
+    constexpr uint32_t RUN = RG_DENSE_RUN;
+    const uint32_t tid = threadIdx.x, k = a.k;
     const uint64_t mask = head_mask((int)k, DST);
-    const uint64_t sym0 = d.q_lo * SPW;                     // stream symbol at bit 0 of the staged stretch
-    const uint32_t staged_syms = d.n_words * SPW;
-    // ---- stage the record slots, the stream stretch; test the tile
-    uint32_t bad = (d.n_words == 0u || n_rec > (uint32_t)RG_SLOTS + 1u || n_rec < 2u) ? 1u : 0u;
-    // (the stretch of the stream first: its loads are in flight beside those of the record slots -- one round trip, not two)
-    if constexpr (FROM4) {
-        uint32_t *src32 = reinterpret_cast<uint32_t *>(L.src);
-        for (uint32_t i = tid; i < 2u * d.n_words; i += 256u) {
-            const uint64_t wi = 2u * d.q_lo + i;  // (a stretch may end half a stream word past the pool's last word: all A there, in no window)
-            uint32_t any_bad;
-            src32[i] = pack_4to2_checked(wi < a.n_src4_words ? a.src4[wi] : 0x1111111111111111ull, any_bad);  // FourToTwo, construction_utils.jl:47-52
-            bad |= any_bad ? 1u : 0u;                                         // (a symbol that is not one-hot: the general path finds which, and whether a window holds it)
-        }
-    } else {
-        for (uint32_t i = tid; i < d.n_words; i += 256u) L.src[i] = a.stream[d.q_lo + i];
-    }
-    if (tid < 2u) L.src[d.n_words + tid] = 0;
-    for (uint32_t i = tid; i < n_rec; i += 256u) {
-        const uint64_t rec = d.r_lo + (uint64_t)i;
-        const uint64_t o = a.rec_off[rec];
-        const bool real = rec < a.n_records;
-        const RaggedSpan sp = real ? a.spans[rec] : RaggedSpan{0, 0};
-        const uint32_t rel = o <= e0 ? 0u : (o - e0 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)(o - e0));
-        const uint32_t delta = (uint32_t)(sp.first_base + a.stream_origin + e0 - o - sym0);
-        L.slot[i] = (uint64_t)rel | ((uint64_t)delta << 32);
-        if (i + 1u == n_rec && rel < n_el) bad = 1u;        // more records than slots: the staged slice does not close the tile
-        if (i + 1u < n_rec && real) {                       // (the last slot only closes the search range)
-            const uint64_t o_next = a.rec_off[rec + 1];
-            const uint64_t lo_e = o > e0 ? o : e0, hi_e = o_next < e0 + n_el ? o_next : e0 + n_el;  // its elements inside the tile
-            if (o_next - o < (uint64_t)RUN) bad = 1u;       // a record that owns fewer than RUN elements (or none)
-            if (hi_e > lo_e) {                              // its windows must lie in the staged stretch (RUN - 1 symbols of slack for the roll)
-                const uint64_t first = sp.first_base + a.stream_origin + (lo_e - o), end = sp.first_base + a.stream_origin + (hi_e - 1u - o) + k;
-                if (first < sym0 || end > sym0 + staged_syms) bad = 1u;
-            }
-        }
-    }
-    constexpr uint32_t N_WORDS = RG_MAX_PASSES * RG_UNIT / RUN / 64;
-    static_assert(N_WORDS <= 128 && N_WORDS % 2 == 0, "one wavefront scans the bitmap's words, two per lane");
-    if (tid < N_WORDS) L.bits[tid] = 0;
-    lds_atomics_settle();
-    if (__syncthreads_or((int)bad)) return false;           // (also orders the staging before what follows)
-    // ---- the bitmap of record beginnings
-    uint32_t *bits32 = reinterpret_cast<uint32_t *>(L.bits);
-    for (uint32_t i = 1u + tid; i < n_rec; i += 256u) {
-        const uint32_t rel = (uint32_t)L.slot[i];
-        const uint32_t j = (rel + RUN - 1u) / RUN;          // the first run that starts at or behind the record's first element
-        if (rel > 0u && j * RUN < n_el) atomicOr(&bits32[j >> 5], 1u << (j & 31u));  // (a record that begins inside the LAST run needs no bit)
-    }
-    block_sync();
-    if (tid < 64u) {                                        // exclusive prefix of the words' population counts (one wavefront, two words per lane)
-        const uint32_t c0 = 2u * tid < N_WORDS ? (uint32_t)__popcll(L.bits[2u * tid]) : 0u;
-        const uint32_t c1 = 2u * tid + 1u < N_WORDS ? (uint32_t)__popcll(L.bits[2u * tid + 1u]) : 0u;
-        uint32_t incl = c0 + c1;
-#pragma unroll
-        for (uint32_t step = 1; step < 64u; step <<= 1) {
-            const uint32_t up = __shfl_up(incl, step, 64);
-            if (tid >= step) incl += up;
-        }
-        if (2u * tid < N_WORDS) {
-            L.base[2u * tid] = incl - c0 - c1;
-            L.base[2u * tid + 1u] = incl - c1;
-        }
-    }
-    block_sync();
-    // ---- the runs
     const uint32_t top = (uint32_t)DST * (k - 1u);
     const uint64_t seed_rot = (a.seed << 5) | (a.seed >> 59);
+    const uint64_t kbits = k >= 64u ? ~0ull : (1ull << k) - 1ull;
+    auto flag_bits = [&](uint32_t p, uint32_t span) -> uint64_t {  // flags of the symbols [p, p + span) of the stretch (span <= 33)
+        const uint32_t b = p + fbase;
+        return funnel64(L.flg[b >> 6], L.flg[(b >> 6) + 1u], b & 63u) & ((1ull << span) - 1ull);
+    };
     for (uint32_t j = tid; j * RUN < n_el; j += 256u) {
         const uint32_t e = j * RUN;
         const uint64_t word = L.bits[j >> 6];               // (the same word for the whole wavefront)
@@ -437,14 +390,30 @@ __device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const Rag
             continue;
         }
 #endif
-        dense_cut<DST>(L.src, (uint32_t)(s0 >> 32) + e, k, mask, fw, rc, syms);
+        const uint32_t pA = (uint32_t)(s0 >> 32) + e, pB = (uint32_t)(s1 >> 32) + e + lenA;
+        const uint64_t g = e0 + e;
+        dense_cut<DST>(L.src, pA, k, mask, fw, rc, syms);
         // a lane whose run crosses into the next record cuts that record's first window too (one lane in 24 at 95 kmers per read:
         // most wavefronts run this once, for a few lanes) -- every lane then holds a whole run and stores it with 16-byte stores
         // (a version that left the sub-runs to a list and stored them element by element had half the vector instructions of
         // this one and was SLOWER: 2.4 times the store instructions, and those are what the launch waits for)
         uint64_t fwB = 0, rcB = 0;
         uint32_t symsB = 0;
-        if (lenA < cnt) dense_cut<DST>(L.src, (uint32_t)(s1 >> 32) + e + lenA, k, mask, fwB, rcB, symsB);
+        if (lenA < cnt) dense_cut<DST>(L.src, pB, k, mask, fwB, rcB, symsB);
+        uint64_t fA = 0, fB = 0;                            // flagged symbols of the two sub-runs
+        if constexpr (FLAGGED) {
+            fA = flag_bits(pA, k + lenA - 1u);
+            if (lenA < cnt) fB = flag_bits(pB, k + (cnt - lenA) - 1u);
+            if (!a.skip) {                                  // the first element whose window holds a flagged symbol (outputs are unspecified then)
+                if (fA) {
+                    const uint32_t first = (uint32_t)__builtin_ctzll(fA);
+                    atomicMin(a.err_slot, (unsigned long long)(g + (first >= k ? first - k + 1u : 0u)));
+                } else if (fB) {
+                    const uint32_t first = (uint32_t)__builtin_ctzll(fB);
+                    atomicMin(a.err_slot, (unsigned long long)(g + lenA + (first >= k ? first - k + 1u : 0u)));
+                }
+            }
+        }
         dense_finish<MODE>(fw, rc, seed_rot, X[0], Y[0]);
 #pragma unroll
         for (uint32_t t = 1; t < RUN; ++t) {
@@ -457,7 +426,15 @@ __device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const Rag
             }
             dense_finish<MODE>(fw, rc, seed_rot, X[t], Y[t]);
         }
-        const uint64_t g = e0 + e;
+        if constexpr (FLAGGED) {
+            if (a.skip) {
+#pragma unroll
+                for (uint32_t t = 0; t < RUN; ++t) {
+                    const uint64_t in_window = t < lenA ? (fA >> t) & kbits : (fB >> (t - lenA)) & kbits;
+                    if (in_window) X[t] = Y[t] = ~0ull;     // never a canonical kmer, never a (kmer, reverse complement) pair
+                }
+            }
+        }
 #if defined(KMERS_RG_CUT) && KMERS_RG_CUT == 1  // diagnostic build: everything but the stores (profiles/r05_batch.md)
         {
             uint64_t all = 0;
@@ -484,6 +461,120 @@ __device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const Rag
             }
         }
     }
+}
+
+// true: the tile was written.  false (uniformly): the tile is not dense, nothing was written, the general path must run.
+// FROM: 0 = the recoded stream (and `flags`, the recode pass's flag words, or NULL); 4 / 8 = the optimistic launch, the tile
+// recodes its own stretch of a 4-bit pool / of DNA or RNA text and makes its own flag bits.
+template <int DST, int MODE, int FROM>
+__device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const RaggedTile &d, uint64_t e0, uint32_t n_el, const DenseLds &L,
+                                                  const uint64_t *flags) {
+    constexpr uint32_t RUN = RG_DENSE_RUN, SPW = 64u / (uint32_t)DST;
+    static_assert(FROM == 0 || DST == 2, "the optimistic launch yields 2-bit kmers");
+    const uint32_t tid = threadIdx.x, k = a.k, n_rec = d.n_slots;
+    const uint64_t sym0 = d.q_lo * SPW;                     // stream symbol at bit 0 of the staged stretch
+    const uint32_t staged_syms = d.n_words * SPW;
+    // ---- stage the record slots, the stream stretch (and its flag bits); test the tile
+    uint32_t bad = (d.n_words == 0u || n_rec > (uint32_t)RG_SLOTS + 1u || n_rec < 2u) ? 1u : 0u;
+    uint32_t flagged = 0, n_flg = 0, fbase = 0;
+    // (the stretch of the stream first: its loads are in flight beside those of the record slots -- one round trip, not two)
+    if constexpr (FROM == 4) {
+        uint32_t *src32 = reinterpret_cast<uint32_t *>(L.src);
+        uint16_t *flg16 = reinterpret_cast<uint16_t *>(L.flg);
+        const uint32_t n_in = 2u * d.n_words, n_pad = (n_in + 3u) & ~3u;  // (whole flag words: the padding is unflagged)
+        for (uint32_t i = tid; i < n_pad; i += 256u) {
+            const uint64_t wi = 2u * d.q_lo + i;  // (a stretch may end half a stream word past the pool's last word: all A there, in no window)
+            uint32_t any_bad;
+            const uint64_t x = i < n_in && wi < a.n_src_words ? a.src_opt[wi] : 0x1111111111111111ull;
+            const uint32_t c = pack_4to2_checked(x, any_bad);  // FourToTwo, construction_utils.jl:47-52
+            if (i < n_in) src32[i] = c;
+            const uint32_t f = any_bad ? (uint32_t)bad_bits16(bad_nibbles4(x)) & 0xffffu : 0u;  // a symbol that is not one-hot: which ones
+            flg16[i] = (uint16_t)f;
+            flagged |= f;
+        }
+        n_flg = n_pad / 4u;
+    } else if constexpr (FROM == 8) {
+        uint16_t *src16 = reinterpret_cast<uint16_t *>(L.src);
+        uint8_t *flg8 = reinterpret_cast<uint8_t *>(L.flg);
+        const uint32_t n_in = 4u * d.n_words, n_pad = (n_in + 7u) & ~7u;
+        for (uint32_t i = tid; i < n_pad; i += 256u) {
+            const uint64_t wi = 4u * d.q_lo + i;
+            uint32_t off;
+            const uint64_t x = i < n_in && wi < a.n_src_words ? a.src_opt[wi] : 0x4141414141414141ull;
+            const uint32_t c = text8_codes(x, a.text, off);  // AsciiEncode, src/construction.jl:94-95
+            if (i < n_in) src16[i] = (uint16_t)c;
+            const uint32_t f = off ? gather_byte_flags(text8_bad_bytes(x, a.text)) : 0u;
+            flg8[i] = (uint8_t)f;
+            flagged |= f;
+        }
+        n_flg = n_pad / 8u;
+    } else {
+        for (uint32_t i = tid; i < d.n_words; i += 256u) L.src[i] = a.stream[d.q_lo + i];
+        if (flags) {
+            for (uint32_t i = tid; i < d.n_fwords; i += 256u) {
+                const uint64_t w = flags[d.f_lo + i];
+                L.flg[i] = w;
+                flagged |= w != 0 ? 1u : 0u;
+            }
+            n_flg = d.n_fwords;
+            fbase = (uint32_t)(sym0 - d.f_lo * 64u);        // (the flag words begin at or before the stretch)
+        }
+    }
+    if (tid < 2u) {
+        L.src[d.n_words + tid] = 0;
+        L.flg[n_flg + tid] = 0;
+    }
+    for (uint32_t i = tid; i < n_rec; i += 256u) {
+        const uint64_t rec = d.r_lo + (uint64_t)i;
+        const uint64_t o = a.rec_off[rec];
+        const bool real = rec < a.n_records;
+        const RaggedSpan sp = real ? a.spans[rec] : RaggedSpan{0, 0};
+        const uint32_t rel = o <= e0 ? 0u : (o - e0 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)(o - e0));
+        const uint32_t delta = (uint32_t)(sp.first_base + a.stream_origin + e0 - o - sym0);
+        L.slot[i] = (uint64_t)rel | ((uint64_t)delta << 32);
+        if (i + 1u == n_rec && rel < n_el) bad = 1u;        // more records than slots: the staged slice does not close the tile
+        if (i + 1u < n_rec && real) {                       // (the last slot only closes the search range)
+            const uint64_t o_next = a.rec_off[rec + 1];
+            const uint64_t lo_e = o > e0 ? o : e0, hi_e = o_next < e0 + n_el ? o_next : e0 + n_el;  // its elements inside the tile
+            if (o_next - o < (uint64_t)RUN) bad = 1u;       // a record that owns fewer than RUN elements (or none)
+            if (hi_e > lo_e) {                              // its windows must lie in the staged stretch (RUN - 1 symbols of slack for the roll)
+                const uint64_t first = sp.first_base + a.stream_origin + (lo_e - o), end = sp.first_base + a.stream_origin + (hi_e - 1u - o) + k;
+                if (first < sym0 || end > sym0 + staged_syms) bad = 1u;
+            }
+        }
+    }
+    constexpr uint32_t N_WORDS = RG_MAX_PASSES * RG_UNIT / RUN / 64;
+    static_assert(N_WORDS <= 128 && N_WORDS % 2 == 0, "one wavefront scans the bitmap's words, two per lane");
+    if (tid < N_WORDS) L.bits[tid] = 0;
+    lds_atomics_settle();
+    if (__syncthreads_or((int)bad)) return false;           // (also orders the staging before what follows)
+    const bool any_flag = (FROM != 0 || flags) && __syncthreads_or((int)flagged) != 0;  // (uniform: both sides of the && are)
+    // ---- the bitmap of record beginnings
+    uint32_t *bits32 = reinterpret_cast<uint32_t *>(L.bits);
+    for (uint32_t i = 1u + tid; i < n_rec; i += 256u) {
+        const uint32_t rel = (uint32_t)L.slot[i];
+        const uint32_t j = (rel + RUN - 1u) / RUN;          // the first run that starts at or behind the record's first element
+        if (rel > 0u && j * RUN < n_el) atomicOr(&bits32[j >> 5], 1u << (j & 31u));  // (a record that begins inside the LAST run needs no bit)
+    }
+    block_sync();
+    if (tid < 64u) {                                        // exclusive prefix of the words' population counts (one wavefront, two words per lane)
+        const uint32_t c0 = 2u * tid < N_WORDS ? (uint32_t)__popcll(L.bits[2u * tid]) : 0u;
+        const uint32_t c1 = 2u * tid + 1u < N_WORDS ? (uint32_t)__popcll(L.bits[2u * tid + 1u]) : 0u;
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (uint32_t step = 1; step < 64u; step <<= 1) {
+            const uint32_t up = __shfl_up(incl, step, 64);
+            if (tid >= step) incl += up;
+        }
+        if (2u * tid < N_WORDS) {
+            L.base[2u * tid] = incl - c0 - c1;
+            L.base[2u * tid + 1u] = incl - c1;
+        }
+    }
+    block_sync();
+    // ---- the runs
+    if (any_flag) dense_runs<DST, MODE, true>(a, L, e0, n_el, fbase);
+    else dense_runs<DST, MODE, false>(a, L, e0, n_el, fbase);
     return true;
 }
 
@@ -493,7 +584,8 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
     __shared__ uint64_t off_l[RG_SLOTS + 1];    // element offset of every record slot of the tile
     __shared__ uint64_t delta_l[RG_SLOTS + 1];  // first stream symbol of the slot's record minus offset * stride: window of element g = delta + g * stride
     __shared__ uint64_t src_l[RG_STAGE + 2];
-    __shared__ uint64_t flg_l[RG_STAGE / 2 + 2];
+    __shared__ uint64_t flg_l[RG_STAGE / 2 + 4];
+    __shared__ uint64_t aux_l[RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64 * 3 / 2 + 2];  // the dense path's bitmap and its prefix counts
     const uint32_t tid = threadIdx.x;
     const uint32_t k = a.k;
     const uint64_t mask = head_mask((int)k, DST);
@@ -512,15 +604,21 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
     const uint64_t r_lo = d.r_lo;
     const uint64_t e_last = e0 + d.n_el - 1u;
     if constexpr (N == 1 && VEC) {
-        // dense tiles (comment above ragged_dense_tile): one-word kmers, aligned outputs, consecutive windows, a pool without flagged symbols
+        // dense tiles (comment above ragged_dense_tile): one-word kmers, aligned outputs, consecutive windows
+        DenseLds L;
+        L.slot = off_l;
+        L.src = src_l;
+        L.flg = flg_l;
+        L.bits = aux_l;
+        L.base = reinterpret_cast<uint32_t *>(aux_l + RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64);
+        static_assert(sizeof(aux_l) >= (RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64) * 12 + 16, "LDS carve");
         if constexpr (DST == 2) {
-            if (a.src4) {  // the optimistic launch (RaggedArgs): dense or nothing
-                DenseLds L;
-                L.slot = off_l;
-                L.src = src_l;
-                L.bits = flg_l;
-                L.base = reinterpret_cast<uint32_t *>(flg_l + RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64);
-                const bool done = a.tile <= (uint32_t)(RG_MAX_PASSES * RG_UNIT) && ragged_dense_tile<DST, MODE, true>(a, d, e0, (uint32_t)(e_last - e0 + 1), L);
+            if (a.src_opt) {  // the optimistic launch (RaggedArgs): dense or nothing
+                bool done = false;
+                if (a.tile <= (uint32_t)(RG_MAX_PASSES * RG_UNIT)) {
+                    if (a.opt_from == 8u) done = ragged_dense_tile<DST, MODE, 8>(a, d, e0, (uint32_t)(e_last - e0 + 1), L, nullptr);
+                    else done = ragged_dense_tile<DST, MODE, 4>(a, d, e0, (uint32_t)(e_last - e0 + 1), L, nullptr);
+                }
                 if (!done && tid == 0) {
                     a.tile_status[tile] = 1;
                     atomicAdd(a.redo_count, 1ull);
@@ -529,14 +627,8 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
             }
         }
         if (a.tile_status && !a.tile_status[tile]) return;  // (the launch after an optimistic one: this tile is done)
-        if (a.stride == 1u && !flags && a.dense >= 0 && a.tile <= (uint32_t)(RG_MAX_PASSES * RG_UNIT)) {
-            static_assert(sizeof(flg_l) >= (RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64) * 12 + 16, "LDS carve");
-            DenseLds L;
-            L.slot = off_l;
-            L.src = src_l;
-            L.bits = flg_l;
-            L.base = reinterpret_cast<uint32_t *>(flg_l + RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64);
-            if (ragged_dense_tile<DST, MODE, false>(a, d, e0, (uint32_t)(e_last - e0 + 1), L)) return;
+        if (a.stride == 1u && a.dense >= 0 && a.tile <= (uint32_t)(RG_MAX_PASSES * RG_UNIT)) {
+            if (ragged_dense_tile<DST, MODE, 0>(a, d, e0, (uint32_t)(e_last - e0 + 1), L, flags)) return;
             block_sync();  // (not dense: the general path below re-stages the tile)
         }
     }

@@ -251,6 +251,39 @@ __device__ __forceinline__ void store_kmer(uint64_t *out, uint64_t g, const uint
     }
 }
 
+// AsciiEncode of DNA / RNA text into a 2-bit alphabet without the table (text = 1: DNA, T valid; 2: RNA, U valid), 8 bytes at once:
+// the 16 bits of their codes, and `off` != 0 iff one of them is not a symbol.  On the 32-bit halves, priced by
+// profiles/r04_valu_rates.txt: the letter a code stands for comes from ONE v_perm (the code bytes select from "ACGT" / "ACGU"), the
+// four codes of a half are gathered by ONE v_dot4 (bytes times 1, 4, 16, 64), and the word gets one verdict; the flag of every
+// byte (text8_bad_bytes) is only computed if a byte is off.
+__device__ __forceinline__ uint32_t text8_codes(uint64_t x, uint32_t text, uint32_t &off) {
+    const uint32_t letters = text == 2u ? 0x55474341u : 0x54474341u;
+    auto half = [&](uint32_t d, uint32_t &o) {
+        const uint32_t U = d & 0xDFDFDFDFu;                   // upper case
+        const uint32_t c2 = (U >> 1) & 0x03030303u;
+        const uint32_t code = c2 ^ ((c2 >> 1) & 0x01010101u);
+        o |= U ^ __builtin_amdgcn_perm(letters, letters, code);  // (selector bytes 0..3: bytes of `letters`)
+        return __builtin_amdgcn_udot4(code, 0x40100401u, 0u, false);
+    };
+    off = 0;
+    const uint32_t lo = half((uint32_t)x, off), hi = half((uint32_t)(x >> 32), off);
+    return lo | (hi << 8);
+}
+// bit 8j: byte j of the word is not a symbol of the text's alphabet
+__device__ __forceinline__ uint64_t text8_bad_bytes(uint64_t x, uint32_t text) {
+    const uint64_t B1 = 0x0101010101010101ull;
+    const uint64_t U = x & 0xDFDFDFDFDFDFDFDFull;
+    const uint64_t c2 = (U >> 1) & (3ull * B1);
+    const uint64_t code = c2 ^ ((c2 >> 1) & B1);
+    const uint64_t b0 = code & B1, b1 = (code >> 1) & B1;
+    const uint64_t is1 = b0 & ~b1, is2 = b1 & ~b0, is3 = b0 & b1;
+    // the letter each code stands for: 'A' + {0, 2, 6, 0x13 ('T') or 0x14 ('U')}
+    uint64_t E = 0x41ull * B1 + (is1 << 1) + (is2 << 1) + (is2 << 2) + (is3 << 4) + (is3 << 1) + is3;
+    if (text == 2u) E += is3;
+    const uint64_t bad = U ^ E;
+    return ((bad | ((bad & (0x7Full * B1)) + (0x7Full * B1))) >> 7) & B1;
+}
+
 // Phase 1 for one source word: recode into the DST-bit LDS stream (RecodingScheme,
 // src/construction.jl:75-100).  Returns one flag per offending symbol at bit SRC*j (FourToTwo:
 // count_ones != 1; AsciiEncode: byte outside the alphabet), 0 otherwise.
@@ -266,34 +299,11 @@ __device__ __forceinline__ uint64_t stage_word(uint64_t *lds, uint32_t wi, uint6
         // byte is a symbol iff its upper-cased value is the letter its code stands for (BioSequences.ascii_encode restated;
         // ascii_tables.hpp holds the table this replaces, tests/c/ascii_entry_check.cpp compares the two over all 256 bytes).
         if (text) {
-            // On the 32-bit halves, priced by profiles/r04_valu_rates.txt: the letter a code stands for comes from ONE v_perm
-            // (the code bytes select from "ACGT" / "ACGU"), the four codes of a half are gathered by ONE v_dot4 (bytes times
-            // 1, 4, 16, 64), and the word gets one verdict; the flag of every byte is only computed if a byte is off.
-            const uint32_t letters = text == 2u ? 0x55474341u : 0x54474341u;
-            auto half = [&](uint32_t d, uint32_t &off) {
-                const uint32_t U = d & 0xDFDFDFDFu;                   // upper case
-                const uint32_t c2 = (U >> 1) & 0x03030303u;
-                const uint32_t code = c2 ^ ((c2 >> 1) & 0x01010101u);
-                off |= U ^ __builtin_amdgcn_perm(letters, letters, code);  // (selector bytes 0..3: bytes of `letters`)
-                return __builtin_amdgcn_udot4(code, 0x40100401u, 0u, false);
-            };
-            uint32_t off = 0;
-            const uint32_t lo = half((uint32_t)x, off), hi = half((uint32_t)(x >> 32), off);
-            const uint32_t codes = lo | (hi << 8);
+            uint32_t off;
+            const uint32_t codes = text8_codes(x, text, off);
             if constexpr (REV) reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)(rev2_32(codes) >> 16);
             else reinterpret_cast<uint16_t *>(lds)[wi] = (uint16_t)codes;
-            if (!off) return 0;
-            const uint64_t B1 = 0x0101010101010101ull;
-            const uint64_t U = x & 0xDFDFDFDFDFDFDFDFull;
-            const uint64_t c2 = (U >> 1) & (3ull * B1);
-            const uint64_t code = c2 ^ ((c2 >> 1) & B1);
-            const uint64_t b0 = code & B1, b1 = (code >> 1) & B1;
-            const uint64_t is1 = b0 & ~b1, is2 = b1 & ~b0, is3 = b0 & b1;
-            // the letter each code stands for: 'A' + {0, 2, 6, 0x13 ('T') or 0x14 ('U')}
-            uint64_t E = 0x41ull * B1 + (is1 << 1) + (is2 << 1) + (is2 << 2) + (is3 << 4) + (is3 << 1) + is3;
-            if (text == 2u) E += is3;
-            const uint64_t bad = U ^ E;
-            return ((bad | ((bad & (0x7Full * B1)) + (0x7Full * B1))) >> 7) & B1;  // bit 8j: byte j is not a symbol
+            return off ? text8_bad_bytes(x, text) : 0;
         }
     }
     if constexpr (SRC == 8) {  // AsciiEncode: 8 bytes -> 8 symbols through the alphabet's table

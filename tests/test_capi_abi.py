@@ -110,20 +110,3 @@ def test_class_pool_logic_on_the_cpu(tmp_path):
     assert out.returncode == 0 and "class_pool_check: ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
 
 
-def test_julia_binding_gates_base_collect():
-    """julia/KmersHIP.jl cannot run here (no Julia in the image); what can be pinned is its text: ONE Base.collect method, gated by
-    gpu_dispatch (sources below MIN_BASES keep Kmers.jl's own method), the explicit gpu_collect methods for every iterator the
-    library takes, and the same default threshold as the tested mirror."""
-    import re
-    src = open(os.path.join(ROOT, "julia", "KmersHIP.jl")).read()
-    code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
-    defs = re.findall(r"^(?:function\s+)?Base\.collect\(", code, flags=re.M)
-    assert len(defs) == 1, defs
-    gate = code[code.index("Base.collect(it::GpuIterator"):]
-    gate = gate[:gate.index("\n\n")]
-    assert "gpu_dispatch(it)" in gate and "invoke(collect, Tuple{Any}, it)" in gate and "gpu_collect(it)" in gate
-    for it in ("FwKmers", "FwRvIterator", "CanonicalKmers", "SpacedKmers", "UnambiguousKmers"):
-        assert re.search(rf"function gpu_collect\(it::{it}\{{", code), it
-    m = re.search(r'get\(ENV, "KMERS_HIP_MIN_BASES", "(\d+)"\)', code)
-    from kmers_jl_amd import host
-    assert m and int(m.group(1)) == host.MIN_BASES == 100_000

@@ -560,6 +560,92 @@ def test_batch_dense_tiles_equal_the_general_path_and_the_oracle(km, ctx, orc, s
     ctx.set_param(cap.PARAM_BATCH_PASSES, 0)
 
 
+@pytest.mark.parametrize("src", [4, 8])
+def test_batch_of_reads_with_ns_on_the_dense_path(km, ctx, orc, src):
+    """Reads as people have them (round 6): text or a 4-bit pool, lengths 50-250, an N in one read out of a hundred or out of ten
+    (docs/src/faq.md:28-33; src/iterators/UnambiguousKmers.jl:109-148).  A symbol the kmer alphabet cannot encode costs the ELEMENTS
+    whose windows hold it, not its tile: the dense tile path (csrc/ragged_kernels.hpp, dense_runs<FLAGGED>) writes the all-ones
+    sentinel itself (KMERS_BATCH_SKIP) or reports the first failing element (strict) -- from the recoded stream and, in the
+    optimistic launch, from the pool itself.  Against the oracle and against the general path (KMERS_PARAM_BATCH_DENSE = -1), host
+    and device outputs, device outputs with the count deferred to the end of the call."""
+    cap = km._capi
+    rng = np.random.default_rng(900 + src)
+    ones = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for K, dst, p_read in ((31, 2, 0.01), (31, 2, 0.10), (21, 2, 0.10), (9, 4, 0.05)):
+        n_rec = 6000
+        texts = []
+        for l in rng.integers(50, 251, n_rec):
+            t = naive.random_text(rng, int(l))
+            if rng.random() < p_read:                                   # one to three Ns somewhere in the read
+                t = list(t)
+                for pos in rng.integers(0, len(t), int(rng.integers(1, 4))):
+                    t[pos] = "N"
+                t = "".join(t)
+            if src == 8:
+                t = "".join(c.lower() if rng.random() < 0.2 else c for c in t)
+            texts.append(t)
+        words, spans, n_pool = build_pool(texts, src, rng, False)
+        seq = cap.Seq(words.ctypes.data, n_pool, 0, 0, src, 0)
+        N = 1
+        # what every element should be: the strict result of the clean windows, all-ones where a window holds an N
+        exp_a, exp_b, offs, first_bad = [], [], [0], None
+        for i, t in enumerate(texts):
+            n = max(0, len(t) - K + 1)
+            up = t.upper()
+            clean = up.replace("N", "A")
+            w = naive.ascii_words(clean) if src == 8 else naive.longseq_words(clean, src)
+            if dst == 2:
+                a, b, r = orc.canonical(w, len(t), src, dst, K, seed=5)
+            else:
+                a, b, r = orc.canonical(w, len(t), src, dst, K, seed=5)
+            assert r.status == 0
+            holds = np.array([("N" in up[j:j + K]) for j in range(n)], bool)
+            if dst == 4:                                                # a 4-bit kmer alphabet encodes N: nothing is masked, nothing fails
+                w2 = naive.ascii_words(t) if src == 8 else naive.longseq_words(up, src)
+                a, b, r = orc.canonical(w2, len(t), src, dst, K, seed=5)
+                holds[:] = False
+            a, b = a.copy(), b.copy()
+            a[holds] = ones
+            b[holds] = ones
+            if holds.any() and first_bad is None:
+                first_bad = (i, up.index("N") + 1)                     # the reference throws at the record's first N (1-based)
+            exp_a.append(a)
+            exp_b.append(b)
+            offs.append(offs[-1] + n)
+        exp_a, exp_b, total = np.concatenate(exp_a), np.concatenate(exp_b), offs[-1]
+        res = cap.Result()
+        got = {}
+        for dense in (0, -1):
+            ctx.set_param(cap.PARAM_BATCH_DENSE, dense)
+            a, b = np.zeros((total, N), np.uint64), np.zeros(total, np.uint64)
+            rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, n_rec, cap.BATCH_CANONICAL, K, dst, vp(a), vp(b), 5, None, total,
+                                     cap.BATCH_SKIP, C.byref(res))
+            assert rc == 0 and res.n_out == total, (src, K, dense, ctx.last_error())
+            assert np.array_equal(a, exp_a) and np.array_equal(b, exp_b), (src, K, dst, p_read, dense)
+            got[dense] = a
+            # strict: the first failing record and the position of its first N
+            rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), spans, n_rec, cap.BATCH_CANONICAL, K, dst, vp(a), vp(b), 5, None, total, 0, C.byref(res))
+            if first_bad is None:
+                assert rc == 0
+            else:
+                assert rc == cap.E_ENCODE and (int(res.n_out), int(res.err_pos)) == first_bad, (src, K, dense, int(res.n_out), int(res.err_pos), first_bad)
+        # device outputs: the count is read on the device, the call waits once (the optimistic launch) -- same elements
+        ctx.set_param(cap.PARAM_BATCH_DENSE, 0)
+        d_w, d_a, d_b = ctx.alloc(words.nbytes + 16), ctx.alloc(total * 8 + 16), ctx.alloc(total * 8 + 16)
+        ctx.h2d(d_w, words)
+        dseq = cap.Seq(d_w, n_pool, 0, 0, src, 0)
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(dseq), spans, n_rec, cap.BATCH_CANONICAL, K, dst, d_a, d_b, 5, None, total + 1000,
+                                 cap.BATCH_SKIP | cap.MEM_DEVICE, C.byref(res))
+        assert rc == 0 and res.n_out == total, ctx.last_error()
+        a, b = np.zeros((total, N), np.uint64), np.zeros(total, np.uint64)
+        ctx.d2h(a, d_a)
+        ctx.d2h(b, d_b)
+        assert np.array_equal(a, exp_a) and np.array_equal(b, exp_b), (src, K, "device outputs")
+        for q in (d_w, d_a, d_b):
+            ctx.free(q)
+    ctx.set_param(cap.PARAM_BATCH_DENSE, 0)
+
+
 def test_batch_with_device_outputs_waits_once_and_still_reports_everything(km, ctx, orc):
     """Device outputs and a sane capacity: the call sizes its layout for the CAPACITY and reads the element count on the device (no
     host round trip between the scan and the element kernel, csrc/batch_api.hip).  Same elements, the true count in res.n_out,
