@@ -54,7 +54,7 @@ FX_CONSTANT = 0x517CC1B727220A95
 GOLDEN = 0x9E3779B97F4A7C15
 NORTH_STAR_BASES = 10_000_000_000
 N_SIMDS = 1024  # 256 CUs x 4 SIMDs
-# What a SIMD of this device issues (tools/valu_rates.hip, profiles/r04_valu_rates.txt; cycles per wave64 vector instruction,
+# What a SIMD of this device issues (tools/device_probes/valu_rates.hip, profiles/r04_valu_rates.txt; cycles per wave64 vector instruction,
 # instructions of a launch / the launch's span, two or more wavefronts per SIMD): 2.24 for the simple two-operand integer
 # instructions over registers or literals (v_and / v_or / v_xor / v_add / v_sub / v_mov / right shifts; v_bitop3 over three
 # registers), 4.1 for everything else these kernels use (v_alignbit, v_perm, v_lshl_or, v_bfe, v_cndmask, compares, multiplies,
@@ -952,7 +952,7 @@ def measure_legs(args, device_index=0, timeout=600):
                     "valu_floor_ms": round(valu * VALU_CYCLES_FAST / N_SIMDS / (clock_ghz * 1e6), 4),
                     "valu_floor_ms_slow": round(valu * VALU_CYCLES_SLOW / N_SIMDS / (clock_ghz * 1e6), 4),
                     "source": f"one dispatch of a rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace child pass of this run, kernel {d['name'][:60]}; "
-                              f"issue rates {VALU_CYCLES_FAST} / {VALU_CYCLES_SLOW} cycles per instruction and SIMD: tools/valu_rates.hip, profiles/r04_valu_rates.txt"}
+                              f"issue rates {VALU_CYCLES_FAST} / {VALU_CYCLES_SLOW} cycles per instruction and SIMD: tools/device_probes/valu_rates.hip, profiles/r04_valu_rates.txt"}
     return res
 
 

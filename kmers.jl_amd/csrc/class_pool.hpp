@@ -3,7 +3,7 @@
 //
 // Why (profiles/r05_vmm.md): HBM on MI355X behaves as three REGION CLASSES of physical memory; store streams that run side by
 // side inside one class share ~6.0-6.4 TB/s, streams in different classes reach ~7.1-7.2 TB/s (profiles/r03_alloc.md).  The class
-// belongs to the PHYSICAL memory (tools/vmm_va.hip: the same handles mapped in reverse order give the mirrored map, one handle
+// belongs to the PHYSICAL memory (tools/device_probes/vmm_va.hip: the same handles mapped in reverse order give the mirrored map, one handle
 // mapped at many addresses a flat one).  Rounds 3-4 reserved most of HBM as one block and placed arrays inside its measured map;
 // the pool instead takes physical memory from HIP's virtual-memory management in 1 GiB handles, measures the class of each
 // once, and ASSEMBLES every block from handles of the classes it should have: the arrays of one launch in different classes at
@@ -11,7 +11,7 @@
 // how fine-grained the physical map of a box is, arrays of any size.
 //
 // (Why not finer: hipMemMap takes whole handles, so a stripe is a handle.  Arrays striped A B A B at 2-64 MiB do reach the
-// two-class rate with every write window, tools/vmm_stripes.hip -- but the class of a 32 MiB handle cannot be measured on its own
+// two-class rate with every write window, tools/device_probes/vmm_stripes.hip -- but the class of a 32 MiB handle cannot be measured on its own
 // (a probe needs ~1 GiB per stream to tell 6.2 from 7.2 TB/s), and consecutive small handles are NOT neighbours in memory: the
 // driver serves them from scattered fragments first, profiles/r05_pool_walk_32MiB_handles.txt.)
 #pragma once
@@ -314,7 +314,9 @@ inline const Block *partner_block(const State &s, size_t bytes, const Block **ot
 constexpr uint64_t CACHE_AGE_TICKS = 32;       // a cached block nobody asked for over this many allocations / frees is taken apart
 constexpr size_t HOARD_MIN_CHUNKS = 4;         // what the pool may hold beyond blocks (out or cached): representatives included,
 constexpr size_t HOARD_FRACTION = 4;           //   max(HOARD_MIN_CHUNKS, 1 / HOARD_FRACTION of the chunks in blocks)
-constexpr float GOOD_PLAN = 0.95f;             // the pool grows (within its search budget) until a block's plan is this good
+constexpr float GOOD_PLAN = 0.985f;            // the pool grows (within its search budget) until a block's plan is this good (0.95 until
+                                               // round 6: an 80 GB array was accepted with 3 of its 75 handles in its partner's class, and the 1 Gbase
+                                               // slice that lay on them ran 12 % slower than its neighbours, profiles/r06_n1.md)
 
 // the classes a new block of `bytes` should NOT have, chunk by chunk, beside `partner` (plan()'s rule for ROLE_DEFAULT)
 inline std::vector<uint8_t> forbidden_beside(const Block *partner, size_t bytes) {

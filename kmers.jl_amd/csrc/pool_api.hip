@@ -1,7 +1,7 @@
 // pool_api.hip -- the device's CLASS POOL behind kmers_dev_alloc (include/kmers_hip.h, "device memory"): physical memory in 1 GiB
 // handles of HIP's virtual-memory management, the HBM region class of every handle MEASURED once, every block assembled from
 // handles of the classes it should have.  The pure logic (which classes where) is csrc/class_pool.hpp; the measurements behind
-// the design are profiles/r05_vmm.md (tools/vmm_va.hip, vmm_stripes.hip, vmm_life.hip).
+// the design are profiles/r05_vmm.md (tools/device_probes/vmm_va.hip, vmm_stripes.hip, vmm_life.hip).
 //
 // What the reference does here: `collect(CanonicalDNAMers{31}(seq))` allocates one Vector per call (src/iterators/CanonicalKmers.jl:
 // 199-225 yields the elements; Base.collect makes the array).  On this device WHERE such an array lies is worth 15 % of the rate
@@ -10,7 +10,7 @@
 // interleaved in physical memory: it grows by one handle at a time as blocks are asked for and holds what it was asked for plus
 // what it had to walk past to find the classes it wanted (until kmers_pool_trim).
 //
-// Three properties of the VMM calls on this stack (ROCm 7.2, measured by tools/vmm_life.hip) shape the code:
+// Three properties of the VMM calls on this stack (ROCm 7.2, measured by tools/device_probes/vmm_life.hip) shape the code:
 //   * hipMemMap takes whole handles (no offset).
 //   * A range that is unmapped and mapped again -- in place, or after hipMemAddressFree and a new reservation that returns the
 //     same address -- keeps its OLD translations in the device's TLB until something flushes it; a hipMalloc + hipFree does

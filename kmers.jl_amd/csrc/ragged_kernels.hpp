@@ -478,40 +478,115 @@ __device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const Rag
     uint32_t bad = (d.n_words == 0u || n_rec > (uint32_t)RG_SLOTS + 1u || n_rec < 2u) ? 1u : 0u;
     uint32_t flagged = 0, n_flg = 0, fbase = 0;
     // (the stretch of the stream first: its loads are in flight beside those of the record slots -- one round trip, not two)
-    if constexpr (FROM == 4) {
-        uint32_t *src32 = reinterpret_cast<uint32_t *>(L.src);
-        uint16_t *flg16 = reinterpret_cast<uint16_t *>(L.flg);
-        const uint32_t n_in = 2u * d.n_words, n_pad = (n_in + 3u) & ~3u;  // (whole flag words: the padding is unflagged)
-        for (uint32_t i = tid; i < n_pad; i += 256u) {
-            const uint64_t wi = 2u * d.q_lo + i;  // (a stretch may end half a stream word past the pool's last word: all A there, in no window)
-            uint32_t any_bad;
-            const uint64_t x = i < n_in && wi < a.n_src_words ? a.src_opt[wi] : 0x1111111111111111ull;
-            const uint32_t c = pack_4to2_checked(x, any_bad);  // FourToTwo, construction_utils.jl:47-52
-            if (i < n_in) src32[i] = c;
-            const uint32_t f = any_bad ? (uint32_t)bad_bits16(bad_nibbles4(x)) & 0xffffu : 0u;  // a symbol that is not one-hot: which ones
-            flg16[i] = (uint16_t)f;
-            flagged |= f;
+    // the record slots: two steps per lane cover the RG_SLOTS + 1 slots; their loads are issued together with the stretch's
+    uint64_t slot_o[2] = {0, 0}, slot_next[2] = {0, 0};
+    RaggedSpan slot_sp[2] = {{0, 0}, {0, 0}};
+    auto slots_load = [&]() {
+#pragma unroll
+        for (uint32_t t = 0; t < 2u; ++t) {
+            const uint32_t i = tid + t * 256u;
+            if (i < n_rec) {
+                const uint64_t rec = d.r_lo + (uint64_t)i;
+                const bool real = rec < a.n_records;
+                slot_o[t] = a.rec_off[rec];
+                slot_next[t] = (i + 1u < n_rec && real) ? a.rec_off[rec + 1] : 0;
+                slot_sp[t] = real ? a.spans[rec] : RaggedSpan{0, 0};
+            }
         }
-        n_flg = n_pad / 4u;
-    } else if constexpr (FROM == 8) {
-        uint16_t *src16 = reinterpret_cast<uint16_t *>(L.src);
-        uint8_t *flg8 = reinterpret_cast<uint8_t *>(L.flg);
-        const uint32_t n_in = 4u * d.n_words, n_pad = (n_in + 7u) & ~7u;
-        for (uint32_t i = tid; i < n_pad; i += 256u) {
-            const uint64_t wi = 4u * d.q_lo + i;
-            uint32_t off;
-            const uint64_t x = i < n_in && wi < a.n_src_words ? a.src_opt[wi] : 0x4141414141414141ull;
-            const uint32_t c = text8_codes(x, a.text, off);  // AsciiEncode, src/construction.jl:94-95
-            if (i < n_in) src16[i] = (uint16_t)c;
-            const uint32_t f = off ? gather_byte_flags(text8_bad_bytes(x, a.text)) : 0u;
-            flg8[i] = (uint8_t)f;
-            flagged |= f;
+    };
+    auto slot_stage = [&](uint32_t i, uint64_t o, uint64_t o_next, const RaggedSpan &sp) {
+        const bool real = d.r_lo + (uint64_t)i < a.n_records;
+        const uint32_t rel = o <= e0 ? 0u : (o - e0 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)(o - e0));
+        const uint32_t delta = (uint32_t)(sp.first_base + a.stream_origin + e0 - o - sym0);
+        L.slot[i] = (uint64_t)rel | ((uint64_t)delta << 32);
+        if (i + 1u == n_rec && rel < n_el) bad = 1u;        // more records than slots: the staged slice does not close the tile
+        if (i + 1u < n_rec && real) {                       // (the last slot only closes the search range)
+            const uint64_t lo_e = o > e0 ? o : e0, hi_e = o_next < e0 + n_el ? o_next : e0 + n_el;  // its elements inside the tile
+            if (o_next - o < (uint64_t)RUN) bad = 1u;       // a record that owns fewer than RUN elements (or none)
+            if (hi_e > lo_e) {                              // its windows must lie in the staged stretch (RUN - 1 symbols of slack for the roll)
+                const uint64_t first = sp.first_base + a.stream_origin + (lo_e - o), end = sp.first_base + a.stream_origin + (hi_e - 1u - o) + k;
+                if (first < sym0 || end > sym0 + staged_syms) bad = 1u;
+            }
         }
-        n_flg = n_pad / 8u;
+    };
+    // A tile's lifetime is what the launch is made of (about seven tiles per CU at a time): every round trip to HBM in front of the
+    // stores counts, and under the launch's own store traffic a round takes microseconds.  So ALL loads of the stretch are issued
+    // before any of them is used -- up to STEPS steps of two source words per lane held in registers (a longer stretch takes the
+    // plain loop for the rest) -- and 16 bytes at a time where the pool's base allows it.
+    if constexpr (FROM == 4 || FROM == 8) {
+        constexpr uint32_t PER = FROM == 4 ? 2u : 4u;     // source words per stream word
+        constexpr uint64_t FILL = FROM == 4 ? 0x1111111111111111ull : 0x4141414141414141ull;  // "A": in no window, never flagged
+        constexpr uint32_t STEPS = FROM == 4 ? 2u : 4u;   // 512 / 1024 pairs of words: stretches of 512 stream words (16 k symbols)
+        const uint64_t w0 = (uint64_t)PER * d.q_lo;       // (a stretch may end past the pool's last word: FILL there)
+        const uint64_t want = (uint64_t)PER * d.n_words;
+        const uint32_t avail = w0 < a.n_src_words ? (uint32_t)(a.n_src_words - w0 < want ? a.n_src_words - w0 : want) : 0u;
+        const uint64_t *src = a.src_opt + w0;
+        const uint32_t n_pairs = (uint32_t)want / 2u;
+        const uint32_t n_pad = FROM == 4 ? (n_pairs + 1u) & ~1u : (n_pairs + 3u) & ~3u;  // (whole flag words: the padding is unflagged)
+        const bool wide = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+        auto load_pair = [&](uint32_t i, uint64_t &x0, uint64_t &x1) {
+            const uint32_t w = 2u * i;
+            if (wide && w + 1u < avail) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + w);
+                x0 = v.x;
+                x1 = v.y;
+            } else {
+                x0 = w < avail ? src[w] : FILL;
+                x1 = w + 1u < avail ? src[w + 1u] : FILL;
+            }
+        };
+        auto stage_pair = [&](uint32_t i, uint64_t x0, uint64_t x1) {
+            if constexpr (FROM == 4) {
+                uint32_t bad0, bad1;
+                const uint32_t c0 = pack_4to2_checked(x0, bad0), c1 = pack_4to2_checked(x1, bad1);  // FourToTwo, construction_utils.jl:47-52
+                if (i < n_pairs) L.src[i] = (uint64_t)c0 | ((uint64_t)c1 << 32);
+                uint32_t f = 0;                     // a symbol that is not one-hot: which ones
+                if (bad0 | bad1) f = (bad0 ? bad_bits16(bad_nibbles4(x0)) : 0u) | ((bad1 ? bad_bits16(bad_nibbles4(x1)) : 0u) << 16);
+                reinterpret_cast<uint32_t *>(L.flg)[i] = f;
+                flagged |= f;
+            } else {
+                uint32_t off0, off1;
+                const uint32_t c0 = text8_codes(x0, a.text, off0), c1 = text8_codes(x1, a.text, off1);  // AsciiEncode, src/construction.jl:94-95
+                if (i < n_pairs) reinterpret_cast<uint32_t *>(L.src)[i] = c0 | (c1 << 16);
+                uint32_t f = 0;
+                if (off0 | off1) f = (off0 ? gather_byte_flags(text8_bad_bytes(x0, a.text)) : 0u) | ((off1 ? gather_byte_flags(text8_bad_bytes(x1, a.text)) : 0u) << 8);
+                reinterpret_cast<uint16_t *>(L.flg)[i] = (uint16_t)f;
+                flagged |= f;
+            }
+        };
+        uint64_t x[STEPS][2];
+#pragma unroll
+        for (uint32_t t = 0; t < STEPS; ++t) {
+            x[t][0] = x[t][1] = FILL;
+            if (tid + t * 256u < n_pad) load_pair(tid + t * 256u, x[t][0], x[t][1]);
+        }
+        slots_load();                                       // (in flight beside the stretch's words: one round trip, not two)
+#pragma unroll
+        for (uint32_t t = 0; t < STEPS; ++t)
+            if (tid + t * 256u < n_pad) stage_pair(tid + t * 256u, x[t][0], x[t][1]);
+        for (uint32_t i = tid + STEPS * 256u; i < n_pad; i += 256u) {
+            uint64_t x0, x1;
+            load_pair(i, x0, x1);
+            stage_pair(i, x0, x1);
+        }
+        n_flg = FROM == 4 ? n_pad / 2u : n_pad / 4u;
     } else {
-        for (uint32_t i = tid; i < d.n_words; i += 256u) L.src[i] = a.stream[d.q_lo + i];
+        uint64_t y[2] = {0, 0}, g[1] = {0};
+#pragma unroll
+        for (uint32_t t = 0; t < 2u; ++t)
+            if (tid + t * 256u < d.n_words) y[t] = a.stream[d.q_lo + tid + t * 256u];
+        if (flags && tid < d.n_fwords) g[0] = flags[d.f_lo + tid];
+        slots_load();
+#pragma unroll
+        for (uint32_t t = 0; t < 2u; ++t)
+            if (tid + t * 256u < d.n_words) L.src[tid + t * 256u] = y[t];
+        for (uint32_t i = tid + 512u; i < d.n_words; i += 256u) L.src[i] = a.stream[d.q_lo + i];
         if (flags) {
-            for (uint32_t i = tid; i < d.n_fwords; i += 256u) {
+            if (tid < d.n_fwords) {
+                L.flg[tid] = g[0];
+                flagged |= g[0] != 0 ? 1u : 0u;
+            }
+            for (uint32_t i = tid + 256u; i < d.n_fwords; i += 256u) {
                 const uint64_t w = flags[d.f_lo + i];
                 L.flg[i] = w;
                 flagged |= w != 0 ? 1u : 0u;
@@ -524,24 +599,10 @@ __device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const Rag
         L.src[d.n_words + tid] = 0;
         L.flg[n_flg + tid] = 0;
     }
-    for (uint32_t i = tid; i < n_rec; i += 256u) {
-        const uint64_t rec = d.r_lo + (uint64_t)i;
-        const uint64_t o = a.rec_off[rec];
-        const bool real = rec < a.n_records;
-        const RaggedSpan sp = real ? a.spans[rec] : RaggedSpan{0, 0};
-        const uint32_t rel = o <= e0 ? 0u : (o - e0 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)(o - e0));
-        const uint32_t delta = (uint32_t)(sp.first_base + a.stream_origin + e0 - o - sym0);
-        L.slot[i] = (uint64_t)rel | ((uint64_t)delta << 32);
-        if (i + 1u == n_rec && rel < n_el) bad = 1u;        // more records than slots: the staged slice does not close the tile
-        if (i + 1u < n_rec && real) {                       // (the last slot only closes the search range)
-            const uint64_t o_next = a.rec_off[rec + 1];
-            const uint64_t lo_e = o > e0 ? o : e0, hi_e = o_next < e0 + n_el ? o_next : e0 + n_el;  // its elements inside the tile
-            if (o_next - o < (uint64_t)RUN) bad = 1u;       // a record that owns fewer than RUN elements (or none)
-            if (hi_e > lo_e) {                              // its windows must lie in the staged stretch (RUN - 1 symbols of slack for the roll)
-                const uint64_t first = sp.first_base + a.stream_origin + (lo_e - o), end = sp.first_base + a.stream_origin + (hi_e - 1u - o) + k;
-                if (first < sym0 || end > sym0 + staged_syms) bad = 1u;
-            }
-        }
+    {
+#pragma unroll
+        for (uint32_t t = 0; t < 2u; ++t)
+            if (tid + t * 256u < n_rec) slot_stage(tid + t * 256u, slot_o[t], slot_next[t], slot_sp[t]);
     }
     constexpr uint32_t N_WORDS = RG_MAX_PASSES * RG_UNIT / RUN / 64;
     static_assert(N_WORDS <= 128 && N_WORDS % 2 == 0, "one wavefront scans the bitmap's words, two per lane");

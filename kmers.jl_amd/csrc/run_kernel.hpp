@@ -202,7 +202,7 @@ __global__ __launch_bounds__(RBLOCK) void run_kernel(const StreamArgs a) {
                     // complemented stream moved down by 2K bits once per run.  Below a kmer's 2K bits sit later symbols of the
                     // stream: they cannot change fw < rc unless the kmers are equal (then either is the canonical one) and they
                     // are shifted out where the kmer is used (XOR: once per lane at the end, shifts commute with XOR).
-                    // 36 cycles of a SIMD per kmer where the rolling step takes 50-54 (tools/roll_rate.hip).
+                    // 36 cycles of a SIMD per kmer where the rolling step takes 50-54 (tools/device_probes/roll_rate.hip).
                     const uint32_t up = 64u - 2u * k;  // 0..62
                     const uint64_t n0 = ~W[0], n1 = ~W[1];
                     const uint64_t A = n0 << up, B = ((n0 >> (2u * k - 1u)) >> 1) | (n1 << up);  // (~W0 : ~W1) >> 2K, zeros below

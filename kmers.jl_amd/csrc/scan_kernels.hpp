@@ -7,7 +7,7 @@
 // has it, then sums the descriptors of the segments before it, nearest first, until it meets one that already holds an inclusive
 // PREFIX; it never waits for a predecessor's prefix, only for aggregates, and every predecessor is a workgroup that is already
 // running (segments are numbered by a ticket drawn at the start, not by blockIdx).  128 MB of spans read, 64 MB of offsets
-// written, nothing else.  What it costs besides (tools/layout_bench.hip, 8 M records): the tickets -- atomics on one address
+// written, nothing else.  What it costs besides (tools/device_probes/layout_bench.hip, 8 M records): the tickets -- atomics on one address
 // retire one per 7.5 ns, and a workgroup cannot load anything before it has its own: 3906 segments of 2048 paid 30 us for them --
 // and the look-back's descriptor loads, which go past the L2 (agent scope): hence long segments, few descriptors, two words each.
 //
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void ragged_layout_kernel(const LayoutArgs a) 
     }
 }
 
-// Chunks per segment (tools/layout_bench.hip; 1 / 2 / 4 / 8 chunks): 1 M records 21 / 18 / 22 / 34 us, 8 M 90 / 65 / 63 / 88 us,
+// Chunks per segment (tools/device_probes/layout_bench.hip; 1 / 2 / 4 / 8 chunks): 1 M records 21 / 18 / 22 / 34 us, 8 M 90 / 65 / 63 / 88 us,
 // 40 M 346 / 302 / 354 / 569 us -- short segments pay for tickets and descriptors, long ones serialise their own phases.
 constexpr int LAYOUT_CHUNKS = 2;
 

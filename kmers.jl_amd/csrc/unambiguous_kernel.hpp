@@ -24,7 +24,7 @@
 //
 // Round 4 (profiles/r04_unamb.md).  The kernel without its stores runs in 0.35 ms per Gbase on the C5 lattice and 0.50 at K = 31
 // (close to what its vector instructions cost the SIMDs: 2.24 cycles each for the simple two-operand integer ones, 4.1 for all
-// others, tools/valu_rates.hip), its stores alone take 0.30 / 0.60 ms at the 7.4 TB/s a persistent grid writes into two region
+// others, tools/device_probes/valu_rates.hip), its stores alone take 0.30 / 0.60 ms at the 7.4 TB/s a persistent grid writes into two region
 // classes, and together they take 0.55 / 0.86: a wavefront that meets a full store queue stalls with its arithmetic behind it.
 // What this version changed: a lane owns the qwords lane, 64 + lane, ... of its wavefront's quarter and a round is
 // exactly one qword per lane (no lane shuffles, half the rounds), the list is frame-aligned and worked off two frames per step
@@ -44,7 +44,7 @@ namespace kmers {
 // and 3 x 65536 ran the same, 7 x 28672, 8 x 24576 and 2 x 98304 lost: profiles/r03_tuning.md); with this round's kernel, on one
 // box: 4 x 49152 K = 31 0.900-0.917 ms / lattice 0.565-0.577, 3 x 49152 0.870-0.885 / 0.558, 3 x 65536 0.842-0.852 / 0.542-0.551
 // (round 3's kernel beside them: 0.860-0.866 / 0.565; profiles/r04_unamb.md) -- the kernel writes at the rate the device takes
-// stores from a persistent grid, and that rate falls with the number of resident workgroups (tools/store_pacing.hip)
+// stores from a persistent grid, and that rate falls with the number of resident workgroups (tools/device_probes/store_pacing.hip)
 #ifndef KMERS_UTILE_MAX
 #define KMERS_UTILE_MAX 65536
 #endif

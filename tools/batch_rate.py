@@ -16,9 +16,7 @@ dev = torch.device("cuda", 0)
 K = int(os.environ.get("BATCH_K", "31"))   # BATCH_K=63: two-word kmers
 NW = (2 * K + 63) // 64
 res = cap.Result()
-ARENA = "--arena" in sys.argv
-if ARENA:
-    ctx.arena_reserve(int(150e9))
+ARENA = "--pool" in sys.argv or "--arena" in sys.argv   # outputs from kmers_dev_alloc (the class pool) instead of torch
 if "--passes" in sys.argv:   # force the tile length (1..8 passes of 1024 elements) instead of the per-call choice
     ctx.set_param(cap.PARAM_BATCH_PASSES, int(sys.argv[sys.argv.index("--passes") + 1]))
 CASES = (("10 M reads x 150", 10_000_000, 150, 151, 4), ("10 M reads x 150", 10_000_000, 150, 151, 2),
@@ -49,7 +47,7 @@ for label, n_reads, lo, hi, src in CASES:
     spans_h = np.stack([starts, lens], axis=1).copy()
     spans_d = torch.from_numpy(spans_h.view(np.int64)).to(dev)
     total = int(np.maximum(lens.astype(np.int64) - K + 1, 0).sum())
-    if ARENA:   # outputs from the context's arena (two region classes), like bench.py's
+    if ARENA:   # outputs from the device's class pool (two region classes), like bench.py's
         pk, ph = ctx.alloc(total * NW * 8), ctx.alloc(total * 8)
         out_k = out_h = None
     else:

@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Files what `tools/evidence.sh` measured on the GPU box (gpurun_out/<round>ev/) under profiles/<round>_* (KMERS_ROUND, default r05):
+"""Files what `tools/evidence.sh` measured on the GPU box (gpurun_out/<round>ev/) under profiles/<round>_* (KMERS_ROUND, default r06).
+    python tools/evidence.py [<dir of box 1> [<dir of box 2> ...]]      (directories under gpurun_out/; default <round>ev)
+ONE table, a column per box (round 6; round 5 committed a file set per box): the files below are those of the FIRST box, a further
+box adds its columns to <round>_legs.md and leaves its two bench lines as <round>_box<n>_bench*.json.
+
 
   <round>_bench.json                 the driver's command, as printed
   <round>_bench_under_rocprof.json   the same program under rocprofv3 --kernel-trace --stats (its line) ...
@@ -19,8 +23,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = os.environ.get("KMERS_ROUND", "r05")
-E = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else RND + "ev")
+RND = os.environ.get("KMERS_ROUND", "r06")
+BOXES = [os.path.join(ROOT, "gpurun_out", d) for d in (sys.argv[1:] or [RND + "ev"])]
+E = BOXES[0]
 P = os.path.join(ROOT, "profiles")
 L = 1_000_000_000
 LEGS = {  # leg -> (label, kernel substring, algorithmic bytes per launch given the leg's printed line)
@@ -41,6 +46,11 @@ LEGS = {  # leg -> (label, kernel substring, algorithmic bytes per launch given 
     "f127": ("FwDNAMers{127} + reverse complements (four-word kmers)", "stream_kernel<4, 2, 4, 0", lambda kept: 64.5 * (L - 126)),
     "comp8": ("fused composition counts of FwDNAMers{8}", "composition_kernel", lambda kept: 0.0),
     "batch": ("kmers_batch: 8 M reads x 125 bases, CanonicalDNAMers{31} + fx_hash per read (element kernel only)", "ragged_kernel", lambda kept: 16.0 * 8_000_000 * 95 + 0.5 * 1e9),
+    "batch_ascii": ("kmers_batch: the same reads from ASCII text (element kernel only)", "ragged_kernel", lambda kept: 16.0 * 8_000_000 * 95 + 1.0 * 1e9),
+    "batch_n10": ("kmers_batch: an N in 10 % of the reads, KMERS_BATCH_SKIP, 4-bit pool (element kernel only)", "ragged_kernel", lambda kept: 16.0 * 8_000_000 * 95 + 0.5 * 1e9),
+    "batch_ascii_n10": ("kmers_batch: an N in 10 % of the reads, KMERS_BATCH_SKIP, from text (element kernel only)", "ragged_kernel", lambda kept: 16.0 * 8_000_000 * 95 + 1.0 * 1e9),
+    "batch_ragged": ("kmers_batch: 6.67 M reads of 50-250 bases, 4-bit pool (element kernel only)", "ragged_kernel", lambda kept: 0.0),
+    "batch_ascii_ragged": ("kmers_batch: 6.67 M reads of 50-250 bases from text (element kernel only)", "ragged_kernel", lambda kept: 0.0),
 }
 
 
@@ -70,48 +80,64 @@ def main():
             json.dump(d, open(os.path.join(P, RND + "_" + name), "w"), indent=1)
     copy(os.path.join(E, "kernel_stats.csv"), RND + "_kernel_stats.csv")
     bench = first_json_line(os.path.join(E, "bench.json")) or {}
-    rows = [f"# Round {RND[1:].lstrip('0')}: every leg in a rocprofv3 pass of its own (`tools/evidence.sh`, one MI355X, outputs from the device's class pool)", "",
-            f"`ms (rocprofv3)` = average duration of the leg's kernel in `profiles/{RND}_kernel_stats_<leg>.csv` (a `--kernel-trace --stats` pass over",
-            "`tools/leg.py --leg <leg>`: warm-up launches + 20 timed ones); `ms (HIP events)` = the median the same process printed; fractions",
+    nb = len(BOXES)
+    rows = [f"# Round {RND[1:].lstrip('0')}: every leg in a rocprofv3 pass of its own (`tools/evidence.sh`, {nb} MI355X box{'es' if nb > 1 else ''}, outputs from the device's class pool)", "",
+            f"`ms (rocprofv3)` = average duration of the leg's kernel in a `--kernel-trace --stats` pass over `tools/leg.py --leg <leg>` (warm-up launches",
+            f"+ 20 timed ones; box 1's summaries are `profiles/{RND}_kernel_stats_<leg>.csv`); `ms (HIP events)` = the median the same process printed; fractions",
             "are of 8 TB/s on the algorithmic bytes of SURVEY.md 8(d).  HBM bytes: `FETCH_SIZE x 2` (gfx950: the counter reports half of a",
-            "coalesced streaming read) `+ WRITE_SIZE`, separate passes over two bare launches (`leg.py --once`).", "",
-            "| leg | kernel | calls | ms (rocprofv3) | frac | ms (HIP events) | frac | HBM bytes / algorithmic |", "|---|---|---|---|---|---|---|---|"]
+            "coalesced streaming read) `+ WRITE_SIZE`, separate passes over two bare launches (`leg.py --once`), box 1.", "",
+            "| leg | kernel | " + " | ".join(f"box {b + 1}: ms (rocprofv3) / frac / ms (events) / frac" for b in range(nb)) + " | HBM bytes / algorithmic (box 1) |",
+            "|---|---|" + "---|" * (nb + 1)]
     for leg, (label, sub, alg_of) in LEGS.items():
-        stats = os.path.join(E, f"kernel_stats_{leg}.csv")
-        if not copy(stats, f"{RND}_kernel_stats_{leg}.csv"):
-            continue
-        kept, ev_ms = 0, None
-        try:
-            last = [l for l in open(os.path.join(E, f"stats_{leg}.txt")) if l.startswith(leg) or l.startswith("kmers_batch")][-1]
-            m = re.search(r"kept=(\d+)", last)
-            kept = int(m.group(1)) if m else 0
-            m = re.search(r": ([0-9.]+) ms", last)
-            ev_ms = float(m.group(1)) if m else None
-        except (OSError, IndexError):
-            pass
-        alg = alg_of(kept)
-        best = None
-        for r in csv.DictReader(open(stats)):
-            if sub in r["Name"] and (best is None or float(r["TotalDurationNs"]) > float(best["TotalDurationNs"])):
-                best = r
-        if not best:
-            continue
-        ms = float(best["AverageNs"]) / 1e6
-        traffic = ""
-        vals = {}
-        for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            v = []
-            for f in glob.glob(os.path.join(E, f"pmc_{c}_{leg}", "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    if sub in r["Kernel_Name"] and r["Counter_Name"] == c:
-                        v.append(float(r["Counter_Value"]))
-            if v:
-                vals[c] = sum(v) / len(v)
-        if len(vals) == 2 and alg:
-            tot = vals["FETCH_SIZE"] * 2048 + vals["WRITE_SIZE"] * 1024
-            traffic = f"{tot / 1e9:.3f} GB / {alg / 1e9:.3f} GB = {tot / alg:.3f}"
-        fr = lambda t: f"{alg / t / 1e6 / 8000:.3f}" if alg and t else "-"
-        rows.append(f"| {label} | `{best['Name'][:70]}` | {best['Calls']} | {ms:.4f} | {fr(ms)} | {ev_ms if ev_ms else '-'} | {fr(ev_ms)} | {traffic} |")
+        cells, kname, traffic = [], "", ""
+        for bi, box in enumerate(BOXES):
+            stats = os.path.join(box, f"kernel_stats_{leg}.csv")
+            if not os.path.exists(stats):
+                cells.append("-")
+                continue
+            if bi == 0:
+                copy(stats, f"{RND}_kernel_stats_{leg}.csv")
+            kept, ev_ms, alg_printed = 0, None, None
+            try:
+                last = [l for l in open(os.path.join(box, f"stats_{leg}.txt")) if l.startswith(leg.split("_")[0]) or l.startswith("kmers_batch")][-1]
+                m = re.search(r"kept=(\d+)", last)
+                kept = int(m.group(1)) if m else 0
+                m = re.search(r": ([0-9.]+) ms", last)
+                ev_ms = float(m.group(1)) if m else None
+            except (OSError, IndexError):
+                pass
+            alg = alg_of(kept)
+            best = None
+            for r in csv.DictReader(open(stats)):
+                if sub in r["Name"] and (best is None or float(r["TotalDurationNs"]) > float(best["TotalDurationNs"])):
+                    best = r
+            if not best:
+                cells.append("-")
+                continue
+            kname = kname or best["Name"][:70]
+            ms = float(best["AverageNs"]) / 1e6
+            fr = lambda t: f"{alg / t / 1e6 / 8000:.3f}" if alg and t else "-"
+            cells.append(f"{ms:.4f} / {fr(ms)} / {ev_ms if ev_ms else '-'} / {fr(ev_ms)}")
+            if bi == 0:
+                vals = {}
+                for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                    v = []
+                    for f in glob.glob(os.path.join(box, f"pmc_{c}_{leg}", "**", "*counter_collection.csv"), recursive=True):
+                        for r in csv.DictReader(open(f)):
+                            if sub in r["Kernel_Name"] and r["Counter_Name"] == c:
+                                v.append(float(r["Counter_Value"]))
+                    if v:
+                        vals[c] = sum(v) / len(v)
+                if len(vals) == 2 and alg:
+                    tot = vals["FETCH_SIZE"] * 2048 + vals["WRITE_SIZE"] * 1024
+                    traffic = f"{tot / 1e9:.3f} GB / {alg / 1e9:.3f} GB = {tot / alg:.3f}"
+        if kname:
+            rows.append(f"| {label} | `{kname}` | " + " | ".join(cells) + f" | {traffic} |")
+    for bi, box in enumerate(BOXES[1:], start=2):   # the further boxes' bench lines
+        for name in ("bench.json", "bench_under_rocprof.json"):
+            d = first_json_line(os.path.join(box, name))
+            if d:
+                json.dump(d, open(os.path.join(P, f"{RND}_box{bi}_{name}"), "w"), indent=1)
     if copy(os.path.join(E, "kernel_stats_minhash_batch.csv"), f"{RND}_kernel_stats_minhash_batch.csv"):
         try:
             lines = [l.strip() for l in open(os.path.join(E, "stats_minhash_batch.txt")) if "records" in l or "genomes" in l or "reads" in l]
@@ -120,15 +146,16 @@ def main():
             pass
     # the headline launch by allocator
     sweep = []
-    for f in sorted(glob.glob(os.path.join(E, "alloc_*.json"))):
+    for bi, box in enumerate(BOXES):
+      for f in sorted(glob.glob(os.path.join(box, "alloc_*.json"))):
         d = first_json_line(f)
         if d:
             cfgd = d.get("config", {})
-            sweep.append(f"| {cfgd.get('alloc', '?')} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} | {d['value']} | "
-                         f"{(cfgd.get('pool') or {}).get('held_GB', '') or cfgd.get('arena_region_map') or ''} |")
+            sweep.append(f"| box {bi + 1}: {cfgd.get('alloc', '?')} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} | {d['value']} | "
+                         f"{(cfgd.get('pool') or {}).get('held_GB', '') or ''} |")
     if sweep:
         rows += ["", "## The headline launch (C2, 1 Gbase) by where its arrays come from (`bench.py --alloc ...`, same box, one process each)", "",
-                 "| allocator | kernel ms | frac of 8 TB/s | Gbases/s | pool: GB held / arena: measured map |", "|---|---|---|---|---|"] + sweep
+                 "| allocator | kernel ms | frac of 8 TB/s | Gbases/s | pool: GB held |", "|---|---|---|---|---|"] + sweep
     open(os.path.join(P, RND + "_legs.md"), "w").write("\n".join(rows) + "\n")
     rf = bench.get("roofline", {})
     if rf.get("traffic") and "measured in this run" in rf.get("traffic_source", ""):

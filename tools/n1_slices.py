@@ -40,6 +40,12 @@ pa, pb, psrc = ctx.alloc(8 * n), ctx.alloc(8 * n), ctx.alloc(8 * (nw + 2))
 info = ctx.pool_info()
 runs = lambda p: "".join("ABC?"[c] for c in ctx.pool_layout(p)[1])
 print(f"pool held {info['held'] / 2**30:.0f} GiB, in use {info['in_use'] / 2**30:.0f}; a {runs(pa)}\n{' ' * 38}b {runs(pb)}", flush=True)
+# (round 6) the handles under every 1 Gbase slice of the two arrays: what a slow slice lies in
+la, lb = runs(pa), runs(pb)
+GiB = 1 << 30
+for i in range(S):
+    lo, hi = 8 * i * L1 // GiB, min(len(la) - 1, (8 * (i + 1) * L1 - 1) // GiB)
+    print(f"slice {i}: a {la[lo:hi + 1]}  b {lb[lo:hi + 1]}  differ at {sum(x != y for x, y in zip(la[lo:hi + 1], lb[lo:hi + 1]))}/{hi - lo + 1} handles", flush=True)
 ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, 0x9E3779B97F4A7C15 ^ 10, 0, nw, 4, 0, psrc), "synth")
 res = cap.Result()
 ASYNC = cap.MEM_DEVICE | cap.ASYNC

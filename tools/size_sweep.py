@@ -25,7 +25,7 @@ import kmers_jl_amd as km
 from oracle import pyoracle
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--lengths", default="100000,300000,1000000,3000000,10000000,32000000,64000000,100000000,320000000,1000000000,10000000000")
+ap.add_argument("--lengths", default="10000,30000,100000,300000,1000000,3000000,10000000,32000000,64000000,100000000,320000000,1000000000,10000000000")
 ap.add_argument("--max-host", type=int, default=256_000_000)
 ap.add_argument("--max-cpu", type=int, default=30_000_000)
 ap.add_argument("--plain", action="store_true", help="KMERS_PARAM_POOL = 0: every array a plain hipMalloc (A/B)")
@@ -90,15 +90,19 @@ for L in [int(x) for x in args.lengths.split(",")]:
                                                cap.MEM_HOST, C.byref(res))
         assert call() == 0
         hreps = 20 if L <= 10_000_000 else 3
-        t0 = time.perf_counter()
-        for _ in range(hreps):
-            assert call() == 0
-        host_ms = (time.perf_counter() - t0) / hreps * 1e3
-        if L <= args.max_cpu:
-            ok, oh = np.zeros((n, 1), np.uint64), np.zeros(n, np.uint64)
+        host_ms = 1e30
+        for _ in range(3):
             t0 = time.perf_counter()
-            ek, eh, _ = orc.canonical(words, L, 4, 2, K, out=ok, out_h=oh)
-            cpu_ms = (time.perf_counter() - t0) * 1e3
+            for _ in range(hreps):
+                assert call() == 0
+            host_ms = min(host_ms, (time.perf_counter() - t0) / hreps * 1e3)
+        if L <= args.max_cpu:
+            ok, oh = np.ones((n, 1), np.uint64), np.ones(n, np.uint64)   # (touched: the timing must not hold the page faults of fresh arrays)
+            cpu_ms = 1e30
+            for _ in range(5 if L <= 3_000_000 else 2):
+                t0 = time.perf_counter()
+                ek, eh, _ = orc.canonical(words, L, 4, 2, K, out=ok, out_h=oh)
+                cpu_ms = min(cpu_ms, (time.perf_counter() - t0) * 1e3)
             assert np.array_equal(ek[:, 0], hk) and np.array_equal(eh, hh), "the host call and the oracle disagree"
     frac = 16.5 * n / (kern_us * 1e-6) / 8e12
     cell = lambda v, f: f.format(v) if v is not None else ""

@@ -8,7 +8,7 @@ import time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 sys.path.insert(0, os.path.join(R, "tests"))
-import torch  # noqa: F401  (before the library: tests/test_gpu_arena.py says why)
+import torch  # noqa: F401  (before the library: tests/test_gpu_pool.py says why)
 import kmers_jl_amd as km
 from oracle import pyoracle
 import test_gpu_fuzz as tf

@@ -52,5 +52,5 @@ if [ -f "$CS/libkmers_hip_stamps.so" ]; then
   KMERS_STAMPS_LIB="$CS/libkmers_hip_stamps.so" KMERS_STAMPS_TILES=49152 KMERS_STAMPS_CASES=2 python3 tools/unamb_stamps.py > "$E/stamps.txt" 2>&1
   cat "$E/stamps.txt"
 fi
-for leg in u21 u31; do python3 tools/leg.py --leg $leg --alloc arena:0 --reps 15; done > "$E/legs.txt" 2>&1
+for leg in u21 u31; do python3 tools/leg.py --leg $leg --alloc pool --reps 15; done > "$E/legs.txt" 2>&1
 cat "$E/legs.txt"

@@ -15,8 +15,7 @@ L = int(os.environ.get("UNAMB_BASES", "1000000000"))
 nw = (L * 4 + 63) // 64
 src = torch.zeros(nw + 2, dtype=torch.int64, device=dev)
 ctx.check(ctx.lib.kmers_synth_dna(ctx.handle, 0x9E3779B97F4A7C15 ^ 5, 0, nw, 4, 2621, src.data_ptr()), "synth")
-if os.environ.get("UNAMB_ARENA", "1") != "0":
-    ctx.check(ctx.lib.kmers_arena_reserve(ctx.handle, 0), "kmers_arena_reserve")
+if os.environ.get("UNAMB_POOL", os.environ.get("UNAMB_ARENA", "1")) != "0":   # outputs from the class pool
     pa, pb = ctx.alloc(8 * L), ctx.alloc(8 * L)
 else:
     ta, tb = torch.empty(L, dtype=torch.int64, device=dev), torch.empty(L, dtype=torch.int64, device=dev)

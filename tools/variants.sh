@@ -9,7 +9,7 @@ for v in "$@"; do
   lib="$ROOT/kmers.jl_amd/csrc/libkmers_hip_$v.so"; [ "$v" = product ] && lib="$ROOT/kmers.jl_amd/csrc/libkmers_hip.so"
   for leg in $LEGS; do
     for rep in 1 2; do
-      KMERS_HIP_LIB="$lib" timeout 300 python3 tools/leg.py --leg $leg --alloc arena:${ARENA_GB:-0} --reps 15 2>&1 | grep -v "amdgpu.ids" | tail -2 | tr '\n' ' ' | sed "s/^/$v: /"; echo
+      KMERS_HIP_LIB="$lib" timeout 300 python3 tools/leg.py --leg $leg --alloc pool --reps 15 2>&1 | grep -v "amdgpu.ids" | tail -2 | tr '\n' ' ' | sed "s/^/$v: /"; echo
     done
   done
 done | tee "$E/legs_ab.txt"

@@ -15,14 +15,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--bases", type=int, default=100_000_000)
 ap.add_argument("--ks", default="128,129,150,256,1000")
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--arena", action="store_true", help="outputs from the context's arena; the single-output launch also into a block taken by role")
+ap.add_argument("--arena", "--pool", dest="arena", action="store_true", help="outputs from kmers_dev_alloc (the class pool); the single-output launch also into a block taken by role")
 ap.add_argument("--force-tiles", type=int, default=0, help="KMERS_PARAM_WIDE_NO_TILES value (2: the tile form for kmers of one to four words too)")
 args = ap.parse_args()
 cap = km._capi
 ctx = km.Context(0)
 ctx.set_param(11, args.force_tiles)
-if args.arena:
-    ctx.arena_reserve(int(120e9))
 dev = torch.device("cuda", 0)
 stream = torch.cuda.ExternalStream(ctx.lib.kmers_ctx_stream(ctx.handle), device=dev)
 L = args.bases
