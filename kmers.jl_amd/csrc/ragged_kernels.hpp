@@ -640,13 +640,15 @@ __device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const Rag
 }
 
 // VEC: out_a / out_b are 16-byte aligned (one-word kmers: RG_RUN elements per lane and pass, 16-byte stores)
+// (amdgpu_waves_per_eu(8): the one-word kernel needs 106 scalar registers as the compiler likes it, which is SEVEN wavefronts per SIMD on
+// gfx9's 800-entry scalar file; asked for eight it keeps a few in vector lanes instead.  With the LDS at 19.8 KiB that is eight tiles
+// per CU in flight, not seven.)
 template <int DST, int N, int MODE, bool VEC>
-__global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void ragged_kernel(const RaggedArgs a) {
     __shared__ uint64_t off_l[RG_SLOTS + 1];    // element offset of every record slot of the tile
     __shared__ uint64_t delta_l[RG_SLOTS + 1];  // first stream symbol of the slot's record minus offset * stride: window of element g = delta + g * stride
     __shared__ uint64_t src_l[RG_STAGE + 2];
     __shared__ uint64_t flg_l[RG_STAGE / 2 + 4];
-    __shared__ uint64_t aux_l[RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64 * 3 / 2 + 2];  // the dense path's bitmap and its prefix counts
     const uint32_t tid = threadIdx.x;
     const uint32_t k = a.k;
     const uint64_t mask = head_mask((int)k, DST);
@@ -670,9 +672,12 @@ __global__ __launch_bounds__(256) void ragged_kernel(const RaggedArgs a) {
         L.slot = off_l;
         L.src = src_l;
         L.flg = flg_l;
-        L.bits = aux_l;
-        L.base = reinterpret_cast<uint32_t *>(aux_l + RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64);
-        static_assert(sizeof(aux_l) >= (RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64) * 12 + 16, "LDS carve");
+        // the dense path's bitmap and its prefix counts live in delta_l, which only the general path uses: 19.8 KiB of LDS per
+        // workgroup = EIGHT workgroups per CU instead of seven (a tile's lifetime over the tiles in flight is what the launch takes)
+        L.bits = delta_l;
+        L.base = reinterpret_cast<uint32_t *>(delta_l + RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64);
+        static_assert(sizeof(delta_l) >= (RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64) * 12 + 16, "LDS carve");
+        static_assert(sizeof(off_l) + sizeof(delta_l) + sizeof(src_l) + sizeof(flg_l) <= 160 * 1024 / 8, "eight workgroups per CU");
         if constexpr (DST == 2) {
             if (a.src_opt) {  // the optimistic launch (RaggedArgs): dense or nothing
                 bool done = false;
