@@ -403,10 +403,10 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     // stores the current one; the stream is double-buffered in LDS so that one barrier per tile suffices.  Stride-1 kernels keep
     // one tile per visit (their load round is a quarter of a load per lane; short-lived workgroups write fastest).
     constexpr uint32_t NBUF = STRIDE1 ? 1u : 2u;
-    // words per lane of one load round (in flight together).  Stride-1 tiles of TEXT hold 1.5 words per lane at the 128 x 1536 shape: both
-    // in one round (round 6: a tile's round trips in front of its stores are what a launch of short-lived workgroups is made of --
-    // kmers_batch from text went from 0.70 to 0.74 on exactly this, profiles/r06_batch.md)
-    constexpr uint32_t PRE = STRIDE1 ? (SRC_BITS == 8 ? 2u : 1u) : (SRC_BITS == 8 ? 8u : 4u);
+    // words per lane of one load round (in flight together).  (Round 6 tried two for stride-1 tiles of TEXT, whose 128 x 1536 shape holds
+    // 1.5 words per lane -- the one-round rule that took kmers_batch from text from 0.70 to 0.74: f1 stayed at 0.801-0.803.  These
+    // tiles are short and sixteen to a CU; their second round hides behind the other tiles' stores.)
+    constexpr uint32_t PRE = STRIDE1 ? 1u : (SRC_BITS == 8 ? 8u : 4u);
     __shared__ uint64_t lds_all[NBUF][LDS_QWORDS];
     struct Geom {
         uint64_t m0, w0;
