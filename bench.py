@@ -450,7 +450,8 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
                                                b.data_ptr(), 0, None, total, cap.MEM_DEVICE | cap.SPANS_DEVICE, C.byref(res)))
         out[f"kmers_batch: {n_reads} reads x {rl} bases, CanonicalDNAMers{{31}} + fx_hash per read"] = {
             "ms": round(ms, 4), "G_elements_per_s": round(total / ms / 1e6, 1), "Gbases_per_s": round(n_reads * rl / ms / 1e6, 1),
-            "GB_per_s": round((16.0 * total + 0.5 * n_reads * rl) / ms / 1e6, 1)}
+            "GB_per_s": round((16.0 * total + 0.5 * n_reads * rl) / ms / 1e6, 1),
+            "frac_of_8TBps": round((16.0 * total + 0.5 * n_reads * rl) / ms / 1e6 / HBM_PEAK_GBPS, 4)}
         del spans
         # SURVEY.md 8(f) rows, the same 1 Gbase: f1 the headline launch from TEXT (1 B/base in: String / Vector{UInt8} sources,
         # FwKmers.jl:117-129), f3 a 4-bit kmer alphabet (Copyable 4 -> 4, two-word kmers), f4 element-wise fx_hash and

@@ -641,7 +641,7 @@ __device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const Rag
 
 // VEC: out_a / out_b are 16-byte aligned (one-word kmers: RG_RUN elements per lane and pass, 16-byte stores)
 // (amdgpu_waves_per_eu(8): the one-word kernel needs 106 scalar registers as the compiler likes it, which is SEVEN wavefronts per SIMD on
-// gfx9's 800-entry scalar file; asked for eight it keeps a few in vector lanes instead.  With the LDS at 19.8 KiB that is eight tiles
+// gfx9's 800-entry scalar file; asked for eight it keeps a few in vector lanes instead.  With the LDS at 19.3 KiB that is eight tiles
 // per CU in flight, not seven.)
 template <int DST, int N, int MODE, bool VEC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void ragged_kernel(const RaggedArgs a) {
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void r
         L.slot = off_l;
         L.src = src_l;
         L.flg = flg_l;
-        // the dense path's bitmap and its prefix counts live in delta_l, which only the general path uses: 19.8 KiB of LDS per
+        // the dense path's bitmap and its prefix counts live in delta_l, which only the general path uses: 19.3 KiB of LDS per
         // workgroup = EIGHT workgroups per CU instead of seven (a tile's lifetime over the tiles in flight is what the launch takes)
         L.bits = delta_l;
         L.base = reinterpret_cast<uint32_t *>(delta_l + RG_MAX_PASSES * RG_UNIT / RG_DENSE_RUN / 64);

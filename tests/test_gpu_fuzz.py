@@ -289,6 +289,105 @@ def test_fuzz_batches(km, ctx, orc, seed):
     ctx.set_param(cap.PARAM_BATCH_PASSES, 0)
 
 
+@pytest.mark.parametrize("seed", BATCH_SEEDS[:25])
+def test_fuzz_batches_of_reads_with_ambiguous_symbols(km, ctx, orc, seed):
+    """Round 6: batches whose records hold symbols the kmer alphabet cannot encode, through BOTH tile paths of the element kernel (the
+    dense one carries flag bits of its own, csrc/ragged_kernels.hpp dense_runs<FLAGGED>): reads in pool order (dense tiles) and spans
+    in any order (the general path), 4-bit pools and text, KMERS_BATCH_SKIP (all-ones for the elements whose windows hold such a
+    symbol, the others as the strict call gives them) and strict (the first failing record in batch order and the position of its first
+    offending symbol: the reference throws there, src/iterators/FwKmers.jl:112), host outputs and device outputs with the count
+    deferred, forced tile lengths."""
+    cap = km._capi
+    rng = np.random.default_rng(8000 + seed)
+    ones = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for case in range(16):
+        src = int(rng.choice([4, 8]))
+        K = int(rng.choice([1, 2, 3, 15, 16, 21, 31, 32]))
+        mode = int(rng.integers(0, 2))
+        ordered = bool(rng.integers(0, 2))
+        n_rec = int(rng.choice([1, 40, 700, 2500]))
+        p_read = float(rng.choice([0.0, 0.02, 0.3, 1.0]))
+        ctx.set_param(cap.PARAM_BATCH_PASSES, int(rng.choice([0, 0, 1, 3, 8])))
+        ctx.set_param(cap.PARAM_BATCH_DENSE, int(rng.choice([0, 0, 0, -1])))
+        texts = []
+        for l in rng.choice([0, K - 1, K, K + 1, K + 2, 60, 125, 251], n_rec):
+            t = list(naive.random_text(rng, int(max(l, 0))))
+            if t and rng.random() < p_read:
+                for pos in rng.integers(0, len(t), int(rng.integers(1, 4))):
+                    t[pos] = str(rng.choice(list("NRYKMW")))
+            t = "".join(t)
+            texts.append("".join(c.lower() if rng.random() < 0.2 else c for c in t) if src == 8 else t)
+        lead = int(rng.choice([0, 1, 17, 64]))
+        pieces, spans, pos = [naive.random_text(rng, lead)], [], lead
+        for t in texts:
+            gap = naive.random_text(rng, int(rng.integers(0, 9))) if rng.random() < 0.3 else ""
+            pieces.append(gap + t)
+            spans.append((pos - lead + len(gap), len(t)))
+            pos += len(gap) + len(t)
+        whole = "".join(pieces)
+        order = np.arange(n_rec) if ordered else rng.permutation(n_rec)
+        spans = [spans[i] for i in order]
+        texts = [texts[i] for i in order]
+        words = naive.ascii_words(whole) if src == 8 else naive.longseq_words(whole if whole else "A", src)
+        arr = (cap.Span * max(n_rec, 1))(*[cap.Span(a, b) for a, b in spans])
+        seq = cap.Seq(words.ctypes.data, len(whole) - lead, lead, 0, src, 0)
+        exp_a, exp_b, offs, first_bad = [], [], [0], None
+        for i, t in enumerate(texts):
+            n = max(0, len(t) - K + 1)
+            up = t.upper()
+            bad_at = [j for j, c in enumerate(up) if c not in "ACGT"]
+            if n:
+                clean = "".join(c if c in "ACGT" else "A" for c in up)
+                w = naive.ascii_words(clean) if src == 8 else naive.longseq_words(clean, src)
+                x, y, r = (orc.fwrv if mode == 0 else (lambda *a: orc.canonical(*a, seed=case)))(w, len(t), src, 2, K)
+                assert r.status == 0
+                holds = np.zeros(n, bool)
+                for j in bad_at:
+                    holds[max(0, j - K + 1):min(n, j + 1)] = True
+                x, y = x.copy(), y.copy()
+                x[holds] = ones
+                y[holds] = ones
+                exp_a.append(x)
+                exp_b.append(y)
+                if holds.any() and first_bad is None:
+                    first_bad = (i, bad_at[0] + 1 if bad_at[0] < n + K - 1 else None)
+            offs.append(offs[-1] + n)
+        total = offs[-1]
+        ea = np.concatenate(exp_a) if exp_a else np.zeros((0, 1), np.uint64)
+        eb = np.concatenate(exp_b) if exp_b else np.zeros((0, 1) if mode == 0 else (0,), np.uint64)
+        tag = (seed, case, src, K, mode, ordered, n_rec, p_read)
+        res = cap.Result()
+        out_a = np.zeros((max(total, 1), 1), np.uint64)
+        out_b = np.zeros((max(total, 1), 1) if mode == 0 else max(total, 1), np.uint64)
+        got_off = np.zeros(n_rec + 1, np.uint64)
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), arr, n_rec, mode, K, 2, vp(out_a), vp(out_b), case, vp(got_off), total, cap.BATCH_SKIP,
+                                 C.byref(res))
+        assert rc == 0 and res.n_out == total and [int(x) for x in got_off] == offs, tag + (ctx.last_error(),)
+        assert np.array_equal(out_a[:total], ea) and np.array_equal(out_b[:total], eb), tag
+        rc = ctx.lib.kmers_batch(ctx.handle, C.byref(seq), arr, n_rec, mode, K, 2, vp(out_a), vp(out_b), case, None, total, 0, C.byref(res))
+        if first_bad is None:
+            assert rc == 0, tag
+            assert np.array_equal(out_a[:total], ea) and np.array_equal(out_b[:total], eb), tag
+        else:
+            assert rc == cap.E_ENCODE and (int(res.n_out), int(res.err_pos)) == first_bad, tag + (int(res.n_out), int(res.err_pos), first_bad)
+        if total and case % 4 == 0:     # device outputs: the layout sized for the capacity, the count read on the device
+            d_w, d_a, d_b = ctx.alloc(words.nbytes + 16), ctx.alloc(total * 8 + 16), ctx.alloc(total * 8 + 16)
+            ctx.h2d(d_w, words)
+            dseq = cap.Seq(d_w, len(whole) - lead, lead, 0, src, 0)
+            rc = ctx.lib.kmers_batch(ctx.handle, C.byref(dseq), arr, n_rec, mode, K, 2, d_a, d_b, case, None, total + 77, cap.BATCH_SKIP | cap.MEM_DEVICE,
+                                     C.byref(res))
+            assert rc == 0 and res.n_out == total, tag + (ctx.last_error(),)
+            a = np.zeros((total, 1), np.uint64)
+            b = np.zeros(eb.shape, np.uint64)
+            ctx.d2h(a, d_a)
+            ctx.d2h(b, d_b)
+            assert np.array_equal(a, ea) and np.array_equal(b, eb), tag + ("device outputs",)
+            for q in (d_w, d_a, d_b):
+                ctx.free(q)
+    ctx.set_param(cap.PARAM_BATCH_PASSES, 0)
+    ctx.set_param(cap.PARAM_BATCH_DENSE, 0)
+
+
 @pytest.mark.parametrize("seed", GEOMETRY_SEEDS)
 def test_unambiguous_geometries(km, ctx, orc, seed):
     """The single-pass UnambiguousKmers kernel (inter-workgroup look-back: rare-event bugs do not show in a handful of runs):

@@ -49,9 +49,16 @@ LEGS = {  # leg -> (label, kernel substring, algorithmic bytes per launch given 
     "batch_ascii": ("kmers_batch: the same reads from ASCII text (element kernel only)", "ragged_kernel", lambda kept: 16.0 * 8_000_000 * 95 + 1.0 * 1e9),
     "batch_n10": ("kmers_batch: an N in 10 % of the reads, KMERS_BATCH_SKIP, 4-bit pool (element kernel only)", "ragged_kernel", lambda kept: 16.0 * 8_000_000 * 95 + 0.5 * 1e9),
     "batch_ascii_n10": ("kmers_batch: an N in 10 % of the reads, KMERS_BATCH_SKIP, from text (element kernel only)", "ragged_kernel", lambda kept: 16.0 * 8_000_000 * 95 + 1.0 * 1e9),
-    "batch_ragged": ("kmers_batch: 6.67 M reads of 50-250 bases, 4-bit pool (element kernel only)", "ragged_kernel", lambda kept: 0.0),
-    "batch_ascii_ragged": ("kmers_batch: 6.67 M reads of 50-250 bases from text (element kernel only)", "ragged_kernel", lambda kept: 0.0),
+    "batch_ragged": ("kmers_batch: 6.67 M reads of 50-250 bases, 4-bit pool (element kernel only)", "ragged_kernel", lambda kept: ragged_bytes(0.5)),
+    "batch_ascii_ragged": ("kmers_batch: 6.67 M reads of 50-250 bases from text (element kernel only)", "ragged_kernel", lambda kept: ragged_bytes(1.0)),
 }
+
+
+def ragged_bytes(per_base):
+    """algorithmic bytes of tools/batch_once.py --ragged --reads 6670000 (its lengths: numpy's default_rng(1), uniform 50..250)"""
+    import numpy as np
+    lengths = np.random.default_rng(1).integers(50, 251, 6_670_000)
+    return 16.0 * float((lengths - 30).sum()) + per_base * float(lengths.sum())
 
 
 def copy(src, dst):
