@@ -111,7 +111,7 @@ int kmers_sync(kmers_ctx *ctx, kmers_result *res);
 #define KMERS_PARAM_MAX_GRID 2   /* cap on workgroups per launch (persistent grid-stride above it) */
 #define KMERS_PARAM_STAMPS_PTR 3 /* diagnostic builds (-DKMERS_STAMPS) only: device buffer for in-kernel stamps */
 #define KMERS_PARAM_SKETCH_HOST_ONLY 4 /* kmers_minhash: 1 = use the host-feedback path even for small sketches (tests) */
-#define KMERS_PARAM_BATCH_PASSES 5     /* kmers_batch: elements per workgroup tile = 1024 * value (1..8); 0 = chosen from the batch size */
+#define KMERS_PARAM_BATCH_PASSES 5     /* kmers_batch: elements per workgroup tile = 1024 * value (1..16); 0 = chosen from the batch size */
 #define KMERS_PARAM_SKETCH_BATCH_LDS 6 /* kmers_minhash_batch: candidate values per workgroup (2048 / 4096 / 8192); 0 = chosen per call */
 #define KMERS_PARAM_SPLIT_ORDER 9      /* the tile kernels visit the two halves of their tile range alternately (two write windows per output
                                          * array).  0: when the launch has ONE output array whose halves lie in two region classes (a block

@@ -35,7 +35,12 @@ namespace kmers {
 constexpr int RG_RUN = KMERS_RG_RUN;     // consecutive elements per lane and pass (one-word kmers: 32 contiguous bytes per lane and array; 64 write at 60 % of that rate, profiles/r01_tuning.md)
 constexpr int RG_UNIT = 1024;            // tile lengths are given in units of this many elements (KMERS_PARAM_BATCH_PASSES)
 constexpr int RG_PASS = 256 * RG_RUN;    // elements per workgroup and pass of the run path; a tile is a multiple of it, 1..RG_MAX_PASSES units
-constexpr int RG_MAX_PASSES = 8;         // (16 measured in round 5: the same time; the dense path's prefix scan takes up to 128 bitmap words)
+#ifndef KMERS_RG_MAX_PASSES
+#define KMERS_RG_MAX_PASSES 16
+#endif
+constexpr int RG_MAX_PASSES = KMERS_RG_MAX_PASSES;  // (the dense path's prefix scan takes up to 128 bitmap words: 16 passes.  Round 5 measured 8 and 16 the same;
+                                         // with a tile's loads in one round and eight tiles per CU, round 6: 8 -> 12 -> 16 = 0.762 -> 0.773 -> 0.775 from a
+                                         // 4-bit pool, 0.733 -> 0.759 -> 0.765 from text, profiles/r06_batch.md)
 #ifndef KMERS_RG_DENSE_RUN
 #define KMERS_RG_DENSE_RUN 2
 #endif
@@ -516,7 +521,7 @@ __device__ __forceinline__ bool ragged_dense_tile(const RaggedArgs &a, const Rag
     if constexpr (FROM == 4 || FROM == 8) {
         constexpr uint32_t PER = FROM == 4 ? 2u : 4u;     // source words per stream word
         constexpr uint64_t FILL = FROM == 4 ? 0x1111111111111111ull : 0x4141414141414141ull;  // "A": in no window, never flagged
-        constexpr uint32_t STEPS = FROM == 4 ? 2u : 4u;   // 512 / 1024 pairs of words: stretches of 512 stream words (16 k symbols)
+        constexpr uint32_t STEPS = FROM == 4 ? 3u : 6u;   // 768 / 1536 pairs of words: stretches of 768 stream words (24 k symbols: 16 k elements of 125-base reads)
         const uint64_t w0 = (uint64_t)PER * d.q_lo;       // (a stretch may end past the pool's last word: FILL there)
         const uint64_t want = (uint64_t)PER * d.n_words;
         const uint32_t avail = w0 < a.n_src_words ? (uint32_t)(a.n_src_words - w0 < want ? a.n_src_words - w0 : want) : 0u;

@@ -349,7 +349,7 @@ def test_batch_tiles_crowded_with_empty_records(km, ctx, orc):
             assert cnt[i] == len(e) and np.array_equal(sk[i, :len(e)], e), (src, i, n_i)
 
 
-@pytest.mark.parametrize("passes", [1, 3, 8])
+@pytest.mark.parametrize("passes", [1, 3, 8, 16])
 def test_batch_tile_sizes_and_record_orders(km, ctx, orc, passes):
     """The tile (1024 elements x 1..8 passes, normally chosen from the batch size) forced to each extreme, over the
     layouts that take different paths of the element kernel: reads in pool order (windows cut from the staged
@@ -545,7 +545,7 @@ def test_batch_dense_tiles_equal_the_general_path_and_the_oracle(km, ctx, orc, s
             got = {}
             for dense in (0, -1):
                 ctx.set_param(cap.PARAM_BATCH_DENSE, dense)
-                ctx.set_param(cap.PARAM_BATCH_PASSES, int(rng.choice([0, 1, 3, 8])))
+                ctx.set_param(cap.PARAM_BATCH_PASSES, int(rng.choice([0, 1, 3, 8, 16])))
                 a = np.full((max(total, 1), 1), 0xAAAAAAAAAAAAAAAA, np.uint64)
                 b = np.full((max(total, 1), 1) if mode == cap.BATCH_FW else max(total, 1), 0xBBBBBBBBBBBBBBBB, np.uint64)
                 off = np.zeros(n_rec + 1, np.uint64)

@@ -219,7 +219,7 @@ def test_fuzz_batches(km, ctx, orc, seed):
         dst = int(rng.choice([2, 4]))
         K = int(rng.choice([1, 3, 15, 16, 17, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256])) if dst == 2 else \
             int(rng.choice([1, 5, 16, 17, 32, 33, 64, 65, 100, 128]))   # beyond 128 / 64: more than four words
-        ctx.set_param(cap.PARAM_BATCH_PASSES, int(rng.choice([0, 0, 1, 3, 8])))   # tile length: per-call choice, or forced
+        ctx.set_param(cap.PARAM_BATCH_PASSES, int(rng.choice([0, 0, 1, 3, 8, 16])))   # tile length: per-call choice, or forced
         n_pool = int(rng.choice([0, 10, 500, 20_000]))
         lead = int(rng.choice([0, 1, 17, 64]))
         text = naive.random_text(rng, lead + n_pool, p_amb=0.0)
@@ -307,7 +307,7 @@ def test_fuzz_batches_of_reads_with_ambiguous_symbols(km, ctx, orc, seed):
         ordered = bool(rng.integers(0, 2))
         n_rec = int(rng.choice([1, 40, 700, 2500]))
         p_read = float(rng.choice([0.0, 0.02, 0.3, 1.0]))
-        ctx.set_param(cap.PARAM_BATCH_PASSES, int(rng.choice([0, 0, 1, 3, 8])))
+        ctx.set_param(cap.PARAM_BATCH_PASSES, int(rng.choice([0, 0, 1, 3, 8, 16])))
         ctx.set_param(cap.PARAM_BATCH_DENSE, int(rng.choice([0, 0, 0, -1])))
         texts = []
         for l in rng.choice([0, K - 1, K, K + 1, K + 2, 60, 125, 251], n_rec):
