@@ -365,6 +365,9 @@ __device__ __forceinline__ void sketch_candidate(const StreamArgs &a, uint64_t h
 // (cut_fw) -- no symbol reversal per kmer.  The strided kernel is bound by its integer work (one SIMD-cycle in four per
 // instruction at 5.9 TB/s), so this is where it counts.
 template <int SRC_BITS, int DST, int N, int MODE, bool STRIDE1, bool TUPLES = false, bool PAIR = false, bool FWD = false>
+// (the strided, forward-only and text instances take 103-106 scalar registers = seven wavefronts per SIMD; compiled for eight
+// -- amdgpu_waves_per_eu(8), what took ragged_kernel from seven tiles per CU to eight -- C5 strict went from 0.79 to 0.767 and f1
+// from 0.807 to 0.813: not applied, round 6)
 __global__ __launch_bounds__(BLOCK) void stream_kernel(const StreamArgs a) {
     static_assert(!FWD || (MODE == MODE_FW && DST == 2 && !TUPLES), "FWD: forward kmers of a 2-bit alphabet, separate arrays");
     __shared__ uint8_t lut[SRC_BITS == 8 ? 256 : 1];
