@@ -66,6 +66,7 @@ struct kmers_device_pool {
         hipEvent_t ev;
     };
     std::map<const char *, std::vector<Pending>> pending;  // cached block -> the work that was queued when it was freed
+    std::vector<uint32_t> dead_ids;  // slots of State::chunks whose handle went back to the driver
     bool need_flush = false;  // something was unmapped since the last TLB flush: nothing may be mapped before the next one
     uint64_t cache_hits = 0, cache_misses = 0, evictions = 0, chunks_created = 0, chunks_returned = 0;
 };
@@ -166,8 +167,14 @@ bool create_chunk(kmers_device_pool *P, uint32_t *id) {
     Chunk c;
     c.handle = h;
     c.home = static_cast<char *>(home);
-    *id = (uint32_t)P->s.chunks.size();
-    P->s.chunks.push_back(c);
+    if (!P->dead_ids.empty()) {  // (the slot of a handle that went back to the driver: a long-lived process walks many)
+        *id = P->dead_ids.back();
+        P->dead_ids.pop_back();
+        P->s.chunks[*id] = c;
+    } else {
+        *id = (uint32_t)P->s.chunks.size();
+        P->s.chunks.push_back(c);
+    }
     P->s.held_bytes += CHUNK_BYTES;
     ++P->chunks_created;
     return true;
@@ -180,8 +187,8 @@ void destroy_chunk(kmers_device_pool *P, uint32_t id) {
     (void)hipMemRelease(static_cast<hipMemGenericAllocationHandle_t>(c.handle));
     (void)hipMemAddressFree(c.home, CHUNK_BYTES);
     (void)hipGetLastError();
-    c.handle = nullptr;
-    c.home = nullptr;
+    c = Chunk();
+    P->dead_ids.push_back(id);
     P->s.held_bytes -= CHUNK_BYTES;
     P->need_flush = true;
     ++P->chunks_returned;
@@ -216,6 +223,7 @@ bool calibrate(kmers_device_pool *P, const kmers_ctx *ctx) {
     if (made < 4) {
         for (int i = 0; i < made; ++i) destroy_chunk(P, id[i]);
         s.chunks.clear();
+        P->dead_ids.clear();
         return false;
     }
     float t[4][4] = {}, warm;
@@ -451,6 +459,7 @@ size_t trim(kmers_device_pool *P, bool all) {
             released += CHUNK_BYTES;
         }
         s.chunks.clear();  // a later block starts a new pool (classes are measured again)
+        P->dead_ids.clear();
         s.n_classes = 0;
         s.slow_ms = s.fast_ms = 0.f;
         P->same_ms = 0.f;
