@@ -17,4 +17,5 @@ for seed in range(lo, hi):
     if seed % 3 == 0:
         tf.test_fuzz_fused_consumers(km, ctx, orc, seed)
     tf.test_fuzz_batches(km, ctx, orc, seed)
+    tf.test_fuzz_batches_of_reads_with_ambiguous_symbols(km, ctx, orc, seed)
     print("seed", seed, "ok", flush=True)
