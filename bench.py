@@ -392,6 +392,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
         mem.free(buf, lone)
         a = mem.empty(2 * 1_000_000_000)
         b = mem.empty(2 * 1_000_000_000)
+        log("[bench] other configs: C3 done")
         # C4: FwDNAMers{63} + reverse_complement over 1 Gbase LongDNA{4}
         L, K = 1_000_000_000, 63
         buf = synth(GOLDEN ^ 4, L, 4)
@@ -399,6 +400,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
         ms = timed(lambda: ctx.lib.kmers_fw(ctx.handle, C.byref(seq), K, 2, a.data_ptr(), b.data_ptr(), ASYNC, C.byref(res)))
         entry("C4 FwDNAMers{63} + reverse_complement, 1 Gbase LongDNA{4}, 32.5 B/kmer", ms, L, 32.5 * (L - K + 1))
         mem.free(buf)
+        log("[bench] C4 done")
         # C5: SpacedDNAMers{21,3} over 1 Gbase LongDNA{4}: strict, and the skip variant with N at p = 0.04
         K, J = 21, 3
         n = (L - K) // J + 1
@@ -425,6 +427,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
         alg = 0.5 * L + 16.0 * m
         entry(f"UnambiguousDNAMers{{31}}, 1 Gbase LongDNA{{4}}, p(N)=0.04, {m} kept, 0.5 B/base + 16 B/kept", ms, L, alg, **ceilings("u31", ms, alg))
         mem.free(amb)
+        log("[bench] C5 / UnambiguousKmers done")
         # fused consumers over the clean 1 Gbase LongDNA{4} (nothing materialised per kmer: their roofline is the integer
         # issue rate, SURVEY.md 8d -- kmers/s and the VALU issue share, not HBM bytes)
         def fused(name, leg, ms, n_kmers):
@@ -440,6 +443,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
         for Kc in (4, 8):
             ms = timed(lambda: ctx.lib.kmers_composition(ctx.handle, C.byref(seq), Kc, b.data_ptr(), cap.MEM_DEVICE, C.byref(res)))
             fused(f"fused composition counts of FwDNAMers{{{Kc}}} (docs/src/composition.md:28-39)", f"comp{Kc}", ms, L - Kc + 1)
+        log("[bench] fused consumers done")
         # ragged batch: 8 M reads x 125 bases = the same 1 Gbase pool, CanonicalDNAMers{31} + fx_hash per read
         n_reads, rl, Kb = 8_000_000, 125, 31
         spans = torch.stack([torch.arange(n_reads, dtype=torch.int64, device=dev) * rl,
@@ -453,6 +457,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
             "GB_per_s": round((16.0 * total + 0.5 * n_reads * rl) / ms / 1e6, 1),
             "frac_of_8TBps": round((16.0 * total + 0.5 * n_reads * rl) / ms / 1e6 / HBM_PEAK_GBPS, 4)}
         del spans
+        log("[bench] kmers_batch (clean 4-bit pool) done")
         # SURVEY.md 8(f) rows, the same 1 Gbase: f1 the headline launch from TEXT (1 B/base in: String / Vector{UInt8} sources,
         # FwKmers.jl:117-129), f3 a 4-bit kmer alphabet (Copyable 4 -> 4, two-word kmers), f4 element-wise fx_hash and
         # reverse_complement over an array of kmers (kmer.jl:255-261, transformations.jl:32-34)
@@ -468,6 +473,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
         torch.cuda.synchronize()
         ms = timed(lambda: ctx.lib.kmers_canonical(ctx.handle, C.byref(tseq), Kf, 2, a.data_ptr(), b.data_ptr(), 0, ASYNC, C.byref(res)))
         entry("f1 CanonicalDNAMers{31} + fx_hash from 1 Gbase of ASCII text (String source), 17 B/kmer", ms, L, 17.0 * (L - Kf + 1))
+        log("[bench] f1 done")
         # kmers_batch on the reads people have (docs/src/minhash.md:31-35, docs/src/faq.md:28-33,
         # src/iterators/UnambiguousKmers.jl:109-132): the same 8 M x 125 from TEXT; with an N in 1 % / 10 % of the reads under
         # KMERS_BATCH_SKIP (4-bit pool and text); lengths uniform 50-250 (about 6.7 M reads of the same pool).  Whole calls.
@@ -475,6 +481,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
             out.update(batch_read_legs(ctx, cap, dev, seq, tseq, buf, text, a, b, timed, L))
         except Exception as e:  # noqa: BLE001
             out["kmers_batch on realistic reads"] = {"error": repr(e)}
+        log("[bench] kmers_batch on realistic reads done")
         del text
         mem.free(text_words)
         del text_words
@@ -491,6 +498,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
         mem.free(a, b, buf)
         del a, b, buf
         torch.cuda.empty_cache()
+        log("[bench] f3 / f4 done")
         try:
             out["e2e host pointers (H2D + kernel + D2H; never `value`)"] = host_pointer_path(ctx, cap, dev)
         except Exception as e:  # noqa: BLE001
@@ -499,6 +507,7 @@ def other_configs(ctx, cap, stream, dev, mem, valu=None, reps=7, write_ceiling_g
             out["e2e host pointers, fused consumers (H2D + kernel; never `value`)"] = host_pointer_consumers(ctx, cap, dev)
         except Exception as e:  # noqa: BLE001
             out["e2e host pointers, fused consumers (H2D + kernel; never `value`)"] = {"error": repr(e)}
+        log("[bench] e2e host-pointer legs done")
         # N1 (north star): CanonicalDNAMers{31} + fx_hash over 10 Gbase LongDNA{4} on ONE GPU: 5 GB in, 160 GB out
         out.update(north_star_one_gpu(ctx, cap, stream, dev, mem, reps))
     return out
@@ -1362,6 +1371,7 @@ def main():
             if leg.out_h is not None:
                 leg.out_h.fill_(0)
             torch.cuda.synchronize()
+    log("[bench] buffers ready, device awake: the timed region")
     elapsed, kern_ms, halo_ms = leg.timed(args.warmup, args.steps)
     per_rank = gather_floats(env, [elapsed, kern_ms, halo_ms, float(sh.n_kmers)])
     elapsed = max(p[0] for p in per_rank)
@@ -1374,6 +1384,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             fresh_report = {"error": repr(e)}
     # ---- integrity of what the timed kernel wrote (outside the timed region) --------------
+    log("[bench] timed region and fresh-outputs leg done")
     verified = leg.verify()
     # ---- the launcher's choice against the alternatives of its table (stream_launch.hpp), same arrays, same run --------
     shape_report = None
@@ -1423,6 +1434,7 @@ def main():
                 fill_gbps = fill_bytes / (float(np.median(fills[1:])) * 1e-3) / 1e9
         except Exception as e:
             log(f"fill measurement failed: {e!r}")
+    log("[bench] verified, launch shapes and fills done")
     leg.release()
 
     # ---- weak runs on N > 1 GPUs: the strong split of the north-star input, in the same run -------------------
@@ -1471,6 +1483,7 @@ def main():
         if strong:  # the child profiles a launch of the rank's shard size, capped at what fits beside this process's buffers
             pmc_args.bases = max(K, min(sh.n_bases, 2_000_000_000))
         child_timeout = 600 if world == 1 else 200
+        log("[bench] line assembled; PMC child passes")
         traffic, source = (None, "not measured (--no-pmc)") if args.no_pmc else measure_traffic(pmc_args, dev_index, child_timeout)
         if traffic is None:
             log(f"roofline.traffic: {source}")
@@ -1489,6 +1502,7 @@ def main():
             except Exception as e:
                 line["other_configs"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
+            log("[bench] other configs done; cpu baseline")
             line["cpu_baseline"] = cpu_baseline(K, bits, seed, args.bases, args.cpu_budget)
         print(json.dumps(line), flush=True)
     if comm is not None:
