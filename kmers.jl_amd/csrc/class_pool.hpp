@@ -36,6 +36,7 @@ constexpr int ROLE_LONE_OUTPUT = 1;  // == KMERS_ALLOC_LONE_OUTPUT: the second h
 struct Chunk {
     void *handle = nullptr;  // hipMemGenericAllocationHandle_t; nullptr: released
     char *home = nullptr;    // the chunk's own mapping, made once and kept: what the probes write through
+    uint32_t va_lead = 0;    // bytes of the home RESERVATION in front of the mapping (pool_api.hip, reserve(): no mapping begins on a GiB boundary)
     uint8_t cls = CLASS_UNKNOWN;
     bool in_use = false;
     bool rep = false;  // the yardstick of its class: never handed out (a representative in use could not be probed against)
@@ -44,6 +45,7 @@ struct Block {
     size_t bytes = 0;      // of the reservation: chunks.size() * CHUNK_BYTES
     size_t req_bytes = 0;  // what was asked for: the array a launch writes
     size_t user_off = 0;   // where the caller's pointer lies inside the reservation (a lone output is shifted so that its MIDDLE is a chunk boundary)
+    uint32_t va_lead = 0;  // bytes of the reservation in front of the block's base (pool_api.hip, reserve())
     std::vector<uint32_t> chunks;
     std::vector<uint8_t> classes;  // of the chunks, in order
     uint64_t serial = 0;
