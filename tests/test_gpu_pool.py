@@ -6,6 +6,7 @@ when it was freed, the hoard is bounded, exhaustion is an error that leaves the 
 process may hammer it (reference: Base.collect makes a fresh Vector per call over src/iterators/CanonicalKmers.jl:199-225;
 src/kmer.jl:255-261)."""
 import ctypes as C
+import gc
 import os
 import subprocess
 import sys
@@ -30,6 +31,7 @@ FX = np.uint64(0x517cc1b727220a95)
 
 @pytest.fixture()
 def ctx():
+    gc.collect()   # (device arrays that earlier test modules left to the collector are blocks that are OUT: a new block would be placed beside them)
     c = km.Context(0)
     yield c
     c.close()
