@@ -10,8 +10,10 @@
 // interleaved in physical memory: it grows by one handle at a time as blocks are asked for and holds what it was asked for plus
 // what it had to walk past to find the classes it wanted (until kmers_pool_trim).
 //
-// Three properties of the VMM calls on this stack (ROCm 7.2, measured by tools/device_probes/vmm_life.hip) shape the code:
+// Four properties of the VMM calls on this stack (ROCm 7.2, measured by tools/device_probes/vmm_life.hip and vmm_churn.hip) shape
+// the code:
 //   * hipMemMap takes whole handles (no offset).
+//   * A 1 GiB handle mapped ON a GiB boundary faults now and then while handles come and go: no mapping begins on one (reserve()).
 //   * A range that is unmapped and mapped again -- in place, or after hipMemAddressFree and a new reservation that returns the
 //     same address -- keeps its OLD translations in the device's TLB until something flushes it; a hipMalloc + hipFree does
 //     (the legacy unmap goes through KFD, which invalidates).  Every unmap here is followed by that flush, and every new block is

@@ -175,6 +175,17 @@ def test_alloc_free_loop_reuses_memory_and_never_shows_stale_data(ctx):
     ctx.free(p)
     st = ctx.pool_stats()
     assert st["cached"] == 0 and st["cached_blocks"] == 0 and hoard_ok(st)[0], st
+    # ... and every allocation is a NEW mapping: none of them begins on a GiB boundary (a 1 GiB handle mapped on one is a single 1 GiB
+    # page, and under the pool's churn of handles the device now and then faults at its first access: csrc/pool_api.hip, reserve();
+    # tools/device_probes/vmm_churn.hip; the runtime hands out such an address about once in thirty reservations)
+    for it in range(40):
+        size = (GiB // 2, GiB, 2 * GiB, 3 * GiB)[it % 4]
+        p = ctx.alloc(size)
+        assert ctx.pool_layout(p)[1] and p % GiB != 0, hex(p)
+        t = rng.integers(0, 1 << 63, 1, dtype=np.uint64)
+        h2d(ctx, p + size - 8, t)
+        assert d2h(ctx, p + size - 8, 1)[0] == t[0]
+        ctx.free(p)
     ctx.set_param(cap.PARAM_POOL_CACHE, 1)
 
 
