@@ -140,7 +140,7 @@ struct Settle {
 // tables that covered the range before, and under the churn of this pool (handles created and returned by the hundred while it
 // searches for a class) the first access through such a mapping now and then dies with "Memory access fault by GPU ... Reason:
 // Unknown" -- one bench.py run in about twenty in round 6, reproduced in plain HIP by tools/device_probes/vmm_churn.hip: with
-// every mapping forced onto a GiB boundary 3 runs of 3 die within 30 s, with none on one 8 runs of 8 / 11 500 handles survive,
+// every mapping forced onto a GiB boundary 3 runs of 3 die within 30 s, with none on one 20 runs of 20 / 30 600 handles survive,
 // left to the runtime's choice (about one address in thirty is a multiple of 1 GiB) 3 of 11 die (profiles/r06_pool.md section 6).  So every
 // reservation is 2 MiB longer than what is mapped under it, and the mapping begins 2 MiB in if the reservation begins on a GiB
 // boundary; the handles of a block lie 1 GiB apart, so none of them begins on one either.
