@@ -13,6 +13,8 @@ cap = km._capi
 ctx = km.Context(0)
 dev = torch.device("cuda", 0)
 K, s = 16, 1000
+if "--s" in sys.argv:        # sketch size (1000: docs/src/minhash.md:34)
+    s = int(sys.argv[sys.argv.index("--s") + 1])
 res = cap.Result()
 if "--lds" in sys.argv:      # force the candidate buffer (2048 / 4096 / 8192 values per workgroup)
     ctx.set_param(cap.PARAM_SKETCH_BATCH_LDS, int(sys.argv[sys.argv.index("--lds") + 1]))
