@@ -297,5 +297,31 @@ def test_julia_binding_gates_base_collect():
     assert 'const MIN_BASES = Ref{Int}(parse(Int, get(ENV, "KMERS_HIP_MIN_BASES", "100000")))' in text
 
 
+def test_the_maintainers_parity_script_uses_names_the_binding_defines():
+    """julia/runtests.jl (KmersHIP against Kmers.jl's own iteration, for a host that has Julia and an MI355X) cannot run here; what can
+    be checked: every `KmersHIP.<name>` it uses is defined in julia/KmersHIP.jl with the keywords it is called with, every iterator
+    type of GpuIterator is exercised through all three device routes, and its brackets balance."""
+    text = open(JULIA).read()
+    script = open(os.path.join(ROOT, "julia", "runtests.jl")).read()
+    used = set(re.findall(r"KmersHIP\.([A-Za-z_][A-Za-z_0-9!]*)", script)) - {"jl"}     # (the file name in comments and the include)
+    assert {"gpu_collect", "gpu", "collect_with_hashes", "sketch", "composition", "minimizers", "collect_batch", "sketch_batch",
+            "MIN_BASES", "gpu_dispatch"} <= used, used
+    for name in used:
+        defined = re.search(rf"(?m)^(function |const |struct |mutable struct )?{re.escape(name)}\b[({{ =]", text)
+        assert defined, f"julia/runtests.jl uses KmersHIP.{name}, which julia/KmersHIP.jl does not define"
+    # keywords as called
+    for call, kw in (("gpu", "chunk"), ("collect_with_hashes", "seed"), ("collect_batch", "hashes"), ("minimizers", "mode")):
+        assert re.search(rf"KmersHIP\.{call}\([^\n]*;\s*{kw}\s*=", script), (call, kw)
+        sig = re.search(rf"(?ms)^(?:function )?{call}\((.*?)\)(?: where|\s*=)", text)
+        assert sig and re.search(rf"(?s);.*\b{kw}\b", sig.group(1)), (call, kw, sig and sig.group(1))
+    for it in ("FwDNAMers", "FwRvIterator", "CanonicalDNAMers", "SpacedDNAMers", "UnambiguousDNAMers"):
+        assert re.search(rf"same\({it}\{{", script), it       # same() = gpu_collect, Base.collect above the gate, iterate() in chunks
+    assert "KmersHIP.gpu_collect(it), collect(it), collect(KmersHIP.gpu(it; chunk = chunk))" in script
+    for a, b in ("()", "[]", "{}"):
+        assert script.count(a) == script.count(b), (a, script.count(a), script.count(b))
+    assert len(re.findall(r"(?m)^@testset |^    @testset |^@testset\b", script)) >= 9
+    # (begin / for / function / try / if ... end balance is Julia's to check; the reference's style of one testset per iterator is kept)
+
+
 if __name__ == "__main__":
     raise SystemExit(pytest.main([__file__, "-q"]))
