@@ -276,21 +276,26 @@ function Kmers.fx_hash(v::Vector{Kmer{A, K, N}}, h::UInt = zero(UInt)) where {A,
     return out
 end
 
-for (op, fn) in ((0, :reverse), (1, :complement), (2, :reverse_complement), (3, :canonical))
-    mod = fn === :reverse ? :Base : :BioSequences
-    @eval function $mod.$fn(v::Vector{Kmer{A, K, N}}) where {A <: NucleicAcidAlphabet, K, N}
-        ctx = context()
-        out = similar(v)
-        bits = BioSequences.bits_per_symbol(A())
-        GC.@preserve v out begin
-            rc = @ccall LIB.kmers_transform(ctx.handle::Ptr{Cvoid}, $op::Cint, pointer(v)::Ptr{UInt64}, K::Cint,
-                                            bits::Cint, length(v)::UInt64, pointer(out)::Ptr{UInt64},
-                                            MEM_HOST::Cint)::Cint
-        end
-        rc == OK || error("kmers_transform: status $rc: $(last_error(ctx))")
-        return out
+# One launch for `f.(v)`, f in reverse / complement / reverse_complement / canonical (src/transformations.jl:1-41).  The three
+# BioSequences functions get a method for vectors of kmers (they have none: nothing changes meaning); `reverse` of a Vector
+# already MEANS the vector back to front, so the element-wise form is `KmersHIP.reverse_each(v)` == `reverse.(v)`.
+function transform_each(op::Integer, v::Vector{Kmer{A, K, N}}) where {A <: NucleicAcidAlphabet, K, N}
+    ctx = context()
+    out = similar(v)
+    bits = BioSequences.bits_per_symbol(A())
+    GC.@preserve v out begin
+        rc = @ccall LIB.kmers_transform(ctx.handle::Ptr{Cvoid}, op::Cint, pointer(v)::Ptr{UInt64}, K::Cint,
+                                        bits::Cint, length(v)::UInt64, pointer(out)::Ptr{UInt64},
+                                        MEM_HOST::Cint)::Cint
     end
+    rc == OK || error("kmers_transform: status $rc: $(last_error(ctx))")
+    return out
 end
+"`reverse.(v)` (src/transformations.jl:1-10) in one launch"
+reverse_each(v::Vector{<:Kmer}) = transform_each(0, v)
+BioSequences.complement(v::Vector{Kmer{A, K, N}}) where {A <: NucleicAcidAlphabet, K, N} = transform_each(1, v)
+BioSequences.reverse_complement(v::Vector{Kmer{A, K, N}}) where {A <: NucleicAcidAlphabet, K, N} = transform_each(2, v)
+BioSequences.canonical(v::Vector{Kmer{A, K, N}}) where {A <: NucleicAcidAlphabet, K, N} = transform_each(3, v)
 
 "as_integer.(v) (src/kmer.jl:305-326) for kmers of up to 128 coding bits: Vector{UInt64} or Vector{UInt128}"
 function Kmers.as_integer(v::Vector{Kmer{A, K, N}}) where {A <: NucleicAcidAlphabet, K, N}
