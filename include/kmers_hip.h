@@ -169,9 +169,10 @@ int kmers_last_launch_shape(kmers_ctx *ctx, int *threads, int *tile_kmers, int *
  * not out; so does any allocation of the library that would otherwise fail.  One pool per device and process, shared by its
  * contexts, thread-safe.  Smaller blocks, a device without virtual-memory management, a pool that cannot get its handles (the
  * cap KMERS_PARAM_POOL_MAX_GIB, a device too full), or KMERS_PARAM_POOL = 0: plain hipMalloc (kmers_dev_free of those waits for
- * the context's stream and is a hipFree).  KMERS_E_NOMEM only when that fails too.  The pointer is aligned to 4096 bytes at
- * least (a block of the pool: to 2 MiB unless it was asked for as a lone output; never to a GiB boundary -- on ROCm 7.2 a 1 GiB
- * handle mapped on one faults now and then while handles come and go, profiles/r06_pool.md section 5). */
+ * the context's stream and is a hipFree).  KMERS_E_NOMEM only when that fails too.  Alignment: what hipMalloc gives
+ * (256 bytes at least) for plain blocks; a block of the pool to 4096 bytes at least (to 2 MiB unless it was asked for as a lone
+ * output) and never to a GiB boundary -- on ROCm 7.2 a 1 GiB handle mapped on one faults now and then while handles come and
+ * go, profiles/r06_pool.md section 5. */
 int kmers_dev_alloc(kmers_ctx *ctx, size_t bytes, void **out);
 /* The same with a word about what the block is for:
  *   KMERS_ALLOC_DEFAULT      anything: inputs, the arrays of a launch with two outputs (placed in different region classes)
