@@ -359,8 +359,10 @@ hipEvent_t get_event(kmers_device_pool *P) {
         P->spare_events.pop_back();
         return e;
     }
+    // No system-scope fence: these events order work on the DEVICE (the next user's stream, or the host before it unmaps) and carry no
+    // data to the host; with the fence a record costs the stream 3 us, without it 0.3-1 (tools/device_probes/marker_cost.hip).
     hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
